@@ -1,0 +1,274 @@
+"""Per-read ranking + text output and the profile table, as the reference writes them.
+
+Host-side half of the `identify` path: consumes the CSR of non-zero
+(read, taxon) scores the device returns and the profile tables, produces the same bytes as
+
+* source/modes/Compare.hpp:1452-1481  (best score),
+* source/modes/Compare.hpp:1485-1890  (ranking, top/further hits, JSON / JSONL / TSV / Kraken text),
+* source/modes/Compare.hpp:3466-3665  (profile CSV).
+
+Arithmetic follows the reference's types: k-mer scores and the error are float32, the relative score
+is float64 with libm's log2 (math.log2 is the same libm call).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from .textnum import dtoa, itoa
+
+K64 = 12
+_F32 = np.float32
+
+
+def weight(k: int) -> np.float32:
+    """Compare.hpp:392: w_k = k^2 / 625 in float."""
+    return _F32(k * k) / _F32(625.0)
+
+
+def best_score(length: int, k_high: int, k_low: int, frames: int) -> np.float32:
+    """Compare.hpp:1452-1481.  The subtraction is unsigned 64-bit in the reference."""
+    best = _F32(0.0)
+    for i in range(k_low, k_high + 1):
+        if frames == 1:
+            span = (length // 3 - i + 1) & 0xFFFFFFFFFFFFFFFF
+        elif frames == 6:
+            span = (2 * ((length - 3 * i + 1) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+        else:
+            span = (length - 3 * i + 1) & 0xFFFFFFFFFFFFFFFF
+        best = _F32(best + _F32(_F32(span) * weight(i)))
+    return best
+
+
+def relative_score(score: np.float32, freq: int, length: int, K: int = K64) -> float:
+    """Compare.hpp:1510 (DNA): score / (1 + log2(freq * double(len - 3K + 1))), uint32 subtraction."""
+    span = (int(length) - 3 * K + 1) & 0xFFFFFFFF
+    prod = float(int(freq)) * float(span)
+    if prod <= 0.0:
+        lg = -math.inf if prod == 0.0 else math.nan
+    else:
+        lg = math.log2(prod)
+    den = 1.0 + lg
+    s = float(score)
+    if den == 0.0:
+        return math.inf if s > 0 else math.nan
+    return s / den
+
+
+@dataclass
+class Hit:
+    tax_idx: int
+    score: np.float32
+    rel: float
+
+
+@dataclass
+class Ranked:
+    hits: list        # sorted by relative score, descending
+    n_top: int
+    best: np.float32
+
+
+def rank_read(tax_idx, scores, length: int, freq_khigh, k_high: int, k_low: int, frames: int,
+              threshold: float, beasts: int, K: int = K64) -> Ranked:
+    """Compare.hpp:1495-1594.  `tax_idx` ascending, `scores` > 0 (the cells the reference scans)."""
+    best = best_score(length, k_high, k_low, frames)
+    thr = float(_F32(threshold))
+    hits = []
+    for t, s in zip(tax_idx, scores):
+        s = _F32(s)
+        if not (s > 0):
+            continue
+        rel = relative_score(s, int(freq_khigh[int(t)]), length, K)
+        if rel >= thr:
+            hits.append(Hit(int(t), s, rel))
+    # std::sort on `rel` descending; libstdc++ uses insertion sort up to 16 elements, i.e. stable there
+    hits.sort(key=lambda h: -h.rel)
+    n_top = 0
+    if hits:
+        max_score = max(h.score for h in hits)
+        n_top = 1
+        for i in range(1, min(len(hits), beasts)):
+            if _F32(hits[i].score / max_score) > _F32(0.8):
+                n_top += 1
+            else:
+                break
+    return Ranked(hits, n_top, best)
+
+
+def _error(best: np.float32, score: np.float32) -> float:
+    return float(_F32(_F32(best - score) / best))
+
+
+class ReadWriter:
+    """Text of the per-read file in one of the reference's four formats (Compare.hpp:1526-1872)."""
+
+    def __init__(self, fmt: str, names, taxids, beasts: int = 3):
+        assert fmt in ("json", "jsonl", "tsv", "kraken")
+        self.fmt, self.names, self.taxids, self.beasts = fmt, names, taxids, beasts
+
+    def header(self) -> str:
+        if self.fmt == "tsv":
+            return "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n"
+        if self.fmt == "json":
+            return "[\n"
+        return ""
+
+    def footer(self) -> str:
+        return "\n]" if self.fmt == "json" else ""
+
+    def _obj(self, h: Hit, best, json_pretty: bool) -> str:
+        tid, nm = itoa(self.taxids[h.tax_idx]), self.names[h.tax_idx]
+        if json_pretty:
+            return ("\t\t\"tax ID\": \"" + tid + "\",\n\t\t\"Name\": \"" + nm + "\",\n\t\t\"k-mer Score\": "
+                    + dtoa(float(h.score)) + ",\n\t\t\"Relative Score\": " + dtoa(h.rel)
+                    + ",\n\t\t\"Error\": " + dtoa(_error(best, h.score)) + "\n\t}")
+        return (" \"tax ID\": \"" + tid + "\", \"Name\": \"" + nm + "\", \"k-mer Score\": " + dtoa(float(h.score))
+                + ", \"Relative Score\": " + dtoa(h.rel) + ", \"Error\": " + dtoa(_error(best, h.score)) + "}")
+
+    def _further(self, r: Ranked):
+        """Indices printed after the top hits: the -b counter only advances when the k-mer score
+        changes (Compare.hpp:1721-1754)."""
+        out, j, before = [], r.n_top, _F32(0.0)
+        i = r.n_top
+        while i < len(r.hits) and j < self.beasts:
+            out.append(i)
+            if before != r.hits[i].score:
+                before = r.hits[i].score
+                j += 1
+            i += 1
+        return out
+
+    def read(self, number: int, name: str, length: int, r: Ranked) -> str:
+        f = self.fmt
+        if not r.hits:
+            if f == "tsv":
+                return itoa(number) + "\t" + name + "\t-\t-\t-\t-\n"
+            if f == "json":
+                return (("{\n" if number == 0 else ",\n{\n") + "\t\"Read number\": " + itoa(number)
+                        + ",\n\t\"Specifier from input file\": \"" + name + "\",\n\t\"Length\": " + itoa(length)
+                        + ",\n\t\"Top hits\": [\n\t],\n\t\"Further hits\": [\n\t]\n}")
+            if f == "jsonl":
+                return ("{ \"Read number\": " + itoa(number) + ", \"Specifier from input file\": \"" + name
+                        + "\", \"Length\": " + itoa(length) + ", \"Top hits\": [], \"Further hits\": [] }\n")
+            # Kraken: the length is appended as ONE raw byte (Compare.hpp:1568)
+            return "U\t" + name + "\t0\t" + chr(length & 0xFF) + "\tA:00\n"
+        if f == "tsv":
+            s1 = s2 = s3 = s4 = ""
+            j, before, i = 0, _F32(0.0), 0
+            while i < len(r.hits) and j < self.beasts:
+                h = r.hits[i]
+                s1 += itoa(self.taxids[h.tax_idx]) + ";"
+                s2 += self.names[h.tax_idx] + ";"
+                s3 += dtoa(h.rel) + "," + dtoa(float(h.score)) + ";"
+                s4 += dtoa(_error(r.best, h.score)) + ";"
+                if before != h.score:
+                    before = h.score
+                    j += 1
+                i += 1
+            s1, s2, s3, s4 = (x[:-1] if x.endswith(";") else x for x in (s1, s2, s3, s4))
+            if not s2:
+                return ""
+            return itoa(number) + "\t" + name + "\t" + s1 + "\t" + s2 + "\t" + s3 + "\t" + s4 + "\n"
+        if f == "json":
+            out = (("{\n" if number == 0 else ",\n{\n") + "\t\"Read number\": " + itoa(number)
+                   + ",\n\t\"Specifier from input file\": \"" + name + "\",\n\t\"Length\": " + itoa(length)
+                   + ",\n\t\"Top hits\": [\n")
+            for i in range(r.n_top):
+                out += ("\t{\n" if i == 0 else ",\n\t{\n") + self._obj(r.hits[i], r.best, True)
+            out += "\n\t],\n\t\"Further hits\": [\n"
+            for n, i in enumerate(self._further(r)):
+                out += ("\t{\n" if n == 0 else ",\n\t{\n") + self._obj(r.hits[i], r.best, True)
+            return out + "\n\t]\n}"
+        if f == "jsonl":
+            out = ("{ \"Read number\": " + itoa(number) + ", \"Specifier from input file\": \"" + name
+                   + "\", \"Length\": " + itoa(length) + ", \"Top hits\": [")
+            for i in range(r.n_top):
+                out += ("{" if i == 0 else ",{") + self._obj(r.hits[i], r.best, False)
+            out += "], \"Further hits\": ["
+            for n, i in enumerate(self._further(r)):
+                out += ("{" if n == 0 else ", {") + self._obj(r.hits[i], r.best, False)
+            return out + "] }\n"
+        # Kraken-like
+        out = ("C\t" + name + "\t" + itoa(self.taxids[r.hits[0].tax_idx]) + "\t" + itoa(length) + "\t")
+        for i in list(range(r.n_top)) + self._further(r):
+            h = r.hits[i]
+            out += itoa(self.taxids[h.tax_idx]) + ":" + dtoa(float(h.score)) + " "
+        return out + "\n"
+
+
+def _g6(x) -> str:
+    """operator<< of a double/integer on a default ostream: %g with 6 significant digits."""
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    return "%g" % float(x)
+
+
+def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int, n_kmers_in_input: int,
+                n_reads: int, frames: int) -> str:
+    """Compare.hpp:3466-3665 without --coverage.  Tables are [level, taxon], level 0 = kHigh."""
+    nK = k_high - k_low + 1
+    n_taxa = len(names)
+    sum_u = [int(count_unique[l, 1:].sum()) for l in range(nK)]
+    sum_a = [0.0] * nK
+    for l in range(nK):
+        acc = 0.0
+        for t in range(1, n_taxa):
+            acc += float(count_all[l, t])
+        sum_a[l] = acc
+    rows = [(names[t].replace(",", " "), [(float(count_all[l, t]), int(count_unique[l, t])) for l in range(nK)],
+             int(taxids[t])) for t in range(1, n_taxa)]
+    rows = [("", [(0.0, 0)] * nK, 0)] + rows  # slot 0 of vOut stays empty (Compare.hpp:3468)
+
+    import functools
+
+    def cmp(a, b):
+        for l in range(nK):
+            if a[1][l][1] != b[1][l][1]:
+                return -1 if a[1][l][1] > b[1][l][1] else 1
+        return 0
+    rows.sort(key=functools.cmp_to_key(cmp))
+    fm = 1 if frames == 1 else (6 if frames == 6 else 3)
+    garbage = [0] * nK
+    j = 0
+    for i in range(k_high - k_low, 0, -1):
+        garbage[j] = n_reads * fm * i
+        j += 1
+    head = "#taxID,Name"
+    for title in ("Unique counts k=", "Unique rel. freq. k=", "Non-unique counts k=",
+                  "Non-unique rel. freq. k=", "Overall rel. freq. k=", "Overall unique rel. freq. k="):
+        for l in range(nK):
+            head += "," + title + str(k_high - l)
+    head += "\n"
+    body = ""
+    ident = [0.0] * nK
+    uident = [0.0] * nK
+    for name, vals, tid in rows:
+        if not (vals[nK - 1][0] > 0):
+            continue
+        line = str(tid) + "," + name
+        for l in range(nK):
+            line += "," + str(vals[l][1])
+        for l in range(nK):
+            line += "," + ("0" if vals[l][1] == 0 else _g6(vals[l][1] / sum_u[l]))
+        for l in range(nK):
+            line += "," + _g6(vals[l][0])
+        for l in range(nK):
+            line += "," + ("0" if vals[l][0] == 0 else _g6(vals[l][0] / sum_a[l]))
+        for l in range(nK):
+            ident[l] += vals[l][0]
+            line += "," + _g6(vals[l][0] / float((n_kmers_in_input - garbage[l]) & 0xFFFFFFFFFFFFFFFF))
+        for l in range(nK):
+            uident[l] += vals[l][1]
+            line += "," + _g6(vals[l][1] / float((n_kmers_in_input - garbage[l]) & 0xFFFFFFFFFFFFFFFF))
+        body += line + "\n"
+    first = "0,not identified" + ",0" * (nK * 4)
+    for l in range(nK):
+        d = float(n_kmers_in_input) - float(garbage[l])
+        first += "," + _g6((d - ident[l]) / d)
+    for l in range(nK):
+        d = float(n_kmers_in_input) - float(garbage[l])
+        first += "," + _g6((d - uident[l]) / d)
+    return head + first + "\n" + body

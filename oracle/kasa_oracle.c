@@ -1,0 +1,584 @@
+/*
+ * kasa_oracle.c -- CPU restatement of kASA's `identify` hot path (encode -> sort -> prefix range ->
+ * sorted-index merge -> score).  TEST INFRASTRUCTURE ONLY (see kasa_oracle.h): the checker for the
+ * HIP path and the "port" CPU baseline of bench.py.  Never linked into, or called from, the product.
+ *
+ * Written from the behaviour of the reference (kASA v1.4.9); no reference source is copied.  Each
+ * function names the reference lines it follows.  Pinned against outputs of the reference's shipped
+ * binary by tests/test_oracle_golden.py (fixtures: tests/golden/, generator: make_fixtures.py).
+ *
+ * Build: see oracle/Makefile (plain gcc, -O2 -ffp-contract=off: IEEE float/double, no fused ops).
+ */
+#include "kasa_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * A1. Codon -> letter.  kASA.hpp:69-87 (index arithmetic), kASA.hpp:621-667 (table contents).
+ * Base code b = (c & 14) >> 1: A,C,T,G,X,Z -> 0..5 (case-insensitive).  LUT index = b0*64+b1*8+b2.
+ * Standard genetic code, stops TAA/TAG -> '[' and TGA -> ']', any Z -> '_', else any X -> '^'.
+ * The letter code stored is (char & 31).
+ * ---------------------------------------------------------------------------------------------- */
+void ko_codon_table(uint8_t lut[366])
+{
+    /* standard code in TCAG order (NCBI transl_table 1) */
+    static const char std_tcag[65] =
+        "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    static const int tcag_of_code[4] = { 2 /*A*/, 1 /*C*/, 0 /*T*/, 3 /*G*/ };
+    memset(lut, 0, 366); /* ' ' & 31 == 0 in the gaps */
+    for (int b0 = 0; b0 < 6; ++b0)
+        for (int b1 = 0; b1 < 6; ++b1)
+            for (int b2 = 0; b2 < 6; ++b2) {
+                char aa;
+                if (b0 == 5 || b1 == 5 || b2 == 5) aa = '_';
+                else if (b0 == 4 || b1 == 4 || b2 == 4) aa = '^';
+                else {
+                    int idx = tcag_of_code[b0] * 16 + tcag_of_code[b1] * 4 + tcag_of_code[b2];
+                    aa = std_tcag[idx];
+                    if (aa == '*') aa = (idx == 14) ? ']' : '[';
+                }
+                lut[b0 * 64 + b1 * 8 + b2] = (uint8_t)(aa & 31);
+            }
+}
+
+float ko_weight(int k) /* Compare.hpp:392: k*k / 625.f, both operands float */
+{
+    return (float)(k * k) / 625.f;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A3. Read preparation.  Read.hpp:1068-1078 (marker), 633-654 (padding), 36-57 (count).
+ * ---------------------------------------------------------------------------------------------- */
+static int64_t marker_len(const ko_params *p) { return 3 * (int64_t)(p->K - p->kLow); }
+
+int64_t ko_padded_len(int64_t rawLen, const ko_params *p)
+{
+    const int64_t m = marker_len(p);
+    int64_t len = rawLen;
+    if (len > 0) {
+        if (p->frames == 1) {
+            while ((len + m) / 3 < p->K) ++len;
+        } else {
+            while (len + m < 3 * (int64_t)p->K) ++len;
+        }
+    }
+    return len + m;
+}
+
+int64_t ko_kmer_count(int64_t L, const ko_params *p)
+{
+    if (p->frames == 1) {
+        const int64_t t = L / 3;
+        return (t > p->K + 1) ? t - p->K + 1 : 0;
+    }
+    return (L > 3 * (int64_t)p->K + 1) ? L - 3 * (int64_t)p->K + 1 : 0;
+}
+
+static inline int is_acgt(uint8_t c)
+{
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'a' || c == 'c' || c == 'g' || c == 't';
+}
+
+static inline uint8_t letter_at(const uint8_t *s, int64_t pos, const uint8_t *lut)
+{
+    const int idx = ((s[pos] & 14) << 5) | ((s[pos + 1] & 14) << 2) | ((s[pos + 2] & 14) >> 1);
+    return lut[idx];
+}
+
+/* Read.hpp:84-220: one k-mer per window start i = 0..count-1, window = K codons from i (3 frames
+ * interleaved by the rolling update; emission order is the start position). */
+static void encode_prepared(const uint8_t *s, int64_t L, const ko_params *p, const uint8_t *lut,
+                            uint64_t *out, int64_t count)
+{
+    const int K = p->K;
+    if (p->frames == 1) { /* Read.hpp:223-261: translate frame 0 once, slide over letters */
+        for (int64_t i = 0; i < count; ++i) {
+            uint64_t v = 0;
+            for (int j = 0; j < K; ++j) v = (v << 5) | letter_at(s, 3 * (i + j), lut);
+            out[i] = v;
+        }
+        return;
+    }
+    (void)L;
+    for (int64_t i = 0; i < count; ++i) {
+        uint64_t v = 0;
+        for (int j = 0; j < K; ++j) v = (v << 5) | letter_at(s, i + 3 * j, lut);
+        out[i] = v;
+    }
+}
+
+int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads, const ko_params *p,
+                        const uint8_t lut[366], uint64_t *outKmer, uint32_t *outRead)
+{
+    int64_t total = 0;
+    int64_t cap = 0;
+    uint8_t *buf = NULL, *rc = NULL;
+    const int64_t m = marker_len(p);
+    for (int64_t r = 0; r < nReads; ++r) {
+        const int64_t raw = off[r + 1] - off[r];
+        const int64_t L = ko_padded_len(raw, p);
+        const int64_t cnt = (raw > 0) ? ko_kmer_count(L, p) : 0;
+        const int strands = (p->frames == 6) ? 2 : 1;
+        if (!outKmer) { total += cnt * strands; continue; }
+        if (raw == 0) continue;
+        if (L + 4 > cap) {
+            cap = 2 * (L + 4);
+            buf = (uint8_t *)realloc(buf, (size_t)cap);
+            rc = (uint8_t *)realloc(rc, (size_t)cap);
+        }
+        /* Read.hpp:657-675: everything but ACGTacgt becomes Z; Read.hpp:648-650: pad with X */
+        const uint8_t *src = bases + off[r];
+        for (int64_t i = 0; i < raw; ++i) buf[i] = is_acgt(src[i]) ? src[i] : (uint8_t)'Z';
+        for (int64_t i = raw; i < L; ++i) buf[i] = 'X'; /* padding + marker are both X */
+        if (cnt > 0) {
+            encode_prepared(buf, L, p, lut, outKmer + total, cnt);
+            for (int64_t i = 0; i < cnt; ++i) outRead[total + i] = (uint32_t)r;
+            total += cnt;
+        }
+        if (strands == 2) {
+            /* kASA.hpp:214-221 on the padded read, marker appended afterwards (Read.hpp:612-622) */
+            static const uint8_t comp[8] = { 'T', 'G', 'A', 'C', 'X', 'Z', 'X', 'X' };
+            const int64_t body = L - m;
+            for (int64_t j = 0; j < body; ++j) rc[body - 1 - j] = comp[(buf[j] >> 1) & 7];
+            for (int64_t i = body; i < L; ++i) rc[i] = 'X';
+            if (cnt > 0) {
+                encode_prepared(rc, L, p, lut, outKmer + total, cnt);
+                for (int64_t i = 0; i < cnt; ++i) outRead[total + i] = (uint32_t)r;
+                total += cnt;
+            }
+        }
+    }
+    free(buf);
+    free(rc);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A5. Sort by k-mer (Compare.hpp:1077; unstable there, stable here -- tie order never reaches the
+ * output, DESIGN.md "Oracle") and prefix ranges (Compare.hpp:1098-1117, Trie.hpp:398-462,494-520).
+ * ---------------------------------------------------------------------------------------------- */
+void ko_sort_queries(uint64_t *kmer, uint32_t *read, uint64_t n)
+{
+    if (n < 2) return;
+    uint64_t *k2 = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint32_t *r2 = (uint32_t *)malloc(n * sizeof(uint32_t));
+    uint64_t *ka = kmer, *kb = k2;
+    uint32_t *ra = read, *rb = r2;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int sh = 8 * pass;
+        uint64_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (uint64_t i = 0; i < n; ++i) ++hist[((ka[i] >> sh) & 255) + 1];
+        int trivial = 0;
+        for (int d = 0; d < 256; ++d)
+            if (hist[d + 1] == n) trivial = 1;
+        if (trivial) continue;
+        for (int d = 0; d < 256; ++d) hist[d + 1] += hist[d];
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t dst = hist[(ka[i] >> sh) & 255]++;
+            kb[dst] = ka[i];
+            rb[dst] = ra[i];
+        }
+        uint64_t *tk = ka; ka = kb; kb = tk;
+        uint32_t *tr = ra; ra = rb; rb = tr;
+    }
+    if (ka != kmer) {
+        memcpy(kmer, ka, n * sizeof(uint64_t));
+        memcpy(read, ra, n * sizeof(uint32_t));
+    }
+    free(k2);
+    free(r2);
+}
+
+void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uint64_t n,
+               uint64_t *rangeStart, uint32_t *rangeLenM1)
+{
+    const int sh = 5 * (p->K - 6);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t pre = kmer[i] >> sh;
+        uint64_t lo = 0, hi = ix->nTrie;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (ix->triePrefix[mid] < pre) lo = mid + 1; else hi = mid;
+        }
+        if (lo < ix->nTrie && ix->triePrefix[lo] == pre) {
+            rangeStart[i] = ix->trieStart[lo];
+            rangeLenM1[i] = ix->trieLenM1[lo];
+        } else {
+            rangeStart[i] = KO_RANGE_NONE;
+            rangeLenM1[i] = 0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-level state shared by both comparison routines: the remembered prefix, the read list of the
+ * open group and its taxon set (BitArray.hpp:98-117: bitset + insertion-ordered list).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t mem;     /* vMemoryOfSeenkMers */
+    uint64_t hits;    /* vPositions */
+    uint64_t *reads;  /* vReadIDs */
+    uint64_t readsCap;
+    uint64_t *bits;   /* taxon bitset */
+    uint32_t *taxList;
+    uint32_t nTax;
+} level_state;
+
+typedef struct {
+    const ko_params *p;
+    const ko_index *ix;
+    int nK;
+    level_state *lv;
+    double *countAll;
+    uint64_t *countUnique;
+    uint64_t *countTotal;
+    float *M;
+    int haveM;
+} cmp_ctx;
+
+static void ctx_init(cmp_ctx *c, const ko_params *p, const ko_index *ix, double *ca, uint64_t *cu,
+                     uint64_t *ct, float *M)
+{
+    c->p = p; c->ix = ix; c->nK = p->kHigh - p->kLow + 1;
+    c->countAll = ca; c->countUnique = cu; c->countTotal = ct; c->M = M; c->haveM = (M != NULL);
+    c->lv = (level_state *)calloc((size_t)c->nK, sizeof(level_state));
+    const size_t words = ((size_t)ix->nTaxa + 63) >> 6;
+    for (int i = 0; i < c->nK; ++i) {
+        c->lv[i].bits = (uint64_t *)calloc(words ? words : 1, 8);
+        c->lv[i].taxList = (uint32_t *)malloc(((size_t)ix->nTaxa + 1) * 4);
+        c->lv[i].readsCap = 128;
+        c->lv[i].reads = (uint64_t *)malloc(128 * 8);
+    }
+}
+
+static void ctx_free(cmp_ctx *c)
+{
+    for (int i = 0; i < c->nK; ++i) { free(c->lv[i].bits); free(c->lv[i].taxList); free(c->lv[i].reads); }
+    free(c->lv);
+}
+
+static inline void lv_mark(level_state *s, uint32_t t)
+{
+    if (!((s->bits[t >> 6] >> (t & 63)) & 1)) {
+        s->taxList[s->nTax++] = t;
+        s->bits[t >> 6] |= 1ULL << (t & 63);
+    }
+}
+
+static inline void lv_clear_taxa(level_state *s)
+{
+    for (uint32_t i = 0; i < s->nTax; ++i) s->bits[s->taxList[i] >> 6] = 0;
+    s->nTax = 0;
+}
+
+static inline void lv_push(cmp_ctx *c, level_state *s, uint32_t rid)
+{
+    if (c->haveM) { /* Compare.hpp:721-728; profile-only mode just counts (687-689) */
+        if (s->hits >= s->readsCap) {
+            s->readsCap *= 2;
+            s->reads = (uint64_t *)realloc(s->reads, s->readsCap * 8);
+        }
+        s->reads[s->hits] = rid;
+    }
+    s->hits++;
+}
+
+/* A7. Compare.hpp:648-673 -> 516-532 (non-AVX), 534-597 (AVX, only when avxQuirk && n > 3),
+ * 599-645 (counts only).  lvIdx = 0 for kHigh (Compare.hpp:922-925). */
+static void flush_level(cmp_ctx *c, int lvIdx)
+{
+    level_state *s = &c->lv[lvIdx];
+    const uint64_t n = s->nTax;
+    const uint64_t h = s->hits;
+    if (n == 0) return; /* the reference iterates an empty taxon list: nothing is touched */
+    const uint32_t nTaxa = c->ix->nTaxa;
+    const uint64_t base = (uint64_t)nTaxa * (uint64_t)lvIdx;
+    const float weight = ko_weight(c->p->kHigh - lvIdx);
+    const float score = weight * (1.f / (float)n);
+    const double counts = (double)h / (double)n;
+    const int avx = c->p->avxQuirk && n > 3;
+
+    if (!c->haveM || !avx) {
+        for (uint32_t i = 0; i < s->nTax; ++i) {
+            const uint32_t t = s->taxList[i];
+            c->countAll[base + t] += counts;
+            if (c->p->coverage && c->countTotal) c->countTotal[base + t] += 1;
+            if (n == 1 && !avx) c->countUnique[base + t] += h;
+            if (c->haveM)
+                for (uint64_t r = 0; r < h; ++r) {
+                    float *cell = &c->M[s->reads[r] * (uint64_t)nTaxa + t];
+                    *cell = *cell + score;
+                }
+        }
+        return;
+    }
+    /* scoreMatchAVX: 8-slot gather blocks; a taxon takes reads from the list head only while the
+     * block has room, a block is written back slot by slot (Compare.hpp:559-575,588-596). */
+    uint64_t blkRead[8], blkTax[8];
+    float blkVal[8];
+    uint32_t blk = 0;
+    for (uint32_t i = 0; i < s->nTax; ++i) {
+        const uint32_t t = s->taxList[i];
+        c->countAll[base + t] += counts;
+        if (c->p->coverage && c->countTotal) c->countTotal[base + t] += 1;
+        for (uint64_t r = 0; blk < 8 && r < h; ++r, ++blk) {
+            blkRead[blk] = s->reads[r];
+            blkTax[blk] = t;
+            blkVal[blk] = c->M[s->reads[r] * (uint64_t)nTaxa + t];
+        }
+        if (blk == 8) {
+            for (uint32_t j = 0; j < 8; ++j) blkVal[j] = blkVal[j] + score;
+            for (uint32_t j = 0; j < 8; ++j) c->M[blkRead[j] * (uint64_t)nTaxa + blkTax[j]] = blkVal[j];
+            blk = 0;
+        }
+    }
+    if (blk > 0) {
+        for (uint32_t j = 0; j < blk; ++j) blkVal[j] = blkVal[j] + score;
+        for (uint32_t j = 0; j < blk; ++j) c->M[blkRead[j] * (uint64_t)nTaxa + blkTax[j]] = blkVal[j];
+    }
+}
+
+static inline int shift_of(const ko_params *p, int lvIdx) { return 5 * (p->K - (p->kHigh - lvIdx)); }
+
+/* first position in [lo, hiIncl+1) whose (kmer >> sh) is >= val (std::lower_bound, Compare.hpp:824,980) */
+static uint64_t lower_bound_shifted(const uint64_t *km, uint64_t lo, uint64_t hiExcl, int sh, uint64_t val)
+{
+    while (lo < hiExcl) {
+        const uint64_t mid = lo + ((hiExcl - lo) >> 1);
+        if ((km[mid] >> sh) < val) lo = mid + 1; else hiExcl = mid;
+    }
+    return lo;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A6. Compare.hpp:678-1069, statement by statement in the same order (64-bit keys, no spaced masks,
+ * no post-processing).  Level index lv: 0 = kHigh ... nK-1 = kLow (kASA.hpp:299-302).
+ * ---------------------------------------------------------------------------------------------- */
+int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+                          const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                          uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                          uint64_t *countTotal, float *M)
+{
+    (void)nReads;
+    cmp_ctx c;
+    ctx_init(&c, p, ix, countAll, countUnique, countTotal, M);
+    const int nK = c.nK;
+    const int low = nK - 1;
+    const uint64_t *km = ix->kmer;
+    const uint32_t *tx = ix->tax;
+
+    uint64_t pos = 0;
+    while (pos < nQ) {
+        const uint64_t rs = qRS[pos];
+        const uint64_t rl = qRL[pos];
+        uint64_t qi = pos;
+        if (rs == KO_RANGE_NONE) { ++pos; continue; } /* :753-756 */
+        while (pos < nQ) {                             /* :758-766 */
+            const uint64_t cur = qRS[pos];
+            if (cur != rs && cur != KO_RANGE_NONE) break;
+            ++pos;
+        }
+        for (int i = 0; i < nK; ++i) {                 /* :769-773 */
+            c.lv[i].hits = 0; c.lv[i].mem = 0; lv_clear_taxa(&c.lv[i]);
+        }
+        uint64_t seenKmer = 0;                         /* :774 */
+        const uint64_t rb = rs, re = rs + rl;          /* :777-778, re is the last entry (inclusive) */
+        uint64_t it = rb;
+        int determine = 1;
+
+        for (; qi < pos; ++qi) {                       /* :785 */
+            if (qRS[qi] == KO_RANGE_NONE) continue;
+            int sh = shift_of(p, low);
+            const uint64_t q = qKmer[qi];
+            const uint32_t rid = qRead[qi];
+            uint64_t qs = q >> sh;
+            int inputIterated = 1;
+
+            if (seenKmer != q && (km[it] >> sh) != qs && determine) { /* :803-829 */
+                if ((km[rb] >> sh) == qs) {
+                    it = rb;
+                } else if ((km[re] >> sh) == qs) {
+                    uint64_t t = 1;
+                    while ((km[re - t] >> sh) == qs) ++t;
+                    it = re - (t - 1);
+                } else if (qs < (km[rb] >> sh) || qs > (km[re] >> sh)) {
+                    continue; /* not inside the range; `determine` stays set (:819) */
+                } else {
+                    it = lower_bound_shifted(km, rb, re + 1, sh, qs);
+                }
+            }
+            determine = 0;
+
+            if ((qs & 31) == 30) continue;             /* :836-838 */
+
+            if (seenKmer == q || it == re + 1) {       /* :841-853 duplicates / index exhausted */
+                for (int l = low; l >= 0; --l)
+                    if ((q >> shift_of(p, l)) == c.lv[l].mem) lv_push(&c, &c.lv[l], rid);
+                continue;
+            }
+            seenKmer = q;                              /* :855 */
+
+            int breakOut = 0;
+            while (it != re + 1 && !breakOut) {        /* :861 */
+                const uint64_t e = km[it];
+                int l = low;
+                for (; l >= 0; --l) {                  /* :865 */
+                    sh = shift_of(p, l);
+                    qs = q >> sh;
+                    const uint64_t es = e >> sh;
+                    if (qs < es) {                     /* :875-893 input smaller */
+                        if (inputIterated)
+                            for (int u = l; u >= 0; --u) {
+                                if ((q >> shift_of(p, u)) == c.lv[u].mem) lv_push(&c, &c.lv[u], rid);
+                                else break;
+                            }
+                        breakOut = 1;
+                        break;
+                    } else if (qs == es) {             /* :895-956 */
+                        if ((qs & 31) == 30) { breakOut = 1; break; }
+                        level_state *s = &c.lv[l];
+                        if (qs == s->mem) {
+                            lv_mark(s, tx[it]);
+                            if (inputIterated) lv_push(&c, s, rid);
+                        } else {
+                            flush_level(&c, l);
+                            s->hits = 0;
+                            lv_push(&c, s, rid);
+                            lv_clear_taxa(s);
+                            lv_mark(s, tx[it]);
+                            s->mem = qs;
+                        }
+                    } else {                           /* :957-993 index smaller: walk / jump */
+                        uint64_t t = 1;
+                        while (it + t != re + 1) {
+                            const uint64_t nx = km[it + t];
+                            if (qs > (nx >> sh)) {
+                                int u = low;
+                                for (; u >= 0; --u) {
+                                    if (c.lv[u].mem == (nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
+                                    else break;
+                                }
+                                if (u < low) {
+                                    ++t;
+                                } else {
+                                    t = lower_bound_shifted(km, it + t, re + 1, sh, qs) - it;
+                                    break;
+                                }
+                            } else {
+                                break;
+                            }
+                        }
+                        it += t;
+                        break;
+                    }
+                }
+                if (l == -1) ++it;                     /* :997-999 */
+                inputIterated = 0;
+            }
+        }
+
+        uint64_t t = 0;                                /* :1007-1028 rest of the range */
+        while (it + t != re + 1) {
+            const uint64_t nx = km[it + t];
+            int u = low;
+            for (; u >= 0; --u) {
+                if (c.lv[u].mem == (nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
+                else break;
+            }
+            if (u < low) ++t; else break;
+        }
+        for (int l = low; l >= 0; --l) flush_level(&c, l); /* :1032-1041 */
+    }
+    ctx_free(&c);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the same result as a group-by.  Per prefix range, per query in sorted
+ * order, per k ascending: prefix P; '^' ends the query; absent from the range ends the query; same P
+ * as the open group of that k joins it, otherwise the open group is flushed and a new one starts
+ * with all distinct taxa of the index entries carrying P (index order).  This is what the device
+ * kernels compute; tests require it to equal ko_compare_sequential bit for bit.
+ * ---------------------------------------------------------------------------------------------- */
+int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+                           const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                           uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                           uint64_t *countTotal, float *M)
+{
+    (void)nReads;
+    cmp_ctx c;
+    ctx_init(&c, p, ix, countAll, countUnique, countTotal, M);
+    const int nK = c.nK;
+    const int low = nK - 1;
+    const uint64_t *km = ix->kmer;
+    uint64_t pos = 0;
+    while (pos < nQ) {
+        const uint64_t rs = qRS[pos];
+        if (rs == KO_RANGE_NONE) { ++pos; continue; }
+        const uint64_t lo = rs, hi = rs + qRL[pos] + 1; /* [lo, hi) */
+        uint64_t qi = pos;
+        while (pos < nQ && (qRS[pos] == rs || qRS[pos] == KO_RANGE_NONE)) ++pos;
+        for (int i = 0; i < nK; ++i) { c.lv[i].hits = 0; c.lv[i].mem = 0; lv_clear_taxa(&c.lv[i]); }
+        for (; qi < pos; ++qi) {
+            if (qRS[qi] == KO_RANGE_NONE) continue;
+            const uint64_t q = qKmer[qi];
+            uint64_t a = lo, b = hi;
+            for (int l = low; l >= 0; --l) {
+                const int sh = shift_of(p, l);
+                const uint64_t P = q >> sh;
+                if ((P & 31) == 30) break;
+                a = lower_bound_shifted(km, a, b, sh, P);
+                b = lower_bound_shifted(km, a, b, sh, P + 1);
+                if (a == b) break;
+                level_state *s = &c.lv[l];
+                if (s->nTax && s->mem == P) {
+                    lv_push(&c, s, qRead[qi]);
+                } else {
+                    flush_level(&c, l);
+                    s->hits = 0;
+                    lv_clear_taxa(s);
+                    s->mem = P;
+                    lv_push(&c, s, qRead[qi]);
+                    for (uint64_t i = a; i < b; ++i) lv_mark(s, ix->tax[i]);
+                }
+            }
+        }
+        for (int l = low; l >= 0; --l) flush_level(&c, l);
+    }
+    ctx_free(&c);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A8. Per-read numbers.  Compare.hpp:1452-1481, 1510, 1634.
+ * ---------------------------------------------------------------------------------------------- */
+float ko_best_score(uint64_t readLen, const ko_params *p)
+{
+    float best = 0.f;
+    for (int32_t i = p->kLow; i <= p->kHigh; ++i) {
+        const float w = ko_weight(i);
+        if (p->frames == 1) {
+            best += (float)(readLen / 3 - (uint64_t)i + 1) * w;
+        } else if (p->frames == 6) {
+            best += (float)(2 * (readLen - (uint64_t)(i * 3) + 1)) * w;
+        } else {
+            best += (float)(readLen - (uint64_t)(i * 3) + 1) * w;
+        }
+    }
+    return best;
+}
+
+double ko_relative_score(float kmerScore, uint64_t freqAtKHigh, uint64_t readLen, const ko_params *p)
+{
+    /* the reference subtracts in 32-bit unsigned arithmetic (uint32_t length, int K) */
+    const uint32_t span = (uint32_t)readLen - (uint32_t)(p->K * 3) + 1u;
+    return (double)kmerScore / (1.0 + log2((double)freqAtKHigh * (double)span));
+}
+
+double ko_error_score(float bestScore, float kmerScore)
+{
+    const float e = (bestScore - kmerScore) / bestScore;
+    return (double)e;
+}

@@ -1,0 +1,92 @@
+/*
+ * kasa_oracle.h -- CPU restatement of kASA's `identify` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / reported baseline.  The product path (kasa_amd + libkasa_hip.so) never links or calls it.
+ *
+ * Every function cites the reference file:line (relative to the kASA v1.4.9 tree) it restates.
+ * Parity pinning: tests/test_oracle_golden.py checks this restatement against outputs of the
+ * reference's own shipped binary (binaries/kASA_linux, v1.4.9) captured by
+ * tests/golden/make_fixtures.py -- see DESIGN.md "Oracle".
+ */
+#ifndef KASA_ORACLE_H
+#define KASA_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KO_RANGE_NONE UINT64_MAX
+
+typedef struct {
+    int32_t K;        /* letters per packed k-mer of the index: 12 (64-bit index) */
+    int32_t kHigh;    /* largest k evaluated  (-k <kHigh> <kLow>) */
+    int32_t kLow;     /* smallest k evaluated */
+    int32_t frames;   /* 3 (default) or 6 (--six); 1 (--one) */
+    int32_t avxQuirk; /* 1: flush like the reference's scoreMatchAVX (n>3), i.e. like the shipped
+                         -march=native binary; 0: scoreMatchNonAVX for every n (the parity target) */
+    int32_t coverage; /* 1: also count countTotal (--coverage) */
+} ko_params;
+
+typedef struct {
+    const uint64_t *kmer;     /* sorted by (kmer, taxid) */
+    const uint32_t *tax;      /* DENSE taxon index (1..nTaxa-1), i.e. after the content-file map */
+    uint64_t n;
+    const uint32_t *triePrefix; /* _trie entries: 30-bit prefixes, ascending */
+    const uint64_t *trieStart;  /* running sum of counts */
+    const uint32_t *trieLenM1;  /* count - 1 */
+    uint64_t nTrie;
+    uint32_t nTaxa;           /* incl. index 0 = "non_unique" */
+} ko_index;
+
+/* kASA.hpp:621-667 -- the built-in codon table as a 366-entry LUT of 5-bit letter codes. */
+void ko_codon_table(uint8_t lut[366]);
+
+/* Read.hpp:633-654,612-630,36-57 -- padded length (incl. marker) and k-mer count of one raw read. */
+int64_t ko_padded_len(int64_t rawLen, const ko_params *p);
+int64_t ko_kmer_count(int64_t paddedLen, const ko_params *p);
+
+/* Read.hpp:657-675,84-220,264-293 -- clean + pad + (revcomp) + translate + pack a batch of reads.
+ * bases: concatenated raw read bytes, off[nReads+1].  Returns the number of k-mers; when outKmer is
+ * NULL only counts.  Emission order = read order, forward strand then reverse complement. */
+int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads, const ko_params *p,
+                        const uint8_t lut[366], uint64_t *outKmer, uint32_t *outRead);
+
+/* Compare.hpp:1077 -- sort by k-mer only (stable LSD radix here; ties do not matter). */
+void ko_sort_queries(uint64_t *kmer, uint32_t *read, uint64_t n);
+
+/* Compare.hpp:1098-1117 + Trie.hpp:494-520 -- prefix (kmer>>30) -> (start, len-1) or KO_RANGE_NONE. */
+void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uint64_t n,
+               uint64_t *rangeStart, uint32_t *rangeLenM1);
+
+/* Compare.hpp:678-1069 -- faithful sequential merge of the sorted queries against the index.
+ * Tables are [lv * nTaxa + t] with lv = 0 for kHigh ... nK-1 for kLow (Compare.hpp:922).
+ * M is the dense nReads x nTaxa float matrix (Utilities.hpp:592-636) or NULL (profile only). */
+int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+                          const uint32_t *qRead, const uint64_t *qRangeStart,
+                          const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
+                          double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);
+
+/* SURVEY.md section 0.1 -- the closed form the device implements (group by (range, k, prefix)),
+ * evaluated with the same flush order.  Must equal ko_compare_sequential bit for bit. */
+int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+                           const uint32_t *qRead, const uint64_t *qRangeStart,
+                           const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
+                           double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);
+
+/* Compare.hpp:1452-1481 */
+float ko_best_score(uint64_t readLen, const ko_params *p);
+/* Compare.hpp:1510 -- relative score of one (read, taxon) cell. */
+double ko_relative_score(float kmerScore, uint64_t freqAtKHigh, uint64_t readLen, const ko_params *p);
+/* Compare.hpp:1634 -- error of one hit (float arithmetic, printed as double). */
+double ko_error_score(float bestScore, float kmerScore);
+
+/* Compare.hpp:392 -- w_k = k^2/625 as float. */
+float ko_weight(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,156 @@
+"""ctypes wrapper around oracle/libkasa_oracle.so (the CPU restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing in kasa_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+RANGE_NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+class Params(C.Structure):
+    _fields_ = [("K", C.c_int32), ("kHigh", C.c_int32), ("kLow", C.c_int32), ("frames", C.c_int32),
+                ("avxQuirk", C.c_int32), ("coverage", C.c_int32)]
+
+
+class _Index(C.Structure):
+    _fields_ = [("kmer", C.c_void_p), ("tax", C.c_void_p), ("n", C.c_uint64),
+                ("triePrefix", C.c_void_p), ("trieStart", C.c_void_p), ("trieLenM1", C.c_void_p),
+                ("nTrie", C.c_uint64), ("nTaxa", C.c_uint32)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libkasa_oracle.so")
+    src = os.path.join(_HERE, "kasa_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ko_encode_batch.restype = C.c_int64
+        _LIB.ko_padded_len.restype = C.c_int64
+        _LIB.ko_kmer_count.restype = C.c_int64
+        _LIB.ko_best_score.restype = C.c_float
+        _LIB.ko_relative_score.restype = C.c_double
+        _LIB.ko_error_score.restype = C.c_double
+        _LIB.ko_weight.restype = C.c_float
+        _LIB.ko_best_score.argtypes = [C.c_uint64, C.POINTER(Params)]
+        _LIB.ko_relative_score.argtypes = [C.c_float, C.c_uint64, C.c_uint64, C.POINTER(Params)]
+        _LIB.ko_error_score.argtypes = [C.c_float, C.c_float]
+        _LIB.ko_padded_len.argtypes = [C.c_int64, C.POINTER(Params)]
+        _LIB.ko_kmer_count.argtypes = [C.c_int64, C.POINTER(Params)]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def params(k_high=12, k_low=7, frames=3, avx_quirk=False, coverage=False, K=12) -> Params:
+    return Params(K, k_high, k_low, frames, int(avx_quirk), int(coverage))
+
+
+def codon_table() -> np.ndarray:
+    lut = np.zeros(366, dtype=np.uint8)
+    lib().ko_codon_table(_p(lut))
+    return lut
+
+
+def encode(bases: np.ndarray, offsets: np.ndarray, p: Params, lut=None):
+    """-> (kmer u64[nQ], read u32[nQ]) in emission order (Read.hpp:84-293)."""
+    L = lib()
+    lut = codon_table() if lut is None else lut
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.shape[0] - 1
+    total = L.ko_encode_batch(_p(bases), _p(offsets), C.c_int64(n), C.byref(p), _p(lut), None, None)
+    km = np.zeros(total, dtype=np.uint64)
+    rd = np.zeros(total, dtype=np.uint32)
+    got = L.ko_encode_batch(_p(bases), _p(offsets), C.c_int64(n), C.byref(p), _p(lut), _p(km), _p(rd))
+    assert got == total
+    return km, rd
+
+
+def sort_queries(km: np.ndarray, rd: np.ndarray):
+    km, rd = km.copy(), rd.copy()
+    lib().ko_sort_queries(_p(km), _p(rd), C.c_uint64(km.shape[0]))
+    return km, rd
+
+
+class IndexView:
+    """Keeps the numpy arrays alive next to the C struct."""
+
+    def __init__(self, ix):
+        self.kmer = np.ascontiguousarray(ix.kmer, dtype=np.uint64)
+        self.tax = np.ascontiguousarray(ix.tax, dtype=np.uint32)
+        self.tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32)
+        self.ts = np.ascontiguousarray(ix.trie_start, dtype=np.uint64)
+        self.tl = np.ascontiguousarray(ix.trie_len_m1, dtype=np.uint32)
+        self.n_taxa = ix.content.n_taxa
+        self.c = _Index(_p(self.kmer), _p(self.tax), self.kmer.shape[0], _p(self.tp), _p(self.ts),
+                        _p(self.tl), self.tp.shape[0], self.n_taxa)
+
+
+def ranges(iv: IndexView, p: Params, km: np.ndarray):
+    rs = np.zeros(km.shape[0], dtype=np.uint64)
+    rl = np.zeros(km.shape[0], dtype=np.uint32)
+    lib().ko_ranges(C.byref(iv.c), C.byref(p), _p(km), C.c_uint64(km.shape[0]), _p(rs), _p(rl))
+    return rs, rl
+
+
+@dataclass
+class CompareResult:
+    count_all: np.ndarray     # f64[nK, nTaxa], row 0 = kHigh
+    count_unique: np.ndarray  # u64[nK, nTaxa]
+    count_total: np.ndarray   # u64[nK, nTaxa]
+    M: np.ndarray             # f32[nReads, nTaxa] or None
+
+
+def compare(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, want_reads=True,
+            closed_form=False) -> CompareResult:
+    nK = p.kHigh - p.kLow + 1
+    ca = np.zeros((nK, iv.n_taxa), dtype=np.float64)
+    cu = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
+    ct = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
+    M = np.zeros((n_reads, iv.n_taxa), dtype=np.float32) if want_reads else None
+    fn = lib().ko_compare_closed_form if closed_form else lib().ko_compare_sequential
+    rc = fn(C.byref(p), C.byref(iv.c), _p(km), _p(rd), _p(rs), _p(rl), C.c_uint64(km.shape[0]),
+            C.c_uint64(n_reads), _p(ca), _p(cu), _p(ct), _p(M) if want_reads else None)
+    assert rc == 0
+    return CompareResult(ca, cu, ct, M)
+
+
+def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False):
+    """Whole reference batch: encode -> sort -> ranges -> merge.  Returns (CompareResult, nQueries)."""
+    iv = IndexView(ix)
+    km, rd = encode(bases, offsets, p)
+    km, rd = sort_queries(km, rd)
+    rs, rl = ranges(iv, p, km)
+    res = compare(iv, p, km, rd, rs, rl, offsets.shape[0] - 1, want_reads, closed_form)
+    return res, int(km.shape[0])
+
+
+def best_score(length: int, p: Params) -> np.float32:
+    return np.float32(lib().ko_best_score(C.c_uint64(int(length)), C.byref(p)))
+
+
+def relative_score(score, freq: int, length: int, p: Params) -> float:
+    return float(lib().ko_relative_score(C.c_float(float(score)), C.c_uint64(int(freq)),
+                                         C.c_uint64(int(length)), C.byref(p)))
+
+
+def error_score(best, score) -> float:
+    return float(lib().ko_error_score(C.c_float(float(best)), C.c_float(float(score))))

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the development container, where /root/reference exists.  The reference's own test
+assets hold no expected outputs for `identify`, and its source tree cannot be
+compiled here under the round's rules (it needs cmake-generated STXXL headers) -- but it ships a
+prebuilt binary of the same version, binaries/kASA_linux (v1.4.9, an AVX build), which runs here.
+This script drives that binary: `build` on a seeded synthetic database, then `identify` in several
+configurations, and stores inputs + the binary's outputs as fixtures.  Nothing of the reference's
+source or binary is copied; only its outputs (and the index files it wrote, which are data).
+
+The binary is started through the dynamic loader because the read-only mount drops the x bit.
+
+    python tests/golden/make_fixtures.py          # regenerates every case
+"""
+import gzip
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+REF = "/root/reference"
+KASA = ["/lib64/ld-linux-x86-64.so.2", os.path.join(REF, "binaries", "kASA_linux")]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(args, cwd):
+    tmp = os.path.join(cwd, "tmp")
+    os.makedirs(tmp, exist_ok=True)
+    cmd = KASA + args + ["-t", tmp + "/"]
+    p = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout)
+        raise SystemExit("reference failed: " + " ".join(args))
+    return p.stdout
+
+
+def mutate(s, rate, rng):
+    s = list(s)
+    for i in range(len(s)):
+        if rng.random() < rate:
+            s[i] = rng.choice("ACGT")
+    return "".join(s)
+
+
+def write_db(d, genomes):
+    with open(os.path.join(d, "db.fasta"), "w") as f, open(os.path.join(d, "content.txt"), "w") as c:
+        for g, s in enumerate(genomes):
+            acc = "ACC%03d.1" % g
+            f.write(">%s synthetic taxon %d\n" % (acc, g))
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+            c.write("Taxon %d\t%d\t%d\t%s\n" % (g, 100 + g, 100 + g, acc))
+
+
+def trim_index(d):
+    """The reference zero-pads index and trie files to 2,101,248-byte blocks; keep the records only."""
+    n = int(open(os.path.join(d, "idx_info.txt")).read().split()[0])
+    m = int(open(os.path.join(d, "idx_trie.txt")).read().split()[0])
+    for name, cnt in (("idx", n), ("idx_trie", m)):
+        p = os.path.join(d, name)
+        with open(p, "rb") as f:
+            data = f.read(cnt * 12)
+        with open(p, "wb") as f:
+            f.write(data)
+
+
+def case_pairs(out):
+    """6 taxa in 3 sibling pairs (3 % apart): at most 2-3 taxa per k-mer -> the binary's scalar path."""
+    rng = random.Random(11)
+    G, L = 6, 1500
+    genomes = []
+    for g in range(G):
+        genomes.append(mutate(genomes[g - 1], 0.03, rng) if g % 2 else
+                       "".join(rng.choice("ACGT") for _ in range(L)))
+    write_db(out, genomes)
+    rng = random.Random(12)
+    reads = []
+    for r in range(48):
+        g = rng.randrange(G)
+        p = rng.randrange(L - 150)
+        reads.append(("read%d_t%d" % (r, g), mutate(genomes[g][p:p + 150], 0.01, rng)))
+    g0 = genomes[0]
+    reads.append(("withN", g0[100:160] + "NNNN" + g0[164:250]))
+    reads.append(("dash_and_lower", g0[300:340].lower() + "-" + g0[341:450]))
+    reads.append(("tiny10", g0[500:510]))                       # padded to 3K -> zero k-mers
+    reads.append(("len21", g0[520:541]))                        # padded length 36 -> 0 k-mers
+    reads.append(("len22", g0[520:542]))
+    reads.append(("len23", g0[520:543]))                        # first length with k-mers
+    reads.append(("len36", g0[600:636]))
+    reads.append(("len40", g0[600:640]))
+    reads.append(("tandem", g0[700:730] * 5))                   # the same k-mers several times in one read
+    reads.append(("twice", g0[800:875] + g0[800:875]))
+    reads.append(("foreign", "".join(rng.choice("ACGT") for _ in range(150))))
+    reads.append(("polyA", "A" * 150))
+    with open(os.path.join(out, "reads.fastq"), "w") as f:
+        for n, s in reads:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    with open(os.path.join(out, "reads.fasta"), "w") as f:      # multi-line FASTA of the same reads
+        for n, s in reads:
+            f.write(">%s\n" % n)
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+    run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
+    base = ["identify", "-c", "content.txt", "-d", "idx", "-m", "4", "-n", "1"]
+    runs = {
+        "default.json": ["-i", "reads.fastq", "--json"],
+        "b100.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100"],
+        "b100.tsv": ["-i", "reads.fastq", "--tsv", "-b", "100"],
+        "b1.tsv": ["-i", "reads.fastq", "--tsv", "-b", "1"],
+        "default.ktsv": ["-i", "reads.fastq", "--kraken"],
+        "fasta.jsonl": ["-i", "reads.fasta", "--jsonl", "-b", "100"],
+        "k12_9.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "-k", "12", "9"],
+        "k10_7.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "-k", "10", "7"],
+        "k12_12.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "-k", "12", "12"],
+        "six.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--six"],
+        "thr04.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--threshold", "0.4"],
+        "ram.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "-r"],
+    }
+    for name, extra in runs.items():
+        stem = name.rsplit(".", 1)[0]
+        run(base + extra + ["-q", "out_" + name, "-p", "prof_" + stem + ".csv"], out)
+    # the reference's own example input (2 reads; N- and '-'-containing, multi-line FASTA)
+    shutil.copy(os.path.join(REF, "example/work/input/exampleInput.fasta"), os.path.join(out, "exampleInput.fasta"))
+    run(base + ["-i", "exampleInput.fasta", "--jsonl", "-b", "100", "-q", "out_exampleInput.jsonl",
+                "-p", "prof_exampleInput.csv"], out)
+    # (example.fastq.gz is left out: the shipped binary spins forever on that gzipped input here)
+
+
+def case_clones(out):
+    """6 near-identical taxa: most k-mers are shared by > 3 taxa, so the shipped (AVX) binary takes
+    its scoreMatchAVX branch.  Reads sit on disjoint windows so no two reads share a k-mer."""
+    rng = random.Random(21)
+    L = 1200
+    base_g = "".join(rng.choice("ACGT") for _ in range(L))
+    genomes = [base_g] + [mutate(base_g, 0.004, rng) for _ in range(5)]
+    write_db(out, genomes)
+    rng = random.Random(22)
+    with open(os.path.join(out, "reads.fastq"), "w") as f:
+        for r in range(7):
+            g = rng.randrange(6)
+            p = r * 160
+            s = genomes[g][p:p + 150]
+            f.write("@clone%d_t%d\n%s\n+\n%s\n" % (r, g, s, "I" * 150))
+        # the same k-mers several times inside ONE read: groups with > 3 taxa and > 1 hit, where the
+        # AVX branch loses increments (and tie order cannot matter: all hits carry the same read id)
+        for r, unit in enumerate((30, 45)):
+            s = (genomes[0][1125:1125 + unit] * 6)[:150]
+            f.write("@tandem%d\n%s\n+\n%s\n" % (r, s, "I" * 150))
+    run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
+    base = ["identify", "-c", "content.txt", "-d", "idx", "-m", "4", "-n", "1", "-i", "reads.fastq"]
+    run(base + ["--jsonl", "-b", "100", "-q", "out_b100.jsonl", "-p", "prof_b100.csv"], out)
+    run(base + ["-p", "prof_only.csv"], out)
+
+
+def finish(out):
+    trim_index(out)
+    for junk in ("tmp", "stxxl.log", "stxxl.errlog"):
+        p = os.path.join(out, junk)
+        if os.path.isdir(p):
+            shutil.rmtree(p)
+        elif os.path.exists(p):
+            os.remove(p)
+
+
+def main():
+    if not os.path.exists(KASA[1]):
+        raise SystemExit("needs /root/reference (development container only)")
+    only = sys.argv[1:]
+    for name, fn in (("pairs", case_pairs), ("clones", case_clones)):
+        if only and name not in only:
+            continue
+        out = os.path.join(HERE, name)
+        if os.path.isdir(out):
+            shutil.rmtree(out)
+        os.makedirs(out)
+        fn(out)
+        finish(out)
+        print("wrote", out, sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+    ver = subprocess.run(KASA, stdout=subprocess.PIPE, text=True, timeout=60).stdout.splitlines()[0]
+    with open(os.path.join(HERE, "PROVENANCE.json"), "w") as f:
+        json.dump({"reference_binary": "binaries/kASA_linux", "banner": ver.split(" ran on")[0],
+                   "note": "AVX build: groups with more than 3 taxa go through scoreMatchAVX"}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

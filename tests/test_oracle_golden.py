@@ -1,0 +1,60 @@
+"""Pin the oracle: its results, rendered by the host-side report module, must equal byte for byte
+what the reference's shipped binary wrote for the same inputs (tests/golden/, make_fixtures.py)."""
+import os
+
+import pytest
+
+from kasa_amd import reads
+from tests import helpers
+
+PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts)
+    ("default.json", "reads.fastq", "json", 12, 7, 3, 0.0, 3),
+    ("b100.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
+    ("b100.tsv", "reads.fastq", "tsv", 12, 7, 3, 0.0, 100),
+    ("b1.tsv", "reads.fastq", "tsv", 12, 7, 3, 0.0, 1),
+    ("default.ktsv", "reads.fastq", "kraken", 12, 7, 3, 0.0, 3),
+    ("fasta.jsonl", "reads.fasta", "jsonl", 12, 7, 3, 0.0, 100),
+    ("k12_9.jsonl", "reads.fastq", "jsonl", 12, 9, 3, 0.0, 100),
+    ("k10_7.jsonl", "reads.fastq", "jsonl", 10, 7, 3, 0.0, 100),
+    ("k12_12.jsonl", "reads.fastq", "jsonl", 12, 12, 3, 0.0, 100),
+    ("six.jsonl", "reads.fastq", "jsonl", 12, 7, 6, 0.0, 100),
+    ("thr04.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.4, 100),
+    ("ram.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
+    ("exampleInput.jsonl", "exampleInput.fasta", "jsonl", 12, 7, 3, 0.0, 100),
+]
+
+
+def _read(path, binary=False):
+    with open(path, "rb") as f:
+        data = f.read()
+    return data if binary else data.decode("latin-1")
+
+
+@pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
+@pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
+def test_pairs_byte_identical(case, closed_form):
+    stem, infile, fmt, kh, kl, frames, thr, beasts = case
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, infile))
+    res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=closed_form)
+    text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
+                                nq, fmt, kh, kl, frames, thr, beasts)
+    assert text == _read(os.path.join(d, "out_" + stem))
+    assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+
+
+@pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
+def test_clones_avx_build(closed_form):
+    """> 3 taxa per k-mer: the shipped binary is an AVX build, the oracle's avxQuirk flag restates
+    that branch (Compare.hpp:534-597).  The parity target for the device is avxQuirk = 0."""
+    d, ix = helpers.load_case("clones")
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    res, nq = helpers.oracle_identify(ix, batch, avx_quirk=True, closed_form=closed_form)
+    text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
+                                nq, "jsonl", 12, 7, 3, 0.0, 100)
+    assert text == _read(os.path.join(d, "out_b100.jsonl"))
+    assert prof == _read(os.path.join(d, "prof_b100.csv"))
+    assert prof == _read(os.path.join(d, "prof_only.csv"))
+    # and the scalar branch really differs on this data (otherwise the case pins nothing)
+    res2, _ = helpers.oracle_identify(ix, batch, avx_quirk=False)
+    assert (res2.M != res.M).any()
