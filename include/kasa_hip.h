@@ -1,0 +1,138 @@
+/*
+ * kasa_hip.h -- C ABI of the MI355X (gfx950) implementation of kASA's `identify` hot path.
+ *
+ * kASA has no plugin/FFI interface: the hot path is the set of calls that
+ * Compare::CompareWithLib_partialSort (source/modes/Compare.hpp:2733) makes per batch.  This header
+ * declares exactly those calls as a drop-in seam; each entry names the reference code it replaces.
+ * Plain pointers and sizes only; every buffer passed in is owned by the caller and only borrowed for
+ * the duration of the call; nothing returned outlives kasa_ctx_destroy / kasa_index_destroy.
+ *
+ * Errors: the reference throws std::runtime_error / bad_alloc and prints "ERROR: <what>"
+ * (source/main.cpp:1717-1720).  Here every call returns a status (0 = ok) and never lets a C++
+ * exception or HIP error cross the boundary; kasa_last_error() returns the message the host wrapper
+ * rethrows as runtime_error (INTEGRATION.md shows the reference-side binding).
+ *
+ * Threading (Compare.hpp:3263-3283, main.cpp:1292-1326): a kasa_index is immutable after creation
+ * and may be shared by any number of contexts / threads; a kasa_ctx (stream, batch buffers, profile
+ * tables) is single-threaded.
+ *
+ * Table layout everywhere: [level * nTaxa + taxIdx], level 0 = kHigh ... nK-1 = kLow, taxIdx = dense
+ * index of the content file (0 = "non_unique"), exactly Compare.hpp:922.
+ */
+#ifndef KASA_HIP_H
+#define KASA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kasa_index kasa_index;
+typedef struct kasa_ctx kasa_ctx;
+
+enum {
+    KASA_OK = 0,
+    KASA_E_ARG = 1,       /* bad argument (the message says which) */
+    KASA_E_HIP = 2,       /* a HIP runtime call failed */
+    KASA_E_NOMEM = 3,     /* device or host allocation failed (reference: bad_alloc) */
+    KASA_E_STATE = 4,     /* calls out of order (e.g. lookup before sort) */
+    KASA_E_LIMIT = 5      /* a documented capacity limit was hit (message says which) */
+};
+
+/* stages of one batch, for kasa_ctx_stage_ms() */
+enum {
+    KASA_STAGE_ENCODE = 0,   /* Read.hpp:763-827  convertAndSort -> convertLinesTokMers_new */
+    KASA_STAGE_SORT = 1,     /* Compare.hpp:1077/1130 sort by k-mer */
+    KASA_STAGE_LOOKUP = 2,   /* Compare.hpp:1098-1117 + :803-829,:861-995: prefix table + search */
+    KASA_STAGE_GROUP = 3,    /* Compare.hpp:917-955,1005-1041: per-level groups, taxon sets, flush order */
+    KASA_STAGE_REGROUP = 4,  /* the scatter of Compare.hpp:528-530, done as a stable sort back to reads */
+    KASA_STAGE_SCORE = 5,    /* Compare.hpp:516-532 score accumulation in reference order */
+    KASA_STAGE_COUNT = 6
+};
+
+/* Message of the last failed call on this thread ("" if none). */
+const char *kasa_last_error(void);
+
+/* Number of visible HIP devices (0 if none / no driver). */
+int kasa_device_count(int *count);
+
+/* ---- index residency: replaces Compare::ReadIndex::loadIndex / loadTrie / loadContentAndFrequencyFiles
+ *      (source/modes/Compare.hpp:111-337).
+ * records   : nRecords packed {u64 kmer, u32 taxid} entries of 12 bytes, sorted by (kmer, taxid) --
+ *             the index file as it is on disk (may be an mmap of it).
+ * triePrefix/trieCount : the `_trie` file (source/modes/Trie.hpp:365-394): 30-bit prefixes ascending
+ *             and their entry counts; may be NULL/0 -- the device derives its own two-level prefix
+ *             table from the records and, when given, checks it against this one.
+ * taxIds    : taxIds[i] = tax ID of dense index i as in the content file (taxIds[0] = 0), nTaxa
+ *             entries (Compare.hpp:121-151).
+ */
+int kasa_index_create(int device, const void *records, uint64_t nRecords, int recordBytes,
+                      const uint32_t *triePrefix, const uint64_t *trieCount, uint64_t nTrie,
+                      const uint32_t *taxIds, uint32_t nTaxa, kasa_index **out);
+void kasa_index_destroy(kasa_index *ix);
+uint64_t kasa_index_size(const kasa_index *ix);
+uint64_t kasa_index_device_bytes(const kasa_index *ix);
+
+/* ---- context: replaces the kASA / Read / Compare constructors (source/kASA.hpp:276-305) and
+ *      setCodonTable (source/kASA.hpp:579-615).
+ * kHigh/kLow : -k <kHigh> <kLow>; frames: 3 (default) or 6 (--six); codonLut: 366-byte table of
+ * 5-bit letter codes indexed like kASA.hpp:75, or NULL for the built-in table (kASA.hpp:621-667).
+ */
+int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int frames, const uint8_t *codonLut,
+                    kasa_ctx **out);
+void kasa_ctx_destroy(kasa_ctx *ctx);
+
+/* ---- one batch ------------------------------------------------------------------------------- */
+
+/* Hand the raw reads of one batch to the device: concatenated bases and offsets[nReads+1].
+ * Replaces the vLines the reference keeps per batch (Read.hpp:612-630).  Cleaning (non-ACGT -> Z),
+ * padding and the X marker (Read.hpp:633-675,1068-1078) happen on the device.  H2D copy only. */
+int kasa_batch_upload(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offsets, int64_t nReads);
+
+/* Read::convertAndSort (Read.hpp:763-827): every read -> packed k-mers + read id, device resident. */
+int kasa_batch_encode(kasa_ctx *ctx, uint64_t *nKmers);
+
+/* Compare::sortInputAndCheckInvalidkMers_sta (Compare.hpp:1074-1260): sort by k-mer and find each
+ * query's place in the index.  unique != 0 is -e/--unique (Compare.hpp:3167-3178). */
+int kasa_batch_sort_and_range(kasa_ctx *ctx, int unique);
+
+/* Compare::compareWithDatabase + scoreMatchForReadIDsAndTaxIDs (Compare.hpp:678-1069,516-673):
+ * adds this batch into the context's profile tables; with wantPerRead also produces the non-zero
+ * cells of the reads x taxa score matrix (Utilities.hpp:592-636) as a CSR. */
+int kasa_batch_lookup_score(kasa_ctx *ctx, int wantPerRead, int coverage);
+
+/* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
+ * scoringFunc scans (Compare.hpp:1501-1522). */
+int kasa_batch_scores_size(kasa_ctx *ctx, uint64_t *nnz);
+int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxIdx, float *score);
+
+/* ---- profile tables: vCount_all / vCount_unique / vCount_total (Compare.hpp:2830-2839) ---------- */
+int kasa_profile_reset(kasa_ctx *ctx);
+/* countAll as double (exact 64.64 fixed-point sums rounded once), countUnique, countTotal; any may
+ * be NULL.  nK * nTaxa entries each. */
+int kasa_profile_fetch(kasa_ctx *ctx, double *countAll, uint64_t *countUnique, uint64_t *countTotal);
+/* The same tables as 6 integer limbs per cell {unique, total, all[0..3] (32 bits each, little
+ * endian)} so that ranks can be summed with a plain integer reduce (the thread reduce of
+ * Compare.hpp:3445-3454 across GPUs); import adds limbs back in. */
+int kasa_profile_export_limbs(kasa_ctx *ctx, uint64_t *limbs);
+int kasa_profile_import_limbs(kasa_ctx *ctx, const uint64_t *limbs);
+
+/* ---- measurement + test taps ------------------------------------------------------------------ */
+/* HIP-event time (ms) and launch count of a stage, accumulated since the last reset. */
+int kasa_ctx_stage_ms(kasa_ctx *ctx, int stage, double *ms, uint64_t *launches);
+int kasa_ctx_stage_reset(kasa_ctx *ctx);
+/* HIP-event time of the dominant kernel alone (the lookup kernel), for the roofline line. */
+int kasa_ctx_lookup_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
+/* Queries of the batch after encode / after sort (k-mer, read id); for parity tests. */
+int kasa_batch_fetch_queries(kasa_ctx *ctx, uint64_t *kmers, uint32_t *reads, uint64_t n);
+/* Test tap: install (k-mer, read id) queries directly instead of upload + encode (any order). */
+int kasa_batch_set_queries(kasa_ctx *ctx, const uint64_t *kmers, const uint32_t *reads, uint64_t n, int64_t nReads);
+/* Per sorted query: deepest matched level k (0 = none) and an index position sharing that prefix. */
+int kasa_batch_fetch_lookup(kasa_ctx *ctx, uint8_t *depth, uint32_t *indexPos, uint64_t n);
+int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);
+int kasa_ctx_synchronize(kasa_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

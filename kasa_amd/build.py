@@ -1,0 +1,32 @@
+"""Build the HIP extension in-tree (kasa_amd/libkasa_hip.so) for gfx950 with hipcc."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "kasa_hip.hip")
+SO = os.path.join(HERE, "libkasa_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "kasa_hip.h")
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required)")
+
+
+def build(force: bool = False) -> str:
+    newest = max(os.path.getmtime(p) for p in (SRC, HEADER))
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+        return SO
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-result", "-o", SO, SRC]
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,221 @@
+"""ctypes binding of the C ABI in include/kasa_hip.h (libkasa_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, calls raise.  The
+reference throws std::runtime_error and main prints "ERROR: <what>" (source/main.cpp:1717-1720); the
+binding turns every non-zero status into RuntimeError(kasa_last_error()) the same way.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libkasa_hip.so")
+_lib = None
+
+STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
+
+EXPORTS = [
+    "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
+    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_encode",
+    "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
+    "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
+    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_fetch_queries",
+    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"{SO_PATH} is missing: build it with `python -m kasa_amd.build` "
+                               "(there is no CPU fallback for the identify path)")
+        L = C.CDLL(SO_PATH)
+        L.kasa_last_error.restype = C.c_char_p
+        L.kasa_index_size.restype = C.c_uint64
+        L.kasa_index_device_bytes.restype = C.c_uint64
+        L.kasa_index_size.argtypes = [C.c_void_p]
+        L.kasa_index_device_bytes.argtypes = [C.c_void_p]
+        L.kasa_index_destroy.argtypes = [C.c_void_p]
+        L.kasa_index_destroy.restype = None
+        L.kasa_ctx_destroy.argtypes = [C.c_void_p]
+        L.kasa_ctx_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise RuntimeError(lib().kasa_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().kasa_device_count(C.byref(n))
+    return n.value
+
+
+class DeviceIndex:
+    """HBM-resident index (immutable, shareable between contexts)."""
+
+    def __init__(self, ix, device: int = 0, check_trie: bool = True):
+        from .formats import REC_DTYPE
+        rec = np.zeros(ix.n, dtype=REC_DTYPE)
+        rec["kmer"], rec["tax"] = ix.kmer, ix.taxid
+        tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32) if check_trie else None
+        tc = np.ascontiguousarray(ix.trie_count, dtype=np.uint64) if check_trie else None
+        ids = np.ascontiguousarray(ix.content.taxids, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().kasa_index_create(C.c_int(device), _p(rec), C.c_uint64(ix.n), C.c_int(12), _p(tp), _p(tc),
+                                       C.c_uint64(0 if tp is None else tp.shape[0]), _p(ids),
+                                       C.c_uint32(ids.shape[0]), C.byref(h)))
+        self.h = h
+        self.n_taxa = int(ids.shape[0])
+        self.n = ix.n
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib().kasa_index_device_bytes(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kasa_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One identify context: stream, batch buffers, profile tables (single-threaded)."""
+
+    def __init__(self, dix: DeviceIndex, k_high=12, k_low=7, frames=3, codon_lut=None):
+        self.dix = dix
+        self.k_high, self.k_low = max(k_high, k_low), min(k_high, k_low)
+        self.nK = self.k_high - self.k_low + 1
+        self.n_reads = 0
+        self.n_kmers = 0
+        h = C.c_void_p()
+        lut = np.ascontiguousarray(codon_lut, dtype=np.uint8) if codon_lut is not None else None
+        _check(lib().kasa_ctx_create(dix.h, C.c_int(k_high), C.c_int(k_low), C.c_int(frames), _p(lut), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().kasa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- batch ----
+    def upload(self, bases: np.ndarray, offsets: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n_reads = int(offsets.shape[0] - 1)
+        _check(lib().kasa_batch_upload(self.h, _p(bases), _p(offsets), C.c_int64(self.n_reads)))
+
+    def encode(self) -> int:
+        n = C.c_uint64(0)
+        _check(lib().kasa_batch_encode(self.h, C.byref(n)))
+        self.n_kmers = int(n.value)
+        return self.n_kmers
+
+    def sort_and_range(self, unique: bool = False):
+        _check(lib().kasa_batch_sort_and_range(self.h, C.c_int(int(unique))))
+
+    def lookup_score(self, want_per_read: bool = True, coverage: bool = False):
+        _check(lib().kasa_batch_lookup_score(self.h, C.c_int(int(want_per_read)), C.c_int(int(coverage))))
+
+    def scores(self):
+        """CSR (offsets u64[nReads+1], taxIdx u32[nnz], score f32[nnz])."""
+        nnz = C.c_uint64(0)
+        _check(lib().kasa_batch_scores_size(self.h, C.byref(nnz)))
+        off = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        tax = np.zeros(nnz.value, dtype=np.uint32)
+        sc = np.zeros(nnz.value, dtype=np.float32)
+        _check(lib().kasa_batch_scores_fetch(self.h, _p(off), _p(tax), _p(sc)))
+        return off, tax, sc
+
+    def run_batch(self, bases, offsets, want_per_read=True, coverage=False):
+        self.upload(bases, offsets)
+        self.encode()
+        self.sort_and_range()
+        self.lookup_score(want_per_read, coverage)
+
+    # ---- profile ----
+    def profile_reset(self):
+        _check(lib().kasa_profile_reset(self.h))
+
+    def profile(self):
+        shape = (self.nK, self.dix.n_taxa)
+        ca = np.zeros(shape, dtype=np.float64)
+        cu = np.zeros(shape, dtype=np.uint64)
+        ct = np.zeros(shape, dtype=np.uint64)
+        _check(lib().kasa_profile_fetch(self.h, _p(ca), _p(cu), _p(ct)))
+        return ca, cu, ct
+
+    def profile_limbs(self) -> np.ndarray:
+        out = np.zeros((self.nK * self.dix.n_taxa, 6), dtype=np.uint64)
+        _check(lib().kasa_profile_export_limbs(self.h, _p(out)))
+        return out
+
+    def profile_set_limbs(self, limbs: np.ndarray):
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        _check(lib().kasa_profile_import_limbs(self.h, _p(limbs)))
+
+    # ---- measurement / taps ----
+    def stage_ms(self):
+        out = {}
+        for i, name in enumerate(STAGES):
+            ms, n = C.c_double(0), C.c_uint64(0)
+            _check(lib().kasa_ctx_stage_ms(self.h, C.c_int(i), C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, int(n.value))
+        return out
+
+    def stage_reset(self):
+        _check(lib().kasa_ctx_stage_reset(self.h))
+
+    def lookup_kernel_ms(self):
+        ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
+        return ms.value, int(n.value), int(q.value)
+
+    def queries(self):
+        km = np.zeros(self.n_kmers, dtype=np.uint64)
+        rd = np.zeros(self.n_kmers, dtype=np.uint32)
+        _check(lib().kasa_batch_fetch_queries(self.h, _p(km), _p(rd), C.c_uint64(self.n_kmers)))
+        return km, rd
+
+    def set_queries(self, kmers: np.ndarray, reads: np.ndarray, n_reads: int):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        reads = np.ascontiguousarray(reads, dtype=np.uint32)
+        _check(lib().kasa_batch_set_queries(self.h, _p(kmers), _p(reads), C.c_uint64(kmers.shape[0]), C.c_int64(n_reads)))
+        self.n_reads, self.n_kmers = int(n_reads), int(kmers.shape[0])
+
+    def lookup(self):
+        d = np.zeros(self.n_kmers, dtype=np.uint8)
+        pos = np.zeros(self.n_kmers, dtype=np.uint32)
+        _check(lib().kasa_batch_fetch_lookup(self.h, _p(d), _p(pos), C.c_uint64(self.n_kmers)))
+        return d, pos
+
+    def device_bytes(self) -> int:
+        b = C.c_uint64(0)
+        _check(lib().kasa_ctx_device_bytes(self.h, C.byref(b)))
+        return int(b.value)
+
+    def synchronize(self):
+        _check(lib().kasa_ctx_synchronize(self.h))

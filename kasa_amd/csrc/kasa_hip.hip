@@ -1,0 +1,1418 @@
+// kasa_hip.hip -- MI355X (gfx950 / CDNA4) implementation of kASA's `identify` hot path behind the C ABI
+// of include/kasa_hip.h.  Written for 64-wide wavefronts and HBM-bound integer work: no MFMA (there is
+// no contraction anywhere on this path), coalesced streaming of the sorted query and index arrays,
+// LDS for the per-tile scans, everything resident in HBM between stages.
+//
+// Pipeline of one batch (reference lines in include/kasa_hip.h and DESIGN.md):
+//   encode  : reads -> packed 5-bit-letter k-mers (+ read id)                       [encode_kernel]
+//   sort    : LSD radix sort of (k-mer, read) on the 5*K key bits                    [rocPRIM onesweep]
+//   lookup  : two-level prefix table + binary search in the HBM-resident index      [lookup_kernel]
+//   group   : per k level: query groups, taxon sets of the index groups, flush order [group_kernel]
+//   regroup : stable sort of sorted positions by read id                            [rocPRIM]
+//   score   : per read, events replayed in the reference's flush order (float32)    [score_kernel]
+//
+// The semantics implemented are the closed form of SURVEY.md section 0.1; tests compare every stage with
+// the CPU oracle (oracle/), which is itself pinned to the reference binary's outputs.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/kasa_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// constants
+// ------------------------------------------------------------------------------------------------
+static constexpr int KLETTERS = 12;               // letters per packed k-mer (64-bit index)
+static constexpr int KEYBITS = 5 * KLETTERS;      // 60
+static constexpr int KEYSHIFT = 64 - KEYBITS;     // 4
+static constexpr int RANGE_LETTERS = 6;           // depth of the reference's prefix trie (Trie.hpp)
+static constexpr int MAX_LEVELS = 12;
+static constexpr int TILE = 1024;                 // sorted queries per workgroup in lookup/group
+static constexpr int TILE_THREADS = 256;
+static constexpr int ITEMS = TILE / TILE_THREADS; // 4
+static constexpr uint32_t NOPOS = 0xFFFFFFFFu;
+static constexpr int PCAP = 1024;                 // pending (not yet flushed) groups per read
+static constexpr uint32_t REF_SINGLE = 0x80000000u;
+static constexpr int TLIST = 256;                // touched taxa of a read kept as a list (else dense scan)
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? KASA_E_NOMEM : KASA_E_HIP, "%s failed: %s",    \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+
+extern "C" const char *kasa_last_error(void) { return g_err.c_str(); }
+
+extern "C" int kasa_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    if (count) *count = n;
+    return KASA_OK;
+}
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return KASA_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 16 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            return fail(KASA_E_NOMEM, "device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return KASA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lcp_letters(uint64_t a, uint64_t b)
+{
+    const uint64_t x = (a ^ b) << KEYSHIFT;
+    return x ? (__clzll(x) / 5) : KLETTERS;
+}
+
+__device__ __forceinline__ int group_letters(int k) { return k < RANGE_LETTERS ? RANGE_LETTERS : k; }
+
+// ------------------------------------------------------------------------------------------------
+// index
+// ------------------------------------------------------------------------------------------------
+struct kasa_index {
+    int device = 0;
+    uint64_t n = 0;
+    uint32_t nTaxa = 0;
+    DevBuf kmer;   // u64[n]
+    DevBuf tax;    // u32[n] dense taxon index
+    DevBuf meta;   // u8[n]: low nibble = letters shared with the previous entry, high nibble = letters
+                   //        shared with the nearest earlier entry of the same taxon
+    DevBuf table;  // u32[2^tb]: number of entries whose top `tb` key bits are <= b
+    int tb = 0;
+    uint64_t bytes() const { return kmer.cap + tax.cap + meta.cap + table.cap; }
+};
+
+__global__ void unpack_records_kernel(const uint8_t *__restrict__ rec, uint64_t n, uint64_t *__restrict__ kmer,
+                                      uint32_t *__restrict__ taxid)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(rec + i * 12); // 12-byte records are 4-aligned
+    kmer[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    taxid[i] = w[2];
+}
+
+__global__ void dense_tax_kernel(uint32_t *__restrict__ tax, uint64_t n, const uint32_t *__restrict__ sortedIds,
+                                 const uint32_t *__restrict__ denseOf, uint32_t nTaxa, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = tax[i];
+    uint32_t lo = 0, hi = nTaxa;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sortedIds[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (lo < nTaxa && sortedIds[lo] == id) tax[i] = denseOf[lo];
+    else { tax[i] = 0; atomicAdd(bad, 1u); }
+}
+
+__global__ void index_check_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ taxid, uint64_t n,
+                                   uint32_t *__restrict__ bad)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    const uint64_t a = kmer[i - 1], b = kmer[i];
+    if (a > b || (a == b && taxid[i - 1] >= taxid[i]) || (b >> KEYBITS)) atomicAdd(bad, 1u);
+}
+
+__global__ void lcp_prev_kernel(const uint64_t *__restrict__ kmer, uint64_t n, uint8_t *__restrict__ meta)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    meta[i] = (i == 0) ? 0 : (uint8_t)lcp_letters(kmer[i - 1], kmer[i]);
+}
+
+// after a stable sort of positions by taxon: consecutive positions of one taxon are index neighbours
+// of that taxon, so the letters they share is exactly "how deep the earlier one shadows the later one"
+__global__ void dup_level_kernel(const uint32_t *__restrict__ taxSorted, const uint32_t *__restrict__ order,
+                                 const uint64_t *__restrict__ kmer, uint64_t n, uint8_t *__restrict__ meta)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t d = 0;
+    if (i > 0 && taxSorted[i] == taxSorted[i - 1]) d = (uint8_t)lcp_letters(kmer[order[i - 1]], kmer[order[i]]);
+    const uint32_t pos = order[i];
+    meta[pos] = (uint8_t)((meta[pos] & 15) | (d << 4));
+}
+
+__global__ void table_mark_kernel(const uint64_t *__restrict__ kmer, uint64_t n, int shift, uint32_t *__restrict__ table)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t b = kmer[i] >> shift;
+    if (i + 1 == n || (kmer[i + 1] >> shift) != b) table[b] = (uint32_t)(i + 1);
+}
+
+__global__ void trie_check_kernel(const uint32_t *__restrict__ prefix, const uint64_t *__restrict__ start,
+                                  const uint64_t *__restrict__ count, uint64_t nTrie, const uint64_t *__restrict__ kmer,
+                                  uint64_t n, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i >= nTrie) return;
+    const uint64_t s = start[i], c = count[i];
+    const int sh = 5 * (KLETTERS - RANGE_LETTERS);
+    bool ok = c > 0 && s + c <= n;
+    if (ok) ok = (kmer[s] >> sh) == prefix[i] && (kmer[s + c - 1] >> sh) == prefix[i];
+    if (ok && s > 0) ok = (kmer[s - 1] >> sh) < prefix[i];
+    if (ok && s + c < n) ok = (kmer[s + c] >> sh) > prefix[i];
+    if (!ok) atomicAdd(bad, 1u);
+}
+
+static inline unsigned blocks_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+extern "C" int kasa_index_create(int device, const void *records, uint64_t nRecords, int recordBytes,
+                                 const uint32_t *triePrefix, const uint64_t *trieCount, uint64_t nTrie,
+                                 const uint32_t *taxIds, uint32_t nTaxa, kasa_index **out)
+{
+    if (!out) return fail(KASA_E_ARG, "kasa_index_create: out is NULL");
+    *out = nullptr;
+    if (recordBytes != 12)
+        return fail(KASA_E_ARG, "kasa_index_create: only 12-byte {u64 kmer,u32 taxid} records (k<=12 index) are supported, got %d", recordBytes);
+    if (!records && nRecords) return fail(KASA_E_ARG, "kasa_index_create: records is NULL");
+    if (nRecords == 0) return fail(KASA_E_ARG, "The index file cannot be found or is empty!");
+    if (nRecords >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_index_create: %llu records exceed the 32-bit position range of this build", (unsigned long long)nRecords);
+    if (!taxIds || nTaxa < 2) return fail(KASA_E_ARG, "kasa_index_create: content mapping missing");
+    int ndev = 0;
+    kasa_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(KASA_E_HIP, "kasa_index_create: no HIP device %d (found %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+
+    kasa_index *ix = new (std::nothrow) kasa_index();
+    if (!ix) return fail(KASA_E_NOMEM, "host allocation failed");
+    ix->device = device; ix->n = nRecords; ix->nTaxa = nTaxa;
+    int rc = KASA_OK;
+    DevBuf raw, ids, dense, bad, order, taxSorted, iota, tmp, tpre, tstart, tcount;
+    auto cleanup = [&](int code) {
+        raw.release(); ids.release(); dense.release(); bad.release(); order.release(); taxSorted.release();
+        iota.release(); tmp.release(); tpre.release(); tstart.release(); tcount.release();
+        if (code != KASA_OK) { ix->kmer.release(); ix->tax.release(); ix->meta.release(); ix->table.release(); delete ix; }
+        return code;
+    };
+#define TRY(x) do { rc = (x); if (rc != KASA_OK) return cleanup(rc); } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cleanup(fail(e_ == hipErrorOutOfMemory ? KASA_E_NOMEM : KASA_E_HIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
+    const uint64_t n = nRecords;
+    TRY(raw.reserve(n * 12));
+    TRY(ix->kmer.reserve(n * 8));
+    TRY(ix->tax.reserve(n * 4));
+    TRY(ix->meta.reserve(n));
+    TRY(bad.reserve(16));
+    TRYHIP(hipMemcpy(raw.p, records, n * 12, hipMemcpyHostToDevice));
+    TRYHIP(hipMemset(bad.p, 0, 16));
+    unpack_records_kernel<<<blocks_for(n, 256), 256>>>(raw.as<uint8_t>(), n, ix->kmer.as<uint64_t>(), ix->tax.as<uint32_t>());
+    index_check_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), ix->tax.as<uint32_t>(), n, bad.as<uint32_t>());
+    raw.release();
+    // taxid -> dense index (Compare.hpp:139-143)
+    {
+        std::vector<uint32_t> perm(nTaxa), sid(nTaxa), did(nTaxa);
+        for (uint32_t i = 0; i < nTaxa; ++i) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return taxIds[a] < taxIds[b]; });
+        for (uint32_t i = 0; i < nTaxa; ++i) { sid[i] = taxIds[perm[i]]; did[i] = perm[i]; }
+        TRY(ids.reserve(nTaxa * 4));
+        TRY(dense.reserve(nTaxa * 4));
+        TRYHIP(hipMemcpy(ids.p, sid.data(), nTaxa * 4, hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(dense.p, did.data(), nTaxa * 4, hipMemcpyHostToDevice));
+        dense_tax_kernel<<<blocks_for(n, 256), 256>>>(ix->tax.as<uint32_t>(), n, ids.as<uint32_t>(), dense.as<uint32_t>(), nTaxa, bad.as<uint32_t>() + 1);
+    }
+    uint32_t hbad[4] = {0, 0, 0, 0};
+    TRYHIP(hipMemcpy(hbad, bad.p, 16, hipMemcpyDeviceToHost));
+    if (hbad[0]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the index is not sorted by (kmer, taxid), not unique, or uses more than %d key bits (%u violations)", KEYBITS, hbad[0]));
+    if (hbad[1]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: %u index entries carry a tax ID the content file does not know", hbad[1]));
+
+    // meta: shared letters with the previous entry and with the previous entry of the same taxon
+    lcp_prev_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), n, ix->meta.as<uint8_t>());
+    {
+        TRY(order.reserve(n * 4));
+        TRY(taxSorted.reserve(n * 4));
+        size_t tmpBytes = 0;
+        unsigned bits = 1;
+        while ((1ull << bits) < nTaxa) ++bits;
+        rocprim::counting_iterator<uint32_t> cnt(0);
+        TRYHIP(rocprim::radix_sort_pairs(nullptr, tmpBytes, ix->tax.as<uint32_t>(), taxSorted.as<uint32_t>(), cnt,
+                                         order.as<uint32_t>(), (size_t)n, 0u, bits, (hipStream_t)0));
+        TRY(tmp.reserve(tmpBytes));
+        TRYHIP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, ix->tax.as<uint32_t>(), taxSorted.as<uint32_t>(), cnt,
+                                         order.as<uint32_t>(), (size_t)n, 0u, bits, (hipStream_t)0));
+        dup_level_kernel<<<blocks_for(n, 256), 256>>>(taxSorted.as<uint32_t>(), order.as<uint32_t>(), ix->kmer.as<uint64_t>(), n, ix->meta.as<uint8_t>());
+        TRYHIP(hipDeviceSynchronize());
+        order.release(); taxSorted.release();
+    }
+    // two-level prefix table: level 1 = top `tb` key bits -> entry range, level 2 = binary search
+    {
+        int tb = 8;
+        while (tb < 28 && (1ull << (tb + 1)) <= n) ++tb;
+        ix->tb = tb;
+        const uint64_t nb = 1ull << tb;
+        TRY(ix->table.reserve(nb * 4));
+        TRYHIP(hipMemset(ix->table.p, 0, nb * 4));
+        table_mark_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), n, KEYBITS - tb, ix->table.as<uint32_t>());
+        size_t tmpBytes = 0;
+        TRYHIP(rocprim::inclusive_scan(nullptr, tmpBytes, ix->table.as<uint32_t>(), ix->table.as<uint32_t>(), (size_t)nb, rocprim::maximum<uint32_t>(), (hipStream_t)0));
+        TRY(tmp.reserve(tmpBytes));
+        TRYHIP(rocprim::inclusive_scan(tmp.p, tmpBytes, ix->table.as<uint32_t>(), ix->table.as<uint32_t>(), (size_t)nb, rocprim::maximum<uint32_t>(), (hipStream_t)0));
+    }
+    // the reference's `_trie` file, when given, must describe the same ranges (Trie.hpp:398-462)
+    if (triePrefix && trieCount && nTrie) {
+        std::vector<uint64_t> start(nTrie);
+        uint64_t run = 0;
+        for (uint64_t i = 0; i < nTrie; ++i) { start[i] = run; run += trieCount[i]; }
+        if (run != n) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the trie file counts %llu entries, the index has %llu", (unsigned long long)run, (unsigned long long)n));
+        TRY(tpre.reserve(nTrie * 4)); TRY(tstart.reserve(nTrie * 8)); TRY(tcount.reserve(nTrie * 8));
+        TRYHIP(hipMemcpy(tpre.p, triePrefix, nTrie * 4, hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(tstart.p, start.data(), nTrie * 8, hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(tcount.p, trieCount, nTrie * 8, hipMemcpyHostToDevice));
+        TRYHIP(hipMemset(bad.p, 0, 16));
+        trie_check_kernel<<<blocks_for(nTrie, 256), 256>>>(tpre.as<uint32_t>(), tstart.as<uint64_t>(), tcount.as<uint64_t>(), nTrie, ix->kmer.as<uint64_t>(), n, bad.as<uint32_t>());
+        TRYHIP(hipMemcpy(hbad, bad.p, 16, hipMemcpyDeviceToHost));
+        if (hbad[0]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the trie file does not match the index (%u ranges differ)", hbad[0]));
+    }
+    TRYHIP(hipDeviceSynchronize());
+    TRYHIP(hipGetLastError());
+#undef TRY
+#undef TRYHIP
+    cleanup(KASA_OK);
+    *out = ix;
+    return KASA_OK;
+}
+
+extern "C" void kasa_index_destroy(kasa_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    ix->kmer.release(); ix->tax.release(); ix->meta.release(); ix->table.release();
+    delete ix;
+}
+
+extern "C" uint64_t kasa_index_size(const kasa_index *ix) { return ix ? ix->n : 0; }
+extern "C" uint64_t kasa_index_device_bytes(const kasa_index *ix) { return ix ? ix->bytes() : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct StageTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> open;
+    std::vector<hipEvent_t> pool;
+    double ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct kasa_ctx {
+    const kasa_index *ix = nullptr;
+    int kHigh = 12, kLow = 7, nK = 6, frames = 3;
+    hipStream_t stream = nullptr;
+    // batch state
+    int64_t nReads = 0;
+    uint64_t nBases = 0;
+    uint64_t nQ = 0;
+    uint32_t maxCnt = 0;
+    int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
+    bool haveScores = false;
+    // buffers
+    DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nReads+1], u64[nReads+1]
+    DevBuf qKmerA, qKmerB, qReadA, qReadB;     // double buffers of the query arrays
+    DevBuf depth, rep;                         // u8[nQ], u32[nQ]
+    DevBuf tileFirst, tileNext;                // u32[nK][nTiles]
+    DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
+    DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
+    DevBuf scratch, touched;                   // per-block dense score rows + touched lists
+    DevBuf rowPos, rowLen, rowOff, stTax, stScore, outTax, outScore;
+    DevBuf cntUnique, cntTotal, cntAllHi, cntAllLo; // u64[nK*nTaxa] each
+    uint64_t poolCap = 0, stCap = 0, nnz = 0;
+    uint64_t *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays
+    StageTimer timers[KASA_STAGE_COUNT];
+    StageTimer lookupKernel;
+    uint64_t lookupQueries = 0;
+    std::vector<int64_t> hostOff;
+};
+
+static int timer_begin(kasa_ctx *c, StageTimer &t, hipEvent_t *a, hipEvent_t *b)
+{
+    auto get = [&](hipEvent_t *e) -> int {
+        if (!t.pool.empty()) { *e = t.pool.back(); t.pool.pop_back(); return KASA_OK; }
+        HIPCHK(hipEventCreate(e));
+        return KASA_OK;
+    };
+    int rc = get(a); if (rc) return rc;
+    rc = get(b); if (rc) return rc;
+    HIPCHK(hipEventRecord(*a, c->stream));
+    return KASA_OK;
+}
+
+static int timer_end(kasa_ctx *c, StageTimer &t, hipEvent_t a, hipEvent_t b)
+{
+    HIPCHK(hipEventRecord(b, c->stream));
+    t.open.emplace_back(a, b);
+    t.launches++;
+    return KASA_OK;
+}
+
+static int timer_resolve(StageTimer &t)
+{
+    for (auto &pr : t.open) {
+        HIPCHK(hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        t.ms += ms;
+        t.pool.push_back(pr.first);
+        t.pool.push_back(pr.second);
+    }
+    t.open.clear();
+    return KASA_OK;
+}
+
+static void builtin_codon_table(uint8_t lut[366])
+{
+    // kASA.hpp:621-667: standard code, stops TAA/TAG -> '[', TGA -> ']', any Z -> '_', else any X -> '^';
+    // index = b0*64 + b1*8 + b2 with b = (c & 14) >> 1 (A,C,T,G,X,Z = 0..5), value = letter & 31
+    static const char aaTCAG[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    static const int tcag[4] = {2, 1, 0, 3};
+    memset(lut, 0, 366);
+    for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b)
+            for (int c = 0; c < 6; ++c) {
+                char aa;
+                if (a == 5 || b == 5 || c == 5) aa = '_';
+                else if (a == 4 || b == 4 || c == 4) aa = '^';
+                else {
+                    const int i = tcag[a] * 16 + tcag[b] * 4 + tcag[c];
+                    aa = aaTCAG[i];
+                    if (aa == '*') aa = (i == 14) ? ']' : '[';
+                }
+                lut[a * 64 + b * 8 + c] = (uint8_t)(aa & 31);
+            }
+}
+
+extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int frames, const uint8_t *codonLut, kasa_ctx **out)
+{
+    if (!out) return fail(KASA_E_ARG, "kasa_ctx_create: out is NULL");
+    *out = nullptr;
+    if (!ix) return fail(KASA_E_ARG, "kasa_ctx_create: index is NULL");
+    if (kHigh < kLow) std::swap(kHigh, kLow); // "-k <lower> <upper> is okay too" (README)
+    if (kLow < 1 || kHigh > KLETTERS) return fail(KASA_E_ARG, "kasa_ctx_create: k range [%d,%d] outside [1,%d]", kLow, kHigh, KLETTERS);
+    if (frames != 3 && frames != 6) return fail(KASA_E_ARG, "kasa_ctx_create: frames must be 3 or 6 (--one is not on this path yet)");
+    HIPCHK(hipSetDevice(ix->device));
+    kasa_ctx *c = new (std::nothrow) kasa_ctx();
+    if (!c) return fail(KASA_E_NOMEM, "host allocation failed");
+    c->ix = ix; c->kHigh = kHigh; c->kLow = kLow; c->nK = kHigh - kLow + 1; c->frames = frames;
+    auto bail = [&](int code) { kasa_ctx_destroy(c); return code; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
+    uint8_t lut[366];
+    if (codonLut) memcpy(lut, codonLut, 366); else builtin_codon_table(lut);
+    int rc = c->lut.reserve(512); if (rc) return bail(rc);
+    if (hipMemcpy(c->lut.p, lut, 366, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(KASA_E_HIP, "LUT upload failed"));
+    const size_t cells = (size_t)c->nK * ix->nTaxa * 8;
+    if ((rc = c->cntUnique.reserve(cells)) || (rc = c->cntTotal.reserve(cells)) || (rc = c->cntAllHi.reserve(cells)) ||
+        (rc = c->cntAllLo.reserve(cells)) || (rc = c->misc.reserve(256)))
+        return bail(rc);
+    *out = c;
+    rc = kasa_profile_reset(c);
+    if (rc) { *out = nullptr; return bail(rc); }
+    return KASA_OK;
+}
+
+extern "C" void kasa_ctx_destroy(kasa_ctx *c)
+{
+    if (!c) return;
+    if (c->ix) (void)hipSetDevice(c->ix->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
+                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                     &c->misc, &c->scratch, &c->touched, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                     &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
+    for (DevBuf *b : all) b->release();
+    auto drop = [](StageTimer &t) {
+        for (auto &pr : t.open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        for (auto e : t.pool) (void)hipEventDestroy(e);
+    };
+    for (auto &t : c->timers) drop(t);
+    drop(c->lookupKernel);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int kasa_profile_reset(kasa_ctx *c)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const size_t cells = (size_t)c->nK * c->ix->nTaxa * 8;
+    HIPCHK(hipMemsetAsync(c->cntUnique.p, 0, cells, c->stream));
+    HIPCHK(hipMemsetAsync(c->cntTotal.p, 0, cells, c->stream));
+    HIPCHK(hipMemsetAsync(c->cntAllHi.p, 0, cells, c->stream));
+    HIPCHK(hipMemsetAsync(c->cntAllLo.p, 0, cells, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// upload + encode
+// ------------------------------------------------------------------------------------------------
+static inline int64_t host_padded_len(int64_t raw, int K, int kLow)
+{
+    // Read.hpp:633-654 + 1068-1078: pad with X up to 3K (marker included), then the marker X * 3(K-kLow)
+    const int64_t m = 3 * (int64_t)(K - kLow);
+    int64_t len = raw;
+    if (len > 0 && len + m < 3 * (int64_t)K) len = 3 * (int64_t)K - m;
+    return len + m;
+}
+
+static inline int64_t host_kmer_count(int64_t L, int K)
+{
+    return (L > 3 * (int64_t)K + 1) ? L - 3 * (int64_t)K + 1 : 0; // Read.hpp:36-57
+}
+
+extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (nReads < 0 || (nReads > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
+    if ((uint64_t)nReads >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    c->state = 0; c->haveScores = false; c->nReads = nReads; c->nQ = 0;
+    const uint64_t nBases = nReads ? (uint64_t)(offsets[nReads] - offsets[0]) : 0;
+    std::vector<uint64_t> koff((size_t)nReads + 1);
+    c->hostOff.assign((size_t)nReads + 1, 0);
+    uint64_t run = 0;
+    uint32_t maxCnt = 0;
+    const int strands = (c->frames == 6) ? 2 : 1;
+    for (int64_t r = 0; r < nReads; ++r) {
+        const int64_t raw = offsets[r + 1] - offsets[r];
+        if (raw < 0) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
+        c->hostOff[(size_t)r] = offsets[r] - offsets[0];
+        koff[(size_t)r] = run;
+        const uint64_t cnt = raw > 0 ? (uint64_t)host_kmer_count(host_padded_len(raw, KLETTERS, c->kLow), KLETTERS) * strands : 0;
+        run += cnt;
+        if (cnt > maxCnt) maxCnt = (uint32_t)std::min<uint64_t>(cnt, 0xFFFFFFFFull);
+    }
+    koff[(size_t)nReads] = run;
+    c->hostOff[(size_t)nReads] = (int64_t)nBases;
+    if (run >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: %llu k-mers exceed the 32-bit position range of one batch; split the batch", (unsigned long long)run);
+    c->nQ = run; c->nBases = nBases; c->maxCnt = maxCnt;
+    int rc;
+    if ((rc = c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nReads + 1) * 8)) ||
+        (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)))
+        return rc;
+    if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->baseOff.p, c->hostOff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->kmerOff.p, koff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->state = 1;
+    return KASA_OK;
+}
+
+// One wavefront per read.  The cleaned bases of a window chunk are staged in LDS as 3-bit codes, the
+// codon letters are computed once per start position, each lane then packs K letters at stride 3.
+static constexpr int ENC_CHUNK = 512;                       // windows per chunk
+static constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;   // bases needed for one chunk (+ slack)
+static constexpr int ENC_WAVES = 4;
+
+__global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
+    const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
+    int64_t nReads, int kLow, int strands, const uint8_t *__restrict__ lutG, uint64_t *__restrict__ outKmer,
+    uint32_t *__restrict__ outRead)
+{
+    __shared__ uint8_t sLut[384];
+    __shared__ uint8_t sCode[ENC_WAVES][ENC_SPAN + 8];
+    __shared__ uint8_t sLetter[ENC_WAVES][ENC_SPAN + 8];
+    for (int i = threadIdx.x; i < 366; i += blockDim.x) sLut[i] = lutG[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t wavesTotal = (int64_t)gridDim.x * ENC_WAVES;
+    const int64_t marker = 3 * (int64_t)(KLETTERS - kLow);
+    for (int64_t r = (int64_t)blockIdx.x * ENC_WAVES + wv; r < nReads; r += wavesTotal) {
+        const int64_t b0 = baseOff[r];
+        const int64_t raw = baseOff[r + 1] - b0;
+        if (raw <= 0) continue;
+        int64_t body = raw;                                  // padded read without the marker
+        if (body + marker < 3 * (int64_t)KLETTERS) body = 3 * (int64_t)KLETTERS - marker;
+        const int64_t L = body + marker;
+        const int64_t cnt = (L > 3 * (int64_t)KLETTERS + 1) ? L - 3 * (int64_t)KLETTERS + 1 : 0;
+        if (cnt == 0) continue;
+        const uint64_t o0 = kmerOff[r];
+        for (int s = 0; s < strands; ++s) {
+            for (int64_t w0 = 0; w0 < cnt; w0 += ENC_CHUNK) {
+                const int nw = (int)((cnt - w0 < ENC_CHUNK) ? cnt - w0 : ENC_CHUNK);
+                const int span = nw + 3 * KLETTERS - 1;     // bases w0 .. w0+span-1
+                for (int i = lane; i < span; i += 64) {
+                    const int64_t pos = w0 + i;
+                    uint8_t code;
+                    if (pos >= body) code = 4;               // X: padding and marker
+                    else {
+                        const int64_t src = (s == 0) ? pos : (body - 1 - pos);
+                        if (src >= raw) code = 4;            // padding X (reverse strand sees it first)
+                        else {
+                            const uint8_t ch = bases[b0 + src];
+                            const uint8_t up = ch & 0xDF;
+                            const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+                            code = ok ? (uint8_t)((ch & 14) >> 1) : (uint8_t)5;  // everything else is Z
+                            if (s == 1 && code < 4) code ^= 2;                   // A<->T, C<->G
+                        }
+                    }
+                    sCode[wv][i] = code;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS writes of this wave are done
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < span - 2; i += 64)
+                    sLetter[wv][i] = sLut[sCode[wv][i] * 64 + sCode[wv][i + 1] * 8 + sCode[wv][i + 2]];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < nw; i += 64) {
+                    uint64_t v = 0;
+#pragma unroll
+                    for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | sLetter[wv][i + 3 * j];
+                    const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
+                    outKmer[o] = v;
+                    outRead[o] = (uint32_t)r;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 1) return fail(KASA_E_STATE, "kasa_batch_encode: no batch uploaded");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc;
+    const uint64_t nQ = c->nQ;
+    if ((rc = c->qKmerA.reserve(nQ * 8 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
+    hipEvent_t a, b;
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_ENCODE], &a, &b))) return rc;
+    if (c->nReads > 0 && nQ > 0) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((c->nReads + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
+        encode_kernel<<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+            c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->frames == 6 ? 2 : 1, c->lut.as<uint8_t>(),
+            c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_ENCODE], a, b))) return rc;
+    c->qKmer = c->qKmerA.as<uint64_t>();
+    c->qRead = c->qReadA.as<uint32_t>();
+    c->state = 2;
+    if (nKmers) *nKmers = nQ;
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sort + lookup
+// ------------------------------------------------------------------------------------------------
+// One query per thread, TILE queries per workgroup (the same tiling as group_kernel).  Level 1 of the
+// prefix table narrows the search to the entries sharing the top `tb` key bits, a binary search
+// finishes it.  Consecutive threads hold consecutive sorted queries, so table and index reads of a
+// wavefront fall into a few cache lines.  Also emits, per tile and level, the first position that
+// closes a group ("special"), the seed of the flush-order computation.
+__global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
+    const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer, uint32_t nIdx,
+    const uint32_t *__restrict__ table, int tb, int kHigh, int kLow, uint8_t *__restrict__ depth,
+    uint32_t *__restrict__ rep, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
+{
+    __shared__ uint32_t sFirst[MAX_LEVELS];
+    const int nK = kHigh - kLow + 1;
+    if (threadIdx.x < MAX_LEVELS) sFirst[threadIdx.x] = NOPOS;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * TILE;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t p = base + it * TILE_THREADS + threadIdx.x;   // striped: coalesced loads
+        if (p >= nQ) continue;
+        const uint64_t q = qKmer[p];
+        const uint64_t bkt = q >> (KEYBITS - tb);
+        uint32_t lo = bkt ? table[bkt - 1] : 0u;
+        uint32_t hi = table[bkt];
+        while (lo < hi) {                                           // first entry >= q
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (idxKmer[mid] < q) lo = mid + 1; else hi = mid;
+        }
+        const int la = (lo < nIdx) ? lcp_letters(q, idxKmer[lo]) : 0;
+        const int lb = (lo > 0) ? lcp_letters(q, idxKmer[lo - 1]) : 0;
+        int L = la >= lb ? la : lb;
+        const uint32_t r = la >= lb ? lo : lo - 1;
+        int d = 0;
+        if (L >= RANGE_LETTERS) {                                   // the 6-letter prefix exists (Trie.hpp:494)
+            if (L > kHigh) L = kHigh;
+            d = L;
+            for (int k = kLow; k <= L; ++k)                         // '^' ends the query (Compare.hpp:836,897)
+                if (((q >> (5 * (KLETTERS - k))) & 31) == 30) { d = k - 1; break; }
+            if (d < kLow) d = 0;
+        }
+        depth[p] = (uint8_t)d;
+        rep[p] = r;
+        const int ql = (p == 0) ? 0 : lcp_letters(qKmer[p - 1], q);
+        for (int lv = 0; lv < nK; ++lv) {
+            const int k = kHigh - lv;
+            const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
+            if (special) atomicMin(&sFirst[lv], p);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
+}
+
+// tileNext[lv][t] = first special position in any tile after t (or nQ)
+__global__ void tile_suffix_kernel(const uint32_t *__restrict__ tileFirst, uint32_t *__restrict__ tileNext,
+                                   uint32_t nTiles, uint32_t nQ)
+{
+    __shared__ uint32_t sh[1024];
+    const int lv = blockIdx.x;
+    const uint32_t *in = tileFirst + (size_t)lv * nTiles;
+    uint32_t *out = tileNext + (size_t)lv * nTiles;
+    uint32_t carry = nQ;
+    for (int64_t hiT = (int64_t)nTiles; hiT > 0; hiT -= 1024) {
+        const int64_t t = hiT - 1 - threadIdx.x;                    // thread 0 takes the last tile of the chunk
+        uint32_t v = (t >= 0) ? in[t] : NOPOS;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive min-scan in reversed order
+            uint32_t o = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : NOPOS;
+            __syncthreads();
+            if (o < sh[threadIdx.x]) sh[threadIdx.x] = o;
+            __syncthreads();
+        }
+        const uint32_t excl = (threadIdx.x == 0) ? NOPOS : sh[threadIdx.x - 1];
+        if (t >= 0) out[t] = excl < carry ? excl : carry;
+        const uint32_t all = sh[1023];
+        __syncthreads();
+        if (all < carry) carry = all;
+    }
+}
+
+extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_sort_and_range: batch not encoded");
+    if (unique) return fail(KASA_E_ARG, "-e/--unique is not on this path yet (the reference calls it BETA; its result depends on an unstable sort)");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint64_t nQ = c->nQ;
+    int rc;
+    if ((rc = c->qKmerB.reserve(nQ * 8 + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) ||
+        (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)))
+        return rc;
+    const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
+    if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4))) return rc;
+    hipEvent_t a, b;
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_SORT], &a, &b))) return rc;
+    if (nQ > 0) {
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qKmerA.as<uint64_t>(), c->qKmerB.as<uint64_t>(),
+                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KEYBITS, c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerA.as<uint64_t>(), c->qKmerB.as<uint64_t>(),
+                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KEYBITS, c->stream));
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_SORT], a, b))) return rc;
+    c->qKmer = c->qKmerB.as<uint64_t>();
+    c->qRead = c->qReadB.as<uint32_t>();
+
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_LOOKUP], &a, &b))) return rc;
+    if (nQ > 0) {
+        hipEvent_t ka, kb;
+        if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
+        lookup_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+            c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
+            c->tileFirst.as<uint32_t>(), nTiles);
+        HIPCHK(hipGetLastError());
+        if ((rc = timer_end(c, c->lookupKernel, ka, kb))) return rc;
+        c->lookupQueries += nQ;
+        tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)nQ);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_LOOKUP], a, b))) return rc;
+    c->state = 3;
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// group: per level, per sorted query -> (flush position F, taxon-set reference)
+// ------------------------------------------------------------------------------------------------
+// Block-wide scans over the 256 per-thread aggregates of a tile (each thread owns ITEMS consecutive
+// positions).  suffix_min: min over threads to the right; prefix_max: max over threads to the left.
+__device__ __forceinline__ uint32_t block_excl_suffix_min(uint32_t v, uint32_t *sh)
+{
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < TILE_THREADS; off <<= 1) {
+        const uint32_t o = (t + off < TILE_THREADS) ? sh[t + off] : NOPOS;
+        __syncthreads();
+        if (o < sh[t]) sh[t] = o;
+        __syncthreads();
+    }
+    const uint32_t r = (t + 1 < TILE_THREADS) ? sh[t + 1] : NOPOS;
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
+{
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < TILE_THREADS; off <<= 1) {
+        const int o = (t >= off) ? sh[t - off] : -1;
+        __syncthreads();
+        if (o > sh[t]) sh[t] = o;
+        __syncthreads();
+    }
+    const int r = (t > 0) ? sh[t - 1] : -1;
+    __syncthreads();
+    return r;
+}
+
+// Taxon set of the index group (letters shared >= g) around entry j (BitArray.hpp:98-117 semantics:
+// distinct taxa in index order).  One taxon -> REF_SINGLE | taxon, otherwise an offset into `pool`
+// where {n, taxon_1..n} is appended.
+__device__ uint32_t group_taxa(uint32_t j, int g, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
+                               uint32_t nIdx, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor,
+                               bool coverage, uint64_t *__restrict__ cntTotalLv)
+{
+    uint32_t a = j;
+    while (a > 0 && (meta[a] & 15) >= g) --a;
+    uint32_t b = j + 1;
+    while (b < nIdx && (meta[b] & 15) >= g) ++b;
+    uint32_t n = 0;
+    for (uint32_t i = a; i < b; ++i) n += ((meta[i] >> 4) < g) ? 1u : 0u;
+    if (coverage)
+        for (uint32_t i = a; i < b; ++i)
+            if ((meta[i] >> 4) < g) atomicAdd((unsigned long long *)&cntTotalLv[tax[i]], 1ull);
+    if (n == 1) return REF_SINGLE | tax[a];
+    const uint32_t off = atomicAdd(poolCursor, n + 1);
+    if (off + n + 1 > poolCap) return 0x7FFFFFFFu; // overflow: the host grows the pool and reruns
+    pool[off] = n;
+    uint32_t w = off + 1;
+    for (uint32_t i = a; i < b; ++i)
+        if ((meta[i] >> 4) < g) pool[w++] = tax[i];
+    return off;
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void group_kernel(
+    const uint64_t *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
+    uint32_t nIdx, int kHigh, int kLow, uint2 *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap,
+    uint32_t *__restrict__ poolCursor, int coverage, uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
+{
+    __shared__ uint32_t shU[TILE_THREADS];
+    __shared__ int shI[TILE_THREADS];
+    __shared__ uint32_t sInfo[TILE];
+    const int nK = kHigh - kLow + 1;
+    const int t = threadIdx.x;
+    const uint32_t base = blockIdx.x * TILE + t * ITEMS;         // blocked: this thread owns base..base+3
+    uint8_t ql[ITEMS], d[ITEMS];
+    uint32_t rp[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t p = base + i;
+        if (p < nQ) {
+            const uint64_t q = qKmer[p];
+            ql[i] = (p == 0) ? 0 : (uint8_t)lcp_letters(qKmer[p - 1], q);
+            d[i] = depth[p];
+            rp[i] = rep[p];
+        } else { ql[i] = 0; d[i] = 0; rp[i] = 0; }
+    }
+    for (int lv = 0; lv < nK; ++lv) {
+        const int k = kHigh - lv;
+        const int g = group_letters(k);
+        // ---- flush position: next position that closes the level-k group (suffix scan)
+        bool sp[ITEMS];
+        uint32_t firstSp = NOPOS;
+#pragma unroll
+        for (int i = ITEMS - 1; i >= 0; --i) {
+            const uint32_t p = base + i;
+            sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
+            if (sp[i]) firstSp = p;
+        }
+        uint32_t carry = block_excl_suffix_min(firstSp, shU);
+        if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
+        uint32_t F[ITEMS];
+#pragma unroll
+        for (int i = ITEMS - 1; i >= 0; --i) {
+            F[i] = carry;
+            if (sp[i]) carry = base + i;
+        }
+        // ---- group leaders: first query of a level-k group, or the first matched query of the tile
+        int lastLeader = -1;
+        bool leader[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const bool matched = (base + i < nQ) && d[i] >= k;
+            leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));
+            if (leader[i]) lastLeader = t * ITEMS + i;
+        }
+        int lead = block_excl_prefix_max(lastLeader, shI);
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (leader[i])
+                sInfo[t * ITEMS + i] = group_taxa(rp[i], g, meta, tax, nIdx, pool, poolCap, poolCursor,
+                                                  coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const uint32_t p = base + i;
+            if (leader[i]) lead = t * ITEMS + i;
+            if (p < nQ) {
+                const bool matched = d[i] >= k;
+                rec[(size_t)p * nK + lv] = make_uint2(F[i], (matched && lead >= 0) ? sInfo[lead] : 0u);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// score: one wavefront per read, events replayed in flush order
+// ------------------------------------------------------------------------------------------------
+struct ScoreArgs {
+    const uint32_t *plist; const uint64_t *kmerOff; const uint2 *rec; const uint32_t *pool;
+    uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
+    float *scratch;                              // per block: nTaxa floats, all zero between reads
+    uint64_t *cntUnique, *cntAllHi, *cntAllLo;
+    uint32_t *rowPos, *rowLen; uint32_t *stTax; float *stScore; uint32_t stCap; uint32_t *stCursor;
+    uint32_t *errFlag; int wantPerRead;
+};
+
+__global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
+{
+    __shared__ uint32_t pF[PCAP], pRef[PCAP];
+    __shared__ uint32_t pCnt[PCAP];
+    __shared__ uint8_t pK[PCAP];
+    __shared__ uint32_t sTouched;
+    __shared__ uint32_t sList[TLIST];
+    const int lane = threadIdx.x;
+    const int nK = A.kHigh - A.kLow + 1;
+    float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
+
+    for (uint32_t r = blockIdx.x; r < A.nReads; r += gridDim.x) {
+        const uint64_t o0 = A.kmerOff[r];
+        const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
+        int head = 0, tail = 0;            // pending window [head, tail), sorted by (F, k) ascending
+        if (lane == 0) sTouched = 0;
+        __syncthreads();
+
+        // apply the pending entry at `e` (all lanes call it with the same e)
+        auto apply = [&](int e) {
+            const uint32_t ref = pRef[e];
+            const int k = pK[e];
+            const uint32_t c = pCnt[e];
+            const int lv = A.kHigh - k;
+            uint32_t n; const uint32_t *list; uint32_t single;
+            if (ref & REF_SINGLE) { n = 1; single = ref & 0x7FFFFFFFu; list = &single; }
+            else { n = A.pool[ref]; list = A.pool + ref + 1; single = 0; }
+            const float w = (float)(k * k) / 625.0f;                         // Compare.hpp:392
+            const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));         // Compare.hpp:924
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t tx = (n == 1) ? single : list[i];
+                if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
+                if (A.wantPerRead) {
+                    float v = score[tx];
+                    if (v == 0.0f) { const uint32_t ti = atomicAdd(&sTouched, 1u); if (ti < (uint32_t)TLIST) sList[ti] = tx; }
+                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);    // Compare.hpp:528-530, one add per hit
+                    score[tx] = v;
+                }
+                const size_t cell = (size_t)lv * A.nTaxa + tx;
+                if (n == 1) {
+                    atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
+                    atomicAdd((unsigned long long *)&A.cntAllHi[cell], (unsigned long long)c);
+                } else {
+                    // c / n as 64.64 fixed point: c * floor(2^64 / n)
+                    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
+                    if ((n & (n - 1)) == 0) R += 1;                          // n divides 2^64
+                    const uint64_t loAdd = (uint64_t)c * R;
+                    uint64_t hiAdd = __umul64hi((uint64_t)c, R);
+                    const uint64_t old = atomicAdd((unsigned long long *)&A.cntAllLo[cell], (unsigned long long)loAdd);
+                    if (old + loAdd < old) ++hiAdd;
+                    if (hiAdd) atomicAdd((unsigned long long *)&A.cntAllHi[cell], (unsigned long long)hiAdd);
+                }
+            }
+        };
+
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t p = A.plist[o0 + j];
+            // everything that flushes at or before p precedes all events of this and later queries
+            while (head < tail && pF[head] <= p) { apply(head); ++head; }
+            if (head == tail) head = tail = 0;
+            uint32_t myF = 0, myRef = 0;
+            if (lane < nK) { const uint2 v = A.rec[(size_t)p * nK + lane]; myF = v.x; myRef = v.y; }
+            for (int lv = nK - 1; lv >= 0; --lv) {                            // k ascending
+                const uint32_t F = __shfl(myF, lv);
+                const uint32_t ref = __shfl(myRef, lv);
+                if (ref == 0) continue;
+                const int k = A.kHigh - lv;
+                // position of (F, k) in the sorted window; equal key = same group: bump its count
+                int pos = tail;
+                bool same = false;
+                for (int b0 = head; b0 < tail; b0 += 64) {
+                    const int e = b0 + lane;
+                    bool ge = false, eq = false;
+                    if (e < tail) {
+                        const uint32_t eF = pF[e]; const int eK = pK[e];
+                        ge = (eF > F) || (eF == F && eK >= k);
+                        eq = (eF == F && eK == k);
+                    }
+                    const unsigned long long m = __ballot(ge);
+                    if (m) { pos = b0 + __ffsll((long long)m) - 1; same = (__ballot(eq) != 0ull); break; }
+                }
+                if (same) {
+                    if (lane == 0) pCnt[pos] = pCnt[pos] + 1;
+                    __syncthreads();
+                    continue;
+                }
+                if (tail >= PCAP) {
+                    if (head > 0) {                                           // compact the window to the front
+                        for (int b0 = head; b0 < tail; b0 += 64) {
+                            const int e = b0 + lane;
+                            uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
+                            if (e < tail) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
+                            __syncthreads();
+                            if (e < tail) { pF[e - head] = f; pRef[e - head] = rf; pCnt[e - head] = cc; pK[e - head] = kk; }
+                            __syncthreads();
+                        }
+                        pos -= head; tail -= head; head = 0;
+                    }
+                    if (tail >= PCAP) { if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
+                }
+                for (int hi = tail; hi > pos; hi -= 64) {                     // shift [pos, tail) right by one
+                    const int e = hi - 1 - lane;
+                    uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
+                    if (e >= pos) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
+                    __syncthreads();
+                    if (e >= pos) { pF[e + 1] = f; pRef[e + 1] = rf; pCnt[e + 1] = cc; pK[e + 1] = kk; }
+                    __syncthreads();
+                }
+                if (lane == 0) { pF[pos] = F; pRef[pos] = ref; pCnt[pos] = 1; pK[pos] = (uint8_t)k; }
+                ++tail;
+                __syncthreads();
+            }
+        }
+        while (head < tail) { apply(head); ++head; }
+        __syncthreads();
+
+        // ---- emit the row (taxon ascending) and clear the dense row
+        if (A.wantPerRead) {
+            const uint32_t m = sTouched;
+            uint32_t start = 0;
+            if (lane == 0) {
+                start = m ? atomicAdd(A.stCursor, m) : 0u;
+                A.rowPos[r] = start; A.rowLen[r] = m;
+            }
+            start = __shfl(start, 0);
+            __threadfence_block();
+            if (m && start + m <= A.stCap) {
+                if (m <= 64) {
+                    const uint32_t mine = (lane < (int)m) ? sList[lane] : 0xFFFFFFFFu;
+                    uint32_t rank = 0;
+                    for (uint32_t i = 0; i < m; ++i) rank += (__shfl(mine, (int)i) < mine) ? 1u : 0u;
+                    if (lane < (int)m) { A.stTax[start + rank] = mine; A.stScore[start + rank] = score[mine]; }
+                } else {
+                    uint32_t w = start;
+                    for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) {
+                        const uint32_t tx = b0 + lane;
+                        const float v = (tx < A.nTaxa) ? score[tx] : 0.0f;
+                        const unsigned long long mk = __ballot(v > 0.0f);
+                        if (v > 0.0f) {
+                            const uint32_t o = w + __popcll(mk & ((1ull << lane) - 1ull));
+                            A.stTax[o] = tx; A.stScore[o] = v;
+                        }
+                        w += __popcll(mk);
+                    }
+                }
+            }
+            __syncthreads();
+            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
+                                const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
+                                const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nReads) return;
+    const uint32_t s = rowPos[r], m = rowLen[r];
+    const uint64_t o = rowOff[r];
+    for (uint32_t i = 0; i < m; ++i) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
+}
+
+__global__ void widen_kernel(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverage)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_lookup_score: batch not sorted");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint64_t nQ = c->nQ;
+    const uint32_t nReads = (uint32_t)c->nReads;
+    const uint32_t nTaxa = c->ix->nTaxa;
+    const int nK = c->nK;
+    int rc;
+    c->haveScores = false; c->nnz = 0;
+    if (nQ == 0 || nReads == 0) {
+        if (wantPerRead) {
+            if ((rc = c->rowOff.reserve(((size_t)nReads + 1) * 8))) return rc;
+            HIPCHK(hipMemsetAsync(c->rowOff.p, 0, ((size_t)nReads + 1) * 8, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->haveScores = true;
+        }
+        c->state = 4;
+        return KASA_OK;
+    }
+    const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
+    if ((rc = c->rec.reserve(nQ * (size_t)nK * 8 + 64))) return rc;
+    uint32_t *counters = c->misc.as<uint32_t>(); // [0] pool cursor, [1] staging cursor, [2] error flags
+    hipEvent_t a, b;
+
+    // ---- group
+    if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ / 2);
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = c->pool.reserve(c->poolCap * 4))) return rc;
+        const uint32_t one = 1;
+        HIPCHK(hipMemcpyAsync(counters, &one, 4, hipMemcpyHostToDevice, c->stream)); // offset 0 means "no match"
+        if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
+        group_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+            c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x7FFFFFF0ull),
+            counters, coverage && attempt == 0, c->cntTotal.as<uint64_t>(), nTaxa);
+        HIPCHK(hipGetLastError());
+        if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
+        uint32_t used = 0;
+        HIPCHK(hipMemcpyAsync(&used, counters, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (used <= c->poolCap) break;
+        if ((uint64_t)used >= 0x7FFFFFF0ull) return fail(KASA_E_LIMIT, "taxon-list pool exceeds 2^31 entries in one batch; split the batch");
+        c->poolCap = (uint64_t)used + used / 8 + 1024;
+        if (attempt > 3) return fail(KASA_E_LIMIT, "taxon-list pool did not converge");
+    }
+
+    // ---- regroup: sorted positions by read, stable (so each read sees its queries in sorted order)
+    if ((rc = c->plist.reserve(nQ * 4 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_REGROUP], &a, &b))) return rc;
+    {
+        unsigned bits = 1;
+        while ((1ull << bits) < (uint64_t)nReads) ++bits;
+        rocprim::counting_iterator<uint32_t> iota(0);
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
+                                         (size_t)nQ, 0u, bits, c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
+                                         (size_t)nQ, 0u, bits, c->stream));
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_REGROUP], a, b))) return rc;
+
+    // ---- score
+    const uint32_t blocks = std::min<uint32_t>(nReads, 256u * 16u);
+    if ((rc = c->scratch.reserve((size_t)blocks * nTaxa * 4))) return rc;
+    if (wantPerRead) {
+        if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
+            (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)))
+            return rc;
+        if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 4);
+    }
+    // profile tables are accumulated by the score kernel with integer atomics: a rerun (staging
+    // overflow) must not count twice, so the first pass runs with a generous staging area and a
+    // rerun only re-emits rows (wantPerRead = 2: no profile adds)
+    for (int attempt = 0;; ++attempt) {
+        if (wantPerRead && ((rc = c->stTax.reserve(c->stCap * 4)) || (rc = c->stScore.reserve(c->stCap * 4)))) return rc;
+        HIPCHK(hipMemsetAsync(counters + 1, 0, 8, c->stream));
+        HIPCHK(hipMemsetAsync(c->scratch.p, 0, (size_t)blocks * nTaxa * 4, c->stream));
+        ScoreArgs A;
+        A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
+        A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
+        A.scratch = c->scratch.as<float>();
+        A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
+        A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
+        A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
+        A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
+        A.wantPerRead = wantPerRead ? 1 : 0;
+        if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
+        if (attempt == 0) {
+            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
+        } else {
+            // second pass writes its profile adds into throw-away tables
+            DevBuf junk;
+            const size_t cells = (size_t)nK * nTaxa * 8;
+            if ((rc = junk.reserve(cells * 3))) return rc;
+            HIPCHK(hipMemsetAsync(junk.p, 0, cells * 3, c->stream));
+            A.cntUnique = junk.as<uint64_t>(); A.cntAllHi = A.cntUnique + (size_t)nK * nTaxa; A.cntAllLo = A.cntAllHi + (size_t)nK * nTaxa;
+            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            junk.release();
+        }
+        HIPCHK(hipGetLastError());
+        if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
+        uint32_t h[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h, counters + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[1] & 2u) return fail(KASA_E_LIMIT, "a read keeps more than %d distinct groups pending; this build cannot order it", PCAP);
+        if (!wantPerRead) break;
+        if ((uint64_t)h[0] <= c->stCap) { c->nnz = h[0]; break; }
+        c->stCap = (uint64_t)h[0] + h[0] / 8 + 1024;
+        if (attempt > 2) return fail(KASA_E_LIMIT, "score staging did not converge");
+    }
+    if (wantPerRead) {
+        // CSR offsets = exclusive scan of the row lengths, then rows copied in read order
+        DevBuf &len64 = c->qReadA; // reuse: u64[nReads+1] fits (nQ >= nReads is not guaranteed -> reserve)
+        if ((rc = len64.reserve(((size_t)nReads + 1) * 8 + 64))) return rc;
+        HIPCHK(hipMemsetAsync(len64.p, 0, ((size_t)nReads + 1) * 8, c->stream));
+        widen_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rowLen.as<uint32_t>(), len64.as<uint64_t>(), nReads);
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
+                                       rocprim::plus<uint64_t>(), c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
+                                       rocprim::plus<uint64_t>(), c->stream));
+        if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
+        row_copy_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
+            nReads, c->stTax.as<uint32_t>(), c->stScore.as<float>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->haveScores = true;
+    }
+    c->state = 4;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_scores_size(kasa_ctx *c, uint64_t *nnz)
+{
+    if (!c || !nnz) return fail(KASA_E_ARG, "kasa_batch_scores_size: NULL argument");
+    if (!c->haveScores) return fail(KASA_E_STATE, "kasa_batch_scores_size: no per-read scores (call kasa_batch_lookup_score with wantPerRead)");
+    *nnz = c->nnz;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint32_t *taxIdx, float *score)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (!c->haveScores) return fail(KASA_E_STATE, "kasa_batch_scores_fetch: no per-read scores");
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (readOffsets) HIPCHK(hipMemcpy(readOffsets, c->rowOff.p, ((size_t)c->nReads + 1) * 8, hipMemcpyDeviceToHost));
+    if (c->nnz && taxIdx) HIPCHK(hipMemcpy(taxIdx, c->outTax.p, c->nnz * 4, hipMemcpyDeviceToHost));
+    if (c->nnz && score) HIPCHK(hipMemcpy(score, c->outScore.p, c->nnz * 4, hipMemcpyDeviceToHost));
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profile tables
+// ------------------------------------------------------------------------------------------------
+static int fetch_tables(kasa_ctx *c, std::vector<uint64_t> &u, std::vector<uint64_t> &t, std::vector<uint64_t> &hi, std::vector<uint64_t> &lo)
+{
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t cells = (size_t)c->nK * c->ix->nTaxa;
+    u.resize(cells); t.resize(cells); hi.resize(cells); lo.resize(cells);
+    HIPCHK(hipMemcpy(u.data(), c->cntUnique.p, cells * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t.data(), c->cntTotal.p, cells * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hi.data(), c->cntAllHi.p, cells * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lo.data(), c->cntAllLo.p, cells * 8, hipMemcpyDeviceToHost));
+    return KASA_OK;
+}
+
+extern "C" int kasa_profile_fetch(kasa_ctx *c, double *countAll, uint64_t *countUnique, uint64_t *countTotal)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    std::vector<uint64_t> u, t, hi, lo;
+    int rc = fetch_tables(c, u, t, hi, lo);
+    if (rc) return rc;
+    for (size_t i = 0; i < u.size(); ++i) {
+        if (countUnique) countUnique[i] = u[i];
+        if (countTotal) countTotal[i] = t[i];
+        if (countAll) countAll[i] = (double)hi[i] + (double)lo[i] * 5.42101086242752217e-20; // 2^-64
+    }
+    return KASA_OK;
+}
+
+extern "C" int kasa_profile_export_limbs(kasa_ctx *c, uint64_t *limbs)
+{
+    if (!c || !limbs) return fail(KASA_E_ARG, "kasa_profile_export_limbs: NULL argument");
+    std::vector<uint64_t> u, t, hi, lo;
+    int rc = fetch_tables(c, u, t, hi, lo);
+    if (rc) return rc;
+    for (size_t i = 0; i < u.size(); ++i) {
+        uint64_t *o = limbs + i * 6;
+        o[0] = u[i]; o[1] = t[i];
+        o[2] = lo[i] & 0xFFFFFFFFull; o[3] = lo[i] >> 32; o[4] = hi[i] & 0xFFFFFFFFull; o[5] = hi[i] >> 32;
+    }
+    return KASA_OK;
+}
+
+extern "C" int kasa_profile_import_limbs(kasa_ctx *c, const uint64_t *limbs)
+{
+    if (!c || !limbs) return fail(KASA_E_ARG, "kasa_profile_import_limbs: NULL argument");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const size_t cells = (size_t)c->nK * c->ix->nTaxa;
+    std::vector<uint64_t> u(cells), t(cells), hi(cells), lo(cells);
+    for (size_t i = 0; i < cells; ++i) {
+        const uint64_t *o = limbs + i * 6;
+        u[i] = o[0]; t[i] = o[1];
+        unsigned __int128 v = (unsigned __int128)o[2] + ((unsigned __int128)o[3] << 32) + ((unsigned __int128)o[4] << 64) + ((unsigned __int128)o[5] << 96);
+        lo[i] = (uint64_t)v; hi[i] = (uint64_t)(v >> 64);
+    }
+    HIPCHK(hipMemcpy(c->cntUnique.p, u.data(), cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->cntTotal.p, t.data(), cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->cntAllHi.p, hi.data(), cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->cntAllLo.p, lo.data(), cells * 8, hipMemcpyHostToDevice));
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// measurement + test taps
+// ------------------------------------------------------------------------------------------------
+extern "C" int kasa_ctx_stage_ms(kasa_ctx *c, int stage, double *ms, uint64_t *launches)
+{
+    if (!c || stage < 0 || stage >= KASA_STAGE_COUNT) return fail(KASA_E_ARG, "kasa_ctx_stage_ms: bad argument");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = timer_resolve(c->timers[stage]);
+    if (rc) return rc;
+    if (ms) *ms = c->timers[stage].ms;
+    if (launches) *launches = c->timers[stage].launches;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_lookup_kernel_ms(kasa_ctx *c, double *ms, uint64_t *launches, uint64_t *queries)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = timer_resolve(c->lookupKernel);
+    if (rc) return rc;
+    if (ms) *ms = c->lookupKernel.ms;
+    if (launches) *launches = c->lookupKernel.launches;
+    if (queries) *queries = c->lookupQueries;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_stage_reset(kasa_ctx *c)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    for (auto &t : c->timers) { int rc = timer_resolve(t); if (rc) return rc; t.ms = 0; t.launches = 0; }
+    int rc = timer_resolve(c->lookupKernel); if (rc) return rc;
+    c->lookupKernel.ms = 0; c->lookupKernel.launches = 0; c->lookupQueries = 0;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_fetch_queries(kasa_ctx *c, uint64_t *kmers, uint32_t *reads, uint64_t n)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_fetch_queries: batch not encoded");
+    if (n > c->nQ) return fail(KASA_E_ARG, "kasa_batch_fetch_queries: n exceeds the batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n && kmers) HIPCHK(hipMemcpy(kmers, c->qKmer, n * 8, hipMemcpyDeviceToHost));
+    if (n && reads) HIPCHK(hipMemcpy(reads, c->qRead, n * 4, hipMemcpyDeviceToHost));
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_set_queries(kasa_ctx *c, const uint64_t *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
+    if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    c->state = 0; c->haveScores = false;
+    std::vector<uint64_t> koff((size_t)nReads + 1, 0);
+    uint32_t maxCnt = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if ((int64_t)reads[i] >= nReads) return fail(KASA_E_ARG, "kasa_batch_set_queries: read id out of range");
+        if (kmers[i] >> KEYBITS) return fail(KASA_E_ARG, "kasa_batch_set_queries: k-mer uses more than %d bits", KEYBITS);
+        koff[(size_t)reads[i] + 1]++;
+    }
+    for (int64_t r = 0; r < nReads; ++r) { maxCnt = std::max<uint32_t>(maxCnt, (uint32_t)koff[(size_t)r + 1]); koff[(size_t)r + 1] += koff[(size_t)r]; }
+    int rc;
+    if ((rc = c->qKmerA.reserve(n * 8 + 64)) || (rc = c->qReadA.reserve(n * 4 + 64)) || (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)))
+        return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->qKmerA.p, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) HIPCHK(hipMemcpyAsync(c->qReadA.p, reads, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->kmerOff.p, koff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->nReads = nReads; c->nQ = n; c->maxCnt = maxCnt;
+    c->qKmer = c->qKmerA.as<uint64_t>(); c->qRead = c->qReadA.as<uint32_t>();
+    c->state = 2;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_fetch_lookup(kasa_ctx *c, uint8_t *depth, uint32_t *indexPos, uint64_t n)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_fetch_lookup: batch not sorted");
+    if (n > c->nQ) return fail(KASA_E_ARG, "kasa_batch_fetch_lookup: n exceeds the batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n && depth) HIPCHK(hipMemcpy(depth, c->depth.p, n, hipMemcpyDeviceToHost));
+    if (n && indexPos) HIPCHK(hipMemcpy(indexPos, c->rep.p, n * 4, hipMemcpyDeviceToHost));
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
+{
+    if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
+    const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
+                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                           &c->misc, &c->scratch, &c->touched, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
+    uint64_t s = 0;
+    for (const DevBuf *b : all) s += b->cap;
+    *bytes = s;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_synchronize(kasa_ctx *c)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}

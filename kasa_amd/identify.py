@@ -1,0 +1,69 @@
+"""Host driver of `identify`: the per-batch call sequence of Compare::CompareWithLib_partialSort
+(source/modes/Compare.hpp:2733-3766) on top of the C ABI.
+
+    read batch (Read.hpp:1054) -> kasa_batch_upload/encode -> kasa_batch_sort_and_range
+    -> kasa_batch_lookup_score -> rank + write per-read text (Compare.hpp:1485-1890)
+    after the file: profile CSV (Compare.hpp:3466-3665)
+
+Batch boundaries matter for the last float digit of per-read scores (the flush order depends on
+which reads share a batch): `batch_reads=None` processes the whole input as one
+batch, which is what the reference does whenever the input fits its -m budget.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi, report
+from .formats import Index
+from .reads import ReadBatch
+
+
+class Identify:
+    def __init__(self, index: Index, device: int = 0, k_high: int = 12, k_low: int = 7, frames: int = 3,
+                 threshold: float = 0.0, beasts: int = 3, fmt: str = "json", dix: capi.DeviceIndex = None):
+        self.index = index
+        self.k_high, self.k_low = max(k_high, k_low), min(k_high, k_low)
+        self.frames, self.threshold, self.beasts, self.fmt = frames, threshold, beasts, fmt
+        self.dix = dix if dix is not None else capi.DeviceIndex(index, device)
+        self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames)
+        self.n_kmers = 0
+        self.n_reads = 0
+
+    def close(self):
+        self.ctx.close()
+
+    def run(self, reads: ReadBatch, want_per_read: bool = True, batch_reads: int = None, coverage: bool = False):
+        """-> (per-read text or None, profile CSV text, list of CSR batches)."""
+        ix = self.index
+        writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts)
+        freq = ix.freq_at(self.k_high)
+        out = [writer.header()] if want_per_read else None
+        csr = []
+        self.ctx.profile_reset()
+        self.n_kmers = 0
+        self.n_reads = 0
+        step = reads.n if not batch_reads else batch_reads
+        a = 0
+        while a < reads.n or (a == 0 and reads.n == 0):
+            b = min(reads.n, a + max(step, 1))
+            part = reads.slice(a, b)
+            self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage)
+            self.n_kmers += self.ctx.n_kmers
+            if want_per_read:
+                off, tax, sc = self.ctx.scores()
+                csr.append((off, tax, sc))
+                for r in range(part.n):
+                    lo, hi = int(off[r]), int(off[r + 1])
+                    rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(part.lengths[r]), freq, self.k_high,
+                                          self.k_low, self.frames, self.threshold, self.beasts)
+                    out.append(writer.read(self.n_reads + r, part.names[r], int(part.lengths[r]), rk))
+            self.n_reads += part.n
+            a = b
+            if reads.n == 0:
+                break
+        if want_per_read:
+            out.append(writer.footer())
+        ca, cu, ct = self.ctx.profile()
+        prof = report.profile_csv(ca, cu, ix.content.names, ix.content.taxids, self.k_high, self.k_low,
+                                  self.n_kmers, self.n_reads, self.frames)
+        return ("".join(out) if want_per_read else None), prof, csr

@@ -1,0 +1,210 @@
+"""GPU parity: the HIP path through the C ABI against (a) the reference binary's own output files,
+(b) the CPU oracle on seeded inputs, stage by stage.  Bit-exact for k-mers, positions, unique counts
+and float32 per-read scores; countAll (a double in the reference, an exact 64.64 fixed-point sum here)
+within 1e-12 relative, and identical once printed with the reference's 6 significant digits."""
+import os
+
+import numpy as np
+import pytest
+
+from kasa_amd import capi, formats, reads, report
+from kasa_amd.identify import Identify
+from oracle import oracle
+from tests import helpers
+from tests.test_oracle_golden import PAIRS, _read
+from tests.test_oracle_properties import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_or_fail():
+    assert capi.device_count() > 0, "no HIP device visible: the GPU parity tests need a real MI355X"
+
+
+def csr_rows(off, tax, sc):
+    return [(tax[int(off[r]):int(off[r + 1])], sc[int(off[r]):int(off[r + 1])]) for r in range(off.shape[0] - 1)]
+
+
+def assert_csr_equal(rows_gpu, rows_oracle):
+    assert len(rows_gpu) == len(rows_oracle)
+    for r, ((tg, sg), (to, so)) in enumerate(zip(rows_gpu, rows_oracle)):
+        assert np.array_equal(tg, to), f"read {r}: taxa differ {tg} vs {to}"
+        assert np.array_equal(sg.view(np.uint32), so.view(np.uint32)), f"read {r}: scores differ {sg} vs {so}"
+
+
+@pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
+def test_golden_files_byte_identical(case):
+    """End to end against the files the reference binary wrote."""
+    _gpu_or_fail()
+    stem, infile, fmt, kh, kl, frames, thr, beasts = case
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, infile))
+    idf = Identify(ix, 0, kh, kl, frames, thr, beasts, fmt)
+    text, prof, _ = idf.run(batch)
+    assert text == _read(os.path.join(d, "out_" + stem))
+    assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+    idf.close()
+
+
+@pytest.mark.parametrize("frames", [3, 6])
+@pytest.mark.parametrize("krange", [(12, 7), (12, 12), (9, 6), (12, 5)])
+def test_stages_vs_oracle_golden_inputs(frames, krange):
+    """encode, sort, lookup depth, profile tables and per-read CSR against the oracle."""
+    _gpu_or_fail()
+    kh, kl = krange
+    for name in ("pairs", "clones"):
+        d, ix = helpers.load_case(name)
+        batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+        p = oracle.params(kh, kl, frames)
+        dix = capi.DeviceIndex(ix)
+        ctx = capi.Context(dix, kh, kl, frames)
+        ctx.upload(batch.bases, batch.offsets)
+        n = ctx.encode()
+        km_o, rd_o = oracle.encode(batch.bases, batch.offsets, p)
+        km_g, rd_g = ctx.queries()
+        assert n == km_o.shape[0]
+        assert np.array_equal(km_g, km_o) and np.array_equal(rd_g, rd_o)
+        ctx.sort_and_range()
+        km_s, _ = ctx.queries()
+        assert np.array_equal(km_s, np.sort(km_o))
+        ctx.lookup_score(True)
+        res, _ = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+        ca, cu, _ = ctx.profile()
+        assert np.array_equal(cu, res.count_unique)
+        np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+        assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+        ctx.close(); dix.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_adversarial_queries_vs_oracle(seed):
+    """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(5000 + seed)
+    letters = [[1, 2], [1, 2, 30], [3, 4, 5, 30, 31], list(range(1, 21))][seed % 4]
+    k_low = int(rng.integers(5, 12))
+    k_high = int(rng.integers(k_low, 13))
+    n_taxa = int(rng.integers(2, 40))
+    n_reads = int(rng.integers(1, 50))
+    ix, q, rd = random_case(seed, int(rng.integers(1, 3000)), int(rng.integers(5, 6000)), n_taxa, letters,
+                            k_high, k_low, n_reads)
+    p = oracle.params(k_high, k_low, 3)
+    iv = oracle.IndexView(ix)
+    qs, rs_ = oracle.sort_queries(q, rd)
+    a, b = oracle.ranges(iv, p, qs)
+    res = oracle.compare(iv, p, qs, rs_, a, b, n_reads, True, closed_form=False)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, k_high, k_low, 3)
+    ctx.set_queries(q, rd, n_reads)
+    ctx.sort_and_range()
+    ctx.lookup_score(True, coverage=False)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.close(); dix.close()
+
+
+def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150):
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genomes = []
+    for g in range(n_taxa):
+        if g % 2 == 1:
+            s = genomes[g - 1].copy()
+            m = rng.random(genome_len) < 0.03
+            s[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+        else:
+            s = alphabet[rng.integers(0, 4, size=genome_len)]
+        genomes.append(s)
+    content = formats.Content(["non_unique"] + [f"Taxon {g}" for g in range(n_taxa)],
+                              np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for g, s in enumerate(genomes):  # index = forward k-mers of every genome (3 frames), as `build --three`
+        km, _ = oracle.encode(s, np.array([0, genome_len], dtype=np.int64), p)
+        kms.append(km)
+        tids.append(np.full(km.shape[0], 100 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, n_reads, read_len, seed + 1)
+    return ix, batch
+
+
+def test_medium_synthetic_vs_oracle():
+    """20 taxa x 20 kb, 4000 reads (520k queries, 500+ tiles): every stage against the oracle."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(7, 20, 20000, 4000)
+    p = oracle.params(12, 7, 3)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    assert ctx.n_kmers == nq
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    # profile-only mode gives the same tables; batches accumulate
+    ctx.profile_reset()
+    half = batch.n // 2
+    for part in (batch.slice(0, half), batch.slice(half, batch.n)):
+        ctx.run_batch(part.bases, part.offsets, False)
+    ca2, cu2, _ = ctx.profile()
+    assert np.array_equal(cu2, cu)
+    np.testing.assert_allclose(ca2, ca, rtol=1e-12, atol=0)
+    ctx.close(); dix.close()
+
+
+def test_empty_and_degenerate_batches():
+    _gpu_or_fail()
+    d, ix = helpers.load_case("pairs")
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(np.zeros(0, np.uint8), np.zeros(1, np.int64), True)   # no reads
+    off, tax, sc = ctx.scores()
+    assert off.tolist() == [0] and tax.size == 0
+    ctx.run_batch(np.frombuffer(b"ACGTACGTAC", dtype=np.uint8), np.array([0, 10], np.int64), True)  # 0 k-mers
+    off, tax, sc = ctx.scores()
+    assert off.tolist() == [0, 0]
+    ctx.run_batch(np.frombuffer(b"ACGT", dtype=np.uint8), np.array([0, 0, 4, 4], np.int64), True)   # empty reads
+    assert ctx.scores()[0].tolist() == [0, 0, 0, 0]
+    with pytest.raises(RuntimeError):
+        capi.Context(dix, 13, 7, 3)
+    with pytest.raises(RuntimeError):
+        ctx2 = capi.Context(dix, 12, 7, 3)
+        ctx2.sort_and_range()
+    ctx.close(); dix.close()
+
+
+def test_coverage_counts_groups():
+    """--coverage: countTotal counts each matched (level, prefix) group once (Compare.hpp:690)."""
+    _gpu_or_fail()
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    p = oracle.params(12, 7, 3, coverage=True)
+    iv = oracle.IndexView(ix)
+    km, rd = oracle.sort_queries(*oracle.encode(batch.bases, batch.offsets, p))
+    rs, rl = oracle.ranges(iv, p, km)
+    res = oracle.compare(iv, p, km, rd, rs, rl, batch.n, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, True, coverage=True)
+    _, _, ct = ctx.profile()
+    assert np.array_equal(ct, res.count_total)
+    ctx.close(); dix.close()
+
+
+def test_profile_limbs_roundtrip_and_sum():
+    _gpu_or_fail()
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, False)
+    ca, cu, _ = ctx.profile()
+    limbs = ctx.profile_limbs()
+    ctx.profile_set_limbs(limbs * np.uint64(2))      # "two ranks with the same shard"
+    ca2, cu2, _ = ctx.profile()
+    assert np.array_equal(cu2, cu * np.uint64(2))
+    np.testing.assert_allclose(ca2, 2 * ca, rtol=1e-15)
+    ctx.close(); dix.close()

@@ -1,0 +1,97 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/kasa_hip.h, number
+text, file formats, read parsing.  No compute call is made here (no GPU in this tier)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kasa_amd import capi, formats, reads, textnum
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "kasa_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*\*?(kasa_[a-z_0-9]+)\(", header, re.M))
+    L = capi.lib()
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(capi.EXPORTS)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    d, ix = helpers.load_case("pairs")
+    with pytest.raises(RuntimeError):
+        capi.DeviceIndex(ix)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under kasa_amd/ may import, include, link or call it."""
+    bad = re.compile(r"^\s*(?:import|from)\s+oracle\b|#include[^\n]*oracle|libkasa_oracle|\bko_[a-z_]+\s*\(", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kasa_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not bad.search(src), f
+
+
+def test_cached_powers_match_published_constants():
+    # first / second / last entries of the Grisu cached-power table (Loitsch 2010; double-conversion)
+    assert textnum._POWERS[0] == (0xfa8fd5a0081c0288, -1220)
+    assert textnum._POWERS[1] == (0xbaaee17fa23ebf76, -1193)
+    assert textnum._POWERS[44] == (0x9c40000000000000, -50)          # 10^4, exact
+    assert textnum._POWERS[86][1] == 1066
+
+
+def test_dtoa_reproduces_every_number_the_reference_printed(golden_dir):
+    pat = re.compile(r"(?<![\w.])-?\d+\.\d+(?:e-?\d+)?(?![\w.])")
+    n = 0
+    for case in ("pairs", "clones"):
+        d = os.path.join(golden_dir, case)
+        for f in sorted(os.listdir(d)):
+            if f.startswith("out_") and not f.endswith(".ktsv"):
+                for tok in pat.findall(open(os.path.join(d, f), errors="replace").read()):
+                    assert textnum.dtoa(float(tok)) == tok, (f, tok)
+                    n += 1
+    assert n > 2000
+
+
+def test_dtoa_roundtrip_random():
+    rng = np.random.default_rng(3)
+    for v in rng.random(3000) * 200:
+        assert float(textnum.dtoa(float(v))) == float(v)
+    for v in rng.random(3000).astype(np.float32) * np.float32(100):
+        assert float(textnum.dtoa(float(v))) == float(v)
+    assert textnum.dtoa(0.0) == "0.0" and textnum.dtoa(1e21) == "1e21" and textnum.dtoa(100.0) == "100.0"
+
+
+def test_index_files_roundtrip(tmp_path, golden_dir):
+    d, ix = helpers.load_case("pairs")
+    assert ix.n == int(open(os.path.join(d, "idx_info.txt")).read())
+    assert (np.diff(ix.kmer.astype(np.float64)) >= 0).all()
+    # our trie/frequency derivation equals what the reference's build wrote
+    tp, tc = formats.trie_from_kmers(ix.kmer)
+    assert np.array_equal(tp, ix.trie_prefix) and np.array_equal(tc, ix.trie_count)
+    assert np.array_equal(formats.freq_from_index(ix.kmer, ix.tax, ix.content.n_taxa), ix.freq)
+    formats.write_index(ix, str(tmp_path / "idx"), str(tmp_path / "content.txt"))
+    ix2 = formats.load_index(str(tmp_path / "idx"), str(tmp_path / "content.txt"))
+    assert np.array_equal(ix2.kmer, ix.kmer) and np.array_equal(ix2.tax, ix.tax)
+    assert np.array_equal(ix2.freq, ix.freq)
+
+
+def test_read_parsing_matches_reference_conventions(golden_dir):
+    d = os.path.join(golden_dir, "pairs")
+    fq = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    fa = reads.parse_reads(os.path.join(d, "reads.fasta"))
+    assert fq.n == fa.n and fq.names == fa.names
+    assert np.array_equal(fq.bases, fa.bases)
+    assert fq.names[0].endswith(" ")
+    assert int(fq.lengths[0]) == 151                     # one sequence line: +1
+    assert int(fa.lengths[0]) == 150 + 3                 # three 60-column lines: +3
+    with pytest.raises(RuntimeError):
+        p = os.path.join(str(d), "..", "PROVENANCE.json")
+        reads.parse_reads(p)
