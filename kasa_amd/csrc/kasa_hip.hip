@@ -224,6 +224,7 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
     kasa_device_count(&ndev);
     if (device < 0 || device >= ndev) return fail(KASA_E_HIP, "kasa_index_create: no HIP device %d (found %d)", device, ndev);
     HIPCHK(hipSetDevice(device));
+    (void)hipGetLastError(); // do not inherit a stale sticky error from unrelated earlier calls
 
     kasa_index *ix = new (std::nothrow) kasa_index();
     if (!ix) return fail(KASA_E_NOMEM, "host allocation failed");
@@ -345,6 +346,7 @@ struct StageTimer {
 
 struct kasa_ctx {
     const kasa_index *ix = nullptr;
+    int device = 0;
     int kHigh = 12, kLow = 7, nK = 6, frames = 3;
     hipStream_t stream = nullptr;
     // batch state
@@ -440,7 +442,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     HIPCHK(hipSetDevice(ix->device));
     kasa_ctx *c = new (std::nothrow) kasa_ctx();
     if (!c) return fail(KASA_E_NOMEM, "host allocation failed");
-    c->ix = ix; c->kHigh = kHigh; c->kLow = kLow; c->nK = kHigh - kLow + 1; c->frames = frames;
+    c->ix = ix; c->device = ix->device; c->kHigh = kHigh; c->kLow = kLow; c->nK = kHigh - kLow + 1; c->frames = frames;
     auto bail = [&](int code) { kasa_ctx_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
     uint8_t lut[366];
@@ -460,7 +462,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
 extern "C" void kasa_ctx_destroy(kasa_ctx *c)
 {
     if (!c) return;
-    if (c->ix) (void)hipSetDevice(c->ix->device);
+    (void)hipSetDevice(c->device); // the index may already be gone: never touch it here
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,

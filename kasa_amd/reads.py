@@ -32,7 +32,8 @@ class ReadBatch:
 
     def slice(self, a: int, b: int) -> "ReadBatch":
         o = self.offsets[a:b + 1]
-        return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], self.names[a:b], self.lengths[a:b])
+        names = self.names[a:b] if self.names is not None else None
+        return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b])
 
 
 def _open(path: str):

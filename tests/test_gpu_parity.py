@@ -170,10 +170,12 @@ def test_empty_and_degenerate_batches():
     assert ctx.scores()[0].tolist() == [0, 0, 0, 0]
     with pytest.raises(RuntimeError):
         capi.Context(dix, 13, 7, 3)
+    ctx2 = capi.Context(dix, 12, 7, 3)
     with pytest.raises(RuntimeError):
-        ctx2 = capi.Context(dix, 12, 7, 3)
-        ctx2.sort_and_range()
-    ctx.close(); dix.close()
+        ctx2.sort_and_range()                        # nothing encoded yet
+    with pytest.raises(RuntimeError):
+        ctx2.scores()
+    ctx2.close(); ctx.close(); dix.close()
 
 
 def test_coverage_counts_groups():
