@@ -23,7 +23,7 @@ EXPORTS = [
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_fetch_queries",
-    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries",
+    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
 ]
 
 
@@ -216,6 +216,14 @@ class Context:
         b = C.c_uint64(0)
         _check(lib().kasa_ctx_device_bytes(self.h, C.byref(b)))
         return int(b.value)
+
+    def force_slow_score(self, on: bool):
+        _check(lib().kasa_ctx_debug(self.h, C.c_int(int(on)), None))
+
+    def last_slow_reads(self) -> int:
+        n = C.c_uint32(0)
+        _check(lib().kasa_ctx_debug(self.h, C.c_int(-1), C.byref(n)))
+        return int(n.value)
 
     def synchronize(self):
         _check(lib().kasa_ctx_synchronize(self.h))

@@ -45,6 +45,7 @@ static constexpr int ITEMS = TILE / TILE_THREADS; // 4
 static constexpr uint32_t NOPOS = 0xFFFFFFFFu;
 static constexpr int PCAP = 1024;                 // pending (not yet flushed) groups per read
 static constexpr uint32_t REF_SINGLE = 0x80000000u;
+static constexpr uint32_t REF_PAIR = 0x40000000u;
 static constexpr int TLIST = 256;                // touched taxa of a read kept as a list (else dense scan)
 
 static thread_local std::string g_err;
@@ -363,7 +364,8 @@ struct kasa_ctx {
     DevBuf tileFirst, tileNext;                // u32[nK][nTiles]
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
-    DevBuf scratch, touched;                   // per-block dense score rows + touched lists
+    DevBuf scratch, touched, fbList;           // per-block dense score rows; reads left to the slow kernel
+    bool forceSlowScore = false; uint32_t lastSlowReads = 0;
     DevBuf rowPos, rowLen, rowOff, stTax, stScore, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllLo; // u64[nK*nTaxa] each
     uint64_t poolCap = 0, stCap = 0, nnz = 0;
@@ -466,7 +468,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->touched, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -810,24 +812,36 @@ __device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
 }
 
 // Taxon set of the index group (letters shared >= g) around entry j (BitArray.hpp:98-117 semantics:
-// distinct taxa in index order).  One taxon -> REF_SINGLE | taxon, otherwise an offset into `pool`
-// where {n, taxon_1..n} is appended.
+// distinct taxa in index order), encoded in 32 bits:
+//   REF_SINGLE | taxon                      one taxon
+//   REF_PAIR | taxonA << 15 | taxonB        two taxa, both < 2^15 (index order)
+//   offset into `pool`                      {n, taxon_1..n} appended there
 __device__ uint32_t group_taxa(uint32_t j, int g, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
                                uint32_t nIdx, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor,
                                bool coverage, uint64_t *__restrict__ cntTotalLv)
 {
-    uint32_t a = j;
-    while (a > 0 && (meta[a] & 15) >= g) --a;
-    uint32_t b = j + 1;
-    while (b < nIdx && (meta[b] & 15) >= g) ++b;
-    uint32_t n = 0;
-    for (uint32_t i = a; i < b; ++i) n += ((meta[i] >> 4) < g) ? 1u : 0u;
-    if (coverage)
-        for (uint32_t i = a; i < b; ++i)
-            if ((meta[i] >> 4) < g) atomicAdd((unsigned long long *)&cntTotalLv[tax[i]], 1ull);
-    if (n == 1) return REF_SINGLE | tax[a];
+    uint32_t a = j, b = j + 1;
+    const bool openLeft = (j > 0) && (meta[j] & 15) >= g;
+    const bool openRight = (b < nIdx) && (meta[b] & 15) >= g;
+    if (!openLeft && !openRight) {                       // the group is this one entry (the common case)
+        const uint32_t t0 = tax[j];
+        if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[t0], 1ull);
+        return REF_SINGLE | t0;
+    }
+    if (openLeft) { --a; while (a > 0 && (meta[a] & 15) >= g) --a; }
+    if (openRight) { ++b; while (b < nIdx && (meta[b] & 15) >= g) ++b; }
+    uint32_t n = 0, t0 = 0, t1 = 0;
+    for (uint32_t i = a; i < b; ++i)
+        if ((meta[i] >> 4) < g) {
+            const uint32_t tx = tax[i];
+            if (n == 0) t0 = tx; else if (n == 1) t1 = tx;
+            ++n;
+            if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[tx], 1ull);
+        }
+    if (n == 1) return REF_SINGLE | t0;
+    if (n == 2 && t0 < 32768u && t1 < 32768u) return REF_PAIR | (t0 << 15) | t1;
     const uint32_t off = atomicAdd(poolCursor, n + 1);
-    if (off + n + 1 > poolCap) return 0x7FFFFFFFu; // overflow: the host grows the pool and reruns
+    if (off + n + 1 > poolCap || off + n + 1 >= REF_PAIR) return REF_PAIR - 1; // overflow: the host grows the pool and reruns
     pool[off] = n;
     uint32_t w = off + 1;
     for (uint32_t i = a; i < b; ++i)
@@ -918,7 +932,24 @@ struct ScoreArgs {
     uint64_t *cntUnique, *cntAllHi, *cntAllLo;
     uint32_t *rowPos, *rowLen; uint32_t *stTax; float *stScore; uint32_t stCap; uint32_t *stCursor;
     uint32_t *errFlag; int wantPerRead;
+    int addProfile;                              // 0 on a rerun that only re-emits rows
+    const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
+    uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
 };
+
+// c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
+// is c * floor(2^64 / n)) and independent of the order in which waves arrive.
+__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *loTab, size_t cell, uint32_t c, uint32_t n)
+{
+    if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
+    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
+    if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
+    const uint64_t loAdd = (uint64_t)c * R;
+    uint64_t hiAdd = __umul64hi((uint64_t)c, R);
+    const uint64_t old = atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)loAdd);
+    if (old + loAdd < old) ++hiAdd;
+    if (hiAdd) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hiAdd);
+}
 
 __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 {
@@ -931,7 +962,9 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     const int nK = A.kHigh - A.kLow + 1;
     float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
 
-    for (uint32_t r = blockIdx.x; r < A.nReads; r += gridDim.x) {
+    const uint32_t nWork = A.list ? A.nList : A.nReads;
+    for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
+        const uint32_t r = A.list ? A.list[wi] : wi;
         const uint64_t o0 = A.kmerOff[r];
         const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
         int head = 0, tail = 0;            // pending window [head, tail), sorted by (F, k) ascending
@@ -944,13 +977,14 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
             const int k = pK[e];
             const uint32_t c = pCnt[e];
             const int lv = A.kHigh - k;
-            uint32_t n; const uint32_t *list; uint32_t single;
-            if (ref & REF_SINGLE) { n = 1; single = ref & 0x7FFFFFFFu; list = &single; }
-            else { n = A.pool[ref]; list = A.pool + ref + 1; single = 0; }
+            uint32_t n; const uint32_t *list; uint32_t single = 0, pairB = 0;
+            if (ref & REF_SINGLE) { n = 1; single = ref & 0x7FFFFFFFu; list = nullptr; }
+            else if (ref & REF_PAIR) { n = 2; single = (ref >> 15) & 0x7FFFu; pairB = ref & 0x7FFFu; list = nullptr; }
+            else { n = A.pool[ref]; list = A.pool + ref + 1; }
             const float w = (float)(k * k) / 625.0f;                         // Compare.hpp:392
             const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));         // Compare.hpp:924
             for (uint32_t i = 0; i < n; ++i) {
-                const uint32_t tx = (n == 1) ? single : list[i];
+                const uint32_t tx = list ? list[i] : (i == 0 ? single : pairB);
                 if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
                 if (A.wantPerRead) {
                     float v = score[tx];
@@ -958,19 +992,10 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);    // Compare.hpp:528-530, one add per hit
                     score[tx] = v;
                 }
-                const size_t cell = (size_t)lv * A.nTaxa + tx;
-                if (n == 1) {
-                    atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
-                    atomicAdd((unsigned long long *)&A.cntAllHi[cell], (unsigned long long)c);
-                } else {
-                    // c / n as 64.64 fixed point: c * floor(2^64 / n)
-                    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
-                    if ((n & (n - 1)) == 0) R += 1;                          // n divides 2^64
-                    const uint64_t loAdd = (uint64_t)c * R;
-                    uint64_t hiAdd = __umul64hi((uint64_t)c, R);
-                    const uint64_t old = atomicAdd((unsigned long long *)&A.cntAllLo[cell], (unsigned long long)loAdd);
-                    if (old + loAdd < old) ++hiAdd;
-                    if (hiAdd) atomicAdd((unsigned long long *)&A.cntAllHi[cell], (unsigned long long)hiAdd);
+                if (A.addProfile) {
+                    const size_t cell = (size_t)lv * A.nTaxa + tx;
+                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
+                    fixed_add(A.cntAllHi, A.cntAllLo, cell, c, n);
                 }
             }
         };
@@ -1074,6 +1099,152 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain, so
+// 64 reads run side by side in a wavefront; the small per-read state (pending groups, a handful of
+// taxa with their score and per-level profile counters) lives in LDS, strided by lane.  A read that
+// does not fit (more than FPL groups pending, more than FTA taxa, a taxon set larger than 4, more
+// than FNK levels) is handed to score_kernel untouched: nothing of it has reached global memory.
+// ------------------------------------------------------------------------------------------------
+static constexpr int FPL = 12;
+static constexpr int FTA = 4;
+static constexpr int FNK = 6;
+
+__global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
+{
+    __shared__ uint32_t pF[FPL][64], pRef[FPL][64], pKC[FPL][64];   // pKC = k | hits << 8
+    __shared__ uint32_t aTax[FTA][64];
+    __shared__ float aScore[FTA][64];
+    __shared__ uint16_t aCnt[FTA][FNK][4][64];                      // hits per (taxon, level, |T| = 1..4)
+    const int lane = threadIdx.x;
+    const int nK = A.kHigh - A.kLow + 1;
+    const uint32_t stride = gridDim.x * 64u;
+    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
+        const uint32_t r = base + lane;
+        const bool active = r < A.nReads;
+        bool fb = false;
+        int np = 0, na = 0;
+        if (active) {
+            const uint64_t o0 = A.kmerOff[r];
+            const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
+            if (cnt > 60000u) fb = true;                               // 16-bit counters
+
+            auto apply = [&](int e) {
+                const uint32_t ref = pRef[e][lane];
+                const uint32_t kc = pKC[e][lane];
+                const int k = (int)(kc & 255u);
+                const uint32_t c = kc >> 8;
+                const int lv = A.kHigh - k;
+                uint32_t n, tx[4];
+                if (ref & REF_SINGLE) { n = 1; tx[0] = ref & 0x7FFFFFFFu; }
+                else if (ref & REF_PAIR) { n = 2; tx[0] = (ref >> 15) & 0x7FFFu; tx[1] = ref & 0x7FFFu; }
+                else {
+                    n = A.pool[ref];
+                    if (n > 4) { fb = true; return; }
+                    for (uint32_t i = 0; i < n; ++i) tx[i] = A.pool[ref + 1 + i];
+                }
+                const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
+                const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));       // Compare.hpp:924
+                for (uint32_t i = 0; i < n; ++i) {
+                    int e2 = 0;
+                    while (e2 < na && aTax[e2][lane] != tx[i]) ++e2;
+                    if (e2 == na) {
+                        if (na == FTA) { fb = true; return; }
+                        aTax[na][lane] = tx[i];
+                        aScore[na][lane] = 0.0f;
+                        for (int l2 = 0; l2 < FNK; ++l2)
+                            for (int q = 0; q < 4; ++q) aCnt[na][l2][q][lane] = 0;
+                        ++na;
+                    }
+                    float v = aScore[e2][lane];
+                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);      // Compare.hpp:528-530
+                    aScore[e2][lane] = v;
+                    aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c);
+                }
+            };
+
+            for (uint32_t j = 0; j < cnt && !fb; ++j) {
+                const uint32_t p = A.plist[o0 + j];
+                int nf = 0;
+                while (nf < np && !fb && pF[nf][lane] <= p) { apply(nf); ++nf; }   // flushed before p
+                if (nf) {
+                    for (int i = nf; i < np; ++i) { pF[i - nf][lane] = pF[i][lane]; pRef[i - nf][lane] = pRef[i][lane]; pKC[i - nf][lane] = pKC[i][lane]; }
+                    np -= nf;
+                }
+                const uint2 *rp = A.rec + (size_t)p * nK;
+                for (int lv = nK - 1; lv >= 0 && !fb; --lv) {                  // k ascending
+                    const uint2 v = rp[lv];
+                    if (v.y == 0) continue;
+                    const uint32_t k = (uint32_t)(A.kHigh - lv);
+                    int pos = np;                                              // insertion point from the back
+                    while (pos > 0) {
+                        const uint32_t eF = pF[pos - 1][lane];
+                        const uint32_t eK = pKC[pos - 1][lane] & 255u;
+                        if (eF > v.x || (eF == v.x && eK > k)) --pos; else break;
+                    }
+                    if (pos > 0 && pF[pos - 1][lane] == v.x && (pKC[pos - 1][lane] & 255u) == k) {
+                        pKC[pos - 1][lane] += 256u;                            // same group again
+                        continue;
+                    }
+                    if (np == FPL) { fb = true; break; }
+                    for (int i = np; i > pos; --i) { pF[i][lane] = pF[i - 1][lane]; pRef[i][lane] = pRef[i - 1][lane]; pKC[i][lane] = pKC[i - 1][lane]; }
+                    pF[pos][lane] = v.x; pRef[pos][lane] = v.y; pKC[pos][lane] = k | 256u;
+                    ++np;
+                }
+            }
+            for (int i = 0; i < np && !fb; ++i) apply(i);
+            if (!fb) {                                                         // taxon ascending (<= FTA entries)
+                for (int i = 1; i < na; ++i)
+                    for (int j2 = i; j2 > 0 && aTax[j2 - 1][lane] > aTax[j2][lane]; --j2) {
+                        const uint32_t tt = aTax[j2][lane]; aTax[j2][lane] = aTax[j2 - 1][lane]; aTax[j2 - 1][lane] = tt;
+                        const float ss = aScore[j2][lane]; aScore[j2][lane] = aScore[j2 - 1][lane]; aScore[j2 - 1][lane] = ss;
+                        for (int l2 = 0; l2 < FNK; ++l2)
+                            for (int q = 0; q < 4; ++q) {
+                                const uint16_t cc = aCnt[j2][l2][q][lane]; aCnt[j2][l2][q][lane] = aCnt[j2 - 1][l2][q][lane]; aCnt[j2 - 1][l2][q][lane] = cc;
+                            }
+                    }
+            }
+        }
+        // ---- converged: one staging allocation per wavefront
+        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)na : 0u;
+        uint32_t incl = m;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t start = 0;
+        if (lane == 0 && total) start = atomicAdd(A.stCursor, total);
+        start = __shfl(start, 0) + (incl - m);
+        if (active && !fb) {
+            if (A.wantPerRead) {
+                A.rowPos[r] = start; A.rowLen[r] = m;
+                if (start + m <= A.stCap)
+                    for (uint32_t i = 0; i < m; ++i) { A.stTax[start + i] = aTax[i][lane]; A.stScore[start + i] = aScore[i][lane]; }
+            }
+            if (A.addProfile)
+                for (int e = 0; e < na; ++e)
+                    for (int lv = 0; lv < nK; ++lv) {
+                        const size_t cell = (size_t)lv * A.nTaxa + aTax[e][lane];
+                        const uint32_t c1 = aCnt[e][lv][0][lane];
+                        if (c1) { atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c1); fixed_add(A.cntAllHi, A.cntAllLo, cell, c1, 1); }
+                        for (uint32_t q = 1; q < 4; ++q) {
+                            const uint32_t cq = aCnt[e][lv][q][lane];
+                            if (cq) fixed_add(A.cntAllHi, A.cntAllLo, cell, cq, q + 1);
+                        }
+                    }
+        }
+        const unsigned long long fbMask = __ballot(active && fb);
+        if (fbMask) {
+            uint32_t fbBase = 0;
+            if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
+            fbBase = __shfl(fbBase, 0);
+            if (active && fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+}
+
+
 __global__ void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
                                 const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
@@ -1126,7 +1297,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
         group_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x7FFFFFF0ull),
+            c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull),
             counters, coverage && attempt == 0, c->cntTotal.as<uint64_t>(), nTaxa);
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
@@ -1134,7 +1305,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         HIPCHK(hipMemcpyAsync(&used, counters, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (used <= c->poolCap) break;
-        if ((uint64_t)used >= 0x7FFFFFF0ull) return fail(KASA_E_LIMIT, "taxon-list pool exceeds 2^31 entries in one batch; split the batch");
+        if ((uint64_t)used >= 0x3FFFFFF0ull) return fail(KASA_E_LIMIT, "taxon-list pool exceeds 2^30 entries in one batch; split the batch");
         c->poolCap = (uint64_t)used + used / 8 + 1024;
         if (attempt > 3) return fail(KASA_E_LIMIT, "taxon-list pool did not converge");
     }
@@ -1156,45 +1327,50 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
     if ((rc = timer_end(c, c->timers[KASA_STAGE_REGROUP], a, b))) return rc;
 
     // ---- score
-    const uint32_t blocks = std::min<uint32_t>(nReads, 256u * 16u);
-    if ((rc = c->scratch.reserve((size_t)blocks * nTaxa * 4))) return rc;
     if (wantPerRead) {
         if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
             (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)))
             return rc;
-        if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 4);
+        if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 3);
     }
-    // profile tables are accumulated by the score kernel with integer atomics: a rerun (staging
-    // overflow) must not count twice, so the first pass runs with a generous staging area and a
-    // rerun only re-emits rows (wantPerRead = 2: no profile adds)
+    if ((rc = c->fbList.reserve((size_t)nReads * 4 + 64))) return rc;
+    // The profile tables are accumulated with integer atomics inside the score kernels; a rerun after
+    // a staging overflow must not count twice, so reruns only re-emit rows (addProfile = 0).
     for (int attempt = 0;; ++attempt) {
         if (wantPerRead && ((rc = c->stTax.reserve(c->stCap * 4)) || (rc = c->stScore.reserve(c->stCap * 4)))) return rc;
-        HIPCHK(hipMemsetAsync(counters + 1, 0, 8, c->stream));
-        HIPCHK(hipMemsetAsync(c->scratch.p, 0, (size_t)blocks * nTaxa * 4, c->stream));
+        HIPCHK(hipMemsetAsync(counters + 1, 0, 12, c->stream)); // staging cursor, error flags, fallback count
         ScoreArgs A;
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
-        A.scratch = c->scratch.as<float>();
+        A.scratch = nullptr;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
         A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
         A.wantPerRead = wantPerRead ? 1 : 0;
+        A.addProfile = attempt == 0 ? 1 : 0;
+        A.list = nullptr; A.nList = 0;
+        A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
-        if (attempt == 0) {
-            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
-        } else {
-            // second pass writes its profile adds into throw-away tables
-            DevBuf junk;
-            const size_t cells = (size_t)nK * nTaxa * 8;
-            if ((rc = junk.reserve(cells * 3))) return rc;
-            HIPCHK(hipMemsetAsync(junk.p, 0, cells * 3, c->stream));
-            A.cntUnique = junk.as<uint64_t>(); A.cntAllHi = A.cntUnique + (size_t)nK * nTaxa; A.cntAllLo = A.cntAllHi + (size_t)nK * nTaxa;
-            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
+        uint32_t nSlow = nReads;
+        const bool fast = nK <= FNK && !c->forceSlowScore;
+        if (fast) {
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 32u);
+            score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&nSlow, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            junk.release();
+            A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
-        HIPCHK(hipGetLastError());
+        if (nSlow > 0) {
+            const uint32_t blocks = std::min<uint32_t>(nSlow, 256u * 16u);
+            if ((rc = c->scratch.reserve((size_t)blocks * nTaxa * 4))) return rc;
+            HIPCHK(hipMemsetAsync(c->scratch.p, 0, (size_t)blocks * nTaxa * 4, c->stream));
+            A.scratch = c->scratch.as<float>();
+            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
+            HIPCHK(hipGetLastError());
+        }
+        c->lastSlowReads = nSlow;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
         uint32_t h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, counters + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1403,11 +1579,19 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->touched, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlowReads)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (forceSlowScore >= 0) c->forceSlowScore = forceSlowScore != 0;
+    if (lastSlowReads) *lastSlowReads = c->lastSlowReads;
     return KASA_OK;
 }
 

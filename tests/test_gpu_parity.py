@@ -76,8 +76,9 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
         ctx.close(); dix.close()
 
 
+@pytest.mark.parametrize("slow", [False, True], ids=["fast+fallback", "slow_only"])
 @pytest.mark.parametrize("seed", range(24))
-def test_adversarial_queries_vs_oracle(seed):
+def test_adversarial_queries_vs_oracle(seed, slow):
     """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles."""
     _gpu_or_fail()
     rng = np.random.default_rng(5000 + seed)
@@ -95,6 +96,7 @@ def test_adversarial_queries_vs_oracle(seed):
     res = oracle.compare(iv, p, qs, rs_, a, b, n_reads, True, closed_form=False)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, k_high, k_low, 3)
+    ctx.force_slow_score(slow)
     ctx.set_queries(q, rd, n_reads)
     ctx.sort_and_range()
     ctx.lookup_score(True, coverage=False)
@@ -138,12 +140,18 @@ def test_medium_synthetic_vs_oracle():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    ctx.run_batch(batch.bases, batch.offsets, True)
-    assert ctx.n_kmers == nq
-    ca, cu, _ = ctx.profile()
-    assert np.array_equal(cu, res.count_unique)
-    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
-    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    for slow in (False, True):
+        ctx.force_slow_score(slow)
+        ctx.profile_reset()
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        assert ctx.n_kmers == nq
+        ca, cu, _ = ctx.profile()
+        assert np.array_equal(cu, res.count_unique)
+        np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+        assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+        if not slow:
+            assert ctx.last_slow_reads() < batch.n // 10      # the lane-per-read path carries the load
+    ctx.force_slow_score(False)
     # profile-only mode gives the same tables; batches accumulate
     ctx.profile_reset()
     half = batch.n // 2
