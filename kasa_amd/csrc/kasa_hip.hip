@@ -364,7 +364,7 @@ struct kasa_ctx {
     DevBuf tileFirst, tileNext;                // u32[nK][nTiles]
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
-    DevBuf scratch, touched, fbList;           // per-block dense score rows; reads left to the slow kernel
+    DevBuf scratch, touched, fbList, fastScratch;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0;
     DevBuf rowPos, rowLen, rowOff, stTax, stScore, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllLo; // u64[nK*nTaxa] each
@@ -468,7 +468,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -935,6 +935,7 @@ struct ScoreArgs {
     int addProfile;                              // 0 on a rerun that only re-emits rows
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
+    uint32_t *ovTax; float *ovScore; uint32_t *logCell, *logNC; // fast kernel: per-lane scratch [i * lanes + lane]
 };
 
 // c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
@@ -1106,9 +1107,12 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // does not fit (more than FPL groups pending, more than FTA taxa, a taxon set larger than 4, more
 // than FNK levels) is handed to score_kernel untouched: nothing of it has reached global memory.
 // ------------------------------------------------------------------------------------------------
-static constexpr int FPL = 12;
-static constexpr int FTA = 4;
-static constexpr int FNK = 6;
+static constexpr int FPL = 12;      // pending groups per read
+static constexpr int FTA = 4;       // taxa with per-level counters in LDS (first come)
+static constexpr int FNK = 6;       // levels
+static constexpr int FOV = 192;     // further taxa of a read: (taxon, score) in per-lane global scratch
+static constexpr int FLOG = 256;    // their profile contributions, logged and added at the end of the read
+static constexpr uint32_t ROW_UNSORTED = 0x80000000u;
 
 __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
 {
@@ -1118,12 +1122,17 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     __shared__ uint16_t aCnt[FTA][FNK][4][64];                      // hits per (taxon, level, |T| = 1..4)
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
-    const uint32_t stride = gridDim.x * 64u;
-    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
+    const uint32_t lanes = gridDim.x * 64u;
+    const uint32_t gl = blockIdx.x * 64u + lane;
+    uint32_t *ovTax = A.ovTax + gl;            // element i at [i * lanes]
+    float *ovScore = A.ovScore + gl;
+    uint32_t *logCell = A.logCell + gl;
+    uint32_t *logNC = A.logNC + gl;
+    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += lanes) {
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
         bool fb = false;
-        int np = 0, na = 0;
+        int np = 0, na = 0, no = 0, nl = 0;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
@@ -1146,20 +1155,38 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
                 const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));       // Compare.hpp:924
                 for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t t = tx[i];
                     int e2 = 0;
-                    while (e2 < na && aTax[e2][lane] != tx[i]) ++e2;
-                    if (e2 == na) {
-                        if (na == FTA) { fb = true; return; }
-                        aTax[na][lane] = tx[i];
+                    while (e2 < na && aTax[e2][lane] != t) ++e2;
+                    if (e2 == na && na < FTA) {
+                        aTax[na][lane] = t;
                         aScore[na][lane] = 0.0f;
                         for (int l2 = 0; l2 < FNK; ++l2)
                             for (int q = 0; q < 4; ++q) aCnt[na][l2][q][lane] = 0;
                         ++na;
                     }
-                    float v = aScore[e2][lane];
-                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);      // Compare.hpp:528-530
-                    aScore[e2][lane] = v;
-                    aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c);
+                    if (e2 < FTA) {
+                        float v = aScore[e2][lane];
+                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530
+                        aScore[e2][lane] = v;
+                        aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c);
+                        continue;
+                    }
+                    int o = 0;
+                    while (o < no && ovTax[(size_t)o * lanes] != t) ++o;
+                    if (o == no) {
+                        if (no == FOV) { fb = true; return; }
+                        ovTax[(size_t)o * lanes] = t;
+                        ovScore[(size_t)o * lanes] = 0.0f;
+                        ++no;
+                    }
+                    float v = ovScore[(size_t)o * lanes];
+                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
+                    ovScore[(size_t)o * lanes] = v;
+                    if (nl == FLOG) { fb = true; return; }
+                    logCell[(size_t)nl * lanes] = (uint32_t)lv * A.nTaxa + t;
+                    logNC[(size_t)nl * lanes] = (n << 24) | c;
+                    ++nl;
                 }
             };
 
@@ -1193,20 +1220,9 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 }
             }
             for (int i = 0; i < np && !fb; ++i) apply(i);
-            if (!fb) {                                                         // taxon ascending (<= FTA entries)
-                for (int i = 1; i < na; ++i)
-                    for (int j2 = i; j2 > 0 && aTax[j2 - 1][lane] > aTax[j2][lane]; --j2) {
-                        const uint32_t tt = aTax[j2][lane]; aTax[j2][lane] = aTax[j2 - 1][lane]; aTax[j2 - 1][lane] = tt;
-                        const float ss = aScore[j2][lane]; aScore[j2][lane] = aScore[j2 - 1][lane]; aScore[j2 - 1][lane] = ss;
-                        for (int l2 = 0; l2 < FNK; ++l2)
-                            for (int q = 0; q < 4; ++q) {
-                                const uint16_t cc = aCnt[j2][l2][q][lane]; aCnt[j2][l2][q][lane] = aCnt[j2 - 1][l2][q][lane]; aCnt[j2 - 1][l2][q][lane] = cc;
-                            }
-                    }
-            }
         }
         // ---- converged: one staging allocation per wavefront
-        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)na : 0u;
+        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)(na + no) : 0u;
         uint32_t incl = m;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
@@ -1218,11 +1234,13 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
         start = __shfl(start, 0) + (incl - m);
         if (active && !fb) {
             if (A.wantPerRead) {
-                A.rowPos[r] = start; A.rowLen[r] = m;
-                if (start + m <= A.stCap)
-                    for (uint32_t i = 0; i < m; ++i) { A.stTax[start + i] = aTax[i][lane]; A.stScore[start + i] = aScore[i][lane]; }
+                A.rowPos[r] = start; A.rowLen[r] = m | (m > 1 ? ROW_UNSORTED : 0u);
+                if (start + m <= A.stCap) {
+                    for (int i = 0; i < na; ++i) { A.stTax[start + i] = aTax[i][lane]; A.stScore[start + i] = aScore[i][lane]; }
+                    for (int i = 0; i < no; ++i) { A.stTax[start + na + i] = ovTax[(size_t)i * lanes]; A.stScore[start + na + i] = ovScore[(size_t)i * lanes]; }
+                }
             }
-            if (A.addProfile)
+            if (A.addProfile) {
                 for (int e = 0; e < na; ++e)
                     for (int lv = 0; lv < nK; ++lv) {
                         const size_t cell = (size_t)lv * A.nTaxa + aTax[e][lane];
@@ -1233,6 +1251,14 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                             if (cq) fixed_add(A.cntAllHi, A.cntAllLo, cell, cq, q + 1);
                         }
                     }
+                for (int i = 0; i < nl; ++i) {
+                    const size_t cell = logCell[(size_t)i * lanes];
+                    const uint32_t nc = logNC[(size_t)i * lanes];
+                    const uint32_t n = nc >> 24, c = nc & 0xFFFFFFu;
+                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
+                    fixed_add(A.cntAllHi, A.cntAllLo, cell, c, n);
+                }
+            }
         }
         const unsigned long long fbMask = __ballot(active && fb);
         if (fbMask) {
@@ -1244,22 +1270,59 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     }
 }
 
-
-__global__ void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
+// Rows of the staging area -> CSR in read order; rows the fast path left unsorted (<= FTA + FOV entries)
+// are sorted by taxon on the way: one wavefront per row, bitonic in LDS.
+__global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
                                 const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nReads) return;
-    const uint32_t s = rowPos[r], m = rowLen[r];
-    const uint64_t o = rowOff[r];
-    for (uint32_t i = 0; i < m; ++i) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
+    __shared__ uint32_t sT[4][256];
+    __shared__ float sS[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += waves) {
+        const uint32_t s = rowPos[r];
+        const uint32_t raw = rowLen[r];
+        const uint32_t m = raw & ~ROW_UNSORTED;
+        const uint64_t o = rowOff[r];
+        if (!(raw & ROW_UNSORTED) || m > 256u) {
+            for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
+            continue;
+        }
+        uint32_t n2 = 2;
+        while (n2 < m) n2 <<= 1;
+        for (uint32_t i = lane; i < n2; i += 64) {
+            sT[wv][i] = (i < m) ? stTax[s + i] : 0xFFFFFFFFu;
+            sS[wv][i] = (i < m) ? stScore[s + i] : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t size = 2; size <= n2; size <<= 1)
+            for (uint32_t st = size >> 1; st > 0; st >>= 1) {
+                for (uint32_t i = lane; i < n2; i += 64) {
+                    const uint32_t j = i ^ st;
+                    if (j > i) {
+                        const bool up = (i & size) == 0;
+                        const uint32_t a = sT[wv][i], b = sT[wv][j];
+                        if ((a > b) == up) {
+                            sT[wv][i] = b; sT[wv][j] = a;
+                            const float fa = sS[wv][i]; sS[wv][i] = sS[wv][j]; sS[wv][j] = fa;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = sT[wv][i]; outScore[o + i] = sS[wv][i]; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 __global__ void widen_kernel(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i];
+    if (i < n) out[i] = in[i] & 0x7FFFFFFFu;   // bit 31 = ROW_UNSORTED
 }
 
 extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverage)
@@ -1342,7 +1405,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         ScoreArgs A;
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
-        A.scratch = nullptr;
+        A.scratch = nullptr; A.ovTax = nullptr; A.ovScore = nullptr; A.logCell = nullptr; A.logNC = nullptr;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
@@ -1355,7 +1418,13 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         uint32_t nSlow = nReads;
         const bool fast = nK <= FNK && !c->forceSlowScore;
         if (fast) {
-            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 32u);
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 6u);
+            const size_t lanes = (size_t)fblocks * 64;
+            if ((rc = c->fastScratch.reserve(lanes * (size_t)(FOV + FLOG) * 8))) return rc;
+            A.ovTax = c->fastScratch.as<uint32_t>();
+            A.ovScore = reinterpret_cast<float *>(A.ovTax + lanes * FOV);
+            A.logCell = A.ovTax + lanes * FOV * 2;
+            A.logNC = A.logCell + lanes * FLOG;
             score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(&nSlow, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1394,7 +1463,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
         if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
-        row_copy_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
+        row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
             nReads, c->stTax.as<uint32_t>(), c->stScore.as<float>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1579,7 +1648,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
