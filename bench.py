@@ -153,6 +153,7 @@ def main():
                        "taxa": args.taxa, "parallelism": f"read-sharded x{world}, index replicated"},
             "kmers_per_s": n_kmers * world * args.steps / dt,
             "identified_fraction": identified,
+            "reads_on_general_score_kernel": ctx.last_slow_reads(),
             "stage_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stages.items()},
             "roofline": {"bound": "hbm", "kernel": "lookup_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

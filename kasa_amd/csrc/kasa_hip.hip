@@ -1144,18 +1144,15 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 const int k = (int)(kc & 255u);
                 const uint32_t c = kc >> 8;
                 const int lv = A.kHigh - k;
-                uint32_t n, tx[4];
-                if (ref & REF_SINGLE) { n = 1; tx[0] = ref & 0x7FFFFFFFu; }
-                else if (ref & REF_PAIR) { n = 2; tx[0] = (ref >> 15) & 0x7FFFu; tx[1] = ref & 0x7FFFu; }
-                else {
-                    n = A.pool[ref];
-                    if (n > 4) { fb = true; return; }
-                    for (uint32_t i = 0; i < n; ++i) tx[i] = A.pool[ref + 1 + i];
-                }
+                uint32_t n, t0 = 0, t1 = 0;
+                const uint32_t *list = nullptr;
+                if (ref & REF_SINGLE) { n = 1; t0 = ref & 0x7FFFFFFFu; }
+                else if (ref & REF_PAIR) { n = 2; t0 = (ref >> 15) & 0x7FFFu; t1 = ref & 0x7FFFu; }
+                else { n = A.pool[ref]; list = A.pool + ref + 1; }
                 const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
                 const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));       // Compare.hpp:924
                 for (uint32_t i = 0; i < n; ++i) {
-                    const uint32_t t = tx[i];
+                    const uint32_t t = list ? list[i] : (i == 0 ? t0 : t1);
                     int e2 = 0;
                     while (e2 < na && aTax[e2][lane] != t) ++e2;
                     if (e2 == na && na < FTA) {
@@ -1165,28 +1162,31 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                             for (int q = 0; q < 4; ++q) aCnt[na][l2][q][lane] = 0;
                         ++na;
                     }
+                    bool logIt = true;
                     if (e2 < FTA) {
                         float v = aScore[e2][lane];
                         for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530
                         aScore[e2][lane] = v;
-                        aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c);
-                        continue;
+                        if (n <= 4) { aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c); logIt = false; }
+                    } else {
+                        int o = 0;
+                        while (o < no && ovTax[(size_t)o * lanes] != t) ++o;
+                        if (o == no) {
+                            if (no == FOV) { fb = true; return; }
+                            ovTax[(size_t)o * lanes] = t;
+                            ovScore[(size_t)o * lanes] = 0.0f;
+                            ++no;
+                        }
+                        float v = ovScore[(size_t)o * lanes];
+                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
+                        ovScore[(size_t)o * lanes] = v;
                     }
-                    int o = 0;
-                    while (o < no && ovTax[(size_t)o * lanes] != t) ++o;
-                    if (o == no) {
-                        if (no == FOV) { fb = true; return; }
-                        ovTax[(size_t)o * lanes] = t;
-                        ovScore[(size_t)o * lanes] = 0.0f;
-                        ++no;
+                    if (logIt) {
+                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; return; }
+                        logCell[(size_t)nl * lanes] = (uint32_t)lv * A.nTaxa + t;
+                        logNC[(size_t)nl * lanes] = (n << 16) | c;
+                        ++nl;
                     }
-                    float v = ovScore[(size_t)o * lanes];
-                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
-                    ovScore[(size_t)o * lanes] = v;
-                    if (nl == FLOG) { fb = true; return; }
-                    logCell[(size_t)nl * lanes] = (uint32_t)lv * A.nTaxa + t;
-                    logNC[(size_t)nl * lanes] = (n << 24) | c;
-                    ++nl;
                 }
             };
 
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 for (int i = 0; i < nl; ++i) {
                     const size_t cell = logCell[(size_t)i * lanes];
                     const uint32_t nc = logNC[(size_t)i * lanes];
-                    const uint32_t n = nc >> 24, c = nc & 0xFFFFFFu;
+                    const uint32_t n = nc >> 16, c = nc & 0xFFFFu;
                     if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
                     fixed_add(A.cntAllHi, A.cntAllLo, cell, c, n);
                 }
