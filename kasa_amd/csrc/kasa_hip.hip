@@ -935,7 +935,7 @@ struct ScoreArgs {
     int addProfile;                              // 0 on a rerun that only re-emits rows
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
-    uint32_t *ovTax; float *ovScore; uint32_t *logCell, *logNC; // fast kernel: per-lane scratch [i * lanes + lane]
+    uint32_t *ovTax; float *ovScore; uint32_t *ovUsed, *logCell, *logNC; // fast kernel: per-lane scratch [i * lanes + lane]
 };
 
 // c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
@@ -1110,8 +1110,9 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 static constexpr int FPL = 12;      // pending groups per read
 static constexpr int FTA = 4;       // taxa with per-level counters in LDS (first come)
 static constexpr int FNK = 6;       // levels
-static constexpr int FOV = 192;     // further taxa of a read: (taxon, score) in per-lane global scratch
-static constexpr int FLOG = 256;    // their profile contributions, logged and added at the end of the read
+static constexpr int FOV = 384;     // further taxa of a read: open-addressing table in per-lane global scratch
+static constexpr int FHS = 512;     // ... with this many slots (power of two)
+static constexpr int FLOG = 640;    // their profile contributions, logged and added at the end of the read
 static constexpr uint32_t ROW_UNSORTED = 0x80000000u;
 
 __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
@@ -1124,8 +1125,9 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t lanes = gridDim.x * 64u;
     const uint32_t gl = blockIdx.x * 64u + lane;
-    uint32_t *ovTax = A.ovTax + gl;            // element i at [i * lanes]
+    uint32_t *ovTax = A.ovTax + gl;            // element i at [i * lanes]; hash slots, 0xFFFFFFFF = empty
     float *ovScore = A.ovScore + gl;
+    uint32_t *ovUsed = A.ovUsed + gl;          // slots in insertion order
     uint32_t *logCell = A.logCell + gl;
     uint32_t *logNC = A.logNC + gl;
     for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += lanes) {
@@ -1169,15 +1171,17 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         aScore[e2][lane] = v;
                         if (n <= 4) { aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c); logIt = false; }
                     } else {
-                        int o = 0;
-                        while (o < no && ovTax[(size_t)o * lanes] != t) ++o;
-                        if (o == no) {
+                        uint32_t o = (t * 2654435761u) >> 23;                  // 9 bits
+                        uint32_t cur = ovTax[(size_t)o * lanes];
+                        while (cur != t && cur != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = ovTax[(size_t)o * lanes]; }
+                        float v = 0.0f;
+                        if (cur == t) v = ovScore[(size_t)o * lanes];
+                        else {
                             if (no == FOV) { fb = true; return; }
                             ovTax[(size_t)o * lanes] = t;
-                            ovScore[(size_t)o * lanes] = 0.0f;
+                            ovUsed[(size_t)no * lanes] = o;
                             ++no;
                         }
-                        float v = ovScore[(size_t)o * lanes];
                         for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
                         ovScore[(size_t)o * lanes] = v;
                     }
@@ -1237,7 +1241,10 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 A.rowPos[r] = start; A.rowLen[r] = m | (m > 1 ? ROW_UNSORTED : 0u);
                 if (start + m <= A.stCap) {
                     for (int i = 0; i < na; ++i) { A.stTax[start + i] = aTax[i][lane]; A.stScore[start + i] = aScore[i][lane]; }
-                    for (int i = 0; i < no; ++i) { A.stTax[start + na + i] = ovTax[(size_t)i * lanes]; A.stScore[start + na + i] = ovScore[(size_t)i * lanes]; }
+                    for (int i = 0; i < no; ++i) {
+                        const uint32_t o = ovUsed[(size_t)i * lanes];
+                        A.stTax[start + na + i] = ovTax[(size_t)o * lanes]; A.stScore[start + na + i] = ovScore[(size_t)o * lanes];
+                    }
                 }
             }
             if (A.addProfile) {
@@ -1260,6 +1267,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 }
             }
         }
+        for (int i = 0; i < no; ++i) ovTax[(size_t)ovUsed[(size_t)i * lanes] * lanes] = 0xFFFFFFFFu;
         const unsigned long long fbMask = __ballot(active && fb);
         if (fbMask) {
             uint32_t fbBase = 0;
@@ -1276,8 +1284,8 @@ __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restric
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
                                 const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
 {
-    __shared__ uint32_t sT[4][256];
-    __shared__ float sS[4][256];
+    __shared__ uint32_t sT[4][512];
+    __shared__ float sS[4][512];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t waves = gridDim.x * 4u;
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += waves) {
@@ -1285,7 +1293,7 @@ __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restric
         const uint32_t raw = rowLen[r];
         const uint32_t m = raw & ~ROW_UNSORTED;
         const uint64_t o = rowOff[r];
-        if (!(raw & ROW_UNSORTED) || m > 256u) {
+        if (!(raw & ROW_UNSORTED) || m > 512u) {
             for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
             continue;
         }
@@ -1405,7 +1413,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         ScoreArgs A;
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
-        A.scratch = nullptr; A.ovTax = nullptr; A.ovScore = nullptr; A.logCell = nullptr; A.logNC = nullptr;
+        A.scratch = nullptr; A.ovTax = nullptr; A.ovScore = nullptr; A.ovUsed = nullptr; A.logCell = nullptr; A.logNC = nullptr;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
@@ -1418,13 +1426,15 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         uint32_t nSlow = nReads;
         const bool fast = nK <= FNK && !c->forceSlowScore;
         if (fast) {
-            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 6u);
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 5u);
             const size_t lanes = (size_t)fblocks * 64;
-            if ((rc = c->fastScratch.reserve(lanes * (size_t)(FOV + FLOG) * 8))) return rc;
+            if ((rc = c->fastScratch.reserve(lanes * (size_t)(2 * FHS + FOV + 2 * FLOG) * 4))) return rc;
             A.ovTax = c->fastScratch.as<uint32_t>();
-            A.ovScore = reinterpret_cast<float *>(A.ovTax + lanes * FOV);
-            A.logCell = A.ovTax + lanes * FOV * 2;
+            A.ovScore = reinterpret_cast<float *>(A.ovTax + lanes * FHS);
+            A.ovUsed = A.ovTax + lanes * FHS * 2;
+            A.logCell = A.ovUsed + lanes * FOV;
             A.logNC = A.logCell + lanes * FLOG;
+            HIPCHK(hipMemsetAsync(A.ovTax, 0xFF, lanes * (size_t)FHS * 4, c->stream));
             score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(&nSlow, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
