@@ -73,6 +73,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     from kasa_amd import capi, synth
+    from kasa_amd import dist as kdist
     assert capi.device_count() > local_rank, "no HIP device for this rank"
 
     k_high, k_low = 12, 7
@@ -95,8 +96,7 @@ def main():
         ctx.sort_and_range()
         ctx.lookup_score(want, False)
         if dist is not None:
-            limbs = torch.from_numpy(ctx.profile_limbs().astype(np.int64)).cuda()
-            dist.all_reduce(limbs)                 # RCCL sum of the integer limbs (exact)
+            kdist.allreduce_limbs(ctx.profile_limbs(), device="cuda")   # one RCCL sum of integer limbs (exact)
 
     def fence():
         ctx.synchronize()

@@ -220,6 +220,10 @@ class Context:
     def force_slow_score(self, on: bool):
         _check(lib().kasa_ctx_debug(self.h, C.c_int(int(on)), None))
 
+    def debug_flags(self, flags: int):
+        """bit 0: general score kernel for every read; bit 1: per-query lookup instead of streamed tiles."""
+        _check(lib().kasa_ctx_debug(self.h, C.c_int(int(flags)), None))
+
     def last_slow_reads(self) -> int:
         n = C.c_uint32(0)
         _check(lib().kasa_ctx_debug(self.h, C.c_int(-1), C.byref(n)))

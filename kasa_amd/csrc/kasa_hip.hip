@@ -14,6 +14,7 @@
 // The semantics implemented are the closed form of SURVEY.md section 0.1; tests compare every stage with
 // the CPU oracle (oracle/), which is itself pinned to the reference binary's outputs.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -361,7 +362,8 @@ struct kasa_ctx {
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nReads+1], u64[nReads+1]
     DevBuf qKmerA, qKmerB, qReadA, qReadB;     // double buffers of the query arrays
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
-    DevBuf tileFirst, tileNext;                // u32[nK][nTiles]
+    DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
+    int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
     DevBuf scratch, touched, fbList, fastScratch;           // per-block dense score rows; reads left to the slow kernel
@@ -467,7 +469,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     (void)hipSetDevice(c->device); // the index may already be gone: never touch it here
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                      &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
@@ -701,6 +703,109 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
     if (threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
 }
 
+// ---- streaming variant --------------------------------------------------------------------------
+// When a batch is dense (the normal case: ~3 queries per index record at 10 M reads vs 4e8 records), a
+// tile of 1024 consecutive sorted queries touches a short contiguous span of the index.  tile_bounds
+// finds that span once per tile (prefix table + binary search, one thread per tile edge); lookup_tile
+// then streams the span into LDS with coalesced loads and answers all 1024 queries from LDS.  Every
+// index record and every query is read from HBM once: the merge-join lower bound of SURVEY.md 8(d).
+static constexpr int LSPAN = 3072;   // index records staged per tile (24 KiB); larger spans use lookup_kernel's path
+
+__device__ __forceinline__ uint32_t lower_bound_global(const uint64_t *__restrict__ idxKmer, const uint32_t *__restrict__ table,
+                                                       int tb, uint64_t q)
+{
+    const uint64_t bkt = q >> (KEYBITS - tb);
+    uint32_t lo = bkt ? table[bkt - 1] : 0u;
+    uint32_t hi = table[bkt];
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (idxKmer[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void tile_bounds_kernel(const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer,
+                                   const uint32_t *__restrict__ table, int tb, uint32_t nTiles, uint32_t *__restrict__ bounds)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // edge 2t = first query of tile t, 2t+1 = last
+    if (i >= 2 * nTiles) return;
+    const uint32_t t = i >> 1;
+    uint32_t p = t * TILE + ((i & 1) ? (TILE - 1) : 0);
+    if (p >= nQ) p = nQ - 1;
+    bounds[i] = lower_bound_global(idxKmer, table, tb, qKmer[p]);
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
+    const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer, uint32_t nIdx,
+    const uint32_t *__restrict__ table, int tb, const uint32_t *__restrict__ bounds, int kHigh, int kLow,
+    uint8_t *__restrict__ depth, uint32_t *__restrict__ rep, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
+{
+    __shared__ uint64_t sIdx[LSPAN];
+    __shared__ uint32_t sFirst[MAX_LEVELS];
+    const int nK = kHigh - kLow + 1;
+    if (threadIdx.x < MAX_LEVELS) sFirst[threadIdx.x] = NOPOS;
+    const uint32_t lbFirst = bounds[2 * blockIdx.x], lbLast = bounds[2 * blockIdx.x + 1];
+    const uint32_t ilo = lbFirst ? lbFirst - 1 : 0u;                     // predecessor of the first query
+    const uint32_t ihi = (lbLast < nIdx) ? lbLast + 1 : nIdx;            // successor of the last query
+    const uint32_t span = ihi - ilo;
+    const bool staged = span <= (uint32_t)LSPAN;
+    if (staged)
+        for (uint32_t i = threadIdx.x; i < span; i += TILE_THREADS) sIdx[i] = idxKmer[ilo + i];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * TILE;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t p = base + it * TILE_THREADS + threadIdx.x;
+        if (p >= nQ) continue;
+        const uint64_t q = qKmer[p];
+        uint32_t lo;
+        uint64_t eLo = 0, ePrev = 0;
+        bool hasLo, hasPrev;
+        if (staged) {
+            uint32_t a = 0, b = span;                                    // first staged entry >= q
+            while (a < b) {
+                const uint32_t mid = a + ((b - a) >> 1);
+                if (sIdx[mid] < q) a = mid + 1; else b = mid;
+            }
+            lo = ilo + a;
+            hasLo = a < span; hasPrev = a > 0;
+            if (hasLo) eLo = sIdx[a];
+            if (hasPrev) ePrev = sIdx[a - 1];
+            // by construction the true lower bound lies in [lbFirst, lbLast] subset of the staged span;
+            // a == 0 can only happen for lo == 0 (no predecessor exists) or when ilo == lbFirst - 1 < lo
+            if (!hasPrev && lo > 0) { ePrev = idxKmer[lo - 1]; hasPrev = true; }
+            if (!hasLo && lo < nIdx) { eLo = idxKmer[lo]; hasLo = true; }
+        } else {
+            lo = lower_bound_global(idxKmer, table, tb, q);
+            hasLo = lo < nIdx; hasPrev = lo > 0;
+            if (hasLo) eLo = idxKmer[lo];
+            if (hasPrev) ePrev = idxKmer[lo - 1];
+        }
+        const int la = hasLo ? lcp_letters(q, eLo) : 0;
+        const int lb = hasPrev ? lcp_letters(q, ePrev) : 0;
+        int L = la >= lb ? la : lb;
+        const uint32_t r = la >= lb ? lo : lo - 1;
+        int d = 0;
+        if (L >= RANGE_LETTERS) {
+            if (L > kHigh) L = kHigh;
+            d = L;
+            for (int k = kLow; k <= L; ++k)
+                if (((q >> (5 * (KLETTERS - k))) & 31) == 30) { d = k - 1; break; }
+            if (d < kLow) d = 0;
+        }
+        depth[p] = (uint8_t)d;
+        rep[p] = r;
+        const int ql = (p == 0) ? 0 : lcp_letters(qKmer[p - 1], q);
+        for (int lv = 0; lv < nK; ++lv) {
+            const int k = kHigh - lv;
+            const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
+            if (special) atomicMin(&sFirst[lv], p);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
+}
+
 // tileNext[lv][t] = first special position in any tile after t (or nQ)
 __global__ void tile_suffix_kernel(const uint32_t *__restrict__ tileFirst, uint32_t *__restrict__ tileNext,
                                    uint32_t nTiles, uint32_t nQ)
@@ -741,7 +846,9 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
         (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)))
         return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
-    if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4))) return rc;
+    if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4)) ||
+        (rc = c->tileBounds.reserve(((size_t)nTiles + 1) * 8)))
+        return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_SORT], &a, &b))) return rc;
     if (nQ > 0) {
@@ -760,9 +867,17 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
     if (nQ > 0) {
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
-        lookup_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
-            c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
-            c->tileFirst.as<uint32_t>(), nTiles);
+        if (c->lookupMode == 1) {
+            lookup_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+                c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
+                c->tileFirst.as<uint32_t>(), nTiles);
+        } else {
+            tile_bounds_kernel<<<blocks_for(2ull * nTiles, 256), 256, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(),
+                c->ix->table.as<uint32_t>(), c->ix->tb, nTiles, c->tileBounds.as<uint32_t>());
+            lookup_tile_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+                c->ix->table.as<uint32_t>(), c->ix->tb, c->tileBounds.as<uint32_t>(), c->kHigh, c->kLow, c->depth.as<uint8_t>(),
+                c->rep.as<uint32_t>(), c->tileFirst.as<uint32_t>(), nTiles);
+        }
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->lookupKernel, ka, kb))) return rc;
         c->lookupQueries += nQ;
@@ -1420,6 +1535,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
         A.wantPerRead = wantPerRead ? 1 : 0;
         A.addProfile = attempt == 0 ? 1 : 0;
+        if (getenv("KASA_EXPERIMENT_NOPROFILE")) A.addProfile = 0; // measurement experiment only
         A.list = nullptr; A.nList = 0;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
@@ -1657,7 +1773,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 {
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                            &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     uint64_t s = 0;
@@ -1669,7 +1785,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlowReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (forceSlowScore >= 0) c->forceSlowScore = forceSlowScore != 0;
+    if (forceSlowScore >= 0) { c->forceSlowScore = (forceSlowScore & 1) != 0; c->lookupMode = (forceSlowScore & 2) ? 1 : 0; }
     if (lastSlowReads) *lastSlowReads = c->lastSlowReads;
     return KASA_OK;
 }

@@ -76,7 +76,7 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
         ctx.close(); dix.close()
 
 
-@pytest.mark.parametrize("slow", [False, True], ids=["fast+fallback", "slow_only"])
+@pytest.mark.parametrize("slow", [0, 1, 2], ids=["fast+fallback", "general_score", "per_query_lookup"])
 @pytest.mark.parametrize("seed", range(24))
 def test_adversarial_queries_vs_oracle(seed, slow):
     """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles."""
@@ -96,7 +96,7 @@ def test_adversarial_queries_vs_oracle(seed, slow):
     res = oracle.compare(iv, p, qs, rs_, a, b, n_reads, True, closed_form=False)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, k_high, k_low, 3)
-    ctx.force_slow_score(slow)
+    ctx.debug_flags(slow)
     ctx.set_queries(q, rd, n_reads)
     ctx.sort_and_range()
     ctx.lookup_score(True, coverage=False)
@@ -140,8 +140,8 @@ def test_medium_synthetic_vs_oracle():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    for slow in (False, True):
-        ctx.force_slow_score(slow)
+    for slow in (0, 1, 2):
+        ctx.debug_flags(slow)
         ctx.profile_reset()
         ctx.run_batch(batch.bases, batch.offsets, True)
         assert ctx.n_kmers == nq
@@ -149,9 +149,9 @@ def test_medium_synthetic_vs_oracle():
         assert np.array_equal(cu, res.count_unique)
         np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
         assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
-        if not slow:
+        if slow != 1:
             assert ctx.last_slow_reads() < batch.n // 10      # the lane-per-read path carries the load
-    ctx.force_slow_score(False)
+    ctx.debug_flags(0)
     # profile-only mode gives the same tables; batches accumulate
     ctx.profile_reset()
     half = batch.n // 2
