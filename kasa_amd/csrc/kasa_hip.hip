@@ -696,7 +696,9 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
         for (int lv = 0; lv < nK; ++lv) {
             const int k = kHigh - lv;
             const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
-            if (special) atomicMin(&sFirst[lv], p);
+            // p grows with the lane: the lowest special lane holds this wavefront's minimum
+            const unsigned long long m = __ballot(special);
+            if (special && (m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicMin(&sFirst[lv], p);
         }
     }
     __syncthreads();
@@ -799,7 +801,9 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
         for (int lv = 0; lv < nK; ++lv) {
             const int k = kHigh - lv;
             const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
-            if (special) atomicMin(&sFirst[lv], p);
+            // p grows with the lane: the lowest special lane holds this wavefront's minimum
+            const unsigned long long m = __ballot(special);
+            if (special && (m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicMin(&sFirst[lv], p);
         }
     }
     __syncthreads();
