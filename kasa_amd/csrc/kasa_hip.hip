@@ -1054,7 +1054,7 @@ struct ScoreArgs {
     int addProfile;                              // 0 on a rerun that only re-emits rows
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
-    uint32_t *ovTax; float *ovScore; uint32_t *ovUsed, *logCell, *logNC; // fast kernel: per-lane scratch [i * lanes + lane]
+    uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
 };
 
 // c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
@@ -1226,45 +1226,45 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // does not fit (more than FPL groups pending, more than FTA taxa, a taxon set larger than 4, more
 // than FNK levels) is handed to score_kernel untouched: nothing of it has reached global memory.
 // ------------------------------------------------------------------------------------------------
-static constexpr int FPL = 12;      // pending groups per read
-static constexpr int FTA = 4;       // taxa with per-level counters in LDS (first come)
+static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
+static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS (first come)
 static constexpr int FNK = 6;       // levels
-static constexpr int FOV = 384;     // further taxa of a read: open-addressing table in per-lane global scratch
-static constexpr int FHS = 512;     // ... with this many slots (power of two)
-static constexpr int FLOG = 640;    // their profile contributions, logged and added at the end of the read
+static constexpr int FHS = 256;     // further taxa of a read: open-addressing table in per-block global scratch
+static constexpr int FOV = 192;     // ... holding at most this many
+static constexpr int FLOG = 320;    // their profile contributions, logged and added at the end of the read
 static constexpr uint32_t ROW_UNSORTED = 0x80000000u;
+static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FHS + FOV + 2 * FLOG + 4 * FPL); // u32 words per block
 
 __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
 {
-    __shared__ uint32_t pF[FPL][64], pRef[FPL][64], pKC[FPL][64];   // pKC = k | hits << 8
-    __shared__ uint32_t aTax[FTA][64];
-    __shared__ float aScore[FTA][64];
-    __shared__ uint16_t aCnt[FTA][FNK][4][64];                      // hits per (taxon, level, |T| = 1..4)
+    __shared__ unsigned long long cnt64[FTA][FNK][64];              // 4 x 16-bit hit counters (|T| = 1..4) per (taxon, level)
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
-    const uint32_t lanes = gridDim.x * 64u;
-    const uint32_t gl = blockIdx.x * 64u + lane;
-    uint32_t *ovTax = A.ovTax + gl;            // element i at [i * lanes]; hash slots, 0xFFFFFFFF = empty
-    float *ovScore = A.ovScore + gl;
-    uint32_t *ovUsed = A.ovUsed + gl;          // slots in insertion order
-    uint32_t *logCell = A.logCell + gl;
-    uint32_t *logNC = A.logNC + gl;
-    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += lanes) {
+    const uint32_t stride = gridDim.x * 64u;
+    // per-block scratch, element i of a lane at [i * 64 + lane]: contiguous per block, so it stays TLB- and cache-friendly
+    uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
+    uint2 *hs = reinterpret_cast<uint2 *>(blk) + lane;                               // {taxon | EMPTY, score bits}
+    uint32_t *used = blk + 64 * 2 * FHS + lane;                                      // hash slots in insertion order
+    uint2 *lg = reinterpret_cast<uint2 *>(blk + 64 * (2 * FHS + FOV)) + lane;        // {cell, n << 16 | hits}
+    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * (2 * FHS + FOV + 2 * FLOG)) + lane; // {F, ref, k | hits << 8, -}
+    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
         bool fb = false;
         int np = 0, na = 0, no = 0, nl = 0;
+        uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu;
+        float mS0 = 0.0f, mS1 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < FTA; ++e)
+#pragma unroll
+            for (int l2 = 0; l2 < FNK; ++l2) cnt64[e][l2][lane] = 0ull;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
             if (cnt > 60000u) fb = true;                               // 16-bit counters
 
-            auto apply = [&](int e) {
-                const uint32_t ref = pRef[e][lane];
-                const uint32_t kc = pKC[e][lane];
-                const int k = (int)(kc & 255u);
-                const uint32_t c = kc >> 8;
-                const int lv = A.kHigh - k;
+            auto applyEvent = [&](uint32_t k, uint32_t ref, uint32_t c) {
+                const int lv = A.kHigh - (int)k;
                 uint32_t n, t0 = 0, t1 = 0;
                 const uint32_t *list = nullptr;
                 if (ref & REF_SINGLE) { n = 1; t0 = ref & 0x7FFFFFFFu; }
@@ -1272,77 +1272,103 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 else { n = A.pool[ref]; list = A.pool + ref + 1; }
                 const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
                 const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));       // Compare.hpp:924
-                for (uint32_t i = 0; i < n; ++i) {
+                for (uint32_t i = 0; i < n && !fb; ++i) {
                     const uint32_t t = list ? list[i] : (i == 0 ? t0 : t1);
-                    int e2 = 0;
-                    while (e2 < na && aTax[e2][lane] != t) ++e2;
-                    if (e2 == na && na < FTA) {
-                        aTax[na][lane] = t;
-                        aScore[na][lane] = 0.0f;
-                        for (int l2 = 0; l2 < FNK; ++l2)
-                            for (int q = 0; q < 4; ++q) aCnt[na][l2][q][lane] = 0;
-                        ++na;
-                    }
+                    int e = -1;
+                    if (t == mTax0) e = 0;
+                    else if (t == mTax1) e = 1;
+                    else if (na < FTA) { e = na; if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
                     bool logIt = true;
-                    if (e2 < FTA) {
-                        float v = aScore[e2][lane];
-                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530
-                        aScore[e2][lane] = v;
-                        if (n <= 4) { aCnt[e2][lv][n - 1][lane] = (uint16_t)(aCnt[e2][lv][n - 1][lane] + c); logIt = false; }
+                    if (e >= 0) {
+                        float v = (e == 0) ? mS0 : mS1;
+                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
+                        if (e == 0) mS0 = v; else mS1 = v;
+                        if (n <= 4) { cnt64[e][lv][lane] += (unsigned long long)c << (16 * (n - 1)); logIt = false; }
                     } else {
-                        uint32_t o = (t * 2654435761u) >> 23;                  // 9 bits
-                        uint32_t cur = ovTax[(size_t)o * lanes];
-                        while (cur != t && cur != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = ovTax[(size_t)o * lanes]; }
+                        uint32_t o = (t * 2654435761u) >> 24;                  // 8 bits
+                        uint2 cur = hs[(size_t)o * 64];
+                        while (cur.x != t && cur.x != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = hs[(size_t)o * 64]; }
                         float v = 0.0f;
-                        if (cur == t) v = ovScore[(size_t)o * lanes];
+                        if (cur.x == t) v = __uint_as_float(cur.y);
                         else {
-                            if (no == FOV) { fb = true; return; }
-                            ovTax[(size_t)o * lanes] = t;
-                            ovUsed[(size_t)no * lanes] = o;
+                            if (no == FOV) { fb = true; break; }
+                            used[(size_t)no * 64] = o;
                             ++no;
                         }
                         for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
-                        ovScore[(size_t)o * lanes] = v;
+                        hs[(size_t)o * 64] = make_uint2(t, __float_as_uint(v));
                     }
                     if (logIt) {
-                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; return; }
-                        logCell[(size_t)nl * lanes] = (uint32_t)lv * A.nTaxa + t;
-                        logNC[(size_t)nl * lanes] = (n << 16) | c;
+                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; break; }
+                        lg[(size_t)nl * 64] = make_uint2((uint32_t)lv * A.nTaxa + t, (n << 16) | c);
                         ++nl;
                     }
                 }
             };
 
+            uint32_t pcur = cnt ? A.plist[o0] : 0u;
             for (uint32_t j = 0; j < cnt && !fb; ++j) {
-                const uint32_t p = A.plist[o0 + j];
-                int nf = 0;
-                while (nf < np && !fb && pF[nf][lane] <= p) { apply(nf); ++nf; }   // flushed before p
-                if (nf) {
-                    for (int i = nf; i < np; ++i) { pF[i - nf][lane] = pF[i][lane]; pRef[i - nf][lane] = pRef[i][lane]; pKC[i - nf][lane] = pKC[i][lane]; }
-                    np -= nf;
+                const uint32_t pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
+                // the (up to) 6 events of this query, k ascending; absent levels sink to the end
+                uint32_t eF[FNK], eR[FNK], eK[FNK];
+                const uint2 *rp = A.rec + (size_t)pcur * nK;
+                bool early = true;
+#pragma unroll
+                for (int i = 0; i < FNK; ++i) {
+                    const int lv = nK - 1 - i;
+                    uint2 v = make_uint2(0xFFFFFFFFu, 0u);
+                    if (lv >= 0) v = rp[lv];
+                    if (v.y == 0u) v.x = 0xFFFFFFFFu;
+                    eF[i] = v.x; eR[i] = v.y; eK[i] = (uint32_t)(A.kHigh - lv);
+                    if (v.y != 0u && v.x > pnext) early = false;
                 }
-                const uint2 *rp = A.rec + (size_t)p * nK;
-                for (int lv = nK - 1; lv >= 0 && !fb; --lv) {                  // k ascending
-                    const uint2 v = rp[lv];
-                    if (v.y == 0) continue;
-                    const uint32_t k = (uint32_t)(A.kHigh - lv);
-                    int pos = np;                                              // insertion point from the back
-                    while (pos > 0) {
-                        const uint32_t eF = pF[pos - 1][lane];
-                        const uint32_t eK = pKC[pos - 1][lane] & 255u;
-                        if (eF > v.x || (eF == v.x && eK > k)) --pos; else break;
+#pragma unroll
+                for (int a2 = 0; a2 < FNK - 1; ++a2)                           // stable: ties keep k ascending
+#pragma unroll
+                    for (int b2 = 0; b2 < FNK - 1 - a2; ++b2)
+                        if (eF[b2] > eF[b2 + 1]) {
+                            uint32_t x = eF[b2]; eF[b2] = eF[b2 + 1]; eF[b2 + 1] = x;
+                            x = eR[b2]; eR[b2] = eR[b2 + 1]; eR[b2 + 1] = x;
+                            x = eK[b2]; eK[b2] = eK[b2 + 1]; eK[b2 + 1] = x;
+                        }
+                if (np == 0 && early) {
+                    // every group of this query closes before the read's next query: replay at once
+#pragma unroll
+                    for (int i = 0; i < FNK; ++i)
+                        if (eR[i] != 0u && !fb) applyEvent(eK[i], eR[i], 1u);
+                } else {
+                    // general case: merge into the pending list (sorted by (F, k)), then flush what closes
+#pragma unroll
+                    for (int i = 0; i < FNK; ++i) {
+                        if (eR[i] == 0u || fb) continue;
+                        int pos = np;
+                        while (pos > 0) {
+                            const uint4 e4 = pend[(size_t)(pos - 1) * 64];
+                            if (e4.x > eF[i] || (e4.x == eF[i] && (e4.z & 255u) > eK[i])) --pos; else break;
+                        }
+                        if (pos > 0) {
+                            uint4 e4 = pend[(size_t)(pos - 1) * 64];
+                            if (e4.x == eF[i] && (e4.z & 255u) == eK[i]) { e4.z += 256u; pend[(size_t)(pos - 1) * 64] = e4; continue; }
+                        }
+                        if (np == FPL) { fb = true; continue; }
+                        for (int q = np; q > pos; --q) pend[(size_t)q * 64] = pend[(size_t)(q - 1) * 64];
+                        pend[(size_t)pos * 64] = make_uint4(eF[i], eR[i], eK[i] | 256u, 0u);
+                        ++np;
                     }
-                    if (pos > 0 && pF[pos - 1][lane] == v.x && (pKC[pos - 1][lane] & 255u) == k) {
-                        pKC[pos - 1][lane] += 256u;                            // same group again
-                        continue;
+                    int nf = 0;
+                    while (nf < np && !fb) {
+                        const uint4 e4 = pend[(size_t)nf * 64];
+                        if (e4.x > pnext) break;
+                        applyEvent(e4.z & 255u, e4.y, e4.z >> 8);
+                        ++nf;
                     }
-                    if (np == FPL) { fb = true; break; }
-                    for (int i = np; i > pos; --i) { pF[i][lane] = pF[i - 1][lane]; pRef[i][lane] = pRef[i - 1][lane]; pKC[i][lane] = pKC[i - 1][lane]; }
-                    pF[pos][lane] = v.x; pRef[pos][lane] = v.y; pKC[pos][lane] = k | 256u;
-                    ++np;
+                    if (nf) {
+                        for (int q = nf; q < np; ++q) pend[(size_t)(q - nf) * 64] = pend[(size_t)q * 64];
+                        np -= nf;
+                    }
                 }
+                pcur = pnext;
             }
-            for (int i = 0; i < np && !fb; ++i) apply(i);
         }
         // ---- converged: one staging allocation per wavefront
         const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)(na + no) : 0u;
@@ -1359,34 +1385,38 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
             if (A.wantPerRead) {
                 A.rowPos[r] = start; A.rowLen[r] = m | (m > 1 ? ROW_UNSORTED : 0u);
                 if (start + m <= A.stCap) {
-                    for (int i = 0; i < na; ++i) { A.stTax[start + i] = aTax[i][lane]; A.stScore[start + i] = aScore[i][lane]; }
+                    if (na > 0) { A.stTax[start] = mTax0; A.stScore[start] = mS0; }
+                    if (na > 1) { A.stTax[start + 1] = mTax1; A.stScore[start + 1] = mS1; }
                     for (int i = 0; i < no; ++i) {
-                        const uint32_t o = ovUsed[(size_t)i * lanes];
-                        A.stTax[start + na + i] = ovTax[(size_t)o * lanes]; A.stScore[start + na + i] = ovScore[(size_t)o * lanes];
+                        const uint2 e2 = hs[(size_t)used[(size_t)i * 64] * 64];
+                        A.stTax[start + na + i] = e2.x; A.stScore[start + na + i] = __uint_as_float(e2.y);
                     }
                 }
             }
             if (A.addProfile) {
-                for (int e = 0; e < na; ++e)
+                for (int e = 0; e < na; ++e) {
+                    const uint32_t t = (e == 0) ? mTax0 : mTax1;
                     for (int lv = 0; lv < nK; ++lv) {
-                        const size_t cell = (size_t)lv * A.nTaxa + aTax[e][lane];
-                        const uint32_t c1 = aCnt[e][lv][0][lane];
+                        const unsigned long long pk = cnt64[e][lv][lane];
+                        if (!pk) continue;
+                        const size_t cell = (size_t)lv * A.nTaxa + t;
+                        const uint32_t c1 = (uint32_t)(pk & 0xFFFFu);
                         if (c1) { atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c1); fixed_add(A.cntAllHi, A.cntAllLo, cell, c1, 1); }
                         for (uint32_t q = 1; q < 4; ++q) {
-                            const uint32_t cq = aCnt[e][lv][q][lane];
+                            const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFu);
                             if (cq) fixed_add(A.cntAllHi, A.cntAllLo, cell, cq, q + 1);
                         }
                     }
+                }
                 for (int i = 0; i < nl; ++i) {
-                    const size_t cell = logCell[(size_t)i * lanes];
-                    const uint32_t nc = logNC[(size_t)i * lanes];
-                    const uint32_t n = nc >> 16, c = nc & 0xFFFFu;
-                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
-                    fixed_add(A.cntAllHi, A.cntAllLo, cell, c, n);
+                    const uint2 e2 = lg[(size_t)i * 64];
+                    const uint32_t n = e2.y >> 16, c = e2.y & 0xFFFFu;
+                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[e2.x], (unsigned long long)c);
+                    fixed_add(A.cntAllHi, A.cntAllLo, e2.x, c, n);
                 }
             }
         }
-        for (int i = 0; i < no; ++i) ovTax[(size_t)ovUsed[(size_t)i * lanes] * lanes] = 0xFFFFFFFFu;
+        for (int i = 0; i < no; ++i) hs[(size_t)used[(size_t)i * 64] * 64] = make_uint2(0xFFFFFFFFu, 0u);
         const unsigned long long fbMask = __ballot(active && fb);
         if (fbMask) {
             uint32_t fbBase = 0;
@@ -1532,7 +1562,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         ScoreArgs A;
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
-        A.scratch = nullptr; A.ovTax = nullptr; A.ovScore = nullptr; A.ovUsed = nullptr; A.logCell = nullptr; A.logNC = nullptr;
+        A.scratch = nullptr; A.fastScratch = nullptr;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
@@ -1546,15 +1576,12 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         uint32_t nSlow = nReads;
         const bool fast = nK <= FNK && !c->forceSlowScore;
         if (fast) {
-            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 5u);
-            const size_t lanes = (size_t)fblocks * 64;
-            if ((rc = c->fastScratch.reserve(lanes * (size_t)(2 * FHS + FOV + 2 * FLOG) * 4))) return rc;
-            A.ovTax = c->fastScratch.as<uint32_t>();
-            A.ovScore = reinterpret_cast<float *>(A.ovTax + lanes * FHS);
-            A.ovUsed = A.ovTax + lanes * FHS * 2;
-            A.logCell = A.ovUsed + lanes * FOV;
-            A.logNC = A.logCell + lanes * FLOG;
-            HIPCHK(hipMemsetAsync(A.ovTax, 0xFF, lanes * (size_t)FHS * 4, c->stream));
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 20u);
+            const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
+            if ((rc = c->fastScratch.reserve(words * 4))) return rc;
+            A.fastScratch = c->fastScratch.as<uint32_t>();
+            // hash slots start empty (0xFF..); the kernel restores that after every read
+            HIPCHK(hipMemsetAsync(A.fastScratch, 0xFF, words * 4, c->stream));
             score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(&nSlow, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
