@@ -1055,6 +1055,7 @@ struct ScoreArgs {
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
     uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
+    uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
 };
 
 // c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
@@ -1229,10 +1230,11 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
 static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS (first come)
 static constexpr int FNK = 6;       // levels
-static constexpr int FHS = 256;     // further taxa of a read: open-addressing table in per-block global scratch
-static constexpr int FOV = 192;     // ... holding at most this many
-static constexpr int FLOG = 320;    // their profile contributions, logged and added at the end of the read
+static constexpr int FHS = 1024;    // further taxa of a read: open-addressing table in per-block global scratch
+static constexpr int FOV = 640;     // ... holding at most this many
+static constexpr int FLOG = 896;    // their profile contributions, logged and added at the end of the read
 static constexpr uint32_t ROW_UNSORTED = 0x80000000u;
+static constexpr uint32_t DEAD_SCORE = 0xFFFFFFFFu;   // table entry whose chain moved to a register slot
 static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FHS + FOV + 2 * FLOG + 4 * FPL); // u32 words per block
 
 __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
@@ -1241,6 +1243,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t stride = gridDim.x * 64u;
+    const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
     // per-block scratch, element i of a lane at [i * 64 + lane]: contiguous per block, so it stays TLB- and cache-friendly
     uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
     uint2 *hs = reinterpret_cast<uint2 *>(blk) + lane;                               // {taxon | EMPTY, score bits}
@@ -1251,7 +1254,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
         bool fb = false;
-        int np = 0, na = 0, no = 0, nl = 0;
+        int np = 0, na = 0, no = 0, nl = 0, nd = 0;
         uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu;
         float mS0 = 0.0f, mS1 = 0.0f;
 #pragma unroll
@@ -1261,7 +1264,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
-            if (cnt > 60000u) fb = true;                               // 16-bit counters
+            if (cnt > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
 
             auto applyEvent = [&](uint32_t k, uint32_t ref, uint32_t c) {
                 const int lv = A.kHigh - (int)k;
@@ -1277,7 +1280,18 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                     int e = -1;
                     if (t == mTax0) e = 0;
                     else if (t == mTax1) e = 1;
-                    else if (na < FTA) { e = na; if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                    else if (na < FTA && (int)k >= kPromote) {
+                        // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
+                        // slot.  If shallow matches already started its chain in the table, carry the sum over.
+                        uint32_t o = (t * 2654435761u) >> 22;
+                        uint2 cur = hs[(size_t)o * 64];
+                        while (cur.x != t && cur.x != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = hs[(size_t)o * 64]; }
+                        float v0 = 0.0f;
+                        if (cur.x == t) { v0 = __uint_as_float(cur.y); hs[(size_t)o * 64] = make_uint2(t, DEAD_SCORE); ++nd; }
+                        e = na;
+                        if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
+                        ++na;
+                    }
                     bool logIt = true;
                     if (e >= 0) {
                         float v = (e == 0) ? mS0 : mS1;
@@ -1285,13 +1299,13 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         if (e == 0) mS0 = v; else mS1 = v;
                         if (n <= 4) { cnt64[e][lv][lane] += (unsigned long long)c << (16 * (n - 1)); logIt = false; }
                     } else {
-                        uint32_t o = (t * 2654435761u) >> 24;                  // 8 bits
+                        uint32_t o = (t * 2654435761u) >> 22;                  // 10 bits
                         uint2 cur = hs[(size_t)o * 64];
                         while (cur.x != t && cur.x != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = hs[(size_t)o * 64]; }
                         float v = 0.0f;
                         if (cur.x == t) v = __uint_as_float(cur.y);
                         else {
-                            if (no == FOV) { fb = true; break; }
+                            if (no == FOV) { fb = true; atomicAdd(&A.why[1], 1u); break; }
                             used[(size_t)no * 64] = o;
                             ++no;
                         }
@@ -1299,7 +1313,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         hs[(size_t)o * 64] = make_uint2(t, __float_as_uint(v));
                     }
                     if (logIt) {
-                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; break; }
+                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; atomicAdd(&A.why[nl == FLOG ? 2 : 3], 1u); break; }
                         lg[(size_t)nl * 64] = make_uint2((uint32_t)lv * A.nTaxa + t, (n << 16) | c);
                         ++nl;
                     }
@@ -1350,7 +1364,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                             uint4 e4 = pend[(size_t)(pos - 1) * 64];
                             if (e4.x == eF[i] && (e4.z & 255u) == eK[i]) { e4.z += 256u; pend[(size_t)(pos - 1) * 64] = e4; continue; }
                         }
-                        if (np == FPL) { fb = true; continue; }
+                        if (np == FPL) { fb = true; atomicAdd(&A.why[4], 1u); continue; }
                         for (int q = np; q > pos; --q) pend[(size_t)q * 64] = pend[(size_t)(q - 1) * 64];
                         pend[(size_t)pos * 64] = make_uint4(eF[i], eR[i], eK[i] | 256u, 0u);
                         ++np;
@@ -1371,7 +1385,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
             }
         }
         // ---- converged: one staging allocation per wavefront
-        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)(na + no) : 0u;
+        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)(na + no - nd) : 0u;
         uint32_t incl = m;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
@@ -1387,9 +1401,11 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 if (start + m <= A.stCap) {
                     if (na > 0) { A.stTax[start] = mTax0; A.stScore[start] = mS0; }
                     if (na > 1) { A.stTax[start + 1] = mTax1; A.stScore[start + 1] = mS1; }
+                    uint32_t w = start + na;
                     for (int i = 0; i < no; ++i) {
                         const uint2 e2 = hs[(size_t)used[(size_t)i * 64] * 64];
-                        A.stTax[start + na + i] = e2.x; A.stScore[start + na + i] = __uint_as_float(e2.y);
+                        if (e2.y == DEAD_SCORE) continue;
+                        A.stTax[w] = e2.x; A.stScore[w] = __uint_as_float(e2.y); ++w;
                     }
                 }
             }
@@ -1433,8 +1449,8 @@ __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restric
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
                                 const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
 {
-    __shared__ uint32_t sT[4][512];
-    __shared__ float sS[4][512];
+    __shared__ uint32_t sT[4][1024];
+    __shared__ float sS[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t waves = gridDim.x * 4u;
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += waves) {
@@ -1442,7 +1458,7 @@ __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restric
         const uint32_t raw = rowLen[r];
         const uint32_t m = raw & ~ROW_UNSORTED;
         const uint64_t o = rowOff[r];
-        if (!(raw & ROW_UNSORTED) || m > 512u) {
+        if (!(raw & ROW_UNSORTED) || m > 1024u) {
             for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
             continue;
         }
@@ -1571,7 +1587,8 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         A.addProfile = attempt == 0 ? 1 : 0;
         if (getenv("KASA_EXPERIMENT_NOPROFILE")) A.addProfile = 0; // measurement experiment only
         A.list = nullptr; A.nList = 0;
-        A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3;
+        A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
+        HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
         const bool fast = nK <= FNK && !c->forceSlowScore;
@@ -1818,6 +1835,11 @@ extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlo
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (forceSlowScore >= 0) { c->forceSlowScore = (forceSlowScore & 1) != 0; c->lookupMode = (forceSlowScore & 2) ? 1 : 0; }
     if (lastSlowReads) *lastSlowReads = c->lastSlowReads;
+    if (getenv("KASA_DEBUG_WHY")) {
+        uint32_t w[8];
+        if (hipMemcpy(w, c->misc.as<uint32_t>() + 8, 32, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[kasa] fallback reasons: cnt=%u taxa=%u log=%u big=%u pending=%u\n", w[0], w[1], w[2], w[3], w[4]);
+    }
     return KASA_OK;
 }
 
