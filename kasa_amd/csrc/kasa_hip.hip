@@ -935,21 +935,25 @@ __device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
 //   REF_SINGLE | taxon                      one taxon
 //   REF_PAIR | taxonA << 15 | taxonB        two taxa, both < 2^15 (index order)
 //   offset into `pool`                      {n, taxon_1..n} appended there
-__device__ uint32_t group_taxa(uint32_t j, int g, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
-                               uint32_t nIdx, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor,
-                               bool coverage, uint64_t *__restrict__ cntTotalLv)
+// Step 1: bounds [a, b) of the group, its number of distinct taxa, and the 32-bit encoding when it fits
+// inline (0 = needs n + 1 words in the pool).
+__device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const uint8_t *__restrict__ meta,
+                                               const uint32_t *__restrict__ tax, uint32_t nIdx, bool coverage,
+                                               uint64_t *__restrict__ cntTotalLv, uint32_t &a, uint32_t &b, uint32_t &n)
 {
-    uint32_t a = j, b = j + 1;
+    a = j; b = j + 1;
     const bool openLeft = (j > 0) && (meta[j] & 15) >= g;
     const bool openRight = (b < nIdx) && (meta[b] & 15) >= g;
     if (!openLeft && !openRight) {                       // the group is this one entry (the common case)
         const uint32_t t0 = tax[j];
         if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[t0], 1ull);
+        n = 1;
         return REF_SINGLE | t0;
     }
     if (openLeft) { --a; while (a > 0 && (meta[a] & 15) >= g) --a; }
     if (openRight) { ++b; while (b < nIdx && (meta[b] & 15) >= g) ++b; }
-    uint32_t n = 0, t0 = 0, t1 = 0;
+    uint32_t t0 = 0, t1 = 0;
+    n = 0;
     for (uint32_t i = a; i < b; ++i)
         if ((meta[i] >> 4) < g) {
             const uint32_t tx = tax[i];
@@ -959,13 +963,37 @@ __device__ uint32_t group_taxa(uint32_t j, int g, const uint8_t *__restrict__ me
         }
     if (n == 1) return REF_SINGLE | t0;
     if (n == 2 && t0 < 32768u && t1 < 32768u) return REF_PAIR | (t0 << 15) | t1;
-    const uint32_t off = atomicAdd(poolCursor, n + 1);
-    if (off + n + 1 > poolCap || off + n + 1 >= REF_PAIR) return REF_PAIR - 1; // overflow: the host grows the pool and reruns
+    return 0u;
+}
+
+// Step 2: append {n, taxa...} at pool[off]
+__device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t n, int g, const uint8_t *__restrict__ meta,
+                                               const uint32_t *__restrict__ tax, uint32_t *__restrict__ pool, uint32_t poolCap,
+                                               uint32_t off)
+{
+    if (off + n + 1 > poolCap || off + n + 1 >= REF_PAIR) return REF_PAIR - 1;  // overflow: the host grows the pool and reruns
     pool[off] = n;
     uint32_t w = off + 1;
     for (uint32_t i = a; i < b; ++i)
         if ((meta[i] >> 4) < g) pool[w++] = tax[i];
     return off;
+}
+
+__device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *sh, uint32_t &total)
+{
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < TILE_THREADS; off <<= 1) {
+        const uint32_t o = (t >= off) ? sh[t - off] : 0u;
+        __syncthreads();
+        sh[t] += o;
+        __syncthreads();
+    }
+    const uint32_t incl = sh[t];
+    total = sh[TILE_THREADS - 1];
+    __syncthreads();
+    return incl - v;
 }
 
 __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
@@ -977,6 +1005,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
     __shared__ uint32_t shU[TILE_THREADS];
     __shared__ int shI[TILE_THREADS];
     __shared__ uint32_t sInfo[TILE];
+    __shared__ uint32_t sBase;
     const int nK = kHigh - kLow + 1;
     const int t = threadIdx.x;
     const uint32_t base = blockIdx.x * TILE + t * ITEMS;         // blocked: this thread owns base..base+3
@@ -1022,11 +1051,35 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
             if (leader[i]) lastLeader = t * ITEMS + i;
         }
         int lead = block_excl_prefix_max(lastLeader, shI);
+        // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
+        // with ONE allocation per workgroup and level
+        uint32_t ga[ITEMS], gb[ITEMS], gn[ITEMS], gref[ITEMS];
+        uint32_t need = 0;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
+            if (leader[i]) {
+                gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
+                                     ga[i], gb[i], gn[i]);
+                if (gref[i] == 0u) need += gn[i] + 1;
+            }
+        }
+        uint32_t total = 0;
+        uint32_t off = block_excl_prefix_sum(need, shU, total);
+        if (total) {                                                   // uniform across the workgroup
+            if (t == 0) sBase = atomicAdd(poolCursor, total);
+            __syncthreads();
+            off += sBase;
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i)
+                if (leader[i] && gref[i] == 0u) {
+                    gref[i] = group_emit(ga[i], gb[i], gn[i], g, meta, tax, pool, poolCap, off);
+                    off += gn[i] + 1;
+                }
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
-            if (leader[i])
-                sInfo[t * ITEMS + i] = group_taxa(rp[i], g, meta, tax, nIdx, pool, poolCap, poolCursor,
-                                                  coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa);
+            if (leader[i]) sInfo[t * ITEMS + i] = gref[i];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
