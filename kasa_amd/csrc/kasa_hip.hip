@@ -368,8 +368,8 @@ struct kasa_ctx {
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
     DevBuf scratch, touched, fbList, fastScratch;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0;
-    DevBuf rowPos, rowLen, rowOff, stTax, stScore, outTax, outScore;
-    DevBuf cntUnique, cntTotal, cntAllHi, cntAllLo; // u64[nK*nTaxa] each
+    DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
+    DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
     uint64_t poolCap = 0, stCap = 0, nnz = 0;
     uint64_t *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays
     StageTimer timers[KASA_STAGE_COUNT];
@@ -455,7 +455,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     if (hipMemcpy(c->lut.p, lut, 366, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(KASA_E_HIP, "LUT upload failed"));
     const size_t cells = (size_t)c->nK * ix->nTaxa * 8;
     if ((rc = c->cntUnique.reserve(cells)) || (rc = c->cntTotal.reserve(cells)) || (rc = c->cntAllHi.reserve(cells)) ||
-        (rc = c->cntAllLo.reserve(cells)) || (rc = c->misc.reserve(256)))
+        (rc = c->cntAllMid.reserve(cells)) || (rc = c->cntAllLo.reserve(cells)) || (rc = c->misc.reserve(256)))
         return bail(rc);
     *out = c;
     rc = kasa_profile_reset(c);
@@ -470,7 +470,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
+                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -491,6 +491,7 @@ extern "C" int kasa_profile_reset(kasa_ctx *c)
     HIPCHK(hipMemsetAsync(c->cntUnique.p, 0, cells, c->stream));
     HIPCHK(hipMemsetAsync(c->cntTotal.p, 0, cells, c->stream));
     HIPCHK(hipMemsetAsync(c->cntAllHi.p, 0, cells, c->stream));
+    HIPCHK(hipMemsetAsync(c->cntAllMid.p, 0, cells, c->stream));
     HIPCHK(hipMemsetAsync(c->cntAllLo.p, 0, cells, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return KASA_OK;
@@ -996,6 +997,85 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
     return incl - v;
 }
 
+// One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
+// taxon-set references (leaders compute them, members copy them through LDS).
+__device__ __forceinline__ void group_level(
+    int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[ITEMS], const uint8_t (&d)[ITEMS], const uint32_t (&rp)[ITEMS],
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
+    uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
+    uint64_t *__restrict__ cntTotal, uint32_t nTaxa, uint32_t *shU, int *shI, uint32_t *sInfo, uint32_t *sBase,
+    uint32_t (&F)[ITEMS], uint32_t (&R)[ITEMS])
+{
+    const int k = kHigh - lv;
+    const int g = group_letters(k);
+    // ---- flush position: next position that closes the level-k group (suffix scan)
+    bool sp[ITEMS];
+    uint32_t firstSp = NOPOS;
+#pragma unroll
+    for (int i = ITEMS - 1; i >= 0; --i) {
+        const uint32_t p = base + i;
+        sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
+        if (sp[i]) firstSp = p;
+    }
+    uint32_t carry = block_excl_suffix_min(firstSp, shU);
+    if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
+#pragma unroll
+    for (int i = ITEMS - 1; i >= 0; --i) {
+        F[i] = carry;
+        if (sp[i]) carry = base + i;
+    }
+    // ---- group leaders: first query of a level-k group, or the first matched query of the tile
+    int lastLeader = -1;
+    bool leader[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const bool matched = (base + i < nQ) && d[i] >= k;
+        leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));
+        if (leader[i]) lastLeader = t * ITEMS + i;
+    }
+    int lead = block_excl_prefix_max(lastLeader, shI);
+    // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
+    // with ONE allocation per workgroup and level
+    uint32_t ga[ITEMS], gb[ITEMS], gn[ITEMS], gref[ITEMS];
+    uint32_t need = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
+        if (leader[i]) {
+            gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
+                                 ga[i], gb[i], gn[i]);
+            if (gref[i] == 0u) need += gn[i] + 1;
+        }
+    }
+    uint32_t total = 0;
+    uint32_t off = block_excl_prefix_sum(need, shU, total);
+    if (total) {                                                   // uniform across the workgroup
+        if (t == 0) *sBase = atomicAdd(poolCursor, total);
+        __syncthreads();
+        off += *sBase;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+            if (leader[i] && gref[i] == 0u) {
+                gref[i] = group_emit(ga[i], gb[i], gn[i], g, meta, tax, pool, poolCap, off);
+                off += gn[i] + 1;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+        if (leader[i]) sInfo[t * ITEMS + i] = gref[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        if (leader[i]) lead = t * ITEMS + i;
+        const bool matched = (base + i < nQ) && d[i] >= k;
+        R[i] = (matched && lead >= 0) ? sInfo[lead] : 0u;
+    }
+    __syncthreads();
+}
+
+// NKR > 0: all levels of a query are collected in registers and written as one contiguous record (nK <= NKR);
+// NKR == 0: any number of levels, one 8-byte store per level.
+template <int NKR>
 __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
     const uint64_t *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
     const uint32_t *__restrict__ tileNext, uint32_t nTiles, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
@@ -1021,76 +1101,41 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
             rp[i] = rep[p];
         } else { ql[i] = 0; d[i] = 0; rp[i] = 0; }
     }
-    for (int lv = 0; lv < nK; ++lv) {
-        const int k = kHigh - lv;
-        const int g = group_letters(k);
-        // ---- flush position: next position that closes the level-k group (suffix scan)
-        bool sp[ITEMS];
-        uint32_t firstSp = NOPOS;
+    if constexpr (NKR > 0) {
+        uint32_t allF[NKR][ITEMS], allR[NKR][ITEMS];
 #pragma unroll
-        for (int i = ITEMS - 1; i >= 0; --i) {
+        for (int lv = 0; lv < NKR; ++lv) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
+            if (lv < nK)                                          // uniform: barriers inside are safe
+                group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
+                            coverage, cntTotal, nTaxa, shU, shI, sInfo, &sBase, allF[lv], allR[lv]);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
             const uint32_t p = base + i;
-            sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
-            if (sp[i]) firstSp = p;
-        }
-        uint32_t carry = block_excl_suffix_min(firstSp, shU);
-        if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
-        uint32_t F[ITEMS];
+            if (p >= nQ) continue;
+            uint2 *o = rec + (size_t)p * nK;
+            if (NKR == 6 && nK == 6) {                             // 48-byte record: three 16-byte stores
+                uint4 *o4 = reinterpret_cast<uint4 *>(o);
+                o4[0] = make_uint4(allF[0][i], allR[0][i], allF[1][i], allR[1][i]);
+                o4[1] = make_uint4(allF[2][i], allR[2][i], allF[3][i], allR[3][i]);
+                o4[2] = make_uint4(allF[4][i], allR[4][i], allF[5][i], allR[5][i]);
+            } else {
 #pragma unroll
-        for (int i = ITEMS - 1; i >= 0; --i) {
-            F[i] = carry;
-            if (sp[i]) carry = base + i;
-        }
-        // ---- group leaders: first query of a level-k group, or the first matched query of the tile
-        int lastLeader = -1;
-        bool leader[ITEMS];
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const bool matched = (base + i < nQ) && d[i] >= k;
-            leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));
-            if (leader[i]) lastLeader = t * ITEMS + i;
-        }
-        int lead = block_excl_prefix_max(lastLeader, shI);
-        // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
-        // with ONE allocation per workgroup and level
-        uint32_t ga[ITEMS], gb[ITEMS], gn[ITEMS], gref[ITEMS];
-        uint32_t need = 0;
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
-            if (leader[i]) {
-                gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
-                                     ga[i], gb[i], gn[i]);
-                if (gref[i] == 0u) need += gn[i] + 1;
+                for (int lv = 0; lv < NKR; ++lv)
+                    if (lv < nK) o[lv] = make_uint2(allF[lv][i], allR[lv][i]);
             }
         }
-        uint32_t total = 0;
-        uint32_t off = block_excl_prefix_sum(need, shU, total);
-        if (total) {                                                   // uniform across the workgroup
-            if (t == 0) sBase = atomicAdd(poolCursor, total);
-            __syncthreads();
-            off += sBase;
+    } else {
+        for (int lv = 0; lv < nK; ++lv) {
+            uint32_t F[ITEMS], R[ITEMS];
+            group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
+                        coverage, cntTotal, nTaxa, shU, shI, sInfo, &sBase, F, R);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i)
-                if (leader[i] && gref[i] == 0u) {
-                    gref[i] = group_emit(ga[i], gb[i], gn[i], g, meta, tax, pool, poolCap, off);
-                    off += gn[i] + 1;
-                }
+                if (base + i < nQ) rec[(size_t)(base + i) * nK + lv] = make_uint2(F[i], R[i]);
         }
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
-            if (leader[i]) sInfo[t * ITEMS + i] = gref[i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const uint32_t p = base + i;
-            if (leader[i]) lead = t * ITEMS + i;
-            if (p < nQ) {
-                const bool matched = d[i] >= k;
-                rec[(size_t)p * nK + lv] = make_uint2(F[i], (matched && lead >= 0) ? sInfo[lead] : 0u);
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -1101,8 +1146,8 @@ struct ScoreArgs {
     const uint32_t *plist; const uint64_t *kmerOff; const uint2 *rec; const uint32_t *pool;
     uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
     float *scratch;                              // per block: nTaxa floats, all zero between reads
-    uint64_t *cntUnique, *cntAllHi, *cntAllLo;
-    uint32_t *rowPos, *rowLen; uint32_t *stTax; float *stScore; uint32_t stCap; uint32_t *stCursor;
+    uint64_t *cntUnique, *cntAllHi, *cntAllMid, *cntAllLo;
+    uint32_t *rowPos, *rowLen; uint2 *st; uint32_t stCap; uint32_t *stCursor;   // staging rows: {taxon, score bits}
     uint32_t *errFlag; int wantPerRead;
     int addProfile;                              // 0 on a rerun that only re-emits rows
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
@@ -1111,18 +1156,21 @@ struct ScoreArgs {
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
 };
 
-// c / n added to a 64.64 fixed-point cell {hi, lo}: integer atomics, so the sum is exact (each term
-// is c * floor(2^64 / n)) and independent of the order in which waves arrive.
-__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *loTab, size_t cell, uint32_t c, uint32_t n)
+// c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
+// x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
+// with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
+// terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
+__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint32_t c, uint32_t n)
 {
     if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
     uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
     if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
-    const uint64_t loAdd = (uint64_t)c * R;
-    uint64_t hiAdd = __umul64hi((uint64_t)c, R);
-    const uint64_t old = atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)loAdd);
-    if (old + loAdd < old) ++hiAdd;
-    if (hiAdd) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hiAdd);
+    const uint64_t lo64 = (uint64_t)c * R;
+    const uint64_t hi = __umul64hi((uint64_t)c, R);
+    const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
+    if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
+    if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
+    if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
 }
 
 __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
@@ -1169,7 +1217,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                 if (A.addProfile) {
                     const size_t cell = (size_t)lv * A.nTaxa + tx;
                     if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
-                    fixed_add(A.cntAllHi, A.cntAllLo, cell, c, n);
+                    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c, n);
                 }
             }
         };
@@ -1250,7 +1298,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     const uint32_t mine = (lane < (int)m) ? sList[lane] : 0xFFFFFFFFu;
                     uint32_t rank = 0;
                     for (uint32_t i = 0; i < m; ++i) rank += (__shfl(mine, (int)i) < mine) ? 1u : 0u;
-                    if (lane < (int)m) { A.stTax[start + rank] = mine; A.stScore[start + rank] = score[mine]; }
+                    if (lane < (int)m) A.st[start + rank] = make_uint2(mine, __float_as_uint(score[mine]));
                 } else {
                     uint32_t w = start;
                     for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) {
@@ -1259,7 +1307,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                         const unsigned long long mk = __ballot(v > 0.0f);
                         if (v > 0.0f) {
                             const uint32_t o = w + __popcll(mk & ((1ull << lane) - 1ull));
-                            A.stTax[o] = tx; A.stScore[o] = v;
+                            A.st[o] = make_uint2(tx, __float_as_uint(v));
                         }
                         w += __popcll(mk);
                     }
@@ -1452,13 +1500,13 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
             if (A.wantPerRead) {
                 A.rowPos[r] = start; A.rowLen[r] = m | (m > 1 ? ROW_UNSORTED : 0u);
                 if (start + m <= A.stCap) {
-                    if (na > 0) { A.stTax[start] = mTax0; A.stScore[start] = mS0; }
-                    if (na > 1) { A.stTax[start + 1] = mTax1; A.stScore[start + 1] = mS1; }
+                    if (na > 0) A.st[start] = make_uint2(mTax0, __float_as_uint(mS0));
+                    if (na > 1) A.st[start + 1] = make_uint2(mTax1, __float_as_uint(mS1));
                     uint32_t w = start + na;
                     for (int i = 0; i < no; ++i) {
                         const uint2 e2 = hs[(size_t)used[(size_t)i * 64] * 64];
                         if (e2.y == DEAD_SCORE) continue;
-                        A.stTax[w] = e2.x; A.stScore[w] = __uint_as_float(e2.y); ++w;
+                        A.st[w] = e2; ++w;
                     }
                 }
             }
@@ -1470,10 +1518,10 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         if (!pk) continue;
                         const size_t cell = (size_t)lv * A.nTaxa + t;
                         const uint32_t c1 = (uint32_t)(pk & 0xFFFFu);
-                        if (c1) { atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c1); fixed_add(A.cntAllHi, A.cntAllLo, cell, c1, 1); }
+                        if (c1) { atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c1); fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c1, 1); }
                         for (uint32_t q = 1; q < 4; ++q) {
                             const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFu);
-                            if (cq) fixed_add(A.cntAllHi, A.cntAllLo, cell, cq, q + 1);
+                            if (cq) fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, cq, q + 1);
                         }
                     }
                 }
@@ -1481,7 +1529,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                     const uint2 e2 = lg[(size_t)i * 64];
                     const uint32_t n = e2.y >> 16, c = e2.y & 0xFFFFu;
                     if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[e2.x], (unsigned long long)c);
-                    fixed_add(A.cntAllHi, A.cntAllLo, e2.x, c, n);
+                    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, e2.x, c, n);
                 }
             }
         }
@@ -1499,8 +1547,8 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
 // Rows of the staging area -> CSR in read order; rows the fast path left unsorted (<= FTA + FOV entries)
 // are sorted by taxon on the way: one wavefront per row, bitonic in LDS.
 __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
-                                const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint32_t *__restrict__ stTax,
-                                const float *__restrict__ stScore, uint32_t *__restrict__ outTax, float *__restrict__ outScore)
+                                const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint2 *__restrict__ st,
+                                uint32_t *__restrict__ outTax, float *__restrict__ outScore)
 {
     __shared__ uint32_t sT[4][1024];
     __shared__ float sS[4][1024];
@@ -1512,14 +1560,15 @@ __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restric
         const uint32_t m = raw & ~ROW_UNSORTED;
         const uint64_t o = rowOff[r];
         if (!(raw & ROW_UNSORTED) || m > 1024u) {
-            for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = stTax[s + i]; outScore[o + i] = stScore[s + i]; }
+            for (uint32_t i = lane; i < m; i += 64) { const uint2 e = st[s + i]; outTax[o + i] = e.x; outScore[o + i] = __uint_as_float(e.y); }
             continue;
         }
         uint32_t n2 = 2;
         while (n2 < m) n2 <<= 1;
         for (uint32_t i = lane; i < n2; i += 64) {
-            sT[wv][i] = (i < m) ? stTax[s + i] : 0xFFFFFFFFu;
-            sS[wv][i] = (i < m) ? stScore[s + i] : 0.0f;
+            const uint2 e = (i < m) ? st[s + i] : make_uint2(0xFFFFFFFFu, 0u);
+            sT[wv][i] = e.x;
+            sS[wv][i] = __uint_as_float(e.y);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1584,10 +1633,13 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         const uint32_t one = 1;
         HIPCHK(hipMemcpyAsync(counters, &one, 4, hipMemcpyHostToDevice, c->stream)); // offset 0 means "no match"
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
-        group_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
-            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull),
-            counters, coverage && attempt == 0, c->cntTotal.as<uint64_t>(), nTaxa);
+        {
+            auto kern = (nK <= 6) ? group_kernel<6> : group_kernel<0>;
+            kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+                c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+                c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull),
+                counters, coverage && attempt == 0, c->cntTotal.as<uint64_t>(), nTaxa);
+        }
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
         uint32_t used = 0;
@@ -1626,15 +1678,15 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
     // The profile tables are accumulated with integer atomics inside the score kernels; a rerun after
     // a staging overflow must not count twice, so reruns only re-emit rows (addProfile = 0).
     for (int attempt = 0;; ++attempt) {
-        if (wantPerRead && ((rc = c->stTax.reserve(c->stCap * 4)) || (rc = c->stScore.reserve(c->stCap * 4)))) return rc;
+        if (wantPerRead && (rc = c->st.reserve(c->stCap * 8))) return rc;
         HIPCHK(hipMemsetAsync(counters + 1, 0, 12, c->stream)); // staging cursor, error flags, fallback count
         ScoreArgs A;
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.fastScratch = nullptr;
-        A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
+        A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
-        A.stTax = c->stTax.as<uint32_t>(); A.stScore = c->stScore.as<float>();
+        A.st = c->st.as<uint2>();
         A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
         A.wantPerRead = wantPerRead ? 1 : 0;
         A.addProfile = attempt == 0 ? 1 : 0;
@@ -1691,7 +1743,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
                                        rocprim::plus<uint64_t>(), c->stream));
         if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
         row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
-            nReads, c->stTax.as<uint32_t>(), c->stScore.as<float>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
+            nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
         c->haveScores = true;
@@ -1722,6 +1774,7 @@ extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint3
 // ------------------------------------------------------------------------------------------------
 // profile tables
 // ------------------------------------------------------------------------------------------------
+// the three accumulators of a cell folded into a 128-bit value {hi, lo}
 static int fetch_tables(kasa_ctx *c, std::vector<uint64_t> &u, std::vector<uint64_t> &t, std::vector<uint64_t> &hi, std::vector<uint64_t> &lo)
 {
     HIPCHK(hipSetDevice(c->ix->device));
@@ -1732,6 +1785,12 @@ static int fetch_tables(kasa_ctx *c, std::vector<uint64_t> &u, std::vector<uint6
     HIPCHK(hipMemcpy(t.data(), c->cntTotal.p, cells * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hi.data(), c->cntAllHi.p, cells * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(lo.data(), c->cntAllLo.p, cells * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> mid(cells);
+    HIPCHK(hipMemcpy(mid.data(), c->cntAllMid.p, cells * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cells; ++i) {
+        const unsigned __int128 v = ((unsigned __int128)hi[i] << 64) + ((unsigned __int128)mid[i] << 32) + lo[i];
+        hi[i] = (uint64_t)(v >> 64); lo[i] = (uint64_t)v;
+    }
     return KASA_OK;
 }
 
@@ -1778,7 +1837,10 @@ extern "C" int kasa_profile_import_limbs(kasa_ctx *c, const uint64_t *limbs)
     HIPCHK(hipMemcpy(c->cntUnique.p, u.data(), cells * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->cntTotal.p, t.data(), cells * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->cntAllHi.p, hi.data(), cells * 8, hipMemcpyHostToDevice));
+    std::vector<uint64_t> mid(cells);
+    for (size_t i = 0; i < cells; ++i) { mid[i] = lo[i] >> 32; lo[i] &= 0xFFFFFFFFull; }
     HIPCHK(hipMemcpy(c->cntAllLo.p, lo.data(), cells * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->cntAllMid.p, mid.data(), cells * 8, hipMemcpyHostToDevice));
     return KASA_OK;
 }
 
@@ -1875,8 +1937,8 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->stTax, &c->stScore,
-                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
+                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;
