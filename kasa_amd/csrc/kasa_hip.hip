@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -366,7 +368,7 @@ struct kasa_ctx {
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
-    DevBuf scratch, touched, fbList, fastScratch;           // per-block dense score rows; reads left to the slow kernel
+    DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profUniq, profSums;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0;
     DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
@@ -470,7 +472,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -1160,13 +1162,13 @@ struct ScoreArgs {
 // x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
 // with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
 // terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
-__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint32_t c, uint32_t n)
+__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint64_t c, uint32_t n)
 {
     if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
     uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
     if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
-    const uint64_t lo64 = (uint64_t)c * R;
-    const uint64_t hi = __umul64hi((uint64_t)c, R);
+    const uint64_t lo64 = c * R;
+    const uint64_t hi = __umul64hi(c, R);
     const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
     if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
     if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
@@ -1329,15 +1331,35 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // than FNK levels) is handed to score_kernel untouched: nothing of it has reached global memory.
 // ------------------------------------------------------------------------------------------------
 static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
-static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS (first come)
+static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
 static constexpr int FNK = 6;       // levels
-static constexpr int FHS = 1024;    // further taxa of a read: open-addressing table in per-block global scratch
-static constexpr int FOV = 640;     // ... holding at most this many
-static constexpr int FLOG = 896;    // their profile contributions, logged and added at the end of the read
-static constexpr uint32_t ROW_UNSORTED = 0x80000000u;
-static constexpr uint32_t DEAD_SCORE = 0xFFFFFFFFu;   // table entry whose chain moved to a register slot
-static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FHS + FOV + 2 * FLOG + 4 * FPL); // u32 words per block
+static constexpr int FLOG = 960;    // contributions to all other taxa, logged per read and resolved by row_merge_kernel
+static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * FNK * 4 + FLOG)
+static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
+static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG + 4 * FPL); // u32 words per block
 
+// A staging record (8 bytes).  x = taxon (24 bits) | level << 24 (4 bits) | consumed << 28 | kind << 30
+//   kind 0  event:        y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
+//                         `consumed`: its score already went into a register slot (profile still counts it).
+//   kind 1  final score:  y = float bits (a register-slot taxon)
+//   kind 2  profile only: y = |T| << 16 | hits
+static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_CONSUMED = 1u << 28;
+
+__device__ __forceinline__ float event_score(int k, uint32_t n)
+{
+    const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
+    return __fmul_rn(w, __fdiv_rn(1.0f, (float)n));                // Compare.hpp:924
+}
+
+// ------------------------------------------------------------------------------------------------
+// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain per
+// (read, taxon), so 64 reads run side by side in a wavefront.  The (up to) two taxa a read really comes
+// from -- those with a deep match -- live in registers with their per-level hit counters in LDS; every
+// other contribution (chance matches of short prefixes, ~150 per read against a 4e8-record index) is
+// appended to a per-lane log as an 8-byte record and resolved later, per read, by row_merge_kernel.
+// The kernel performs no atomics on the profile tables: everything it finds leaves as records, so it can
+// be rerun.  A read it cannot hold is handed to score_kernel untouched.
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
 {
     __shared__ unsigned long long cnt64[FTA][FNK][64];              // 4 x 16-bit hit counters (|T| = 1..4) per (taxon, level)
@@ -1345,17 +1367,15 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t stride = gridDim.x * 64u;
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
-    // per-block scratch, element i of a lane at [i * 64 + lane]: contiguous per block, so it stays TLB- and cache-friendly
+    // per-block scratch, element i of a lane at [i * 64 + lane]
     uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
-    uint2 *hs = reinterpret_cast<uint2 *>(blk) + lane;                               // {taxon | EMPTY, score bits}
-    uint32_t *used = blk + 64 * 2 * FHS + lane;                                      // hash slots in insertion order
-    uint2 *lg = reinterpret_cast<uint2 *>(blk + 64 * (2 * FHS + FOV)) + lane;        // {cell, n << 16 | hits}
-    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * (2 * FHS + FOV + 2 * FLOG)) + lane; // {F, ref, k | hits << 8, -}
+    uint2 *lg = reinterpret_cast<uint2 *>(blk) + lane;
+    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * 2 * FLOG) + lane;             // {F, ref, k | hits << 8, -}
     for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
         bool fb = false;
-        int np = 0, na = 0, no = 0, nl = 0, nd = 0;
+        int np = 0, na = 0, nl = 0;
         uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu;
         float mS0 = 0.0f, mS1 = 0.0f;
 #pragma unroll
@@ -1374,8 +1394,8 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 if (ref & REF_SINGLE) { n = 1; t0 = ref & 0x7FFFFFFFu; }
                 else if (ref & REF_PAIR) { n = 2; t0 = (ref >> 15) & 0x7FFFu; t1 = ref & 0x7FFFu; }
                 else { n = A.pool[ref]; list = A.pool + ref + 1; }
-                const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
-                const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));       // Compare.hpp:924
+                if (n >= (1u << 13) || c >= (1u << 16)) { fb = true; atomicAdd(&A.why[3], 1u); return; }
+                const float s = event_score((int)k, n);
                 for (uint32_t i = 0; i < n && !fb; ++i) {
                     const uint32_t t = list ? list[i] : (i == 0 ? t0 : t1);
                     int e = -1;
@@ -1383,39 +1403,31 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                     else if (t == mTax1) e = 1;
                     else if (na < FTA && (int)k >= kPromote) {
                         // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
-                        // slot.  If shallow matches already started its chain in the table, carry the sum over.
-                        uint32_t o = (t * 2654435761u) >> 22;
-                        uint2 cur = hs[(size_t)o * 64];
-                        while (cur.x != t && cur.x != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = hs[(size_t)o * 64]; }
+                        // slot.  If shallow matches already started its chain in the log, replay them first.
                         float v0 = 0.0f;
-                        if (cur.x == t) { v0 = __uint_as_float(cur.y); hs[(size_t)o * 64] = make_uint2(t, DEAD_SCORE); ++nd; }
+                        for (int q = 0; q < nl; ++q) {
+                            uint2 e2 = lg[(size_t)q * 64];
+                            if ((e2.x & 0xC0FFFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
+                            const float s2 = event_score(A.kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                            for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
+                            e2.x |= RK_CONSUMED;
+                            lg[(size_t)q * 64] = e2;
+                        }
                         e = na;
                         if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
                         ++na;
                     }
-                    bool logIt = true;
+                    uint32_t kind = 0xFFFFFFFFu;                               // record to log, if any
                     if (e >= 0) {
                         float v = (e == 0) ? mS0 : mS1;
                         for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
                         if (e == 0) mS0 = v; else mS1 = v;
-                        if (n <= 4) { cnt64[e][lv][lane] += (unsigned long long)c << (16 * (n - 1)); logIt = false; }
-                    } else {
-                        uint32_t o = (t * 2654435761u) >> 22;                  // 10 bits
-                        uint2 cur = hs[(size_t)o * 64];
-                        while (cur.x != t && cur.x != 0xFFFFFFFFu) { o = (o + 1) & (FHS - 1); cur = hs[(size_t)o * 64]; }
-                        float v = 0.0f;
-                        if (cur.x == t) v = __uint_as_float(cur.y);
-                        else {
-                            if (no == FOV) { fb = true; atomicAdd(&A.why[1], 1u); break; }
-                            used[(size_t)no * 64] = o;
-                            ++no;
-                        }
-                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);
-                        hs[(size_t)o * 64] = make_uint2(t, __float_as_uint(v));
-                    }
-                    if (logIt) {
-                        if (nl == FLOG || n >= (1u << 16) || c >= (1u << 16)) { fb = true; atomicAdd(&A.why[nl == FLOG ? 2 : 3], 1u); break; }
-                        lg[(size_t)nl * 64] = make_uint2((uint32_t)lv * A.nTaxa + t, (n << 16) | c);
+                        if (n <= 4) cnt64[e][lv][lane] += (unsigned long long)c << (16 * (n - 1));
+                        else kind = RK_PROFILE;
+                    } else kind = 0u;
+                    if (kind != 0xFFFFFFFFu) {
+                        if (nl == FLOG || t >= (1u << 20)) { fb = true; atomicAdd(&A.why[2], 1u); break; }
+                        lg[(size_t)nl * 64] = make_uint2(t | ((uint32_t)lv << 24) | kind, (n << 16) | c);
                         ++nl;
                     }
                 }
@@ -1485,10 +1497,17 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 pcur = pnext;
             }
         }
-        // ---- converged: one staging allocation per wavefront
-        const uint32_t m = (active && !fb && A.wantPerRead) ? (uint32_t)(na + no - nd) : 0u;
+        // ---- the read's staging row: final scores of the register taxa, their counters as profile records, the log
+        uint32_t nprof = 0;
+        if (active && !fb)
+            for (int e = 0; e < na; ++e)
+                for (int lv = 0; lv < nK; ++lv) {
+                    const unsigned long long pk = cnt64[e][lv][lane];
+                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);
+                }
+        const uint32_t m = (active && !fb) ? (uint32_t)na + nprof + (uint32_t)nl : 0u;
         uint32_t incl = m;
-        for (int off = 1; off < 64; off <<= 1) {
+        for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
             const uint32_t o = __shfl_up(incl, off);
             if (lane >= off) incl += o;
         }
@@ -1497,43 +1516,24 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
         if (lane == 0 && total) start = atomicAdd(A.stCursor, total);
         start = __shfl(start, 0) + (incl - m);
         if (active && !fb) {
-            if (A.wantPerRead) {
-                A.rowPos[r] = start; A.rowLen[r] = m | (m > 1 ? ROW_UNSORTED : 0u);
-                if (start + m <= A.stCap) {
-                    if (na > 0) A.st[start] = make_uint2(mTax0, __float_as_uint(mS0));
-                    if (na > 1) A.st[start + 1] = make_uint2(mTax1, __float_as_uint(mS1));
-                    uint32_t w = start + na;
-                    for (int i = 0; i < no; ++i) {
-                        const uint2 e2 = hs[(size_t)used[(size_t)i * 64] * 64];
-                        if (e2.y == DEAD_SCORE) continue;
-                        A.st[w] = e2; ++w;
-                    }
-                }
-            }
-            if (A.addProfile) {
+            A.rowPos[r] = start; A.rowLen[r] = m | (m ? ROW_MERGE : 0u);
+            if (start + m <= A.stCap) {
+                uint32_t w = start;
+                if (na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
+                if (na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
                 for (int e = 0; e < na; ++e) {
                     const uint32_t t = (e == 0) ? mTax0 : mTax1;
                     for (int lv = 0; lv < nK; ++lv) {
                         const unsigned long long pk = cnt64[e][lv][lane];
-                        if (!pk) continue;
-                        const size_t cell = (size_t)lv * A.nTaxa + t;
-                        const uint32_t c1 = (uint32_t)(pk & 0xFFFFu);
-                        if (c1) { atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c1); fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c1, 1); }
-                        for (uint32_t q = 1; q < 4; ++q) {
-                            const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFu);
-                            if (cq) fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, cq, q + 1);
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
+                            if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << 24) | RK_PROFILE, ((q + 1) << 16) | cq);
                         }
                     }
                 }
-                for (int i = 0; i < nl; ++i) {
-                    const uint2 e2 = lg[(size_t)i * 64];
-                    const uint32_t n = e2.y >> 16, c = e2.y & 0xFFFFu;
-                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[e2.x], (unsigned long long)c);
-                    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, e2.x, c, n);
-                }
+                for (int i = 0; i < nl; ++i) A.st[w + i] = lg[(size_t)i * 64];
             }
         }
-        for (int i = 0; i < no; ++i) hs[(size_t)used[(size_t)i * 64] * 64] = make_uint2(0xFFFFFFFFu, 0u);
         const unsigned long long fbMask = __ballot(active && fb);
         if (fbMask) {
             uint32_t fbBase = 0;
@@ -1544,60 +1544,129 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
     }
 }
 
-// Rows of the staging area -> CSR in read order; rows the fast path left unsorted (<= FTA + FOV entries)
-// are sorted by taxon on the way: one wavefront per row, bitonic in LDS.
+// ------------------------------------------------------------------------------------------------
+// row_merge: one wavefront per staging row written by score_fast_kernel.  Sorts the row's records by
+// (taxon, position) in LDS, sums each taxon's event scores IN THAT ORDER (= the read's flush order), and
+// compacts the row in place to final {taxon, score} pairs, taxon ascending.  Every event / profile record
+// also leaves as a 64-bit profile key {level:3 | |T|:13 | taxon:20 | hits:16} for the sort-reduce below.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
+                                                       uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
+                                                       int kHigh)
+{
+    __shared__ uint32_t sKey[RMAX];
+    __shared__ uint16_t sIdx[RMAX];
+    __shared__ uint2 sRec[RMAX];
+    const int lane = threadIdx.x;
+    for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+        const uint32_t raw = rowLen[r];
+        if (!(raw & ROW_MERGE)) continue;                              // uniform per block
+        const uint32_t m = raw & ~ROW_MERGE;
+        const uint32_t s0 = rowPos[r];
+        uint32_t n2 = 2;
+        while (n2 < m) n2 <<= 1;
+        for (uint32_t i = lane; i < n2; i += 64) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (i < m) {
+                const uint2 e = st[s0 + i];
+                sRec[i] = e;
+                const uint32_t kind = e.x >> 30;
+                if (kind != 2u) key = ((e.x & 0xFFFFFu) << 11) | (kind == 1u ? 0u : (i & 0x7FFu));   // final score first in its run
+                if (kind != 1u)
+                    profKeys[s0 + i] = ((uint64_t)(((e.x >> 24) & 7u) << 13 | (e.y >> 16)) << 36) | ((uint64_t)(e.x & 0xFFFFFu) << 16) | (e.y & 0xFFFFu);
+            }
+            sKey[i] = key;
+            sIdx[i] = (uint16_t)i;
+        }
+        __syncthreads();
+        for (uint32_t size = 2; size <= n2; size <<= 1)
+            for (uint32_t stp = size >> 1; stp > 0; stp >>= 1) {
+                for (uint32_t i = lane; i < n2; i += 64) {
+                    const uint32_t j = i ^ stp;
+                    if (j > i) {
+                        const bool up = (i & size) == 0;
+                        const uint32_t a = sKey[i], b = sKey[j];
+                        if ((a > b) == up) {
+                            sKey[i] = b; sKey[j] = a;
+                            const uint16_t t = sIdx[i]; sIdx[i] = sIdx[j]; sIdx[j] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        // runs of equal taxon; the lane that sees a run start replays the run
+        uint32_t outBase = 0;
+        for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            bool startsRun = false;
+            float v = 0.0f;
+            uint32_t tax = 0;
+            if (i < m && sKey[i] != 0xFFFFFFFFu) {
+                tax = sKey[i] >> 11;
+                startsRun = (i == 0) || ((sKey[i - 1] >> 11) != tax);
+                if (startsRun) {
+                    bool any = false;
+                    for (uint32_t q = i; q < m && sKey[q] != 0xFFFFFFFFu && (sKey[q] >> 11) == tax; ++q) {
+                        const uint2 e = sRec[sIdx[q]];
+                        if ((e.x >> 30) == 1u) { v = __uint_as_float(e.y); any = true; }
+                        else if (!(e.x & RK_CONSUMED)) {
+                            const float s = event_score(kHigh - (int)((e.x >> 24) & 15u), e.y >> 16);
+                            for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, s);
+                            any = true;
+                        }
+                    }
+                    startsRun = any;
+                }
+            }
+            const unsigned long long mk = __ballot(startsRun);
+            if (startsRun) st[s0 + outBase + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2(tax, __float_as_uint(v));
+            outBase += (uint32_t)__popcll(mk);
+        }
+        if (lane == 0) rowLen[r] = outBase;
+        __syncthreads();
+    }
+}
+
+struct ProfKeyOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & 0xFFFFFFFFFull; } };
+struct ProfHitsOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return v & 0xFFFFull; } };
+
+// profile sort-reduce: keys sorted on bits [16, 52); one add per distinct (level, |T|, taxon)
+__global__ void profile_apply_kernel(const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ sums, const uint32_t *__restrict__ nRuns,
+                                     uint32_t nTaxa, uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
+                                     uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *nRuns) return;
+    const uint64_t key = uniq[i];
+    if (key == 0xFFFFFFFFFull) return;                                  // sentinel slots
+    const uint32_t tax = (uint32_t)(key & 0xFFFFFu);
+    const uint32_t n = (uint32_t)((key >> 20) & 0x1FFFu);
+    const uint32_t lv = (uint32_t)(key >> 33);
+    const uint64_t c = sums[i];
+    const size_t cell = (size_t)lv * nTaxa + tax;
+    if (n == 1) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
+    fixed_add(hiTab, midTab, loTab, cell, c, n);
+}
+
+// final rows -> CSR in read order (rows are already {taxon, score}, taxon ascending)
 __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint2 *__restrict__ st,
                                 uint32_t *__restrict__ outTax, float *__restrict__ outScore)
 {
-    __shared__ uint32_t sT[4][1024];
-    __shared__ float sS[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t waves = gridDim.x * 4u;
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += waves) {
         const uint32_t s = rowPos[r];
-        const uint32_t raw = rowLen[r];
-        const uint32_t m = raw & ~ROW_UNSORTED;
+        const uint32_t m = rowLen[r] & ~ROW_MERGE;
         const uint64_t o = rowOff[r];
-        if (!(raw & ROW_UNSORTED) || m > 1024u) {
-            for (uint32_t i = lane; i < m; i += 64) { const uint2 e = st[s + i]; outTax[o + i] = e.x; outScore[o + i] = __uint_as_float(e.y); }
-            continue;
-        }
-        uint32_t n2 = 2;
-        while (n2 < m) n2 <<= 1;
-        for (uint32_t i = lane; i < n2; i += 64) {
-            const uint2 e = (i < m) ? st[s + i] : make_uint2(0xFFFFFFFFu, 0u);
-            sT[wv][i] = e.x;
-            sS[wv][i] = __uint_as_float(e.y);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t size = 2; size <= n2; size <<= 1)
-            for (uint32_t st = size >> 1; st > 0; st >>= 1) {
-                for (uint32_t i = lane; i < n2; i += 64) {
-                    const uint32_t j = i ^ st;
-                    if (j > i) {
-                        const bool up = (i & size) == 0;
-                        const uint32_t a = sT[wv][i], b = sT[wv][j];
-                        if ((a > b) == up) {
-                            sT[wv][i] = b; sT[wv][j] = a;
-                            const float fa = sS[wv][i]; sS[wv][i] = sS[wv][j]; sS[wv][j] = fa;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-        for (uint32_t i = lane; i < m; i += 64) { outTax[o + i] = sT[wv][i]; outScore[o + i] = sS[wv][i]; }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < m; i += 64) { const uint2 e = st[s + i]; outTax[o + i] = e.x; outScore[o + i] = __uint_as_float(e.y); }
     }
 }
 
 __global__ void widen_kernel(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = in[i] & 0x7FFFFFFFu;   // bit 31 = ROW_UNSORTED
+    if (i < n) out[i] = in[i] & 0x7FFFFFFFu;   // bit 31 = ROW_MERGE
 }
 
 extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverage)
@@ -1668,19 +1737,20 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
     if ((rc = timer_end(c, c->timers[KASA_STAGE_REGROUP], a, b))) return rc;
 
     // ---- score
-    if (wantPerRead) {
-        if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
-            (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)))
-            return rc;
-        if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 3);
-    }
-    if ((rc = c->fbList.reserve((size_t)nReads * 4 + 64))) return rc;
-    // The profile tables are accumulated with integer atomics inside the score kernels; a rerun after
-    // a staging overflow must not count twice, so reruns only re-emit rows (addProfile = 0).
+    if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
+        (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)) || (rc = c->fbList.reserve((size_t)nReads * 4 + 64)))
+        return rc;
+    if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
+    const bool fast = nK <= FNK && !c->forceSlowScore;
+    bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
+    uint32_t staged = 0;
+    ScoreArgs A;
     for (int attempt = 0;; ++attempt) {
-        if (wantPerRead && (rc = c->st.reserve(c->stCap * 8))) return rc;
+        if (attempt > 4) return fail(KASA_E_LIMIT, "score staging did not converge");
+        if ((rc = c->st.reserve(c->stCap * 8))) return rc;
         HIPCHK(hipMemsetAsync(counters + 1, 0, 12, c->stream)); // staging cursor, error flags, fallback count
-        ScoreArgs A;
+        HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
+        HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
         A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.fastScratch = nullptr;
@@ -1688,26 +1758,28 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.st = c->st.as<uint2>();
         A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
-        A.wantPerRead = wantPerRead ? 1 : 0;
-        A.addProfile = attempt == 0 ? 1 : 0;
-        if (getenv("KASA_EXPERIMENT_NOPROFILE")) A.addProfile = 0; // measurement experiment only
+        A.wantPerRead = 1;
+        A.addProfile = slowProfileDone ? 0 : 1;
         A.list = nullptr; A.nList = 0;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
-        HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
-        const bool fast = nK <= FNK && !c->forceSlowScore;
+        uint32_t h[3] = {0, 0, 0};
         if (fast) {
             const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 20u);
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
-            // hash slots start empty (0xFF..); the kernel restores that after every read
-            HIPCHK(hipMemsetAsync(A.fastScratch, 0xFF, words * 4, c->stream));
             score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(&nSlow, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(h, counters + 1, 12, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
+            nSlow = h[2];
+            if ((uint64_t)h[0] > c->stCap) {          // the fast kernel has no side effects: grow and rerun
+                if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
+                c->stCap = (uint64_t)h[0] + h[0] / 8 + (uint64_t)nSlow * 64 + 1024;
+                continue;
+            }
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         if (nSlow > 0) {
@@ -1717,21 +1789,48 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
             A.scratch = c->scratch.as<float>();
             score_kernel<<<blocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
+            slowProfileDone = true;
         }
         c->lastSlowReads = nSlow;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
-        uint32_t h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, counters + 1, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (h[1] & 2u) return fail(KASA_E_LIMIT, "a read keeps more than %d distinct groups pending; this build cannot order it", PCAP);
-        if (!wantPerRead) break;
-        if ((uint64_t)h[0] <= c->stCap) { c->nnz = h[0]; break; }
+        if ((uint64_t)h[0] <= c->stCap) { staged = h[0]; break; }
         c->stCap = (uint64_t)h[0] + h[0] / 8 + 1024;
-        if (attempt > 2) return fail(KASA_E_LIMIT, "score staging did not converge");
+    }
+    // ---- resolve the fast kernel's records: per-read merge, then the profile contributions by sort + reduce
+    if (fast && staged > 0) {
+        if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
+        if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;
+        HIPCHK(hipMemsetAsync(c->profKeys.p, 0xFF, (size_t)staged * 8, c->stream));
+        row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), nReads,
+            c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh);
+        HIPCHK(hipGetLastError());
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 52u, c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 52u, c->stream));
+        const uint64_t perTaxon = std::min<uint64_t>(8191, nTaxa);
+        const uint64_t cap = std::min<uint64_t>((uint64_t)staged, (uint64_t)nK * nTaxa * perTaxon) + 2;
+        if ((rc = c->profUniq.reserve(cap * 8)) || (rc = c->profSums.reserve(cap * 8))) return rc;
+        auto keysIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfKeyOf());
+        auto valsIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfHitsOf());
+        uint32_t *nRuns = counters + 16;
+        tmpBytes = 0;
+        HIPCHK(rocprim::reduce_by_key(nullptr, tmpBytes, keysIn, valsIn, (unsigned int)staged, c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(),
+                                      nRuns, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::reduce_by_key(c->sortTmp.p, tmpBytes, keysIn, valsIn, (unsigned int)staged, c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(),
+                                      nRuns, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), c->stream));
+        profile_apply_kernel<<<blocks_for(cap, 256), 256, 0, c->stream>>>(c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(), nRuns, nTaxa,
+            c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+        HIPCHK(hipGetLastError());
+        if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
     }
     if (wantPerRead) {
         // CSR offsets = exclusive scan of the row lengths, then rows copied in read order
-        DevBuf &len64 = c->qReadA; // reuse: u64[nReads+1] fits (nQ >= nReads is not guaranteed -> reserve)
+        DevBuf &len64 = c->qReadA; // reuse
         if ((rc = len64.reserve(((size_t)nReads + 1) * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(len64.p, 0, ((size_t)nReads + 1) * 8, c->stream));
         widen_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rowLen.as<uint32_t>(), len64.as<uint64_t>(), nReads);
@@ -1741,6 +1840,10 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
         HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
+        uint64_t nnz = 0;
+        HIPCHK(hipMemcpyAsync(&nnz, c->rowOff.as<uint64_t>() + nReads, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->nnz = nnz;
         if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
         row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
             nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
@@ -1937,7 +2040,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
