@@ -131,7 +131,8 @@ int kasa_batch_set_queries(kasa_ctx *ctx, const uint64_t *kmers, const uint32_t 
 int kasa_batch_fetch_lookup(kasa_ctx *ctx, uint8_t *depth, uint32_t *indexPos, uint64_t n);
 int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
- * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup; lastSlowReads (may be
+ * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row
+ * merge instead of the bitmap one; lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

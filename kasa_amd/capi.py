@@ -221,7 +221,8 @@ class Context:
         _check(lib().kasa_ctx_debug(self.h, C.c_int(int(on)), None))
 
     def debug_flags(self, flags: int):
-        """bit 0: general score kernel for every read; bit 1: per-query lookup instead of streamed tiles."""
+        """bit 0: general score kernel for every read; bit 1: per-query lookup instead of streamed tiles;
+        bit 2: sorting row merge instead of the bitmap one."""
         _check(lib().kasa_ctx_debug(self.h, C.c_int(int(flags)), None))
 
     def last_slow_reads(self) -> int:

@@ -369,7 +369,7 @@ struct kasa_ctx {
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profUniq, profSums;           // per-block dense score rows; reads left to the slow kernel
-    bool forceSlowScore = false; uint32_t lastSlowReads = 0;
+    bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
     DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
     uint64_t poolCap = 0, stCap = 0, nnz = 0;
@@ -1338,6 +1338,10 @@ static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sort
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
 static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG + 4 * FPL); // u32 words per block
 
+// One wavefront working alone on LDS: LDS instructions of a wave execute in order, so only the compiler has
+// to be kept from moving them across the point (a workgroup barrier would also drain pending global stores).
+#define LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 // A staging record (8 bytes).  x = taxon (24 bits) | level << 24 (4 bits) | consumed << 28 | kind << 30
 //   kind 0  event:        y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
 //                         `consumed`: its score already went into a register slot (profile still counts it).
@@ -1433,18 +1437,32 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 }
             };
 
+            // the gather of a query's record (random, 48 B) is issued one query ahead of its use
             uint32_t pcur = cnt ? A.plist[o0] : 0u;
+            uint32_t pnext = (cnt > 1) ? A.plist[o0 + 1] : 0xFFFFFFFFu;
+            uint2 cur[FNK], nxt[FNK];
+#pragma unroll
+            for (int i = 0; i < FNK; ++i) {
+                const int lv = nK - 1 - i;
+                cur[i] = (cnt && lv >= 0) ? A.rec[(size_t)pcur * nK + lv] : make_uint2(0xFFFFFFFFu, 0u);
+                nxt[i] = make_uint2(0xFFFFFFFFu, 0u);
+            }
             for (uint32_t j = 0; j < cnt && !fb; ++j) {
-                const uint32_t pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
+                const uint32_t pnn = (j + 2 < cnt) ? A.plist[o0 + j + 2] : 0xFFFFFFFFu;
+                if (j + 1 < cnt) {
+#pragma unroll
+                    for (int i = 0; i < FNK; ++i) {
+                        const int lv = nK - 1 - i;
+                        if (lv >= 0) nxt[i] = A.rec[(size_t)pnext * nK + lv];
+                    }
+                }
                 // the (up to) 6 events of this query, k ascending; absent levels sink to the end
                 uint32_t eF[FNK], eR[FNK], eK[FNK];
-                const uint2 *rp = A.rec + (size_t)pcur * nK;
                 bool early = true;
 #pragma unroll
                 for (int i = 0; i < FNK; ++i) {
                     const int lv = nK - 1 - i;
-                    uint2 v = make_uint2(0xFFFFFFFFu, 0u);
-                    if (lv >= 0) v = rp[lv];
+                    uint2 v = cur[i];
                     if (v.y == 0u) v.x = 0xFFFFFFFFu;
                     eF[i] = v.x; eR[i] = v.y; eK[i] = (uint32_t)(A.kHigh - lv);
                     if (v.y != 0u && v.x > pnext) early = false;
@@ -1494,7 +1512,9 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         np -= nf;
                     }
                 }
-                pcur = pnext;
+#pragma unroll
+                for (int i = 0; i < FNK; ++i) cur[i] = nxt[i];
+                pcur = pnext; pnext = pnn;
             }
         }
         // ---- the read's staging row: final scores of the register taxa, their counters as profile records, the log
@@ -1578,7 +1598,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
             sKey[i] = key;
             sIdx[i] = (uint16_t)i;
         }
-        __syncthreads();
+        LDS_WAVE_SYNC();
         for (uint32_t size = 2; size <= n2; size <<= 1)
             for (uint32_t stp = size >> 1; stp > 0; stp >>= 1) {
                 for (uint32_t i = lane; i < n2; i += 64) {
@@ -1592,7 +1612,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                         }
                     }
                 }
-                __syncthreads();
+                LDS_WAVE_SYNC();
             }
         // runs of equal taxon; the lane that sees a run start replays the run
         uint32_t outBase = 0;
@@ -1623,7 +1643,93 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
             outBase += (uint32_t)__popcll(mk);
         }
         if (lane == 0) rowLen[r] = outBase;
-        __syncthreads();
+        LDS_WAVE_SYNC();
+    }
+}
+
+// The same for indices with at most BM_WORDS * 32 taxa, without sorting: a bitmap of the row's taxa gives every
+// distinct taxon its rank (= its slot in the ascending output); only taxa with several records need the ordered
+// replay, done by the lane that holds the taxon's first record.
+// Two instantiations: rows of up to 256 records over up to 2048 taxa need only 4.5 KiB of LDS, so many rows are
+// in flight per CU (the kernel is latency-bound: a handful of dependent global round trips per row); the rest
+// takes the large instantiation.  A row is processed by exactly one of them (mLo < m <= RCAP).
+static constexpr int BM_WORDS = 512;
+
+template <int RCAP, int BMW>
+__global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
+                                                              uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
+                                                              int kHigh, uint32_t nTaxa, uint32_t mLo)
+{
+    __shared__ uint32_t bm[BMW], pre[BMW];
+    __shared__ uint2 sRec[RCAP];
+    __shared__ uint32_t cnt[RCAP], first[RCAP];
+    const int lane = threadIdx.x;
+    const uint32_t W = (nTaxa + 31u) >> 5;
+    for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
+        const uint32_t raw = rowLen[r];
+        if (!(raw & ROW_MERGE)) continue;                              // uniform per block
+        const uint32_t m = raw & ~ROW_MERGE;
+        if (m <= mLo || m > (uint32_t)RCAP) continue;
+        const uint32_t s0 = rowPos[r];
+        for (uint32_t w = lane; w < W; w += 64) bm[w] = 0u;
+        for (uint32_t i = lane; i < m; i += 64) { cnt[i] = 0u; first[i] = 0xFFFFFFFFu; }
+        LDS_WAVE_SYNC();
+        for (uint32_t i = lane; i < m; i += 64) {
+            const uint2 e = st[s0 + i];
+            sRec[i] = e;
+            const uint32_t kind = e.x >> 30;
+            const uint32_t t = e.x & 0xFFFFFu;
+            if (kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
+            if (kind != 1u)
+                profKeys[s0 + i] = ((uint64_t)(((e.x >> 24) & 7u) << 13 | (e.y >> 16)) << 36) | ((uint64_t)t << 16) | (e.y & 0xFFFFu);
+        }
+        LDS_WAVE_SYNC();
+        uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
+        for (uint32_t w0 = 0; w0 < W; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const uint32_t pc = (w < W) ? (uint32_t)__popc(bm[w]) : 0u;
+            uint32_t incl = pc;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            if (w < W) pre[w] = carry + incl - pc;
+            carry += __shfl(incl, 63);
+        }
+        const uint32_t nSlots = carry;
+        LDS_WAVE_SYNC();
+        for (uint32_t i = lane; i < m; i += 64) {
+            const uint2 e = sRec[i];
+            if ((e.x >> 30) == 2u) continue;
+            const uint32_t t = e.x & 0xFFFFFu;
+            const uint32_t slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+            atomicAdd(&cnt[slot], 1u);
+            atomicMin(&first[slot], i);
+        }
+        LDS_WAVE_SYNC();
+        for (uint32_t i = lane; i < m; i += 64) {
+            const uint2 e = sRec[i];
+            if ((e.x >> 30) == 2u) continue;
+            const uint32_t t = e.x & 0xFFFFFu;
+            const uint32_t slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+            if (first[slot] != i) continue;                            // the taxon's first record owns the slot
+            float v = 0.0f;
+            const uint32_t nrec = cnt[slot];
+            uint32_t seen = 0;
+            for (uint32_t q = i; q < m && seen < nrec; ++q) {          // its records in row order = flush order
+                const uint2 e2 = sRec[q];
+                if ((e2.x >> 30) == 2u || (e2.x & 0xFFFFFu) != t) continue;
+                ++seen;
+                if ((e2.x >> 30) == 1u) v = __uint_as_float(e2.y);
+                else if (!(e2.x & RK_CONSUMED)) {
+                    const float sc = event_score(kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                    for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
+                }
+            }
+            st[s0 + slot] = make_uint2(t, __float_as_uint(v));
+        }
+        if (lane == 0) rowLen[r] = nSlots;                             // flag cleared: the other instantiation skips it
+        LDS_WAVE_SYNC();
     }
 }
 
@@ -1804,8 +1910,18 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(c->profKeys.p, 0xFF, (size_t)staged * 8, c->stream));
-        row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), nReads,
-            c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh);
+        if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
+            uint32_t mLo = 0;
+            if (nTaxa <= 2048u) {
+                row_merge_bitmap_kernel<256, 64><<<std::min<uint32_t>(nReads, 256u * 64u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                    c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u);
+                mLo = 256;
+            }
+            row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo);
+        } else
+            row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), nReads,
+                c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh);
         HIPCHK(hipGetLastError());
         size_t tmpBytes = 0;
         HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 52u, c->stream));
@@ -2051,7 +2167,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlowReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (forceSlowScore >= 0) { c->forceSlowScore = (forceSlowScore & 1) != 0; c->lookupMode = (forceSlowScore & 2) ? 1 : 0; }
+    if (forceSlowScore >= 0) { c->forceSlowScore = (forceSlowScore & 1) != 0; c->lookupMode = (forceSlowScore & 2) ? 1 : 0; c->debugFlags = forceSlowScore; }
     if (lastSlowReads) *lastSlowReads = c->lastSlowReads;
     if (getenv("KASA_DEBUG_WHY")) {
         uint32_t w[8];

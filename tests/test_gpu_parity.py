@@ -76,7 +76,7 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
         ctx.close(); dix.close()
 
 
-@pytest.mark.parametrize("slow", [0, 1, 2], ids=["fast+fallback", "general_score", "per_query_lookup"])
+@pytest.mark.parametrize("slow", [0, 1, 2, 4], ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge"])
 @pytest.mark.parametrize("seed", range(24))
 def test_adversarial_queries_vs_oracle(seed, slow):
     """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles."""
@@ -140,7 +140,7 @@ def test_medium_synthetic_vs_oracle():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    for slow in (0, 1, 2):
+    for slow in (0, 1, 2, 4):
         ctx.debug_flags(slow)
         ctx.profile_reset()
         ctx.run_batch(batch.bases, batch.offsets, True)
