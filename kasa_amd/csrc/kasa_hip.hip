@@ -901,43 +901,42 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 // ------------------------------------------------------------------------------------------------
 // Block-wide scans over the 256 per-thread aggregates of a tile (each thread owns ITEMS consecutive
 // positions).  suffix_min: min over threads to the right; prefix_max: max over threads to the left.
+// suffix_min: min over threads to the right; prefix_max: max over threads to the left.  Each wavefront scans
+// with shuffles, the four wavefront totals are combined through LDS: two barriers per scan.
 __device__ __forceinline__ uint32_t block_excl_suffix_min(uint32_t v, uint32_t *sh)
 {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < TILE_THREADS; off <<= 1) {
-        const uint32_t o = (t + off < TILE_THREADS) ? sh[t + off] : NOPOS;
-        __syncthreads();
-        if (o < sh[t]) sh[t] = o;
-        __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t incl = v;                                      // inclusive suffix min inside the wavefront
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(incl, off);
+        if (lane + off < 64 && o < incl) incl = o;
     }
-    const uint32_t r = (t + 1 < TILE_THREADS) ? sh[t + 1] : NOPOS;
+    uint32_t excl = __shfl_down(incl, 1);
+    if (lane == 63) excl = NOPOS;
+    if (lane == 0) sh[wv] = incl;
     __syncthreads();
-    return r;
+    for (int w = wv + 1; w < TILE_THREADS / 64; ++w) { const uint32_t o = sh[w]; if (o < excl) excl = o; }
+    __syncthreads();
+    return excl;
 }
 
 __device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
 {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < TILE_THREADS; off <<= 1) {
-        const int o = (t >= off) ? sh[t - off] : -1;
-        __syncthreads();
-        if (o > sh[t]) sh[t] = o;
-        __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off && o > incl) incl = o;
     }
-    const int r = (t > 0) ? sh[t - 1] : -1;
+    int excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -1;
+    if (lane == 63) sh[wv] = incl;
     __syncthreads();
-    return r;
+    for (int w = 0; w < wv; ++w) { const int o = sh[w]; if (o > excl) excl = o; }
+    __syncthreads();
+    return excl;
 }
 
-// Taxon set of the index group (letters shared >= g) around entry j (BitArray.hpp:98-117 semantics:
-// distinct taxa in index order), encoded in 32 bits:
-//   REF_SINGLE | taxon                      one taxon
-//   REF_PAIR | taxonA << 15 | taxonB        two taxa, both < 2^15 (index order)
-//   offset into `pool`                      {n, taxon_1..n} appended there
 // Step 1: bounds [a, b) of the group, its number of distinct taxa, and the 32-bit encoding when it fits
 // inline (0 = needs n + 1 words in the pool).
 __device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const uint8_t *__restrict__ meta,
@@ -984,19 +983,19 @@ __device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t 
 
 __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *sh, uint32_t &total)
 {
-    const int t = threadIdx.x;
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < TILE_THREADS; off <<= 1) {
-        const uint32_t o = (t >= off) ? sh[t - off] : 0u;
-        __syncthreads();
-        sh[t] += o;
-        __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
     }
-    const uint32_t incl = sh[t];
-    total = sh[TILE_THREADS - 1];
+    if (lane == 63) sh[wv] = incl;
     __syncthreads();
-    return incl - v;
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < TILE_THREADS / 64; ++w) { const uint32_t o = sh[w]; if (w < wv) before += o; all += o; }
+    total = all;
+    __syncthreads();
+    return before + incl - v;
 }
 
 // One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
@@ -1650,7 +1649,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
 // The same for indices with at most BM_WORDS * 32 taxa, without sorting: a bitmap of the row's taxa gives every
 // distinct taxon its rank (= its slot in the ascending output); only taxa with several records need the ordered
 // replay, done by the lane that holds the taxon's first record.
-// Two instantiations: rows of up to 256 records over up to 2048 taxa need only 4.5 KiB of LDS, so many rows are
+// Two instantiations: rows of up to 512 records over up to 2048 taxa need only 8.5 KiB of LDS, so many rows are
 // in flight per CU (the kernel is latency-bound: a handful of dependent global round trips per row); the rest
 // takes the large instantiation.  A row is processed by exactly one of them (mLo < m <= RCAP).
 static constexpr int BM_WORDS = 512;
@@ -1913,9 +1912,9 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
-                row_merge_bitmap_kernel<256, 64><<<std::min<uint32_t>(nReads, 256u * 64u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                     c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u);
-                mLo = 256;
+                mLo = 512;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                 c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo);
