@@ -28,5 +28,22 @@ def build(force: bool = False) -> str:
     return SO
 
 
+HOST_SRC = os.path.join(HERE, "host", "kasa_identify.cpp")
+HOST_BIN = os.path.join(HERE, "host", "kasa_identify")
+
+
+def build_host(force: bool = False) -> str:
+    """The C++ host driver (kASA's `identify` CLI over the C ABI)."""
+    build()
+    newest = max(os.path.getmtime(p) for p in (HOST_SRC, HEADER, os.path.join(HERE, "host", "grisu_powers.inc")))
+    if not force and os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) >= newest:
+        return HOST_BIN
+    cmd = ["g++", "-O2", "-std=c++17", "-o", HOST_BIN, HOST_SRC, "-L" + HERE, "-lkasa_hip", "-lz",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_host(force=True))

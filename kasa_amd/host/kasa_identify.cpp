@@ -1,0 +1,530 @@
+// kasa_identify -- C++ host driver for `kASA identify` on top of the C ABI in include/kasa_hip.h.
+//
+// Keeps the reference's CLI surface for this mode (source/main.cpp:303-586, :979-1116): the same flags,
+// the same index / trie / frequency / content files, the same per-read (JSON / JSONL / TSV / Kraken) and
+// profile (CSV) outputs, "OUT:" / "ERROR:" prefixes and exit codes.  What Compare::CompareWithLib_partialSort
+// (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
+// file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
+//
+// Not supported here (reported as errors, never silently ignored): protein input, --one, -e/--unique,
+// --filter/--coherence/--visualize, paired-end, 128-bit and halved indices.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "../../include/kasa_hip.h"
+
+using std::string;
+using std::vector;
+
+static void throwLast() { throw std::runtime_error(kasa_last_error()); }
+
+// ---------------------------------------------------------------------------------------------------
+// number text: Grisu2 as source/utils/dToStr.h prints doubles (same grid, same rounding, same prettify)
+// ---------------------------------------------------------------------------------------------------
+namespace numtext {
+struct DiyFp { uint64_t f; int e; };
+static const DiyFp kPowers[87] = {
+#include "grisu_powers.inc"
+};
+static inline DiyFp mul(DiyFp a, DiyFp b)
+{
+    const unsigned __int128 p = (unsigned __int128)a.f * b.f;
+    uint64_t h = (uint64_t)(p >> 64);
+    if ((uint64_t)p & (1ull << 63)) ++h;
+    return {h, a.e + b.e + 64};
+}
+static inline DiyFp normalize(uint64_t f, int e)
+{
+    const int s = __builtin_clzll(f);
+    return {f << s, e - s};
+}
+static void grisuRound(char *buf, int len, uint64_t delta, uint64_t rest, uint64_t tenKappa, uint64_t wpw)
+{
+    while (rest < wpw && delta - rest >= tenKappa && (rest + tenKappa < wpw || wpw - rest > rest + tenKappa - wpw)) {
+        buf[len - 1]--;
+        rest += tenKappa;
+    }
+}
+static int countDigits32(uint32_t n)
+{
+    int d = 1;
+    for (uint32_t lim = 10; d < 10 && n >= lim; lim *= 10) ++d;
+    return d;
+}
+static void grisu2(double value, char *buf, int *length, int *K)
+{
+    static const uint32_t kPow10[] = {1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000, 1000000000};
+    uint64_t bits; memcpy(&bits, &value, 8);
+    const int biased = (int)((bits >> 52) & 0x7FF);
+    const uint64_t frac = bits & ((1ull << 52) - 1);
+    uint64_t f; int e;
+    if (biased) { f = frac | (1ull << 52); e = biased - 1075; } else { f = frac; e = -1074; }
+    DiyFp pl = normalize((f << 1) + 1, e - 1);
+    uint64_t mf; int me;
+    if (f == (1ull << 52)) { mf = (f << 2) - 1; me = e - 2; } else { mf = (f << 1) - 1; me = e - 1; }
+    DiyFp mi = {mf << (me - pl.e), pl.e};
+    const double dk = (-61 - pl.e) * 0.30102999566398114 + 347;
+    int k = (int)dk;
+    if (k != dk) ++k;
+    const unsigned index = (unsigned)((k >> 3) + 1);
+    *K = -(-348 + (int)(index << 3));
+    const DiyFp c = kPowers[index];
+    const DiyFp W = mul(normalize(f, e), c);
+    DiyFp Wp = mul(pl, c), Wm = mul(mi, c);
+    Wm.f++; Wp.f--;
+    uint64_t delta = Wp.f - Wm.f;
+    const int oneE = Wp.e;
+    const uint64_t oneF = 1ull << -oneE;
+    const uint64_t wpw = Wp.f - W.f;
+    uint32_t p1 = (uint32_t)(Wp.f >> -oneE);
+    uint64_t p2 = Wp.f & (oneF - 1);
+    int kappa = countDigits32(p1);
+    int len = 0;
+    while (kappa > 0) {
+        const uint32_t div = kPow10[kappa - 1];
+        const uint32_t d = p1 / div;
+        p1 %= div;
+        if (d || len) buf[len++] = (char)('0' + d);
+        --kappa;
+        const uint64_t tmp = ((uint64_t)p1 << -oneE) + p2;
+        if (tmp <= delta) {
+            *K += kappa;
+            grisuRound(buf, len, delta, tmp, (uint64_t)kPow10[kappa] << -oneE, wpw);
+            *length = len;
+            return;
+        }
+    }
+    for (;;) {
+        p2 *= 10; delta *= 10;
+        const char d = (char)(p2 >> -oneE);
+        if (d || len) buf[len++] = (char)('0' + d);
+        p2 &= oneF - 1;
+        --kappa;
+        if (p2 < delta) {
+            *K += kappa;
+            grisuRound(buf, len, delta, p2, oneF, wpw * (-kappa < 10 ? kPow10[-kappa] : 0));
+            *length = len;
+            return;
+        }
+    }
+}
+static void dtoa(double value, string &out)
+{
+    if (std::isnan(value)) { out += "NaN"; return; }
+    if (std::isinf(value)) { out += "inf"; return; }
+    if (value == 0) { out += "0.0"; return; }
+    if (value < 0) { out += '-'; value = -value; }
+    char d[32]; int n, k;
+    grisu2(value, d, &n, &k);
+    const int kk = n + k;
+    auto expo = [&](int x) { if (x < 0) { out += '-'; x = -x; } out += std::to_string(x); };
+    if (n <= kk && kk <= 21) { out.append(d, n); out.append((size_t)(kk - n), '0'); out += ".0"; }
+    else if (0 < kk && kk <= 21) { out.append(d, kk); out += '.'; out.append(d + kk, n - kk); }
+    else if (-6 < kk && kk <= 0) { out += "0."; out.append((size_t)(-kk), '0'); out.append(d, n); }
+    else if (n == 1) { out += d[0]; out += 'e'; expo(kk - 1); }
+    else { out += d[0]; out += '.'; out.append(d + 1, n - 1); out += 'e'; expo(kk - 1); }
+}
+static void itoa(uint64_t v, string &out) { out += std::to_string(v); }
+} // namespace numtext
+
+// ---------------------------------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------------------------------
+struct Content { vector<string> names; vector<uint32_t> taxids; };
+
+static vector<string> splitTabs(const string &s)
+{
+    vector<string> out; size_t a = 0;
+    for (;;) { const size_t b = s.find('\t', a); out.push_back(s.substr(a, b == string::npos ? b : b - a)); if (b == string::npos) break; a = b + 1; }
+    return out;
+}
+
+static Content loadContent(const string &path) // Compare.hpp:111-151
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("The content file or the frequency file cannot be found!");
+    Content c; c.names.push_back("non_unique"); c.taxids.push_back(0);
+    string line; bool asStr = false;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        const auto cols = splitTabs(line);
+        if (cols.size() >= 5) asStr = true;
+        if (cols.size() < 4) throw std::runtime_error("Content file contains less than 4 columns, it may be damaged... The faulty line was: " + line + "\n");
+        string nm = cols[0]; nm.erase(std::remove(nm.begin(), nm.end(), ','), nm.end());
+        c.names.push_back(nm);
+        c.taxids.push_back((uint32_t)std::stoul(asStr ? cols[4] : cols[1]));
+    }
+    return c;
+}
+
+static vector<uint64_t> loadFreqAtK(const string &prefix, size_t nTaxa, int kHigh) // Compare.hpp:166-179, column of k = kHigh
+{
+    std::ifstream f(prefix + "_f.txt");
+    if (!f) throw std::runtime_error("The content file or the frequency file cannot be found!");
+    vector<uint64_t> out(nTaxa, 0);
+    string line; size_t row = 0;
+    while (std::getline(f, line)) {
+        if (line.empty()) continue;
+        const auto cols = splitTabs(line);
+        const size_t numK = cols.size() - 1;
+        if (row < nTaxa && 1 + numK - (size_t)kHigh < cols.size()) out[row] = std::stoull(cols[1 + numK - kHigh]);
+        ++row;
+    }
+    return out;
+}
+
+struct ReadSet { vector<uint8_t> bases; vector<int64_t> off{0}; vector<string> names; vector<uint32_t> lengths; };
+
+static ReadSet readInput(const string &path) // what Read.hpp:699-760 hands on, for reads that fit one chunk
+{
+    gzFile g = gzopen(path.c_str(), "rb");
+    if (!g) throw std::runtime_error("Input file not found");
+    string data; char buf[1 << 16]; int n;
+    while ((n = gzread(g, buf, sizeof(buf))) > 0) data.append(buf, (size_t)n);
+    gzclose(g);
+    ReadSet rs;
+    if (data.empty()) return rs;
+    if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
+    const bool fasta = data[0] == '>';
+    vector<std::pair<size_t, size_t>> lines; // [begin, end)
+    for (size_t a = 0; a < data.size();) { size_t b = data.find('\n', a); if (b == string::npos) b = data.size(); size_t e = b; if (e > a && data[e - 1] == '\r') --e; lines.emplace_back(a, e); a = b + 1; }
+    size_t i = 0;
+    auto isEmpty = [&](size_t k) { return lines[k].first == lines[k].second; };
+    while (i < lines.size()) {
+        if (isEmpty(i)) { ++i; continue; }
+        rs.names.push_back(data.substr(lines[i].first + 1, lines[i].second - lines[i].first - 1) + " "); // Read.hpp:711-714
+        ++i;
+        uint32_t nLines = 0; const size_t b0 = rs.bases.size();
+        while (i < lines.size()) {
+            if (!isEmpty(i) && data[lines[i].first] == (fasta ? '>' : '+')) break;
+            if (!isEmpty(i)) rs.bases.insert(rs.bases.end(), data.begin() + lines[i].first, data.begin() + lines[i].second);
+            if (!isEmpty(i) || !fasta) ++nLines;
+            ++i;
+        }
+        const size_t len = rs.bases.size() - b0;
+        for (size_t k = b0; k < rs.bases.size(); ++k)
+            if (rs.bases[k] == ' ' || rs.bases[k] == '\t') throw std::runtime_error("Spaces or tabs inside read, please check your input."); // Read.hpp:659
+        if (!fasta) {
+            ++i; size_t q = 0;
+            while (i < lines.size() && q < len) { q += lines[i].second - lines[i].first; ++i; }
+            if (q > len) throw std::runtime_error("Quality string and DNA string do not have the same length!");
+        }
+        rs.off.push_back((int64_t)rs.bases.size());
+        rs.lengths.push_back((uint32_t)(len + nLines)); // one extra per sequence line (Read.hpp:723-731)
+    }
+    return rs;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ranking + text (Compare.hpp:1452-1890) and profile (Compare.hpp:3466-3665)
+// ---------------------------------------------------------------------------------------------------
+struct Params {
+    string content, index, input, rtt, profile;
+    int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0;
+    float threshold = 0.f;
+    enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
+    bool verbose = false, coverage = false;
+};
+
+static float weightOf(int k) { return (float)(k * k) / 625.f; }
+
+static float bestScore(uint64_t len, const Params &p) // Compare.hpp:1452-1481
+{
+    float best = 0.f;
+    for (int i = p.kLow; i <= p.kHigh; ++i) {
+        if (p.frames == 6) best += (float)(2 * (len - (uint64_t)(i * 3) + 1)) * weightOf(i);
+        else best += (float)(len - (uint64_t)(i * 3) + 1) * weightOf(i);
+    }
+    return best;
+}
+
+struct Writer {
+    const Params &p; const Content &c; const vector<uint64_t> &freq;
+    vector<std::tuple<size_t, float, double>> res;
+    Writer(const Params &pp, const Content &cc, const vector<uint64_t> &ff) : p(pp), c(cc), freq(ff), res(cc.names.size()) {}
+
+    void obj(string &o, const std::tuple<size_t, float, double> &h, float best, bool pretty) const
+    {
+        using numtext::dtoa; using numtext::itoa;
+        if (pretty) {
+            o += "\t\t\"tax ID\": \""; itoa(c.taxids[std::get<0>(h)], o); o += "\",\n\t\t\"Name\": \""; o += c.names[std::get<0>(h)];
+            o += "\",\n\t\t\"k-mer Score\": "; dtoa(std::get<1>(h), o); o += ",\n\t\t\"Relative Score\": "; dtoa(std::get<2>(h), o);
+            o += ",\n\t\t\"Error\": "; dtoa((best - std::get<1>(h)) / best, o); o += "\n\t}";
+        } else {
+            o += " \"tax ID\": \""; itoa(c.taxids[std::get<0>(h)], o); o += "\", \"Name\": \""; o += c.names[std::get<0>(h)];
+            o += "\", \"k-mer Score\": "; dtoa(std::get<1>(h), o); o += ", \"Relative Score\": "; dtoa(std::get<2>(h), o);
+            o += ", \"Error\": "; dtoa((best - std::get<1>(h)) / best, o); o += "}";
+        }
+    }
+
+    void read(string &o, uint64_t number, const string &name, uint32_t len, const uint32_t *tax, const float *score, uint64_t n)
+    {
+        using numtext::dtoa; using numtext::itoa;
+        const float best = bestScore(len, p);
+        int64_t cnt = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (!(score[i] > 0.f)) continue;
+            const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - 12 * 3 + 1)))); // Compare.hpp:1510
+            if (rel >= p.threshold) { res[cnt] = std::make_tuple((size_t)tax[i], score[i], rel); ++cnt; }
+        }
+        if (cnt == 0) {
+            switch (p.fmt) {
+            case Params::Tsv: itoa(number, o); o += "\t"; o += name; o += "\t-\t-\t-\t-\n"; break;
+            case Params::Json:
+                o += number == 0 ? "{\n" : ",\n{\n"; o += "\t\"Read number\": "; itoa(number, o);
+                o += ",\n\t\"Specifier from input file\": \""; o += name; o += "\",\n\t\"Length\": "; itoa(len, o);
+                o += ",\n\t\"Top hits\": [\n\t],\n\t\"Further hits\": [\n\t]\n}"; break;
+            case Params::JsonL:
+                o += "{ \"Read number\": "; itoa(number, o); o += ", \"Specifier from input file\": \""; o += name;
+                o += "\", \"Length\": "; itoa(len, o); o += ", \"Top hits\": [], \"Further hits\": [] }\n"; break;
+            case Params::Kraken: o += "U\t"; o += name; o += "\t0\t"; o += (char)len; o += "\tA:00\n"; break; // one raw byte (Compare.hpp:1568)
+            }
+            return;
+        }
+        std::sort(res.begin(), res.begin() + cnt, [](const std::tuple<size_t, float, double> &a, const std::tuple<size_t, float, double> &b) { return std::get<2>(a) > std::get<2>(b); });
+        float maxV = 0.f;
+        for (int64_t i = 0; i < cnt; ++i) maxV = std::max(maxV, std::get<1>(res[i]));
+        int64_t top = 1;
+        for (int64_t i = 1; i < cnt && i < p.beasts; ++i) { if (std::get<1>(res[i]) / maxV > 0.8f) ++top; else break; }
+        float before = 0;
+        switch (p.fmt) {
+        case Params::Tsv: {
+            string s1, s2, s3, s4; itoa(number, s1); s1 += "\t"; s1 += name + "\t";
+            for (int64_t j = 0, i = 0; i < cnt && j < p.beasts; ++i) {
+                const auto &h = res[i];
+                itoa(c.taxids[std::get<0>(h)], s1); s1 += ";"; s2 += c.names[std::get<0>(h)]; s2 += ";";
+                dtoa(std::get<2>(h), s3); s3 += ","; dtoa(std::get<1>(h), s3); s3 += ";";
+                dtoa((best - std::get<1>(h)) / best, s4); s4 += ";";
+                if (before != std::get<1>(h)) { before = std::get<1>(h); ++j; }
+            }
+            for (string *s : {&s1, &s2, &s3, &s4}) if (!s->empty() && s->back() == ';') s->pop_back();
+            if (!s2.empty()) { o += s1; o += "\t"; o += s2; o += "\t"; o += s3; o += "\t"; o += s4; o += "\n"; }
+        } break;
+        case Params::Json: {
+            o += number == 0 ? "{\n" : ",\n{\n"; o += "\t\"Read number\": "; itoa(number, o);
+            o += ",\n\t\"Specifier from input file\": \""; o += name; o += "\",\n\t\"Length\": "; itoa(len, o); o += ",\n\t\"Top hits\": [\n";
+            for (int64_t i = 0; i < top; ++i) { o += i == 0 ? "\t{\n" : ",\n\t{\n"; obj(o, res[i], best, true); }
+            o += "\n\t],\n\t\"Further hits\": [\n";
+            for (int64_t j = top, i = top; i < cnt && j < p.beasts; ++i) {
+                o += j == top ? "\t{\n" : ",\n\t{\n"; obj(o, res[i], best, true);
+                if (before != std::get<1>(res[i])) { before = std::get<1>(res[i]); ++j; }
+            }
+            o += "\n\t]\n}";
+        } break;
+        case Params::JsonL: {
+            o += "{ \"Read number\": "; itoa(number, o); o += ", \"Specifier from input file\": \""; o += name; o += "\", \"Length\": "; itoa(len, o); o += ", \"Top hits\": [";
+            for (int64_t i = 0; i < top; ++i) { o += i == 0 ? "{" : ",{"; obj(o, res[i], best, false); }
+            o += "], \"Further hits\": [";
+            for (int64_t j = top, i = top; i < cnt && j < p.beasts; ++i) {
+                o += j == top ? "{" : ", {"; obj(o, res[i], best, false);
+                if (before != std::get<1>(res[i])) { before = std::get<1>(res[i]); ++j; }
+            }
+            o += "] }\n";
+        } break;
+        case Params::Kraken: {
+            o += "C\t"; o += name; o += "\t"; itoa(c.taxids[std::get<0>(res[0])], o); o += "\t"; itoa(len, o); o += "\t";
+            for (int64_t i = 0; i < top; ++i) { itoa(c.taxids[std::get<0>(res[i])], o); o += ":"; dtoa(std::get<1>(res[i]), o); o += " "; }
+            for (int64_t j = top, i = top; i < cnt && j < p.beasts; ++i) {
+                itoa(c.taxids[std::get<0>(res[i])], o); o += ":"; dtoa(std::get<1>(res[i]), o); o += " ";
+                if (before != std::get<1>(res[i])) { before = std::get<1>(res[i]); ++j; }
+            }
+            o += "\n";
+        } break;
+        }
+    }
+};
+
+static void writeProfile(const string &path, const Params &p, const Content &c, const vector<double> &all, const vector<uint64_t> &uniq,
+                         uint64_t nKmers, uint64_t nReads)
+{
+    const int nK = p.kHigh - p.kLow + 1;
+    const size_t nT = c.names.size();
+    vector<uint64_t> sumU(nK, 0); vector<double> sumA(nK, 0.0);
+    struct Row { string name; vector<std::pair<double, uint64_t>> v; uint32_t tid; };
+    vector<Row> rows(nT, Row{"", vector<std::pair<double, uint64_t>>(nK, {0.0, 0}), 0});
+    for (size_t t = 1; t < nT; ++t) {
+        Row r{c.names[t], vector<std::pair<double, uint64_t>>(nK), c.taxids[t]};
+        std::replace(r.name.begin(), r.name.end(), ',', ' ');
+        for (int l = 0; l < nK; ++l) { r.v[l] = {all[l * nT + t], uniq[l * nT + t]}; sumU[l] += uniq[l * nT + t]; sumA[l] += all[l * nT + t]; }
+        rows[t] = r;
+    }
+    std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) {
+        for (size_t i = 0; i < a.v.size(); ++i) { if (a.v[i].second == b.v[i].second) continue; return a.v[i].second > b.v[i].second; }
+        return false; });
+    const uint64_t fm = p.frames == 6 ? 6 : 3;
+    vector<uint64_t> garbage(nK, 0);
+    for (int i = p.kHigh - p.kLow, j = 0; i > 0; --i, ++j) garbage[j] = nReads * fm * i;
+    std::ofstream f(path);
+    if (!f) throw std::runtime_error("Profile file couldn't be opened for writing!");
+    std::ostringstream body;
+    f << "#taxID,Name";
+    for (const char *title : {"Unique counts k=", "Unique rel. freq. k=", "Non-unique counts k=", "Non-unique rel. freq. k=", "Overall rel. freq. k=", "Overall unique rel. freq. k="})
+        for (int l = 0; l < nK; ++l) f << "," << title << p.kHigh - l;
+    f << "\n";
+    vector<double> ident(nK, 0), uident(nK, 0);
+    for (const Row &r : rows) {
+        if (!(r.v[nK - 1].first > 0)) continue;
+        body << r.tid << "," << r.name;
+        for (int l = 0; l < nK; ++l) body << "," << r.v[l].second;
+        for (int l = 0; l < nK; ++l) { if (r.v[l].second == 0) body << "," << 0.0; else body << "," << static_cast<double>(r.v[l].second) / sumU[l]; }
+        for (int l = 0; l < nK; ++l) body << "," << r.v[l].first;
+        for (int l = 0; l < nK; ++l) { if (r.v[l].first == 0) body << "," << 0.0; else body << "," << r.v[l].first / sumA[l]; }
+        for (int l = 0; l < nK; ++l) { ident[l] += r.v[l].first; body << "," << r.v[l].first / (nKmers - garbage[l]); }
+        for (int l = 0; l < nK; ++l) { uident[l] += r.v[l].second; body << "," << static_cast<double>(r.v[l].second) / (nKmers - garbage[l]); }
+        body << "\n";
+    }
+    f << "0,not identified";
+    for (int l = 0; l < nK * 4; ++l) f << "," << 0.0;
+    for (int l = 0; l < nK; ++l) f << "," << (double(nKmers) - double(garbage[l]) - ident[l]) / (double(nKmers) - double(garbage[l]));
+    for (int l = 0; l < nK; ++l) f << "," << (double(nKmers) - double(garbage[l]) - uident[l]) / (double(nKmers) - double(garbage[l]));
+    f << "\n" << body.str();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// main
+// ---------------------------------------------------------------------------------------------------
+static int run(int argc, char **argv)
+{
+    vector<string> a(argv, argv + argc);
+    std::cout << "OUT: kasa_identify (MI355X path of kASA identify)\nOUT: ";
+    for (auto &s : a) std::cout << s << " ";
+    std::cout << std::endl;
+    if (argc < 2 || a[1] != "identify") throw std::runtime_error("only the mode `identify` is available on this path");
+    Params p;
+    for (int i = 2; i < argc; ++i) {
+        const string &s = a[i];
+        auto next = [&]() -> string { if (i + 1 >= argc) throw std::runtime_error("missing value after " + s); return a[++i]; };
+        if (s == "-c" || s == "--content") p.content = next();
+        else if (s == "-d" || s == "--database") p.index = next();
+        else if (s == "-i" || s == "--input") { p.input = next(); if (!std::ifstream(p.input)) throw std::runtime_error("Input file not found"); }
+        else if (s == "-q" || s == "--rtt") p.rtt = next();
+        else if (s == "-p" || s == "--profile") p.profile = next();
+        else if (s == "-k") { p.kHigh = std::stoi(next()); p.kLow = std::stoi(next()); if (p.kHigh > 25) p.kHigh = 25; if (p.kLow < 1) p.kLow = 1; if (p.kLow > p.kHigh) std::swap(p.kLow, p.kHigh); }
+        else if (s == "--kH") { p.kHigh = std::min(25, std::stoi(next())); }
+        else if (s == "--kL") { p.kLow = std::max(1, std::stoi(next())); }
+        else if (s == "-b" || s == "--beasts") p.beasts = std::stoi(next());
+        else if (s == "--json") p.fmt = Params::Json;
+        else if (s == "--jsonl") p.fmt = Params::JsonL;
+        else if (s == "--tsv") p.fmt = Params::Tsv;
+        else if (s == "--kraken") p.fmt = Params::Kraken;
+        else if (s == "--threshold") p.threshold = std::stof(next());
+        else if (s == "--six") p.frames = 6;
+        else if (s == "--three") p.frames = 3;
+        else if (s == "--coverage") p.coverage = true;
+        else if (s == "-v" || s == "--verbose") p.verbose = true;
+        else if (s == "--device") p.device = std::stoi(next());
+        else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
+        else if (s == "-m" || s == "--memory" || s == "-n" || s == "--threads" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
+        else if (s == "-e" || s == "--unique" || s == "--one" || s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-1" || s == "-2" || s == "-z" || s == "-a" || s == "--alphabet")
+            throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
+        else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
+    }
+    std::ifstream info(p.index + "_info.txt");
+    if (!info) throw std::runtime_error("Info file for this index can not be found!");
+    uint64_t nRec = 0, vecType = 0; info >> nRec; info >> vecType;
+    if (vecType == 128 || vecType == 3) throw std::runtime_error("128-bit and halved indices are not supported by the MI355X identify path yet");
+    if (p.kHigh > 12) { std::cerr << "WARNING: This index can not be used with a k higher than 12! Setting to this maximum..." << std::endl; p.kHigh = 12; }
+    if (p.kLow > 12) p.kLow = 12;
+    if (p.content.empty()) p.content = p.index + "_content.txt";
+    const Content content = loadContent(p.content);
+    const vector<uint64_t> freq = loadFreqAtK(p.index, content.names.size(), p.kHigh);
+
+    // index + trie files as they are on disk
+    const int fd = open(p.index.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("The index file cannot be found!");
+    void *rec = mmap(nullptr, nRec * 12, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (rec == MAP_FAILED) throw std::runtime_error("The index file cannot be mapped!");
+    vector<uint32_t> tp; vector<uint64_t> tc;
+    {
+        std::ifstream ts(p.index + "_trie.txt"); std::ifstream tf(p.index + "_trie", std::ios::binary);
+        if (!ts || !tf) throw std::runtime_error("The trie file cannot be found!");
+        uint64_t m = 0; ts >> m; tp.resize(m); tc.resize(m);
+        vector<char> raw(m * 12); tf.read(raw.data(), (std::streamsize)raw.size());
+        for (uint64_t i = 0; i < m; ++i) { memcpy(&tc[i], &raw[i * 12], 8); memcpy(&tp[i], &raw[i * 12 + 8], 4); }
+    }
+    kasa_index *ix = nullptr;
+    if (kasa_index_create(p.device, rec, nRec, 12, tp.data(), tc.data(), tp.size(), content.taxids.data(), (uint32_t)content.taxids.size(), &ix)) throwLast();
+    munmap(rec, nRec * 12); close(fd);
+    kasa_ctx *ctx = nullptr;
+    if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
+
+    ReadSet rs = readInput(p.input);
+    const uint64_t nReads = rs.names.size();
+    std::ofstream out;
+    if (!p.rtt.empty()) {
+        out.open(p.rtt, std::ios::binary);
+        if (!out) throw std::runtime_error("Readwise output file could not be created!");
+        if (p.fmt == Params::Tsv) out << "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n";
+        else if (p.fmt == Params::Json) out << "[\n";
+    }
+    if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
+
+    // batches: the device takes up to 2^32 k-mers at once; the reference cuts batches by its -m budget instead
+    // (INTEGRATION.md section 4 on what that means for the last float digit)
+    const uint64_t maxKmersPerBatch = 3000000000ull;
+    uint64_t totalKmers = 0, done = 0;
+    Writer w(p, content, freq);
+    string text;
+    while (done < nReads || (nReads == 0 && done == 0)) {
+        uint64_t end = done, est = 0;
+        while (end < nReads) {
+            const uint64_t len = (uint64_t)(rs.off[end + 1] - rs.off[end]);
+            const uint64_t k = (len + 64) * (p.frames == 6 ? 2 : 1);
+            if (end > done && est + k > maxKmersPerBatch) break;
+            est += k; ++end;
+        }
+        uint64_t nk = 0;
+        if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
+        if (kasa_batch_encode(ctx, &nk)) throwLast();
+        if (kasa_batch_sort_and_range(ctx, 0)) throwLast();
+        if (kasa_batch_lookup_score(ctx, !p.rtt.empty(), p.coverage)) throwLast();
+        totalKmers += nk;
+        if (!p.rtt.empty()) {
+            uint64_t nnz = 0;
+            if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
+            vector<uint64_t> ro(end - done + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
+            if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
+            for (uint64_t r = done; r < end; ++r) {
+                const uint64_t lo = ro[r - done], hi = ro[r - done + 1];
+                w.read(text, r, rs.names[r], rs.lengths[r], tx.data() + lo, sc.data() + lo, hi - lo);
+                if (text.size() > (1u << 24)) { out << text; text.clear(); }
+            }
+        }
+        done = end;
+        if (nReads == 0) break;
+    }
+    if (!p.rtt.empty()) { out << text; if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
+    const int nK = p.kHigh - p.kLow + 1;
+    vector<double> all((size_t)nK * content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
+    if (kasa_profile_fetch(ctx, all.data(), uniq.data(), tot.data())) throwLast();
+    if (!p.profile.empty()) writeProfile(p.profile, p, content, all, uniq, totalKmers, nReads);
+    if (p.verbose) {
+        double ident = 0; for (size_t t = 1; t < content.names.size(); ++t) ident += all[(size_t)(nK - 1) * content.names.size() + t];
+        std::cout << "OUT: Number of k-mers in input: " << totalKmers << " of which " << ident / totalKmers * 100. << " % were identified." << std::endl;
+    }
+    kasa_ctx_destroy(ctx);
+    kasa_index_destroy(ix);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    try { return run(argc, argv); }
+    catch (const std::exception &e) { std::cerr << "ERROR: " << e.what() << std::endl; return 1; } // main.cpp:1717-1720
+}

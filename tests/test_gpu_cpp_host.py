@@ -1,0 +1,43 @@
+"""The C++ host driver (kasa_amd/host/kasa_identify: kASA's `identify` CLI over the C ABI) must write the
+same bytes as the reference binary wrote for the same command lines (tests/golden/pairs)."""
+import os
+import subprocess
+
+import pytest
+
+from kasa_amd import build as hipbuild, capi
+from tests.test_oracle_golden import PAIRS, _read
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = {"json": "--json", "jsonl": "--jsonl", "tsv": "--tsv", "kraken": "--kraken"}
+
+
+@pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
+def test_cpp_host_byte_identical(case, tmp_path):
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    stem, infile, fmt, kh, kl, frames, thr, beasts = case
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile),
+           "-q", out, "-p", prof, FLAGS[fmt], "-b", str(beasts), "-k", str(kh), str(kl), "-m", "4", "-n", "1", "-t", str(tmp_path)]
+    if frames == 6:
+        cmd.append("--six")
+    if thr:
+        cmd += ["--threshold", str(thr)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == _read(os.path.join(d, "out_" + stem))
+    assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+
+
+def test_cpp_host_errors_like_the_reference(tmp_path):
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    r = subprocess.run([exe, "identify", "-d", os.path.join(d, "nope"), "-i", os.path.join(d, "reads.fastq")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == 1 and r.stderr.startswith("ERROR: ")
+    r = subprocess.run([exe, "identify", "--frobnicate"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == 1 and "unknown parameter" in r.stderr
