@@ -714,7 +714,7 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
 // finds that span once per tile (prefix table + binary search, one thread per tile edge); lookup_tile
 // then streams the span into LDS with coalesced loads and answers all 1024 queries from LDS.  Every
 // index record and every query is read from HBM once: the merge-join lower bound of SURVEY.md 8(d).
-static constexpr int LSPAN = 3072;   // index records staged per tile (24 KiB); larger spans use lookup_kernel's path
+static constexpr int LSPAN = 1536;   // index records staged per tile (12 KiB); larger spans use lookup_kernel's path
 
 __device__ __forceinline__ uint32_t lower_bound_global(const uint64_t *__restrict__ idxKmer, const uint32_t *__restrict__ table,
                                                        int tb, uint64_t q)
@@ -732,53 +732,102 @@ __device__ __forceinline__ uint32_t lower_bound_global(const uint64_t *__restric
 __global__ void tile_bounds_kernel(const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer,
                                    const uint32_t *__restrict__ table, int tb, uint32_t nTiles, uint32_t *__restrict__ bounds)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // edge 2t = first query of tile t, 2t+1 = last
+    // edge 2t: start of the level-1 bucket of the tile's first query; edge 2t+1: end of the bucket of its last query.
+    // The true lower bounds of all the tile's queries lie inside [bounds[2t], bounds[2t+1]] -- two table reads, no search.
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * nTiles) return;
     const uint32_t t = i >> 1;
     uint32_t p = t * TILE + ((i & 1) ? (TILE - 1) : 0);
     if (p >= nQ) p = nQ - 1;
-    bounds[i] = lower_bound_global(idxKmer, table, tb, qKmer[p]);
+    const uint64_t bkt = qKmer[p] >> (KEYBITS - tb);
+    bounds[i] = (i & 1) ? table[bkt] : (bkt ? table[bkt - 1] : 0u);
+    (void)idxKmer;
 }
 
+// One workgroup per tile, a thread owns ITEMS = 4 CONSECUTIVE sorted queries (32 bytes, two 16-byte loads; a
+// wavefront reads 2 KiB contiguous), so a query's predecessor is in a register, results leave as one 16-byte and
+// one 4-byte store, and the per-level "first special position" needs one ballot per level.
 __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
     const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer, uint32_t nIdx,
     const uint32_t *__restrict__ table, int tb, const uint32_t *__restrict__ bounds, int kHigh, int kLow,
     uint8_t *__restrict__ depth, uint32_t *__restrict__ rep, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
 {
-    __shared__ uint64_t sIdx[LSPAN];
+    __shared__ uint64_t sIdx[LSPAN + 2];
     __shared__ uint32_t sFirst[MAX_LEVELS];
     const int nK = kHigh - kLow + 1;
-    if (threadIdx.x < MAX_LEVELS) sFirst[threadIdx.x] = NOPOS;
-    const uint32_t lbFirst = bounds[2 * blockIdx.x], lbLast = bounds[2 * blockIdx.x + 1];
-    const uint32_t ilo = lbFirst ? lbFirst - 1 : 0u;                     // predecessor of the first query
-    const uint32_t ihi = (lbLast < nIdx) ? lbLast + 1 : nIdx;            // successor of the last query
+    const int tid = threadIdx.x;
+    if (tid < MAX_LEVELS) sFirst[tid] = NOPOS;
+    const uint32_t base = blockIdx.x * TILE;
+    const uint32_t p0 = base + ITEMS * tid;
+    const bool fullTile = base + TILE <= nQ;
+    uint64_t qv[ITEMS];
+    if (fullTile) {
+        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0);
+        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0 + 2);
+        qv[0] = v0.x; qv[1] = v0.y; qv[2] = v1.x; qv[3] = v1.y;
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) qv[it] = (p0 + it < nQ) ? qKmer[p0 + it] : 0ull;
+    }
+    const uint64_t qBefore = (p0 > 0 && p0 < nQ) ? qKmer[p0 - 1] : 0ull;
+    const uint2 bd = *reinterpret_cast<const uint2 *>(bounds + 2 * (size_t)blockIdx.x);
+    const uint32_t ilo = bd.x ? bd.x - 1 : 0u;                         // predecessor of the first query
+    const uint32_t ihi = (bd.y < nIdx) ? bd.y + 1 : nIdx;              // successor of the last query
     const uint32_t span = ihi - ilo;
     const bool staged = span <= (uint32_t)LSPAN;
-    if (staged)
-        for (uint32_t i = threadIdx.x; i < span; i += TILE_THREADS) sIdx[i] = idxKmer[ilo + i];
+    if (staged) {
+        const uint32_t a0 = ilo & ~1u;                                 // 16-byte aligned start (one extra record at most)
+        const uint32_t shift = ilo - a0;
+        for (uint32_t i = 2 * tid; i < span + shift; i += 2 * TILE_THREADS) {
+            if (a0 + i + 1 < nIdx) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(idxKmer + a0 + i);
+                if (i >= shift) sIdx[i - shift] = v.x;
+                if (i + 1 >= shift && i + 1 - shift < span) sIdx[i + 1 - shift] = v.y;
+            } else if (a0 + i < nIdx && i >= shift) sIdx[i - shift] = idxKmer[a0 + i];
+        }
+    }
     __syncthreads();
-    const uint32_t base = blockIdx.x * TILE;
+    uint32_t pos[ITEMS];
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint32_t p = base + it * TILE_THREADS + threadIdx.x;
+    for (int it = 0; it < ITEMS; ++it) pos[it] = 0;
+    if (staged) {
+        // branch-free lower bound for the thread's first query; its next three queries are consecutive in sorted
+        // order, so their lower bounds lie a step or two further on: gallop from the previous answer
+        uint32_t step = 1;
+        while ((step << 1) <= span) step <<= 1;
+        uint32_t a = 0;
+        for (; step > 0; step >>= 1) {
+            const uint32_t probe = a + step;
+            if (probe <= span && sIdx[probe - 1] < qv[0]) a = probe;
+        }
+        pos[0] = a;
+#pragma unroll
+        for (int it = 1; it < ITEMS; ++it) {
+            while (a < span && sIdx[a] < qv[it]) ++a;
+            pos[it] = a;
+        }
+    }
+    uint32_t outRep[ITEMS];
+    uint32_t outD[ITEMS];
+    uint32_t firstAt[MAX_LEVELS];                                      // per level: this thread's first special position
+#pragma unroll
+    for (int lv = 0; lv < MAX_LEVELS; ++lv) firstAt[lv] = NOPOS;
+#pragma unroll
+    for (int it = ITEMS - 1; it >= 0; --it) {                          // descending, so the smallest position wins
+        const uint32_t p = p0 + it;
+        outRep[it] = 0; outD[it] = 0;
         if (p >= nQ) continue;
-        const uint64_t q = qKmer[p];
+        const uint64_t q = qv[it];
         uint32_t lo;
         uint64_t eLo = 0, ePrev = 0;
         bool hasLo, hasPrev;
         if (staged) {
-            uint32_t a = 0, b = span;                                    // first staged entry >= q
-            while (a < b) {
-                const uint32_t mid = a + ((b - a) >> 1);
-                if (sIdx[mid] < q) a = mid + 1; else b = mid;
-            }
+            const uint32_t a = pos[it];
             lo = ilo + a;
             hasLo = a < span; hasPrev = a > 0;
             if (hasLo) eLo = sIdx[a];
             if (hasPrev) ePrev = sIdx[a - 1];
-            // by construction the true lower bound lies in [lbFirst, lbLast] subset of the staged span;
-            // a == 0 can only happen for lo == 0 (no predecessor exists) or when ilo == lbFirst - 1 < lo
-            if (!hasPrev && lo > 0) { ePrev = idxKmer[lo - 1]; hasPrev = true; }
+            if (!hasPrev && lo > 0) { ePrev = idxKmer[lo - 1]; hasPrev = true; }       // only at the very ends of the index
             if (!hasLo && lo < nIdx) { eLo = idxKmer[lo]; hasLo = true; }
         } else {
             lo = lower_bound_global(idxKmer, table, tb, q);
@@ -791,26 +840,41 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
         int L = la >= lb ? la : lb;
         const uint32_t r = la >= lb ? lo : lo - 1;
         int d = 0;
-        if (L >= RANGE_LETTERS) {
+        if (L >= RANGE_LETTERS) {                                       // the 6-letter prefix exists (Trie.hpp:494)
             if (L > kHigh) L = kHigh;
             d = L;
-            for (int k = kLow; k <= L; ++k)
+            for (int k = kLow; k <= L; ++k)                             // '^' ends the query (Compare.hpp:836,897)
                 if (((q >> (5 * (KLETTERS - k))) & 31) == 30) { d = k - 1; break; }
             if (d < kLow) d = 0;
         }
-        depth[p] = (uint8_t)d;
-        rep[p] = r;
-        const int ql = (p == 0) ? 0 : lcp_letters(qKmer[p - 1], q);
-        for (int lv = 0; lv < nK; ++lv) {
+        outD[it] = (uint32_t)d;
+        outRep[it] = r;
+        const uint64_t prevQ = it ? qv[it - 1] : qBefore;
+        const int ql = (p == 0) ? 0 : lcp_letters(prevQ, q);
+#pragma unroll
+        for (int lv = 0; lv < MAX_LEVELS; ++lv) {
             const int k = kHigh - lv;
-            const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
-            // p grows with the lane: the lowest special lane holds this wavefront's minimum
-            const unsigned long long m = __ballot(special);
-            if (special && (m & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicMin(&sFirst[lv], p);
+            if (lv < nK && ((ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k))) firstAt[lv] = p;
         }
     }
+    // positions grow with the lane: per level the lowest lane with a special position holds the wavefront's minimum
+#pragma unroll
+    for (int lv = 0; lv < MAX_LEVELS; ++lv) {
+        if (lv >= nK) break;
+        const bool has = firstAt[lv] != NOPOS;
+        const unsigned long long m = __ballot(has);
+        if (has && (m & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicMin(&sFirst[lv], firstAt[lv]);
+    }
+    if (fullTile) {
+        *reinterpret_cast<uint4 *>(rep + p0) = make_uint4(outRep[0], outRep[1], outRep[2], outRep[3]);
+        *reinterpret_cast<uchar4 *>(depth + p0) = make_uchar4((uint8_t)outD[0], (uint8_t)outD[1], (uint8_t)outD[2], (uint8_t)outD[3]);
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it)
+            if (p0 + it < nQ) { rep[p0 + it] = outRep[it]; depth[p0 + it] = (uint8_t)outD[it]; }
+    }
     __syncthreads();
-    if (threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
+    if (tid < nK) tileFirst[(size_t)tid * nTiles + blockIdx.x] = sFirst[tid];
 }
 
 // tileNext[lv][t] = first special position in any tile after t (or nQ)
@@ -873,14 +937,15 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_LOOKUP], &a, &b))) return rc;
     if (nQ > 0) {
         hipEvent_t ka, kb;
-        if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
         if (c->lookupMode == 1) {
+            if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
             lookup_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
                 c->tileFirst.as<uint32_t>(), nTiles);
         } else {
             tile_bounds_kernel<<<blocks_for(2ull * nTiles, 256), 256, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(),
                 c->ix->table.as<uint32_t>(), c->ix->tb, nTiles, c->tileBounds.as<uint32_t>());
+            if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;   // the roofline kernel alone
             lookup_tile_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->tileBounds.as<uint32_t>(), c->kHigh, c->kLow, c->depth.as<uint8_t>(),
                 c->rep.as<uint32_t>(), c->tileFirst.as<uint32_t>(), nTiles);
