@@ -1428,7 +1428,7 @@ __device__ __forceinline__ float event_score(int k, uint32_t n)
 // The kernel performs no atomics on the profile tables: everything it finds leaves as records, so it can
 // be rerun.  A read it cannot hold is handed to score_kernel untouched.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void score_fast_kernel(ScoreArgs A)
 {
     __shared__ unsigned long long cnt64[FTA][FNK][64];              // 4 x 16-bit hit counters (|T| = 1..4) per (taxon, level)
     const int lane = threadIdx.x;
@@ -1501,32 +1501,18 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                 }
             };
 
-            // the gather of a query's record (random, 48 B) is issued one query ahead of its use
             uint32_t pcur = cnt ? A.plist[o0] : 0u;
-            uint32_t pnext = (cnt > 1) ? A.plist[o0 + 1] : 0xFFFFFFFFu;
-            uint2 cur[FNK], nxt[FNK];
-#pragma unroll
-            for (int i = 0; i < FNK; ++i) {
-                const int lv = nK - 1 - i;
-                cur[i] = (cnt && lv >= 0) ? A.rec[(size_t)pcur * nK + lv] : make_uint2(0xFFFFFFFFu, 0u);
-                nxt[i] = make_uint2(0xFFFFFFFFu, 0u);
-            }
             for (uint32_t j = 0; j < cnt && !fb; ++j) {
-                const uint32_t pnn = (j + 2 < cnt) ? A.plist[o0 + j + 2] : 0xFFFFFFFFu;
-                if (j + 1 < cnt) {
-#pragma unroll
-                    for (int i = 0; i < FNK; ++i) {
-                        const int lv = nK - 1 - i;
-                        if (lv >= 0) nxt[i] = A.rec[(size_t)pnext * nK + lv];
-                    }
-                }
+                const uint32_t pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
+                const uint2 *rp = A.rec + (size_t)pcur * nK;
                 // the (up to) 6 events of this query, k ascending; absent levels sink to the end
                 uint32_t eF[FNK], eR[FNK], eK[FNK];
                 bool early = true;
 #pragma unroll
                 for (int i = 0; i < FNK; ++i) {
                     const int lv = nK - 1 - i;
-                    uint2 v = cur[i];
+                    uint2 v = make_uint2(0xFFFFFFFFu, 0u);
+                    if (lv >= 0) v = rp[lv];
                     if (v.y == 0u) v.x = 0xFFFFFFFFu;
                     eF[i] = v.x; eR[i] = v.y; eK[i] = (uint32_t)(A.kHigh - lv);
                     if (v.y != 0u && v.x > pnext) early = false;
@@ -1576,9 +1562,7 @@ __global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
                         np -= nf;
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < FNK; ++i) cur[i] = nxt[i];
-                pcur = pnext; pnext = pnn;
+                pcur = pnext;
             }
         }
         // ---- the read's staging row: final scores of the register taxa, their counters as profile records, the log
@@ -1936,7 +1920,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         uint32_t nSlow = nReads;
         uint32_t h[3] = {0, 0, 0};
         if (fast) {
-            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 20u);
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 32u);
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
