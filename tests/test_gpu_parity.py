@@ -218,3 +218,77 @@ def test_profile_limbs_roundtrip_and_sum():
     assert np.array_equal(cu2, cu * np.uint64(2))
     np.testing.assert_allclose(ca2, 2 * ca, rtol=1e-15)
     ctx.close(); dix.close()
+
+
+def _check_against_oracle(ix, batch, kh, kl, frames, flags=0):
+    p = oracle.params(kh, kl, frames)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, kh, kl, frames)
+    ctx.debug_flags(flags)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    assert ctx.n_kmers == nq
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    slow = ctx.last_slow_reads()
+    ctx.close(); dix.close()
+    return slow
+
+
+@pytest.mark.parametrize("krange", [(12, 1), (12, 4), (8, 6), (11, 3)])
+def test_wide_k_ranges(krange):
+    """More than 6 levels and levels below the 6-letter prefix of the trie (general kernels only)."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(21, 8, 6000, 300)
+    _check_against_oracle(ix, batch, krange[0], krange[1], 3)
+
+
+def test_long_reads_and_mixed_lengths():
+    """Reads of 1..6000 bases in one batch: encoder chunking, reads with zero k-mers, many k-mers per read."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(5)
+    ix, base = synthetic_world(33, 6, 8000, 10)
+    gen = base.bases  # reuse random bases as a pool
+    lens = [1, 2, 21, 22, 23, 35, 36, 37, 150, 151, 700, 1999, 6000, 0, 64, 513, 548, 1024]
+    parts, off = [], [0]
+    pool = np.concatenate([gen] * 8)
+    for L in lens:
+        a = int(rng.integers(0, pool.shape[0] - 6001))
+        parts.append(pool[a:a + L])
+        off.append(off[-1] + L)
+    batch = reads.ReadBatch(np.concatenate(parts), np.asarray(off, dtype=np.int64), None,
+                            np.asarray([l + 1 for l in lens], dtype=np.uint32))
+    for frames in (3, 6):
+        _check_against_oracle(ix, batch, 12, 7, frames)
+
+
+def test_many_taxa_per_read_and_large_content():
+    """A crowded index: 3000 taxa over 24 kb (every short prefix shared by many taxa) -> long staging rows, taxon
+    sets of all sizes, the sorting row merge for > 16384 taxa is exercised through the debug flag as well."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(9)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_taxa, L = 3000, 600
+    root = alphabet[rng.integers(0, 4, size=L)]
+    genomes = []
+    for g in range(n_taxa):
+        s = root.copy()
+        m = rng.random(L) < 0.15
+        s[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+        genomes.append(s)
+    content = formats.Content(["non_unique"] + [f"T{g}" for g in range(n_taxa)],
+                              np.concatenate(([0], 10 + np.arange(n_taxa))).astype(np.uint32))
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for g, s in enumerate(genomes):
+        km, _ = oracle.encode(s, np.array([0, L], dtype=np.int64), p)
+        kms.append(km)
+        tids.append(np.full(km.shape[0], 10 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, 64, 150, 77)
+    slow = _check_against_oracle(ix, batch, 12, 7, 3)
+    _check_against_oracle(ix, batch, 12, 7, 3, flags=4)
+    _check_against_oracle(ix, batch, 12, 7, 3, flags=1)
+    assert slow >= 0
