@@ -1435,10 +1435,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t stride = gridDim.x * 64u;
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
-    // per-block scratch, element i of a lane at [i * 64 + lane]
+    // per-block scratch; every lane owns a CONTIGUOUS log (records are appended one by one, so consecutive
+    // 8-byte stores of a lane fill whole sectors) and a contiguous pending list
     uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
-    uint2 *lg = reinterpret_cast<uint2 *>(blk) + lane;
-    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * 2 * FLOG) + lane;             // {F, ref, k | hits << 8, -}
+    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;
+    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * 2 * FLOG) + (size_t)lane * FPL;   // {F, ref, k | hits << 8, -}
     for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
@@ -1474,12 +1475,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         // slot.  If shallow matches already started its chain in the log, replay them first.
                         float v0 = 0.0f;
                         for (int q = 0; q < nl; ++q) {
-                            uint2 e2 = lg[(size_t)q * 64];
+                            uint2 e2 = lg[q];
                             if ((e2.x & 0xC0FFFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
                             const float s2 = event_score(A.kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
                             for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
                             e2.x |= RK_CONSUMED;
-                            lg[(size_t)q * 64] = e2;
+                            lg[q] = e2;
                         }
                         e = na;
                         if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     } else kind = 0u;
                     if (kind != 0xFFFFFFFFu) {
                         if (nl == FLOG || t >= (1u << 20)) { fb = true; atomicAdd(&A.why[2], 1u); break; }
-                        lg[(size_t)nl * 64] = make_uint2(t | ((uint32_t)lv << 24) | kind, (n << 16) | c);
+                        lg[nl] = make_uint2(t | ((uint32_t)lv << 24) | kind, (n << 16) | c);
                         ++nl;
                     }
                 }
@@ -1538,27 +1539,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         if (eR[i] == 0u || fb) continue;
                         int pos = np;
                         while (pos > 0) {
-                            const uint4 e4 = pend[(size_t)(pos - 1) * 64];
+                            const uint4 e4 = pend[pos - 1];
                             if (e4.x > eF[i] || (e4.x == eF[i] && (e4.z & 255u) > eK[i])) --pos; else break;
                         }
                         if (pos > 0) {
-                            uint4 e4 = pend[(size_t)(pos - 1) * 64];
-                            if (e4.x == eF[i] && (e4.z & 255u) == eK[i]) { e4.z += 256u; pend[(size_t)(pos - 1) * 64] = e4; continue; }
+                            uint4 e4 = pend[pos - 1];
+                            if (e4.x == eF[i] && (e4.z & 255u) == eK[i]) { e4.z += 256u; pend[pos - 1] = e4; continue; }
                         }
                         if (np == FPL) { fb = true; atomicAdd(&A.why[4], 1u); continue; }
-                        for (int q = np; q > pos; --q) pend[(size_t)q * 64] = pend[(size_t)(q - 1) * 64];
-                        pend[(size_t)pos * 64] = make_uint4(eF[i], eR[i], eK[i] | 256u, 0u);
+                        for (int q = np; q > pos; --q) pend[q] = pend[q - 1];
+                        pend[pos] = make_uint4(eF[i], eR[i], eK[i] | 256u, 0u);
                         ++np;
                     }
                     int nf = 0;
                     while (nf < np && !fb) {
-                        const uint4 e4 = pend[(size_t)nf * 64];
+                        const uint4 e4 = pend[nf];
                         if (e4.x > pnext) break;
                         applyEvent(e4.z & 255u, e4.y, e4.z >> 8);
                         ++nf;
                     }
                     if (nf) {
-                        for (int q = nf; q < np; ++q) pend[(size_t)(q - nf) * 64] = pend[(size_t)q * 64];
+                        for (int q = nf; q < np; ++q) pend[q - nf] = pend[q];
                         np -= nf;
                     }
                 }
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         }
                     }
                 }
-                for (int i = 0; i < nl; ++i) A.st[w + i] = lg[(size_t)i * 64];
+                for (int i = 0; i < nl; ++i) A.st[w + i] = lg[i];
             }
         }
         const unsigned long long fbMask = __ballot(active && fb);
