@@ -59,7 +59,9 @@ int kasa_device_count(int *count);
 /* ---- index residency: replaces Compare::ReadIndex::loadIndex / loadTrie / loadContentAndFrequencyFiles
  *      (source/modes/Compare.hpp:111-337).
  * records   : nRecords packed {u64 kmer, u32 taxid} entries of 12 bytes, sorted by (kmer, taxid) --
- *             the index file as it is on disk (may be an mmap of it).
+ *             the index file as it is on disk (may be an mmap of it); or, with recordBytes = 6, the
+ *             "halved" index of shrink strategy 2, {u32 low 30 bits, u16 dense taxon index}
+ *             (source/utils/packedPairs.hpp:100-105), which needs the trie arrays.
  * triePrefix/trieCount : the `_trie` file (source/modes/Trie.hpp:365-394): 30-bit prefixes ascending
  *             and their entry counts; may be NULL/0 -- the device derives its own two-level prefix
  *             table from the records and, when given, checks it against this one.

@@ -218,8 +218,30 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
 {
     if (!out) return fail(KASA_E_ARG, "kasa_index_create: out is NULL");
     *out = nullptr;
+    if (recordBytes == 6) {
+        // "halved" index of shrink strategy 2 (source/modes/Shrink.hpp:78-143, source/utils/packedPairs.hpp:100-105):
+        // {u32 low 30 bits of the k-mer, u16 dense taxon index}; the upper 30 bits are the entry's `_trie` prefix.
+        // Rebuilt here into full records, then loaded like any other index.
+        if (!records || !triePrefix || !trieCount || !nTrie || !taxIds) return fail(KASA_E_ARG, "kasa_index_create: a halved index needs its trie and content mapping");
+        std::vector<uint8_t> full;
+        try { full.resize((size_t)nRecords * 12); } catch (...) { return fail(KASA_E_NOMEM, "host allocation failed"); }
+        const uint8_t *src = static_cast<const uint8_t *>(records);
+        uint64_t i = 0;
+        for (uint64_t t = 0; t < nTrie; ++t)
+            for (uint64_t c2 = 0; c2 < trieCount[t]; ++c2, ++i) {
+                if (i >= nRecords) return fail(KASA_E_ARG, "kasa_index_create: the trie file counts more entries than the index has");
+                uint32_t low; uint16_t tix;
+                memcpy(&low, src + i * 6, 4); memcpy(&tix, src + i * 6 + 4, 2);
+                if (tix >= nTaxa) return fail(KASA_E_ARG, "kasa_index_create: halved index entry %llu names taxon index %u of %u", (unsigned long long)i, tix, nTaxa);
+                const uint64_t km = ((uint64_t)triePrefix[t] << 30) | (low & 0x3FFFFFFFu);
+                const uint32_t tid = taxIds[tix];
+                memcpy(&full[i * 12], &km, 8); memcpy(&full[i * 12 + 8], &tid, 4);
+            }
+        if (i != nRecords) return fail(KASA_E_ARG, "kasa_index_create: the trie file counts %llu entries, the index has %llu", (unsigned long long)i, (unsigned long long)nRecords);
+        return kasa_index_create(device, full.data(), nRecords, 12, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
+    }
     if (recordBytes != 12)
-        return fail(KASA_E_ARG, "kasa_index_create: only 12-byte {u64 kmer,u32 taxid} records (k<=12 index) are supported, got %d", recordBytes);
+        return fail(KASA_E_ARG, "kasa_index_create: 12-byte {u64 kmer,u32 taxid} or 6-byte halved records are supported (a 20-byte k<=25 index is not), got %d", recordBytes);
     if (!records && nRecords) return fail(KASA_E_ARG, "kasa_index_create: records is NULL");
     if (nRecords == 0) return fail(KASA_E_ARG, "The index file cannot be found or is empty!");
     if (nRecords >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_index_create: %llu records exceed the 32-bit position range of this build", (unsigned long long)nRecords);

@@ -22,6 +22,7 @@ import numpy as np
 
 REC_DTYPE = np.dtype([("kmer", "<u8"), ("tax", "<u4")], align=False)  # 12 B
 TRIE_DTYPE = np.dtype([("count", "<u8"), ("prefix", "<u4")], align=False)  # 12 B
+HALF_DTYPE = np.dtype([("low", "<u4"), ("tax", "<u2")], align=False)  # 6 B (shrink strategy 2)
 
 K64 = 12  # letters per packed k-mer in a 64-bit index
 TRIE_LETTERS = 6
@@ -81,7 +82,7 @@ def read_records(prefix: str):
     if kind == 128:
         raise NotImplementedError("128-bit (k<=25) index: not on this round's path, see DESIGN.md")
     if kind == 3:
-        raise NotImplementedError("halved (shrink strategy 2) index: see DESIGN.md")
+        return None, None  # halved records: rebuilt by load_index with the trie and the content file
     rec = np.fromfile(prefix, dtype=REC_DTYPE, count=n)
     if rec.shape[0] != n:
         raise RuntimeError("The index file is shorter than _info.txt says")
@@ -150,6 +151,16 @@ def load_index(prefix: str, content_path: str) -> Index:
     content = read_content(content_path)
     kmer, taxid = read_records(prefix)
     tp, tc = read_trie(prefix)
+    if kmer is None:
+        # shrink strategy 2 (source/modes/Shrink.hpp:78-143): {u32 low 30 bits, u16 dense taxon index} per entry,
+        # the upper 30 bits of an entry are its _trie prefix
+        n, _ = read_info(prefix)
+        half = np.fromfile(prefix, dtype=HALF_DTYPE, count=n)
+        if int(tc.sum()) != n:
+            raise RuntimeError("The trie file does not match the halved index")
+        pre = np.repeat(tp.astype(np.uint64), tc.astype(np.int64))
+        kmer = (pre << np.uint64(30)) | (half["low"].astype(np.uint64) & np.uint64(0x3FFFFFFF))
+        taxid = content.taxids[half["tax"].astype(np.int64)]
     freq = read_freq(prefix, content.n_taxa)
     return Index(kmer, taxid, dense_tax(taxid, content), tp, tc, content, freq)
 

@@ -7,7 +7,7 @@
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
 // Not supported here (reported as errors, never silently ignored): protein input, --one, -e/--unique,
-// --filter/--coherence/--visualize, paired-end, 128-bit and halved indices.
+// --filter/--coherence/--visualize, paired-end, 128-bit (k <= 25) indices.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -438,7 +438,8 @@ static int run(int argc, char **argv)
     std::ifstream info(p.index + "_info.txt");
     if (!info) throw std::runtime_error("Info file for this index can not be found!");
     uint64_t nRec = 0, vecType = 0; info >> nRec; info >> vecType;
-    if (vecType == 128 || vecType == 3) throw std::runtime_error("128-bit and halved indices are not supported by the MI355X identify path yet");
+    if (vecType == 128) throw std::runtime_error("128-bit (k <= 25) indices are not supported by the MI355X identify path yet");
+    const int recBytes = vecType == 3 ? 6 : 12;                        // 3: halved index of shrink strategy 2
     if (p.kHigh > 12) { std::cerr << "WARNING: This index can not be used with a k higher than 12! Setting to this maximum..." << std::endl; p.kHigh = 12; }
     if (p.kLow > 12) p.kLow = 12;
     if (p.content.empty()) p.content = p.index + "_content.txt";
@@ -448,7 +449,7 @@ static int run(int argc, char **argv)
     // index + trie files as they are on disk
     const int fd = open(p.index.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("The index file cannot be found!");
-    void *rec = mmap(nullptr, nRec * 12, PROT_READ, MAP_PRIVATE, fd, 0);
+    void *rec = mmap(nullptr, nRec * recBytes, PROT_READ, MAP_PRIVATE, fd, 0);
     if (rec == MAP_FAILED) throw std::runtime_error("The index file cannot be mapped!");
     vector<uint32_t> tp; vector<uint64_t> tc;
     {
@@ -459,8 +460,8 @@ static int run(int argc, char **argv)
         for (uint64_t i = 0; i < m; ++i) { memcpy(&tc[i], &raw[i * 12], 8); memcpy(&tp[i], &raw[i * 12 + 8], 4); }
     }
     kasa_index *ix = nullptr;
-    if (kasa_index_create(p.device, rec, nRec, 12, tp.data(), tc.data(), tp.size(), content.taxids.data(), (uint32_t)content.taxids.size(), &ix)) throwLast();
-    munmap(rec, nRec * 12); close(fd);
+    if (kasa_index_create(p.device, rec, nRec, recBytes, tp.data(), tc.data(), tp.size(), content.taxids.data(), (uint32_t)content.taxids.size(), &ix)) throwLast();
+    munmap(rec, nRec * recBytes); close(fd);
     kasa_ctx *ctx = nullptr;
     if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
 

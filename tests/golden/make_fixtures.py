@@ -58,12 +58,17 @@ def write_db(d, genomes):
 
 def trim_index(d):
     """The reference zero-pads index and trie files to 2,101,248-byte blocks; keep the records only."""
-    n = int(open(os.path.join(d, "idx_info.txt")).read().split()[0])
-    m = int(open(os.path.join(d, "idx_trie.txt")).read().split()[0])
-    for name, cnt in (("idx", n), ("idx_trie", m)):
+    jobs = []
+    for stem, rec in (("idx", 12), ("idx_half", 6)):
+        if not os.path.exists(os.path.join(d, stem + "_info.txt")):
+            continue
+        n = int(open(os.path.join(d, stem + "_info.txt")).read().split()[0])
+        m = int(open(os.path.join(d, stem + "_trie.txt")).read().split()[0])
+        jobs += [(stem, n * rec), (stem + "_trie", m * 12)]
+    for name, nbytes in jobs:
         p = os.path.join(d, name)
         with open(p, "rb") as f:
-            data = f.read(cnt * 12)
+            data = f.read(nbytes)
         with open(p, "wb") as f:
             f.write(data)
 
@@ -123,6 +128,9 @@ def case_pairs(out):
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]
         run(base + extra + ["-q", "out_" + name, "-p", "prof_" + stem + ".csv"], out)
+    # the "halved" index of shrink strategy 2 (6-byte records) and a run on it
+    run(["shrink", "-c", "content.txt", "-d", "idx", "-o", "idx_half", "-s", "2", "-m", "4", "-n", "1"], out)
+    run(base + ["-d", "idx_half", "-i", "reads.fastq", "--jsonl", "-b", "100", "-q", "out_half.jsonl", "-p", "prof_half.csv"], out)
     # the reference's own example input (2 reads; N- and '-'-containing, multi-line FASTA)
     shutil.copy(os.path.join(REF, "example/work/input/exampleInput.fasta"), os.path.join(out, "exampleInput.fasta"))
     run(base + ["-i", "exampleInput.fasta", "--jsonl", "-b", "100", "-q", "out_exampleInput.jsonl",

@@ -10,9 +10,9 @@ from oracle import oracle
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load_case(name):
+def load_case(name, stem="idx"):
     d = os.path.join(GOLDEN, name)
-    return d, formats.load_index(os.path.join(d, "idx"), os.path.join(d, "content.txt"))
+    return d, formats.load_index(os.path.join(d, stem), os.path.join(d, "content.txt"))
 
 
 def csr_from_dense(M):

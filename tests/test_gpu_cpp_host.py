@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 from kasa_amd import build as hipbuild, capi
-from tests.test_oracle_golden import PAIRS, _read
+from tests.test_oracle_golden import PAIRS, _read, unpack
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
@@ -18,10 +18,10 @@ FLAGS = {"json": "--json", "jsonl": "--jsonl", "tsv": "--tsv", "kraken": "--krak
 def test_cpp_host_byte_identical(case, tmp_path):
     assert capi.device_count() > 0
     exe = hipbuild.build_host()
-    stem, infile, fmt, kh, kl, frames, thr, beasts = case
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
     d = os.path.join(helpers.GOLDEN, "pairs")
     out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
-    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile),
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, idx), "-i", os.path.join(d, infile),
            "-q", out, "-p", prof, FLAGS[fmt], "-b", str(beasts), "-k", str(kh), str(kl), "-m", "4", "-n", "1", "-t", str(tmp_path)]
     if frames == 6:
         cmd.append("--six")

@@ -11,7 +11,7 @@ from kasa_amd import capi, formats, reads, report
 from kasa_amd.identify import Identify
 from oracle import oracle
 from tests import helpers
-from tests.test_oracle_golden import PAIRS, _read
+from tests.test_oracle_golden import PAIRS, _read, unpack
 from tests.test_oracle_properties import random_case
 
 pytestmark = pytest.mark.gpu
@@ -36,8 +36,8 @@ def assert_csr_equal(rows_gpu, rows_oracle):
 def test_golden_files_byte_identical(case):
     """End to end against the files the reference binary wrote."""
     _gpu_or_fail()
-    stem, infile, fmt, kh, kl, frames, thr, beasts = case
-    d, ix = helpers.load_case("pairs")
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
+    d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
     idf = Identify(ix, 0, kh, kl, frames, thr, beasts, fmt)
     text, prof, _ = idf.run(batch)

@@ -7,7 +7,7 @@ import pytest
 from kasa_amd import reads
 from tests import helpers
 
-PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts)
+PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts[, index stem])
     ("default.json", "reads.fastq", "json", 12, 7, 3, 0.0, 3),
     ("b100.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
     ("b100.tsv", "reads.fastq", "tsv", 12, 7, 3, 0.0, 100),
@@ -21,7 +21,12 @@ PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beas
     ("thr04.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.4, 100),
     ("ram.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
     ("exampleInput.jsonl", "exampleInput.fasta", "jsonl", 12, 7, 3, 0.0, 100),
+    ("half.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100, "idx_half"),   # 6-byte index of shrink strategy 2
 ]
+
+
+def unpack(case):
+    return case[:8] + ((case[8],) if len(case) > 8 else ("idx",))
 
 
 def _read(path, binary=False):
@@ -33,8 +38,8 @@ def _read(path, binary=False):
 @pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
 @pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
 def test_pairs_byte_identical(case, closed_form):
-    stem, infile, fmt, kh, kl, frames, thr, beasts = case
-    d, ix = helpers.load_case("pairs")
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
+    d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
     res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=closed_form)
     text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
