@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--taxa", type=int, default=1400)
     ap.add_argument("--genome-len", type=int, default=300_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=60_000)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="no per-read scores (kASA without -q)")
     args = ap.parse_args()
