@@ -77,12 +77,19 @@ uint64_t kasa_index_device_bytes(const kasa_index *ix);
 
 /* ---- context: replaces the kASA / Read / Compare constructors (source/kASA.hpp:276-305) and
  *      setCodonTable (source/kASA.hpp:579-615).
- * kHigh/kLow : -k <kHigh> <kLow>; frames: 3 (default) or 6 (--six); codonLut: 366-byte table of
- * 5-bit letter codes indexed like kASA.hpp:75, or NULL for the built-in table (kASA.hpp:621-667).
+ * kHigh/kLow : -k <kHigh> <kLow>; frames: 3 (default), 6 (--six) or 1 (--one, Read.hpp:223-261);
+ * codonLut: 366-byte table of 5-bit letter codes indexed like kASA.hpp:75, or NULL for the built-in
+ * table (kASA.hpp:621-667).
  */
 int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int frames, const uint8_t *codonLut,
                     kasa_ctx **out);
 void kasa_ctx_destroy(kasa_ctx *ctx);
+
+/* The next batches hold amino-acid sequences instead of DNA (what kASA::detectAlphabet decides per
+ * input file, kASA.hpp:155-183): letters are taken as they are ('*' -> '[', code = char & 31), padding
+ * and marker are '^', a read of L letters gives L-K+1 k-mers (Read.hpp:36-41,60-81,636-640,663-667,
+ * 1069-1073); --six is switched off (kASA.hpp:181).  protein = 0 returns to DNA. */
+int kasa_ctx_set_protein(kasa_ctx *ctx, int protein);
 
 /* ---- one batch ------------------------------------------------------------------------------- */
 
@@ -95,7 +102,9 @@ int kasa_batch_upload(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offset
 int kasa_batch_encode(kasa_ctx *ctx, uint64_t *nKmers);
 
 /* Compare::sortInputAndCheckInvalidkMers_sta (Compare.hpp:1074-1260): sort by k-mer and find each
- * query's place in the index.  unique != 0 is -e/--unique (Compare.hpp:3167-3178). */
+ * query's place in the index.  unique != 0 is -e/--unique (Compare.hpp:3167-3178): records equal in
+ * (k-mer, read id) are kept once.  The reference applies std::unique to an unstable sort, so duplicates
+ * it happens not to place side by side survive there; here all of them are dropped. */
 int kasa_batch_sort_and_range(kasa_ctx *ctx, int unique);
 
 /* Compare::compareWithDatabase + scoreMatchForReadIDsAndTaxIDs (Compare.hpp:678-1069,516-673):
@@ -125,6 +134,10 @@ int kasa_ctx_stage_ms(kasa_ctx *ctx, int stage, double *ms, uint64_t *launches);
 int kasa_ctx_stage_reset(kasa_ctx *ctx);
 /* HIP-event time of the dominant kernel alone (the lookup kernel), for the roofline line. */
 int kasa_ctx_lookup_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
+/* Number of query records the batch holds right now: the k-mer count of kasa_batch_encode, less the
+ * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
+int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);
+
 /* Queries of the batch after encode / after sort (k-mer, read id); for parity tests. */
 int kasa_batch_fetch_queries(kasa_ctx *ctx, uint64_t *kmers, uint32_t *reads, uint64_t n);
 /* Test tap: install (k-mer, read id) queries directly instead of upload + encode (any order). */

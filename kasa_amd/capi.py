@@ -19,10 +19,10 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
-    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_encode",
+    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_encode",
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
-    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_fetch_queries",
+    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
 ]
 
@@ -134,6 +134,10 @@ class Context:
         self.n_kmers = int(n.value)
         return self.n_kmers
 
+    def set_protein(self, protein: bool):
+        """Amino-acid input for the next batches (kASA.hpp:155-183)."""
+        _check(lib().kasa_ctx_set_protein(self.h, C.c_int(int(protein))))
+
     def sort_and_range(self, unique: bool = False):
         _check(lib().kasa_batch_sort_and_range(self.h, C.c_int(int(unique))))
 
@@ -150,10 +154,10 @@ class Context:
         _check(lib().kasa_batch_scores_fetch(self.h, _p(off), _p(tax), _p(sc)))
         return off, tax, sc
 
-    def run_batch(self, bases, offsets, want_per_read=True, coverage=False):
+    def run_batch(self, bases, offsets, want_per_read=True, coverage=False, unique=False):
         self.upload(bases, offsets)
         self.encode()
-        self.sort_and_range()
+        self.sort_and_range(unique)
         self.lookup_score(want_per_read, coverage)
 
     # ---- profile ----
@@ -194,10 +198,16 @@ class Context:
         _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
         return ms.value, int(n.value), int(q.value)
 
+    def query_count(self) -> int:
+        n = C.c_uint64(0)
+        _check(lib().kasa_batch_query_count(self.h, C.byref(n)))
+        return int(n.value)
+
     def queries(self):
-        km = np.zeros(self.n_kmers, dtype=np.uint64)
-        rd = np.zeros(self.n_kmers, dtype=np.uint32)
-        _check(lib().kasa_batch_fetch_queries(self.h, _p(km), _p(rd), C.c_uint64(self.n_kmers)))
+        n = self.query_count()
+        km = np.zeros(n, dtype=np.uint64)
+        rd = np.zeros(n, dtype=np.uint32)
+        _check(lib().kasa_batch_fetch_queries(self.h, _p(km), _p(rd), C.c_uint64(n)))
         return km, rd
 
     def set_queries(self, kmers: np.ndarray, reads: np.ndarray, n_reads: int):

@@ -374,6 +374,9 @@ struct kasa_ctx {
     const kasa_index *ix = nullptr;
     int device = 0;
     int kHigh = 12, kLow = 7, nK = 6, frames = 3;
+    bool protein = false;                      // amino-acid input (kasa_ctx_set_protein)
+    int enc_mode() const { return protein ? 2 : (frames == 1 ? 1 : 0); }   // ENC_PROTEIN / ENC_ONE / ENC_DNA
+    int strands() const { return (frames == 6 && !protein) ? 2 : 1; }      // kASA.hpp:181: protein input switches --six off
     hipStream_t stream = nullptr;
     // batch state
     int64_t nReads = 0;
@@ -466,7 +469,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     if (!ix) return fail(KASA_E_ARG, "kasa_ctx_create: index is NULL");
     if (kHigh < kLow) std::swap(kHigh, kLow); // "-k <lower> <upper> is okay too" (README)
     if (kLow < 1 || kHigh > KLETTERS) return fail(KASA_E_ARG, "kasa_ctx_create: k range [%d,%d] outside [1,%d]", kLow, kHigh, KLETTERS);
-    if (frames != 3 && frames != 6) return fail(KASA_E_ARG, "kasa_ctx_create: frames must be 3 or 6 (--one is not on this path yet)");
+    if (frames != 1 && frames != 3 && frames != 6) return fail(KASA_E_ARG, "kasa_ctx_create: frames must be 1, 3 or 6");
     HIPCHK(hipSetDevice(ix->device));
     kasa_ctx *c = new (std::nothrow) kasa_ctx();
     if (!c) return fail(KASA_E_NOMEM, "host allocation failed");
@@ -484,6 +487,14 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     *out = c;
     rc = kasa_profile_reset(c);
     if (rc) { *out = nullptr; return bail(rc); }
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_set_protein(kasa_ctx *c, int protein)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    c->protein = protein != 0;
+    c->state = 0;          // an uploaded batch was measured with the other geometry
     return KASA_OK;
 }
 
@@ -524,18 +535,22 @@ extern "C" int kasa_profile_reset(kasa_ctx *c)
 // ------------------------------------------------------------------------------------------------
 // upload + encode
 // ------------------------------------------------------------------------------------------------
-static inline int64_t host_padded_len(int64_t raw, int K, int kLow)
+// Input geometry of one read (Read.hpp:633-654 padding, :1068-1078 marker, :36-57 k-mer count) for the three
+// input kinds: mode 0 = DNA in 3 or 6 frames, 1 = DNA in one frame (--one), 2 = amino-acid input.
+// body = padded read without the marker, L = body + marker, cnt = k-mers per strand.
+enum { ENC_DNA = 0, ENC_ONE = 1, ENC_PROTEIN = 2 };
+__host__ __device__ static inline void enc_geometry(int mode, int kLow, int64_t raw, int64_t &body, int64_t &L, int64_t &cnt)
 {
-    // Read.hpp:633-654 + 1068-1078: pad with X up to 3K (marker included), then the marker X * 3(K-kLow)
-    const int64_t m = 3 * (int64_t)(K - kLow);
-    int64_t len = raw;
-    if (len > 0 && len + m < 3 * (int64_t)K) len = 3 * (int64_t)K - m;
-    return len + m;
-}
-
-static inline int64_t host_kmer_count(int64_t L, int K)
-{
-    return (L > 3 * (int64_t)K + 1) ? L - 3 * (int64_t)K + 1 : 0; // Read.hpp:36-57
+    const int64_t K = KLETTERS;
+    const int64_t marker = (mode == ENC_PROTEIN ? 1 : 3) * (K - (int64_t)kLow);
+    body = raw;
+    if (mode == ENC_PROTEIN) {
+        if (body + marker < K) body = K - marker;
+    } else if (body + marker < 3 * K) body = 3 * K - marker;   // --one: (len + m) / 3 < K  <=>  len + m < 3K
+    L = body + marker;
+    if (mode == ENC_PROTEIN) cnt = (L > K + 1) ? L - K + 1 : 0;
+    else if (mode == ENC_ONE) { const int64_t t = L / 3; cnt = (t > K + 1) ? t - K + 1 : 0; }
+    else cnt = (L > 3 * K + 1) ? L - 3 * K + 1 : 0;
 }
 
 extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
@@ -550,13 +565,16 @@ extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_
     c->hostOff.assign((size_t)nReads + 1, 0);
     uint64_t run = 0;
     uint32_t maxCnt = 0;
-    const int strands = (c->frames == 6) ? 2 : 1;
+    const int mode = c->enc_mode();
+    const int strands = c->strands();
     for (int64_t r = 0; r < nReads; ++r) {
         const int64_t raw = offsets[r + 1] - offsets[r];
         if (raw < 0) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
         c->hostOff[(size_t)r] = offsets[r] - offsets[0];
         koff[(size_t)r] = run;
-        const uint64_t cnt = raw > 0 ? (uint64_t)host_kmer_count(host_padded_len(raw, KLETTERS, c->kLow), KLETTERS) * strands : 0;
+        int64_t body, L, perStrand = 0;
+        if (raw > 0) enc_geometry(mode, c->kLow, raw, body, L, perStrand);
+        const uint64_t cnt = (uint64_t)perStrand * strands;
         run += cnt;
         if (cnt > maxCnt) maxCnt = (uint32_t)std::min<uint64_t>(cnt, 0xFFFFFFFFull);
     }
@@ -577,14 +595,16 @@ extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_
 }
 
 // One wavefront per read.  The cleaned bases of a window chunk are staged in LDS as 3-bit codes, the
-// codon letters are computed once per start position, each lane then packs K letters at stride 3.
+// codon letters are computed once per start position, each lane then packs K letters: window w starts at
+// base w * ws and takes its letters at stride ls (DNA: ws 1, ls 3; --one: ws 3, ls 3, Read.hpp:223-261;
+// amino-acid input: ws 1, ls 1 and the letters are the input itself, Read.hpp:60-81).
 static constexpr int ENC_CHUNK = 512;                       // windows per chunk
 static constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;   // bases needed for one chunk (+ slack)
 static constexpr int ENC_WAVES = 4;
 
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
-    int64_t nReads, int kLow, int strands, const uint8_t *__restrict__ lutG, uint64_t *__restrict__ outKmer,
+    int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG, uint64_t *__restrict__ outKmer,
     uint32_t *__restrict__ outRead)
 {
     __shared__ uint8_t sLut[384];
@@ -595,48 +615,60 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t wavesTotal = (int64_t)gridDim.x * ENC_WAVES;
-    const int64_t marker = 3 * (int64_t)(KLETTERS - kLow);
+    const int ws = (mode == ENC_ONE) ? 3 : 1;
+    const int ls = (mode == ENC_PROTEIN) ? 1 : 3;
+    const int tail = (KLETTERS - 1) * ls + ((mode == ENC_PROTEIN) ? 1 : 3);   // bases of the last window
+    const int chunk = (mode == ENC_ONE) ? ENC_CHUNK / 3 : ENC_CHUNK;
     for (int64_t r = (int64_t)blockIdx.x * ENC_WAVES + wv; r < nReads; r += wavesTotal) {
         const int64_t b0 = baseOff[r];
         const int64_t raw = baseOff[r + 1] - b0;
         if (raw <= 0) continue;
-        int64_t body = raw;                                  // padded read without the marker
-        if (body + marker < 3 * (int64_t)KLETTERS) body = 3 * (int64_t)KLETTERS - marker;
-        const int64_t L = body + marker;
-        const int64_t cnt = (L > 3 * (int64_t)KLETTERS + 1) ? L - 3 * (int64_t)KLETTERS + 1 : 0;
+        int64_t body, L, cnt;
+        enc_geometry(mode, kLow, raw, body, L, cnt);
         if (cnt == 0) continue;
         const uint64_t o0 = kmerOff[r];
         for (int s = 0; s < strands; ++s) {
-            for (int64_t w0 = 0; w0 < cnt; w0 += ENC_CHUNK) {
-                const int nw = (int)((cnt - w0 < ENC_CHUNK) ? cnt - w0 : ENC_CHUNK);
-                const int span = nw + 3 * KLETTERS - 1;     // bases w0 .. w0+span-1
-                for (int i = lane; i < span; i += 64) {
-                    const int64_t pos = w0 + i;
-                    uint8_t code;
-                    if (pos >= body) code = 4;               // X: padding and marker
-                    else {
-                        const int64_t src = (s == 0) ? pos : (body - 1 - pos);
-                        if (src >= raw) code = 4;            // padding X (reverse strand sees it first)
-                        else {
-                            const uint8_t ch = bases[b0 + src];
-                            const uint8_t up = ch & 0xDF;
-                            const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
-                            code = ok ? (uint8_t)((ch & 14) >> 1) : (uint8_t)5;  // everything else is Z
-                            if (s == 1 && code < 4) code ^= 2;                   // A<->T, C<->G
-                        }
+            for (int64_t w0 = 0; w0 < cnt; w0 += chunk) {
+                const int nw = (int)((cnt - w0 < chunk) ? cnt - w0 : chunk);
+                const int span = (nw - 1) * ws + tail;      // bases w0*ws .. w0*ws+span-1
+                const int64_t base0 = w0 * ws;
+                if (mode == ENC_PROTEIN) {
+                    for (int i = lane; i < span; i += 64) {
+                        const int64_t pos = base0 + i;
+                        uint8_t ch = (pos < raw) ? bases[b0 + pos] : (uint8_t)'^';   // padding and marker are '^'
+                        if (ch == '*') ch = '[';                                    // Read.hpp:663-667
+                        sLetter[wv][i] = ch & 31;
                     }
-                    sCode[wv][i] = code;
+                } else {
+                    for (int i = lane; i < span; i += 64) {
+                        const int64_t pos = base0 + i;
+                        uint8_t code;
+                        if (pos >= body) code = 4;               // X: padding and marker
+                        else {
+                            const int64_t src = (s == 0) ? pos : (body - 1 - pos);
+                            if (src >= raw) code = 4;            // padding X (reverse strand sees it first)
+                            else {
+                                const uint8_t ch = bases[b0 + src];
+                                const uint8_t up = ch & 0xDF;
+                                const bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+                                code = ok ? (uint8_t)((ch & 14) >> 1) : (uint8_t)5;  // everything else is Z
+                                if (s == 1 && code < 4) code ^= 2;                   // A<->T, C<->G
+                            }
+                        }
+                        sCode[wv][i] = code;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS writes of this wave are done
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < span - 2; i += 64)
+                        sLetter[wv][i] = sLut[sCode[wv][i] * 64 + sCode[wv][i + 1] * 8 + sCode[wv][i + 2]];
                 }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS writes of this wave are done
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < span - 2; i += 64)
-                    sLetter[wv][i] = sLut[sCode[wv][i] * 64 + sCode[wv][i + 1] * 8 + sCode[wv][i + 2]];
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < nw; i += 64) {
                     uint64_t v = 0;
+                    const uint8_t *lt = &sLetter[wv][i * ws];
 #pragma unroll
-                    for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | sLetter[wv][i + 3 * j];
+                    for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
                     outRead[o] = (uint32_t)r;
@@ -661,7 +693,7 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     if (c->nReads > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nReads + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         encode_kernel<<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
-            c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->frames == 6 ? 2 : 1, c->lut.as<uint8_t>(),
+            c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
             c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
@@ -927,21 +959,35 @@ __global__ void tile_suffix_kernel(const uint32_t *__restrict__ tileFirst, uint3
     }
 }
 
+__global__ void unique_flag_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n, uint32_t *__restrict__ flag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || kmer[i] != kmer[i - 1] || read[i] != read[i - 1]) ? 1u : 0u;
+}
+
+__global__ void read_count_kernel(const uint32_t *__restrict__ read, uint32_t n, uint64_t *__restrict__ cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd((unsigned long long *)&cnt[read[i]], 1ull);
+}
+
+__global__ void unique_scatter_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n,
+                                      const uint32_t *__restrict__ slot, uint64_t *__restrict__ outKmer, uint32_t *__restrict__ outRead)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sl = slot[i];
+    if (i == 0 || sl != slot[i - 1]) { outKmer[sl - 1] = kmer[i]; outRead[sl - 1] = read[i]; }
+}
+
 extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_sort_and_range: batch not encoded");
-    if (unique) return fail(KASA_E_ARG, "-e/--unique is not on this path yet (the reference calls it BETA; its result depends on an unstable sort)");
     HIPCHK(hipSetDevice(c->ix->device));
-    const uint64_t nQ = c->nQ;
+    uint64_t nQ = c->nQ;
     int rc;
-    if ((rc = c->qKmerB.reserve(nQ * 8 + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) ||
-        (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)))
-        return rc;
-    const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
-    if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4)) ||
-        (rc = c->tileBounds.reserve(((size_t)nTiles + 1) * 8)))
-        return rc;
+    if ((rc = c->qKmerB.reserve(nQ * 8 + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64))) return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_SORT], &a, &b))) return rc;
     if (nQ > 0) {
@@ -952,9 +998,42 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
         HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerA.as<uint64_t>(), c->qKmerB.as<uint64_t>(),
                                          c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KEYBITS, c->stream));
     }
-    if ((rc = timer_end(c, c->timers[KASA_STAGE_SORT], a, b))) return rc;
     c->qKmer = c->qKmerB.as<uint64_t>();
     c->qRead = c->qReadB.as<uint32_t>();
+    if (unique && nQ > 1) {
+        // -e (Compare.hpp:3167-3178): drop records equal in (k-mer, read id) to their predecessor.  The sort above is
+        // stable and the encoder emits reads in ascending order, so every duplicate of a read is adjacent here.
+        if ((rc = c->rep.reserve(nQ * 4 + 64))) return rc;            // rep is free until the lookup: slots of the survivors
+        uint32_t *slot = c->rep.as<uint32_t>();
+        unique_flag_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qKmer, c->qRead, (uint32_t)nQ, slot);
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::inclusive_scan(nullptr, tmpBytes, slot, slot, (size_t)nQ, rocprim::plus<uint32_t>(), c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::inclusive_scan(c->sortTmp.p, tmpBytes, slot, slot, (size_t)nQ, rocprim::plus<uint32_t>(), c->stream));
+        unique_scatter_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qKmer, c->qRead, (uint32_t)nQ, slot,
+            c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+        uint32_t kept = 0;
+        HIPCHK(hipMemcpyAsync(&kept, slot + (nQ - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        nQ = c->nQ = kept;
+        // back into the "sorted" buffers: later stages reuse the A buffers as scratch
+        HIPCHK(hipMemcpyAsync(c->qKmerB.p, c->qKmerA.p, nQ * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->qReadB.p, c->qReadA.p, nQ * 4, hipMemcpyDeviceToDevice, c->stream));
+        // k-mers per read changed: recount, kmerOff = exclusive running sum (what the score kernels index plist with)
+        uint64_t *ko = c->kmerOff.as<uint64_t>();
+        HIPCHK(hipMemsetAsync(ko, 0, ((size_t)c->nReads + 1) * 8, c->stream));
+        read_count_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qReadB.as<uint32_t>(), (uint32_t)nQ, ko);
+        HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, ko, ko, (uint64_t)0, (size_t)c->nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, ko, ko, (uint64_t)0, (size_t)c->nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_SORT], a, b))) return rc;
+    if ((rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64))) return rc;
+    const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
+    if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4)) ||
+        (rc = c->tileBounds.reserve(((size_t)nTiles + 1) * 8)))
+        return rc;
 
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_LOOKUP], &a, &b))) return rc;
     if (nQ > 0) {
@@ -2167,6 +2246,14 @@ extern "C" int kasa_ctx_stage_reset(kasa_ctx *c)
     for (auto &t : c->timers) { int rc = timer_resolve(t); if (rc) return rc; t.ms = 0; t.launches = 0; }
     int rc = timer_resolve(c->lookupKernel); if (rc) return rc;
     c->lookupKernel.ms = 0; c->lookupKernel.launches = 0; c->lookupQueries = 0;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_query_count(kasa_ctx *c, uint64_t *n)
+{
+    if (!c || !n) return fail(KASA_E_ARG, "kasa_batch_query_count: NULL argument");
+    if (c->state < 1) return fail(KASA_E_STATE, "kasa_batch_query_count: no batch uploaded");
+    *n = c->nQ;
     return KASA_OK;
 }
 

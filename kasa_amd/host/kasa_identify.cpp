@@ -6,8 +6,8 @@
 // (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
-// Not supported here (reported as errors, never silently ignored): protein input, --one, -e/--unique,
-// --filter/--coherence/--visualize, paired-end, 128-bit (k <= 25) indices.
+// Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize, paired-end,
+// custom alphabets/codon tables, 128-bit (k <= 25) indices.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -189,9 +189,24 @@ static vector<uint64_t> loadFreqAtK(const string &prefix, size_t nTaxa, int kHig
     return out;
 }
 
-struct ReadSet { vector<uint8_t> bases; vector<int64_t> off{0}; vector<string> names; vector<uint32_t> lengths; };
+struct ReadSet { vector<uint8_t> bases; vector<int64_t> off{0}; vector<string> names; vector<uint32_t> lengths; bool protein = false; };
 
-static ReadSet readInput(const string &path) // what Read.hpp:699-760 hands on, for reads that fit one chunk
+// kASA::detectAlphabet (kASA.hpp:155-183) on the first four characters of the file's second line
+// (Utilities::getFirstSequenceOfFile, Utilities.hpp:137-143)
+static bool detectProtein(const string &data, bool verbose)
+{
+    size_t a = data.find('\n');
+    string four;
+    if (a != string::npos) { size_t b = data.find('\n', a + 1); if (b == string::npos) b = data.size(); four = data.substr(a + 1, std::min<size_t>(4, b - a - 1)); }
+    auto in = [](const string &s, const char *set) { if (s.empty()) return false; for (char c : s) if (!strchr(set, toupper((unsigned char)c)) || c == 0) return false; return true; };
+    if (in(four, "ACGTURYKMSWBDHVN-")) { if (verbose) std::cout << "OUT: DNA sequences detected." << std::endl; return false; }
+    if (!in(four, "ABCDEFGHIJKLMNOPQRSTUVWXYZ*-"))
+        std::cerr << "ERROR: The sequence is neither recognized as protein nor DNA. It will be treated as protein sequence but it may fail... Sequence was: " << four << std::endl;
+    else if (verbose) std::cout << "OUT: Protein sequences detected." << std::endl;
+    return true;
+}
+
+static ReadSet readInput(const string &path, bool verbose) // what Read.hpp:699-760 hands on, for reads that fit one chunk
 {
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) throw std::runtime_error("Input file not found");
@@ -202,6 +217,7 @@ static ReadSet readInput(const string &path) // what Read.hpp:699-760 hands on, 
     if (data.empty()) return rs;
     if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
     const bool fasta = data[0] == '>';
+    rs.protein = detectProtein(data, verbose);
     vector<std::pair<size_t, size_t>> lines; // [begin, end)
     for (size_t a = 0; a < data.size();) { size_t b = data.find('\n', a); if (b == string::npos) b = data.size(); size_t e = b; if (e > a && data[e - 1] == '\r') --e; lines.emplace_back(a, e); a = b + 1; }
     size_t i = 0;
@@ -239,7 +255,7 @@ struct Params {
     int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0;
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
-    bool verbose = false, coverage = false;
+    bool verbose = false, coverage = false, unique = false, protein = false;
 };
 
 static float weightOf(int k) { return (float)(k * k) / 625.f; }
@@ -248,7 +264,9 @@ static float bestScore(uint64_t len, const Params &p) // Compare.hpp:1452-1481
 {
     float best = 0.f;
     for (int i = p.kLow; i <= p.kHigh; ++i) {
-        if (p.frames == 6) best += (float)(2 * (len - (uint64_t)(i * 3) + 1)) * weightOf(i);
+        if (p.protein) best += (float)(len - (uint64_t)i + 1) * weightOf(i);
+        else if (p.frames == 1) best += (float)(len / 3 - (uint64_t)i + 1) * weightOf(i);
+        else if (p.frames == 6) best += (float)(2 * (len - (uint64_t)(i * 3) + 1)) * weightOf(i);
         else best += (float)(len - (uint64_t)(i * 3) + 1) * weightOf(i);
     }
     return best;
@@ -280,7 +298,7 @@ struct Writer {
         int64_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
             if (!(score[i] > 0.f)) continue;
-            const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - 12 * 3 + 1)))); // Compare.hpp:1510
+            const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - (p.protein ? 12 : 12 * 3) + 1)))); // Compare.hpp:1506-1511
             if (rel >= p.threshold) { res[cnt] = std::make_tuple((size_t)tax[i], score[i], rel); ++cnt; }
         }
         if (cnt == 0) {
@@ -367,7 +385,7 @@ static void writeProfile(const string &path, const Params &p, const Content &c, 
     std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) {
         for (size_t i = 0; i < a.v.size(); ++i) { if (a.v[i].second == b.v[i].second) continue; return a.v[i].second > b.v[i].second; }
         return false; });
-    const uint64_t fm = p.frames == 6 ? 6 : 3;
+    const uint64_t fm = p.frames == 1 ? 1 : ((p.frames == 6 && !p.protein) ? 6 : 3);   // Compare.hpp:3500
     vector<uint64_t> garbage(nK, 0);
     for (int i = p.kHigh - p.kLow, j = 0; i > 0; --i, ++j) garbage[j] = nReads * fm * i;
     std::ofstream f(path);
@@ -407,6 +425,7 @@ static int run(int argc, char **argv)
     std::cout << std::endl;
     if (argc < 2 || a[1] != "identify") throw std::runtime_error("only the mode `identify` is available on this path");
     Params p;
+    int frameFlags = 0;
     for (int i = 2; i < argc; ++i) {
         const string &s = a[i];
         auto next = [&]() -> string { if (i + 1 >= argc) throw std::runtime_error("missing value after " + s); return a[++i]; };
@@ -424,17 +443,20 @@ static int run(int argc, char **argv)
         else if (s == "--tsv") p.fmt = Params::Tsv;
         else if (s == "--kraken") p.fmt = Params::Kraken;
         else if (s == "--threshold") p.threshold = std::stof(next());
-        else if (s == "--six") p.frames = 6;
-        else if (s == "--three") p.frames = 3;
+        else if (s == "--six") { p.frames = 6; ++frameFlags; }
+        else if (s == "--three") { p.frames = 3; ++frameFlags; }
+        else if (s == "--one") { p.frames = 1; ++frameFlags; }
+        else if (s == "-e" || s == "--unique") p.unique = true;
         else if (s == "--coverage") p.coverage = true;
         else if (s == "-v" || s == "--verbose") p.verbose = true;
         else if (s == "--device") p.device = std::stoi(next());
         else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
         else if (s == "-m" || s == "--memory" || s == "-n" || s == "--threads" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
-        else if (s == "-e" || s == "--unique" || s == "--one" || s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-1" || s == "-2" || s == "-z" || s == "-a" || s == "--alphabet")
+        else if (s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-1" || s == "-2" || s == "-z" || s == "-a" || s == "--alphabet")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }
+    if (frameFlags >= 2) throw std::runtime_error("You'll have to decide between using one, three, or six frames. Currently, more than one option was chosen. Please check your parameters!"); // main.cpp:618-620
     std::ifstream info(p.index + "_info.txt");
     if (!info) throw std::runtime_error("Info file for this index can not be found!");
     uint64_t nRec = 0, vecType = 0; info >> nRec; info >> vecType;
@@ -465,7 +487,9 @@ static int run(int argc, char **argv)
     kasa_ctx *ctx = nullptr;
     if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
 
-    ReadSet rs = readInput(p.input);
+    ReadSet rs = readInput(p.input, p.verbose);
+    p.protein = rs.protein;
+    if (kasa_ctx_set_protein(ctx, p.protein ? 1 : 0)) throwLast();
     const uint64_t nReads = rs.names.size();
     std::ofstream out;
     if (!p.rtt.empty()) {
@@ -493,7 +517,7 @@ static int run(int argc, char **argv)
         uint64_t nk = 0;
         if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
         if (kasa_batch_encode(ctx, &nk)) throwLast();
-        if (kasa_batch_sort_and_range(ctx, 0)) throwLast();
+        if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
         if (kasa_batch_lookup_score(ctx, !p.rtt.empty(), p.coverage)) throwLast();
         totalKmers += nk;
         if (!p.rtt.empty()) {

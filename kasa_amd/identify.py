@@ -20,12 +20,14 @@ from .reads import ReadBatch
 
 class Identify:
     def __init__(self, index: Index, device: int = 0, k_high: int = 12, k_low: int = 7, frames: int = 3,
-                 threshold: float = 0.0, beasts: int = 3, fmt: str = "json", dix: capi.DeviceIndex = None):
+                 threshold: float = 0.0, beasts: int = 3, fmt: str = "json", dix: capi.DeviceIndex = None,
+                 unique: bool = False):
         self.index = index
         self.k_high, self.k_low = max(k_high, k_low), min(k_high, k_low)
         self.frames, self.threshold, self.beasts, self.fmt = frames, threshold, beasts, fmt
         self.dix = dix if dix is not None else capi.DeviceIndex(index, device)
         self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames)
+        self.unique = unique
         self.n_kmers = 0
         self.n_reads = 0
 
@@ -40,6 +42,8 @@ class Identify:
         out = [writer.header()] if want_per_read else None
         csr = []
         self.ctx.profile_reset()
+        protein = bool(reads.protein)
+        self.ctx.set_protein(protein)
         self.n_kmers = 0
         self.n_reads = 0
         step = reads.n if not batch_reads else batch_reads
@@ -47,7 +51,7 @@ class Identify:
         while a < reads.n or (a == 0 and reads.n == 0):
             b = min(reads.n, a + max(step, 1))
             part = reads.slice(a, b)
-            self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage)
+            self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique)
             self.n_kmers += self.ctx.n_kmers
             if want_per_read:
                 off, tax, sc = self.ctx.scores()
@@ -55,7 +59,7 @@ class Identify:
                 for r in range(part.n):
                     lo, hi = int(off[r]), int(off[r + 1])
                     rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(part.lengths[r]), freq, self.k_high,
-                                          self.k_low, self.frames, self.threshold, self.beasts)
+                                          self.k_low, self.frames, self.threshold, self.beasts, protein=protein)
                     out.append(writer.read(self.n_reads + r, part.names[r], int(part.lengths[r]), rk))
             self.n_reads += part.n
             a = b
@@ -65,5 +69,5 @@ class Identify:
             out.append(writer.footer())
         ca, cu, ct = self.ctx.profile()
         prof = report.profile_csv(ca, cu, ix.content.names, ix.content.taxids, self.k_high, self.k_low,
-                                  self.n_kmers, self.n_reads, self.frames)
+                                  self.n_kmers, self.n_reads, 3 if (protein and self.frames == 6) else self.frames)
         return ("".join(out) if want_per_read else None), prof, csr

@@ -13,6 +13,7 @@ reads fit one batch chunk (every read shorter than ~100 MiB of k-mers, i.e. all 
 from __future__ import annotations
 
 import gzip
+import re
 from dataclasses import dataclass
 
 import numpy as np
@@ -25,6 +26,7 @@ class ReadBatch:
     offsets: np.ndarray   # i64[n+1]
     names: list           # str, with the trailing space
     lengths: np.ndarray   # u32[n]  ("Length" of the reference's output)
+    protein: bool = False  # amino-acid input as kASA::detectAlphabet decides (kASA.hpp:155-183)
 
     @property
     def n(self) -> int:
@@ -33,13 +35,25 @@ class ReadBatch:
     def slice(self, a: int, b: int) -> "ReadBatch":
         o = self.offsets[a:b + 1]
         names = self.names[a:b] if self.names is not None else None
-        return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b])
+        return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b], self.protein)
 
 
 def _open(path: str):
     with open(path, "rb") as f:
         magic = f.read(2)
     return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+
+
+_DNA4 = re.compile(r"^[ACGTURYKMSWBDHVN-]+$", re.IGNORECASE)
+
+
+def detect_protein(data: bytes) -> bool:
+    """kASA::detectAlphabet (kASA.hpp:155-183) on what Utilities::getFirstSequenceOfFile hands it
+    (Utilities.hpp:137-143): the first four characters of the file's second line.  Anything that is not
+    made of IUPAC nucleotide letters counts as amino-acid input."""
+    lines = data.split(b"\n", 2)
+    second = lines[1] if len(lines) > 1 else b""
+    return _DNA4.match(second[:4].decode("latin-1")) is None
 
 
 def parse_reads(path: str) -> ReadBatch:
@@ -101,7 +115,7 @@ def parse_reads(path: str) -> ReadBatch:
     if seqs:
         np.cumsum([len(s) for s in seqs], out=off[1:])
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
-    return ReadBatch(bases, off, names, np.asarray(lens, dtype=np.uint32))
+    return ReadBatch(bases, off, names, np.asarray(lens, dtype=np.uint32), detect_protein(data))
 
 
 def synthetic_reads(genomes, n_reads: int, read_len: int, seed: int, sub_rate: float = 0.01) -> ReadBatch:

@@ -28,11 +28,13 @@ def weight(k: int) -> np.float32:
     return _F32(k * k) / _F32(625.0)
 
 
-def best_score(length: int, k_high: int, k_low: int, frames: int) -> np.float32:
+def best_score(length: int, k_high: int, k_low: int, frames: int, protein: bool = False) -> np.float32:
     """Compare.hpp:1452-1481.  The subtraction is unsigned 64-bit in the reference."""
     best = _F32(0.0)
     for i in range(k_low, k_high + 1):
-        if frames == 1:
+        if protein:
+            span = (length - i + 1) & 0xFFFFFFFFFFFFFFFF
+        elif frames == 1:
             span = (length // 3 - i + 1) & 0xFFFFFFFFFFFFFFFF
         elif frames == 6:
             span = (2 * ((length - 3 * i + 1) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
@@ -42,9 +44,10 @@ def best_score(length: int, k_high: int, k_low: int, frames: int) -> np.float32:
     return best
 
 
-def relative_score(score: np.float32, freq: int, length: int, K: int = K64) -> float:
-    """Compare.hpp:1510 (DNA): score / (1 + log2(freq * double(len - 3K + 1))), uint32 subtraction."""
-    span = (int(length) - 3 * K + 1) & 0xFFFFFFFF
+def relative_score(score: np.float32, freq: int, length: int, K: int = K64, protein: bool = False) -> float:
+    """Compare.hpp:1506-1511: score / (1 + log2(freq * double(len - 3K + 1))) (len - K + 1 for protein
+    input), uint32 subtraction."""
+    span = (int(length) - (K if protein else 3 * K) + 1) & 0xFFFFFFFF
     prod = float(int(freq)) * float(span)
     if prod <= 0.0:
         lg = -math.inf if prod == 0.0 else math.nan
@@ -72,16 +75,16 @@ class Ranked:
 
 
 def rank_read(tax_idx, scores, length: int, freq_khigh, k_high: int, k_low: int, frames: int,
-              threshold: float, beasts: int, K: int = K64) -> Ranked:
+              threshold: float, beasts: int, K: int = K64, protein: bool = False) -> Ranked:
     """Compare.hpp:1495-1594.  `tax_idx` ascending, `scores` > 0 (the cells the reference scans)."""
-    best = best_score(length, k_high, k_low, frames)
+    best = best_score(length, k_high, k_low, frames, protein)
     thr = float(_F32(threshold))
     hits = []
     for t, s in zip(tax_idx, scores):
         s = _F32(s)
         if not (s > 0):
             continue
-        rel = relative_score(s, int(freq_khigh[int(t)]), length, K)
+        rel = relative_score(s, int(freq_khigh[int(t)]), length, K, protein)
         if rel >= thr:
             hits.append(Hit(int(t), s, rel))
     # std::sort on `rel` descending; libstdc++ uses insertion sort up to 16 elements, i.e. stable there

@@ -50,14 +50,19 @@ float ko_weight(int k) /* Compare.hpp:392: k*k / 625.f, both operands float */
 /* ------------------------------------------------------------------------------------------------
  * A3. Read preparation.  Read.hpp:1068-1078 (marker), 633-654 (padding), 36-57 (count).
  * ---------------------------------------------------------------------------------------------- */
-static int64_t marker_len(const ko_params *p) { return 3 * (int64_t)(p->K - p->kLow); }
+static int64_t marker_len(const ko_params *p) /* Read.hpp:1068-1078: '^' x (K-kLow) for protein, 'X' x 3(K-kLow) else */
+{
+    return (p->protein ? 1 : 3) * (int64_t)(p->K - p->kLow);
+}
 
 int64_t ko_padded_len(int64_t rawLen, const ko_params *p)
 {
     const int64_t m = marker_len(p);
     int64_t len = rawLen;
     if (len > 0) {
-        if (p->frames == 1) {
+        if (p->protein) {
+            while (len + m < p->K) ++len;
+        } else if (p->frames == 1) {
             while ((len + m) / 3 < p->K) ++len;
         } else {
             while (len + m < 3 * (int64_t)p->K) ++len;
@@ -68,6 +73,7 @@ int64_t ko_padded_len(int64_t rawLen, const ko_params *p)
 
 int64_t ko_kmer_count(int64_t L, const ko_params *p)
 {
+    if (p->protein) return (L > p->K + 1) ? L - p->K + 1 : 0;
     if (p->frames == 1) {
         const int64_t t = L / 3;
         return (t > p->K + 1) ? t - p->K + 1 : 0;
@@ -92,6 +98,14 @@ static void encode_prepared(const uint8_t *s, int64_t L, const ko_params *p, con
                             uint64_t *out, int64_t count)
 {
     const int K = p->K;
+    if (p->protein) { /* Read.hpp:60-81 + kASA.hpp:333-379: the letters are the input, code = char & 31 */
+        for (int64_t i = 0; i < count; ++i) {
+            uint64_t v = 0;
+            for (int j = 0; j < K; ++j) v = (v << 5) | (uint64_t)(s[i + j] & 31);
+            out[i] = v;
+        }
+        return;
+    }
     if (p->frames == 1) { /* Read.hpp:223-261: translate frame 0 once, slide over letters */
         for (int64_t i = 0; i < count; ++i) {
             uint64_t v = 0;
@@ -119,7 +133,7 @@ int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads
         const int64_t raw = off[r + 1] - off[r];
         const int64_t L = ko_padded_len(raw, p);
         const int64_t cnt = (raw > 0) ? ko_kmer_count(L, p) : 0;
-        const int strands = (p->frames == 6) ? 2 : 1;
+        const int strands = (p->frames == 6 && !p->protein) ? 2 : 1; /* kASA.hpp:181: protein switches --six off */
         if (!outKmer) { total += cnt * strands; continue; }
         if (raw == 0) continue;
         if (L + 4 > cap) {
@@ -129,8 +143,13 @@ int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads
         }
         /* Read.hpp:657-675: everything but ACGTacgt becomes Z; Read.hpp:648-650: pad with X */
         const uint8_t *src = bases + off[r];
-        for (int64_t i = 0; i < raw; ++i) buf[i] = is_acgt(src[i]) ? src[i] : (uint8_t)'Z';
-        for (int64_t i = raw; i < L; ++i) buf[i] = 'X'; /* padding + marker are both X */
+        if (p->protein) { /* Read.hpp:663-667: '*' becomes '['; padding and marker are '^' (Read.hpp:636-640,1069-1073) */
+            for (int64_t i = 0; i < raw; ++i) buf[i] = (src[i] == '*') ? (uint8_t)'[' : src[i];
+            for (int64_t i = raw; i < L; ++i) buf[i] = '^';
+        } else {
+            for (int64_t i = 0; i < raw; ++i) buf[i] = is_acgt(src[i]) ? src[i] : (uint8_t)'Z';
+            for (int64_t i = raw; i < L; ++i) buf[i] = 'X'; /* padding + marker are both X */
+        }
         if (cnt > 0) {
             encode_prepared(buf, L, p, lut, outKmer + total, cnt);
             for (int64_t i = 0; i < cnt; ++i) outRead[total + i] = (uint32_t)r;
@@ -551,6 +570,19 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_
     return 0;
 }
 
+uint64_t ko_unique_queries(uint64_t *kmer, uint32_t *read, uint64_t n)
+{
+    if (n == 0) return 0;
+    uint64_t w = 1;
+    for (uint64_t i = 1; i < n; ++i)
+        if (kmer[i] != kmer[w - 1] || read[i] != read[w - 1]) {
+            kmer[w] = kmer[i];
+            read[w] = read[i];
+            ++w;
+        }
+    return w;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * A8. Per-read numbers.  Compare.hpp:1452-1481, 1510, 1634.
  * ---------------------------------------------------------------------------------------------- */
@@ -559,7 +591,9 @@ float ko_best_score(uint64_t readLen, const ko_params *p)
     float best = 0.f;
     for (int32_t i = p->kLow; i <= p->kHigh; ++i) {
         const float w = ko_weight(i);
-        if (p->frames == 1) {
+        if (p->protein) {
+            best += (float)(readLen - (uint64_t)i + 1) * w;
+        } else if (p->frames == 1) {
             best += (float)(readLen / 3 - (uint64_t)i + 1) * w;
         } else if (p->frames == 6) {
             best += (float)(2 * (readLen - (uint64_t)(i * 3) + 1)) * w;
@@ -573,7 +607,7 @@ float ko_best_score(uint64_t readLen, const ko_params *p)
 double ko_relative_score(float kmerScore, uint64_t freqAtKHigh, uint64_t readLen, const ko_params *p)
 {
     /* the reference subtracts in 32-bit unsigned arithmetic (uint32_t length, int K) */
-    const uint32_t span = (uint32_t)readLen - (uint32_t)(p->K * 3) + 1u;
+    const uint32_t span = (uint32_t)readLen - (uint32_t)(p->protein ? p->K : p->K * 3) + 1u;
     return (double)kmerScore / (1.0 + log2((double)freqAtKHigh * (double)span));
 }
 

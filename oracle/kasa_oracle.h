@@ -28,6 +28,7 @@ typedef struct {
     int32_t avxQuirk; /* 1: flush like the reference's scoreMatchAVX (n>3), i.e. like the shipped
                          -march=native binary; 0: scoreMatchNonAVX for every n (the parity target) */
     int32_t coverage; /* 1: also count countTotal (--coverage) */
+    int32_t protein;  /* 1: the reads are amino-acid sequences (kASA.hpp:155-183, Read.hpp:60-81) */
 } ko_params;
 
 typedef struct {
@@ -56,6 +57,12 @@ int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads
 
 /* Compare.hpp:1077 -- sort by k-mer only (stable LSD radix here; ties do not matter). */
 void ko_sort_queries(uint64_t *kmer, uint32_t *read, uint64_t n);
+
+/* Compare.hpp:3167-3178 (-e): drop a record equal in (k-mer, read id) to its predecessor.  The reference applies
+ * std::unique to the output of an unstable sort by k-mer, so which duplicates end up adjacent is an accident of its
+ * sort; after the stable sort here all of them are.  Identical whenever no other read shares the duplicated k-mer.
+ * Returns the new count. */
+uint64_t ko_unique_queries(uint64_t *kmer, uint32_t *read, uint64_t n);
 
 /* Compare.hpp:1098-1117 + Trie.hpp:494-520 -- prefix (kmer>>30) -> (start, len-1) or KO_RANGE_NONE. */
 void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uint64_t n,

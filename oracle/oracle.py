@@ -19,7 +19,7 @@ RANGE_NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 class Params(C.Structure):
     _fields_ = [("K", C.c_int32), ("kHigh", C.c_int32), ("kLow", C.c_int32), ("frames", C.c_int32),
-                ("avxQuirk", C.c_int32), ("coverage", C.c_int32)]
+                ("avxQuirk", C.c_int32), ("coverage", C.c_int32), ("protein", C.c_int32)]
 
 
 class _Index(C.Structure):
@@ -41,6 +41,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.ko_encode_batch.restype = C.c_int64
+        _LIB.ko_unique_queries.restype = C.c_uint64
         _LIB.ko_padded_len.restype = C.c_int64
         _LIB.ko_kmer_count.restype = C.c_int64
         _LIB.ko_best_score.restype = C.c_float
@@ -59,8 +60,8 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def params(k_high=12, k_low=7, frames=3, avx_quirk=False, coverage=False, K=12) -> Params:
-    return Params(K, k_high, k_low, frames, int(avx_quirk), int(coverage))
+def params(k_high=12, k_low=7, frames=3, avx_quirk=False, coverage=False, K=12, protein=False) -> Params:
+    return Params(K, k_high, k_low, frames, int(avx_quirk), int(coverage), int(protein))
 
 
 def codon_table() -> np.ndarray:
@@ -133,14 +134,25 @@ def compare(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, want_reads=T
     return CompareResult(ca, cu, ct, M)
 
 
-def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False):
-    """Whole reference batch: encode -> sort -> ranges -> merge.  Returns (CompareResult, nQueries)."""
+def unique_queries(km: np.ndarray, rd: np.ndarray):
+    """-e (Compare.hpp:3167-3178) on sorted records."""
+    km, rd = km.copy(), rd.copy()
+    n = int(lib().ko_unique_queries(_p(km), _p(rd), C.c_uint64(km.shape[0])))
+    return km[:n], rd[:n]
+
+
+def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False, unique=False):
+    """Whole reference batch: encode -> sort [-> unique] -> ranges -> merge.  Returns (CompareResult, nQueries);
+    nQueries counts the k-mers before -e, as iNumberOfkMersInInput does (Compare.hpp:3124)."""
     iv = IndexView(ix)
     km, rd = encode(bases, offsets, p)
+    n_in = int(km.shape[0])
     km, rd = sort_queries(km, rd)
+    if unique:
+        km, rd = unique_queries(km, rd)
     rs, rl = ranges(iv, p, km)
     res = compare(iv, p, km, rd, rs, rl, offsets.shape[0] - 1, want_reads, closed_form)
-    return res, int(km.shape[0])
+    return res, n_in
 
 
 def best_score(length: int, p: Params) -> np.float32:

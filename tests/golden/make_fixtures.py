@@ -73,6 +73,39 @@ def trim_index(d):
             f.write(data)
 
 
+# standard genetic code in kASA's letters: stops TAA/TAG -> '*' (written '[' by the reader), TGA -> ']'
+# (the table `build` translates the database with; README "amino-acid-like" alphabet)
+_AA = {}
+for _i, _c0 in enumerate("TCAG"):
+    for _j, _c1 in enumerate("TCAG"):
+        for _k, _c2 in enumerate("TCAG"):
+            _AA[_c0 + _c1 + _c2] = "FFLLSSSSYY**CC]WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"[16 * _i + 4 * _j + _k]
+
+
+def translate(s):
+    return "".join(_AA[s[i:i + 3]] for i in range(0, len(s) - 2, 3))
+
+
+def write_protein_reads(out, genomes):
+    rng = random.Random(13)
+    L = len(genomes[0])
+    reads = []
+    for r in range(24):
+        g = rng.randrange(len(genomes)); p = rng.randrange(L - 180); fr = rng.randrange(3)
+        ln = rng.choice([30, 50, 60])
+        reads.append(("prot%d_t%d" % (r, g), translate(genomes[g][p + fr:p + fr + 3 * ln])))
+    g0 = genomes[0]
+    reads.append(("plower", translate(g0[300:450]).lower()))
+    reads.append(("ptiny5", translate(g0[600:615])))
+    reads.append(("plen12", translate(g0[600:636])))
+    reads.append(("plen13", translate(g0[600:639])))
+    reads.append(("plen14", translate(g0[600:642])))
+    reads.append(("pforeign", "".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(50))))
+    with open(os.path.join(out, "reads_prot.fasta"), "w") as f:
+        for n, s in reads:
+            f.write(">%s\n%s\n" % (n, s))
+
+
 def case_pairs(out):
     """6 taxa in 3 sibling pairs (3 % apart): at most 2-3 taxa per k-mer -> the binary's scalar path."""
     rng = random.Random(11)
@@ -109,6 +142,15 @@ def case_pairs(out):
             f.write(">%s\n" % n)
             for i in range(0, len(s), 60):
                 f.write(s[i:i + 60] + "\n")
+    g = genomes
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    dup = [("tandem", g[0][700:730] * 5), ("twice", g[0][800:875] * 2), ("triple", g[2][100:150] * 3),
+           ("plain1", g[1][0:150]), ("plain3", g[3][200:350]), ("plain4", g[4][400:550]), ("plain5", g[5][900:1050]),
+           ("palin", g[2][300:360] + "".join(comp[c] for c in reversed(g[2][300:360])))]
+    with open(os.path.join(out, "reads_dup.fastq"), "w") as f:
+        for n, s in dup:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    write_protein_reads(out, genomes)
     run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
     base = ["identify", "-c", "content.txt", "-d", "idx", "-m", "4", "-n", "1"]
     runs = {
@@ -124,6 +166,14 @@ def case_pairs(out):
         "six.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--six"],
         "thr04.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--threshold", "0.4"],
         "ram.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "-r"],
+        "one.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--one"],
+        # reads that repeat their own k-mers, without and with -e (std::unique after an unstable sort: the outcome
+        # is defined only where no OTHER read shares the repeated k-mers, hence the disjoint windows)
+        "dup.jsonl": ["-i", "reads_dup.fastq", "--jsonl", "-b", "100"],
+        "unique.jsonl": ["-i", "reads_dup.fastq", "--jsonl", "-b", "100", "-e"],
+        "unique6.jsonl": ["-i", "reads_dup.fastq", "--jsonl", "-b", "100", "-e", "--six"],
+        # amino-acid input (the binary detects it from the first sequence)
+        "prot.jsonl": ["-i", "reads_prot.fasta", "--jsonl", "-b", "100"],
     }
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]

@@ -25,21 +25,23 @@ def csr_from_dense(M):
 
 
 def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low, frames,
-           threshold=0.0, beasts=3):
+           threshold=0.0, beasts=3, protein=False):
     w = report.ReadWriter(fmt, ix.content.names, ix.content.taxids, beasts)
     freq = ix.freq_at(k_high)
     out = [w.header()]
     for r in range(batch.n):
         t, s = rows[r]
-        rk = report.rank_read(t, s, int(batch.lengths[r]), freq, k_high, k_low, frames, threshold, beasts)
+        rk = report.rank_read(t, s, int(batch.lengths[r]), freq, k_high, k_low, frames, threshold, beasts,
+                              protein=protein)
         out.append(w.read(r, batch.names[r], int(batch.lengths[r]), rk))
     out.append(w.footer())
     prof = report.profile_csv(count_all, count_unique, ix.content.names, ix.content.taxids, k_high, k_low,
-                              n_kmers, batch.n, frames)
+                              n_kmers, batch.n, 3 if (protein and frames == 6) else frames)
     return "".join(out), prof
 
 
-def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, closed_form=False):
-    p = oracle.params(k_high, k_low, frames, avx_quirk)
-    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form)
+def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, closed_form=False, unique=False,
+                    protein=False):
+    p = oracle.params(k_high, k_low, frames, avx_quirk, protein=protein)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique)
     return res, nq

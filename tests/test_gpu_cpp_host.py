@@ -18,13 +18,17 @@ FLAGS = {"json": "--json", "jsonl": "--jsonl", "tsv": "--tsv", "kraken": "--krak
 def test_cpp_host_byte_identical(case, tmp_path):
     assert capi.device_count() > 0
     exe = hipbuild.build_host()
-    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
     d = os.path.join(helpers.GOLDEN, "pairs")
     out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
     cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, idx), "-i", os.path.join(d, infile),
            "-q", out, "-p", prof, FLAGS[fmt], "-b", str(beasts), "-k", str(kh), str(kl), "-m", "4", "-n", "1", "-t", str(tmp_path)]
     if frames == 6:
         cmd.append("--six")
+    if frames == 1:
+        cmd.append("--one")
+    if uniq:
+        cmd.append("-e")
     if thr:
         cmd += ["--threshold", str(thr)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)

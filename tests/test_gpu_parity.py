@@ -36,17 +36,17 @@ def assert_csr_equal(rows_gpu, rows_oracle):
 def test_golden_files_byte_identical(case):
     """End to end against the files the reference binary wrote."""
     _gpu_or_fail()
-    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
     d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
-    idf = Identify(ix, 0, kh, kl, frames, thr, beasts, fmt)
+    idf = Identify(ix, 0, kh, kl, frames, thr, beasts, fmt, unique=uniq)
     text, prof, _ = idf.run(batch)
     assert text == _read(os.path.join(d, "out_" + stem))
     assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
     idf.close()
 
 
-@pytest.mark.parametrize("frames", [3, 6])
+@pytest.mark.parametrize("frames", [3, 6, 1])
 @pytest.mark.parametrize("krange", [(12, 7), (12, 12), (9, 6), (12, 5)])
 def test_stages_vs_oracle_golden_inputs(frames, krange):
     """encode, sort, lookup depth, profile tables and per-read CSR against the oracle."""
@@ -220,14 +220,21 @@ def test_profile_limbs_roundtrip_and_sum():
     ctx.close(); dix.close()
 
 
-def _check_against_oracle(ix, batch, kh, kl, frames, flags=0):
-    p = oracle.params(kh, kl, frames)
-    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+def _check_against_oracle(ix, batch, kh, kl, frames, flags=0, unique=False, protein=False):
+    p = oracle.params(kh, kl, frames, protein=protein)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, unique=unique)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, kl, frames)
+    ctx.set_protein(protein)
     ctx.debug_flags(flags)
-    ctx.run_batch(batch.bases, batch.offsets, True)
+    ctx.run_batch(batch.bases, batch.offsets, True, unique=unique)
     assert ctx.n_kmers == nq
+    if unique or protein:   # the stage outputs as well
+        km_o, rd_o = oracle.sort_queries(*oracle.encode(batch.bases, batch.offsets, p))
+        if unique:
+            km_o, rd_o = oracle.unique_queries(km_o, rd_o)
+        km_g, rd_g = ctx.queries()
+        assert np.array_equal(km_g, km_o) and np.array_equal(rd_g, rd_o)
     ca, cu, _ = ctx.profile()
     assert np.array_equal(cu, res.count_unique)
     np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
@@ -260,8 +267,56 @@ def test_long_reads_and_mixed_lengths():
         off.append(off[-1] + L)
     batch = reads.ReadBatch(np.concatenate(parts), np.asarray(off, dtype=np.int64), None,
                             np.asarray([l + 1 for l in lens], dtype=np.uint32))
-    for frames in (3, 6):
+    for frames in (3, 6, 1):
         _check_against_oracle(ix, batch, 12, 7, frames)
+    _check_against_oracle(ix, batch, 12, 7, 3, unique=True)
+
+
+@pytest.mark.parametrize("frames", [3, 6])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_unique_drops_repeats_inside_reads(frames, flags):
+    """-e: tandem-repeat reads (the same k-mer many times in one read, also shared between reads) across several
+    tiles; per-read k-mer counts change, so the per-read offsets are recomputed on the device."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(77)
+    ix, base = synthetic_world(41, 6, 3000, 400)
+    pool = base.bases
+    parts, off = [], [0]
+    for r in range(300):
+        a = int(rng.integers(0, pool.shape[0] - 200))
+        unit = pool[a:a + int(rng.integers(20, 80))]
+        seq = np.tile(unit, 8)[:int(rng.integers(40, 300))] if r % 3 else pool[a:a + 150]
+        parts.append(seq)
+        off.append(off[-1] + seq.shape[0])
+    batch = reads.ReadBatch(np.concatenate(parts), np.asarray(off, dtype=np.int64), None,
+                            np.asarray([p.shape[0] + 1 for p in parts], dtype=np.uint32))
+    _check_against_oracle(ix, batch, 12, 7, frames, flags, unique=True)
+
+
+@pytest.mark.parametrize("krange", [(12, 7), (12, 12), (10, 5)])
+def test_protein_reads(krange):
+    """Amino-acid input: letters 'A'..'Z', '*', lower case, lengths around K, reads longer than an encoder chunk."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(88)
+    ix, dna = synthetic_world(51, 6, 3000, 100)
+    # translate stretches of the genomes the way the index was built, so that the reads match
+    lut = oracle.codon_table()
+    pool = dna.bases
+    code = (pool & 14) >> 1
+    parts, off = [], [0]
+    for r, L in enumerate([0, 1, 5, 11, 12, 13, 14, 20, 50, 50, 64, 100, 333, 700, 30, 30]):
+        a = int(rng.integers(0, pool.shape[0] - 3 * 701))
+        c = code[a:a + 3 * L].reshape(-1, 3).astype(np.int64)
+        aa = (lut[c[:, 0] * 64 + c[:, 1] * 8 + c[:, 2]] + 64).astype(np.uint8)
+        aa[aa == ord("[")] = ord("*")
+        if r % 4 == 1:
+            aa = np.where((aa >= 65) & (aa <= 90), aa + 32, aa).astype(np.uint8)   # lower case
+        parts.append(aa)
+        off.append(off[-1] + L)
+    batch = reads.ReadBatch(np.concatenate(parts), np.asarray(off, dtype=np.int64), None,
+                            np.asarray([p.shape[0] + 1 for p in parts], dtype=np.uint32), True)
+    slow = _check_against_oracle(ix, batch, krange[0], krange[1], 3, protein=True)
+    _check_against_oracle(ix, batch, krange[0], krange[1], 6, protein=True)   # --six is ignored for protein input
 
 
 def test_many_taxa_per_read_and_large_content():

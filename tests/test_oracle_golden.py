@@ -7,7 +7,7 @@ import pytest
 from kasa_amd import reads
 from tests import helpers
 
-PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts[, index stem])
+PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts[, index stem[, -e]])
     ("default.json", "reads.fastq", "json", 12, 7, 3, 0.0, 3),
     ("b100.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
     ("b100.tsv", "reads.fastq", "tsv", 12, 7, 3, 0.0, 100),
@@ -22,11 +22,16 @@ PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beas
     ("ram.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
     ("exampleInput.jsonl", "exampleInput.fasta", "jsonl", 12, 7, 3, 0.0, 100),
     ("half.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100, "idx_half"),   # 6-byte index of shrink strategy 2
+    ("one.jsonl", "reads.fastq", "jsonl", 12, 7, 1, 0.0, 100),                # --one
+    ("prot.jsonl", "reads_prot.fasta", "jsonl", 12, 7, 3, 0.0, 100),          # amino-acid input (detected from the file)
+    ("dup.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 3, 0.0, 100),            # reads repeating their own k-mers ...
+    ("unique.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 3, 0.0, 100, "idx", True),   # ... and the same with -e
+    ("unique6.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 6, 0.0, 100, "idx", True),  # -e --six
 ]
 
 
 def unpack(case):
-    return case[:8] + ((case[8],) if len(case) > 8 else ("idx",))
+    return case[:8] + ((case[8],) if len(case) > 8 else ("idx",)) + ((case[9],) if len(case) > 9 else (False,))
 
 
 def _read(path, binary=False):
@@ -38,12 +43,14 @@ def _read(path, binary=False):
 @pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
 @pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
 def test_pairs_byte_identical(case, closed_form):
-    stem, infile, fmt, kh, kl, frames, thr, beasts, idx = unpack(case)
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
     d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
-    res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=closed_form)
+    assert batch.protein == (stem == "prot.jsonl")
+    res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=closed_form, unique=uniq,
+                                      protein=batch.protein)
     text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
-                                nq, fmt, kh, kl, frames, thr, beasts)
+                                nq, fmt, kh, kl, frames, thr, beasts, protein=batch.protein)
     assert text == _read(os.path.join(d, "out_" + stem))
     assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
 
