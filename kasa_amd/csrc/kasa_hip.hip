@@ -115,6 +115,16 @@ __device__ __forceinline__ int lcp_letters(uint64_t a, uint64_t b)
     return x ? (__clzll(x) / 5) : KLETTERS;
 }
 
+__device__ __forceinline__ int lcp_of_xor(uint64_t x)   // lcp_letters when the XOR of the two keys is at hand
+{
+    x <<= KEYSHIFT;
+    return x ? (__clzll(x) / 5) : KLETTERS;
+}
+
+// 5-bit-field constants over the 12 letters of a key: '^' (30) in every field, the low four bits, bit 4
+static constexpr uint64_t field_repeat(uint64_t v) { uint64_t r = 0; for (int i = 0; i < KLETTERS; ++i) r |= v << (5 * i); return r; }
+static constexpr uint64_t HAT_ALL = field_repeat(30), LOW4_ALL = field_repeat(15), BIT4_ALL = field_repeat(16);
+
 __device__ __forceinline__ int group_letters(int k) { return k < RANGE_LETTERS ? RANGE_LETTERS : k; }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,13 +873,13 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
     }
     uint32_t outRep[ITEMS];
     uint32_t outD[ITEMS];
-    uint32_t firstAt[MAX_LEVELS];                                      // per level: this thread's first special position
+    uint32_t special[ITEMS];                                           // bit lv: the position opens a level-(kHigh-lv) group
+    const uint32_t allLv = (1u << nK) - 1u;                            // nK <= MAX_LEVELS = 12
+    const uint64_t hatLetters = (2ull << (5 * (KLETTERS - kLow) + 4)) - 1ull;   // the bits of letters kLow..12
 #pragma unroll
-    for (int lv = 0; lv < MAX_LEVELS; ++lv) firstAt[lv] = NOPOS;
-#pragma unroll
-    for (int it = ITEMS - 1; it >= 0; --it) {                          // descending, so the smallest position wins
+    for (int it = 0; it < ITEMS; ++it) {
         const uint32_t p = p0 + it;
-        outRep[it] = 0; outD[it] = 0;
+        outRep[it] = 0; outD[it] = 0; special[it] = 0;
         if (p >= nQ) continue;
         const uint64_t q = qv[it];
         uint32_t lo;
@@ -889,35 +899,44 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
             if (hasLo) eLo = idxKmer[lo];
             if (hasPrev) ePrev = idxKmer[lo - 1];
         }
-        const int la = hasLo ? lcp_letters(q, eLo) : 0;
-        const int lb = hasPrev ? lcp_letters(q, ePrev) : 0;
-        int L = la >= lb ? la : lb;
-        const uint32_t r = la >= lb ? lo : lo - 1;
+        // letters shared with the closer neighbour: the smaller XOR has the longer common prefix
+        const uint64_t xa = hasLo ? (q ^ eLo) : ~0ull;
+        const uint64_t xb = hasPrev ? (q ^ ePrev) : ~0ull;
+        const int la = lcp_of_xor(xa);
+        int L = lcp_of_xor(xa < xb ? xa : xb);
+        const uint32_t r = (la == L) ? lo : lo - 1;                     // ties go to the lower bound itself
         int d = 0;
         if (L >= RANGE_LETTERS) {                                       // the 6-letter prefix exists (Trie.hpp:494)
-            if (L > kHigh) L = kHigh;
-            d = L;
-            for (int k = kLow; k <= L; ++k)                             // '^' ends the query (Compare.hpp:836,897)
-                if (((q >> (5 * (KLETTERS - k))) & 31) == 30) { d = k - 1; break; }
+            d = L > kHigh ? kHigh : L;
+            // '^' ends the query (Compare.hpp:836,897): first letter >= kLow that equals 30, found without a loop --
+            // per 5-bit field, bit 4 of ((x & 01111b) + 01111b) | x is set iff the field of x = q ^ "^^^..." is non-zero
+            const uint64_t x = q ^ HAT_ALL;
+            const uint64_t z = ~(((x & LOW4_ALL) + LOW4_ALL) | x) & BIT4_ALL & hatLetters;
+            if (z) {
+                const int khat = KLETTERS - (59 - __clzll(z)) / 5;       // bit 5(12-k)+4 belongs to letter k
+                if (khat <= d) d = khat - 1;
+            }
             if (d < kLow) d = 0;
         }
         outD[it] = (uint32_t)d;
         outRep[it] = r;
         const uint64_t prevQ = it ? qv[it - 1] : qBefore;
         const int ql = (p == 0) ? 0 : lcp_letters(prevQ, q);
-#pragma unroll
-        for (int lv = 0; lv < MAX_LEVELS; ++lv) {
-            const int k = kHigh - lv;
-            if (lv < nK && ((ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k))) firstAt[lv] = p;
-        }
+        // special for level k: a new range (ql < 6), or a new matched group: ql < k <= d
+        uint32_t m = allLv;
+        if (ql >= RANGE_LETTERS) m = (d > ql) ? ((((2u << (d - ql - 1)) - 1u) << (kHigh - d)) & allLv) : 0u;
+        special[it] = m;
     }
-    // positions grow with the lane: per level the lowest lane with a special position holds the wavefront's minimum
-#pragma unroll
-    for (int lv = 0; lv < MAX_LEVELS; ++lv) {
-        if (lv >= nK) break;
-        const bool has = firstAt[lv] != NOPOS;
-        const unsigned long long m = __ballot(has);
-        if (has && (m & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicMin(&sFirst[lv], firstAt[lv]);
+    // positions grow with the lane and with the item: per level the lowest lane holding a special position has the
+    // wavefront's minimum
+    const uint32_t anySpecial = special[0] | special[1] | special[2] | special[3];
+    for (int lv = 0; lv < nK; ++lv) {
+        const bool has = (anySpecial >> lv) & 1u;
+        const unsigned long long mk = __ballot(has);
+        if (has && (mk & ((1ull << (tid & 63)) - 1ull)) == 0ull) {
+            const uint32_t it = ((special[0] >> lv) & 1u) ? 0u : ((special[1] >> lv) & 1u) ? 1u : ((special[2] >> lv) & 1u) ? 2u : 3u;
+            atomicMin(&sFirst[lv], p0 + it);
+        }
     }
     if (fullTile) {
         *reinterpret_cast<uint4 *>(rep + p0) = make_uint4(outRep[0], outRep[1], outRep[2], outRep[3]);
