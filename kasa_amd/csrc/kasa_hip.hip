@@ -1539,6 +1539,21 @@ __device__ __forceinline__ float event_score(int k, uint32_t n)
     return __fmul_rn(w, __fdiv_rn(1.0f, (float)n));                // Compare.hpp:924
 }
 
+// The same two correctly rounded divisions, done once per workgroup: w_k for every k and 1/n for n < EV_INV.
+static constexpr int EV_INV = 64;
+struct EventTables { float w[32]; float inv[EV_INV]; };
+__device__ __forceinline__ void event_tables_init(EventTables &T)
+{
+    for (int i = threadIdx.x; i < 32; i += blockDim.x) T.w[i] = (float)(i * i) / 625.0f;
+    for (int i = threadIdx.x; i < EV_INV; i += blockDim.x) T.inv[i] = i ? __fdiv_rn(1.0f, (float)i) : 0.0f;
+    __syncthreads();
+}
+__device__ __forceinline__ float event_score(const EventTables &T, int k, uint32_t n)
+{
+    const float inv = (n < (uint32_t)EV_INV) ? T.inv[n] : __fdiv_rn(1.0f, (float)n);
+    return __fmul_rn(T.w[k & 31], inv);
+}
+
 // ------------------------------------------------------------------------------------------------
 // score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain per
 // (read, taxon), so 64 reads run side by side in a wavefront.  The (up to) two taxa a read really comes
@@ -1551,6 +1566,8 @@ __device__ __forceinline__ float event_score(int k, uint32_t n)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void score_fast_kernel(ScoreArgs A)
 {
     __shared__ unsigned long long cnt64[FTA][FNK][64];              // 4 x 16-bit hit counters (|T| = 1..4) per (taxon, level)
+    __shared__ EventTables evT;
+    event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t stride = gridDim.x * 64u;
@@ -1584,7 +1601,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 else if (ref & REF_PAIR) { n = 2; t0 = (ref >> 15) & 0x7FFFu; t1 = ref & 0x7FFFu; }
                 else { n = A.pool[ref]; list = A.pool + ref + 1; }
                 if (n >= (1u << 13) || c >= (1u << 16)) { fb = true; atomicAdd(&A.why[3], 1u); return; }
-                const float s = event_score((int)k, n);
+                const float s = event_score(evT, (int)k, n);
                 for (uint32_t i = 0; i < n && !fb; ++i) {
                     const uint32_t t = list ? list[i] : (i == 0 ? t0 : t1);
                     int e = -1;
@@ -1597,7 +1614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         for (int q = 0; q < nl; ++q) {
                             uint2 e2 = lg[q];
                             if ((e2.x & 0xC0FFFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
-                            const float s2 = event_score(A.kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                            const float s2 = event_score(evT, A.kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
                             for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
                             e2.x |= RK_CONSUMED;
                             lg[q] = e2;
@@ -1832,6 +1849,8 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
     __shared__ uint32_t bm[BMW], pre[BMW];
     __shared__ uint2 sRec[RCAP];
     __shared__ uint32_t cnt[RCAP], first[RCAP];
+    __shared__ EventTables evT;
+    event_tables_init(evT);
     const int lane = threadIdx.x;
     const uint32_t W = (nTaxa + 31u) >> 5;
     for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
@@ -1891,7 +1910,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                 ++seen;
                 if ((e2.x >> 30) == 1u) v = __uint_as_float(e2.y);
                 else if (!(e2.x & RK_CONSUMED)) {
-                    const float sc = event_score(kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                    const float sc = event_score(evT, kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
                     for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
                 }
             }
