@@ -24,8 +24,35 @@ REC_DTYPE = np.dtype([("kmer", "<u8"), ("tax", "<u4")], align=False)  # 12 B
 TRIE_DTYPE = np.dtype([("count", "<u8"), ("prefix", "<u4")], align=False)  # 12 B
 HALF_DTYPE = np.dtype([("low", "<u4"), ("tax", "<u2")], align=False)  # 6 B (shrink strategy 2)
 
+REC128_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8"), ("tax", "<u4")], align=False)  # 20 B (packedLargePair)
+KEY128_DTYPE = np.dtype([("lo", "<u8"), ("hi", "<u8")], align=False)  # a 128-bit k-mer: low word first
+
 K64 = 12  # letters per packed k-mer in a 64-bit index
+K128 = 25  # ... in a 128-bit index (source/utils/uint128_t.hpp, main.cpp --kH)
 TRIE_LETTERS = 6
+
+
+def is_wide(kmer: np.ndarray) -> bool:
+    return kmer.dtype == KEY128_DTYPE
+
+
+def key_shr(kmer: np.ndarray, s: int) -> np.ndarray:
+    """Low 64 bits of (kmer >> s) for u64 keys and for (lo, hi) 128-bit keys."""
+    if not is_wide(kmer):
+        return kmer >> np.uint64(s) if s < 64 else np.zeros(kmer.shape, np.uint64)
+    lo, hi = kmer["lo"], kmer["hi"]
+    if s == 0:
+        return lo.copy()
+    if s >= 64:
+        return hi >> np.uint64(s - 64) if s < 128 else np.zeros(lo.shape, np.uint64)
+    return (lo >> np.uint64(s)) | (hi << np.uint64(64 - s))
+
+
+def key_order(kmer: np.ndarray, *minor) -> np.ndarray:
+    """argsort by numeric key value (then by the minor keys, first = least significant... as np.lexsort)."""
+    if is_wide(kmer):
+        return np.lexsort(tuple(minor) + (kmer["lo"], kmer["hi"]))
+    return np.lexsort(tuple(minor) + (kmer,))
 
 
 @dataclass
@@ -40,14 +67,19 @@ class Content:
 
 @dataclass
 class Index:
-    """A 64-bit kASA index in host memory (dense taxon indices already applied)."""
-    kmer: np.ndarray        # u64[n], ascending
+    """A kASA index in host memory (dense taxon indices already applied).  64-bit index: u64 keys of 12 letters;
+    128-bit index: KEY128_DTYPE keys of 25 letters."""
+    kmer: np.ndarray        # u64[n] or KEY128_DTYPE[n], ascending
     taxid: np.ndarray       # u32[n], original tax IDs from the file
     tax: np.ndarray         # u32[n], dense taxon index via the content file
     trie_prefix: np.ndarray  # u32[m], ascending 30-bit prefixes
     trie_count: np.ndarray   # u64[m]
     content: Content
-    freq: np.ndarray        # u64[nTaxa, K64]: freq[t, j] = k-mers of taxon t at k = K64 - j
+    freq: np.ndarray        # u64[nTaxa, K]: freq[t, j] = k-mers of taxon t at k = K - j
+
+    @property
+    def K(self) -> int:
+        return K128 if is_wide(self.kmer) else K64
 
     @property
     def n(self) -> int:
@@ -66,7 +98,7 @@ class Index:
 
     def freq_at(self, k: int) -> np.ndarray:
         """k-mer count of every taxon at length k (what Compare.hpp:166-179 loads per level)."""
-        return self.freq[:, K64 - k]
+        return self.freq[:, self.K - k]
 
 
 def read_info(prefix: str):
@@ -80,7 +112,12 @@ def read_info(prefix: str):
 def read_records(prefix: str):
     n, kind = read_info(prefix)
     if kind == 128:
-        raise NotImplementedError("128-bit (k<=25) index: not on this round's path, see DESIGN.md")
+        rec = np.fromfile(prefix, dtype=REC128_DTYPE, count=n)
+        if rec.shape[0] != n:
+            raise RuntimeError("The index file is shorter than _info.txt says")
+        km = np.zeros(n, dtype=KEY128_DTYPE)
+        km["lo"], km["hi"] = rec["lo"], rec["hi"]
+        return km, np.ascontiguousarray(rec["tax"])
     if kind == 3:
         return None, None  # halved records: rebuilt by load_index with the trie and the content file
     rec = np.fromfile(prefix, dtype=REC_DTYPE, count=n)
@@ -118,8 +155,8 @@ def read_content(path: str) -> Content:
     return Content(names, np.asarray(taxids, dtype=np.uint32))
 
 
-def read_freq(prefix: str, n_taxa: int) -> np.ndarray:
-    out = np.zeros((n_taxa, K64), dtype=np.uint64)
+def read_freq(prefix: str, n_taxa: int, K: int = K64) -> np.ndarray:
+    out = np.zeros((n_taxa, K), dtype=np.uint64)
     row = 0
     with open(prefix + "_f.txt") as f:
         for line in f:
@@ -129,7 +166,7 @@ def read_freq(prefix: str, n_taxa: int) -> np.ndarray:
             cols = line.split("\t")
             vals = [int(x) for x in cols[1:]]
             if row < n_taxa:
-                out[row, :len(vals)] = vals[:K64]
+                out[row, :min(len(vals), K)] = vals[:K]
             row += 1
     return out
 
@@ -161,7 +198,7 @@ def load_index(prefix: str, content_path: str) -> Index:
         pre = np.repeat(tp.astype(np.uint64), tc.astype(np.int64))
         kmer = (pre << np.uint64(30)) | (half["low"].astype(np.uint64) & np.uint64(0x3FFFFFFF))
         taxid = content.taxids[half["tax"].astype(np.int64)]
-    freq = read_freq(prefix, content.n_taxa)
+    freq = read_freq(prefix, content.n_taxa, K128 if is_wide(kmer) else K64)
     return Index(kmer, taxid, dense_tax(taxid, content), tp, tc, content, freq)
 
 
@@ -171,7 +208,8 @@ def load_index(prefix: str, content_path: str) -> Index:
 
 def trie_from_kmers(kmer: np.ndarray):
     """prefix30 -> count table of a sorted k-mer array (what Trie.hpp:365-394 writes)."""
-    pre = (kmer >> np.uint64(5 * (K64 - TRIE_LETTERS))).astype(np.uint32)
+    K = K128 if is_wide(kmer) else K64
+    pre = key_shr(kmer, 5 * (K - TRIE_LETTERS)).astype(np.uint32)
     if pre.shape[0] == 0:
         return pre, np.zeros(0, dtype=np.uint64)
     change = np.flatnonzero(np.concatenate(([True], pre[1:] != pre[:-1])))
@@ -181,16 +219,17 @@ def trie_from_kmers(kmer: np.ndarray):
 
 def freq_from_index(kmer: np.ndarray, tax: np.ndarray, n_taxa: int) -> np.ndarray:
     """kASA.hpp:517-526: for j = 0..K-1 count entries whose letter (from the right) j is not '^'."""
-    out = np.zeros((n_taxa, K64), dtype=np.uint64)
-    for j in range(K64):
-        ok = ((kmer >> np.uint64(5 * j)) & np.uint64(31)) != np.uint64(30)
+    K = K128 if is_wide(kmer) else K64
+    out = np.zeros((n_taxa, K), dtype=np.uint64)
+    for j in range(K):
+        ok = (key_shr(kmer, 5 * j) & np.uint64(31)) != np.uint64(30)
         out[:, j] = np.bincount(tax[ok], minlength=n_taxa).astype(np.uint64)
     return out
 
 
 def make_index(kmer: np.ndarray, taxid: np.ndarray, content: Content) -> Index:
     """Sort + unique (kmer, taxid) pairs into an Index (Build.hpp:305-356's net effect)."""
-    order = np.lexsort((taxid, kmer))
+    order = key_order(kmer, taxid)
     kmer, taxid = kmer[order], taxid[order]
     if kmer.shape[0]:
         keep = np.concatenate(([True], (kmer[1:] != kmer[:-1]) | (taxid[1:] != taxid[:-1])))
@@ -202,11 +241,15 @@ def make_index(kmer: np.ndarray, taxid: np.ndarray, content: Content) -> Index:
 
 
 def write_index(ix: Index, prefix: str, content_path: str) -> None:
-    rec = np.zeros(ix.n, dtype=REC_DTYPE)
-    rec["kmer"], rec["tax"] = ix.kmer, ix.taxid
+    if is_wide(ix.kmer):
+        rec = np.zeros(ix.n, dtype=REC128_DTYPE)
+        rec["lo"], rec["hi"], rec["tax"] = ix.kmer["lo"], ix.kmer["hi"], ix.taxid
+    else:
+        rec = np.zeros(ix.n, dtype=REC_DTYPE)
+        rec["kmer"], rec["tax"] = ix.kmer, ix.taxid
     rec.tofile(prefix)
     with open(prefix + "_info.txt", "w") as f:
-        f.write(str(ix.n))
+        f.write(str(ix.n) + ("\n128" if is_wide(ix.kmer) else ""))
     t = np.zeros(ix.trie_prefix.shape[0], dtype=TRIE_DTYPE)
     t["count"], t["prefix"] = ix.trie_count, ix.trie_prefix
     t.tofile(prefix + "_trie")

@@ -95,20 +95,20 @@ static inline uint8_t letter_at(const uint8_t *s, int64_t pos, const uint8_t *lu
 /* Read.hpp:84-220: one k-mer per window start i = 0..count-1, window = K codons from i (3 frames
  * interleaved by the rolling update; emission order is the start position). */
 static void encode_prepared(const uint8_t *s, int64_t L, const ko_params *p, const uint8_t *lut,
-                            uint64_t *out, int64_t count)
+                            ko_key *out, int64_t count)
 {
     const int K = p->K;
     if (p->protein) { /* Read.hpp:60-81 + kASA.hpp:333-379: the letters are the input, code = char & 31 */
         for (int64_t i = 0; i < count; ++i) {
-            uint64_t v = 0;
-            for (int j = 0; j < K; ++j) v = (v << 5) | (uint64_t)(s[i + j] & 31);
+            ko_key v = 0;
+            for (int j = 0; j < K; ++j) v = (v << 5) | (ko_key)(s[i + j] & 31);
             out[i] = v;
         }
         return;
     }
     if (p->frames == 1) { /* Read.hpp:223-261: translate frame 0 once, slide over letters */
         for (int64_t i = 0; i < count; ++i) {
-            uint64_t v = 0;
+            ko_key v = 0;
             for (int j = 0; j < K; ++j) v = (v << 5) | letter_at(s, 3 * (i + j), lut);
             out[i] = v;
         }
@@ -116,14 +116,14 @@ static void encode_prepared(const uint8_t *s, int64_t L, const ko_params *p, con
     }
     (void)L;
     for (int64_t i = 0; i < count; ++i) {
-        uint64_t v = 0;
+        ko_key v = 0;
         for (int j = 0; j < K; ++j) v = (v << 5) | letter_at(s, i + 3 * j, lut);
         out[i] = v;
     }
 }
 
 int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads, const ko_params *p,
-                        const uint8_t lut[366], uint64_t *outKmer, uint32_t *outRead)
+                        const uint8_t lut[366], ko_key *outKmer, uint32_t *outRead)
 {
     int64_t total = 0;
     int64_t cap = 0;
@@ -177,45 +177,45 @@ int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads
  * A5. Sort by k-mer (Compare.hpp:1077; unstable there, stable here -- tie order never reaches the
  * output, DESIGN.md "Oracle") and prefix ranges (Compare.hpp:1098-1117, Trie.hpp:398-462,494-520).
  * ---------------------------------------------------------------------------------------------- */
-void ko_sort_queries(uint64_t *kmer, uint32_t *read, uint64_t n)
+void ko_sort_queries(ko_key *kmer, uint32_t *read, uint64_t n)
 {
     if (n < 2) return;
-    uint64_t *k2 = (uint64_t *)malloc(n * sizeof(uint64_t));
+    ko_key *k2 = (ko_key *)malloc(n * sizeof(ko_key));
     uint32_t *r2 = (uint32_t *)malloc(n * sizeof(uint32_t));
-    uint64_t *ka = kmer, *kb = k2;
+    ko_key *ka = kmer, *kb = k2;
     uint32_t *ra = read, *rb = r2;
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < (int)sizeof(ko_key); ++pass) {
         const int sh = 8 * pass;
         uint64_t hist[257];
         memset(hist, 0, sizeof(hist));
-        for (uint64_t i = 0; i < n; ++i) ++hist[((ka[i] >> sh) & 255) + 1];
+        for (uint64_t i = 0; i < n; ++i) ++hist[(uint32_t)((ka[i] >> sh) & 255) + 1];
         int trivial = 0;
         for (int d = 0; d < 256; ++d)
             if (hist[d + 1] == n) trivial = 1;
         if (trivial) continue;
         for (int d = 0; d < 256; ++d) hist[d + 1] += hist[d];
         for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t dst = hist[(ka[i] >> sh) & 255]++;
+            const uint64_t dst = hist[(uint32_t)((ka[i] >> sh) & 255)]++;
             kb[dst] = ka[i];
             rb[dst] = ra[i];
         }
-        uint64_t *tk = ka; ka = kb; kb = tk;
+        ko_key *tk = ka; ka = kb; kb = tk;
         uint32_t *tr = ra; ra = rb; rb = tr;
     }
     if (ka != kmer) {
-        memcpy(kmer, ka, n * sizeof(uint64_t));
+        memcpy(kmer, ka, n * sizeof(ko_key));
         memcpy(read, ra, n * sizeof(uint32_t));
     }
     free(k2);
     free(r2);
 }
 
-void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uint64_t n,
+void ko_ranges(const ko_index *ix, const ko_params *p, const ko_key *kmer, uint64_t n,
                uint64_t *rangeStart, uint32_t *rangeLenM1)
 {
     const int sh = 5 * (p->K - 6);
     for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t pre = kmer[i] >> sh;
+        const uint64_t pre = (uint64_t)(kmer[i] >> sh);   /* Compare.hpp:1102-1107: >> 30, or >> 95 for 128-bit keys */
         uint64_t lo = 0, hi = ix->nTrie;
         while (lo < hi) {
             const uint64_t mid = (lo + hi) >> 1;
@@ -236,7 +236,7 @@ void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uin
  * open group and its taxon set (BitArray.hpp:98-117: bitset + insertion-ordered list).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
-    uint64_t mem;     /* vMemoryOfSeenkMers */
+    ko_key mem;       /* vMemoryOfSeenkMers */
     uint64_t hits;    /* vPositions */
     uint64_t *reads;  /* vReadIDs */
     uint64_t readsCap;
@@ -362,7 +362,7 @@ static void flush_level(cmp_ctx *c, int lvIdx)
 static inline int shift_of(const ko_params *p, int lvIdx) { return 5 * (p->K - (p->kHigh - lvIdx)); }
 
 /* first position in [lo, hiIncl+1) whose (kmer >> sh) is >= val (std::lower_bound, Compare.hpp:824,980) */
-static uint64_t lower_bound_shifted(const uint64_t *km, uint64_t lo, uint64_t hiExcl, int sh, uint64_t val)
+static uint64_t lower_bound_shifted(const ko_key *km, uint64_t lo, uint64_t hiExcl, int sh, ko_key val)
 {
     while (lo < hiExcl) {
         const uint64_t mid = lo + ((hiExcl - lo) >> 1);
@@ -375,7 +375,7 @@ static uint64_t lower_bound_shifted(const uint64_t *km, uint64_t lo, uint64_t hi
  * A6. Compare.hpp:678-1069, statement by statement in the same order (64-bit keys, no spaced masks,
  * no post-processing).  Level index lv: 0 = kHigh ... nK-1 = kLow (kASA.hpp:299-302).
  * ---------------------------------------------------------------------------------------------- */
-int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                           const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
                           uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
                           uint64_t *countTotal, float *M)
@@ -385,7 +385,12 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
     ctx_init(&c, p, ix, countAll, countUnique, countTotal, M);
     const int nK = c.nK;
     const int low = nK - 1;
-    const uint64_t *km = ix->kmer;
+    const ko_key *km = ix->kmer;
+    /* the reference's `compare` functor (Compare.hpp:700-706) is declared with uint64_t parameters: with 128-bit keys
+     * it sees the low words only.  EQ/CMP3 are that functor; everything else in the routine is full width. */
+    const int q64 = (sizeof(ko_key) > 8) && p->cmp64Quirk;
+#define KO_EQ(a, b) (q64 ? ((uint64_t)(a) == (uint64_t)(b)) : ((a) == (b)))
+#define KO_LT(a, b) (q64 ? ((uint64_t)(a) < (uint64_t)(b)) : ((a) < (b)))
     const uint32_t *tx = ix->tax;
 
     uint64_t pos = 0;
@@ -402,7 +407,7 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
         for (int i = 0; i < nK; ++i) {                 /* :769-773 */
             c.lv[i].hits = 0; c.lv[i].mem = 0; lv_clear_taxa(&c.lv[i]);
         }
-        uint64_t seenKmer = 0;                         /* :774 */
+        ko_key seenKmer = 0;                           /* :774 */
         const uint64_t rb = rs, re = rs + rl;          /* :777-778, re is the last entry (inclusive) */
         uint64_t it = rb;
         int determine = 1;
@@ -410,9 +415,9 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
         for (; qi < pos; ++qi) {                       /* :785 */
             if (qRS[qi] == KO_RANGE_NONE) continue;
             int sh = shift_of(p, low);
-            const uint64_t q = qKmer[qi];
+            const ko_key q = qKmer[qi];
             const uint32_t rid = qRead[qi];
-            uint64_t qs = q >> sh;
+            ko_key qs = q >> sh;
             int inputIterated = 1;
 
             if (seenKmer != q && (km[it] >> sh) != qs && determine) { /* :803-829 */
@@ -432,33 +437,33 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
 
             if ((qs & 31) == 30) continue;             /* :836-838 */
 
-            if (seenKmer == q || it == re + 1) {       /* :841-853 duplicates / index exhausted */
+            if (KO_EQ(seenKmer, q) || it == re + 1) {  /* :841-853 duplicates / index exhausted */
                 for (int l = low; l >= 0; --l)
-                    if ((q >> shift_of(p, l)) == c.lv[l].mem) lv_push(&c, &c.lv[l], rid);
+                    if (KO_EQ(q >> shift_of(p, l), c.lv[l].mem)) lv_push(&c, &c.lv[l], rid);
                 continue;
             }
             seenKmer = q;                              /* :855 */
 
             int breakOut = 0;
             while (it != re + 1 && !breakOut) {        /* :861 */
-                const uint64_t e = km[it];
+                const ko_key e = km[it];
                 int l = low;
                 for (; l >= 0; --l) {                  /* :865 */
                     sh = shift_of(p, l);
                     qs = q >> sh;
-                    const uint64_t es = e >> sh;
-                    if (qs < es) {                     /* :875-893 input smaller */
+                    const ko_key es = e >> sh;
+                    if (KO_LT(qs, es)) {               /* :874-893 input smaller */
                         if (inputIterated)
                             for (int u = l; u >= 0; --u) {
-                                if ((q >> shift_of(p, u)) == c.lv[u].mem) lv_push(&c, &c.lv[u], rid);
+                                if (KO_EQ(q >> shift_of(p, u), c.lv[u].mem)) lv_push(&c, &c.lv[u], rid);
                                 else break;
                             }
                         breakOut = 1;
                         break;
-                    } else if (qs == es) {             /* :895-956 */
+                    } else if (!KO_LT(es, qs)) {       /* :895-956 equal (compareTwoKmers: neither is smaller) */
                         if ((qs & 31) == 30) { breakOut = 1; break; }
                         level_state *s = &c.lv[l];
-                        if (qs == s->mem) {
+                        if (KO_EQ(qs, s->mem)) {
                             lv_mark(s, tx[it]);
                             if (inputIterated) lv_push(&c, s, rid);
                         } else {
@@ -472,11 +477,11 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
                     } else {                           /* :957-993 index smaller: walk / jump */
                         uint64_t t = 1;
                         while (it + t != re + 1) {
-                            const uint64_t nx = km[it + t];
-                            if (qs > (nx >> sh)) {
+                            const ko_key nx = km[it + t];
+                            if (qs > (nx >> sh)) {                  /* :963, full width */
                                 int u = low;
                                 for (; u >= 0; --u) {
-                                    if (c.lv[u].mem == (nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
+                                    if (KO_EQ(c.lv[u].mem, nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
                                     else break;
                                 }
                                 if (u < low) {
@@ -500,16 +505,18 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
 
         uint64_t t = 0;                                /* :1007-1028 rest of the range */
         while (it + t != re + 1) {
-            const uint64_t nx = km[it + t];
+            const ko_key nx = km[it + t];
             int u = low;
             for (; u >= 0; --u) {
-                if (c.lv[u].mem == (nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
+                if (KO_EQ(c.lv[u].mem, nx >> shift_of(p, u))) lv_mark(&c.lv[u], tx[it + t]);
                 else break;
             }
             if (u < low) ++t; else break;
         }
         for (int l = low; l >= 0; --l) flush_level(&c, l); /* :1032-1041 */
     }
+#undef KO_EQ
+#undef KO_LT
     ctx_free(&c);
     return 0;
 }
@@ -521,7 +528,7 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t
  * with all distinct taxa of the index entries carrying P (index order).  This is what the device
  * kernels compute; tests require it to equal ko_compare_sequential bit for bit.
  * ---------------------------------------------------------------------------------------------- */
-int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                            const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
                            uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
                            uint64_t *countTotal, float *M)
@@ -531,7 +538,7 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_
     ctx_init(&c, p, ix, countAll, countUnique, countTotal, M);
     const int nK = c.nK;
     const int low = nK - 1;
-    const uint64_t *km = ix->kmer;
+    const ko_key *km = ix->kmer;
     uint64_t pos = 0;
     while (pos < nQ) {
         const uint64_t rs = qRS[pos];
@@ -542,11 +549,11 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_
         for (int i = 0; i < nK; ++i) { c.lv[i].hits = 0; c.lv[i].mem = 0; lv_clear_taxa(&c.lv[i]); }
         for (; qi < pos; ++qi) {
             if (qRS[qi] == KO_RANGE_NONE) continue;
-            const uint64_t q = qKmer[qi];
+            const ko_key q = qKmer[qi];
             uint64_t a = lo, b = hi;
             for (int l = low; l >= 0; --l) {
                 const int sh = shift_of(p, l);
-                const uint64_t P = q >> sh;
+                const ko_key P = q >> sh;
                 if ((P & 31) == 30) break;
                 a = lower_bound_shifted(km, a, b, sh, P);
                 b = lower_bound_shifted(km, a, b, sh, P + 1);
@@ -570,7 +577,7 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_
     return 0;
 }
 
-uint64_t ko_unique_queries(uint64_t *kmer, uint32_t *read, uint64_t n)
+uint64_t ko_unique_queries(ko_key *kmer, uint32_t *read, uint64_t n)
 {
     if (n == 0) return 0;
     uint64_t w = 1;

@@ -20,8 +20,18 @@ extern "C" {
 
 #define KO_RANGE_NONE UINT64_MAX
 
+/* One source, two libraries (oracle/Makefile): libkasa_oracle.so for the 64-bit index (K = 12 letters,
+ * uint64_t keys) and libkasa_oracle128.so, built with -DKO_WIDE, for the 128-bit index (K = 25 letters,
+ * source/utils/uint128_t.hpp; a key is 16 bytes little endian: low word first, as packedLargePair stores
+ * it, packedPairs.hpp:132-155). */
+#ifdef KO_WIDE
+typedef unsigned __int128 ko_key;
+#else
+typedef uint64_t ko_key;
+#endif
+
 typedef struct {
-    int32_t K;        /* letters per packed k-mer of the index: 12 (64-bit index) */
+    int32_t K;        /* letters per packed k-mer of the index: 12 (64-bit index) or 25 (128-bit, KO_WIDE) */
     int32_t kHigh;    /* largest k evaluated  (-k <kHigh> <kLow>) */
     int32_t kLow;     /* smallest k evaluated */
     int32_t frames;   /* 3 (default) or 6 (--six); 1 (--one) */
@@ -29,10 +39,13 @@ typedef struct {
                          -march=native binary; 0: scoreMatchNonAVX for every n (the parity target) */
     int32_t coverage; /* 1: also count countTotal (--coverage) */
     int32_t protein;  /* 1: the reads are amino-acid sequences (kASA.hpp:155-183, Read.hpp:60-81) */
+    int32_t cmp64Quirk; /* KO_WIDE, ko_compare_sequential only: 1 = the comparator of compareWithDatabase sees just
+                         the low 64 bits of its operands, as in the stock reference (a std::function declared with
+                         uint64_t parameters, Compare.hpp:700-706); 0 = full width */
 } ko_params;
 
 typedef struct {
-    const uint64_t *kmer;     /* sorted by (kmer, taxid) */
+    const ko_key *kmer;       /* sorted by (kmer, taxid) */
     const uint32_t *tax;      /* DENSE taxon index (1..nTaxa-1), i.e. after the content-file map */
     uint64_t n;
     const uint32_t *triePrefix; /* _trie entries: 30-bit prefixes, ascending */
@@ -53,32 +66,32 @@ int64_t ko_kmer_count(int64_t paddedLen, const ko_params *p);
  * bases: concatenated raw read bytes, off[nReads+1].  Returns the number of k-mers; when outKmer is
  * NULL only counts.  Emission order = read order, forward strand then reverse complement. */
 int64_t ko_encode_batch(const uint8_t *bases, const int64_t *off, int64_t nReads, const ko_params *p,
-                        const uint8_t lut[366], uint64_t *outKmer, uint32_t *outRead);
+                        const uint8_t lut[366], ko_key *outKmer, uint32_t *outRead);
 
 /* Compare.hpp:1077 -- sort by k-mer only (stable LSD radix here; ties do not matter). */
-void ko_sort_queries(uint64_t *kmer, uint32_t *read, uint64_t n);
+void ko_sort_queries(ko_key *kmer, uint32_t *read, uint64_t n);
 
 /* Compare.hpp:3167-3178 (-e): drop a record equal in (k-mer, read id) to its predecessor.  The reference applies
  * std::unique to the output of an unstable sort by k-mer, so which duplicates end up adjacent is an accident of its
  * sort; after the stable sort here all of them are.  Identical whenever no other read shares the duplicated k-mer.
  * Returns the new count. */
-uint64_t ko_unique_queries(uint64_t *kmer, uint32_t *read, uint64_t n);
+uint64_t ko_unique_queries(ko_key *kmer, uint32_t *read, uint64_t n);
 
 /* Compare.hpp:1098-1117 + Trie.hpp:494-520 -- prefix (kmer>>30) -> (start, len-1) or KO_RANGE_NONE. */
-void ko_ranges(const ko_index *ix, const ko_params *p, const uint64_t *kmer, uint64_t n,
+void ko_ranges(const ko_index *ix, const ko_params *p, const ko_key *kmer, uint64_t n,
                uint64_t *rangeStart, uint32_t *rangeLenM1);
 
 /* Compare.hpp:678-1069 -- faithful sequential merge of the sorted queries against the index.
  * Tables are [lv * nTaxa + t] with lv = 0 for kHigh ... nK-1 for kLow (Compare.hpp:922).
  * M is the dense nReads x nTaxa float matrix (Utilities.hpp:592-636) or NULL (profile only). */
-int ko_compare_sequential(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                           const uint32_t *qRead, const uint64_t *qRangeStart,
                           const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
                           double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);
 
 /* SURVEY.md section 0.1 -- the closed form the device implements (group by (range, k, prefix)),
  * evaluated with the same flush order.  Must equal ko_compare_sequential bit for bit. */
-int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const uint64_t *qKmer,
+int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                            const uint32_t *qRead, const uint64_t *qRangeStart,
                            const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
                            double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);

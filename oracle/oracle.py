@@ -13,13 +13,12 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
 RANGE_NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 class Params(C.Structure):
     _fields_ = [("K", C.c_int32), ("kHigh", C.c_int32), ("kLow", C.c_int32), ("frames", C.c_int32),
-                ("avxQuirk", C.c_int32), ("coverage", C.c_int32), ("protein", C.c_int32)]
+                ("avxQuirk", C.c_int32), ("coverage", C.c_int32), ("protein", C.c_int32), ("cmp64Quirk", C.c_int32)]
 
 
 class _Index(C.Structure):
@@ -28,18 +27,30 @@ class _Index(C.Structure):
                 ("nTrie", C.c_uint64), ("nTaxa", C.c_uint32)]
 
 
-def build(force: bool = False) -> str:
+KEY128 = np.dtype([("lo", "<u8"), ("hi", "<u8")], align=False)   # unsigned __int128, little endian
+
+
+def build(force: bool = False, wide: bool = False) -> str:
     so = os.path.join(_HERE, "libkasa_oracle.so")
+    so128 = os.path.join(_HERE, "libkasa_oracle128.so")
     src = os.path.join(_HERE, "kasa_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    if force or any(not os.path.exists(x) or os.path.getmtime(x) < os.path.getmtime(src) for x in (so, so128)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
-    return so
+    return so128 if wide else so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        _LIB = C.CDLL(build())
+_LIBS = {}
+
+
+def key_dtype(K: int):
+    return KEY128 if K > 12 else np.dtype(np.uint64)
+
+
+def lib(K: int = 12):
+    """The 64-bit-key library (K = 12 letters) or the 128-bit-key one (K = 25), same source."""
+    wide = K > 12
+    if wide not in _LIBS:
+        _LIB = C.CDLL(build(wide=wide))
         _LIB.ko_encode_batch.restype = C.c_int64
         _LIB.ko_unique_queries.restype = C.c_uint64
         _LIB.ko_padded_len.restype = C.c_int64
@@ -53,15 +64,17 @@ def lib():
         _LIB.ko_error_score.argtypes = [C.c_float, C.c_float]
         _LIB.ko_padded_len.argtypes = [C.c_int64, C.POINTER(Params)]
         _LIB.ko_kmer_count.argtypes = [C.c_int64, C.POINTER(Params)]
-    return _LIB
+        _LIBS[wide] = _LIB
+    return _LIBS[wide]
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def params(k_high=12, k_low=7, frames=3, avx_quirk=False, coverage=False, K=12, protein=False) -> Params:
-    return Params(K, k_high, k_low, frames, int(avx_quirk), int(coverage), int(protein))
+def params(k_high=12, k_low=7, frames=3, avx_quirk=False, coverage=False, K=12, protein=False,
+           cmp64_quirk=False) -> Params:
+    return Params(K, k_high, k_low, frames, int(avx_quirk), int(coverage), int(protein), int(cmp64_quirk))
 
 
 def codon_table() -> np.ndarray:
@@ -72,22 +85,26 @@ def codon_table() -> np.ndarray:
 
 def encode(bases: np.ndarray, offsets: np.ndarray, p: Params, lut=None):
     """-> (kmer u64[nQ], read u32[nQ]) in emission order (Read.hpp:84-293)."""
-    L = lib()
+    L = lib(p.K)
     lut = codon_table() if lut is None else lut
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n = offsets.shape[0] - 1
     total = L.ko_encode_batch(_p(bases), _p(offsets), C.c_int64(n), C.byref(p), _p(lut), None, None)
-    km = np.zeros(total, dtype=np.uint64)
+    km = np.zeros(total, dtype=key_dtype(p.K))
     rd = np.zeros(total, dtype=np.uint32)
     got = L.ko_encode_batch(_p(bases), _p(offsets), C.c_int64(n), C.byref(p), _p(lut), _p(km), _p(rd))
     assert got == total
     return km, rd
 
 
+def _K_of(km: np.ndarray) -> int:
+    return 25 if km.dtype == KEY128 else 12
+
+
 def sort_queries(km: np.ndarray, rd: np.ndarray):
     km, rd = km.copy(), rd.copy()
-    lib().ko_sort_queries(_p(km), _p(rd), C.c_uint64(km.shape[0]))
+    lib(_K_of(km)).ko_sort_queries(_p(km), _p(rd), C.c_uint64(km.shape[0]))
     return km, rd
 
 
@@ -95,7 +112,8 @@ class IndexView:
     """Keeps the numpy arrays alive next to the C struct."""
 
     def __init__(self, ix):
-        self.kmer = np.ascontiguousarray(ix.kmer, dtype=np.uint64)
+        self.kmer = np.ascontiguousarray(ix.kmer)   # u64 or KEY128 (same layout as formats.KEY128_DTYPE)
+        self.K = 25 if self.kmer.dtype.itemsize == 16 else 12
         self.tax = np.ascontiguousarray(ix.tax, dtype=np.uint32)
         self.tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32)
         self.ts = np.ascontiguousarray(ix.trie_start, dtype=np.uint64)
@@ -108,7 +126,7 @@ class IndexView:
 def ranges(iv: IndexView, p: Params, km: np.ndarray):
     rs = np.zeros(km.shape[0], dtype=np.uint64)
     rl = np.zeros(km.shape[0], dtype=np.uint32)
-    lib().ko_ranges(C.byref(iv.c), C.byref(p), _p(km), C.c_uint64(km.shape[0]), _p(rs), _p(rl))
+    lib(p.K).ko_ranges(C.byref(iv.c), C.byref(p), _p(km), C.c_uint64(km.shape[0]), _p(rs), _p(rl))
     return rs, rl
 
 
@@ -127,7 +145,7 @@ def compare(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, want_reads=T
     cu = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
     ct = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
     M = np.zeros((n_reads, iv.n_taxa), dtype=np.float32) if want_reads else None
-    fn = lib().ko_compare_closed_form if closed_form else lib().ko_compare_sequential
+    fn = lib(p.K).ko_compare_closed_form if closed_form else lib(p.K).ko_compare_sequential
     rc = fn(C.byref(p), C.byref(iv.c), _p(km), _p(rd), _p(rs), _p(rl), C.c_uint64(km.shape[0]),
             C.c_uint64(n_reads), _p(ca), _p(cu), _p(ct), _p(M) if want_reads else None)
     assert rc == 0
@@ -137,7 +155,7 @@ def compare(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, want_reads=T
 def unique_queries(km: np.ndarray, rd: np.ndarray):
     """-e (Compare.hpp:3167-3178) on sorted records."""
     km, rd = km.copy(), rd.copy()
-    n = int(lib().ko_unique_queries(_p(km), _p(rd), C.c_uint64(km.shape[0])))
+    n = int(lib(_K_of(km)).ko_unique_queries(_p(km), _p(rd), C.c_uint64(km.shape[0])))
     return km[:n], rd[:n]
 
 
@@ -156,11 +174,11 @@ def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=F
 
 
 def best_score(length: int, p: Params) -> np.float32:
-    return np.float32(lib().ko_best_score(C.c_uint64(int(length)), C.byref(p)))
+    return np.float32(lib(p.K).ko_best_score(C.c_uint64(int(length)), C.byref(p)))
 
 
 def relative_score(score, freq: int, length: int, p: Params) -> float:
-    return float(lib().ko_relative_score(C.c_float(float(score)), C.c_uint64(int(freq)),
+    return float(lib(p.K).ko_relative_score(C.c_float(float(score)), C.c_uint64(int(freq)),
                                          C.c_uint64(int(length)), C.byref(p)))
 
 

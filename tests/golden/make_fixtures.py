@@ -59,7 +59,7 @@ def write_db(d, genomes):
 def trim_index(d):
     """The reference zero-pads index and trie files to 2,101,248-byte blocks; keep the records only."""
     jobs = []
-    for stem, rec in (("idx", 12), ("idx_half", 6)):
+    for stem, rec in (("idx", 12), ("idx_half", 6), ("idx25", 20)):
         if not os.path.exists(os.path.join(d, stem + "_info.txt")):
             continue
         n = int(open(os.path.join(d, stem + "_info.txt")).read().split()[0])
@@ -181,6 +181,13 @@ def case_pairs(out):
     # the "halved" index of shrink strategy 2 (6-byte records) and a run on it
     run(["shrink", "-c", "content.txt", "-d", "idx", "-o", "idx_half", "-s", "2", "-m", "4", "-n", "1"], out)
     run(base + ["-d", "idx_half", "-i", "reads.fastq", "--jsonl", "-b", "100", "-q", "out_half.jsonl", "-p", "prof_half.csv"], out)
+    # a 128-bit index (k up to 25) of the same database and runs on it
+    run(["build", "-c", "content.txt", "-d", "idx25", "-i", "db.fasta", "-m", "4", "-n", "1", "--kH", "25"], out)
+    wide = {"w25_7": ["-k", "25", "7"], "w12_7": ["-k", "12", "7"], "w25_20": ["-k", "25", "20"], "w16_9": ["-k", "16", "9"],
+            "w25_7_six": ["-k", "25", "7", "--six"]}
+    for name, extra in wide.items():
+        run(["identify", "-c", "content.txt", "-d", "idx25", "-m", "4", "-n", "1", "--jsonl", "-b", "100", "-i", "reads.fastq"]
+            + extra + ["-q", "out_" + name + ".jsonl", "-p", "prof_" + name + ".csv"], out)
     # the reference's own example input (2 reads; N- and '-'-containing, multi-line FASTA)
     shutil.copy(os.path.join(REF, "example/work/input/exampleInput.fasta"), os.path.join(out, "exampleInput.fasta"))
     run(base + ["-i", "exampleInput.fasta", "--jsonl", "-b", "100", "-q", "out_exampleInput.jsonl",

@@ -32,7 +32,7 @@ def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low
     for r in range(batch.n):
         t, s = rows[r]
         rk = report.rank_read(t, s, int(batch.lengths[r]), freq, k_high, k_low, frames, threshold, beasts,
-                              protein=protein)
+                              K=ix.K, protein=protein)
         out.append(w.read(r, batch.names[r], int(batch.lengths[r]), rk))
     out.append(w.footer())
     prof = report.profile_csv(count_all, count_unique, ix.content.names, ix.content.taxids, k_high, k_low,
@@ -41,7 +41,7 @@ def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low
 
 
 def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, closed_form=False, unique=False,
-                    protein=False):
-    p = oracle.params(k_high, k_low, frames, avx_quirk, protein=protein)
+                    protein=False, cmp64_quirk=False):
+    p = oracle.params(k_high, k_low, frames, avx_quirk, K=ix.K, protein=protein, cmp64_quirk=cmp64_quirk)
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique)
     return res, nq

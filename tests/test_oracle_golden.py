@@ -70,3 +70,30 @@ def test_clones_avx_build(closed_form):
     # and the scalar branch really differs on this data (otherwise the case pins nothing)
     res2, _ = helpers.oracle_identify(ix, batch, avx_quirk=False)
     assert (res2.M != res.M).any()
+
+
+WIDE = [  # 128-bit index (build --kH 25): (output stem, kHigh, kLow, frames)
+    ("w25_7", 25, 7, 3), ("w12_7", 12, 7, 3), ("w25_20", 25, 20, 3), ("w16_9", 16, 9, 3), ("w25_7_six", 25, 7, 6),
+]
+
+
+@pytest.mark.parametrize("case", WIDE, ids=[c[0] for c in WIDE])
+def test_wide_index_stock_binary_and_parity_target(case):
+    """128-bit keys (K = 25).  Inside compareWithDatabase the stock reference compares through a functor declared
+    with uint64_t parameters (Compare.hpp:700-706), i.e. on the low words only.  The sequential restatement with
+    that quirk switched on reproduces the shipped binary byte for byte -- which pins the 128-bit oracle; with full
+    width comparisons it equals the closed form, the parity target of the device, and
+    differs from the stock files."""
+    stem, kh, kl, frames = case
+    d, ix = helpers.load_case("pairs", "idx25")
+    assert ix.K == 25
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    texts = {}
+    for name, cf, quirk in (("stock", False, True), ("sequential", False, False), ("closed", True, False)):
+        res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=cf, cmp64_quirk=quirk)
+        texts[name] = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
+                                     nq, "jsonl", kh, kl, frames, 0.0, 100)
+    assert texts["stock"][0] == _read(os.path.join(d, "out_" + stem + ".jsonl"))
+    assert texts["stock"][1] == _read(os.path.join(d, "prof_" + stem + ".csv"))
+    assert texts["sequential"] == texts["closed"]
+    assert texts["closed"][0] != texts["stock"][0]
