@@ -61,7 +61,10 @@ int kasa_device_count(int *count);
  * records   : nRecords packed {u64 kmer, u32 taxid} entries of 12 bytes, sorted by (kmer, taxid) --
  *             the index file as it is on disk (may be an mmap of it); or, with recordBytes = 6, the
  *             "halved" index of shrink strategy 2, {u32 low 30 bits, u16 dense taxon index}
- *             (source/utils/packedPairs.hpp:100-105), which needs the trie arrays.
+ *             (source/utils/packedPairs.hpp:100-105), which needs the trie arrays; or, with
+ *             recordBytes = 20, the 128-bit index of `build --kH 25`: {u64 low, u64 high, u32 taxid}
+ *             (packedLargePair, packedPairs.hpp:132-155; _info.txt carries the marker 128), 25 letters
+ *             per k-mer, levels up to k = 25.
  * triePrefix/trieCount : the `_trie` file (source/modes/Trie.hpp:365-394): 30-bit prefixes ascending
  *             and their entry counts; may be NULL/0 -- the device derives its own two-level prefix
  *             table from the records and, when given, checks it against this one.
@@ -77,7 +80,7 @@ uint64_t kasa_index_device_bytes(const kasa_index *ix);
 
 /* ---- context: replaces the kASA / Read / Compare constructors (source/kASA.hpp:276-305) and
  *      setCodonTable (source/kASA.hpp:579-615).
- * kHigh/kLow : -k <kHigh> <kLow>; frames: 3 (default), 6 (--six) or 1 (--one, Read.hpp:223-261);
+ * kHigh/kLow : -k <kHigh> <kLow>, at most 12 with a 64-bit index and 25 with a 128-bit one; frames: 3 (default), 6 (--six) or 1 (--one, Read.hpp:223-261);
  * codonLut: 366-byte table of 5-bit letter codes indexed like kASA.hpp:75, or NULL for the built-in
  * table (kASA.hpp:621-667).
  */
@@ -138,10 +141,11 @@ int kasa_ctx_lookup_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uin
  * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
 int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);
 
-/* Queries of the batch after encode / after sort (k-mer, read id); for parity tests. */
-int kasa_batch_fetch_queries(kasa_ctx *ctx, uint64_t *kmers, uint32_t *reads, uint64_t n);
+/* Queries of the batch after encode / after sort (k-mer, read id); for parity tests.  A k-mer is one
+ * uint64_t with a 64-bit index, two (low word, high word) with a 128-bit index. */
+int kasa_batch_fetch_queries(kasa_ctx *ctx, void *kmers, uint32_t *reads, uint64_t n);
 /* Test tap: install (k-mer, read id) queries directly instead of upload + encode (any order). */
-int kasa_batch_set_queries(kasa_ctx *ctx, const uint64_t *kmers, const uint32_t *reads, uint64_t n, int64_t nReads);
+int kasa_batch_set_queries(kasa_ctx *ctx, const void *kmers, const uint32_t *reads, uint64_t n, int64_t nReads);
 /* Per sorted query: deepest matched level k (0 = none) and an index position sharing that prefix. */
 int kasa_batch_fetch_lookup(kasa_ctx *ctx, uint8_t *depth, uint32_t *indexPos, uint64_t n);
 int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);

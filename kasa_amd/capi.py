@@ -66,14 +66,19 @@ class DeviceIndex:
     """HBM-resident index (immutable, shareable between contexts)."""
 
     def __init__(self, ix, device: int = 0, check_trie: bool = True):
-        from .formats import REC_DTYPE
-        rec = np.zeros(ix.n, dtype=REC_DTYPE)
-        rec["kmer"], rec["tax"] = ix.kmer, ix.taxid
+        from .formats import REC_DTYPE, REC128_DTYPE, is_wide
+        self.wide = bool(is_wide(ix.kmer))
+        if self.wide:   # 128-bit index: 20-byte {low, high, taxid} records (packedLargePair)
+            rec = np.zeros(ix.n, dtype=REC128_DTYPE)
+            rec["lo"], rec["hi"], rec["tax"] = ix.kmer["lo"], ix.kmer["hi"], ix.taxid
+        else:
+            rec = np.zeros(ix.n, dtype=REC_DTYPE)
+            rec["kmer"], rec["tax"] = ix.kmer, ix.taxid
         tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32) if check_trie else None
         tc = np.ascontiguousarray(ix.trie_count, dtype=np.uint64) if check_trie else None
         ids = np.ascontiguousarray(ix.content.taxids, dtype=np.uint32)
         h = C.c_void_p()
-        _check(lib().kasa_index_create(C.c_int(device), _p(rec), C.c_uint64(ix.n), C.c_int(12), _p(tp), _p(tc),
+        _check(lib().kasa_index_create(C.c_int(device), _p(rec), C.c_uint64(ix.n), C.c_int(rec.dtype.itemsize), _p(tp), _p(tc),
                                        C.c_uint64(0 if tp is None else tp.shape[0]), _p(ids),
                                        C.c_uint32(ids.shape[0]), C.byref(h)))
         self.h = h
@@ -204,14 +209,16 @@ class Context:
         return int(n.value)
 
     def queries(self):
+        from .formats import KEY128_DTYPE
         n = self.query_count()
-        km = np.zeros(n, dtype=np.uint64)
+        km = np.zeros(n, dtype=KEY128_DTYPE if self.dix.wide else np.uint64)
         rd = np.zeros(n, dtype=np.uint32)
         _check(lib().kasa_batch_fetch_queries(self.h, _p(km), _p(rd), C.c_uint64(n)))
         return km, rd
 
     def set_queries(self, kmers: np.ndarray, reads: np.ndarray, n_reads: int):
-        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        from .formats import KEY128_DTYPE
+        kmers = np.ascontiguousarray(kmers, dtype=KEY128_DTYPE if self.dix.wide else np.uint64)
         reads = np.ascontiguousarray(reads, dtype=np.uint32)
         _check(lib().kasa_batch_set_queries(self.h, _p(kmers), _p(reads), C.c_uint64(kmers.shape[0]), C.c_int64(n_reads)))
         self.n_reads, self.n_kmers = int(n_reads), int(kmers.shape[0])

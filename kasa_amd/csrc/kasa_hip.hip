@@ -41,7 +41,7 @@ static constexpr int KLETTERS = 12;               // letters per packed k-mer (6
 static constexpr int KEYBITS = 5 * KLETTERS;      // 60
 static constexpr int KEYSHIFT = 64 - KEYBITS;     // 4
 static constexpr int RANGE_LETTERS = 6;           // depth of the reference's prefix trie (Trie.hpp)
-static constexpr int MAX_LEVELS = 12;
+static constexpr int MAX_LEVELS = 25;
 static constexpr int TILE = 1024;                 // sorted queries per workgroup in lookup/group
 static constexpr int TILE_THREADS = 256;
 static constexpr int ITEMS = TILE / TILE_THREADS; // 4
@@ -109,21 +109,42 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lcp_letters(uint64_t a, uint64_t b)
+// Keys: uint64_t for the 64-bit index (12 letters, 60 bits) or key128 for the 128-bit index (25 letters, 125 bits;
+// source/utils/uint128_t.hpp).  Every key-typed kernel is a template instantiated for both.
+typedef unsigned __int128 key128;
+template <class Key> struct KeyTraits;
+template <> struct KeyTraits<uint64_t> {
+    static constexpr int LETTERS = 12, BITS = 60, SHIFT = 4;
+    typedef uint8_t Meta;                              // low nibble: letters shared with the previous entry, high nibble: dupLvl
+    static constexpr int META_SHIFT = 4, META_MASK = 15;
+};
+template <> struct KeyTraits<key128> {
+    static constexpr int LETTERS = 25, BITS = 125, SHIFT = 3;
+    typedef uint16_t Meta;                             // the same two counts, a byte each
+    static constexpr int META_SHIFT = 8, META_MASK = 255;
+};
+
+__host__ __device__ __forceinline__ int clz_key(uint64_t x) { return __builtin_clzll(x); }             // x != 0
+__host__ __device__ __forceinline__ int clz_key(key128 x)
 {
-    const uint64_t x = (a ^ b) << KEYSHIFT;
-    return x ? (__clzll(x) / 5) : KLETTERS;
+    const uint64_t hi = (uint64_t)(x >> 64);
+    return hi ? __builtin_clzll(hi) : 64 + __builtin_clzll((uint64_t)x);
 }
 
-__device__ __forceinline__ int lcp_of_xor(uint64_t x)   // lcp_letters when the XOR of the two keys is at hand
+template <class Key> __device__ __forceinline__ int lcp_of_xor(Key x)   // letters two keys share, from their XOR
 {
-    x <<= KEYSHIFT;
-    return x ? (__clzll(x) / 5) : KLETTERS;
+    x <<= KeyTraits<Key>::SHIFT;
+    return x ? (clz_key(x) / 5) : KeyTraits<Key>::LETTERS;
 }
+template <class Key> __device__ __forceinline__ int lcp_letters(Key a, Key b) { return lcp_of_xor<Key>(a ^ b); }
 
-// 5-bit-field constants over the 12 letters of a key: '^' (30) in every field, the low four bits, bit 4
-static constexpr uint64_t field_repeat(uint64_t v) { uint64_t r = 0; for (int i = 0; i < KLETTERS; ++i) r |= v << (5 * i); return r; }
-static constexpr uint64_t HAT_ALL = field_repeat(30), LOW4_ALL = field_repeat(15), BIT4_ALL = field_repeat(16);
+// 5-bit-field constants over the letters of a key: '^' (30) in every field, the low four bits, bit 4
+template <class Key> __host__ __device__ constexpr Key field_repeat(unsigned v)
+{
+    Key r = 0;
+    for (int i = 0; i < KeyTraits<Key>::LETTERS; ++i) r |= (Key)v << (5 * i);
+    return r;
+}
 
 __device__ __forceinline__ int group_letters(int k) { return k < RANGE_LETTERS ? RANGE_LETTERS : k; }
 
@@ -134,23 +155,33 @@ struct kasa_index {
     int device = 0;
     uint64_t n = 0;
     uint32_t nTaxa = 0;
-    DevBuf kmer;   // u64[n]
+    bool wide = false; // 128-bit keys (K = 25 letters)
+    int letters() const { return wide ? 25 : 12; }
+    DevBuf kmer;   // u64[n] or key128[n]
     DevBuf tax;    // u32[n] dense taxon index
-    DevBuf meta;   // u8[n]: low nibble = letters shared with the previous entry, high nibble = letters
-                   //        shared with the nearest earlier entry of the same taxon
+    DevBuf meta;   // KeyTraits::Meta[n]: letters shared with the previous entry | letters shared with the nearest
+                   //        earlier entry of the same taxon
     DevBuf table;  // u32[2^tb]: number of entries whose top `tb` key bits are <= b
     int tb = 0;
     uint64_t bytes() const { return kmer.cap + tax.cap + meta.cap + table.cap; }
 };
 
-__global__ void unpack_records_kernel(const uint8_t *__restrict__ rec, uint64_t n, uint64_t *__restrict__ kmer,
+template <class Key>
+__global__ void unpack_records_kernel(const uint8_t *__restrict__ rec, uint64_t n, Key *__restrict__ kmer,
                                       uint32_t *__restrict__ taxid)
 {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(rec + i * 12); // 12-byte records are 4-aligned
-    kmer[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    taxid[i] = w[2];
+    if constexpr (sizeof(Key) == 8) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(rec + i * 12); // 12-byte records are 4-aligned
+        kmer[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+        taxid[i] = w[2];
+    } else {   // packedLargePair (packedPairs.hpp:132-155): low word, high word, tax id = 20 bytes, 4-aligned
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(rec + i * 20);
+        const uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+        kmer[i] = ((key128)hi << 64) | lo;
+        taxid[i] = w[4];
+    }
 }
 
 __global__ void dense_tax_kernel(uint32_t *__restrict__ tax, uint64_t n, const uint32_t *__restrict__ sortedIds,
@@ -168,59 +199,70 @@ __global__ void dense_tax_kernel(uint32_t *__restrict__ tax, uint64_t n, const u
     else { tax[i] = 0; atomicAdd(bad, 1u); }
 }
 
-__global__ void index_check_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ taxid, uint64_t n,
+template <class Key>
+__global__ void index_check_kernel(const Key *__restrict__ kmer, const uint32_t *__restrict__ taxid, uint64_t n,
                                    uint32_t *__restrict__ bad)
 {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i == 0 || i >= n) return;
-    const uint64_t a = kmer[i - 1], b = kmer[i];
-    if (a > b || (a == b && taxid[i - 1] >= taxid[i]) || (b >> KEYBITS)) atomicAdd(bad, 1u);
+    const Key a = kmer[i - 1], b = kmer[i];
+    if (a > b || (a == b && taxid[i - 1] >= taxid[i]) || (b >> KeyTraits<Key>::BITS)) atomicAdd(bad, 1u);
 }
 
-__global__ void lcp_prev_kernel(const uint64_t *__restrict__ kmer, uint64_t n, uint8_t *__restrict__ meta)
+template <class Key>
+__global__ void lcp_prev_kernel(const Key *__restrict__ kmer, uint64_t n, typename KeyTraits<Key>::Meta *__restrict__ meta)
 {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    meta[i] = (i == 0) ? 0 : (uint8_t)lcp_letters(kmer[i - 1], kmer[i]);
+    meta[i] = (i == 0) ? 0 : (typename KeyTraits<Key>::Meta)lcp_letters<Key>(kmer[i - 1], kmer[i]);
 }
 
 // after a stable sort of positions by taxon: consecutive positions of one taxon are index neighbours
 // of that taxon, so the letters they share is exactly "how deep the earlier one shadows the later one"
+template <class Key>
 __global__ void dup_level_kernel(const uint32_t *__restrict__ taxSorted, const uint32_t *__restrict__ order,
-                                 const uint64_t *__restrict__ kmer, uint64_t n, uint8_t *__restrict__ meta)
+                                 const Key *__restrict__ kmer, uint64_t n, typename KeyTraits<Key>::Meta *__restrict__ meta)
 {
+    typedef KeyTraits<Key> T;
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t d = 0;
-    if (i > 0 && taxSorted[i] == taxSorted[i - 1]) d = (uint8_t)lcp_letters(kmer[order[i - 1]], kmer[order[i]]);
+    uint32_t d = 0;
+    if (i > 0 && taxSorted[i] == taxSorted[i - 1]) d = (uint32_t)lcp_letters<Key>(kmer[order[i - 1]], kmer[order[i]]);
     const uint32_t pos = order[i];
-    meta[pos] = (uint8_t)((meta[pos] & 15) | (d << 4));
+    meta[pos] = (typename T::Meta)((meta[pos] & T::META_MASK) | (d << T::META_SHIFT));
 }
 
-__global__ void table_mark_kernel(const uint64_t *__restrict__ kmer, uint64_t n, int shift, uint32_t *__restrict__ table)
+template <class Key>
+__global__ void table_mark_kernel(const Key *__restrict__ kmer, uint64_t n, int shift, uint32_t *__restrict__ table)
 {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t b = kmer[i] >> shift;
-    if (i + 1 == n || (kmer[i + 1] >> shift) != b) table[b] = (uint32_t)(i + 1);
+    const uint64_t b = (uint64_t)(kmer[i] >> shift);
+    if (i + 1 == n || (uint64_t)(kmer[i + 1] >> shift) != b) table[b] = (uint32_t)(i + 1);
 }
 
+template <class Key>
 __global__ void trie_check_kernel(const uint32_t *__restrict__ prefix, const uint64_t *__restrict__ start,
-                                  const uint64_t *__restrict__ count, uint64_t nTrie, const uint64_t *__restrict__ kmer,
+                                  const uint64_t *__restrict__ count, uint64_t nTrie, const Key *__restrict__ kmer,
                                   uint64_t n, uint32_t *__restrict__ bad)
 {
     const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (i >= nTrie) return;
     const uint64_t s = start[i], c = count[i];
-    const int sh = 5 * (KLETTERS - RANGE_LETTERS);
+    const int sh = 5 * (KeyTraits<Key>::LETTERS - RANGE_LETTERS);
     bool ok = c > 0 && s + c <= n;
-    if (ok) ok = (kmer[s] >> sh) == prefix[i] && (kmer[s + c - 1] >> sh) == prefix[i];
-    if (ok && s > 0) ok = (kmer[s - 1] >> sh) < prefix[i];
-    if (ok && s + c < n) ok = (kmer[s + c] >> sh) > prefix[i];
+    if (ok) ok = (uint64_t)(kmer[s] >> sh) == prefix[i] && (uint64_t)(kmer[s + c - 1] >> sh) == prefix[i];
+    if (ok && s > 0) ok = (uint64_t)(kmer[s - 1] >> sh) < prefix[i];
+    if (ok && s + c < n) ok = (uint64_t)(kmer[s + c] >> sh) > prefix[i];
     if (!ok) atomicAdd(bad, 1u);
 }
 
 static inline unsigned blocks_for(uint64_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+template <class Key>
+static int index_create_impl(int device, const void *records, uint64_t nRecords,
+                             const uint32_t *triePrefix, const uint64_t *trieCount, uint64_t nTrie,
+                             const uint32_t *taxIds, uint32_t nTaxa, kasa_index **out);
 
 extern "C" int kasa_index_create(int device, const void *records, uint64_t nRecords, int recordBytes,
                                  const uint32_t *triePrefix, const uint64_t *trieCount, uint64_t nTrie,
@@ -250,8 +292,19 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
         if (i != nRecords) return fail(KASA_E_ARG, "kasa_index_create: the trie file counts %llu entries, the index has %llu", (unsigned long long)i, (unsigned long long)nRecords);
         return kasa_index_create(device, full.data(), nRecords, 12, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
     }
-    if (recordBytes != 12)
-        return fail(KASA_E_ARG, "kasa_index_create: 12-byte {u64 kmer,u32 taxid} or 6-byte halved records are supported (a 20-byte k<=25 index is not), got %d", recordBytes);
+    if (recordBytes == 20) return index_create_impl<key128>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
+    if (recordBytes == 12) return index_create_impl<uint64_t>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
+    return fail(KASA_E_ARG, "kasa_index_create: records are 12 bytes {u64 kmer, u32 taxid}, 20 bytes {u64 low, u64 high, u32 taxid} (k <= 25) or 6 bytes (halved), got %d", recordBytes);
+}
+
+template <class Key>
+static int index_create_impl(int device, const void *records, uint64_t nRecords,
+                             const uint32_t *triePrefix, const uint64_t *trieCount, uint64_t nTrie,
+                             const uint32_t *taxIds, uint32_t nTaxa, kasa_index **out)
+{
+    typedef KeyTraits<Key> T;
+    typedef typename T::Meta Meta;
+    constexpr size_t REC = sizeof(Key) + 4;
     if (!records && nRecords) return fail(KASA_E_ARG, "kasa_index_create: records is NULL");
     if (nRecords == 0) return fail(KASA_E_ARG, "The index file cannot be found or is empty!");
     if (nRecords >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_index_create: %llu records exceed the 32-bit position range of this build", (unsigned long long)nRecords);
@@ -264,7 +317,7 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
 
     kasa_index *ix = new (std::nothrow) kasa_index();
     if (!ix) return fail(KASA_E_NOMEM, "host allocation failed");
-    ix->device = device; ix->n = nRecords; ix->nTaxa = nTaxa;
+    ix->device = device; ix->n = nRecords; ix->nTaxa = nTaxa; ix->wide = sizeof(Key) > 8;
     int rc = KASA_OK;
     DevBuf raw, ids, dense, bad, order, taxSorted, iota, tmp, tpre, tstart, tcount;
     auto cleanup = [&](int code) {
@@ -276,15 +329,15 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
 #define TRY(x) do { rc = (x); if (rc != KASA_OK) return cleanup(rc); } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return cleanup(fail(e_ == hipErrorOutOfMemory ? KASA_E_NOMEM : KASA_E_HIP, "%s failed: %s", #x, hipGetErrorString(e_))); } while (0)
     const uint64_t n = nRecords;
-    TRY(raw.reserve(n * 12));
-    TRY(ix->kmer.reserve(n * 8));
+    TRY(raw.reserve(n * REC));
+    TRY(ix->kmer.reserve(n * sizeof(Key)));
     TRY(ix->tax.reserve(n * 4));
-    TRY(ix->meta.reserve(n));
+    TRY(ix->meta.reserve(n * sizeof(Meta)));
     TRY(bad.reserve(16));
-    TRYHIP(hipMemcpy(raw.p, records, n * 12, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(raw.p, records, n * REC, hipMemcpyHostToDevice));
     TRYHIP(hipMemset(bad.p, 0, 16));
-    unpack_records_kernel<<<blocks_for(n, 256), 256>>>(raw.as<uint8_t>(), n, ix->kmer.as<uint64_t>(), ix->tax.as<uint32_t>());
-    index_check_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), ix->tax.as<uint32_t>(), n, bad.as<uint32_t>());
+    unpack_records_kernel<Key><<<blocks_for(n, 256), 256>>>(raw.as<uint8_t>(), n, ix->kmer.as<Key>(), ix->tax.as<uint32_t>());
+    index_check_kernel<Key><<<blocks_for(n, 256), 256>>>(ix->kmer.as<Key>(), ix->tax.as<uint32_t>(), n, bad.as<uint32_t>());
     raw.release();
     // taxid -> dense index (Compare.hpp:139-143)
     {
@@ -300,11 +353,11 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
     }
     uint32_t hbad[4] = {0, 0, 0, 0};
     TRYHIP(hipMemcpy(hbad, bad.p, 16, hipMemcpyDeviceToHost));
-    if (hbad[0]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the index is not sorted by (kmer, taxid), not unique, or uses more than %d key bits (%u violations)", KEYBITS, hbad[0]));
+    if (hbad[0]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the index is not sorted by (kmer, taxid), not unique, or uses more than %d key bits (%u violations)", T::BITS, hbad[0]));
     if (hbad[1]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: %u index entries carry a tax ID the content file does not know", hbad[1]));
 
     // meta: shared letters with the previous entry and with the previous entry of the same taxon
-    lcp_prev_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), n, ix->meta.as<uint8_t>());
+    lcp_prev_kernel<Key><<<blocks_for(n, 256), 256>>>(ix->kmer.as<Key>(), n, ix->meta.as<Meta>());
     {
         TRY(order.reserve(n * 4));
         TRY(taxSorted.reserve(n * 4));
@@ -317,7 +370,7 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
         TRY(tmp.reserve(tmpBytes));
         TRYHIP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, ix->tax.as<uint32_t>(), taxSorted.as<uint32_t>(), cnt,
                                          order.as<uint32_t>(), (size_t)n, 0u, bits, (hipStream_t)0));
-        dup_level_kernel<<<blocks_for(n, 256), 256>>>(taxSorted.as<uint32_t>(), order.as<uint32_t>(), ix->kmer.as<uint64_t>(), n, ix->meta.as<uint8_t>());
+        dup_level_kernel<Key><<<blocks_for(n, 256), 256>>>(taxSorted.as<uint32_t>(), order.as<uint32_t>(), ix->kmer.as<Key>(), n, ix->meta.as<Meta>());
         TRYHIP(hipDeviceSynchronize());
         order.release(); taxSorted.release();
     }
@@ -329,7 +382,7 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
         const uint64_t nb = 1ull << tb;
         TRY(ix->table.reserve(nb * 4));
         TRYHIP(hipMemset(ix->table.p, 0, nb * 4));
-        table_mark_kernel<<<blocks_for(n, 256), 256>>>(ix->kmer.as<uint64_t>(), n, KEYBITS - tb, ix->table.as<uint32_t>());
+        table_mark_kernel<Key><<<blocks_for(n, 256), 256>>>(ix->kmer.as<Key>(), n, T::BITS - tb, ix->table.as<uint32_t>());
         size_t tmpBytes = 0;
         TRYHIP(rocprim::inclusive_scan(nullptr, tmpBytes, ix->table.as<uint32_t>(), ix->table.as<uint32_t>(), (size_t)nb, rocprim::maximum<uint32_t>(), (hipStream_t)0));
         TRY(tmp.reserve(tmpBytes));
@@ -346,7 +399,7 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
         TRYHIP(hipMemcpy(tstart.p, start.data(), nTrie * 8, hipMemcpyHostToDevice));
         TRYHIP(hipMemcpy(tcount.p, trieCount, nTrie * 8, hipMemcpyHostToDevice));
         TRYHIP(hipMemset(bad.p, 0, 16));
-        trie_check_kernel<<<blocks_for(nTrie, 256), 256>>>(tpre.as<uint32_t>(), tstart.as<uint64_t>(), tcount.as<uint64_t>(), nTrie, ix->kmer.as<uint64_t>(), n, bad.as<uint32_t>());
+        trie_check_kernel<Key><<<blocks_for(nTrie, 256), 256>>>(tpre.as<uint32_t>(), tstart.as<uint64_t>(), tcount.as<uint64_t>(), nTrie, ix->kmer.as<Key>(), n, bad.as<uint32_t>());
         TRYHIP(hipMemcpy(hbad, bad.p, 16, hipMemcpyDeviceToHost));
         if (hbad[0]) return cleanup(fail(KASA_E_ARG, "kasa_index_create: the trie file does not match the index (%u ranges differ)", hbad[0]));
     }
@@ -408,7 +461,10 @@ struct kasa_ctx {
     DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
     uint64_t poolCap = 0, stCap = 0, nnz = 0;
-    uint64_t *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays
+    void *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays; keys are u64 or key128 as the index
+    size_t keyBytes() const { return ix->wide ? 16 : 8; }
+    int K() const { return ix->letters(); }
+    template <class Key> Key *keys() const { return static_cast<Key *>(qKmer); }
     StageTimer timers[KASA_STAGE_COUNT];
     StageTimer lookupKernel;
     uint64_t lookupQueries = 0;
@@ -478,7 +534,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     *out = nullptr;
     if (!ix) return fail(KASA_E_ARG, "kasa_ctx_create: index is NULL");
     if (kHigh < kLow) std::swap(kHigh, kLow); // "-k <lower> <upper> is okay too" (README)
-    if (kLow < 1 || kHigh > KLETTERS) return fail(KASA_E_ARG, "kasa_ctx_create: k range [%d,%d] outside [1,%d]", kLow, kHigh, KLETTERS);
+    if (kLow < 1 || kHigh > ix->letters()) return fail(KASA_E_ARG, "kasa_ctx_create: k range [%d,%d] outside [1,%d]", kLow, kHigh, ix->letters());
     if (frames != 1 && frames != 3 && frames != 6) return fail(KASA_E_ARG, "kasa_ctx_create: frames must be 1, 3 or 6");
     HIPCHK(hipSetDevice(ix->device));
     kasa_ctx *c = new (std::nothrow) kasa_ctx();
@@ -549,9 +605,9 @@ extern "C" int kasa_profile_reset(kasa_ctx *c)
 // input kinds: mode 0 = DNA in 3 or 6 frames, 1 = DNA in one frame (--one), 2 = amino-acid input.
 // body = padded read without the marker, L = body + marker, cnt = k-mers per strand.
 enum { ENC_DNA = 0, ENC_ONE = 1, ENC_PROTEIN = 2 };
-__host__ __device__ static inline void enc_geometry(int mode, int kLow, int64_t raw, int64_t &body, int64_t &L, int64_t &cnt)
+__host__ __device__ static inline void enc_geometry(int mode, int KL, int kLow, int64_t raw, int64_t &body, int64_t &L, int64_t &cnt)
 {
-    const int64_t K = KLETTERS;
+    const int64_t K = KL;
     const int64_t marker = (mode == ENC_PROTEIN ? 1 : 3) * (K - (int64_t)kLow);
     body = raw;
     if (mode == ENC_PROTEIN) {
@@ -583,7 +639,7 @@ extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_
         c->hostOff[(size_t)r] = offsets[r] - offsets[0];
         koff[(size_t)r] = run;
         int64_t body, L, perStrand = 0;
-        if (raw > 0) enc_geometry(mode, c->kLow, raw, body, L, perStrand);
+        if (raw > 0) enc_geometry(mode, c->K(), c->kLow, raw, body, L, perStrand);
         const uint64_t cnt = (uint64_t)perStrand * strands;
         run += cnt;
         if (cnt > maxCnt) maxCnt = (uint32_t)std::min<uint64_t>(cnt, 0xFFFFFFFFull);
@@ -609,14 +665,16 @@ extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_
 // base w * ws and takes its letters at stride ls (DNA: ws 1, ls 3; --one: ws 3, ls 3, Read.hpp:223-261;
 // amino-acid input: ws 1, ls 1 and the letters are the input itself, Read.hpp:60-81).
 static constexpr int ENC_CHUNK = 512;                       // windows per chunk
-static constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;   // bases needed for one chunk (+ slack)
 static constexpr int ENC_WAVES = 4;
 
+template <class Key>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
-    int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG, uint64_t *__restrict__ outKmer,
+    int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG, Key *__restrict__ outKmer,
     uint32_t *__restrict__ outRead)
 {
+    constexpr int KLETTERS = KeyTraits<Key>::LETTERS;
+    constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;      // bases needed for one chunk (+ slack)
     __shared__ uint8_t sLut[384];
     __shared__ uint8_t sCode[ENC_WAVES][ENC_SPAN + 8];
     __shared__ uint8_t sLetter[ENC_WAVES][ENC_SPAN + 8];
@@ -634,7 +692,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
         const int64_t raw = baseOff[r + 1] - b0;
         if (raw <= 0) continue;
         int64_t body, L, cnt;
-        enc_geometry(mode, kLow, raw, body, L, cnt);
+        enc_geometry(mode, KLETTERS, kLow, raw, body, L, cnt);
         if (cnt == 0) continue;
         const uint64_t o0 = kmerOff[r];
         for (int s = 0; s < strands; ++s) {
@@ -675,7 +733,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < nw; i += 64) {
-                    uint64_t v = 0;
+                    Key v = 0;
                     const uint8_t *lt = &sLetter[wv][i * ws];
 #pragma unroll
                     for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
@@ -697,18 +755,23 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     HIPCHK(hipSetDevice(c->ix->device));
     int rc;
     const uint64_t nQ = c->nQ;
-    if ((rc = c->qKmerA.reserve(nQ * 8 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
+    if ((rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_ENCODE], &a, &b))) return rc;
     if (c->nReads > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nReads + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
-        encode_kernel<<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
-            c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
-            c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+        if (c->ix->wide)
+            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+                c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
+                c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>());
+        else
+            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+                c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
+                c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_ENCODE], a, b))) return rc;
-    c->qKmer = c->qKmerA.as<uint64_t>();
+    c->qKmer = c->qKmerA.p;
     c->qRead = c->qReadA.as<uint32_t>();
     c->state = 2;
     if (nKmers) *nKmers = nQ;
@@ -723,8 +786,9 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
 // finishes it.  Consecutive threads hold consecutive sorted queries, so table and index reads of a
 // wavefront fall into a few cache lines.  Also emits, per tile and level, the first position that
 // closes a group ("special"), the seed of the flush-order computation.
+template <class Key>
 __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
-    const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer, uint32_t nIdx,
+    const Key *__restrict__ qKmer, uint32_t nQ, const Key *__restrict__ idxKmer, uint32_t nIdx,
     const uint32_t *__restrict__ table, int tb, int kHigh, int kLow, uint8_t *__restrict__ depth,
     uint32_t *__restrict__ rep, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
 {
@@ -737,16 +801,16 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t p = base + it * TILE_THREADS + threadIdx.x;   // striped: coalesced loads
         if (p >= nQ) continue;
-        const uint64_t q = qKmer[p];
-        const uint64_t bkt = q >> (KEYBITS - tb);
+        const Key q = qKmer[p];
+        const uint64_t bkt = (uint64_t)(q >> (KeyTraits<Key>::BITS - tb));
         uint32_t lo = bkt ? table[bkt - 1] : 0u;
         uint32_t hi = table[bkt];
         while (lo < hi) {                                           // first entry >= q
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (idxKmer[mid] < q) lo = mid + 1; else hi = mid;
         }
-        const int la = (lo < nIdx) ? lcp_letters(q, idxKmer[lo]) : 0;
-        const int lb = (lo > 0) ? lcp_letters(q, idxKmer[lo - 1]) : 0;
+        const int la = (lo < nIdx) ? lcp_letters<Key>(q, idxKmer[lo]) : 0;
+        const int lb = (lo > 0) ? lcp_letters<Key>(q, idxKmer[lo - 1]) : 0;
         int L = la >= lb ? la : lb;
         const uint32_t r = la >= lb ? lo : lo - 1;
         int d = 0;
@@ -754,12 +818,12 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
             if (L > kHigh) L = kHigh;
             d = L;
             for (int k = kLow; k <= L; ++k)                         // '^' ends the query (Compare.hpp:836,897)
-                if (((q >> (5 * (KLETTERS - k))) & 31) == 30) { d = k - 1; break; }
+                if (((uint32_t)(q >> (5 * (KeyTraits<Key>::LETTERS - k))) & 31u) == 30u) { d = k - 1; break; }
             if (d < kLow) d = 0;
         }
         depth[p] = (uint8_t)d;
         rep[p] = r;
-        const int ql = (p == 0) ? 0 : lcp_letters(qKmer[p - 1], q);
+        const int ql = (p == 0) ? 0 : lcp_letters<Key>(qKmer[p - 1], q);
         for (int lv = 0; lv < nK; ++lv) {
             const int k = kHigh - lv;
             const bool special = (ql < RANGE_LETTERS) || (ql < group_letters(k) && d >= k);
@@ -780,10 +844,11 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_kernel(
 // index record and every query is read from HBM once: the merge-join lower bound of SURVEY.md 8(d).
 static constexpr int LSPAN = 1536;   // index records staged per tile (12 KiB); larger spans use lookup_kernel's path
 
-__device__ __forceinline__ uint32_t lower_bound_global(const uint64_t *__restrict__ idxKmer, const uint32_t *__restrict__ table,
-                                                       int tb, uint64_t q)
+template <class Key>
+__device__ __forceinline__ uint32_t lower_bound_global(const Key *__restrict__ idxKmer, const uint32_t *__restrict__ table,
+                                                       int tb, Key q)
 {
-    const uint64_t bkt = q >> (KEYBITS - tb);
+    const uint64_t bkt = (uint64_t)(q >> (KeyTraits<Key>::BITS - tb));
     uint32_t lo = bkt ? table[bkt - 1] : 0u;
     uint32_t hi = table[bkt];
     while (lo < hi) {
@@ -793,7 +858,8 @@ __device__ __forceinline__ uint32_t lower_bound_global(const uint64_t *__restric
     return lo;
 }
 
-__global__ void tile_bounds_kernel(const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer,
+template <class Key>
+__global__ void tile_bounds_kernel(const Key *__restrict__ qKmer, uint32_t nQ, const Key *__restrict__ idxKmer,
                                    const uint32_t *__restrict__ table, int tb, uint32_t nTiles, uint32_t *__restrict__ bounds)
 {
     // edge 2t: start of the level-1 bucket of the tile's first query; edge 2t+1: end of the bucket of its last query.
@@ -803,7 +869,7 @@ __global__ void tile_bounds_kernel(const uint64_t *__restrict__ qKmer, uint32_t 
     const uint32_t t = i >> 1;
     uint32_t p = t * TILE + ((i & 1) ? (TILE - 1) : 0);
     if (p >= nQ) p = nQ - 1;
-    const uint64_t bkt = qKmer[p] >> (KEYBITS - tb);
+    const uint64_t bkt = (uint64_t)(qKmer[p] >> (KeyTraits<Key>::BITS - tb));
     bounds[i] = (i & 1) ? table[bkt] : (bkt ? table[bkt - 1] : 0u);
     (void)idxKmer;
 }
@@ -811,12 +877,15 @@ __global__ void tile_bounds_kernel(const uint64_t *__restrict__ qKmer, uint32_t 
 // One workgroup per tile, a thread owns ITEMS = 4 CONSECUTIVE sorted queries (32 bytes, two 16-byte loads; a
 // wavefront reads 2 KiB contiguous), so a query's predecessor is in a register, results leave as one 16-byte and
 // one 4-byte store, and the per-level "first special position" needs one ballot per level.
+template <class Key>
 __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
-    const uint64_t *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ idxKmer, uint32_t nIdx,
+    const Key *__restrict__ qKmer, uint32_t nQ, const Key *__restrict__ idxKmer, uint32_t nIdx,
     const uint32_t *__restrict__ table, int tb, const uint32_t *__restrict__ bounds, int kHigh, int kLow,
     uint8_t *__restrict__ depth, uint32_t *__restrict__ rep, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
 {
-    __shared__ uint64_t sIdx[LSPAN + 2];
+    constexpr int KLETTERS = KeyTraits<Key>::LETTERS;
+    constexpr Key HAT_ALL = field_repeat<Key>(30), LOW4_ALL = field_repeat<Key>(15), BIT4_ALL = field_repeat<Key>(16);
+    __shared__ Key sIdx[LSPAN + 2];
     __shared__ uint32_t sFirst[MAX_LEVELS];
     const int nK = kHigh - kLow + 1;
     const int tid = threadIdx.x;
@@ -824,30 +893,39 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
     const uint32_t base = blockIdx.x * TILE;
     const uint32_t p0 = base + ITEMS * tid;
     const bool fullTile = base + TILE <= nQ;
-    uint64_t qv[ITEMS];
-    if (fullTile) {
-        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0);
-        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0 + 2);
-        qv[0] = v0.x; qv[1] = v0.y; qv[2] = v1.x; qv[3] = v1.y;
+    Key qv[ITEMS];
+    if constexpr (sizeof(Key) == 8) {
+        if (fullTile) {
+            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0);
+            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(qKmer + p0 + 2);
+            qv[0] = v0.x; qv[1] = v0.y; qv[2] = v1.x; qv[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) qv[it] = (p0 + it < nQ) ? qKmer[p0 + it] : 0ull;
+        }
     } else {
 #pragma unroll
-        for (int it = 0; it < ITEMS; ++it) qv[it] = (p0 + it < nQ) ? qKmer[p0 + it] : 0ull;
+        for (int it = 0; it < ITEMS; ++it) qv[it] = (p0 + it < nQ) ? qKmer[p0 + it] : (Key)0;   // 16-byte loads as they are
     }
-    const uint64_t qBefore = (p0 > 0 && p0 < nQ) ? qKmer[p0 - 1] : 0ull;
+    const Key qBefore = (p0 > 0 && p0 < nQ) ? qKmer[p0 - 1] : (Key)0;
     const uint2 bd = *reinterpret_cast<const uint2 *>(bounds + 2 * (size_t)blockIdx.x);
     const uint32_t ilo = bd.x ? bd.x - 1 : 0u;                         // predecessor of the first query
     const uint32_t ihi = (bd.y < nIdx) ? bd.y + 1 : nIdx;              // successor of the last query
     const uint32_t span = ihi - ilo;
     const bool staged = span <= (uint32_t)LSPAN;
     if (staged) {
-        const uint32_t a0 = ilo & ~1u;                                 // 16-byte aligned start (one extra record at most)
-        const uint32_t shift = ilo - a0;
-        for (uint32_t i = 2 * tid; i < span + shift; i += 2 * TILE_THREADS) {
-            if (a0 + i + 1 < nIdx) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(idxKmer + a0 + i);
-                if (i >= shift) sIdx[i - shift] = v.x;
-                if (i + 1 >= shift && i + 1 - shift < span) sIdx[i + 1 - shift] = v.y;
-            } else if (a0 + i < nIdx && i >= shift) sIdx[i - shift] = idxKmer[a0 + i];
+        if constexpr (sizeof(Key) == 8) {
+            const uint32_t a0 = ilo & ~1u;                             // 16-byte aligned start (one extra record at most)
+            const uint32_t shift = ilo - a0;
+            for (uint32_t i = 2 * tid; i < span + shift; i += 2 * TILE_THREADS) {
+                if (a0 + i + 1 < nIdx) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(idxKmer + a0 + i);
+                    if (i >= shift) sIdx[i - shift] = v.x;
+                    if (i + 1 >= shift && i + 1 - shift < span) sIdx[i + 1 - shift] = v.y;
+                } else if (a0 + i < nIdx && i >= shift) sIdx[i - shift] = idxKmer[a0 + i];
+            }
+        } else {
+            for (uint32_t i = tid; i < span; i += TILE_THREADS) sIdx[i] = idxKmer[ilo + i];
         }
     }
     __syncthreads();
@@ -874,16 +952,16 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
     uint32_t outRep[ITEMS];
     uint32_t outD[ITEMS];
     uint32_t special[ITEMS];                                           // bit lv: the position opens a level-(kHigh-lv) group
-    const uint32_t allLv = (1u << nK) - 1u;                            // nK <= MAX_LEVELS = 12
-    const uint64_t hatLetters = (2ull << (5 * (KLETTERS - kLow) + 4)) - 1ull;   // the bits of letters kLow..12
+    const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);   // nK <= MAX_LEVELS
+    const Key hatLetters = ((Key)2 << (5 * (KLETTERS - kLow) + 4)) - (Key)1;   // the bits of letters kLow..K
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t p = p0 + it;
         outRep[it] = 0; outD[it] = 0; special[it] = 0;
         if (p >= nQ) continue;
-        const uint64_t q = qv[it];
+        const Key q = qv[it];
         uint32_t lo;
-        uint64_t eLo = 0, ePrev = 0;
+        Key eLo = 0, ePrev = 0;
         bool hasLo, hasPrev;
         if (staged) {
             const uint32_t a = pos[it];
@@ -894,34 +972,34 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
             if (!hasPrev && lo > 0) { ePrev = idxKmer[lo - 1]; hasPrev = true; }       // only at the very ends of the index
             if (!hasLo && lo < nIdx) { eLo = idxKmer[lo]; hasLo = true; }
         } else {
-            lo = lower_bound_global(idxKmer, table, tb, q);
+            lo = lower_bound_global<Key>(idxKmer, table, tb, q);
             hasLo = lo < nIdx; hasPrev = lo > 0;
             if (hasLo) eLo = idxKmer[lo];
             if (hasPrev) ePrev = idxKmer[lo - 1];
         }
         // letters shared with the closer neighbour: the smaller XOR has the longer common prefix
-        const uint64_t xa = hasLo ? (q ^ eLo) : ~0ull;
-        const uint64_t xb = hasPrev ? (q ^ ePrev) : ~0ull;
-        const int la = lcp_of_xor(xa);
-        int L = lcp_of_xor(xa < xb ? xa : xb);
+        const Key xa = hasLo ? (q ^ eLo) : ~(Key)0;
+        const Key xb = hasPrev ? (q ^ ePrev) : ~(Key)0;
+        const int la = lcp_of_xor<Key>(xa);
+        int L = lcp_of_xor<Key>(xa < xb ? xa : xb);
         const uint32_t r = (la == L) ? lo : lo - 1;                     // ties go to the lower bound itself
         int d = 0;
         if (L >= RANGE_LETTERS) {                                       // the 6-letter prefix exists (Trie.hpp:494)
             d = L > kHigh ? kHigh : L;
             // '^' ends the query (Compare.hpp:836,897): first letter >= kLow that equals 30, found without a loop --
             // per 5-bit field, bit 4 of ((x & 01111b) + 01111b) | x is set iff the field of x = q ^ "^^^..." is non-zero
-            const uint64_t x = q ^ HAT_ALL;
-            const uint64_t z = ~(((x & LOW4_ALL) + LOW4_ALL) | x) & BIT4_ALL & hatLetters;
+            const Key x = q ^ HAT_ALL;
+            const Key z = ~(((x & LOW4_ALL) + LOW4_ALL) | x) & BIT4_ALL & hatLetters;
             if (z) {
-                const int khat = KLETTERS - (59 - __clzll(z)) / 5;       // bit 5(12-k)+4 belongs to letter k
+                const int khat = KLETTERS - ((int)(8 * sizeof(Key)) - 5 - clz_key(z)) / 5;   // bit 5(K-k)+4 belongs to letter k
                 if (khat <= d) d = khat - 1;
             }
             if (d < kLow) d = 0;
         }
         outD[it] = (uint32_t)d;
         outRep[it] = r;
-        const uint64_t prevQ = it ? qv[it - 1] : qBefore;
-        const int ql = (p == 0) ? 0 : lcp_letters(prevQ, q);
+        const Key prevQ = it ? qv[it - 1] : qBefore;
+        const int ql = (p == 0) ? 0 : lcp_letters<Key>(prevQ, q);
         // special for level k: a new range (ql < 6), or a new matched group: ql < k <= d
         uint32_t m = allLv;
         if (ql >= RANGE_LETTERS) m = (d > ql) ? ((((2u << (d - ql - 1)) - 1u) << (kHigh - d)) & allLv) : 0u;
@@ -978,7 +1056,8 @@ __global__ void tile_suffix_kernel(const uint32_t *__restrict__ tileFirst, uint3
     }
 }
 
-__global__ void unique_flag_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n, uint32_t *__restrict__ flag)
+template <class Key>
+__global__ void unique_flag_kernel(const Key *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n, uint32_t *__restrict__ flag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = (i == 0 || kmer[i] != kmer[i - 1] || read[i] != read[i - 1]) ? 1u : 0u;
@@ -990,8 +1069,9 @@ __global__ void read_count_kernel(const uint32_t *__restrict__ read, uint32_t n,
     if (i < n) atomicAdd((unsigned long long *)&cnt[read[i]], 1ull);
 }
 
-__global__ void unique_scatter_kernel(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n,
-                                      const uint32_t *__restrict__ slot, uint64_t *__restrict__ outKmer, uint32_t *__restrict__ outRead)
+template <class Key>
+__global__ void unique_scatter_kernel(const Key *__restrict__ kmer, const uint32_t *__restrict__ read, uint32_t n,
+                                      const uint32_t *__restrict__ slot, Key *__restrict__ outKmer, uint32_t *__restrict__ outRead)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -999,45 +1079,44 @@ __global__ void unique_scatter_kernel(const uint64_t *__restrict__ kmer, const u
     if (i == 0 || sl != slot[i - 1]) { outKmer[sl - 1] = kmer[i]; outRead[sl - 1] = read[i]; }
 }
 
-extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
+template <class Key>
+static int sort_and_range_impl(kasa_ctx *c, int unique)
 {
-    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_sort_and_range: batch not encoded");
     HIPCHK(hipSetDevice(c->ix->device));
     uint64_t nQ = c->nQ;
     int rc;
-    if ((rc = c->qKmerB.reserve(nQ * 8 + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64))) return rc;
+    if ((rc = c->qKmerB.reserve(nQ * sizeof(Key) + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64))) return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_SORT], &a, &b))) return rc;
     if (nQ > 0) {
         size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qKmerA.as<uint64_t>(), c->qKmerB.as<uint64_t>(),
-                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KEYBITS, c->stream));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qKmerA.as<Key>(), c->qKmerB.as<Key>(),
+                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KeyTraits<Key>::BITS, c->stream));
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerA.as<uint64_t>(), c->qKmerB.as<uint64_t>(),
-                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KEYBITS, c->stream));
+        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerA.as<Key>(), c->qKmerB.as<Key>(),
+                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KeyTraits<Key>::BITS, c->stream));
     }
-    c->qKmer = c->qKmerB.as<uint64_t>();
+    c->qKmer = c->qKmerB.p;
     c->qRead = c->qReadB.as<uint32_t>();
     if (unique && nQ > 1) {
         // -e (Compare.hpp:3167-3178): drop records equal in (k-mer, read id) to their predecessor.  The sort above is
         // stable and the encoder emits reads in ascending order, so every duplicate of a read is adjacent here.
         if ((rc = c->rep.reserve(nQ * 4 + 64))) return rc;            // rep is free until the lookup: slots of the survivors
         uint32_t *slot = c->rep.as<uint32_t>();
-        unique_flag_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qKmer, c->qRead, (uint32_t)nQ, slot);
+        unique_flag_kernel<Key><<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->keys<Key>(), c->qRead, (uint32_t)nQ, slot);
         size_t tmpBytes = 0;
         HIPCHK(rocprim::inclusive_scan(nullptr, tmpBytes, slot, slot, (size_t)nQ, rocprim::plus<uint32_t>(), c->stream));
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
         HIPCHK(rocprim::inclusive_scan(c->sortTmp.p, tmpBytes, slot, slot, (size_t)nQ, rocprim::plus<uint32_t>(), c->stream));
-        unique_scatter_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qKmer, c->qRead, (uint32_t)nQ, slot,
-            c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+        unique_scatter_kernel<Key><<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->keys<Key>(), c->qRead, (uint32_t)nQ, slot,
+            c->qKmerA.as<Key>(), c->qReadA.as<uint32_t>());
         HIPCHK(hipGetLastError());
         uint32_t kept = 0;
         HIPCHK(hipMemcpyAsync(&kept, slot + (nQ - 1), 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         nQ = c->nQ = kept;
         // back into the "sorted" buffers: later stages reuse the A buffers as scratch
-        HIPCHK(hipMemcpyAsync(c->qKmerB.p, c->qKmerA.p, nQ * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->qKmerB.p, c->qKmerA.p, nQ * sizeof(Key), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->qReadB.p, c->qReadA.p, nQ * 4, hipMemcpyDeviceToDevice, c->stream));
         // k-mers per read changed: recount, kmerOff = exclusive running sum (what the score kernels index plist with)
         uint64_t *ko = c->kmerOff.as<uint64_t>();
@@ -1059,14 +1138,14 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
         hipEvent_t ka, kb;
         if (c->lookupMode == 1) {
             if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
-            lookup_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+            lookup_kernel<Key><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
                 c->tileFirst.as<uint32_t>(), nTiles);
         } else {
-            tile_bounds_kernel<<<blocks_for(2ull * nTiles, 256), 256, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(),
+            tile_bounds_kernel<Key><<<blocks_for(2ull * nTiles, 256), 256, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(),
                 c->ix->table.as<uint32_t>(), c->ix->tb, nTiles, c->tileBounds.as<uint32_t>());
             if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;   // the roofline kernel alone
-            lookup_tile_kernel<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, (uint32_t)nQ, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+            lookup_tile_kernel<Key><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->tileBounds.as<uint32_t>(), c->kHigh, c->kLow, c->depth.as<uint8_t>(),
                 c->rep.as<uint32_t>(), c->tileFirst.as<uint32_t>(), nTiles);
         }
@@ -1079,6 +1158,13 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
     if ((rc = timer_end(c, c->timers[KASA_STAGE_LOOKUP], a, b))) return rc;
     c->state = 3;
     return KASA_OK;
+}
+
+extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_sort_and_range: batch not encoded");
+    return c->ix->wide ? sort_and_range_impl<key128>(c, unique) : sort_and_range_impl<uint64_t>(c, unique);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1124,25 +1210,27 @@ __device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
 
 // Step 1: bounds [a, b) of the group, its number of distinct taxa, and the 32-bit encoding when it fits
 // inline (0 = needs n + 1 words in the pool).
-__device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const uint8_t *__restrict__ meta,
+template <class Meta>
+__device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const Meta *__restrict__ meta,
                                                const uint32_t *__restrict__ tax, uint32_t nIdx, bool coverage,
                                                uint64_t *__restrict__ cntTotalLv, uint32_t &a, uint32_t &b, uint32_t &n)
 {
+    constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;   // KeyTraits::META_MASK / META_SHIFT
     a = j; b = j + 1;
-    const bool openLeft = (j > 0) && (meta[j] & 15) >= g;
-    const bool openRight = (b < nIdx) && (meta[b] & 15) >= g;
+    const bool openLeft = (j > 0) && (int)(meta[j] & LM) >= g;
+    const bool openRight = (b < nIdx) && (int)(meta[b] & LM) >= g;
     if (!openLeft && !openRight) {                       // the group is this one entry (the common case)
         const uint32_t t0 = tax[j];
         if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[t0], 1ull);
         n = 1;
         return REF_SINGLE | t0;
     }
-    if (openLeft) { --a; while (a > 0 && (meta[a] & 15) >= g) --a; }
-    if (openRight) { ++b; while (b < nIdx && (meta[b] & 15) >= g) ++b; }
+    if (openLeft) { --a; while (a > 0 && (int)(meta[a] & LM) >= g) --a; }
+    if (openRight) { ++b; while (b < nIdx && (int)(meta[b] & LM) >= g) ++b; }
     uint32_t t0 = 0, t1 = 0;
     n = 0;
     for (uint32_t i = a; i < b; ++i)
-        if ((meta[i] >> 4) < g) {
+        if ((int)(meta[i] >> DS) < g) {
             const uint32_t tx = tax[i];
             if (n == 0) t0 = tx; else if (n == 1) t1 = tx;
             ++n;
@@ -1154,7 +1242,8 @@ __device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const uint8_t 
 }
 
 // Step 2: append {n, taxa...} at pool[off]
-__device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t n, int g, const uint8_t *__restrict__ meta,
+template <class Meta>
+__device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t n, int g, const Meta *__restrict__ meta,
                                                const uint32_t *__restrict__ tax, uint32_t *__restrict__ pool, uint32_t poolCap,
                                                uint32_t off)
 {
@@ -1162,7 +1251,7 @@ __device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t 
     pool[off] = n;
     uint32_t w = off + 1;
     for (uint32_t i = a; i < b; ++i)
-        if ((meta[i] >> 4) < g) pool[w++] = tax[i];
+        if ((int)(meta[i] >> (sizeof(Meta) == 1 ? 4 : 8)) < g) pool[w++] = tax[i];
     return off;
 }
 
@@ -1185,9 +1274,10 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 
 // One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
 // taxon-set references (leaders compute them, members copy them through LDS).
+template <class Meta>
 __device__ __forceinline__ void group_level(
     int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[ITEMS], const uint8_t (&d)[ITEMS], const uint32_t (&rp)[ITEMS],
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa, uint32_t *shU, int *shI, uint32_t *sInfo, uint32_t *sBase,
     uint32_t (&F)[ITEMS], uint32_t (&R)[ITEMS])
@@ -1261,10 +1351,10 @@ __device__ __forceinline__ void group_level(
 
 // NKR > 0: all levels of a query are collected in registers and written as one contiguous record (nK <= NKR);
 // NKR == 0: any number of levels, one 8-byte store per level.
-template <int NKR>
+template <int NKR, class Key>
 __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
-    const uint64_t *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const uint8_t *__restrict__ meta, const uint32_t *__restrict__ tax,
+    const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, int kLow, uint2 *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap,
     uint32_t *__restrict__ poolCursor, int coverage, uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
 {
@@ -1281,8 +1371,8 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t p = base + i;
         if (p < nQ) {
-            const uint64_t q = qKmer[p];
-            ql[i] = (p == 0) ? 0 : (uint8_t)lcp_letters(qKmer[p - 1], q);
+            const Key q = qKmer[p];
+            ql[i] = (p == 0) ? 0 : (uint8_t)lcp_letters<Key>(qKmer[p - 1], q);
             d[i] = depth[p];
             rp[i] = rep[p];
         } else { ql[i] = 0; d[i] = 0; rp[i] = 0; }
@@ -1997,11 +2087,19 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         HIPCHK(hipMemcpyAsync(counters, &one, 4, hipMemcpyHostToDevice, c->stream)); // offset 0 means "no match"
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
         {
-            auto kern = (nK <= 6) ? group_kernel<6> : group_kernel<0>;
-            kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->qKmer, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
-                c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-                c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull),
-                counters, coverage && attempt == 0, c->cntTotal.as<uint64_t>(), nTaxa);
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull);
+            const int cov = coverage && attempt == 0;
+            if (c->ix->wide) {
+                auto kern = (nK <= 6) ? group_kernel<6, key128> : group_kernel<0, key128>;
+                kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+                    c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+                    c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
+            } else {
+                auto kern = (nK <= 6) ? group_kernel<6, uint64_t> : group_kernel<0, uint64_t>;
+                kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+                    c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+                    c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
+            }
         }
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
@@ -2295,19 +2393,19 @@ extern "C" int kasa_batch_query_count(kasa_ctx *c, uint64_t *n)
     return KASA_OK;
 }
 
-extern "C" int kasa_batch_fetch_queries(kasa_ctx *c, uint64_t *kmers, uint32_t *reads, uint64_t n)
+extern "C" int kasa_batch_fetch_queries(kasa_ctx *c, void *kmers, uint32_t *reads, uint64_t n)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (c->state < 2) return fail(KASA_E_STATE, "kasa_batch_fetch_queries: batch not encoded");
     if (n > c->nQ) return fail(KASA_E_ARG, "kasa_batch_fetch_queries: n exceeds the batch");
     HIPCHK(hipSetDevice(c->ix->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (n && kmers) HIPCHK(hipMemcpy(kmers, c->qKmer, n * 8, hipMemcpyDeviceToHost));
+    if (n && kmers) HIPCHK(hipMemcpy(kmers, c->qKmer, n * c->keyBytes(), hipMemcpyDeviceToHost));
     if (n && reads) HIPCHK(hipMemcpy(reads, c->qRead, n * 4, hipMemcpyDeviceToHost));
     return KASA_OK;
 }
 
-extern "C" int kasa_batch_set_queries(kasa_ctx *c, const uint64_t *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
+extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
@@ -2318,19 +2416,21 @@ extern "C" int kasa_batch_set_queries(kasa_ctx *c, const uint64_t *kmers, const 
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
         if ((int64_t)reads[i] >= nReads) return fail(KASA_E_ARG, "kasa_batch_set_queries: read id out of range");
-        if (kmers[i] >> KEYBITS) return fail(KASA_E_ARG, "kasa_batch_set_queries: k-mer uses more than %d bits", KEYBITS);
+        const bool tooWide = c->ix->wide ? ((static_cast<const uint64_t *>(kmers)[2 * i + 1] >> 61) != 0)     // high word of {lo, hi}
+                                         : ((static_cast<const uint64_t *>(kmers)[i] >> 60) != 0);
+        if (tooWide) return fail(KASA_E_ARG, "kasa_batch_set_queries: k-mer uses more than %d bits", c->ix->wide ? 125 : 60);
         koff[(size_t)reads[i] + 1]++;
     }
     for (int64_t r = 0; r < nReads; ++r) { maxCnt = std::max<uint32_t>(maxCnt, (uint32_t)koff[(size_t)r + 1]); koff[(size_t)r + 1] += koff[(size_t)r]; }
     int rc;
-    if ((rc = c->qKmerA.reserve(n * 8 + 64)) || (rc = c->qReadA.reserve(n * 4 + 64)) || (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)))
+    if ((rc = c->qKmerA.reserve(n * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(n * 4 + 64)) || (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)))
         return rc;
-    if (n) HIPCHK(hipMemcpyAsync(c->qKmerA.p, kmers, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) HIPCHK(hipMemcpyAsync(c->qKmerA.p, kmers, n * c->keyBytes(), hipMemcpyHostToDevice, c->stream));
     if (n) HIPCHK(hipMemcpyAsync(c->qReadA.p, reads, n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->kmerOff.p, koff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->nReads = nReads; c->nQ = n; c->maxCnt = maxCnt;
-    c->qKmer = c->qKmerA.as<uint64_t>(); c->qRead = c->qReadA.as<uint32_t>();
+    c->qKmer = c->qKmerA.p; c->qRead = c->qReadA.as<uint32_t>();
     c->state = 2;
     return KASA_OK;
 }

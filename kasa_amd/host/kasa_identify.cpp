@@ -7,7 +7,7 @@
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
 // Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize, paired-end,
-// custom alphabets/codon tables, 128-bit (k <= 25) indices.
+// custom alphabets/codon tables.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -252,7 +252,8 @@ static ReadSet readInput(const string &path, bool verbose) // what Read.hpp:699-
 // ---------------------------------------------------------------------------------------------------
 struct Params {
     string content, index, input, rtt, profile;
-    int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0;
+    int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
+    bool kSetByUser = false;
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
@@ -298,7 +299,7 @@ struct Writer {
         int64_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
             if (!(score[i] > 0.f)) continue;
-            const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - (p.protein ? 12 : 12 * 3) + 1)))); // Compare.hpp:1506-1511
+            const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - (p.protein ? p.K : p.K * 3) + 1)))); // Compare.hpp:1506-1511
             if (rel >= p.threshold) { res[cnt] = std::make_tuple((size_t)tax[i], score[i], rel); ++cnt; }
         }
         if (cnt == 0) {
@@ -434,8 +435,8 @@ static int run(int argc, char **argv)
         else if (s == "-i" || s == "--input") { p.input = next(); if (!std::ifstream(p.input)) throw std::runtime_error("Input file not found"); }
         else if (s == "-q" || s == "--rtt") p.rtt = next();
         else if (s == "-p" || s == "--profile") p.profile = next();
-        else if (s == "-k") { p.kHigh = std::stoi(next()); p.kLow = std::stoi(next()); if (p.kHigh > 25) p.kHigh = 25; if (p.kLow < 1) p.kLow = 1; if (p.kLow > p.kHigh) std::swap(p.kLow, p.kHigh); }
-        else if (s == "--kH") { p.kHigh = std::min(25, std::stoi(next())); }
+        else if (s == "-k") { p.kSetByUser = true; p.kHigh = std::stoi(next()); p.kLow = std::stoi(next()); if (p.kHigh > 25) p.kHigh = 25; if (p.kLow < 1) p.kLow = 1; if (p.kLow > p.kHigh) std::swap(p.kLow, p.kHigh); }
+        else if (s == "--kH") { p.kSetByUser = true; p.kHigh = std::min(25, std::stoi(next())); }
         else if (s == "--kL") { p.kLow = std::max(1, std::stoi(next())); }
         else if (s == "-b" || s == "--beasts") p.beasts = std::stoi(next());
         else if (s == "--json") p.fmt = Params::Json;
@@ -460,10 +461,14 @@ static int run(int argc, char **argv)
     std::ifstream info(p.index + "_info.txt");
     if (!info) throw std::runtime_error("Info file for this index can not be found!");
     uint64_t nRec = 0, vecType = 0; info >> nRec; info >> vecType;
-    if (vecType == 128) throw std::runtime_error("128-bit (k <= 25) indices are not supported by the MI355X identify path yet");
-    const int recBytes = vecType == 3 ? 6 : 12;                        // 3: halved index of shrink strategy 2
-    if (p.kHigh > 12) { std::cerr << "WARNING: This index can not be used with a k higher than 12! Setting to this maximum..." << std::endl; p.kHigh = 12; }
-    if (p.kLow > 12) p.kLow = 12;
+    const int recBytes = vecType == 128 ? 20 : (vecType == 3 ? 6 : 12);   // 128: k <= 25 index, 3: halved index of shrink strategy 2
+    if (vecType == 128) {
+        p.K = 25;
+        if (!p.kSetByUser) p.kHigh = 25;                               // main.cpp:1065-1067
+    } else {
+        if (p.kHigh > 12) { std::cerr << "WARNING: This index can not be used with a k higher than 12! Setting to this maximum..." << std::endl; p.kHigh = 12; }
+        if (p.kLow > 12) p.kLow = 12;
+    }
     if (p.content.empty()) p.content = p.index + "_content.txt";
     const Content content = loadContent(p.content);
     const vector<uint64_t> freq = loadFreqAtK(p.index, content.names.size(), p.kHigh);

@@ -59,7 +59,7 @@ class Identify:
                 for r in range(part.n):
                     lo, hi = int(off[r]), int(off[r + 1])
                     rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(part.lengths[r]), freq, self.k_high,
-                                          self.k_low, self.frames, self.threshold, self.beasts, protein=protein)
+                                          self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
                     out.append(writer.read(self.n_reads + r, part.names[r], int(part.lengths[r]), rk))
             self.n_reads += part.n
             a = b

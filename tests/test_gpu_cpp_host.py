@@ -45,3 +45,30 @@ def test_cpp_host_errors_like_the_reference(tmp_path):
     assert r.returncode == 1 and r.stderr.startswith("ERROR: ")
     r = subprocess.run([exe, "identify", "--frobnicate"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert r.returncode == 1 and "unknown parameter" in r.stderr
+
+
+def test_cpp_host_wide_index(tmp_path):
+    """128-bit index through the C++ driver: default k range (25..7, main.cpp:1065-1067) and -k 12 7, against the
+    oracle's closed form rendered by the Python host writers."""
+    import os as _os
+    from kasa_amd import reads
+    from tests.test_oracle_golden import WIDE
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d, ix = helpers.load_case("pairs", "idx25")
+    batch = reads.parse_reads(_os.path.join(d, "reads.fastq"))
+    for stem, kh, kl, frames in WIDE:
+        out, prof = str(tmp_path / ("out_" + stem)), str(tmp_path / ("prof_" + stem))
+        cmd = [exe, "identify", "-c", _os.path.join(d, "content.txt"), "-d", _os.path.join(d, "idx25"), "-i",
+               _os.path.join(d, "reads.fastq"), "-q", out, "-p", prof, "--jsonl", "-b", "100", "-n", "1"]
+        if (kh, kl) != (25, 7):
+            cmd += ["-k", str(kh), str(kl)]
+        if frames == 6:
+            cmd.append("--six")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=True)
+        text, ptext = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique, nq,
+                                     "jsonl", kh, kl, frames, 0.0, 100)
+        assert _read(out) == text
+        assert _read(prof) == ptext

@@ -107,7 +107,7 @@ def test_adversarial_queries_vs_oracle(seed, slow):
     ctx.close(); dix.close()
 
 
-def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150):
+def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150, K=12):
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
     genomes = []
@@ -121,7 +121,7 @@ def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150):
         genomes.append(s)
     content = formats.Content(["non_unique"] + [f"Taxon {g}" for g in range(n_taxa)],
                               np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
-    p = oracle.params(12, 7, 3)
+    p = oracle.params(K, 7, 3, K=K)
     kms, tids = [], []
     for g, s in enumerate(genomes):  # index = forward k-mers of every genome (3 frames), as `build --three`
         km, _ = oracle.encode(s, np.array([0, genome_len], dtype=np.int64), p)
@@ -221,7 +221,7 @@ def test_profile_limbs_roundtrip_and_sum():
 
 
 def _check_against_oracle(ix, batch, kh, kl, frames, flags=0, unique=False, protein=False):
-    p = oracle.params(kh, kl, frames, protein=protein)
+    p = oracle.params(kh, kl, frames, K=ix.K, protein=protein)
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, unique=unique)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, kl, frames)
@@ -347,3 +347,57 @@ def test_many_taxa_per_read_and_large_content():
     _check_against_oracle(ix, batch, 12, 7, 3, flags=4)
     _check_against_oracle(ix, batch, 12, 7, 3, flags=1)
     assert slow >= 0
+
+
+# ---- 128-bit index (k <= 25) ----------------------------------------------------------------------------------------
+from tests.test_oracle_golden import WIDE  # noqa: E402
+
+
+@pytest.mark.parametrize("case", WIDE, ids=[c[0] for c in WIDE])
+def test_wide_index_golden_inputs(case):
+    """The reference's own --kH 25 index: every stage against the 128-bit oracle, and the rendered files against the
+    oracle's closed form (the parity target: the stock binary compares 128-bit k-mers through a 64-bit functor,
+    tests/test_oracle_golden.py::test_wide_index_stock_binary_and_parity_target)."""
+    _gpu_or_fail()
+    stem, kh, kl, frames = case
+    d, ix = helpers.load_case("pairs", "idx25")
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    p = oracle.params(kh, kl, frames, K=25)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, kh, kl, frames)
+    ctx.upload(batch.bases, batch.offsets)
+    n = ctx.encode()
+    km_o, rd_o = oracle.encode(batch.bases, batch.offsets, p)
+    km_g, rd_g = ctx.queries()
+    assert n == km_o.shape[0] and np.array_equal(km_g, km_o) and np.array_equal(rd_g, rd_o)
+    ctx.sort_and_range()
+    km_s, rd_s = ctx.queries()
+    km_os, rd_os = oracle.sort_queries(km_o, rd_o)
+    assert np.array_equal(km_s, km_os) and np.array_equal(rd_s, rd_os)
+    ctx.lookup_score(True)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form=True)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.close()
+    idf = Identify(ix, 0, kh, kl, frames, 0.0, 100, "jsonl", dix=dix)
+    text, prof, _ = idf.run(batch)
+    want = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique, nq, "jsonl",
+                          kh, kl, frames, 0.0, 100)
+    assert (text, prof) == want
+    idf.close(); dix.close()
+
+
+@pytest.mark.parametrize("krange", [(25, 7), (25, 20), (12, 7), (18, 13), (25, 1)])
+@pytest.mark.parametrize("flags", [0, 2])
+def test_wide_index_synthetic(krange, flags):
+    """8 taxa x 6 kb with 128-bit keys, 400 reads over several tiles: fast (<= 6 levels) and general score kernels,
+    streaming and per-query lookup, -e, --six."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(61, 8, 6000, 400, K=25)
+    assert ix.K == 25
+    _check_against_oracle(ix, batch, krange[0], krange[1], 3, flags)
+    if krange == (25, 20):
+        _check_against_oracle(ix, batch, 25, 20, 6, flags)
+        _check_against_oracle(ix, batch, 25, 20, 3, flags, unique=True)
