@@ -33,13 +33,17 @@ def content_for(n_taxa: int) -> formats.Content:
                            np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
 
 
-def index_from_genomes(g: np.ndarray, device: int = 0) -> formats.Index:
-    """Encode every genome on the device (3 frames, K = 12), sort, unique -> formats.Index."""
+def index_from_genomes(g: np.ndarray, device: int = 0, K: int = formats.K64) -> formats.Index:
+    """Encode every genome on the device (3 frames, K = 12 or 25 letters), sort, unique -> formats.Index."""
     n_taxa, length = g.shape
     content = content_for(n_taxa)
-    boot = formats.make_index(np.array([1], dtype=np.uint64), np.array([100], dtype=np.uint32), content)
+    one = np.array([1], dtype=np.uint64)
+    if K > formats.K64:
+        one = np.zeros(1, dtype=formats.KEY128_DTYPE)
+        one["lo"] = 1
+    boot = formats.make_index(one, np.array([100], dtype=np.uint32), content)
     dix = capi.DeviceIndex(boot, device, check_trie=False)
-    ctx = capi.Context(dix, 12, 12, 3)           # kLow = K: no X marker, every window is a full 12-mer
+    ctx = capi.Context(dix, K, K, 3)             # kLow = K: no X marker, every window is a full K-mer
     off = np.arange(n_taxa + 1, dtype=np.int64) * length
     ctx.upload(g.reshape(-1), off)
     ctx.encode()
@@ -53,7 +57,7 @@ def index_from_genomes(g: np.ndarray, device: int = 0) -> formats.Index:
     km, tid = km[keep], tid[keep]
     tax = (rd[keep] + 1).astype(np.uint32)
     tp, tc = formats.trie_from_kmers(km)
-    freq = np.zeros((content.n_taxa, formats.K64), dtype=np.uint64)
+    freq = np.zeros((content.n_taxa, K), dtype=np.uint64)
     cnt = np.bincount(tax, minlength=content.n_taxa).astype(np.uint64)
     freq[:] = cnt[:, None]                        # no '^' letters in these k-mers: same count at every k
     return formats.Index(km, tid.astype(np.uint32), tax, tp, tc, content, freq)
