@@ -456,6 +456,8 @@ struct kasa_ctx {
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
+    DevBuf ovList;                             // reads the first general pass hands to the second
+    uint32_t lastOverflowReads = 0;
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profUniq, profSums;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
     DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
@@ -571,7 +573,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -1428,6 +1430,7 @@ struct ScoreArgs {
     int addProfile;                              // 0 on a rerun that only re-emits rows
     const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
+    uint32_t *ovList, *ovCount;                  // slow kernel, first pass: reads it hands to the second pass (NULL = last pass)
     uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
 };
@@ -1449,31 +1452,74 @@ __device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uin
     if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
 }
 
+static constexpr int AGG = 256;                                   // per-read profile aggregation table (LDS)
+static constexpr int PCAP_SMALL = 96;                              // pending window of the first pass (small LDS footprint: many wavefronts per CU)
+static constexpr unsigned long long AGG_EMPTY = ~0ull;
+
+__device__ __forceinline__ void profile_add(const ScoreArgs &A, int lv, uint32_t tx, uint32_t n, unsigned long long c)
+{
+    const size_t cell = (size_t)lv * A.nTaxa + tx;
+    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], c);
+    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c, n);
+}
+
+// PC = capacity of the pending window.  The kernel is latency-bound (dependent gathers per query and per taxon
+// list), so the first pass runs with a small window -- little LDS, many resident wavefronts -- and hands the rare
+// read that overflows it (or the aggregation table) to a second pass with the full window.  A read that is handed on
+// leaves nothing behind: its score cells are cleared again and its profile counts never left LDS.
+template <int PC>
 __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 {
-    __shared__ uint32_t pF[PCAP], pRef[PCAP];
-    __shared__ uint32_t pCnt[PCAP];
-    __shared__ uint8_t pK[PCAP];
+    __shared__ unsigned long long aKey[AGG];
+    __shared__ uint32_t aCnt[AGG];
+    __shared__ uint32_t pF[PC], pRef[PC];
+    __shared__ uint32_t pCnt[PC];
+    __shared__ uint8_t pK[PC];
     __shared__ uint32_t sTouched;
     __shared__ uint32_t sList[TLIST];
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
     float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
 
+    for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
     const uint32_t nWork = A.list ? A.nList : A.nReads;
     for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
         const uint32_t r = A.list ? A.list[wi] : wi;
         const uint64_t o0 = A.kmerOff[r];
         const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
         int head = 0, tail = 0;            // pending window [head, tail), sorted by (F, k) ascending
+        uint32_t cTax = 0xFFFFFFFFu;       // this lane's cached score cell (taxa with tx % 64 == lane live here)
+        float cVal = 0.0f;
+        const bool mayHandOn = A.ovList != nullptr;
+        bool ovf = false;                  // this read does not fit this pass (per lane; combined with a ballot)
         if (lane == 0) sTouched = 0;
         __syncthreads();
 
-        // apply the pending entry at `e` (all lanes call it with the same e)
-        auto apply = [&](int e) {
-            const uint32_t ref = pRef[e];
-            const int k = pK[e];
-            const uint32_t c = pCnt[e];
+        // c hits for the score cell of taxon tx; called by the lane that owns the cell (tx % 64 == lane).  The lane keeps
+        // the cell it touched last in a register: a read's events go almost all to one or two taxa, and a
+        // load-add-store chain through global memory per event would cost a round trip each.
+        auto cellAdd = [&](const uint32_t tx, const float sc, const uint32_t c) {
+            if (cTax != tx) {
+                if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
+                cVal = score[tx];
+                cTax = tx;
+                if (cVal == 0.0f) { const uint32_t ti = atomicAdd(&sTouched, 1u); if (ti < (uint32_t)TLIST) sList[ti] = tx; }
+            }
+            for (uint32_t j = 0; j < c; ++j) cVal = __fadd_rn(cVal, sc);      // Compare.hpp:528-530, one add per hit
+        };
+        // profile counts of this read are summed per (level, |T|, taxon) in LDS first and leave as one set of atomics
+        // per distinct key at the end of the read (device-scope atomics are the scarce resource); any lane may call it
+        auto aggAdd = [&](const int lv, const uint32_t n, const uint32_t tx, const uint32_t c) {
+            const unsigned long long key = ((unsigned long long)lv << 52) | ((unsigned long long)n << 32) | tx;
+            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (AGG - 1);
+            for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (AGG - 1)) {
+                const unsigned long long seen = atomicCAS(&aKey[h], AGG_EMPTY, key);
+                if (seen == AGG_EMPTY || seen == key) { atomicAdd(&aCnt[h], c); return; }
+            }
+            if (mayHandOn) ovf = true; else profile_add(A, lv, tx, n, c);
+        };
+        // one flushed group (level k, taxon-set reference, c hits of this read); all lanes call it with the same values
+        auto applyVals = [&](const int k, const uint32_t ref, const uint32_t c) {
             const int lv = A.kHigh - k;
             uint32_t n; const uint32_t *list; uint32_t single = 0, pairB = 0;
             if (ref & REF_SINGLE) { n = 1; single = ref & 0x7FFFFFFFu; list = nullptr; }
@@ -1484,27 +1530,71 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
             for (uint32_t i = 0; i < n; ++i) {
                 const uint32_t tx = list ? list[i] : (i == 0 ? single : pairB);
                 if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
-                if (A.wantPerRead) {
-                    float v = score[tx];
-                    if (v == 0.0f) { const uint32_t ti = atomicAdd(&sTouched, 1u); if (ti < (uint32_t)TLIST) sList[ti] = tx; }
-                    for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);    // Compare.hpp:528-530, one add per hit
-                    score[tx] = v;
-                }
-                if (A.addProfile) {
-                    const size_t cell = (size_t)lv * A.nTaxa + tx;
-                    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], (unsigned long long)c);
-                    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c, n);
-                }
+                if (A.wantPerRead) cellAdd(tx, s, c);
+                if (A.addProfile) aggAdd(lv, n, tx, c);
             }
         };
+        auto apply = [&](int e) { applyVals((int)pK[e], pRef[e], pCnt[e]); };   // the pending entry at `e`
 
+        uint32_t pnext = cnt ? A.plist[o0] : 0u;
         for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t p = A.plist[o0 + j];
+            const uint32_t p = pnext;
+            pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
+            if (mayHandOn && __ballot(ovf) != 0ull) { ovf = true; break; }
             // everything that flushes at or before p precedes all events of this and later queries
             while (head < tail && pF[head] <= p) { apply(head); ++head; }
             if (head == tail) head = tail = 0;
             uint32_t myF = 0, myRef = 0;
             if (lane < nK) { const uint2 v = A.rec[(size_t)p * nK + lane]; myF = v.x; myRef = v.y; }
+            // The usual case: nothing is pending and every group of this query closes before the read's next query.
+            // Then its events need no window.  Lane o holds the event of level k = kHigh - o: every lane decodes its own
+            // event and files its profile counts (lane-parallel); only the float additions are replayed one event at a
+            // time, in (F, k) order, each by the lane that owns the cell.
+            const bool has = myRef != 0u;                                    // lanes >= nK hold 0
+            if (head == tail && __ballot(has && myF > pnext) == 0ull) {
+                uint32_t rank = 0;
+                for (int o = 0; o < nK; ++o) {
+                    const uint32_t oF = __shfl(myF, o), oR = __shfl(myRef, o);
+                    if (oR != 0u && (oF < myF || (oF == myF && o > lane))) ++rank;
+                }
+                uint32_t eN = 0, eT0 = 0, eT1 = 0;
+                float eS = 0.0f;
+                bool isList = false;
+                if (has) {
+                    if (myRef & REF_SINGLE) { eN = 1; eT0 = myRef & 0x7FFFFFFFu; }
+                    else if (myRef & REF_PAIR) { eN = 2; eT0 = (myRef >> 15) & 0x7FFFu; eT1 = myRef & 0x7FFFu; }
+                    else { eN = A.pool[myRef]; isList = true; }
+                    const int k = A.kHigh - lane;
+                    eS = __fmul_rn((float)(k * k) / 625.0f, __fdiv_rn(1.0f, (float)eN));   // Compare.hpp:392,924
+                    if (A.addProfile && !isList) { aggAdd(lane, eN, eT0, 1u); if (eN == 2) aggAdd(lane, 2u, eT1, 1u); }
+                }
+                const int nEv = __popcll(__ballot(has));
+                for (int rk = 0; rk < nEv; ++rk) {
+                    const int src = __ffsll((long long)__ballot(has && rank == (uint32_t)rk)) - 1;
+                    const uint32_t n = __shfl(eN, src);
+                    const float sc = __shfl(eS, src);
+                    if (!__shfl((int)isList, src)) {
+                        const uint32_t t0 = __shfl(eT0, src), t1 = __shfl(eT1, src);
+                        if (A.wantPerRead) {
+                            if ((t0 & 63u) == (uint32_t)lane) cellAdd(t0, sc, 1u);
+                            if (n == 2 && (t1 & 63u) == (uint32_t)lane) cellAdd(t1, sc, 1u);
+                        }
+                    } else {
+                        const uint32_t ref = __shfl(myRef, src);
+                        for (uint32_t b0 = 0; b0 < n; b0 += 64) {             // the taxon list, 64 entries at a time
+                            const uint32_t cntHere = (n - b0 < 64u) ? n - b0 : 64u;
+                            const uint32_t tx = ((uint32_t)lane < cntHere) ? A.pool[ref + 1 + b0 + lane] : 0xFFFFFFFFu;
+                            if (A.addProfile && tx != 0xFFFFFFFFu) aggAdd(src, n, tx, 1u);
+                            if (A.wantPerRead)
+                                for (uint32_t i = 0; i < cntHere; ++i) {
+                                    const uint32_t t = __shfl(tx, (int)i);
+                                    if ((t & 63u) == (uint32_t)lane) cellAdd(t, sc, 1u);
+                                }
+                        }
+                    }
+                }
+                continue;
+            }
             for (int lv = nK - 1; lv >= 0; --lv) {                            // k ascending
                 const uint32_t F = __shfl(myF, lv);
                 const uint32_t ref = __shfl(myRef, lv);
@@ -1529,7 +1619,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     __syncthreads();
                     continue;
                 }
-                if (tail >= PCAP) {
+                if (tail >= PC) {
                     if (head > 0) {                                           // compact the window to the front
                         for (int b0 = head; b0 < tail; b0 += 64) {
                             const int e = b0 + lane;
@@ -1541,7 +1631,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                         }
                         pos -= head; tail -= head; head = 0;
                     }
-                    if (tail >= PCAP) { if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
+                    if (tail >= PC) { if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
                 }
                 for (int hi = tail; hi > pos; hi -= 64) {                     // shift [pos, tail) right by one
                     const int e = hi - 1 - lane;
@@ -1556,8 +1646,28 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                 __syncthreads();
             }
         }
-        while (head < tail) { apply(head); ++head; }
+        if (!ovf) while (head < tail) { apply(head); ++head; }
+        ovf = mayHandOn && (__ballot(ovf) != 0ull);
+        if (ovf) {                                                            // hand the read on, leave no trace
+            __syncthreads();
+            const uint32_t m = sTouched;
+            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
+            for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
+            if (lane == 0) A.ovList[atomicAdd(A.ovCount, 1u)] = r;
+            __syncthreads();
+            continue;
+        }
+        if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
+        __threadfence_block();
         __syncthreads();
+        if (A.addProfile)
+            for (int i = lane; i < AGG; i += 64) {
+                const unsigned long long key = aKey[i];
+                if (key == AGG_EMPTY) continue;
+                profile_add(A, (int)(key >> 52), (uint32_t)key, (uint32_t)(key >> 32) & 0xFFFFFu, aCnt[i]);
+                aKey[i] = AGG_EMPTY; aCnt[i] = 0u;
+            }
 
         // ---- emit the row (taxon ascending) and clear the dense row
         if (A.wantPerRead) {
@@ -2154,6 +2264,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         A.addProfile = slowProfileDone ? 0 : 1;
         A.list = nullptr; A.nList = 0;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
+        A.ovList = nullptr; A.ovCount = nullptr;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
         uint32_t h[3] = {0, 0, 0};
@@ -2175,12 +2286,26 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         if (nSlow > 0) {
-            const uint32_t blocks = std::min<uint32_t>(nSlow, 256u * 16u);
-            if ((rc = c->scratch.reserve((size_t)blocks * nTaxa * 4))) return rc;
-            HIPCHK(hipMemsetAsync(c->scratch.p, 0, (size_t)blocks * nTaxa * 4, c->stream));
+            const uint64_t rowBytes = (uint64_t)nTaxa * 4;
+            const uint32_t maxBlocks = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(256u * 32u, (8ull << 30) / rowBytes));
+            const uint32_t blocks = std::min<uint32_t>(nSlow, maxBlocks);
+            if ((rc = c->scratch.reserve((size_t)blocks * rowBytes)) || (rc = c->ovList.reserve((size_t)nSlow * 4 + 64))) return rc;
+            HIPCHK(hipMemsetAsync(c->scratch.p, 0, (size_t)blocks * rowBytes, c->stream));
+            HIPCHK(hipMemsetAsync(counters + 5, 0, 4, c->stream));
             A.scratch = c->scratch.as<float>();
-            score_kernel<<<blocks, 64, 0, c->stream>>>(A);
+            A.ovList = c->ovList.as<uint32_t>(); A.ovCount = counters + 5;
+            score_kernel<PCAP_SMALL><<<blocks, 64, 0, c->stream>>>(A);      // leaves every score row zeroed again
             HIPCHK(hipGetLastError());
+            uint32_t nOver = 0;
+            HIPCHK(hipMemcpyAsync(&nOver, counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (nOver > 0) {
+                A.list = c->ovList.as<uint32_t>(); A.nList = nOver;
+                A.ovList = nullptr; A.ovCount = nullptr;
+                score_kernel<PCAP><<<std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u)), 64, 0, c->stream>>>(A);
+                HIPCHK(hipGetLastError());
+            }
+            c->lastOverflowReads = nOver;
             slowProfileDone = true;
         }
         c->lastSlowReads = nSlow;
@@ -2452,7 +2577,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
