@@ -1276,42 +1276,76 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 
 // One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
 // taxon-set references (leaders compute them, members copy them through LDS).
+// One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
+// taxon-set references (leaders compute them, members copy them through LDS).
+// Positions grow with the thread index, so "next special position to the right" is the first special of the nearest
+// thread to the right that has one, and "my group's leader" is the last leader of the nearest thread to the left that
+// has one: inside a wavefront a ballot finds that thread, across wavefronts four LDS slots do.  `xs` = exchange slots
+// of this level (levels alternate between two sets, so one barrier per exchange is enough).
+struct GroupExchange { uint32_t firstSp[TILE_THREADS / 64]; int lastLeader[TILE_THREADS / 64]; uint32_t info[TILE]; };
+
 template <class Meta>
 __device__ __forceinline__ void group_level(
     int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[ITEMS], const uint8_t (&d)[ITEMS], const uint32_t (&rp)[ITEMS],
     const uint32_t *__restrict__ tileNext, uint32_t nTiles, const Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
-    uint64_t *__restrict__ cntTotal, uint32_t nTaxa, uint32_t *shU, int *shI, uint32_t *sInfo, uint32_t *sBase,
+    uint64_t *__restrict__ cntTotal, uint32_t nTaxa, GroupExchange &xs, uint32_t *shU, uint32_t *sBase,
     uint32_t (&F)[ITEMS], uint32_t (&R)[ITEMS])
 {
     const int k = kHigh - lv;
     const int g = group_letters(k);
-    // ---- flush position: next position that closes the level-k group (suffix scan)
-    bool sp[ITEMS];
+    const int lane = t & 63, wv = t >> 6;
+    const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // ---- this thread's special positions and leaders
+    bool sp[ITEMS], leader[ITEMS];
     uint32_t firstSp = NOPOS;
+    int lastLeader = -1;
 #pragma unroll
     for (int i = ITEMS - 1; i >= 0; --i) {
         const uint32_t p = base + i;
         sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
         if (sp[i]) firstSp = p;
     }
-    uint32_t carry = block_excl_suffix_min(firstSp, shU);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const bool matched = (base + i < nQ) && d[i] >= k;
+        leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));   // first query of a level-k group, or the first matched query of the tile
+        if (leader[i]) lastLeader = t * ITEMS + i;
+    }
+    // ---- nearest neighbours inside the wavefront
+    const unsigned long long mSp = __ballot(firstSp != NOPOS);
+    const unsigned long long mLd = __ballot(lastLeader >= 0);
+    uint32_t carry = NOPOS;
+    {
+        const unsigned long long hi = mSp & above;
+        const int src = hi ? (__ffsll((long long)hi) - 1) : lane;
+        const uint32_t v = __shfl(firstSp, src);
+        if (hi) carry = v;
+    }
+    int lead = -1;
+    {
+        const unsigned long long lo = mLd & below;
+        const int src = lo ? (63 - __clzll((long long)lo)) : lane;
+        const int v = __shfl(lastLeader, src);
+        if (lo) lead = v;
+    }
+    {
+        const uint32_t wFirst = __shfl(firstSp, mSp ? (__ffsll((long long)mSp) - 1) : 0);
+        const int wLast = __shfl(lastLeader, mLd ? (63 - __clzll((long long)mLd)) : 0);
+        if (lane == 0) { xs.firstSp[wv] = mSp ? wFirst : NOPOS; xs.lastLeader[wv] = mLd ? wLast : -1; }
+    }
+    __syncthreads();
+    if (carry == NOPOS)
+        for (int w = wv + 1; w < TILE_THREADS / 64; ++w) { const uint32_t o = xs.firstSp[w]; if (o != NOPOS) { carry = o; break; } }
+    if (lead < 0)
+        for (int w = wv - 1; w >= 0; --w) { const int o = xs.lastLeader[w]; if (o >= 0) { lead = o; break; } }
     if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
 #pragma unroll
     for (int i = ITEMS - 1; i >= 0; --i) {
         F[i] = carry;
         if (sp[i]) carry = base + i;
     }
-    // ---- group leaders: first query of a level-k group, or the first matched query of the tile
-    int lastLeader = -1;
-    bool leader[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        const bool matched = (base + i < nQ) && d[i] >= k;
-        leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));
-        if (leader[i]) lastLeader = t * ITEMS + i;
-    }
-    int lead = block_excl_prefix_max(lastLeader, shI);
     // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
     // with ONE allocation per workgroup and level
     uint32_t ga[ITEMS], gb[ITEMS], gn[ITEMS], gref[ITEMS];
@@ -1325,9 +1359,9 @@ __device__ __forceinline__ void group_level(
             if (gref[i] == 0u) need += gn[i] + 1;
         }
     }
-    uint32_t total = 0;
-    uint32_t off = block_excl_prefix_sum(need, shU, total);
-    if (total) {                                                   // uniform across the workgroup
+    if (__syncthreads_or(need != 0u)) {                             // uniform across the workgroup
+        uint32_t total = 0;
+        uint32_t off = block_excl_prefix_sum(need, shU, total);
         if (t == 0) *sBase = atomicAdd(poolCursor, total);
         __syncthreads();
         off += *sBase;
@@ -1340,15 +1374,14 @@ __device__ __forceinline__ void group_level(
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-        if (leader[i]) sInfo[t * ITEMS + i] = gref[i];
+        if (leader[i]) xs.info[t * ITEMS + i] = gref[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         if (leader[i]) lead = t * ITEMS + i;
         const bool matched = (base + i < nQ) && d[i] >= k;
-        R[i] = (matched && lead >= 0) ? sInfo[lead] : 0u;
+        R[i] = (matched && lead >= 0) ? xs.info[lead] : 0u;
     }
-    __syncthreads();
 }
 
 // NKR > 0: all levels of a query are collected in registers and written as one contiguous record (nK <= NKR);
@@ -1361,8 +1394,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
     uint32_t *__restrict__ poolCursor, int coverage, uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
 {
     __shared__ uint32_t shU[TILE_THREADS];
-    __shared__ int shI[TILE_THREADS];
-    __shared__ uint32_t sInfo[TILE];
+    __shared__ GroupExchange xs[2];                               // levels alternate: no barrier needed before reuse
     __shared__ uint32_t sBase;
     const int nK = kHigh - kLow + 1;
     const int t = threadIdx.x;
@@ -1387,7 +1419,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
             for (int i = 0; i < ITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
             if (lv < nK)                                          // uniform: barriers inside are safe
                 group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                            coverage, cntTotal, nTaxa, shU, shI, sInfo, &sBase, allF[lv], allR[lv]);
+                            coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, allF[lv], allR[lv]);
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -1409,7 +1441,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
         for (int lv = 0; lv < nK; ++lv) {
             uint32_t F[ITEMS], R[ITEMS];
             group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                        coverage, cntTotal, nTaxa, shU, shI, sInfo, &sBase, F, R);
+                        coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, F, R);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i)
                 if (base + i < nQ) rec[(size_t)(base + i) * nK + lv] = make_uint2(F[i], R[i]);
