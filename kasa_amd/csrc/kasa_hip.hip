@@ -1212,17 +1212,20 @@ __device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
 
 // Step 1: bounds [a, b) of the group, its number of distinct taxa, and the 32-bit encoding when it fits
 // inline (0 = needs n + 1 words in the pool).
+// mPrev / mNext / tx0: letters entry j shares with j-1, letters entry j+1 shares with j (0 past the end), taxon of j --
+// the same for every level of a query, so the kernel gathers them once per query, all queries of a thread at once.
 template <class Meta>
 __device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const Meta *__restrict__ meta,
                                                const uint32_t *__restrict__ tax, uint32_t nIdx, bool coverage,
-                                               uint64_t *__restrict__ cntTotalLv, uint32_t &a, uint32_t &b, uint32_t &n)
+                                               uint64_t *__restrict__ cntTotalLv, int mPrev, int mNext, uint32_t tx0,
+                                               uint32_t &a, uint32_t &b, uint32_t &n)
 {
     constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;   // KeyTraits::META_MASK / META_SHIFT
     a = j; b = j + 1;
-    const bool openLeft = (j > 0) && (int)(meta[j] & LM) >= g;
-    const bool openRight = (b < nIdx) && (int)(meta[b] & LM) >= g;
+    const bool openLeft = (j > 0) && mPrev >= g;
+    const bool openRight = (b < nIdx) && mNext >= g;
     if (!openLeft && !openRight) {                       // the group is this one entry (the common case)
-        const uint32_t t0 = tax[j];
+        const uint32_t t0 = tx0;
         if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[t0], 1ull);
         n = 1;
         return REF_SINGLE | t0;
@@ -1290,6 +1293,7 @@ __device__ __forceinline__ void group_level(
     const uint32_t *__restrict__ tileNext, uint32_t nTiles, const Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa, GroupExchange &xs, uint32_t *shU, uint32_t *sBase,
+    const uint8_t (&mPrev)[ITEMS], const uint8_t (&mNext)[ITEMS], const uint32_t (&tx0)[ITEMS],
     uint32_t (&F)[ITEMS], uint32_t (&R)[ITEMS])
 {
     const int k = kHigh - lv;
@@ -1355,7 +1359,7 @@ __device__ __forceinline__ void group_level(
         gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
         if (leader[i]) {
             gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
-                                 ga[i], gb[i], gn[i]);
+                                 (int)mPrev[i], (int)mNext[i], tx0[i], ga[i], gb[i], gn[i]);
             if (gref[i] == 0u) need += gn[i] + 1;
         }
     }
@@ -1411,6 +1415,21 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
             rp[i] = rep[p];
         } else { ql[i] = 0; d[i] = 0; rp[i] = 0; }
     }
+    // the index neighbourhood of every matched query, gathered once (it is the same at every level) and for all of the
+    // thread's queries at once: twelve independent loads in flight instead of a dependent chain per level
+    constexpr int LM = KeyTraits<Key>::META_MASK;
+    uint8_t mPrev[ITEMS], mNext[ITEMS];
+    uint32_t tx0[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        mPrev[i] = 0; mNext[i] = 0; tx0[i] = 0;
+        if (d[i] > 0) {
+            const uint32_t j = rp[i];
+            mPrev[i] = (uint8_t)(meta[j] & LM);
+            if (j + 1 < nIdx) mNext[i] = (uint8_t)(meta[j + 1] & LM);
+            tx0[i] = tax[j];
+        }
+    }
     if constexpr (NKR > 0) {
         uint32_t allF[NKR][ITEMS], allR[NKR][ITEMS];
 #pragma unroll
@@ -1419,7 +1438,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
             for (int i = 0; i < ITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
             if (lv < nK)                                          // uniform: barriers inside are safe
                 group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                            coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, allF[lv], allR[lv]);
+                            coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, allF[lv], allR[lv]);
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -1441,7 +1460,7 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
         for (int lv = 0; lv < nK; ++lv) {
             uint32_t F[ITEMS], R[ITEMS];
             group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                        coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, F, R);
+                        coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, F, R);
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i)
                 if (base + i < nQ) rec[(size_t)(base + i) * nK + lv] = make_uint2(F[i], R[i]);
