@@ -401,3 +401,76 @@ def test_wide_index_synthetic(krange, flags):
     if krange == (25, 20):
         _check_against_oracle(ix, batch, 25, 20, 6, flags)
         _check_against_oracle(ix, batch, 25, 20, 3, flags, unique=True)
+
+
+# ---- BASELINE.json's full size (C2): properties that do not need the oracle to run 1.3e9 queries ---------------------
+def test_full_size_properties():
+    """10 M x 150 bp reads against the 4.2e8-record index of bench.py (scaled down with KASA_TEST_FULL_READS /
+    KASA_TEST_FULL_TAXA when the box is small):
+      * determinism: two runs give identical bytes;
+      * linearity: the integer profile limbs of the whole batch equal the sum over five read shards (what the multi-GPU
+        reduction relies on);
+      * conservation: per level, sum over taxa of countAll = number of sorted queries whose match reaches that level;
+      * shard invariance of the per-read taxon sets (scores may move in the last float digit with the batch);
+      * a random sample of reads against the CPU oracle on the same 5 GB index."""
+    _gpu_or_fail()
+    from kasa_amd import synth
+    n_reads = int(os.environ.get("KASA_TEST_FULL_READS", "10000000"))
+    n_taxa = int(os.environ.get("KASA_TEST_FULL_TAXA", "1400"))
+    g = synth.genomes(n_taxa, 300_000, seed=11)
+    ix = synth.index_from_genomes(g)
+    batch = synth.reads_from_genomes(g, n_reads, 150, seed=1000)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+
+    def run(b):
+        ctx.run_batch(b.bases, b.offsets, True)
+        return ctx.scores()
+
+    ctx.profile_reset()
+    off1, tax1, sc1 = run(batch)
+    limbs1 = ctx.profile_limbs().copy()
+    ca, cu, _ = ctx.profile()
+    depth, _ = ctx.lookup()
+    # conservation
+    for lv in range(6):
+        k = 12 - lv
+        matched = int(np.count_nonzero(depth >= k))
+        assert abs(float(ca[lv].sum()) - matched) <= 1e-9 * max(1, matched), (k, float(ca[lv].sum()), matched)
+    assert int(cu.sum()) > 0
+    # determinism
+    ctx.profile_reset()
+    off2, tax2, sc2 = run(batch)
+    assert np.array_equal(off1, off2) and np.array_equal(tax1, tax2) and np.array_equal(sc1.view(np.uint32), sc2.view(np.uint32))
+    assert np.array_equal(limbs1, ctx.profile_limbs())
+    del off2, tax2, sc2
+    # linearity + shard invariance
+    ctx.profile_reset()
+    shards = 5
+    for s in range(shards):
+        a, b = s * batch.n // shards, (s + 1) * batch.n // shards
+        o, t, v = run(batch.slice(a, b))
+        lo, hi = int(off1[a]), int(off1[b])
+        assert np.array_equal(o, off1[a:b + 1] - off1[a])
+        assert np.array_equal(t, tax1[lo:hi])
+        np.testing.assert_allclose(v, sc1[lo:hi], rtol=2e-5, atol=0)
+    # limbs are stored un-normalised (independent accumulators): compare the folded 128-bit values
+    def fold(l):
+        l = l.reshape(-1, 6).astype(object)
+        return [(int(r[0]), int(r[1]), int(r[2]) + (int(r[3]) << 32) + (int(r[4]) << 64) + (int(r[5]) << 96)) for r in l[::997]], \
+            l[:, :2].astype(np.uint64)
+    f1, u1 = fold(limbs1)
+    f2, u2 = fold(ctx.profile_limbs())
+    assert np.array_equal(u1, u2) and f1 == f2
+    # oracle sample
+    rng = np.random.default_rng(3)
+    pick = np.sort(rng.choice(batch.n, size=min(1500, batch.n), replace=False))
+    sub_b = np.concatenate([batch.bases[int(batch.offsets[r]):int(batch.offsets[r + 1])] for r in pick])
+    sub_o = np.concatenate(([0], np.cumsum([int(batch.offsets[r + 1] - batch.offsets[r]) for r in pick]))).astype(np.int64)
+    res, _ = oracle.identify_batch(ix, sub_b, sub_o, oracle.params(12, 7, 3), True)
+    for i, r in enumerate(pick):
+        t = (np.flatnonzero(res.M[i, 1:] > 0) + 1).astype(np.uint32)
+        lo, hi = int(off1[r]), int(off1[r + 1])
+        assert np.array_equal(tax1[lo:hi], t), r
+        np.testing.assert_allclose(sc1[lo:hi], res.M[i, t], rtol=2e-5, atol=0)
+    ctx.close(); dix.close()
