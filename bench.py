@@ -42,6 +42,17 @@ def cpu_baseline(ix, sample, k_high, k_low):
     return sample.n / dt, dt
 
 
+def stage_gbps(stages, steps, n_q, n_bases, n_idx, rec_bytes, n_k):
+    key = rec_bytes - 4
+    algo = {"encode": n_bases + n_q * rec_bytes, "sort": 2 * n_q * rec_bytes, "lookup": n_q * rec_bytes + n_idx * rec_bytes,
+            "group": n_q * (key + 1 + 4) + n_q * n_k * 8, "regroup": n_q * 8}
+    out = {}
+    for k, b in algo.items():
+        ms = stages.get(k, (0.0,))[0] / max(1, steps)
+        out[k] = (b / (ms * 1e-3) / 1e9) if ms > 0 else None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,7 +62,7 @@ def main():
     ap.add_argument("--taxa", type=int, default=1400)
     ap.add_argument("--genome-len", type=int, default=300_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=600_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="no per-read scores (kASA without -q)")
     ap.add_argument("--wide", action="store_true",
@@ -162,6 +173,11 @@ def main():
             "identified_fraction": identified,
             "reads_on_general_score_kernel": ctx.last_slow_reads(),
             "stage_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stages.items()},
+            # minimum HBM traffic of a stage / its measured time (GB/s).  encode: bases in +
+            # (key, read id) out; sort: one read + one write of the records (the 8 radix passes it really takes are the
+            # implementation's); lookup: as `roofline` but over the whole stage; group: key + depth + rep in, nK x 8 B out
+            "stage_algorithmic_gbps": stage_gbps(stages, args.steps, n_kmers, args.reads * args.read_len, ix.n,
+                                                rec_bytes, k_high - k_low + 1),
             "roofline": {"bound": "hbm", "kernel": "lookup_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg_s * 1e3},
