@@ -219,7 +219,7 @@ static ReadSet readInput(const string &path, bool verbose) // what Read.hpp:699-
     const bool fasta = data[0] == '>';
     rs.protein = detectProtein(data, verbose);
     vector<std::pair<size_t, size_t>> lines; // [begin, end)
-    for (size_t a = 0; a < data.size();) { size_t b = data.find('\n', a); if (b == string::npos) b = data.size(); size_t e = b; if (e > a && data[e - 1] == '\r') --e; lines.emplace_back(a, e); a = b + 1; }
+    for (size_t a = 0; a < data.size();) { size_t b = data.find('\n', a); if (b == string::npos) b = data.size(); lines.emplace_back(a, b);   /* a '\r' stays part of the line, as with the reference's getline */ a = b + 1; }
     size_t i = 0;
     auto isEmpty = [&](size_t k) { return lines[k].first == lines[k].second; };
     while (i < lines.size()) {

@@ -75,12 +75,12 @@ def parse_reads(path: str) -> ReadBatch:
             if lines[i] == b"":
                 i += 1
                 continue
-            name = lines[i][1:].rstrip(b"\r").decode("latin-1") + " "
+            name = lines[i][1:].decode("latin-1") + " "
             i += 1
             parts = []
             while i < n and not lines[i].startswith(b">"):
                 if lines[i] != b"":
-                    parts.append(lines[i].rstrip(b"\r"))
+                    parts.append(lines[i])
                 i += 1
             seq = b"".join(parts)
             names.append(name)
@@ -91,17 +91,17 @@ def parse_reads(path: str) -> ReadBatch:
             if lines[i] == b"":
                 i += 1
                 continue
-            name = lines[i][1:].rstrip(b"\r").decode("latin-1") + " "
+            name = lines[i][1:].decode("latin-1") + " "
             i += 1
             parts = []
             while i < n and not lines[i].startswith(b"+"):
-                parts.append(lines[i].rstrip(b"\r"))
+                parts.append(lines[i])
                 i += 1
             seq = b"".join(parts)
             i += 1  # '+' line
             q = 0
             while i < n and q < len(seq):  # quality: as many characters as bases
-                q += len(lines[i].rstrip(b"\r"))
+                q += len(lines[i])
                 i += 1
             if q > len(seq):
                 raise RuntimeError("Quality string and DNA string do not have the same length!")

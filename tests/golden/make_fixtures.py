@@ -151,6 +151,15 @@ def case_pairs(out):
         for n, s in dup:
             f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
     write_protein_reads(out, genomes)
+    # input formats at the edges of the reader: CRLF line ends (the reference keeps the '\r': it lands in the name, in
+    # "Length" and, as a non-ACGT letter, in the k-mers), a header with spaces and '+name' / '#' quality lines, a last
+    # line without line feed
+    with open(os.path.join(out, "edge_crlf.fasta"), "w", newline="") as f:
+        f.write(">r1 desc\r\n" + g[0][0:80] + "\r\n" + g[0][80:150] + "\r\n>r2\r\n" + g[1][200:350] + "\r\n")
+    with open(os.path.join(out, "edge_multi.fastq"), "w") as f:
+        f.write("@q1\n" + g[3][0:150] + "\n+\n" + "I" * 150 + "\n@q2 x y\n" + g[4][10:100] + "\n+q2\n" + "#" * 90 + "\n")
+    with open(os.path.join(out, "edge_noeol.fasta"), "w") as f:
+        f.write(">r1\n" + g[5][0:150] + "\n>r2\n" + g[5][300:450])
     run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
     base = ["identify", "-c", "content.txt", "-d", "idx", "-m", "4", "-n", "1"]
     runs = {
@@ -174,6 +183,9 @@ def case_pairs(out):
         "unique6.jsonl": ["-i", "reads_dup.fastq", "--jsonl", "-b", "100", "-e", "--six"],
         # amino-acid input (the binary detects it from the first sequence)
         "prot.jsonl": ["-i", "reads_prot.fasta", "--jsonl", "-b", "100"],
+        "edge_crlf.jsonl": ["-i", "edge_crlf.fasta", "--jsonl", "-b", "100"],
+        "edge_multi.jsonl": ["-i", "edge_multi.fastq", "--jsonl", "-b", "100"],
+        "edge_noeol.jsonl": ["-i", "edge_noeol.fasta", "--jsonl", "-b", "100"],
     }
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]

@@ -27,6 +27,9 @@ PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beas
     ("dup.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 3, 0.0, 100),            # reads repeating their own k-mers ...
     ("unique.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 3, 0.0, 100, "idx", True),   # ... and the same with -e
     ("unique6.jsonl", "reads_dup.fastq", "jsonl", 12, 7, 6, 0.0, 100, "idx", True),  # -e --six
+    ("edge_crlf.jsonl", "edge_crlf.fasta", "jsonl", 12, 7, 3, 0.0, 100),     # CRLF: the '\r' stays in name, length, k-mers
+    ("edge_multi.jsonl", "edge_multi.fastq", "jsonl", 12, 7, 3, 0.0, 100),   # header with spaces, '+name', '#' qualities
+    ("edge_noeol.jsonl", "edge_noeol.fasta", "jsonl", 12, 7, 3, 0.0, 100),   # no line feed at the end of the file
 ]
 
 
