@@ -173,17 +173,22 @@ static Content loadContent(const string &path) // Compare.hpp:111-151
     return c;
 }
 
-static vector<uint64_t> loadFreqAtK(const string &prefix, size_t nTaxa, int kHigh) // Compare.hpp:166-179, column of k = kHigh
+// Compare.hpp:166-179: freq[l * nTaxa + t] = k-mers of taxon t at k = kHigh - l
+static vector<uint64_t> loadFreq(const string &prefix, size_t nTaxa, int kHigh, int kLow)
 {
     std::ifstream f(prefix + "_f.txt");
     if (!f) throw std::runtime_error("The content file or the frequency file cannot be found!");
-    vector<uint64_t> out(nTaxa, 0);
+    const int nK = kHigh - kLow + 1;
+    vector<uint64_t> out(nTaxa * (size_t)nK, 0);
     string line; size_t row = 0;
     while (std::getline(f, line)) {
         if (line.empty()) continue;
         const auto cols = splitTabs(line);
         const size_t numK = cols.size() - 1;
-        if (row < nTaxa && 1 + numK - (size_t)kHigh < cols.size()) out[row] = std::stoull(cols[1 + numK - kHigh]);
+        for (int l = 0; l < nK && row < nTaxa; ++l) {
+            const size_t col = 1 + numK - (size_t)(kHigh - l);
+            if (col >= 1 && col < cols.size()) out[(size_t)l * nTaxa + row] = std::stoull(cols[col]);
+        }
         ++row;
     }
     return out;
@@ -370,15 +375,15 @@ struct Writer {
 };
 
 static void writeProfile(const string &path, const Params &p, const Content &c, const vector<double> &all, const vector<uint64_t> &uniq,
-                         uint64_t nKmers, uint64_t nReads)
+                         const vector<uint64_t> &total, const vector<uint64_t> &freqAll, uint64_t nKmers, uint64_t nReads)
 {
     const int nK = p.kHigh - p.kLow + 1;
     const size_t nT = c.names.size();
     vector<uint64_t> sumU(nK, 0); vector<double> sumA(nK, 0.0);
-    struct Row { string name; vector<std::pair<double, uint64_t>> v; uint32_t tid; };
-    vector<Row> rows(nT, Row{"", vector<std::pair<double, uint64_t>>(nK, {0.0, 0}), 0});
+    struct Row { string name; vector<std::pair<double, uint64_t>> v; uint32_t tid; size_t tix; };
+    vector<Row> rows(nT, Row{"", vector<std::pair<double, uint64_t>>(nK, {0.0, 0}), 0, 0});
     for (size_t t = 1; t < nT; ++t) {
-        Row r{c.names[t], vector<std::pair<double, uint64_t>>(nK), c.taxids[t]};
+        Row r{c.names[t], vector<std::pair<double, uint64_t>>(nK), c.taxids[t], t};
         std::replace(r.name.begin(), r.name.end(), ',', ' ');
         for (int l = 0; l < nK; ++l) { r.v[l] = {all[l * nT + t], uniq[l * nT + t]}; sumU[l] += uniq[l * nT + t]; sumA[l] += all[l * nT + t]; }
         rows[t] = r;
@@ -395,6 +400,9 @@ static void writeProfile(const string &path, const Params &p, const Content &c, 
     f << "#taxID,Name";
     for (const char *title : {"Unique counts k=", "Unique rel. freq. k=", "Non-unique counts k=", "Non-unique rel. freq. k=", "Overall rel. freq. k=", "Overall unique rel. freq. k="})
         for (int l = 0; l < nK; ++l) f << "," << title << p.kHigh - l;
+    if (p.coverage)                                                     // Compare.hpp:3574-3581
+        for (const char *title : {"Special Counts k=", "Genome Coverage k="})
+            for (int l = 0; l < nK; ++l) f << "," << title << p.kHigh - l;
     f << "\n";
     vector<double> ident(nK, 0), uident(nK, 0);
     for (const Row &r : rows) {
@@ -406,12 +414,17 @@ static void writeProfile(const string &path, const Params &p, const Content &c, 
         for (int l = 0; l < nK; ++l) { if (r.v[l].first == 0) body << "," << 0.0; else body << "," << r.v[l].first / sumA[l]; }
         for (int l = 0; l < nK; ++l) { ident[l] += r.v[l].first; body << "," << r.v[l].first / (nKmers - garbage[l]); }
         for (int l = 0; l < nK; ++l) { uident[l] += r.v[l].second; body << "," << static_cast<double>(r.v[l].second) / (nKmers - garbage[l]); }
+        if (p.coverage) {                                               // Compare.hpp:3627-3637
+            for (int l = 0; l < nK; ++l) body << "," << total[l * nT + r.tix];
+            for (int l = 0; l < nK; ++l) body << "," << static_cast<double>(total[l * nT + r.tix]) / freqAll[l * nT + r.tix];
+        }
         body << "\n";
     }
     f << "0,not identified";
     for (int l = 0; l < nK * 4; ++l) f << "," << 0.0;
     for (int l = 0; l < nK; ++l) f << "," << (double(nKmers) - double(garbage[l]) - ident[l]) / (double(nKmers) - double(garbage[l]));
     for (int l = 0; l < nK; ++l) f << "," << (double(nKmers) - double(garbage[l]) - uident[l]) / (double(nKmers) - double(garbage[l]));
+    if (p.coverage) for (int l = 0; l < nK * 2; ++l) f << "," << 0.0;
     f << "\n" << body.str();
 }
 
@@ -471,7 +484,8 @@ static int run(int argc, char **argv)
     }
     if (p.content.empty()) p.content = p.index + "_content.txt";
     const Content content = loadContent(p.content);
-    const vector<uint64_t> freq = loadFreqAtK(p.index, content.names.size(), p.kHigh);
+    const vector<uint64_t> freqAll = loadFreq(p.index, content.names.size(), p.kHigh, p.kLow);
+    const vector<uint64_t> freq(freqAll.begin(), freqAll.begin() + (std::ptrdiff_t)content.names.size());   // level 0: k = kHigh
 
     // index + trie files as they are on disk
     const int fd = open(p.index.c_str(), O_RDONLY);
@@ -543,7 +557,7 @@ static int run(int argc, char **argv)
     const int nK = p.kHigh - p.kLow + 1;
     vector<double> all((size_t)nK * content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
     if (kasa_profile_fetch(ctx, all.data(), uniq.data(), tot.data())) throwLast();
-    if (!p.profile.empty()) writeProfile(p.profile, p, content, all, uniq, totalKmers, nReads);
+    if (!p.profile.empty()) writeProfile(p.profile, p, content, all, uniq, tot, freqAll, totalKmers, nReads);
     if (p.verbose) {
         double ident = 0; for (size_t t = 1; t < content.names.size(); ++t) ident += all[(size_t)(nK - 1) * content.names.size() + t];
         std::cout << "OUT: Number of k-mers in input: " << totalKmers << " of which " << ident / totalKmers * 100. << " % were identified." << std::endl;

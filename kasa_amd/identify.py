@@ -68,6 +68,8 @@ class Identify:
         if want_per_read:
             out.append(writer.footer())
         ca, cu, ct = self.ctx.profile()
+        freq_lv = np.stack([ix.freq_at(k) for k in range(self.k_high, self.k_low - 1, -1)], axis=1) if coverage else None
         prof = report.profile_csv(ca, cu, ix.content.names, ix.content.taxids, self.k_high, self.k_low,
-                                  self.n_kmers, self.n_reads, 3 if (protein and self.frames == 6) else self.frames)
+                                  self.n_kmers, self.n_reads, 3 if (protein and self.frames == 6) else self.frames,
+                                  count_total=ct if coverage else None, freq=freq_lv)
         return ("".join(out) if want_per_read else None), prof, csr

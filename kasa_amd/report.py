@@ -209,9 +209,18 @@ def _g6(x) -> str:
     return "%g" % float(x)
 
 
+def _div(a: float, b: float) -> float:
+    """IEEE double division as C++ does it (x/0 = inf, 0/0 = nan)."""
+    if b == 0.0:
+        return math.nan if (a == 0.0 or a != a) else math.copysign(math.inf, a)
+    return a / b
+
+
 def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int, n_kmers_in_input: int,
-                n_reads: int, frames: int) -> str:
-    """Compare.hpp:3466-3665 without --coverage.  Tables are [level, taxon], level 0 = kHigh."""
+                n_reads: int, frames: int, count_total=None, freq=None) -> str:
+    """Compare.hpp:3466-3665.  Tables are [level, taxon], level 0 = kHigh.  With --coverage pass `count_total`
+    (vCount_total) and `freq` (freq[t, l] = k-mers of taxon t at k = kHigh - l, Compare.hpp:166-179): two more
+    column groups, "Special Counts" and "Genome Coverage" (Compare.hpp:3574-3581,3627-3637)."""
     nK = k_high - k_low + 1
     n_taxa = len(names)
     sum_u = [int(count_unique[l, 1:].sum()) for l in range(nK)]
@@ -221,9 +230,10 @@ def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int,
         for t in range(1, n_taxa):
             acc += float(count_all[l, t])
         sum_a[l] = acc
+    cov = count_total is not None
     rows = [(names[t].replace(",", " "), [(float(count_all[l, t]), int(count_unique[l, t])) for l in range(nK)],
-             int(taxids[t])) for t in range(1, n_taxa)]
-    rows = [("", [(0.0, 0)] * nK, 0)] + rows  # slot 0 of vOut stays empty (Compare.hpp:3468)
+             int(taxids[t]), t) for t in range(1, n_taxa)]
+    rows = [("", [(0.0, 0)] * nK, 0, 0)] + rows  # slot 0 of vOut stays empty (Compare.hpp:3468)
 
     import functools
 
@@ -241,14 +251,15 @@ def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int,
         j += 1
     head = "#taxID,Name"
     for title in ("Unique counts k=", "Unique rel. freq. k=", "Non-unique counts k=",
-                  "Non-unique rel. freq. k=", "Overall rel. freq. k=", "Overall unique rel. freq. k="):
+                  "Non-unique rel. freq. k=", "Overall rel. freq. k=", "Overall unique rel. freq. k=") + \
+            (("Special Counts k=", "Genome Coverage k=") if cov else ()):
         for l in range(nK):
             head += "," + title + str(k_high - l)
     head += "\n"
     body = ""
     ident = [0.0] * nK
     uident = [0.0] * nK
-    for name, vals, tid in rows:
+    for name, vals, tid, tix in rows:
         if not (vals[nK - 1][0] > 0):
             continue
         line = str(tid) + "," + name
@@ -266,6 +277,11 @@ def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int,
         for l in range(nK):
             uident[l] += vals[l][1]
             line += "," + _g6(vals[l][1] / float((n_kmers_in_input - garbage[l]) & 0xFFFFFFFFFFFFFFFF))
+        if cov:
+            for l in range(nK):
+                line += "," + str(int(count_total[l, tix]))
+            for l in range(nK):
+                line += "," + _g6(_div(float(int(count_total[l, tix])), float(int(freq[tix, l]))))
         body += line + "\n"
     first = "0,not identified" + ",0" * (nK * 4)
     for l in range(nK):
@@ -274,4 +290,6 @@ def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int,
     for l in range(nK):
         d = float(n_kmers_in_input) - float(garbage[l])
         first += "," + _g6((d - uident[l]) / d)
+    if cov:
+        first += ",0" * (2 * nK)
     return head + first + "\n" + body

@@ -186,6 +186,7 @@ def case_pairs(out):
         "edge_crlf.jsonl": ["-i", "edge_crlf.fasta", "--jsonl", "-b", "100"],
         "edge_multi.jsonl": ["-i", "edge_multi.fastq", "--jsonl", "-b", "100"],
         "edge_noeol.jsonl": ["-i", "edge_noeol.fasta", "--jsonl", "-b", "100"],
+        "cov.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--coverage"],
     }
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]

@@ -25,7 +25,7 @@ def csr_from_dense(M):
 
 
 def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low, frames,
-           threshold=0.0, beasts=3, protein=False):
+           threshold=0.0, beasts=3, protein=False, count_total=None):
     w = report.ReadWriter(fmt, ix.content.names, ix.content.taxids, beasts)
     freq = ix.freq_at(k_high)
     out = [w.header()]
@@ -36,12 +36,16 @@ def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low
         out.append(w.read(r, batch.names[r], int(batch.lengths[r]), rk))
     out.append(w.footer())
     prof = report.profile_csv(count_all, count_unique, ix.content.names, ix.content.taxids, k_high, k_low,
-                              n_kmers, batch.n, 3 if (protein and frames == 6) else frames)
+                              n_kmers, batch.n, 3 if (protein and frames == 6) else frames,
+                              count_total=count_total,
+                              freq=None if count_total is None else
+                              np.stack([ix.freq_at(k) for k in range(k_high, k_low - 1, -1)], axis=1))
     return "".join(out), prof
 
 
 def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, closed_form=False, unique=False,
-                    protein=False, cmp64_quirk=False):
-    p = oracle.params(k_high, k_low, frames, avx_quirk, K=ix.K, protein=protein, cmp64_quirk=cmp64_quirk)
+                    protein=False, cmp64_quirk=False, coverage=False):
+    p = oracle.params(k_high, k_low, frames, avx_quirk, coverage=coverage, K=ix.K, protein=protein,
+                      cmp64_quirk=cmp64_quirk)
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique)
     return res, nq

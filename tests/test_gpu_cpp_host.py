@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 from kasa_amd import build as hipbuild, capi
-from tests.test_oracle_golden import PAIRS, _read, unpack
+from tests.test_oracle_golden import PAIRS, _read, unpack, wants_coverage
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
@@ -29,6 +29,8 @@ def test_cpp_host_byte_identical(case, tmp_path):
         cmd.append("--one")
     if uniq:
         cmd.append("-e")
+    if wants_coverage(case):
+        cmd.append("--coverage")
     if thr:
         cmd += ["--threshold", str(thr)]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)

@@ -11,7 +11,7 @@ from kasa_amd import capi, formats, reads, report
 from kasa_amd.identify import Identify
 from oracle import oracle
 from tests import helpers
-from tests.test_oracle_golden import PAIRS, _read, unpack
+from tests.test_oracle_golden import PAIRS, _read, unpack, wants_coverage
 from tests.test_oracle_properties import random_case
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,7 @@ def test_golden_files_byte_identical(case):
     d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
     idf = Identify(ix, 0, kh, kl, frames, thr, beasts, fmt, unique=uniq)
-    text, prof, _ = idf.run(batch)
+    text, prof, _ = idf.run(batch, coverage=wants_coverage(case))
     assert text == _read(os.path.join(d, "out_" + stem))
     assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
     idf.close()

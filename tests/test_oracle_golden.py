@@ -7,7 +7,7 @@ import pytest
 from kasa_amd import reads
 from tests import helpers
 
-PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts[, index stem[, -e]])
+PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beasts[, index stem[, -e[, --coverage]]])
     ("default.json", "reads.fastq", "json", 12, 7, 3, 0.0, 3),
     ("b100.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100),
     ("b100.tsv", "reads.fastq", "tsv", 12, 7, 3, 0.0, 100),
@@ -30,11 +30,16 @@ PAIRS = [  # (output stem, input file, fmt, kHigh, kLow, frames, threshold, beas
     ("edge_crlf.jsonl", "edge_crlf.fasta", "jsonl", 12, 7, 3, 0.0, 100),     # CRLF: the '\r' stays in name, length, k-mers
     ("edge_multi.jsonl", "edge_multi.fastq", "jsonl", 12, 7, 3, 0.0, 100),   # header with spaces, '+name', '#' qualities
     ("edge_noeol.jsonl", "edge_noeol.fasta", "jsonl", 12, 7, 3, 0.0, 100),   # no line feed at the end of the file
+    ("cov.jsonl", "reads.fastq", "jsonl", 12, 7, 3, 0.0, 100, "idx", False, True),   # --coverage: two more column groups
 ]
 
 
 def unpack(case):
     return case[:8] + ((case[8],) if len(case) > 8 else ("idx",)) + ((case[9],) if len(case) > 9 else (False,))
+
+
+def wants_coverage(case):
+    return len(case) > 10 and bool(case[10])
 
 
 def _read(path, binary=False):
@@ -50,10 +55,12 @@ def test_pairs_byte_identical(case, closed_form):
     d, ix = helpers.load_case("pairs", idx)
     batch = reads.parse_reads(os.path.join(d, infile))
     assert batch.protein == (stem == "prot.jsonl")
+    cov = wants_coverage(case)
     res, nq = helpers.oracle_identify(ix, batch, kh, kl, frames, closed_form=closed_form, unique=uniq,
-                                      protein=batch.protein)
+                                      protein=batch.protein, coverage=cov)
     text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
-                                nq, fmt, kh, kl, frames, thr, beasts, protein=batch.protein)
+                                nq, fmt, kh, kl, frames, thr, beasts, protein=batch.protein,
+                                count_total=res.count_total if cov else None)
     assert text == _read(os.path.join(d, "out_" + stem))
     assert prof == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
 
