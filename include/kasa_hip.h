@@ -101,6 +101,13 @@ int kasa_ctx_set_protein(kasa_ctx *ctx, int protein);
  * padding and the X marker (Read.hpp:633-675,1068-1078) happen on the device.  H2D copy only. */
 int kasa_batch_upload(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offsets, int64_t nReads);
 
+/* The same for reads made of several sequences: paired-end input (-1/-2; Read::readFastqa_pairedEnd,
+ * Read.hpp:834-1049) hands both mates of a pair on as two entries of vLines with ONE read id, so their
+ * k-mers score into the same row and none spans the junction.  offsets[nSegments+1] delimit the
+ * sequences, segmentRead[s] (ascending, < nReads) names the read of sequence s. */
+int kasa_batch_upload_segments(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offsets, int64_t nSegments,
+                               const uint32_t *segmentRead, int64_t nReads);
+
 /* Read::convertAndSort (Read.hpp:763-827): every read -> packed k-mers + read id, device resident. */
 int kasa_batch_encode(kasa_ctx *ctx, uint64_t *nKmers);
 

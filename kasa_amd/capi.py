@@ -19,7 +19,7 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
-    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_encode",
+    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_segments", "kasa_batch_encode",
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
@@ -127,11 +127,19 @@ class Context:
             pass
 
     # ---- batch ----
-    def upload(self, bases: np.ndarray, offsets: np.ndarray):
+    def upload(self, bases: np.ndarray, offsets: np.ndarray, seg_read: np.ndarray = None, n_reads: int = None):
+        """One sequence per read, or -- paired-end -- `seg_read[s]` = read of sequence s (ascending) and `n_reads`."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-        self.n_reads = int(offsets.shape[0] - 1)
-        _check(lib().kasa_batch_upload(self.h, _p(bases), _p(offsets), C.c_int64(self.n_reads)))
+        n_seq = int(offsets.shape[0] - 1)
+        if seg_read is None:
+            self.n_reads = n_seq
+            _check(lib().kasa_batch_upload(self.h, _p(bases), _p(offsets), C.c_int64(n_seq)))
+        else:
+            seg_read = np.ascontiguousarray(seg_read, dtype=np.uint32)
+            self.n_reads = int(n_reads)
+            _check(lib().kasa_batch_upload_segments(self.h, _p(bases), _p(offsets), C.c_int64(n_seq), _p(seg_read),
+                                                    C.c_int64(self.n_reads)))
 
     def encode(self) -> int:
         n = C.c_uint64(0)
@@ -159,8 +167,8 @@ class Context:
         _check(lib().kasa_batch_scores_fetch(self.h, _p(off), _p(tax), _p(sc)))
         return off, tax, sc
 
-    def run_batch(self, bases, offsets, want_per_read=True, coverage=False, unique=False):
-        self.upload(bases, offsets)
+    def run_batch(self, bases, offsets, want_per_read=True, coverage=False, unique=False, seg_read=None, n_reads=None):
+        self.upload(bases, offsets, seg_read, n_reads)
         self.encode()
         self.sort_and_range(unique)
         self.lookup_score(want_per_read, coverage)

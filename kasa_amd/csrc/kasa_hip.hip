@@ -449,7 +449,9 @@ struct kasa_ctx {
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
     // buffers
-    DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nReads+1], u64[nReads+1]
+    DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
+    DevBuf seqOff, seqRead;                    // u64[nSeq+1] k-mer offset of every uploaded sequence, u32[nSeq] its read
+    int64_t nSeq = 0; bool haveSeqRead = false;
     DevBuf qKmerA, qKmerB, qReadA, qReadB;     // double buffers of the query arrays
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
@@ -571,7 +573,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device); // the index may already be gone: never touch it here
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
+    DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                      &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
@@ -621,45 +623,72 @@ __host__ __device__ static inline void enc_geometry(int mode, int KL, int kLow, 
     else cnt = (L > 3 * K + 1) ? L - 3 * K + 1 : 0;
 }
 
-extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
+// nSeq sequences (offsets[nSeq+1]); seqRead[s] = read the sequence belongs to (ascending; NULL: sequence s is read s).
+// Paired-end input hands both mates of a pair over as two sequences of one read (Read.hpp:834-1049): their k-mers
+// carry the same read id, none spans the junction.
+static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSeq, const uint32_t *seqRead, int64_t nReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (nReads < 0 || (nReads > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
-    if ((uint64_t)nReads >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
+    if (nSeq < 0 || nReads < 0 || (nSeq > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
+    if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->nReads = nReads; c->nQ = 0;
-    const uint64_t nBases = nReads ? (uint64_t)(offsets[nReads] - offsets[0]) : 0;
-    std::vector<uint64_t> koff((size_t)nReads + 1);
-    c->hostOff.assign((size_t)nReads + 1, 0);
+    c->state = 0; c->haveScores = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
+    const uint64_t nBases = nSeq ? (uint64_t)(offsets[nSeq] - offsets[0]) : 0;
+    std::vector<uint64_t> soff((size_t)nSeq + 1), koff((size_t)nReads + 1, 0);
+    c->hostOff.assign((size_t)nSeq + 1, 0);
     uint64_t run = 0;
-    uint32_t maxCnt = 0;
     const int mode = c->enc_mode();
     const int strands = c->strands();
-    for (int64_t r = 0; r < nReads; ++r) {
-        const int64_t raw = offsets[r + 1] - offsets[r];
+    uint32_t prevRead = 0;
+    for (int64_t s = 0; s < nSeq; ++s) {
+        const int64_t raw = offsets[s + 1] - offsets[s];
         if (raw < 0) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
-        c->hostOff[(size_t)r] = offsets[r] - offsets[0];
-        koff[(size_t)r] = run;
+        const uint32_t r = seqRead ? seqRead[s] : (uint32_t)s;
+        if ((int64_t)r >= nReads || r < prevRead) return fail(KASA_E_ARG, "kasa_batch_upload: sequence %lld names read %u (reads: %lld, ids must ascend)", (long long)s, r, (long long)nReads);
+        prevRead = r;
+        c->hostOff[(size_t)s] = offsets[s] - offsets[0];
+        soff[(size_t)s] = run;
         int64_t body, L, perStrand = 0;
         if (raw > 0) enc_geometry(mode, c->K(), c->kLow, raw, body, L, perStrand);
         const uint64_t cnt = (uint64_t)perStrand * strands;
         run += cnt;
-        if (cnt > maxCnt) maxCnt = (uint32_t)std::min<uint64_t>(cnt, 0xFFFFFFFFull);
+        koff[(size_t)r + 1] += cnt;
     }
-    koff[(size_t)nReads] = run;
-    c->hostOff[(size_t)nReads] = (int64_t)nBases;
+    soff[(size_t)nSeq] = run;
+    uint32_t maxCnt = 0;
+    for (int64_t r = 0; r < nReads; ++r) {
+        maxCnt = (uint32_t)std::max<uint64_t>(maxCnt, std::min<uint64_t>(koff[(size_t)r + 1], 0xFFFFFFFFull));
+        koff[(size_t)r + 1] += koff[(size_t)r];
+    }
+    c->hostOff[(size_t)nSeq] = (int64_t)nBases;
     if (run >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: %llu k-mers exceed the 32-bit position range of one batch; split the batch", (unsigned long long)run);
     c->nQ = run; c->nBases = nBases; c->maxCnt = maxCnt;
     int rc;
-    if ((rc = c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nReads + 1) * 8)) ||
-        (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)))
+    if ((rc = c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nSeq + 1) * 8)) ||
+        (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)) || (rc = c->seqOff.reserve(((size_t)nSeq + 1) * 8)) ||
+        (rc = c->seqRead.reserve((size_t)nSeq * 4 + 64)))
         return rc;
     if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->baseOff.p, c->hostOff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->baseOff.p, c->hostOff.data(), ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->kmerOff.p, koff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->seqOff.p, soff.data(), ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    c->haveSeqRead = seqRead != nullptr;
+    if (seqRead && nSeq) HIPCHK(hipMemcpyAsync(c->seqRead.p, seqRead, (size_t)nSeq * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->state = 1;
     return KASA_OK;
+}
+
+extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
+{
+    return upload_impl(c, bases, offsets, nReads, nullptr, nReads);
+}
+
+extern "C" int kasa_batch_upload_segments(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSegments,
+                                          const uint32_t *segmentRead, int64_t nReads)
+{
+    if (nSegments > 0 && !segmentRead) return fail(KASA_E_ARG, "kasa_batch_upload_segments: segmentRead is NULL");
+    return upload_impl(c, bases, offsets, nSegments, segmentRead, nReads);
 }
 
 // One wavefront per read.  The cleaned bases of a window chunk are staged in LDS as 3-bit codes, the
@@ -672,8 +701,8 @@ static constexpr int ENC_WAVES = 4;
 template <class Key>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
-    int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG, Key *__restrict__ outKmer,
-    uint32_t *__restrict__ outRead)
+    const uint32_t *__restrict__ seqRead, int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG,
+    Key *__restrict__ outKmer, uint32_t *__restrict__ outRead)
 {
     constexpr int KLETTERS = KeyTraits<Key>::LETTERS;
     constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;      // bases needed for one chunk (+ slack)
@@ -697,6 +726,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
         enc_geometry(mode, KLETTERS, kLow, raw, body, L, cnt);
         if (cnt == 0) continue;
         const uint64_t o0 = kmerOff[r];
+        const uint32_t rid = seqRead ? seqRead[r] : (uint32_t)r;          // paired-end: both mates carry the pair's id
         for (int s = 0; s < strands; ++s) {
             for (int64_t w0 = 0; w0 < cnt; w0 += chunk) {
                 const int nw = (int)((cnt - w0 < chunk) ? cnt - w0 : chunk);
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                     for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
-                    outRead[o] = (uint32_t)r;
+                    outRead[o] = rid;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -760,16 +790,16 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     if ((rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_ENCODE], &a, &b))) return rc;
-    if (c->nReads > 0 && nQ > 0) {
-        const unsigned blocks = (unsigned)std::min<int64_t>((c->nReads + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
+    if (c->nSeq > 0 && nQ > 0) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide)
             encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
-                c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
-                c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>());
+                c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>());
         else
             encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
-                c->kmerOff.as<uint64_t>(), c->nReads, c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(),
-                c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+                c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
         HIPCHK(hipGetLastError());
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_ENCODE], a, b))) return rc;
@@ -2626,7 +2656,7 @@ extern "C" int kasa_batch_fetch_lookup(kasa_ctx *c, uint8_t *depth, uint32_t *in
 extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 {
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
-    const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
+    const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                            &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};

@@ -6,7 +6,7 @@
 // (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
-// Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize, paired-end,
+// Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize,
 // custom alphabets/codon tables.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
 #include <cmath>
@@ -256,7 +256,7 @@ static ReadSet readInput(const string &path, bool verbose) // what Read.hpp:699-
 // ranking + text (Compare.hpp:1452-1890) and profile (Compare.hpp:3466-3665)
 // ---------------------------------------------------------------------------------------------------
 struct Params {
-    string content, index, input, rtt, profile;
+    string content, index, input, input2, rtt, profile;   // input2: second file of paired-end input (-1 / -2)
     int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
     bool kSetByUser = false;
     float threshold = 0.f;
@@ -445,7 +445,8 @@ static int run(int argc, char **argv)
         auto next = [&]() -> string { if (i + 1 >= argc) throw std::runtime_error("missing value after " + s); return a[++i]; };
         if (s == "-c" || s == "--content") p.content = next();
         else if (s == "-d" || s == "--database") p.index = next();
-        else if (s == "-i" || s == "--input") { p.input = next(); if (!std::ifstream(p.input)) throw std::runtime_error("Input file not found"); }
+        else if (s == "-i" || s == "--input" || s == "-1") { p.input = next(); if (!std::ifstream(p.input)) throw std::runtime_error("Input file not found"); }
+        else if (s == "-2") { p.input2 = next(); if (!std::ifstream(p.input2)) throw std::runtime_error("Input file not found"); }
         else if (s == "-q" || s == "--rtt") p.rtt = next();
         else if (s == "-p" || s == "--profile") p.profile = next();
         else if (s == "-k") { p.kSetByUser = true; p.kHigh = std::stoi(next()); p.kLow = std::stoi(next()); if (p.kHigh > 25) p.kHigh = 25; if (p.kLow < 1) p.kLow = 1; if (p.kLow > p.kHigh) std::swap(p.kLow, p.kHigh); }
@@ -466,7 +467,7 @@ static int run(int argc, char **argv)
         else if (s == "--device") p.device = std::stoi(next());
         else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
         else if (s == "-m" || s == "--memory" || s == "-n" || s == "--threads" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
-        else if (s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-1" || s == "-2" || s == "-z" || s == "-a" || s == "--alphabet")
+        else if (s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-z" || s == "-a" || s == "--alphabet")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }
@@ -507,6 +508,25 @@ static int run(int argc, char **argv)
     if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
 
     ReadSet rs = readInput(p.input, p.verbose);
+    // paired-end (Read.hpp:834-1049): mate r of both files forms read r; the two sequences stay separate (no k-mer spans
+    // the junction) but score into one row; specifier = both names, length = the sum
+    vector<uint32_t> segRead;
+    if (!p.input2.empty()) {
+        ReadSet r2 = readInput(p.input2, false);
+        if (r2.names.size() != rs.names.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
+        ReadSet m; m.protein = rs.protein;
+        for (size_t r = 0; r < rs.names.size(); ++r) {
+            for (const ReadSet *x : {&rs, &r2}) {
+                m.bases.insert(m.bases.end(), x->bases.begin() + x->off[r], x->bases.begin() + x->off[r + 1]);
+                m.off.push_back((int64_t)m.bases.size());
+                segRead.push_back((uint32_t)r);
+            }
+            m.names.push_back(rs.names[r] + r2.names[r]);
+            m.lengths.push_back(rs.lengths[r] + r2.lengths[r]);
+        }
+        rs = std::move(m);
+    }
+    const size_t seqPerRead = segRead.empty() ? 1 : 2;
     p.protein = rs.protein;
     if (kasa_ctx_set_protein(ctx, p.protein ? 1 : 0)) throwLast();
     const uint64_t nReads = rs.names.size();
@@ -528,13 +548,19 @@ static int run(int argc, char **argv)
     while (done < nReads || (nReads == 0 && done == 0)) {
         uint64_t end = done, est = 0;
         while (end < nReads) {
-            const uint64_t len = (uint64_t)(rs.off[end + 1] - rs.off[end]);
-            const uint64_t k = (len + 64) * (p.frames == 6 ? 2 : 1);
+            const uint64_t len = (uint64_t)(rs.off[(end + 1) * seqPerRead] - rs.off[end * seqPerRead]);
+            const uint64_t k = (len + 64 * seqPerRead) * (p.frames == 6 ? 2 : 1);
             if (end > done && est + k > maxKmersPerBatch) break;
             est += k; ++end;
         }
         uint64_t nk = 0;
-        if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
+        if (segRead.empty()) {
+            if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
+        } else {
+            vector<uint32_t> local(segRead.begin() + (std::ptrdiff_t)(done * 2), segRead.begin() + (std::ptrdiff_t)(end * 2));
+            for (auto &v : local) v -= (uint32_t)done;
+            if (kasa_batch_upload_segments(ctx, rs.bases.data(), rs.off.data() + done * 2, (int64_t)((end - done) * 2), local.data(), (int64_t)(end - done))) throwLast();
+        }
         if (kasa_batch_encode(ctx, &nk)) throwLast();
         if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
         if (kasa_batch_lookup_score(ctx, !p.rtt.empty(), p.coverage)) throwLast();

@@ -51,7 +51,7 @@ class Identify:
         while a < reads.n or (a == 0 and reads.n == 0):
             b = min(reads.n, a + max(step, 1))
             part = reads.slice(a, b)
-            self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique)
+            self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique, part.seg_read, part.n)
             self.n_kmers += self.ctx.n_kmers
             if want_per_read:
                 off, tax, sc = self.ctx.scores()

@@ -27,14 +27,20 @@ class ReadBatch:
     names: list           # str, with the trailing space
     lengths: np.ndarray   # u32[n]  ("Length" of the reference's output)
     protein: bool = False  # amino-acid input as kASA::detectAlphabet decides (kASA.hpp:155-183)
+    seg_read: np.ndarray = None  # paired-end: u32[nSequences], read of every sequence (offsets delimit sequences then)
 
     @property
     def n(self) -> int:
-        return int(self.offsets.shape[0] - 1)
+        return int(self.lengths.shape[0]) if self.seg_read is not None else int(self.offsets.shape[0] - 1)
 
     def slice(self, a: int, b: int) -> "ReadBatch":
-        o = self.offsets[a:b + 1]
         names = self.names[a:b] if self.names is not None else None
+        if self.seg_read is not None:
+            sa, sb = np.searchsorted(self.seg_read, [a, b], side="left")
+            o = self.offsets[sa:sb + 1]
+            return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b], self.protein,
+                             (self.seg_read[sa:sb] - np.uint32(a)).astype(np.uint32))
+        o = self.offsets[a:b + 1]
         return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b], self.protein)
 
 
@@ -116,6 +122,24 @@ def parse_reads(path: str) -> ReadBatch:
         np.cumsum([len(s) for s in seqs], out=off[1:])
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
     return ReadBatch(bases, off, names, np.asarray(lens, dtype=np.uint32), detect_protein(data))
+
+
+def parse_pairs(path1: str, path2: str) -> ReadBatch:
+    """-1 <file> -2 <file>: mate i of both files forms read i (Read.hpp:834-1049).  Both sequences keep their own
+    k-mers under one read id; the specifier is both names (each with its trailing space), the length the sum."""
+    b1, b2 = parse_reads(path1), parse_reads(path2)
+    if b1.n != b2.n:
+        raise RuntimeError("paired-end files hold different numbers of reads")
+    n = b1.n
+    parts, off = [], [0]
+    for r in range(n):
+        for b in (b1, b2):
+            parts.append(b.bases[int(b.offsets[r]):int(b.offsets[r + 1])])
+            off.append(off[-1] + parts[-1].shape[0])
+    bases = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return ReadBatch(bases, np.asarray(off, dtype=np.int64), [b1.names[r] + b2.names[r] for r in range(n)],
+                     (b1.lengths + b2.lengths).astype(np.uint32), b1.protein,
+                     np.repeat(np.arange(n, dtype=np.uint32), 2))
 
 
 def synthetic_reads(genomes, n_reads: int, read_len: int, seed: int, sub_rate: float = 0.01) -> ReadBatch:

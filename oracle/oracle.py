@@ -159,17 +159,20 @@ def unique_queries(km: np.ndarray, rd: np.ndarray):
     return km[:n], rd[:n]
 
 
-def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False, unique=False):
+def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False, unique=False, seg_read=None,
+                   n_reads=None):
     """Whole reference batch: encode -> sort [-> unique] -> ranges -> merge.  Returns (CompareResult, nQueries);
     nQueries counts the k-mers before -e, as iNumberOfkMersInInput does (Compare.hpp:3124)."""
     iv = IndexView(ix)
     km, rd = encode(bases, offsets, p)
     n_in = int(km.shape[0])
+    if seg_read is not None:   # paired-end: both mates of a pair are entries of one read (Read.hpp:834-1049)
+        rd = np.ascontiguousarray(np.asarray(seg_read, dtype=np.uint32)[rd])
     km, rd = sort_queries(km, rd)
     if unique:
         km, rd = unique_queries(km, rd)
     rs, rl = ranges(iv, p, km)
-    res = compare(iv, p, km, rd, rs, rl, offsets.shape[0] - 1, want_reads, closed_form)
+    res = compare(iv, p, km, rd, rs, rl, offsets.shape[0] - 1 if n_reads is None else int(n_reads), want_reads, closed_form)
     return res, n_in
 
 

@@ -160,6 +160,16 @@ def case_pairs(out):
         f.write("@q1\n" + g[3][0:150] + "\n+\n" + "I" * 150 + "\n@q2 x y\n" + g[4][10:100] + "\n+q2\n" + "#" * 90 + "\n")
     with open(os.path.join(out, "edge_noeol.fasta"), "w") as f:
         f.write(">r1\n" + g[5][0:150] + "\n>r2\n" + g[5][300:450])
+    # paired-end input: mates 100 bp each, 150 bp apart, second mate reverse-complemented
+    prng = random.Random(31)
+    with open(os.path.join(out, "pair_1.fastq"), "w") as f1, open(os.path.join(out, "pair_2.fastq"), "w") as f2:
+        for r in range(12):
+            gi = prng.randrange(G)
+            p = prng.randrange(L - 400)
+            a = genomes[gi][p:p + 100]
+            b = "".join(comp[c] for c in reversed(genomes[gi][p + 250:p + 350]))
+            f1.write("@pair%d/1\n%s\n+\n%s\n" % (r, a, "I" * 100))
+            f2.write("@pair%d/2\n%s\n+\n%s\n" % (r, b, "I" * 100))
     run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
     base = ["identify", "-c", "content.txt", "-d", "idx", "-m", "4", "-n", "1"]
     runs = {
@@ -187,6 +197,8 @@ def case_pairs(out):
         "edge_multi.jsonl": ["-i", "edge_multi.fastq", "--jsonl", "-b", "100"],
         "edge_noeol.jsonl": ["-i", "edge_noeol.fasta", "--jsonl", "-b", "100"],
         "cov.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--coverage"],
+        "pair.jsonl": ["-1", "pair_1.fastq", "-2", "pair_2.fastq", "--jsonl", "-b", "100"],
+        "pair6.jsonl": ["-1", "pair_1.fastq", "-2", "pair_2.fastq", "--jsonl", "-b", "100", "--six"],
     }
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]

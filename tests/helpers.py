@@ -47,5 +47,6 @@ def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, cl
                     protein=False, cmp64_quirk=False, coverage=False):
     p = oracle.params(k_high, k_low, frames, avx_quirk, coverage=coverage, K=ix.K, protein=protein,
                       cmp64_quirk=cmp64_quirk)
-    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique,
+                                    seg_read=batch.seg_read, n_reads=batch.n)
     return res, nq

@@ -74,3 +74,17 @@ def test_cpp_host_wide_index(tmp_path):
                                      "jsonl", kh, kl, frames, 0.0, 100)
         assert _read(out) == text
         assert _read(prof) == ptext
+
+
+def test_cpp_host_paired_end(tmp_path):
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    for stem, extra in (("pair", []), ("pair6", ["--six"])):
+        out, prof = str(tmp_path / ("o_" + stem)), str(tmp_path / ("p_" + stem))
+        cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-1", os.path.join(d, "pair_1.fastq"),
+               "-2", os.path.join(d, "pair_2.fastq"), "-q", out, "-p", prof, "--jsonl", "-b", "100"] + extra
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert _read(out) == _read(os.path.join(d, "out_" + stem + ".jsonl"))
+        assert _read(prof) == _read(os.path.join(d, "prof_" + stem + ".csv"))

@@ -222,15 +222,19 @@ def test_profile_limbs_roundtrip_and_sum():
 
 def _check_against_oracle(ix, batch, kh, kl, frames, flags=0, unique=False, protein=False):
     p = oracle.params(kh, kl, frames, K=ix.K, protein=protein)
-    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, unique=unique)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, unique=unique, seg_read=batch.seg_read,
+                                    n_reads=batch.n)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, kl, frames)
     ctx.set_protein(protein)
     ctx.debug_flags(flags)
-    ctx.run_batch(batch.bases, batch.offsets, True, unique=unique)
+    ctx.run_batch(batch.bases, batch.offsets, True, unique=unique, seg_read=batch.seg_read, n_reads=batch.n)
     assert ctx.n_kmers == nq
     if unique or protein:   # the stage outputs as well
-        km_o, rd_o = oracle.sort_queries(*oracle.encode(batch.bases, batch.offsets, p))
+        km_o, rd_o = oracle.encode(batch.bases, batch.offsets, p)
+        if batch.seg_read is not None:
+            rd_o = np.ascontiguousarray(batch.seg_read[rd_o])
+        km_o, rd_o = oracle.sort_queries(km_o, rd_o)
         if unique:
             km_o, rd_o = oracle.unique_queries(km_o, rd_o)
         km_g, rd_g = ctx.queries()
@@ -474,3 +478,20 @@ def test_full_size_properties():
         assert np.array_equal(tax1[lo:hi], t), r
         np.testing.assert_allclose(sc1[lo:hi], res.M[i, t], rtol=2e-5, atol=0)
     ctx.close(); dix.close()
+
+
+@pytest.mark.parametrize("case", [("pair", 3), ("pair6", 6)], ids=["pair", "pair6"])
+def test_paired_end_golden_files(case):
+    """-1/-2: two sequences per read through kasa_batch_upload_segments; also in two batches of pairs."""
+    _gpu_or_fail()
+    stem, frames = case
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_pairs(os.path.join(d, "pair_1.fastq"), os.path.join(d, "pair_2.fastq"))
+    idf = Identify(ix, 0, 12, 7, frames, 0.0, 100, "jsonl")
+    text, prof, _ = idf.run(batch)
+    assert text == _read(os.path.join(d, "out_" + stem + ".jsonl"))
+    assert prof == _read(os.path.join(d, "prof_" + stem + ".csv"))
+    _, prof2, _ = idf.run(batch, batch_reads=5)          # the profile does not depend on the batching
+    assert prof2 == prof
+    idf.close()
+    _check_against_oracle(ix, batch, 12, 7, frames, unique=True)

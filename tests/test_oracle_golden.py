@@ -107,3 +107,21 @@ def test_wide_index_stock_binary_and_parity_target(case):
     assert texts["stock"][1] == _read(os.path.join(d, "prof_" + stem + ".csv"))
     assert texts["sequential"] == texts["closed"]
     assert texts["closed"][0] != texts["stock"][0]
+
+
+PAIRED = [("pair", 3), ("pair6", 6)]   # -1 pair_1.fastq -2 pair_2.fastq [--six]
+
+
+@pytest.mark.parametrize("case", PAIRED, ids=[c[0] for c in PAIRED])
+@pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
+def test_paired_end_byte_identical(case, closed_form):
+    """Both mates of a pair enter the batch as two sequences of one read (Read.hpp:834-1049)."""
+    stem, frames = case
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_pairs(os.path.join(d, "pair_1.fastq"), os.path.join(d, "pair_2.fastq"))
+    assert batch.n == 12 and batch.offsets.shape[0] == 25
+    res, nq = helpers.oracle_identify(ix, batch, 12, 7, frames, closed_form=closed_form)
+    text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
+                                nq, "jsonl", 12, 7, frames, 0.0, 100)
+    assert text == _read(os.path.join(d, "out_" + stem + ".jsonl"))
+    assert prof == _read(os.path.join(d, "prof_" + stem + ".csv"))
