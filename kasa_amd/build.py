@@ -38,7 +38,7 @@ def build_host(force: bool = False) -> str:
     newest = max(os.path.getmtime(p) for p in (HOST_SRC, HEADER, os.path.join(HERE, "host", "grisu_powers.inc")))
     if not force and os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) >= newest:
         return HOST_BIN
-    cmd = ["g++", "-O2", "-std=c++17", "-o", HOST_BIN, HOST_SRC, "-L" + HERE, "-lkasa_hip", "-lz",
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", HOST_BIN, HOST_SRC, "-L" + HERE, "-lkasa_hip", "-lz",
            "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return HOST_BIN

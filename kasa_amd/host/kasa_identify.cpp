@@ -9,15 +9,19 @@
 // Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize,
 // custom alphabets/codon tables.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -211,44 +215,123 @@ static bool detectProtein(const string &data, bool verbose)
     return true;
 }
 
-static ReadSet readInput(const string &path, bool verbose) // what Read.hpp:699-760 hands on, for reads that fit one chunk
+// One run of whole records, data[begin, end) with begin at a header line: what Read.hpp:699-760 hands on, for reads that
+// fit one chunk.  A '\r' stays part of its line, as with the reference's getline.
+static void parseRecords(const string &data, size_t begin, size_t end, bool fasta, ReadSet &rs)
+{
+    size_t a = begin;
+    auto nextLine = [&](size_t &lb, size_t &le) -> bool {          // [lb, le) without the line feed
+        if (a >= end) return false;
+        lb = a;
+        const void *nl = memchr(data.data() + a, '\n', end - a);
+        le = nl ? (size_t)((const char *)nl - data.data()) : end;
+        a = le + 1;
+        return true;
+    };
+    size_t lb, le;
+    bool have = nextLine(lb, le);
+    while (have) {
+        if (lb == le) { have = nextLine(lb, le); continue; }
+        rs.names.emplace_back(data, lb + 1, le - lb - 1);           // Read.hpp:711-714: header without its first character
+        rs.names.back().push_back(' ');                             // ... plus a trailing space
+        uint32_t nLines = 0; const size_t b0 = rs.bases.size();
+        while ((have = nextLine(lb, le))) {
+            const bool empty = lb == le;
+            if (!empty && data[lb] == (fasta ? '>' : '+')) break;
+            if (!empty) rs.bases.insert(rs.bases.end(), data.begin() + (std::ptrdiff_t)lb, data.begin() + (std::ptrdiff_t)le);
+            if (!empty || !fasta) ++nLines;
+        }
+        const size_t len = rs.bases.size() - b0;
+        for (size_t k = b0; k < rs.bases.size(); ++k)
+            if (rs.bases[k] == ' ' || rs.bases[k] == '\t') throw std::runtime_error("Spaces or tabs inside read, please check your input."); // Read.hpp:659
+        if (!fasta) {                                               // the '+' line is current: quality lines follow
+            size_t q = 0;
+            while ((have = nextLine(lb, le)) && q < len) q += le - lb;
+            if (q > len) throw std::runtime_error("Quality string and DNA string do not have the same length!");
+        }
+        rs.off.push_back((int64_t)rs.bases.size());
+        rs.lengths.push_back((uint32_t)(len + nLines));             // one extra per sequence line (Read.hpp:723-731)
+    }
+}
+
+// First record start at or after `from` that is safe to cut at (N1: the input is parsed by several threads).  FASTA: a
+// line starting with '>'.  FASTQ: a line starting with '@' whose third line starts with '+' and whose fourth line is as
+// long as its second -- a quality line that happens to start with '@' fails that test.  npos: none found nearby.
+static size_t findRecordStart(const string &data, size_t from, bool fasta)
+{
+    const size_t limit = std::min(data.size(), from + (1u << 20));
+    size_t p = from;
+    while (p < limit) {
+        const void *nl = memchr(data.data() + p, '\n', limit - p);
+        if (!nl) return string::npos;
+        p = (size_t)((const char *)nl - data.data()) + 1;
+        if (p >= data.size()) return string::npos;
+        if (fasta) { if (data[p] == '>') return p; continue; }
+        if (data[p] != '@') continue;
+        size_t l[5]; l[0] = p; bool ok = true;
+        for (int i = 1; i < 5 && ok; ++i) {
+            const void *e = memchr(data.data() + l[i - 1], '\n', data.size() - l[i - 1]);
+            if (!e) { ok = (i == 4); l[i] = data.size() + 1; break; }
+            l[i] = (size_t)((const char *)e - data.data()) + 1;
+        }
+        if (!ok || l[2] >= data.size() || data[l[2]] != '+') continue;
+        if (l[4] - l[3] != l[2] - l[1]) continue;                  // quality as long as the sequence (both with their '\n')
+        if (l[4] < data.size() && data[l[4]] != '@') continue;
+        return p;
+    }
+    return string::npos;
+}
+
+static ReadSet readInput(const string &path, bool verbose, unsigned threads)
 {
     gzFile g = gzopen(path.c_str(), "rb");
     if (!g) throw std::runtime_error("Input file not found");
-    string data; char buf[1 << 16]; int n;
-    while ((n = gzread(g, buf, sizeof(buf))) > 0) data.append(buf, (size_t)n);
+    string data;
+    { struct stat st; if (stat(path.c_str(), &st) == 0 && st.st_size > 0) data.reserve((size_t)st.st_size + 16); }
+    vector<char> buf(1 << 22); int n;
+    while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) data.append(buf.data(), (size_t)n);
     gzclose(g);
     ReadSet rs;
     if (data.empty()) return rs;
     if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
     const bool fasta = data[0] == '>';
     rs.protein = detectProtein(data, verbose);
-    vector<std::pair<size_t, size_t>> lines; // [begin, end)
-    for (size_t a = 0; a < data.size();) { size_t b = data.find('\n', a); if (b == string::npos) b = data.size(); lines.emplace_back(a, b);   /* a '\r' stays part of the line, as with the reference's getline */ a = b + 1; }
-    size_t i = 0;
-    auto isEmpty = [&](size_t k) { return lines[k].first == lines[k].second; };
-    while (i < lines.size()) {
-        if (isEmpty(i)) { ++i; continue; }
-        rs.names.push_back(data.substr(lines[i].first + 1, lines[i].second - lines[i].first - 1) + " "); // Read.hpp:711-714
-        ++i;
-        uint32_t nLines = 0; const size_t b0 = rs.bases.size();
-        while (i < lines.size()) {
-            if (!isEmpty(i) && data[lines[i].first] == (fasta ? '>' : '+')) break;
-            if (!isEmpty(i)) rs.bases.insert(rs.bases.end(), data.begin() + lines[i].first, data.begin() + lines[i].second);
-            if (!isEmpty(i) || !fasta) ++nLines;
-            ++i;
-        }
-        const size_t len = rs.bases.size() - b0;
-        for (size_t k = b0; k < rs.bases.size(); ++k)
-            if (rs.bases[k] == ' ' || rs.bases[k] == '\t') throw std::runtime_error("Spaces or tabs inside read, please check your input."); // Read.hpp:659
-        if (!fasta) {
-            ++i; size_t q = 0;
-            while (i < lines.size() && q < len) { q += lines[i].second - lines[i].first; ++i; }
-            if (q > len) throw std::runtime_error("Quality string and DNA string do not have the same length!");
-        }
-        rs.off.push_back((int64_t)rs.bases.size());
-        rs.lengths.push_back((uint32_t)(len + nLines)); // one extra per sequence line (Read.hpp:723-731)
+    // cut the file into one run of records per thread
+    size_t minChunk = 8u << 20;
+    if (const char *e = getenv("KASA_PARSE_CHUNK")) minChunk = std::max<size_t>(1, (size_t)atoll(e));   // tests force small chunks
+    const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, data.size() / minChunk));
+    vector<size_t> cut{0};
+    for (size_t c = 1; c < want; ++c) {
+        const size_t p = findRecordStart(data, std::max(cut.back(), data.size() / want * c), fasta);
+        if (p != string::npos && p > cut.back()) cut.push_back(p);
     }
+    cut.push_back(data.size());
+    const size_t nc = cut.size() - 1;
+    if (nc == 1) { parseRecords(data, 0, data.size(), fasta, rs); return rs; }
+    vector<ReadSet> part(nc);
+    vector<std::exception_ptr> err(nc);
+    vector<std::thread> pool;
+    for (size_t c = 0; c < nc; ++c)
+        pool.emplace_back([&, c] { try { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); } catch (...) { err[c] = std::current_exception(); } });
+    for (auto &t : pool) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
+    size_t nb = 0, nr = 0;
+    for (auto &q : part) { nb += q.bases.size(); nr += q.names.size(); }
+    rs.bases.resize(nb); rs.off.resize(nr + 1); rs.names.resize(nr); rs.lengths.resize(nr);
+    vector<size_t> b0(nc), r0(nc);
+    for (size_t c = 0, b = 0, r = 0; c < nc; ++c) { b0[c] = b; r0[c] = r; b += part[c].bases.size(); r += part[c].names.size(); }
+    pool.clear();
+    for (size_t c = 0; c < nc; ++c)
+        pool.emplace_back([&, c] {
+            ReadSet &q = part[c];
+            if (!q.bases.empty()) memcpy(rs.bases.data() + b0[c], q.bases.data(), q.bases.size());
+            for (size_t r = 0; r < q.names.size(); ++r) {
+                rs.names[r0[c] + r] = std::move(q.names[r]);
+                rs.lengths[r0[c] + r] = q.lengths[r];
+                rs.off[r0[c] + r + 1] = (int64_t)b0[c] + q.off[r + 1];
+            }
+        });
+    for (auto &t : pool) t.join();
     return rs;
 }
 
@@ -259,6 +342,7 @@ struct Params {
     string content, index, input, input2, rtt, profile;   // input2: second file of paired-end input (-1 / -2)
     int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
     bool kSetByUser = false;
+    unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
@@ -466,7 +550,8 @@ static int run(int argc, char **argv)
         else if (s == "-v" || s == "--verbose") p.verbose = true;
         else if (s == "--device") p.device = std::stoi(next());
         else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
-        else if (s == "-m" || s == "--memory" || s == "-n" || s == "--threads" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
+        else if (s == "-n" || s == "--threads") p.threads = (unsigned)std::max(1, std::stoi(next()));
+        else if (s == "-m" || s == "--memory" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
         else if (s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-z" || s == "-a" || s == "--alphabet")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
@@ -507,12 +592,15 @@ static int run(int argc, char **argv)
     kasa_ctx *ctx = nullptr;
     if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
 
-    ReadSet rs = readInput(p.input, p.verbose);
+    if (p.threads == 0) p.threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const auto tStart = std::chrono::steady_clock::now();
+    auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    ReadSet rs = readInput(p.input, p.verbose, p.threads);
     // paired-end (Read.hpp:834-1049): mate r of both files forms read r; the two sequences stay separate (no k-mer spans
     // the junction) but score into one row; specifier = both names, length = the sum
     vector<uint32_t> segRead;
     if (!p.input2.empty()) {
-        ReadSet r2 = readInput(p.input2, false);
+        ReadSet r2 = readInput(p.input2, false, p.threads);
         if (r2.names.size() != rs.names.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
         ReadSet m; m.protein = rs.protein;
         for (size_t r = 0; r < rs.names.size(); ++r) {
@@ -543,8 +631,8 @@ static int run(int argc, char **argv)
     // (INTEGRATION.md section 4 on what that means for the last float digit)
     const uint64_t maxKmersPerBatch = 3000000000ull;
     uint64_t totalKmers = 0, done = 0;
-    Writer w(p, content, freq);
-    string text;
+    const double tParse = secondsSince(tStart);
+    double tDevice = 0.0, tText = 0.0;
     while (done < nReads || (nReads == 0 && done == 0)) {
         uint64_t end = done, est = 0;
         while (end < nReads) {
@@ -554,6 +642,7 @@ static int run(int argc, char **argv)
             est += k; ++end;
         }
         uint64_t nk = 0;
+        const auto tDev = std::chrono::steady_clock::now();
         if (segRead.empty()) {
             if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
         } else {
@@ -570,16 +659,37 @@ static int run(int argc, char **argv)
             if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
             vector<uint64_t> ro(end - done + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
             if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
-            for (uint64_t r = done; r < end; ++r) {
-                const uint64_t lo = ro[r - done], hi = ro[r - done + 1];
-                w.read(text, r, rs.names[r], rs.lengths[r], tx.data() + lo, sc.data() + lo, hi - lo);
-                if (text.size() > (1u << 24)) { out << text; text.clear(); }
+            tDevice += secondsSince(tDev);
+            // ranking + text (N2): the reads of the batch are split over the threads in slabs, written out in order
+            const auto tTxt = std::chrono::steady_clock::now();
+            const uint64_t slab = 1u << 15;
+            for (uint64_t s0 = done; s0 < end; s0 += slab * p.threads) {
+                const unsigned nt = (unsigned)std::min<uint64_t>(p.threads, (end - s0 + slab - 1) / slab);
+                vector<string> texts(nt);
+                vector<std::exception_ptr> err(nt);
+                auto work = [&](unsigned t) {
+                    try {
+                        Writer w(p, content, freq);
+                        const uint64_t a = s0 + t * slab, b = std::min<uint64_t>(end, a + slab);
+                        string &text = texts[t];
+                        text.reserve((size_t)(b - a) * 320);
+                        for (uint64_t r = a; r < b; ++r) {
+                            const uint64_t lo = ro[r - done], hi = ro[r - done + 1];
+                            w.read(text, r, rs.names[r], rs.lengths[r], tx.data() + lo, sc.data() + lo, hi - lo);
+                        }
+                    } catch (...) { err[t] = std::current_exception(); }
+                };
+                if (nt == 1) work(0);
+                else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
+                for (auto &e : err) if (e) std::rethrow_exception(e);
+                for (auto &t : texts) out.write(t.data(), (std::streamsize)t.size());
             }
-        }
+            tText += secondsSince(tTxt);
+        } else tDevice += secondsSince(tDev);
         done = end;
         if (nReads == 0) break;
     }
-    if (!p.rtt.empty()) { out << text; if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
+    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
     const int nK = p.kHigh - p.kLow + 1;
     vector<double> all((size_t)nK * content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
     if (kasa_profile_fetch(ctx, all.data(), uniq.data(), tot.data())) throwLast();
@@ -587,6 +697,7 @@ static int run(int argc, char **argv)
     if (p.verbose) {
         double ident = 0; for (size_t t = 1; t < content.names.size(); ++t) ident += all[(size_t)(nK - 1) * content.names.size() + t];
         std::cout << "OUT: Number of k-mers in input: " << totalKmers << " of which " << ident / totalKmers * 100. << " % were identified." << std::endl;
+        std::cout << "OUT: Time fastq: " << tParse << " s (" << p.threads << " threads)\nOUT: Time compare: " << tDevice << " s\nOUT: Time output: " << tText << " s" << std::endl;   // Compare.hpp:3689-3690
     }
     kasa_ctx_destroy(ctx);
     kasa_index_destroy(ix);

@@ -88,3 +88,20 @@ def test_cpp_host_paired_end(tmp_path):
         assert r.returncode == 0, r.stderr
         assert _read(out) == _read(os.path.join(d, "out_" + stem + ".jsonl"))
         assert _read(prof) == _read(os.path.join(d, "prof_" + stem + ".csv"))
+
+
+@pytest.mark.parametrize("infile,stem", [("reads.fastq", "b100.jsonl"), ("reads.fasta", "fasta.jsonl"),
+                                          ("edge_crlf.fasta", "edge_crlf.jsonl"), ("edge_multi.fastq", "edge_multi.jsonl")])
+def test_cpp_host_parallel_parser_and_writer(infile, stem, tmp_path):
+    """The input cut into many small runs of records parsed by 4 threads, the text written by 4 threads: same bytes."""
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile),
+           "-q", out, "-p", prof, "--jsonl", "-b", "100", "-n", "4"]
+    env = dict(os.environ, KASA_PARSE_CHUNK="700")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == _read(os.path.join(d, "out_" + stem))
+    assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
