@@ -30,6 +30,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/kasa_hip.h"
@@ -1797,7 +1798,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // ------------------------------------------------------------------------------------------------
 static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
 static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
-static constexpr int FNK = 6;       // levels
+static constexpr int FNK = 6;       // levels of the default instantiation; more levels: score_fast_kernel<12|19|25>
 static constexpr int FLOG = 960;    // contributions to all other taxa, logged per read and resolved by row_merge_kernel
 static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * FNK * 4 + FLOG)
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
@@ -1807,12 +1808,20 @@ static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG + 4 * FPL); 
 // to be kept from moving them across the point (a workgroup barrier would also drain pending global stores).
 #define LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// A staging record (8 bytes).  x = taxon (24 bits) | level << 24 (4 bits) | consumed << 28 | kind << 30
+// A staging record (8 bytes).  x = taxon (20 bits) | level << 23 (5 bits) | consumed << 28 | kind << 30
 //   kind 0  event:        y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
 //                         `consumed`: its score already went into a register slot (profile still counts it).
 //   kind 1  final score:  y = float bits (a register-slot taxon)
 //   kind 2  profile only: y = |T| << 16 | hits
 static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_CONSUMED = 1u << 28;
+static constexpr int RK_LV_SHIFT = 23;
+static constexpr uint32_t RK_LV_MASK = 31u;
+__device__ __forceinline__ uint32_t rk_level(uint32_t x) { return (x >> RK_LV_SHIFT) & RK_LV_MASK; }
+// profile key {level:5 | |T|:13 | taxon:20 | hits:16} of a record
+__device__ __forceinline__ uint64_t profile_key(uint2 e)
+{
+    return ((uint64_t)((rk_level(e.x) << 13) | (e.y >> 16)) << 36) | ((uint64_t)(e.x & 0xFFFFFu) << 16) | (e.y & 0xFFFFu);
+}
 
 __device__ __forceinline__ float event_score(int k, uint32_t n)
 {
@@ -1844,9 +1853,15 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 // The kernel performs no atomics on the profile tables: everything it finds leaves as records, so it can
 // be rerun.  A read it cannot hold is handed to score_kernel untouched.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void score_fast_kernel(ScoreArgs A)
+// NKF = levels the instantiation holds in registers (its per-query sort is a bubble network over NKF slots).  With 6
+// levels a (taxon, level) counter holds four 16-bit fields (|T| = 1..4); with more levels two (|T| = 1, 2), to keep the
+// LDS footprint of a wavefront small -- larger sets leave as profile records through the log.
+template <int NKF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void score_fast_kernel(ScoreArgs A)
 {
-    __shared__ unsigned long long cnt64[FTA][FNK][64];              // 4 x 16-bit hit counters (|T| = 1..4) per (taxon, level)
+    typedef typename std::conditional<NKF <= 6, unsigned long long, uint32_t>::type Counter;
+    constexpr uint32_t CNT_FIELDS = NKF <= 6 ? 4u : 2u;
+    __shared__ Counter cnt64[FTA][NKF][64];                          // 16-bit hit counters per (taxon, level, |T|)
     __shared__ EventTables evT;
     event_tables_init(evT);
     const int lane = threadIdx.x;
@@ -1868,7 +1883,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 #pragma unroll
         for (int e = 0; e < FTA; ++e)
 #pragma unroll
-            for (int l2 = 0; l2 < FNK; ++l2) cnt64[e][l2][lane] = 0ull;
+            for (int l2 = 0; l2 < NKF; ++l2) cnt64[e][l2][lane] = 0;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
@@ -1894,8 +1909,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         float v0 = 0.0f;
                         for (int q = 0; q < nl; ++q) {
                             uint2 e2 = lg[q];
-                            if ((e2.x & 0xC0FFFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
-                            const float s2 = event_score(evT, A.kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                            if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
+                            const float s2 = event_score(evT, A.kHigh - (int)rk_level(e2.x), e2.y >> 16);
                             for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
                             e2.x |= RK_CONSUMED;
                             lg[q] = e2;
@@ -1909,12 +1924,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         float v = (e == 0) ? mS0 : mS1;
                         for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
                         if (e == 0) mS0 = v; else mS1 = v;
-                        if (n <= 4) cnt64[e][lv][lane] += (unsigned long long)c << (16 * (n - 1));
+                        if (n <= CNT_FIELDS) cnt64[e][lv][lane] += (Counter)c << (16 * (n - 1));
                         else kind = RK_PROFILE;
                     } else kind = 0u;
                     if (kind != 0xFFFFFFFFu) {
                         if (nl == FLOG || t >= (1u << 20)) { fb = true; atomicAdd(&A.why[2], 1u); break; }
-                        lg[nl] = make_uint2(t | ((uint32_t)lv << 24) | kind, (n << 16) | c);
+                        lg[nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | c);
                         ++nl;
                     }
                 }
@@ -1925,10 +1940,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 const uint32_t pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
                 const uint2 *rp = A.rec + (size_t)pcur * nK;
                 // the (up to) 6 events of this query, k ascending; absent levels sink to the end
-                uint32_t eF[FNK], eR[FNK], eK[FNK];
+                uint32_t eF[NKF], eR[NKF], eK[NKF];
                 bool early = true;
 #pragma unroll
-                for (int i = 0; i < FNK; ++i) {
+                for (int i = 0; i < NKF; ++i) {
                     const int lv = nK - 1 - i;
                     uint2 v = make_uint2(0xFFFFFFFFu, 0u);
                     if (lv >= 0) v = rp[lv];
@@ -1937,9 +1952,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     if (v.y != 0u && v.x > pnext) early = false;
                 }
 #pragma unroll
-                for (int a2 = 0; a2 < FNK - 1; ++a2)                           // stable: ties keep k ascending
+                for (int a2 = 0; a2 < NKF - 1; ++a2)                           // stable: ties keep k ascending
 #pragma unroll
-                    for (int b2 = 0; b2 < FNK - 1 - a2; ++b2)
+                    for (int b2 = 0; b2 < NKF - 1 - a2; ++b2)
                         if (eF[b2] > eF[b2 + 1]) {
                             uint32_t x = eF[b2]; eF[b2] = eF[b2 + 1]; eF[b2 + 1] = x;
                             x = eR[b2]; eR[b2] = eR[b2 + 1]; eR[b2 + 1] = x;
@@ -1948,12 +1963,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 if (np == 0 && early) {
                     // every group of this query closes before the read's next query: replay at once
 #pragma unroll
-                    for (int i = 0; i < FNK; ++i)
+                    for (int i = 0; i < NKF; ++i)
                         if (eR[i] != 0u && !fb) applyEvent(eK[i], eR[i], 1u);
                 } else {
                     // general case: merge into the pending list (sorted by (F, k)), then flush what closes
 #pragma unroll
-                    for (int i = 0; i < FNK; ++i) {
+                    for (int i = 0; i < NKF; ++i) {
                         if (eR[i] == 0u || fb) continue;
                         int pos = np;
                         while (pos > 0) {
@@ -1990,8 +2005,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             for (int e = 0; e < na; ++e)
                 for (int lv = 0; lv < nK; ++lv) {
                     const unsigned long long pk = cnt64[e][lv][lane];
-                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);
+                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
                 }
+        if (active && !fb && (uint32_t)na + nprof + (uint32_t)nl > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
         const uint32_t m = (active && !fb) ? (uint32_t)na + nprof + (uint32_t)nl : 0u;
         uint32_t incl = m;
         for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
@@ -2014,7 +2030,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                         const unsigned long long pk = cnt64[e][lv][lane];
                         for (uint32_t q = 0; q < 4; ++q) {
                             const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
-                            if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << 24) | RK_PROFILE, ((q + 1) << 16) | cq);
+                            if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
                         }
                     }
                 }
@@ -2035,7 +2051,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 // row_merge: one wavefront per staging row written by score_fast_kernel.  Sorts the row's records by
 // (taxon, position) in LDS, sums each taxon's event scores IN THAT ORDER (= the read's flush order), and
 // compacts the row in place to final {taxon, score} pairs, taxon ascending.  Every event / profile record
-// also leaves as a 64-bit profile key {level:3 | |T|:13 | taxon:20 | hits:16} for the sort-reduce below.
+// also leaves as a 64-bit profile key {level:5 | |T|:13 | taxon:20 | hits:16} for the sort-reduce below.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
                                                        uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
@@ -2060,7 +2076,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                 const uint32_t kind = e.x >> 30;
                 if (kind != 2u) key = ((e.x & 0xFFFFFu) << 11) | (kind == 1u ? 0u : (i & 0x7FFu));   // final score first in its run
                 if (kind != 1u)
-                    profKeys[s0 + i] = ((uint64_t)(((e.x >> 24) & 7u) << 13 | (e.y >> 16)) << 36) | ((uint64_t)(e.x & 0xFFFFFu) << 16) | (e.y & 0xFFFFu);
+                    profKeys[s0 + i] = profile_key(e);
             }
             sKey[i] = key;
             sIdx[i] = (uint16_t)i;
@@ -2097,7 +2113,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                         const uint2 e = sRec[sIdx[q]];
                         if ((e.x >> 30) == 1u) { v = __uint_as_float(e.y); any = true; }
                         else if (!(e.x & RK_CONSUMED)) {
-                            const float s = event_score(kHigh - (int)((e.x >> 24) & 15u), e.y >> 16);
+                            const float s = event_score(kHigh - (int)rk_level(e.x), e.y >> 16);
                             for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, s);
                             any = true;
                         }
@@ -2150,7 +2166,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             const uint32_t t = e.x & 0xFFFFFu;
             if (kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
             if (kind != 1u)
-                profKeys[s0 + i] = ((uint64_t)(((e.x >> 24) & 7u) << 13 | (e.y >> 16)) << 36) | ((uint64_t)t << 16) | (e.y & 0xFFFFu);
+                profKeys[s0 + i] = profile_key(e);
         }
         LDS_WAVE_SYNC();
         uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
@@ -2191,7 +2207,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                 ++seen;
                 if ((e2.x >> 30) == 1u) v = __uint_as_float(e2.y);
                 else if (!(e2.x & RK_CONSUMED)) {
-                    const float sc = event_score(evT, kHigh - (int)((e2.x >> 24) & 15u), e2.y >> 16);
+                    const float sc = event_score(evT, kHigh - (int)rk_level(e2.x), e2.y >> 16);
                     for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
                 }
             }
@@ -2202,10 +2218,11 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
     }
 }
 
-struct ProfKeyOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & 0xFFFFFFFFFull; } };
+static constexpr uint64_t PROF_KEY_MASK = 0x3FFFFFFFFFull;           // 38 bits: level 5 | |T| 13 | taxon 20
+struct ProfKeyOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & PROF_KEY_MASK; } };
 struct ProfHitsOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return v & 0xFFFFull; } };
 
-// profile sort-reduce: keys sorted on bits [16, 52); one add per distinct (level, |T|, taxon)
+// profile sort-reduce: keys sorted on bits [16, 54); one add per distinct (level, |T|, taxon)
 __global__ void profile_apply_kernel(const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ sums, const uint32_t *__restrict__ nRuns,
                                      uint32_t nTaxa, uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
                                      uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab)
@@ -2213,7 +2230,7 @@ __global__ void profile_apply_kernel(const uint64_t *__restrict__ uniq, const ui
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *nRuns) return;
     const uint64_t key = uniq[i];
-    if (key == 0xFFFFFFFFFull) return;                                  // sentinel slots
+    if (key == PROF_KEY_MASK) return;                                   // sentinel slots
     const uint32_t tax = (uint32_t)(key & 0xFFFFFu);
     const uint32_t n = (uint32_t)((key >> 20) & 0x1FFFu);
     const uint32_t lv = (uint32_t)(key >> 33);
@@ -2324,7 +2341,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)) || (rc = c->fbList.reserve((size_t)nReads * 4 + 64)))
         return rc;
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
-    const bool fast = nK <= FNK && !c->forceSlowScore;
+    const bool fast = nK <= 25 && !c->forceSlowScore;
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
     uint32_t staged = 0;
     ScoreArgs A;
@@ -2354,7 +2371,10 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
-            score_fast_kernel<<<fblocks, 64, 0, c->stream>>>(A);
+            if (nK <= 6) score_fast_kernel<6><<<fblocks, 64, 0, c->stream>>>(A);
+            else if (nK <= 12) score_fast_kernel<12><<<fblocks, 64, 0, c->stream>>>(A);
+            else if (nK <= 19) score_fast_kernel<19><<<fblocks, 64, 0, c->stream>>>(A);
+            else score_fast_kernel<25><<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h, counters + 1, 12, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -2416,9 +2436,9 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
                 c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh);
         HIPCHK(hipGetLastError());
         size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 52u, c->stream));
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 54u, c->stream));
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 52u, c->stream));
+        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 54u, c->stream));
         const uint64_t perTaxon = std::min<uint64_t>(8191, nTaxa);
         const uint64_t cap = std::min<uint64_t>((uint64_t)staged, (uint64_t)nK * nTaxa * perTaxon) + 2;
         if ((rc = c->profUniq.reserve(cap * 8)) || (rc = c->profSums.reserve(cap * 8))) return rc;
