@@ -2144,8 +2144,8 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                                                               int kHigh, uint32_t nTaxa, uint32_t mLo)
 {
     __shared__ uint32_t bm[BMW], pre[BMW];
-    __shared__ uint2 sRec[RCAP];
-    __shared__ uint32_t cnt[RCAP], first[RCAP];
+    __shared__ float val[RCAP];                                        // running score of a slot (= taxon of the row)
+    __shared__ uint32_t slotTax[RCAP], claim[RCAP];
     __shared__ EventTables evT;
     event_tables_init(evT);
     const int lane = threadIdx.x;
@@ -2157,16 +2157,15 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
         if (m <= mLo || m > (uint32_t)RCAP) continue;
         const uint32_t s0 = rowPos[r];
         for (uint32_t w = lane; w < W; w += 64) bm[w] = 0u;
-        for (uint32_t i = lane; i < m; i += 64) { cnt[i] = 0u; first[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = lane; i < m; i += 64) { val[i] = 0.0f; claim[i] = 0xFFFFFFFFu; }
         LDS_WAVE_SYNC();
+        // pass 1: the row's taxa as a bitmap; every event / profile record leaves as a profile key
         for (uint32_t i = lane; i < m; i += 64) {
             const uint2 e = st[s0 + i];
-            sRec[i] = e;
             const uint32_t kind = e.x >> 30;
             const uint32_t t = e.x & 0xFFFFFu;
             if (kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
-            if (kind != 1u)
-                profKeys[s0 + i] = profile_key(e);
+            if (kind != 1u) profKeys[s0 + i] = profile_key(e);
         }
         LDS_WAVE_SYNC();
         uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
@@ -2183,36 +2182,40 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
         }
         const uint32_t nSlots = carry;
         LDS_WAVE_SYNC();
-        for (uint32_t i = lane; i < m; i += 64) {
-            const uint2 e = sRec[i];
-            if ((e.x >> 30) == 2u) continue;
-            const uint32_t t = e.x & 0xFFFFFu;
-            const uint32_t slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
-            atomicAdd(&cnt[slot], 1u);
-            atomicMin(&first[slot], i);
-        }
-        LDS_WAVE_SYNC();
-        for (uint32_t i = lane; i < m; i += 64) {
-            const uint2 e = sRec[i];
-            if ((e.x >> 30) == 2u) continue;
-            const uint32_t t = e.x & 0xFFFFFu;
-            const uint32_t slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
-            if (first[slot] != i) continue;                            // the taxon's first record owns the slot
-            float v = 0.0f;
-            const uint32_t nrec = cnt[slot];
-            uint32_t seen = 0;
-            for (uint32_t q = i; q < m && seen < nrec; ++q) {          // its records in row order = flush order
-                const uint2 e2 = sRec[q];
-                if ((e2.x >> 30) == 2u || (e2.x & 0xFFFFFu) != t) continue;
-                ++seen;
-                if ((e2.x >> 30) == 1u) v = __uint_as_float(e2.y);
-                else if (!(e2.x & RK_CONSUMED)) {
-                    const float sc = event_score(evT, kHigh - (int)rk_level(e2.x), e2.y >> 16);
-                    for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
+        // pass 2: 64 records at a time, in row order (= the read's flush order).  A record adds its hits to the running
+        // score of its taxon's slot; two records of one chunk that share a slot take turns in lane order.
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint2 e = make_uint2(0u, 0u);
+            bool pending = false;
+            uint32_t slot = 0;
+            float sc = 0.0f;
+            if (i < m) {
+                e = st[s0 + i];                                        // (L2-hot: read in pass 1 a moment ago)
+                const uint32_t kind = e.x >> 30;
+                if (kind != 2u) {
+                    const uint32_t t = e.x & 0xFFFFFu;
+                    slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
+                    slotTax[slot] = t;                                 // every record of the slot writes the same value
+                    if (kind == 1u) val[slot] = __uint_as_float(e.y);  // the register taxon's final score: its log records are all consumed
+                    else if (!(e.x & RK_CONSUMED)) { pending = true; sc = event_score(evT, kHigh - (int)rk_level(e.x), e.y >> 16); }
                 }
             }
-            st[s0 + slot] = make_uint2(t, __float_as_uint(v));
+            while (__ballot(pending) != 0ull) {
+                if (pending) atomicMin(&claim[slot], (uint32_t)lane);
+                LDS_WAVE_SYNC();
+                if (pending && claim[slot] == (uint32_t)lane) {
+                    float v = val[slot];
+                    for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
+                    val[slot] = v;
+                    claim[slot] = 0xFFFFFFFFu;
+                    pending = false;
+                }
+                LDS_WAVE_SYNC();
+            }
         }
+        LDS_WAVE_SYNC();
+        for (uint32_t sl = lane; sl < nSlots; sl += 64) st[s0 + sl] = make_uint2(slotTax[sl], __float_as_uint(val[sl]));
         if (lane == 0) rowLen[r] = nSlots;                             // flag cleared: the other instantiation skips it
         LDS_WAVE_SYNC();
     }
