@@ -495,3 +495,41 @@ def test_paired_end_golden_files(case):
     assert prof2 == prof
     idf.close()
     _check_against_oracle(ix, batch, 12, 7, frames, unique=True)
+
+
+def test_two_contexts_share_one_index_concurrently():
+    """identify_multiple (main.cpp:1292-1326): several drivers run at the same time on one read-only index.  Two host
+    threads, each with its own context (stream, buffers, profile tables), different batches, same DeviceIndex."""
+    _gpu_or_fail()
+    import threading
+    ix, batch = synthetic_world(71, 10, 8000, 3000)
+    halves = [batch.slice(0, 1400), batch.slice(1400, 3000)]
+    dix = capi.DeviceIndex(ix)
+    out = [None, None]
+    err = []
+
+    def work(i):
+        try:
+            ctx = capi.Context(dix, 12, 7, 3 if i == 0 else 6)
+            for _ in range(3):                                   # a few rounds, so the two really overlap
+                ctx.profile_reset()
+                ctx.run_batch(halves[i].bases, halves[i].offsets, True)
+            out[i] = (ctx.scores(), ctx.profile())
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err, err
+    for i in range(2):
+        p = oracle.params(12, 7, 3 if i == 0 else 6)
+        res, _ = oracle.identify_batch(ix, halves[i].bases, halves[i].offsets, p, True)
+        (off, tax, sc), (ca, cu, _) = out[i]
+        assert np.array_equal(cu, res.count_unique)
+        np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+        assert_csr_equal(csr_rows(off, tax, sc), helpers.csr_from_dense(res.M))
+    dix.close()
