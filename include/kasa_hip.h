@@ -122,6 +122,19 @@ int kasa_batch_sort_and_range(kasa_ctx *ctx, int unique);
  * cells of the reads x taxa score matrix (Utilities.hpp:592-636) as a CSR. */
 int kasa_batch_lookup_score(kasa_ctx *ctx, int wantPerRead, int coverage);
 
+/* The two halves of kasa_batch_lookup_score as separate steps, with the event records in between exposed, for an index
+ * that is range-partitioned over devices (C5; the reference's loadIndex has no such mode, the seam is ours):
+ *   kasa_batch_group          per sorted query and level: flush position + taxon-set reference (8 bytes), taxon lists
+ *                             that do not fit a reference in a pool of 32-bit words {n, taxa...};
+ *   kasa_batch_records_*      size / download of both; import replaces them on a context whose batch is sorted
+ *                             (records = nQueries x nLevels entries {u32 flushPosition, u32 reference}, level kHigh first);
+ *   kasa_batch_score          replays the records per read (scores, profile) exactly as kasa_batch_lookup_score does. */
+int kasa_batch_group(kasa_ctx *ctx, int coverage);
+int kasa_batch_score(kasa_ctx *ctx, int wantPerRead);
+int kasa_batch_records_size(kasa_ctx *ctx, uint64_t *nRecords, uint64_t *nPoolWords);
+int kasa_batch_records_fetch(kasa_ctx *ctx, uint64_t *records, uint32_t *pool);
+int kasa_batch_records_import(kasa_ctx *ctx, const uint64_t *records, uint64_t nRecords, const uint32_t *pool, uint64_t nPoolWords);
+
 /* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
  * scoringFunc scans (Compare.hpp:1501-1522). */
 int kasa_batch_scores_size(kasa_ctx *ctx, uint64_t *nnz);

@@ -20,7 +20,8 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
     "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_segments", "kasa_batch_encode",
-    "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
+    "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
+    "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
@@ -156,6 +157,26 @@ class Context:
 
     def lookup_score(self, want_per_read: bool = True, coverage: bool = False):
         _check(lib().kasa_batch_lookup_score(self.h, C.c_int(int(want_per_read)), C.c_int(int(coverage))))
+
+    def group(self, coverage: bool = False):
+        _check(lib().kasa_batch_group(self.h, C.c_int(int(coverage))))
+
+    def score(self, want_per_read: bool = True):
+        _check(lib().kasa_batch_score(self.h, C.c_int(int(want_per_read))))
+
+    def records(self):
+        """Event records of the batch: (rec u32[nQ, nK, 2] = {flush position, taxon-set reference}, pool u32[])."""
+        n, m = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().kasa_batch_records_size(self.h, C.byref(n), C.byref(m)))
+        rec = np.zeros((int(n.value), 2), dtype=np.uint32)
+        pool = np.zeros(max(1, int(m.value)), dtype=np.uint32)
+        _check(lib().kasa_batch_records_fetch(self.h, _p(rec), _p(pool)))
+        return rec.reshape(-1, self.nK, 2), pool
+
+    def records_import(self, rec: np.ndarray, pool: np.ndarray):
+        rec = np.ascontiguousarray(rec, dtype=np.uint32).reshape(-1, 2)
+        pool = np.ascontiguousarray(pool, dtype=np.uint32)
+        _check(lib().kasa_batch_records_import(self.h, _p(rec), C.c_uint64(rec.shape[0]), _p(pool), C.c_uint64(pool.shape[0])))
 
     def scores(self):
         """CSR (offsets u64[nReads+1], taxIdx u32[nnz], score f32[nnz])."""

@@ -449,6 +449,7 @@ struct kasa_ctx {
     uint32_t maxCnt = 0;
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
+    bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
     // buffers
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
     DevBuf seqOff, seqRead;                    // u64[nSeq+1] k-mer offset of every uploaded sequence, u32[nSeq] its read
@@ -633,7 +634,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     if (nSeq < 0 || nReads < 0 || (nSeq > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
     if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
     const uint64_t nBases = nSeq ? (uint64_t)(offsets[nSeq] - offsets[0]) : 0;
     std::vector<uint64_t> soff((size_t)nSeq + 1), koff((size_t)nReads + 1, 0);
     c->hostOff.assign((size_t)nSeq + 1, 0);
@@ -1115,6 +1116,7 @@ __global__ void unique_scatter_kernel(const Key *__restrict__ kmer, const uint32
 template <class Key>
 static int sort_and_range_impl(kasa_ctx *c, int unique)
 {
+    c->grouped = false;
     HIPCHK(hipSetDevice(c->ix->device));
     uint64_t nQ = c->nQ;
     int rc;
@@ -2264,27 +2266,20 @@ __global__ void widen_kernel(const uint32_t *__restrict__ in, uint64_t *__restri
     if (i < n) out[i] = in[i] & 0x7FFFFFFFu;   // bit 31 = ROW_MERGE
 }
 
-extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverage)
+// lookup_score = group (per-level taxon sets and flush positions of every sorted query -> event records + taxon-list pool)
+// followed by score (records replayed per read).  The two halves are separate entry points so that the records can
+// travel: with a range-partitioned index the partition owner runs `group` on a slice of
+// another rank's sorted queries, and the read owner runs `score` on the records it gets back.
+static int group_stage(kasa_ctx *c, int coverage)
 {
-    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_lookup_score: batch not sorted");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_group: batch not sorted");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint64_t nQ = c->nQ;
-    const uint32_t nReads = (uint32_t)c->nReads;
     const uint32_t nTaxa = c->ix->nTaxa;
     const int nK = c->nK;
     int rc;
-    c->haveScores = false; c->nnz = 0;
-    if (nQ == 0 || nReads == 0) {
-        if (wantPerRead) {
-            if ((rc = c->rowOff.reserve(((size_t)nReads + 1) * 8))) return rc;
-            HIPCHK(hipMemsetAsync(c->rowOff.p, 0, ((size_t)nReads + 1) * 8, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            c->haveScores = true;
-        }
-        c->state = 4;
-        return KASA_OK;
-    }
+    c->haveScores = false; c->nnz = 0; c->grouped = false; c->poolUsed = 1;
+    if (nQ == 0) { c->grouped = true; return KASA_OK; }
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
     if ((rc = c->rec.reserve(nQ * (size_t)nK * 8 + 64))) return rc;
     uint32_t *counters = c->misc.as<uint32_t>(); // [0] pool cursor, [1] staging cursor, [2] error flags
@@ -2317,11 +2312,38 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
         uint32_t used = 0;
         HIPCHK(hipMemcpyAsync(&used, counters, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (used <= c->poolCap) break;
+        if (used <= c->poolCap) { c->poolUsed = used; break; }
         if ((uint64_t)used >= 0x3FFFFFF0ull) return fail(KASA_E_LIMIT, "taxon-list pool exceeds 2^30 entries in one batch; split the batch");
         c->poolCap = (uint64_t)used + used / 8 + 1024;
         if (attempt > 3) return fail(KASA_E_LIMIT, "taxon-list pool did not converge");
     }
+
+    c->grouped = true;
+    return KASA_OK;
+}
+
+static int score_stage(kasa_ctx *c, int wantPerRead)
+{
+    if (c->state < 3 || !c->grouped) return fail(KASA_E_STATE, "kasa_batch_score: no event records (call kasa_batch_group or kasa_batch_records_import)");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint64_t nQ = c->nQ;
+    const uint32_t nReads = (uint32_t)c->nReads;
+    const uint32_t nTaxa = c->ix->nTaxa;
+    const int nK = c->nK;
+    int rc;
+    c->haveScores = false; c->nnz = 0;
+    if (nQ == 0 || nReads == 0) {
+        if (wantPerRead) {
+            if ((rc = c->rowOff.reserve(((size_t)nReads + 1) * 8))) return rc;
+            HIPCHK(hipMemsetAsync(c->rowOff.p, 0, ((size_t)nReads + 1) * 8, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->haveScores = true;
+        }
+        c->state = 4;
+        return KASA_OK;
+    }
+    uint32_t *counters = c->misc.as<uint32_t>(); // [0] pool cursor, [1] staging cursor, [2] error flags
+    hipEvent_t a, b;
 
     // ---- regroup: sorted positions by read, stable (so each read sees its queries in sorted order)
     if ((rc = c->plist.reserve(nQ * 4 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
@@ -2486,6 +2508,70 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
     return KASA_OK;
 }
 
+
+extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverage)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_lookup_score: batch not sorted");
+    int rc = group_stage(c, coverage);
+    if (rc) return rc;
+    return score_stage(c, wantPerRead);
+}
+
+extern "C" int kasa_batch_group(kasa_ctx *c, int coverage)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    return group_stage(c, coverage);
+}
+
+extern "C" int kasa_batch_score(kasa_ctx *c, int wantPerRead)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    return score_stage(c, wantPerRead);
+}
+
+extern "C" int kasa_batch_records_size(kasa_ctx *c, uint64_t *nRecords, uint64_t *nPoolWords)
+{
+    if (!c || !nRecords || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_size: NULL argument");
+    if (!c->grouped) return fail(KASA_E_STATE, "kasa_batch_records_size: no event records");
+    *nRecords = c->nQ * (uint64_t)c->nK;
+    *nPoolWords = c->poolUsed;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_fetch(kasa_ctx *c, uint64_t *records, uint32_t *pool)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (!c->grouped) return fail(KASA_E_STATE, "kasa_batch_records_fetch: no event records");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint64_t n = c->nQ * (uint64_t)c->nK;
+    if (n && records) HIPCHK(hipMemcpy(records, c->rec.p, n * 8, hipMemcpyDeviceToHost));
+    if (pool && c->poolUsed) {
+        if (c->nQ) HIPCHK(hipMemcpy(pool, c->pool.p, (size_t)c->poolUsed * 4, hipMemcpyDeviceToHost));
+        pool[0] = 0;                                                   // word 0 is the cursor's start: never referenced
+    }
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint64_t *records, uint64_t nRecords, const uint32_t *pool, uint64_t nPoolWords)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_records_import: batch not sorted");
+    if (nRecords != c->nQ * (uint64_t)c->nK) return fail(KASA_E_ARG, "kasa_batch_records_import: %llu records for %llu queries x %d levels", (unsigned long long)nRecords, (unsigned long long)c->nQ, c->nK);
+    if ((nRecords && !records) || (nPoolWords && !pool) || nPoolWords >= 0x3FFFFFF0ull) return fail(KASA_E_ARG, "kasa_batch_records_import: bad arguments");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc;
+    if ((rc = c->rec.reserve(nRecords * 8 + 64)) || (rc = c->pool.reserve((nPoolWords + 1) * 4))) return rc;
+    c->poolCap = std::max<uint64_t>(c->poolCap, nPoolWords + 1);
+    if (nRecords) HIPCHK(hipMemcpyAsync(c->rec.p, records, nRecords * 8, hipMemcpyHostToDevice, c->stream));
+    if (nPoolWords) HIPCHK(hipMemcpyAsync(c->pool.p, pool, nPoolWords * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->poolUsed = (uint32_t)std::max<uint64_t>(1, nPoolWords);
+    c->grouped = true; c->haveScores = false;
+    return KASA_OK;
+}
+
 extern "C" int kasa_batch_scores_size(kasa_ctx *c, uint64_t *nnz)
 {
     if (!c || !nnz) return fail(KASA_E_ARG, "kasa_batch_scores_size: NULL argument");
@@ -2640,7 +2726,7 @@ extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false;
+    c->state = 0; c->haveScores = false; c->grouped = false;
     std::vector<uint64_t> koff((size_t)nReads + 1, 0);
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {

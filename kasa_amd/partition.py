@@ -1,0 +1,119 @@
+"""Range-partitioned index (BASELINE.json config C5: an index larger than one GPU's HBM).
+
+The sorted index is cut at 30-bit prefix boundaries -- a prefix range of the reference's `_trie`
+(source/modes/Trie.hpp:494-520) never straddles a cut -- and every partition is an index of its own
+(`capi.DeviceIndex`).  One batch then runs as
+
+    owner   : upload + encode + sort its reads                        (kasa_batch_upload/encode/sort_and_range)
+              cut the sorted queries at the same prefixes: slice j is contiguous
+    worker j: group slice j against partition j                       (kasa_batch_set_queries/sort_and_range/group,
+                                                                        kasa_batch_records_fetch)
+    owner   : concatenate the event records in partition order (= global sorted order), shift flush
+              positions by the slice start and list references by the pool offset, score
+                                                                        (kasa_batch_records_import/score)
+
+A slice is a batch of its own for the worker: its first query opens a new prefix range, so nothing of
+the grouping reaches across a cut, and the result equals the run against the unpartitioned index bit for
+bit (tests/test_gpu_partition.py).  `LocalExchange` runs all partitions in one process (one GPU, tests);
+`kasa_amd/dist.py:partitioned_batch` moves the slices with torch.distributed instead (one partition per
+rank).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi, formats
+
+REF_INLINE = np.uint32(0xC0000000)   # REF_SINGLE | REF_PAIR: the reference holds the taxa itself
+
+
+def split_index(ix: formats.Index, n_parts: int):
+    """-> (list of formats.Index, cuts u64[n_parts]): partition j holds the entries whose 30-bit prefix p
+    satisfies cuts[j] <= p < cuts[j+1]; about equal record counts, cut only between `_trie` entries."""
+    ends = np.cumsum(ix.trie_count.astype(np.int64))
+    parts, cuts = [], []
+    lo_t = 0
+    for j in range(n_parts):
+        target = ix.n * (j + 1) // n_parts
+        hi_t = int(np.searchsorted(ends, target, side="left")) + 1 if j + 1 < n_parts else ends.shape[0]
+        hi_t = max(min(hi_t, ends.shape[0]), lo_t)
+        a = int(ends[lo_t - 1]) if lo_t else 0
+        b = int(ends[hi_t - 1]) if hi_t else 0
+        cuts.append(int(ix.trie_prefix[lo_t]) if lo_t < ends.shape[0] and j > 0 else (0 if j == 0 else 1 << 30))
+        parts.append(formats.Index(ix.kmer[a:b], ix.taxid[a:b], ix.tax[a:b], ix.trie_prefix[lo_t:hi_t],
+                                   ix.trie_count[lo_t:hi_t], ix.content, ix.freq))
+        lo_t = hi_t
+    return parts, np.asarray(cuts, dtype=np.uint64)
+
+
+def slice_starts(km_sorted: np.ndarray, cuts: np.ndarray, K: int) -> np.ndarray:
+    """Start of every partition's slice in the sorted queries (plus the end): i64[n_parts + 1]."""
+    pre = formats.key_shr(km_sorted, 5 * (K - formats.TRIE_LETTERS))
+    s = np.searchsorted(pre, cuts.astype(np.uint64), side="left").astype(np.int64)
+    s[0] = 0
+    return np.concatenate((s, [km_sorted.shape[0]]))
+
+
+def assemble_records(parts, starts):
+    """parts[j] = (rec u32[n_j, nK, 2], pool u32[m_j]) of slice j -> one (rec, pool) for the whole batch."""
+    recs, pools, base = [], [np.zeros(1, dtype=np.uint32)], 1
+    for j, (rec, pool) in enumerate(parts):
+        rec = rec.copy()
+        rec[:, :, 0] += np.uint32(starts[j])                       # flush positions: slice-local -> batch
+        ref = rec[:, :, 1]
+        lists = (ref != 0) & ((ref & REF_INLINE) == 0)              # offsets into the slice's pool (word 0 unused)
+        ref[lists] += np.uint32(base - 1)
+        recs.append(rec)
+        pools.append(pool[1:])
+        base += pool.shape[0] - 1
+    nk = parts[0][0].shape[1] if parts else 1
+    rec_all = np.concatenate(recs) if recs else np.zeros((0, nk, 2), dtype=np.uint32)
+    return rec_all, np.concatenate(pools)
+
+
+class Worker:
+    """Partition owner: groups slices of foreign sorted queries against its partition."""
+
+    def __init__(self, dix: capi.DeviceIndex, k_high: int, k_low: int, frames: int):
+        self.ctx = capi.Context(dix, k_high, k_low, frames)
+
+    def group_slice(self, km: np.ndarray, rd: np.ndarray, n_reads: int):
+        self.ctx.set_queries(km, rd, n_reads)
+        self.ctx.sort_and_range()                                  # already sorted; the sort is stable
+        self.ctx.group()
+        return self.ctx.records()
+
+    def close(self):
+        self.ctx.close()
+
+
+class LocalExchange:
+    """All partitions in this process (one GPU): the reference implementation of the exchange, used by the tests."""
+
+    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0):
+        self.cuts = cuts
+        self.K = parts[0].K
+        self.dix = [capi.DeviceIndex(p, device) for p in parts]
+        self.workers = [Worker(d, k_high, k_low, frames) for d in self.dix]
+        self.owner = capi.Context(self.dix[0], k_high, k_low, frames)   # the owner needs an index only for its key width
+
+    def run_batch(self, batch, want_per_read=True, unique=False):
+        ctx = self.owner
+        ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)
+        ctx.encode()
+        ctx.sort_and_range(unique)
+        km, rd = ctx.queries()
+        starts = slice_starts(km, self.cuts, self.K)
+        parts = [w.group_slice(km[starts[j]:starts[j + 1]], rd[starts[j]:starts[j + 1]], ctx.n_reads)
+                 for j, w in enumerate(self.workers)]
+        rec, pool = assemble_records(parts, starts)
+        ctx.records_import(rec, pool)
+        ctx.score(want_per_read)
+        return ctx
+
+    def close(self):
+        self.owner.close()
+        for w in self.workers:
+            w.close()
+        for d in self.dix:
+            d.close()
