@@ -262,3 +262,28 @@ def write_index(ix: Index, prefix: str, content_path: str) -> None:
         for r in range(1, ix.content.n_taxa):
             tid = int(ix.content.taxids[r])
             f.write(f"{ix.content.names[r]}\t{tid}\t{tid}\tACC{r}\n")
+
+
+def write_index_halved(ix: Index, prefix: str) -> None:
+    """The index of `shrink -s 2` (source/modes/Shrink.hpp:78-143): entries with fewer than seven real letters (their
+    seventh letter is already '^') are dropped, the others keep the low 30 bits of the k-mer and the dense taxon index
+    -- {u32, u16} = 6 bytes -- next to a `_trie` that supplies the upper 30 bits.  64-bit indices only."""
+    if is_wide(ix.kmer):
+        raise NotImplementedError("the halved format exists for 64-bit indices only")
+    keep = ((ix.kmer >> np.uint64(25)) & np.uint64(31)) != np.uint64(30)
+    km, tax, taxid = ix.kmer[keep], ix.tax[keep], ix.taxid[keep]
+    rec = np.zeros(km.shape[0], dtype=HALF_DTYPE)
+    rec["low"] = (km & np.uint64(0x3FFFFFFF)).astype(np.uint32)
+    rec["tax"] = tax.astype(np.uint16)
+    rec.tofile(prefix)
+    with open(prefix + "_info.txt", "w") as f:
+        f.write(str(km.shape[0]) + "\n3")
+    tp, tc = trie_from_kmers(km)
+    t = np.zeros(tp.shape[0], dtype=TRIE_DTYPE)
+    t["count"], t["prefix"] = tc, tp
+    t.tofile(prefix + "_trie")
+    with open(prefix + "_trie.txt", "w") as f:
+        f.write(str(t.shape[0]))
+    with open(prefix + "_f.txt", "w") as f:                          # shrink copies the frequency file of the full index
+        for r in range(ix.content.n_taxa):
+            f.write(ix.content.names[r] + "\t" + "\t".join(str(int(v)) for v in ix.freq[r]) + "\n")

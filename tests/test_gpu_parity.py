@@ -533,3 +533,17 @@ def test_two_contexts_share_one_index_concurrently():
         np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
         assert_csr_equal(csr_rows(off, tax, sc), helpers.csr_from_dense(res.M))
     dix.close()
+
+
+@pytest.mark.parametrize("stem,K", [("idx", 12), ("idx25", 25)])
+def test_index_build_matches_reference_files(stem, K, tmp_path):
+    """`build` with the device encoder + sort (kasa_amd/index_build.py): index, trie, frequency and info files
+    byte-identical to what the reference's build mode wrote for the same FASTA + content file."""
+    _gpu_or_fail()
+    from kasa_amd import index_build
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    ix = index_build.build_index(os.path.join(d, "db.fasta"), os.path.join(d, "content.txt"), K=K)
+    out = str(tmp_path / "new")
+    formats.write_index(ix, out, str(tmp_path / "content_copy.txt"))
+    for suffix in ("", "_trie", "_trie.txt", "_info.txt", "_f.txt"):
+        assert _read(out + suffix) == _read(os.path.join(d, stem + suffix)), suffix

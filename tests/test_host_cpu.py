@@ -95,3 +95,17 @@ def test_read_parsing_matches_reference_conventions(golden_dir):
     with pytest.raises(RuntimeError):
         p = os.path.join(str(d), "..", "PROVENANCE.json")
         reads.parse_reads(p)
+
+
+def test_halved_index_writer_matches_reference_shrink(tmp_path):
+    """formats.write_index_halved == the files `kASA shrink -s 2` wrote for the same index (tests/golden/pairs/idx_half*)."""
+    import os
+    from kasa_amd import formats
+    from tests import helpers
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    ix = formats.load_index(os.path.join(d, "idx"), os.path.join(d, "content.txt"))
+    out = str(tmp_path / "h")
+    formats.write_index_halved(ix, out)
+    for suffix in ("", "_trie", "_trie.txt", "_info.txt", "_f.txt"):
+        with open(out + suffix, "rb") as a, open(os.path.join(d, "idx_half" + suffix), "rb") as b:
+            assert a.read() == b.read(), suffix
