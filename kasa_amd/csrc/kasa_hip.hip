@@ -1858,7 +1858,9 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 // NKF = levels the instantiation holds in registers (its per-query sort is a bubble network over NKF slots).  With 6
 // levels a (taxon, level) counter holds four 16-bit fields (|T| = 1..4); with more levels two (|T| = 1, 2), to keep the
 // LDS footprint of a wavefront small -- larger sets leave as profile records through the log.
-template <int NKF>
+// PERREAD = false (no -q: profile only): the order of a read's events does not matter for the profile, so the per-query
+// sort, the pending list and the float chain are left out; what remains is counting hits per (level, |T|, taxon).
+template <int NKF, bool PERREAD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void score_fast_kernel(ScoreArgs A)
 {
     typedef typename std::conditional<NKF <= 6, unsigned long long, uint32_t>::type Counter;
@@ -1909,7 +1911,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                         // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
                         // slot.  If shallow matches already started its chain in the log, replay them first.
                         float v0 = 0.0f;
-                        for (int q = 0; q < nl; ++q) {
+                        for (int q = 0; PERREAD && q < nl; ++q) {
                             uint2 e2 = lg[q];
                             if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
                             const float s2 = event_score(evT, A.kHigh - (int)rk_level(e2.x), e2.y >> 16);
@@ -1923,12 +1925,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     }
                     uint32_t kind = 0xFFFFFFFFu;                               // record to log, if any
                     if (e >= 0) {
-                        float v = (e == 0) ? mS0 : mS1;
-                        for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
-                        if (e == 0) mS0 = v; else mS1 = v;
+                        if (PERREAD) {
+                            float v = (e == 0) ? mS0 : mS1;
+                            for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
+                            if (e == 0) mS0 = v; else mS1 = v;
+                        }
                         if (n <= CNT_FIELDS) cnt64[e][lv][lane] += (Counter)c << (16 * (n - 1));
                         else kind = RK_PROFILE;
-                    } else kind = 0u;
+                    } else kind = PERREAD ? 0u : RK_PROFILE;
                     if (kind != 0xFFFFFFFFu) {
                         if (nl == FLOG || t >= (1u << 20)) { fb = true; atomicAdd(&A.why[2], 1u); break; }
                         lg[nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | c);
@@ -1952,6 +1956,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     if (v.y == 0u) v.x = 0xFFFFFFFFu;
                     eF[i] = v.x; eR[i] = v.y; eK[i] = (uint32_t)(A.kHigh - lv);
                     if (v.y != 0u && v.x > pnext) early = false;
+                }
+                if (!PERREAD) {                                                // any order will do
+#pragma unroll
+                    for (int i = 0; i < NKF; ++i)
+                        if (eR[i] != 0u && !fb) applyEvent(eK[i], eR[i], 1u);
+                    pcur = pnext;
+                    continue;
                 }
 #pragma unroll
                 for (int a2 = 0; a2 < NKF - 1; ++a2)                           // stable: ties keep k ascending
@@ -2009,8 +2020,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                     const unsigned long long pk = cnt64[e][lv][lane];
                     nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
                 }
-        if (active && !fb && (uint32_t)na + nprof + (uint32_t)nl > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
-        const uint32_t m = (active && !fb) ? (uint32_t)na + nprof + (uint32_t)nl : 0u;
+        if (active && !fb && (PERREAD ? (uint32_t)na : 0u) + nprof + (uint32_t)nl > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
+        const uint32_t nFinal = PERREAD ? (uint32_t)na : 0u;
+        const uint32_t m = (active && !fb) ? nFinal + nprof + (uint32_t)nl : 0u;
         uint32_t incl = m;
         for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
             const uint32_t o = __shfl_up(incl, off);
@@ -2024,8 +2036,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             A.rowPos[r] = start; A.rowLen[r] = m | (m ? ROW_MERGE : 0u);
             if (start + m <= A.stCap) {
                 uint32_t w = start;
-                if (na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
-                if (na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
+                if (PERREAD && na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
+                if (PERREAD && na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
                 for (int e = 0; e < na; ++e) {
                     const uint32_t t = (e == 0) ? mTax0 : mTax1;
                     for (int lv = 0; lv < nK; ++lv) {
@@ -2383,7 +2395,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.st = c->st.as<uint2>();
         A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
-        A.wantPerRead = 1;
+        A.wantPerRead = wantPerRead ? 1 : 0;
         A.addProfile = slowProfileDone ? 0 : 1;
         A.list = nullptr; A.nList = 0;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
@@ -2396,10 +2408,17 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
-            if (nK <= 6) score_fast_kernel<6><<<fblocks, 64, 0, c->stream>>>(A);
-            else if (nK <= 12) score_fast_kernel<12><<<fblocks, 64, 0, c->stream>>>(A);
-            else if (nK <= 19) score_fast_kernel<19><<<fblocks, 64, 0, c->stream>>>(A);
-            else score_fast_kernel<25><<<fblocks, 64, 0, c->stream>>>(A);
+            if (wantPerRead) {
+                if (nK <= 6) score_fast_kernel<6, true><<<fblocks, 64, 0, c->stream>>>(A);
+                else if (nK <= 12) score_fast_kernel<12, true><<<fblocks, 64, 0, c->stream>>>(A);
+                else if (nK <= 19) score_fast_kernel<19, true><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast_kernel<25, true><<<fblocks, 64, 0, c->stream>>>(A);
+            } else {
+                if (nK <= 6) score_fast_kernel<6, false><<<fblocks, 64, 0, c->stream>>>(A);
+                else if (nK <= 12) score_fast_kernel<12, false><<<fblocks, 64, 0, c->stream>>>(A);
+                else if (nK <= 19) score_fast_kernel<19, false><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast_kernel<25, false><<<fblocks, 64, 0, c->stream>>>(A);
+            }
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h, counters + 1, 12, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));

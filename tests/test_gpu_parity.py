@@ -547,3 +547,25 @@ def test_index_build_matches_reference_files(stem, K, tmp_path):
     formats.write_index(ix, out, str(tmp_path / "content_copy.txt"))
     for suffix in ("", "_trie", "_trie.txt", "_info.txt", "_f.txt"):
         assert _read(out + suffix) == _read(os.path.join(d, stem + suffix)), suffix
+
+
+@pytest.mark.parametrize("case", [(12, 7, 3, 12, 0), (12, 7, 6, 12, 0), (25, 7, 3, 25, 0), (12, 1, 3, 12, 0), (12, 7, 3, 12, 1)])
+def test_profile_only_equals_per_read_run(case):
+    """Without -q (kasa_batch_lookup_score(wantPerRead = 0)) the fast kernel skips ordering and float sums; the profile
+    tables must be the same integers as those of the full run, and equal the oracle's."""
+    _gpu_or_fail()
+    kh, kl, frames, K, flags = case
+    ix, batch = synthetic_world(91, 8, 7000, 2000, K=K)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, kh, kl, frames)
+    ctx.debug_flags(flags)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    full = ctx.profile_limbs().copy()
+    ctx.profile_reset()
+    ctx.upload(batch.bases, batch.offsets); ctx.encode(); ctx.sort_and_range(); ctx.lookup_score(False)
+    assert np.array_equal(full, ctx.profile_limbs())
+    res, _ = oracle.identify_batch(ix, batch.bases, batch.offsets, oracle.params(kh, kl, frames, K=K), False)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    ctx.close(); dix.close()
