@@ -6,7 +6,7 @@
 // (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
-// Not supported here (reported as errors, never silently ignored): --filter/--coherence/--visualize,
+// Not supported here (reported as errors, never silently ignored): --coherence/--visualize,
 // custom alphabets/codon tables.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
 #include <chrono>
@@ -18,6 +18,7 @@
 #include <exception>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -342,6 +343,7 @@ struct Params {
     string content, index, input, input2, rtt, profile;   // input2: second file of paired-end input (-1 / -2)
     int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
     bool kSetByUser = false;
+    bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
@@ -381,8 +383,10 @@ struct Writer {
         }
     }
 
+    bool lastContaminated = false;   // --filter: the read just written comes within --errorThreshold of the perfect score
     void read(string &o, uint64_t number, const string &name, uint32_t len, const uint32_t *tax, const float *score, uint64_t n)
     {
+        lastContaminated = false;
         using numtext::dtoa; using numtext::itoa;
         const float best = bestScore(len, p);
         int64_t cnt = 0;
@@ -410,6 +414,7 @@ struct Writer {
         for (int64_t i = 0; i < cnt; ++i) maxV = std::max(maxV, std::get<1>(res[i]));
         int64_t top = 1;
         for (int64_t i = 1; i < cnt && i < p.beasts; ++i) { if (std::get<1>(res[i]) / maxV > 0.8f) ++top; else break; }
+        lastContaminated = (best - double(maxV)) / best < p.errorThreshold;          // Compare.hpp:1597-1599
         float before = 0;
         switch (p.fmt) {
         case Params::Tsv: {
@@ -512,6 +517,61 @@ static void writeProfile(const string &path, const Params &p, const Content &c, 
     f << "\n" << body.str();
 }
 
+// Compare::filter (Compare.hpp:2448-2596): the input is read again and every record goes to <clean>.fast[aq] or
+// <contaminants>.fast[aq] ("_1"/"_2" before the extension for paired input; "_" = that side is not written).
+static string slurp(const string &path)
+{
+    gzFile g = gzopen(path.c_str(), "rb");
+    if (!g) throw std::runtime_error("Input file not found");
+    string data; vector<char> buf(1 << 22); int n;
+    while ((n = gzread(g, buf.data(), (unsigned)buf.size())) > 0) data.append(buf.data(), (size_t)n);
+    gzclose(g);
+    return data;
+}
+
+static void filterReads(const Params &p, const vector<uint64_t> &flagged)
+{
+    const bool paired = !p.input2.empty();
+    vector<string> data{slurp(p.input)};
+    if (paired) data.push_back(slurp(p.input2));
+    const bool fasta = !data[0].empty() && data[0][0] == '>';
+    const string ext = fasta ? ".fasta" : ".fastq";
+    auto openSide = [&](const string &prefix, const char *what) {
+        vector<std::unique_ptr<std::ofstream>> f;
+        if (prefix == "_") return f;
+        for (size_t i = 0; i < data.size(); ++i) {
+            f.emplace_back(new std::ofstream(prefix + (paired ? (i ? "_2" : "_1") : "") + ext, std::ios::binary));
+            if (f.back()->fail()) throw std::runtime_error(string(what) + " output files could not be opened for writing, did you use the correct path?");
+        }
+        return f;
+    };
+    auto clean = openSide(p.filterClean, "Filtered"), cont = openSide(p.filterCont, "Contaminants");
+    if (flagged.empty() && !clean.empty()) { for (size_t i = 0; i < data.size(); ++i) *clean[i] << data[i]; return; }
+    vector<vector<std::pair<size_t, size_t>>> lines(data.size());
+    for (size_t f = 0; f < data.size(); ++f)
+        for (size_t a = 0; a < data[f].size();) { size_t b = data[f].find('\n', a); if (b == string::npos) b = data[f].size(); lines[f].emplace_back(a, b); a = b + 1; }
+    auto line = [&](size_t f, size_t i) { return i < lines[f].size() ? data[f].substr(lines[f][i].first, lines[f][i].second - lines[f][i].first) : string(); };
+    uint64_t rid = 0; size_t fi = 0;
+    vector<std::unique_ptr<std::ofstream>> *target = &clean;
+    const size_t n = lines[0].size();
+    if (fasta) {
+        for (size_t i = 0; i < n; ++i) {
+            const string l1 = line(0, i);
+            if (l1.empty()) continue;
+            if (l1[0] == '>') { const bool hit = fi < flagged.size() && rid == flagged[fi]; target = hit ? &cont : &clean; if (hit) ++fi; ++rid; }
+            if (!target->empty()) { *(*target)[0] << l1 << "\n"; if (paired) *(*target)[1] << line(1, i) << "\n"; }
+        }
+    } else {
+        for (size_t i = 0; i < n; i += 4) {
+            if (line(0, i).empty()) continue;
+            const bool hit = fi < flagged.size() && rid == flagged[fi];
+            target = hit ? &cont : &clean; if (hit) ++fi; ++rid;
+            if (target->empty()) continue;
+            for (size_t f = 0; f < data.size(); ++f) for (size_t k = 0; k < 4; ++k) *(*target)[f] << line(f, i + k) << "\n";
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // main
 // ---------------------------------------------------------------------------------------------------
@@ -552,7 +612,9 @@ static int run(int argc, char **argv)
         else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
         else if (s == "-n" || s == "--threads") p.threads = (unsigned)std::max(1, std::stoi(next()));
         else if (s == "-m" || s == "--memory" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
-        else if (s == "--filter" || s == "--coherence" || s == "--visualize" || s == "-z" || s == "-a" || s == "--alphabet")
+        else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
+        else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
+        else if (s == "--coherence" || s == "--visualize" || s == "-z" || s == "-a" || s == "--alphabet")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }
@@ -633,6 +695,7 @@ static int run(int argc, char **argv)
     uint64_t totalKmers = 0, done = 0;
     const double tParse = secondsSince(tStart);
     double tDevice = 0.0, tText = 0.0;
+    vector<uint64_t> contaminants;              // --filter: read numbers, ascending
     while (done < nReads || (nReads == 0 && done == 0)) {
         uint64_t end = done, est = 0;
         while (end < nReads) {
@@ -652,9 +715,10 @@ static int run(int argc, char **argv)
         }
         if (kasa_batch_encode(ctx, &nk)) throwLast();
         if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
-        if (kasa_batch_lookup_score(ctx, !p.rtt.empty(), p.coverage)) throwLast();
+        const bool wantRows = !p.rtt.empty() || p.filter;
+        if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
         totalKmers += nk;
-        if (!p.rtt.empty()) {
+        if (wantRows) {
             uint64_t nnz = 0;
             if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
             vector<uint64_t> ro(end - done + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
@@ -666,6 +730,7 @@ static int run(int argc, char **argv)
             for (uint64_t s0 = done; s0 < end; s0 += slab * p.threads) {
                 const unsigned nt = (unsigned)std::min<uint64_t>(p.threads, (end - s0 + slab - 1) / slab);
                 vector<string> texts(nt);
+                vector<vector<uint64_t>> flagged(nt);
                 vector<std::exception_ptr> err(nt);
                 auto work = [&](unsigned t) {
                     try {
@@ -676,13 +741,15 @@ static int run(int argc, char **argv)
                         for (uint64_t r = a; r < b; ++r) {
                             const uint64_t lo = ro[r - done], hi = ro[r - done + 1];
                             w.read(text, r, rs.names[r], rs.lengths[r], tx.data() + lo, sc.data() + lo, hi - lo);
+                            if (p.filter && w.lastContaminated) flagged[t].push_back(r);
                         }
                     } catch (...) { err[t] = std::current_exception(); }
                 };
                 if (nt == 1) work(0);
                 else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
                 for (auto &e : err) if (e) std::rethrow_exception(e);
-                for (auto &t : texts) out.write(t.data(), (std::streamsize)t.size());
+                if (!p.rtt.empty()) for (auto &t : texts) out.write(t.data(), (std::streamsize)t.size());
+                for (auto &f : flagged) contaminants.insert(contaminants.end(), f.begin(), f.end());
             }
             tText += secondsSince(tTxt);
         } else tDevice += secondsSince(tDev);
@@ -690,6 +757,7 @@ static int run(int argc, char **argv)
         if (nReads == 0) break;
     }
     if (!p.rtt.empty()) { if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
+    if (p.filter) filterReads(p, contaminants);
     const int nK = p.kHigh - p.kLow + 1;
     vector<double> all((size_t)nK * content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
     if (kasa_profile_fetch(ctx, all.data(), uniq.data(), tot.data())) throwLast();

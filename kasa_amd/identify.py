@@ -28,6 +28,8 @@ class Identify:
         self.dix = dix if dix is not None else capi.DeviceIndex(index, device)
         self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames)
         self.unique = unique
+        self.contaminants = []          # read numbers --filter would move to the contaminants (report.is_contaminant)
+        self.error_threshold = 0.5
         self.n_kmers = 0
         self.n_reads = 0
 
@@ -46,6 +48,7 @@ class Identify:
         self.ctx.set_protein(protein)
         self.n_kmers = 0
         self.n_reads = 0
+        self.contaminants = []
         step = reads.n if not batch_reads else batch_reads
         a = 0
         while a < reads.n or (a == 0 and reads.n == 0):
@@ -61,6 +64,8 @@ class Identify:
                     rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(part.lengths[r]), freq, self.k_high,
                                           self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
                     out.append(writer.read(self.n_reads + r, part.names[r], int(part.lengths[r]), rk))
+                    if rk.hits and report.is_contaminant(rk.best, max(h.score for h in rk.hits), self.error_threshold):
+                        self.contaminants.append(self.n_reads + r)
             self.n_reads += part.n
             a = b
             if reads.n == 0:

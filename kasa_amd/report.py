@@ -293,3 +293,86 @@ def profile_csv(count_all, count_unique, names, taxids, k_high: int, k_low: int,
     if cov:
         first += ",0" * (2 * nK)
     return head + first + "\n" + body
+
+
+def is_contaminant(best: np.float32, max_score: np.float32, error_threshold: float = 0.5) -> bool:
+    """--filter (Compare.hpp:1597-1599, 2281): a read goes to the contaminants when its best-scoring taxon comes
+    within `--errorThreshold` of the perfect score: (best - double(score)) / best < threshold, in double."""
+    b = float(np.float32(best))
+    return (b - float(np.float32(max_score))) / b < float(np.float32(error_threshold))
+
+
+def filter_reads(in_paths, flagged, clean_prefix: str, cont_prefix: str) -> None:
+    """Compare::filter (Compare.hpp:2448-2596): re-read the input file(s) and write every record to `<clean>.fast[aq]`
+    or `<contaminants>.fast[aq]` (`_1`/`_2` before the extension for paired input; "_" = do not write that side).
+    `flagged`: ascending read numbers of the contaminated reads."""
+    import gzip
+    def op(path):
+        with open(path, "rb") as f:
+            magic = f.read(2)
+        return gzip.open(path, "rb") if magic == b"\x1f\x8b" else open(path, "rb")
+    paired = len(in_paths) == 2
+    data = []
+    for p in in_paths:
+        with op(p) as f:
+            data.append(f.read())
+    fasta = data[0][:1] == b">"
+    ext = ".fasta" if fasta else ".fastq"
+    def outs(prefix):
+        if prefix == "_":
+            return None
+        names = [prefix + "_1" + ext, prefix + "_2" + ext] if paired else [prefix + ext]
+        return [open(n, "wb") for n in names]
+    clean, cont = outs(clean_prefix), outs(cont_prefix)
+    try:
+        if not flagged and clean is not None:                     # nothing found: the input is copied as it is
+            for f, d in zip(clean, data):
+                f.write(d)
+            return
+        lines = []
+        for d in data:
+            ls = d.split(b"\n")
+            if ls and ls[-1] == b"":
+                ls.pop()                                           # getline does not return a line after the last '\n'
+            lines.append(ls)
+        flagged = list(flagged)
+        rid = fi = 0
+        target = clean
+        if fasta:
+            for i, l1 in enumerate(lines[0]):
+                if l1 == b"":
+                    continue
+                if l1[:1] == b">":
+                    hit = fi < len(flagged) and rid == flagged[fi]
+                    target = cont if hit else clean
+                    fi += 1 if hit else 0
+                    rid += 1
+                if target is not None:
+                    target[0].write(l1 + b"\n")
+                    if paired:
+                        target[1].write((lines[1][i] if i < len(lines[1]) else b"") + b"\n")
+        else:
+            n = len(lines[0])
+            i = 0
+            while i < n or i == 0:
+                rec = [lines[0][i + k] if i + k < n else b"" for k in range(4)]
+                rec2 = [lines[1][i + k] if i + k < len(lines[1]) else b"" for k in range(4)] if paired else None
+                i += 4
+                if rec[0] == b"":
+                    if i >= n:
+                        break
+                    continue
+                hit = fi < len(flagged) and rid == flagged[fi]
+                target = cont if hit else clean
+                fi += 1 if hit else 0
+                rid += 1
+                if target is not None:
+                    target[0].write(b"".join(x + b"\n" for x in rec))
+                    if paired:
+                        target[1].write(b"".join(x + b"\n" for x in rec2))
+                if i >= n:
+                    break
+    finally:
+        for side in (clean, cont):
+            for f in side or []:
+                f.close()

@@ -203,6 +203,12 @@ def case_pairs(out):
     for name, extra in runs.items():
         stem = name.rsplit(".", 1)[0]
         run(base + extra + ["-q", "out_" + name, "-p", "prof_" + stem + ".csv"], out)
+    # --filter: the input split into clean reads and contaminants (default --errorThreshold 0.5, and 0.7 on the FASTA)
+    run(base + ["-i", "reads.fastq", "--jsonl", "-b", "100", "--filter", "flt_clean", "flt_cont", "-q", "out_flt.jsonl", "-p", "prof_flt.csv"], out)
+    run(base + ["-i", "reads.fasta", "--jsonl", "-b", "100", "--filter", "flta_clean", "flta_cont", "--errorThreshold", "0.7",
+                "-q", "out_flta.jsonl", "-p", "prof_flta.csv"], out)
+    for junk in ("out_flt.jsonl", "prof_flt.csv", "out_flta.jsonl", "prof_flta.csv"):   # same as b100 / fasta
+        os.remove(os.path.join(out, junk))
     # the "halved" index of shrink strategy 2 (6-byte records) and a run on it
     run(["shrink", "-c", "content.txt", "-d", "idx", "-o", "idx_half", "-s", "2", "-m", "4", "-n", "1"], out)
     run(base + ["-d", "idx_half", "-i", "reads.fastq", "--jsonl", "-b", "100", "-q", "out_half.jsonl", "-p", "prof_half.csv"], out)

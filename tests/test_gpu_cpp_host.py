@@ -105,3 +105,22 @@ def test_cpp_host_parallel_parser_and_writer(infile, stem, tmp_path):
     assert r.returncode == 0, r.stderr
     assert _read(out) == _read(os.path.join(d, "out_" + stem))
     assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+
+
+@pytest.mark.parametrize("infile,extra,clean,cont", [("reads.fastq", [], "flt_clean.fastq", "flt_cont.fastq"),
+                                                      ("reads.fasta", ["--errorThreshold", "0.7"], "flta_clean.fasta", "flta_cont.fasta")])
+def test_cpp_host_filter(infile, extra, clean, cont, tmp_path):
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    ext = os.path.splitext(clean)[1]
+    for with_q in (True, False):                                   # --filter works without -q as well (Compare.hpp:2878)
+        c, x = str(tmp_path / ("c%d" % with_q)), str(tmp_path / ("x%d" % with_q))
+        cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile),
+               "-p", str(tmp_path / "prof.csv"), "--jsonl", "-b", "100", "--filter", c, x] + extra
+        if with_q:
+            cmd += ["-q", str(tmp_path / "out.jsonl")]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert _read(c + ext, True) == _read(os.path.join(d, clean), True)
+        assert _read(x + ext, True) == _read(os.path.join(d, cont), True)

@@ -125,3 +125,23 @@ def test_paired_end_byte_identical(case, closed_form):
                                 nq, "jsonl", 12, 7, frames, 0.0, 100)
     assert text == _read(os.path.join(d, "out_" + stem + ".jsonl"))
     assert prof == _read(os.path.join(d, "prof_" + stem + ".csv"))
+
+
+@pytest.mark.parametrize("infile,thr,clean,cont", [("reads.fastq", 0.5, "flt_clean.fastq", "flt_cont.fastq"),
+                                                    ("reads.fasta", 0.7, "flta_clean.fasta", "flta_cont.fasta")])
+def test_filter_outputs_byte_identical(infile, thr, clean, cont, tmp_path):
+    """--filter / --errorThreshold (Compare.hpp:1597-1599, 2448-2596) on the oracle's scores."""
+    from kasa_amd import report
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, infile))
+    res, _ = helpers.oracle_identify(ix, batch, 12, 7, 3)
+    rows = helpers.csr_from_dense(res.M)
+    flagged = []
+    for r in range(batch.n):
+        rk = report.rank_read(rows[r][0], rows[r][1], int(batch.lengths[r]), ix.freq_at(12), 12, 7, 3, 0.0, 100)
+        if rk.hits and report.is_contaminant(rk.best, max(h.score for h in rk.hits), thr):
+            flagged.append(r)
+    report.filter_reads([os.path.join(d, infile)], flagged, str(tmp_path / "c"), str(tmp_path / "x"))
+    ext = os.path.splitext(clean)[1]
+    assert _read(str(tmp_path / ("c" + ext)), True) == _read(os.path.join(d, clean), True)
+    assert _read(str(tmp_path / ("x" + ext)), True) == _read(os.path.join(d, cont), True)
