@@ -182,7 +182,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": lk_avg_s * 1e3},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                # the CPU baseline is reported at N = 1 only
             sample = reads.slice(0, min(args.cpu_sample, reads.n))
             v, secs = cpu_baseline(ix, sample, k_high, k_low)
             out["cpu_baseline"] = {"value": v, "unit": "reads/s", "cores": 1, "kind": "port",
