@@ -86,6 +86,9 @@ uint64_t kasa_index_device_bytes(const kasa_index *ix);
  */
 int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int frames, const uint8_t *codonLut,
                     kasa_ctx **out);
+/* The built-in table (kASA.hpp:621-667) in the codonLut layout: the starting point for -a/--alphabet, which
+ * overwrites the 64 codons of an NCBI gc.prt table in it (kASA::setCodonTable, kASA.hpp:579-615).  Host only. */
+int kasa_builtin_codon_table(uint8_t *lut366);
 void kasa_ctx_destroy(kasa_ctx *ctx);
 
 /* The next batches hold amino-acid sequences instead of DNA (what kASA::detectAlphabet decides per

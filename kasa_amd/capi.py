@@ -19,7 +19,7 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
-    "kasa_index_device_bytes", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_segments", "kasa_batch_encode",
+    "kasa_index_device_bytes", "kasa_builtin_codon_table", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_segments", "kasa_batch_encode",
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
@@ -46,6 +46,36 @@ def lib():
         L.kasa_ctx_destroy.restype = None
         _lib = L
     return _lib
+
+
+def builtin_codon_table() -> np.ndarray:
+    lut = np.zeros(366, dtype=np.uint8)
+    _check(lib().kasa_builtin_codon_table(lut.ctypes.data_as(C.c_void_p)))
+    return lut
+
+
+def codon_table_from_gcprt(path: str, table_id: str) -> np.ndarray:
+    """-a/--alphabet <gc.prt> <id> (kASA::setCodonTable, kASA.hpp:579-615): the 64 codons of NCBI table `id` written
+    over the built-in table ('*' becomes '['); codons with X or Z keep their built-in letters.  Unknown id: a warning
+    and the built-in table, as in the reference."""
+    import sys
+    lut = builtin_codon_table()
+    with open(path) as f:
+        lines = f.read().split("\n")
+    for i, line in enumerate(lines):
+        if ("  id " + str(table_id) + " ,") in line:
+            aa, b1, b2, b3 = lines[i + 1], lines[i + 3], lines[i + 4], lines[i + 5]
+            pa = aa.index('"') + 1
+            pb = min(x for x in (b1.find(c) for c in "TGCA") if x >= 0)
+            while pb < len(b1):
+                idx = ((ord(b1[pb]) & 14) << 5) | ((ord(b2[pb]) & 14) << 2) | ((ord(b3[pb]) & 14) >> 1)
+                ch = aa[pa]
+                lut[idx] = ord("[" if ch == "*" else ch) & 31
+                pb += 1
+                pa += 1
+            return lut
+    sys.stderr.write("WARNING: codon table not found in file. Using built-in.\n")
+    return lut
 
 
 def _check(rc: int):

@@ -534,6 +534,13 @@ static void builtin_codon_table(uint8_t lut[366])
             }
 }
 
+extern "C" int kasa_builtin_codon_table(uint8_t *lut366)
+{
+    if (!lut366) return fail(KASA_E_ARG, "kasa_builtin_codon_table: NULL argument");
+    builtin_codon_table(lut366);
+    return KASA_OK;
+}
+
 extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int frames, const uint8_t *codonLut, kasa_ctx **out)
 {
     if (!out) return fail(KASA_E_ARG, "kasa_ctx_create: out is NULL");

@@ -6,8 +6,7 @@
 // (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
-// Not supported here (reported as errors, never silently ignored): --coherence/--visualize,
-// custom alphabets/codon tables.  128-bit indices (build --kH 25) are read as they are (20-byte records).
+// Not supported here (reported as errors, never silently ignored): --coherence/--visualize.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -343,6 +342,7 @@ struct Params {
     string content, index, input, input2, rtt, profile;   // input2: second file of paired-end input (-1 / -2)
     int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
     bool kSetByUser = false;
+    string codonFile, codonId;                   // -a/--alphabet <gc.prt> <id>
     bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
     float threshold = 0.f;
@@ -517,6 +517,25 @@ static void writeProfile(const string &path, const Params &p, const Content &c, 
     f << "\n" << body.str();
 }
 
+// kASA::setCodonTable (kASA.hpp:579-615): the 64 codons of table `id` of an NCBI gc.prt file written over the built-in table
+static vector<uint8_t> codonTableFromFile(const string &path, const string &id)
+{
+    vector<uint8_t> lut(366);
+    if (kasa_builtin_codon_table(lut.data())) throwLast();
+    std::ifstream f(path);
+    string line; bool found = false;
+    while (std::getline(f, line)) if (line.find("  id " + id + " ,") != string::npos) { found = true; break; }
+    if (!found) { std::cerr << "WARNING: codon table not found in file. Using built-in." << std::endl; return lut; }
+    string aa, dummy, b1, b2, b3;
+    std::getline(f, aa); std::getline(f, dummy); std::getline(f, b1); std::getline(f, b2); std::getline(f, b3);
+    size_t pa = aa.find_first_of('"') + 1, pb = b1.find_first_of("TGCA");
+    for (; pb < b1.size() && pb < b2.size() && pb < b3.size() && pa < aa.size(); ++pb, ++pa) {
+        const int idx = ((b1[pb] & 14) << 5) | ((b2[pb] & 14) << 2) | ((b3[pb] & 14) >> 1);
+        if (idx < 366) lut[(size_t)idx] = (uint8_t)(((aa[pa] == '*') ? '[' : aa[pa]) & 31);
+    }
+    return lut;
+}
+
 // Compare::filter (Compare.hpp:2448-2596): the input is read again and every record goes to <clean>.fast[aq] or
 // <contaminants>.fast[aq] ("_1"/"_2" before the extension for paired input; "_" = that side is not written).
 static string slurp(const string &path)
@@ -614,7 +633,8 @@ static int run(int argc, char **argv)
         else if (s == "-m" || s == "--memory" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
-        else if (s == "--coherence" || s == "--visualize" || s == "-z" || s == "-a" || s == "--alphabet")
+        else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }
+        else if (s == "--coherence" || s == "--visualize" || s == "-z")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }
@@ -652,7 +672,9 @@ static int run(int argc, char **argv)
     if (kasa_index_create(p.device, rec, nRec, recBytes, tp.data(), tc.data(), tp.size(), content.taxids.data(), (uint32_t)content.taxids.size(), &ix)) throwLast();
     munmap(rec, nRec * recBytes); close(fd);
     kasa_ctx *ctx = nullptr;
-    if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, nullptr, &ctx)) throwLast();
+    vector<uint8_t> lut;
+    if (!p.codonFile.empty()) lut = codonTableFromFile(p.codonFile, p.codonId);
+    if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, lut.empty() ? nullptr : lut.data(), &ctx)) throwLast();
 
     if (p.threads == 0) p.threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     const auto tStart = std::chrono::steady_clock::now();

@@ -21,12 +21,12 @@ from .reads import ReadBatch
 class Identify:
     def __init__(self, index: Index, device: int = 0, k_high: int = 12, k_low: int = 7, frames: int = 3,
                  threshold: float = 0.0, beasts: int = 3, fmt: str = "json", dix: capi.DeviceIndex = None,
-                 unique: bool = False):
+                 unique: bool = False, codon_lut=None):
         self.index = index
         self.k_high, self.k_low = max(k_high, k_low), min(k_high, k_low)
         self.frames, self.threshold, self.beasts, self.fmt = frames, threshold, beasts, fmt
         self.dix = dix if dix is not None else capi.DeviceIndex(index, device)
-        self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames)
+        self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames, codon_lut)
         self.unique = unique
         self.contaminants = []          # read numbers --filter would move to the contaminants (report.is_contaminant)
         self.error_threshold = 0.5

@@ -14,7 +14,7 @@ import numpy as np
 from . import capi, formats, reads
 
 
-def build_index(fasta_path: str, content_path: str, device: int = 0, K: int = formats.K64) -> formats.Index:
+def build_index(fasta_path: str, content_path: str, device: int = 0, K: int = formats.K64, codon_lut=None) -> formats.Index:
     content = formats.read_content(content_path)
     acc_to_tax = {}
     with open(content_path) as f:                                 # column 4: accessions of the taxon, ';'-separated
@@ -37,7 +37,7 @@ def build_index(fasta_path: str, content_path: str, device: int = 0, K: int = fo
         one["lo"] = 1
     boot = formats.make_index(one, content.taxids[1:2].copy(), content)
     dix = capi.DeviceIndex(boot, device, check_trie=False)
-    ctx = capi.Context(dix, K, 1, 3)                              # kLow = 1: every tail window, '^'-padded
+    ctx = capi.Context(dix, K, 1, 3, codon_lut)                   # kLow = 1: every tail window, '^'-padded
     ctx.upload(db.bases, db.offsets)
     ctx.encode()
     ctx.sort_and_range()

@@ -11,6 +11,7 @@
  */
 #include "kasa_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,6 +41,34 @@ void ko_codon_table(uint8_t lut[366])
                 }
                 lut[b0 * 64 + b1 * 8 + b2] = (uint8_t)(aa & 31);
             }
+}
+
+int ko_codon_table_from_file(const char *path, const char *id, uint8_t lut[366])
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    char needle[128], line[6][512];
+    snprintf(needle, sizeof(needle), "  id %s ,", id);
+    int found = 0;
+    while (fgets(line[0], sizeof(line[0]), f))
+        if (strstr(line[0], needle)) { found = 1; break; }
+    if (found) {
+        for (int i = 1; i <= 5; ++i)
+            if (!fgets(line[i], sizeof(line[i]), f)) { fclose(f); return 0; }
+        /* line 1: amino acids after the first '"'; line 2: start codons (ignored); lines 3-5: Base1..Base3 */
+        const char *aa = strchr(line[1], '"');
+        const char *b1 = line[3] + strcspn(line[3], "TGCA");
+        if (!aa || !*b1) { fclose(f); return 0; }
+        ++aa;
+        const size_t o = (size_t)(b1 - line[3]);
+        for (size_t i = 0; line[3][o + i] && line[3][o + i] != '\n' && line[3][o + i] != '\r'; ++i) {
+            const int idx = ((line[3][o + i] & 14) << 5) | ((line[4][o + i] & 14) << 2) | ((line[5][o + i] & 14) >> 1);
+            const char c = aa[i];
+            if (idx < 366) lut[idx] = (uint8_t)(((c == '*') ? '[' : c) & 31);
+        }
+    }
+    fclose(f);
+    return found;
 }
 
 float ko_weight(int k) /* Compare.hpp:392: k*k / 625.f, both operands float */

@@ -58,6 +58,10 @@ typedef struct {
 /* kASA.hpp:621-667 -- the built-in codon table as a 366-entry LUT of 5-bit letter codes. */
 void ko_codon_table(uint8_t lut[366]);
 
+/* kASA::setCodonTable (kASA.hpp:579-615): the 64 codons of table `id` of an NCBI gc.prt file written over `lut`
+ * ('*' -> '[').  Returns 1 when the table was found, 0 otherwise (lut untouched), -1 when the file cannot be read. */
+int ko_codon_table_from_file(const char *path, const char *id, uint8_t lut[366]);
+
 /* Read.hpp:633-654,612-630,36-57 -- padded length (incl. marker) and k-mer count of one raw read. */
 int64_t ko_padded_len(int64_t rawLen, const ko_params *p);
 int64_t ko_kmer_count(int64_t paddedLen, const ko_params *p);

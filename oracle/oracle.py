@@ -83,6 +83,14 @@ def codon_table() -> np.ndarray:
     return lut
 
 
+def codon_table_from_file(path: str, table_id: str) -> np.ndarray:
+    """-a <gc.prt> <id> over the built-in table (kASA.hpp:579-615)."""
+    lut = codon_table()
+    rc = lib().ko_codon_table_from_file(path.encode(), str(table_id).encode(), _p(lut))
+    assert rc >= 0
+    return lut
+
+
 def encode(bases: np.ndarray, offsets: np.ndarray, p: Params, lut=None):
     """-> (kmer u64[nQ], read u32[nQ]) in emission order (Read.hpp:84-293)."""
     L = lib(p.K)
@@ -160,11 +168,11 @@ def unique_queries(km: np.ndarray, rd: np.ndarray):
 
 
 def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=False, unique=False, seg_read=None,
-                   n_reads=None):
+                   n_reads=None, lut=None):
     """Whole reference batch: encode -> sort [-> unique] -> ranges -> merge.  Returns (CompareResult, nQueries);
     nQueries counts the k-mers before -e, as iNumberOfkMersInInput does (Compare.hpp:3124)."""
     iv = IndexView(ix)
-    km, rd = encode(bases, offsets, p)
+    km, rd = encode(bases, offsets, p, lut)
     n_in = int(km.shape[0])
     if seg_read is not None:   # paired-end: both mates of a pair are entries of one read (Read.hpp:834-1049)
         rd = np.ascontiguousarray(np.asarray(seg_read, dtype=np.uint32)[rd])

@@ -59,7 +59,7 @@ def write_db(d, genomes):
 def trim_index(d):
     """The reference zero-pads index and trie files to 2,101,248-byte blocks; keep the records only."""
     jobs = []
-    for stem, rec in (("idx", 12), ("idx_half", 6), ("idx25", 20)):
+    for stem, rec in (("idx", 12), ("idx_half", 6), ("idx25", 20), ("idxa", 12)):
         if not os.path.exists(os.path.join(d, stem + "_info.txt")):
             continue
         n = int(open(os.path.join(d, stem + "_info.txt")).read().split()[0])
@@ -219,11 +219,53 @@ def case_pairs(out):
     for name, extra in wide.items():
         run(["identify", "-c", "content.txt", "-d", "idx25", "-m", "4", "-n", "1", "--jsonl", "-b", "100", "-i", "reads.fastq"]
             + extra + ["-q", "out_" + name + ".jsonl", "-p", "prof_" + name + ".csv"], out)
+    # a custom translation table (-a <gc.prt> <id>): index built and queried with the vertebrate mitochondrial code
+    with open(os.path.join(out, "gc.prt"), "w") as f:
+        f.write(GC_PRT)
+    run(["build", "-c", "content.txt", "-d", "idxa", "-i", "db.fasta", "-m", "4", "-n", "1", "-a", "gc.prt", "2"], out)
+    run(["identify", "-c", "content.txt", "-d", "idxa", "-m", "4", "-n", "1", "--jsonl", "-b", "100", "-i", "reads.fastq",
+         "-a", "gc.prt", "2", "-q", "out_alpha.jsonl", "-p", "prof_alpha.csv"], out)
     # the reference's own example input (2 reads; N- and '-'-containing, multi-line FASTA)
     shutil.copy(os.path.join(REF, "example/work/input/exampleInput.fasta"), os.path.join(out, "exampleInput.fasta"))
     run(base + ["-i", "exampleInput.fasta", "--jsonl", "-b", "100", "-q", "out_exampleInput.jsonl",
                 "-p", "prof_exampleInput.csv"], out)
     # (example.fastq.gz is left out: the shipped binary spins forever on that gzipped input here)
+
+
+GC_PRT = """--  Genetic code tables in the layout of NCBI's gc.prt (written for the tests; three of the standard tables)
+Genetic-code-table ::= {
+ {
+  name "Standard" ,
+  name "SGC0" ,
+  id 1 ,
+  ncbieaa  "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+  sncbieaa "---M------**--*----M---------------M----------------------------"
+  -- Base1  TTTTTTTTTTTTTTTTCCCCCCCCCCCCCCCCAAAAAAAAAAAAAAAAGGGGGGGGGGGGGGGG
+  -- Base2  TTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGG
+  -- Base3  TCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAG
+ },
+ {
+  name "Vertebrate Mitochondrial" ,
+  name "SGC1" ,
+  id 2 ,
+  ncbieaa  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG",
+  sncbieaa "----------**--------------------MMMM----------**---M------------"
+  -- Base1  TTTTTTTTTTTTTTTTCCCCCCCCCCCCCCCCAAAAAAAAAAAAAAAAGGGGGGGGGGGGGGGG
+  -- Base2  TTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGG
+  -- Base3  TCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAG
+ },
+ {
+  name "Mold Mitochondrial; Protozoan Mitochondrial" ,
+  name "SGC3" ,
+  id 4 ,
+  ncbieaa  "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG",
+  sncbieaa "--MM------**-------M------------MMMM---------------M------------"
+  -- Base1  TTTTTTTTTTTTTTTTCCCCCCCCCCCCCCCCAAAAAAAAAAAAAAAAGGGGGGGGGGGGGGGG
+  -- Base2  TTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGGTTTTCCCCAAAAGGGG
+  -- Base3  TCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAGTCAG
+ }
+}
+"""
 
 
 def case_clones(out):

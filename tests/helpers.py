@@ -44,9 +44,9 @@ def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low
 
 
 def oracle_identify(ix, batch, k_high=12, k_low=7, frames=3, avx_quirk=False, closed_form=False, unique=False,
-                    protein=False, cmp64_quirk=False, coverage=False):
+                    protein=False, cmp64_quirk=False, coverage=False, lut=None):
     p = oracle.params(k_high, k_low, frames, avx_quirk, coverage=coverage, K=ix.K, protein=protein,
                       cmp64_quirk=cmp64_quirk)
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, closed_form, unique,
-                                    seg_read=batch.seg_read, n_reads=batch.n)
+                                    seg_read=batch.seg_read, n_reads=batch.n, lut=lut)
     return res, nq

@@ -124,3 +124,16 @@ def test_cpp_host_filter(infile, extra, clean, cont, tmp_path):
         assert r.returncode == 0, r.stderr
         assert _read(c + ext, True) == _read(os.path.join(d, clean), True)
         assert _read(x + ext, True) == _read(os.path.join(d, cont), True)
+
+
+def test_cpp_host_custom_codon_table(tmp_path):
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "o"), str(tmp_path / "p")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idxa"), "-i", os.path.join(d, "reads.fastq"),
+           "-a", os.path.join(d, "gc.prt"), "2", "-q", out, "-p", prof, "--jsonl", "-b", "100"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == _read(os.path.join(d, "out_alpha.jsonl"))
+    assert _read(prof) == _read(os.path.join(d, "prof_alpha.csv"))

@@ -569,3 +569,23 @@ def test_profile_only_equals_per_read_run(case):
     assert np.array_equal(cu, res.count_unique)
     np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
     ctx.close(); dix.close()
+
+
+def test_custom_codon_table_build_and_identify(tmp_path):
+    """-a gc.prt 2: the index built on the device with the custom table is the reference's file, identify reproduces the
+    reference's output, and the host-side parser gives the same table as the oracle's."""
+    _gpu_or_fail()
+    from kasa_amd import index_build
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    lut = capi.codon_table_from_gcprt(os.path.join(d, "gc.prt"), "2")
+    assert np.array_equal(lut, oracle.codon_table_from_file(os.path.join(d, "gc.prt"), "2"))
+    assert np.array_equal(capi.builtin_codon_table(), oracle.codon_table())
+    ix = index_build.build_index(os.path.join(d, "db.fasta"), os.path.join(d, "content.txt"), codon_lut=lut)
+    formats.write_index(ix, str(tmp_path / "n"), str(tmp_path / "c.txt"))
+    assert _read(str(tmp_path / "n")) == _read(os.path.join(d, "idxa"))
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    idf = Identify(ix, 0, 12, 7, 3, 0.0, 100, "jsonl", codon_lut=lut)
+    text, prof, _ = idf.run(batch)
+    assert text == _read(os.path.join(d, "out_alpha.jsonl"))
+    assert prof == _read(os.path.join(d, "prof_alpha.csv"))
+    idf.close()

@@ -145,3 +145,18 @@ def test_filter_outputs_byte_identical(infile, thr, clean, cont, tmp_path):
     ext = os.path.splitext(clean)[1]
     assert _read(str(tmp_path / ("c" + ext)), True) == _read(os.path.join(d, clean), True)
     assert _read(str(tmp_path / ("x" + ext)), True) == _read(os.path.join(d, cont), True)
+
+
+@pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
+def test_custom_codon_table(closed_form):
+    """-a gc.prt 2 (kASA::setCodonTable, kASA.hpp:579-615) for `build` and `identify`."""
+    from oracle import oracle
+    d, ix = helpers.load_case("pairs", "idxa")
+    lut = oracle.codon_table_from_file(os.path.join(d, "gc.prt"), "2")
+    assert (lut != oracle.codon_table()).sum() == 4          # TGA -> W (was ']'), ATA -> M, AGA and AGG -> stop '['
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    res, nq = helpers.oracle_identify(ix, batch, 12, 7, 3, closed_form=closed_form, lut=lut)
+    text, prof = helpers.render(ix, batch, helpers.csr_from_dense(res.M), res.count_all, res.count_unique,
+                                nq, "jsonl", 12, 7, 3, 0.0, 100)
+    assert text == _read(os.path.join(d, "out_alpha.jsonl"))
+    assert prof == _read(os.path.join(d, "prof_alpha.csv"))
