@@ -38,9 +38,7 @@
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-static constexpr int KLETTERS = 12;               // letters per packed k-mer (64-bit index)
-static constexpr int KEYBITS = 5 * KLETTERS;      // 60
-static constexpr int KEYSHIFT = 64 - KEYBITS;     // 4
+// letters per packed k-mer, key bits and the index meta entry depend on the key width: KeyTraits<Key> below
 static constexpr int RANGE_LETTERS = 6;           // depth of the reference's prefix trie (Trie.hpp)
 static constexpr int MAX_LEVELS = 25;
 static constexpr int TILE = 1024;                 // sorted queries per workgroup in lookup/group
@@ -1803,13 +1801,12 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // 64 reads run side by side in a wavefront; the small per-read state (pending groups, a handful of
 // taxa with their score and per-level profile counters) lives in LDS, strided by lane.  A read that
 // does not fit (more than FPL groups pending, more than FTA taxa, a taxon set larger than 4, more
-// than FNK levels) is handed to score_kernel untouched: nothing of it has reached global memory.
+// than 25 levels) is handed to score_kernel untouched: nothing of it has reached global memory.
 // ------------------------------------------------------------------------------------------------
 static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
 static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
-static constexpr int FNK = 6;       // levels of the default instantiation; more levels: score_fast_kernel<12|19|25>
 static constexpr int FLOG = 960;    // contributions to all other taxa, logged per read and resolved by row_merge_kernel
-static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * FNK * 4 + FLOG)
+static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * 6 * 4 + FLOG; the fast kernel hands longer rows to score_kernel)
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
 static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG + 4 * FPL); // u32 words per block
 
