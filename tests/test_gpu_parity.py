@@ -589,3 +589,38 @@ def test_custom_codon_table_build_and_identify(tmp_path):
     assert text == _read(os.path.join(d, "out_alpha.jsonl"))
     assert prof == _read(os.path.join(d, "prof_alpha.csv"))
     idf.close()
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_configurations(seed):
+    """Differential test over the option space: key width, k range, frames, -e, paired-end, read lengths (incl. reads
+    shorter than a k-mer and reads longer than an encoder chunk), number of taxa, forced fallback paths."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(9000 + seed)
+    K = 25 if seed % 4 == 3 else 12
+    k_high = int(rng.integers(1, K + 1))
+    k_low = int(rng.integers(1, k_high + 1))
+    if seed % 3 == 0:
+        k_high, k_low = min(K, 12), 7
+    frames = int(rng.choice([1, 3, 6]))
+    unique = bool(rng.integers(0, 2))
+    flags = int(rng.choice([0, 0, 1, 2, 4]))
+    n_taxa = int(rng.integers(2, 24))
+    ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
+    pool = base.bases
+    n_reads = int(rng.integers(1, 300))
+    parts, off, seg = [], [0], []
+    paired = bool(rng.integers(0, 3) == 0)
+    for r in range(n_reads):
+        for _ in range(2 if paired else 1):
+            L = int(rng.choice([0, 1, 20, 35, 36, 37, 40, 76, 77, 100, 150, 151, 300, 700, 1700]))
+            a = int(rng.integers(0, max(1, pool.shape[0] - L)))
+            s = pool[a:a + L].copy()
+            if L and rng.integers(0, 5) == 0:
+                s[int(rng.integers(0, L))] = ord("N")
+            parts.append(s)
+            off.append(off[-1] + s.shape[0])
+            seg.append(r)
+    batch = reads.ReadBatch(np.concatenate(parts) if parts else np.zeros(0, np.uint8), np.asarray(off, dtype=np.int64), None,
+                            np.ones(n_reads, dtype=np.uint32), False, np.asarray(seg, dtype=np.uint32) if paired else None)
+    _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
