@@ -172,6 +172,10 @@ int kasa_batch_set_queries(kasa_ctx *ctx, const void *kmers, const uint32_t *rea
 /* Per sorted query: deepest matched level k (0 = none) and an index position sharing that prefix. */
 int kasa_batch_fetch_lookup(kasa_ctx *ctx, uint8_t *depth, uint32_t *indexPos, uint64_t n);
 int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);
+/* Of the last batch: reads scored by the general kernel (score_kernel) instead of the lane-per-read one, and how many of
+ * those needed its second pass (full pending window / direct profile adds).  Diagnostics for tests and bench.py. */
+int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPassReads);
+
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row
  * merge instead of the bitmap one; lastSlowReads (may be

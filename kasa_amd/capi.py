@@ -24,7 +24,7 @@ EXPORTS = [
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
-    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
+    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
 ]
 
 
@@ -261,6 +261,12 @@ class Context:
         ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
         return ms.value, int(n.value), int(q.value)
+
+    def counters(self):
+        """(reads of the last batch on the general score kernel, those of them that needed its second pass)."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().kasa_ctx_counters(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def query_count(self) -> int:
         n = C.c_uint64(0)

@@ -2384,6 +2384,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
     const bool fast = nK <= 25 && !c->forceSlowScore;
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
+    c->lastOverflowReads = 0;
     uint32_t staged = 0;
     ScoreArgs A;
     for (int attempt = 0;; ++attempt) {
@@ -2454,7 +2455,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
                 score_kernel<PCAP><<<std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u)), 64, 0, c->stream>>>(A);
                 HIPCHK(hipGetLastError());
             }
-            c->lastOverflowReads = nOver;
+            c->lastOverflowReads = std::max(c->lastOverflowReads, nOver);   // over the staging retries of this batch
             slowProfileDone = true;
         }
         c->lastSlowReads = nSlow;
@@ -2806,8 +2807,17 @@ extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlo
     if (getenv("KASA_DEBUG_WHY")) {
         uint32_t w[8];
         if (hipMemcpy(w, c->misc.as<uint32_t>() + 8, 32, hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[kasa] fallback reasons: cnt=%u taxa=%u log=%u big=%u pending=%u\n", w[0], w[1], w[2], w[3], w[4]);
+            fprintf(stderr, "[kasa] fallback reasons: cnt=%u taxa=%u log=%u big=%u pending=%u; general kernel: %u reads, %u of them handed to the second pass\n",
+                    w[0], w[1], w[2], w[3], w[4], c->lastSlowReads, c->lastOverflowReads);
     }
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_counters(kasa_ctx *c, uint32_t *generalReads, uint32_t *secondPassReads)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (generalReads) *generalReads = c->lastSlowReads;
+    if (secondPassReads) *secondPassReads = c->lastOverflowReads;
     return KASA_OK;
 }
 

@@ -624,3 +624,40 @@ def test_random_configurations(seed):
     batch = reads.ReadBatch(np.concatenate(parts) if parts else np.zeros(0, np.uint8), np.asarray(off, dtype=np.int64), None,
                             np.ones(n_reads, dtype=np.uint32), False, np.asarray(seg, dtype=np.uint32) if paired else None)
     _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
+
+
+def test_general_kernel_second_pass_is_reached():
+    """Reads with hundreds of distinct (level, |T|, taxon) keys overflow the per-read aggregation table of the general
+    score kernel's first pass; they are handed to its second pass, which must give the same result."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(19)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_taxa, L = 1200, 400
+    root = alphabet[rng.integers(0, 4, size=L)]
+    genomes = []
+    for g in range(n_taxa):                                     # every taxon a light mutation of one root: huge taxon sets
+        s = root.copy()
+        m = rng.random(L) < 0.02
+        s[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+        genomes.append(s)
+    content = formats.Content(["non_unique"] + [f"T{g}" for g in range(n_taxa)],
+                              np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for g, s in enumerate(genomes):
+        km, _ = oracle.encode(s, np.array([0, L], dtype=np.int64), p)
+        kms.append(km); tids.append(np.full(km.shape[0], 100 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, 60, 150, 5)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.debug_flags(1)                                           # everything on the general kernel
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    general, second = ctx.counters()
+    assert general == batch.n and second > 0, (general, second)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.close(); dix.close()
