@@ -172,6 +172,11 @@ int kasa_batch_set_queries(kasa_ctx *ctx, const void *kmers, const uint32_t *rea
 /* Per sorted query: deepest matched level k (0 = none) and an index position sharing that prefix. */
 int kasa_batch_fetch_lookup(kasa_ctx *ctx, uint8_t *depth, uint32_t *indexPos, uint64_t n);
 int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);
+/* Sizing a batch (the reference sizes its batches by -m, Compare.hpp:2803-2876): free / total HBM of a device, and the
+ * device bytes one query k-mer costs while its batch is in flight (all stages resident). */
+int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
+uint64_t kasa_batch_bytes_per_query(const kasa_ctx *ctx);
+
 /* Of the last batch: reads scored by the general kernel (score_kernel) instead of the lane-per-read one, and how many of
  * those needed its second pass (full pending window / direct profile adds).  Diagnostics for tests and bench.py. */
 int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPassReads);

@@ -24,7 +24,7 @@ EXPORTS = [
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
-    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
+    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
 ]
 
 
@@ -37,6 +37,8 @@ def lib():
         L = C.CDLL(SO_PATH)
         L.kasa_last_error.restype = C.c_char_p
         L.kasa_index_size.restype = C.c_uint64
+        L.kasa_batch_bytes_per_query.restype = C.c_uint64
+        L.kasa_batch_bytes_per_query.argtypes = [C.c_void_p]
         L.kasa_index_device_bytes.restype = C.c_uint64
         L.kasa_index_size.argtypes = [C.c_void_p]
         L.kasa_index_device_bytes.argtypes = [C.c_void_p]
@@ -113,6 +115,7 @@ class DeviceIndex:
                                        C.c_uint64(0 if tp is None else tp.shape[0]), _p(ids),
                                        C.c_uint32(ids.shape[0]), C.byref(h)))
         self.h = h
+        self.device = device
         self.n_taxa = int(ids.shape[0])
         self.n = ix.n
 
@@ -261,6 +264,13 @@ class Context:
         ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
         return ms.value, int(n.value), int(q.value)
+
+    def max_queries_per_batch(self, device: int = 0, fraction: float = 0.8) -> int:
+        """How many query k-mers fit one batch in the HBM that is free right now (at most 2^32 - 16)."""
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().kasa_device_memory(C.c_int(device), C.byref(free), C.byref(total)))
+        per = int(lib().kasa_batch_bytes_per_query(self.h))
+        return int(min(0xFFFFFFF0 - 1, max(1 << 20, fraction * free.value / per)))
 
     def counters(self):
         """(reads of the last batch on the general score kernel, those of them that needed its second pass)."""

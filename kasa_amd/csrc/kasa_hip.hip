@@ -2813,6 +2813,27 @@ extern "C" int kasa_ctx_debug(kasa_ctx *c, int forceSlowScore, uint32_t *lastSlo
     return KASA_OK;
 }
 
+extern "C" int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes)
+{
+    int ndev = 0;
+    kasa_device_count(&ndev);
+    if (device < 0 || device >= ndev) return fail(KASA_E_HIP, "kasa_device_memory: no HIP device %d (found %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (freeBytes) *freeBytes = f;
+    if (totalBytes) *totalBytes = t;
+    return KASA_OK;
+}
+
+// Device bytes one query (k-mer of a read) costs while its batch is in flight: both sort buffers, depth + index
+// position, the nK event records, the positions by read, and a share for pool, staging rows and the CSR.
+extern "C" uint64_t kasa_batch_bytes_per_query(const kasa_ctx *c)
+{
+    if (!c) return 0;
+    return 2 * (c->keyBytes() + 4) + 5 + 8ull * (uint64_t)c->nK + 4 + 40;
+}
+
 extern "C" int kasa_ctx_counters(kasa_ctx *c, uint32_t *generalReads, uint32_t *secondPassReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");

@@ -713,7 +713,13 @@ static int run(int argc, char **argv)
 
     // batches: the device takes up to 2^32 k-mers at once; the reference cuts batches by its -m budget instead
     // (INTEGRATION.md section 4 on what that means for the last float digit)
-    const uint64_t maxKmersPerBatch = 3000000000ull;
+    uint64_t maxKmersPerBatch = 3000000000ull;
+    {   // ... and by the HBM that is free next to the index (the per-query footprint grows with the number of levels)
+        uint64_t freeB = 0, totalB = 0;
+        if (kasa_device_memory(p.device, &freeB, &totalB)) throwLast();
+        const uint64_t per = kasa_batch_bytes_per_query(ctx);
+        if (per) maxKmersPerBatch = std::max<uint64_t>(1u << 20, std::min<uint64_t>(maxKmersPerBatch, (uint64_t)(0.8 * (double)freeB) / per));
+    }
     uint64_t totalKmers = 0, done = 0;
     const double tParse = secondsSince(tStart);
     double tDevice = 0.0, tText = 0.0;

@@ -50,6 +50,11 @@ class Identify:
         self.n_reads = 0
         self.contaminants = []
         step = reads.n if not batch_reads else batch_reads
+        if not batch_reads and reads.n:
+            # the whole input is one batch unless it does not fit the free HBM (the reference cuts batches by its -m budget)
+            per_read = (int(reads.offsets[-1] - reads.offsets[0]) // reads.n + 64) * (2 if self.frames == 6 else 1)
+            fit = self.ctx.max_queries_per_batch(self.ctx.dix.device if hasattr(self.ctx.dix, "device") else 0) // max(1, per_read)
+            step = max(1, min(reads.n, fit))
         a = 0
         while a < reads.n or (a == 0 and reads.n == 0):
             b = min(reads.n, a + max(step, 1))
