@@ -719,6 +719,7 @@ static int run(int argc, char **argv)
         if (kasa_device_memory(p.device, &freeB, &totalB)) throwLast();
         const uint64_t per = kasa_batch_bytes_per_query(ctx);
         if (per) maxKmersPerBatch = std::max<uint64_t>(1u << 20, std::min<uint64_t>(maxKmersPerBatch, (uint64_t)(0.8 * (double)freeB) / per));
+        if (const char *e = getenv("KASA_MAX_BATCH_KMERS")) maxKmersPerBatch = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: force several batches
     }
     uint64_t totalKmers = 0, done = 0;
     const double tParse = secondsSince(tStart);

@@ -137,3 +137,22 @@ def test_cpp_host_custom_codon_table(tmp_path):
     assert r.returncode == 0, r.stderr
     assert _read(out) == _read(os.path.join(d, "out_alpha.jsonl"))
     assert _read(prof) == _read(os.path.join(d, "prof_alpha.csv"))
+
+
+def test_cpp_host_several_batches(tmp_path):
+    """The input cut into many device batches: the profile is the same file (it is additive over batches), the per-read
+    file names the same taxa in the same order (scores may move in the last float digit with the batch, as they do in
+    the reference when -m changes)."""
+    import re
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "o"), str(tmp_path / "p")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
+           "-q", out, "-p", prof, "--jsonl", "-b", "100"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, KASA_MAX_BATCH_KMERS="1500"))
+    assert r.returncode == 0, r.stderr
+    assert _read(prof) == _read(os.path.join(d, "prof_b100.csv"))
+    strip = lambda t: re.sub(r'"(k-mer Score|Relative Score|Error)": [-0-9.e+infa]+', r'"\1": x', t)
+    assert strip(_read(out)) == strip(_read(os.path.join(d, "out_b100.jsonl")))
