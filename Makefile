@@ -1,0 +1,27 @@
+# Convenience targets; `python -m kasa_amd.build` and `__graft_entry__.build()` do the same compiles.
+HIPCC ?= /opt/rocm/bin/hipcc
+LIB    = kasa_amd/libkasa_hip.so
+HOST   = kasa_amd/host/kasa_identify
+
+all: $(LIB) $(HOST) oracle
+
+$(LIB): kasa_amd/csrc/kasa_hip.hip include/kasa_hip.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-result -o $@ $<
+
+$(HOST): kasa_amd/host/kasa_identify.cpp kasa_amd/host/grisu_powers.inc include/kasa_hip.h $(LIB)
+	g++ -O2 -std=c++17 -pthread -o $@ $< -Lkasa_amd -lkasa_hip -lz -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -C oracle
+
+test:
+	python -m pytest tests -q -m "not gpu"
+
+test-gpu:
+	python -m pytest tests -q -m gpu
+
+clean:
+	rm -f $(LIB) $(HOST)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle test test-gpu clean
