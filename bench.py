@@ -71,6 +71,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (one-GPU boxes): KASA_BENCH_SHARE_GPU=1 runs every rank on device 0 and carries the reduce over gloo,
+    # because RCCL refuses two ranks on one device; it exercises the multi-rank code path, it is not a measurement
+    share = os.environ.get("KASA_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -81,7 +86,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -110,7 +118,7 @@ def main():
         ctx.sort_and_range()
         ctx.lookup_score(want, False)
         if dist is not None:
-            kdist.allreduce_limbs(ctx.profile_limbs(), device="cuda")   # one RCCL sum of integer limbs (exact)
+            kdist.allreduce_limbs(ctx.profile_limbs(), device=None if share else "cuda")   # one RCCL sum of integer limbs (exact)
 
     def fence():
         ctx.synchronize()
@@ -131,7 +139,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
