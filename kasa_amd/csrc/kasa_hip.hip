@@ -1823,10 +1823,25 @@ static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_CONSUME
 static constexpr int RK_LV_SHIFT = 23;
 static constexpr uint32_t RK_LV_MASK = 31u;
 __device__ __forceinline__ uint32_t rk_level(uint32_t x) { return (x >> RK_LV_SHIFT) & RK_LV_MASK; }
-// profile key {level:5 | |T|:13 | taxon:20 | hits:16} of a record
-__device__ __forceinline__ uint64_t profile_key(uint2 e)
+// Profile key of a record: {level | |T| | taxon | hits:16}.  The three upper fields are as wide as the batch needs
+// (taxon: enough bits that the all-ones value is no taxon -- it marks unused slots; |T| <= 8191 and < nTaxa), so the
+// radix sort of the keys runs over as few bits as possible: 27 instead of 38 for 1400 taxa and 6 levels.
+struct ProfLayout {
+    uint32_t tb, nb, lb;
+    __host__ __device__ uint32_t bits() const { return tb + nb + lb; }
+};
+static inline ProfLayout prof_layout(uint32_t nTaxa, int nK)
 {
-    return ((uint64_t)((rk_level(e.x) << 13) | (e.y >> 16)) << 36) | ((uint64_t)(e.x & 0xFFFFFu) << 16) | (e.y & 0xFFFFu);
+    ProfLayout L;
+    L.tb = 1; while ((1u << L.tb) <= nTaxa) ++L.tb;              // 2^tb > nTaxa: the all-ones taxon is free
+    L.nb = L.tb < 13 ? L.tb : 13;
+    L.lb = 1; while ((1u << L.lb) < (uint32_t)nK) ++L.lb;
+    return L;
+}
+__device__ __forceinline__ uint64_t profile_key(uint2 e, ProfLayout L)
+{
+    const uint64_t f = ((uint64_t)rk_level(e.x) << (L.tb + L.nb)) | ((uint64_t)(e.y >> 16) << L.tb) | (e.x & 0xFFFFFu);
+    return (f << 16) | (e.y & 0xFFFFu);
 }
 
 __device__ __forceinline__ float event_score(int k, uint32_t n)
@@ -2073,7 +2088,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
                                                        uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
-                                                       int kHigh)
+                                                       int kHigh, ProfLayout PL)
 {
     __shared__ uint32_t sKey[RMAX];
     __shared__ uint16_t sIdx[RMAX];
@@ -2094,7 +2109,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                 const uint32_t kind = e.x >> 30;
                 if (kind != 2u) key = ((e.x & 0xFFFFFu) << 11) | (kind == 1u ? 0u : (i & 0x7FFu));   // final score first in its run
                 if (kind != 1u)
-                    profKeys[s0 + i] = profile_key(e);
+                    profKeys[s0 + i] = profile_key(e, PL);
             }
             sKey[i] = key;
             sIdx[i] = (uint16_t)i;
@@ -2159,7 +2174,7 @@ static constexpr int BM_WORDS = 512;
 template <int RCAP, int BMW>
 __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
                                                               uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
-                                                              int kHigh, uint32_t nTaxa, uint32_t mLo)
+                                                              int kHigh, uint32_t nTaxa, uint32_t mLo, ProfLayout PL)
 {
     __shared__ uint32_t bm[BMW], pre[BMW];
     __shared__ float val[RCAP];                                        // running score of a slot (= taxon of the row)
@@ -2183,7 +2198,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             const uint32_t kind = e.x >> 30;
             const uint32_t t = e.x & 0xFFFFFu;
             if (kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
-            if (kind != 1u) profKeys[s0 + i] = profile_key(e);
+            if (kind != 1u) profKeys[s0 + i] = profile_key(e, PL);
         }
         LDS_WAVE_SYNC();
         uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
@@ -2239,22 +2254,24 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
     }
 }
 
-static constexpr uint64_t PROF_KEY_MASK = 0x3FFFFFFFFFull;           // 38 bits: level 5 | |T| 13 | taxon 20
-struct ProfKeyOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & PROF_KEY_MASK; } };
+struct ProfKeyOf {
+    uint64_t mask;
+    __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & mask; }
+};
 struct ProfHitsOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return v & 0xFFFFull; } };
 
-// profile sort-reduce: keys sorted on bits [16, 54); one add per distinct (level, |T|, taxon)
+// profile sort-reduce: keys sorted on bits [16, 16 + PL.bits()); one add per distinct (level, |T|, taxon)
 __global__ void profile_apply_kernel(const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ sums, const uint32_t *__restrict__ nRuns,
                                      uint32_t nTaxa, uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
-                                     uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab)
+                                     uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *nRuns) return;
     const uint64_t key = uniq[i];
-    if (key == PROF_KEY_MASK) return;                                   // sentinel slots
-    const uint32_t tax = (uint32_t)(key & 0xFFFFFu);
-    const uint32_t n = (uint32_t)((key >> 20) & 0x1FFFu);
-    const uint32_t lv = (uint32_t)(key >> 33);
+    const uint32_t tax = (uint32_t)(key & ((1ull << PL.tb) - 1ull));
+    if (tax == (1u << PL.tb) - 1u) return;                              // unused slots (the key buffer starts as all ones)
+    const uint32_t n = (uint32_t)((key >> PL.tb) & ((1ull << PL.nb) - 1ull));
+    const uint32_t lv = (uint32_t)(key >> (PL.tb + PL.nb));
     const uint64_t c = sums[i];
     const size_t cell = (size_t)lv * nTaxa + tax;
     if (n == 1) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
@@ -2468,6 +2485,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
     }
     // ---- resolve the fast kernel's records: per-read merge, then the profile contributions by sort + reduce
     if (fast && staged > 0) {
+        const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(c->profKeys.p, 0xFF, (size_t)staged * 8, c->stream));
@@ -2475,23 +2493,23 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
                 row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                    c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u);
+                    c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
                 mLo = 512;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo);
+                c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo, PL);
         } else
             row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), nReads,
-                c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh);
+                c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, PL);
         HIPCHK(hipGetLastError());
         size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 54u, c->stream));
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 54u, c->stream));
+        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
         const uint64_t perTaxon = std::min<uint64_t>(8191, nTaxa);
         const uint64_t cap = std::min<uint64_t>((uint64_t)staged, (uint64_t)nK * nTaxa * perTaxon) + 2;
         if ((rc = c->profUniq.reserve(cap * 8)) || (rc = c->profSums.reserve(cap * 8))) return rc;
-        auto keysIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfKeyOf());
+        auto keysIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfKeyOf{(1ull << PL.bits()) - 1ull});
         auto valsIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfHitsOf());
         uint32_t *nRuns = counters + 16;
         tmpBytes = 0;
@@ -2501,7 +2519,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(rocprim::reduce_by_key(c->sortTmp.p, tmpBytes, keysIn, valsIn, (unsigned int)staged, c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(),
                                       nRuns, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), c->stream));
         profile_apply_kernel<<<blocks_for(cap, 256), 256, 0, c->stream>>>(c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(), nRuns, nTaxa,
-            c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+            c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
     }
