@@ -460,7 +460,7 @@ struct kasa_ctx {
     DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
     DevBuf ovList;                             // reads the first general pass hands to the second
     uint32_t lastOverflowReads = 0;
-    DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profUniq, profSums;           // per-block dense score rows; reads left to the slow kernel
+    DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
     DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
@@ -582,7 +582,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -2254,28 +2254,62 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
     }
 }
 
-struct ProfKeyOf {
-    uint64_t mask;
-    __host__ __device__ uint64_t operator()(uint64_t v) const { return (v >> 16) & mask; }
-};
-struct ProfHitsOf { __host__ __device__ uint64_t operator()(uint64_t v) const { return v & 0xFFFFull; } };
-
-// profile sort-reduce: keys sorted on bits [16, 16 + PL.bits()); one add per distinct (level, |T|, taxon)
-__global__ void profile_apply_kernel(const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ sums, const uint32_t *__restrict__ nRuns,
-                                     uint32_t nTaxa, uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
-                                     uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL)
+// The sorted profile keys reduced in one streaming pass.  A distinct (level, |T|, taxon) has tens of thousands of
+// consecutive keys, so almost every workgroup sees a single key: it sums the hits and one thread adds them to the
+// tables.  A workgroup that holds a boundary lets every thread add the runs of its own eight keys.
+static constexpr int PR_THREADS = 256, PR_ITEMS = 8;
+__global__ __launch_bounds__(PR_THREADS) void profile_reduce_kernel(const uint64_t *__restrict__ sorted, uint32_t nKeys, uint32_t nTaxa,
+                                                                     uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
+                                                                     uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *nRuns) return;
-    const uint64_t key = uniq[i];
-    const uint32_t tax = (uint32_t)(key & ((1ull << PL.tb) - 1ull));
-    if (tax == (1u << PL.tb) - 1u) return;                              // unused slots (the key buffer starts as all ones)
-    const uint32_t n = (uint32_t)((key >> PL.tb) & ((1ull << PL.nb) - 1ull));
-    const uint32_t lv = (uint32_t)(key >> (PL.tb + PL.nb));
-    const uint64_t c = sums[i];
-    const size_t cell = (size_t)lv * nTaxa + tax;
-    if (n == 1) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
-    fixed_add(hiTab, midTab, loTab, cell, c, n);
+    __shared__ unsigned long long sSum[PR_THREADS / 64];
+    __shared__ uint64_t sEdge[2];
+    const uint64_t mask = (1ull << PL.bits()) - 1ull;
+    auto add = [&](uint64_t key, uint64_t c) {
+        const uint32_t tax = (uint32_t)(key & ((1ull << PL.tb) - 1ull));
+        if (c == 0 || tax == (1u << PL.tb) - 1u) return;               // unused slots (the key buffer starts as all ones)
+        const uint32_t n = (uint32_t)((key >> PL.tb) & ((1ull << PL.nb) - 1ull));
+        const uint32_t lv = (uint32_t)(key >> (PL.tb + PL.nb));
+        const size_t cell = (size_t)lv * nTaxa + tax;
+        if (n == 1) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
+        fixed_add(hiTab, midTab, loTab, cell, c, n);
+    };
+    const uint32_t chunk = PR_THREADS * PR_ITEMS;
+    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < nKeys; base += (uint64_t)gridDim.x * chunk) {
+        const uint64_t i0 = base + threadIdx.x * PR_ITEMS;
+        uint64_t v[PR_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PR_ITEMS; ++j) v[j] = (i0 + j < nKeys) ? sorted[i0 + j] : ~0ull;
+        if (threadIdx.x == 0) sEdge[0] = (v[0] >> 16) & mask;
+        const uint32_t lastIdx = (base + chunk <= nKeys) ? chunk - 1 : (uint32_t)(nKeys - 1 - base);
+        if (threadIdx.x == lastIdx / PR_ITEMS) sEdge[1] = (v[lastIdx % PR_ITEMS] >> 16) & mask;
+        __syncthreads();
+        const bool uniform = sEdge[0] == sEdge[1];                    // sorted: equal ends mean one key throughout
+        if (uniform) {
+            unsigned long long sum = 0;
+#pragma unroll
+            for (int j = 0; j < PR_ITEMS; ++j) if (i0 + j < nKeys) sum += v[j] & 0xFFFFull;
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+            if ((threadIdx.x & 63) == 0) sSum[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long total = 0;
+                for (int w = 0; w < PR_THREADS / 64; ++w) total += sSum[w];
+                add(sEdge[0], total);
+            }
+        } else {
+            uint64_t cur = (v[0] >> 16) & mask, acc = 0;
+#pragma unroll
+            for (int j = 0; j < PR_ITEMS; ++j) {
+                if (i0 + j >= nKeys) break;
+                const uint64_t k = (v[j] >> 16) & mask;
+                if (k != cur) { add(cur, acc); cur = k; acc = 0; }
+                acc += v[j] & 0xFFFFull;
+            }
+            add(cur, acc);
+        }
+        __syncthreads();
+    }
 }
 
 // final rows -> CSR in read order (rows are already {taxon, score}, taxon ascending)
@@ -2506,19 +2540,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
         HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
-        const uint64_t perTaxon = std::min<uint64_t>(8191, nTaxa);
-        const uint64_t cap = std::min<uint64_t>((uint64_t)staged, (uint64_t)nK * nTaxa * perTaxon) + 2;
-        if ((rc = c->profUniq.reserve(cap * 8)) || (rc = c->profSums.reserve(cap * 8))) return rc;
-        auto keysIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfKeyOf{(1ull << PL.bits()) - 1ull});
-        auto valsIn = rocprim::make_transform_iterator(c->profSorted.as<uint64_t>(), ProfHitsOf());
-        uint32_t *nRuns = counters + 16;
-        tmpBytes = 0;
-        HIPCHK(rocprim::reduce_by_key(nullptr, tmpBytes, keysIn, valsIn, (unsigned int)staged, c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(),
-                                      nRuns, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), c->stream));
-        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::reduce_by_key(c->sortTmp.p, tmpBytes, keysIn, valsIn, (unsigned int)staged, c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(),
-                                      nRuns, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), c->stream));
-        profile_apply_kernel<<<blocks_for(cap, 256), 256, 0, c->stream>>>(c->profUniq.as<uint64_t>(), c->profSums.as<uint64_t>(), nRuns, nTaxa,
+        profile_reduce_kernel<<<std::min<unsigned>(blocks_for(staged, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
+            c->profSorted.as<uint64_t>(), staged, nTaxa,
             c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
@@ -2809,7 +2832,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profUniq, &c->profSums, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
