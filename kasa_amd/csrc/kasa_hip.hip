@@ -17,7 +17,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_reduce_by_key.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
