@@ -2277,8 +2277,16 @@ __global__ __launch_bounds__(PR_THREADS) void profile_reduce_kernel(const uint64
     for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < nKeys; base += (uint64_t)gridDim.x * chunk) {
         const uint64_t i0 = base + threadIdx.x * PR_ITEMS;
         uint64_t v[PR_ITEMS];
+        if (i0 + PR_ITEMS <= nKeys) {                                  // 64 bytes per thread as four 16-byte loads
 #pragma unroll
-        for (int j = 0; j < PR_ITEMS; ++j) v[j] = (i0 + j < nKeys) ? sorted[i0 + j] : ~0ull;
+            for (int j = 0; j < PR_ITEMS; j += 2) {
+                const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(sorted + i0 + j);
+                v[j] = w.x; v[j + 1] = w.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PR_ITEMS; ++j) v[j] = (i0 + j < nKeys) ? sorted[i0 + j] : ~0ull;
+        }
         if (threadIdx.x == 0) sEdge[0] = (v[0] >> 16) & mask;
         const uint32_t lastIdx = (base + chunk <= nKeys) ? chunk - 1 : (uint32_t)(nKeys - 1 - base);
         if (threadIdx.x == lastIdx / PR_ITEMS) sEdge[1] = (v[lastIdx % PR_ITEMS] >> 16) & mask;
