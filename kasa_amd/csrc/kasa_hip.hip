@@ -1206,10 +1206,13 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
     return c->ix->wide ? sort_and_range_impl<key128>(c, unique) : sort_and_range_impl<uint64_t>(c, unique);
 }
 
+static constexpr int GITEMS = 2;                  // the group kernel gives a thread two queries of the tile
+static constexpr int GTHREADS = TILE / GITEMS;    // 512
+
 // ------------------------------------------------------------------------------------------------
 // group: per level, per sorted query -> (flush position F, taxon-set reference)
 // ------------------------------------------------------------------------------------------------
-// Block-wide scans over the 256 per-thread aggregates of a tile (each thread owns ITEMS consecutive
+// Block-wide scans over the 256 per-thread aggregates of a tile (each thread owns GITEMS consecutive
 // positions).  suffix_min: min over threads to the right; prefix_max: max over threads to the left.
 // suffix_min: min over threads to the right; prefix_max: max over threads to the left.  Each wavefront scans
 // with shuffles, the four wavefront totals are combined through LDS: two barriers per scan.
@@ -1225,7 +1228,7 @@ __device__ __forceinline__ uint32_t block_excl_suffix_min(uint32_t v, uint32_t *
     if (lane == 63) excl = NOPOS;
     if (lane == 0) sh[wv] = incl;
     __syncthreads();
-    for (int w = wv + 1; w < TILE_THREADS / 64; ++w) { const uint32_t o = sh[w]; if (o < excl) excl = o; }
+    for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = sh[w]; if (o < excl) excl = o; }
     __syncthreads();
     return excl;
 }
@@ -1308,30 +1311,30 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
     if (lane == 63) sh[wv] = incl;
     __syncthreads();
     uint32_t before = 0, all = 0;
-    for (int w = 0; w < TILE_THREADS / 64; ++w) { const uint32_t o = sh[w]; if (w < wv) before += o; all += o; }
+    for (int w = 0; w < GTHREADS / 64; ++w) { const uint32_t o = sh[w]; if (w < wv) before += o; all += o; }
     total = all;
     __syncthreads();
     return before + incl - v;
 }
 
-// One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
+// One level of the group computation for this thread's GITEMS consecutive queries: flush positions F and the
 // taxon-set references (leaders compute them, members copy them through LDS).
-// One level of the group computation for this thread's ITEMS consecutive queries: flush positions F and the
+// One level of the group computation for this thread's GITEMS consecutive queries: flush positions F and the
 // taxon-set references (leaders compute them, members copy them through LDS).
 // Positions grow with the thread index, so "next special position to the right" is the first special of the nearest
 // thread to the right that has one, and "my group's leader" is the last leader of the nearest thread to the left that
 // has one: inside a wavefront a ballot finds that thread, across wavefronts four LDS slots do.  `xs` = exchange slots
 // of this level (levels alternate between two sets, so one barrier per exchange is enough).
-struct GroupExchange { uint32_t firstSp[TILE_THREADS / 64]; int lastLeader[TILE_THREADS / 64]; uint32_t info[TILE]; };
+struct GroupExchange { uint32_t firstSp[GTHREADS / 64]; int lastLeader[GTHREADS / 64]; uint32_t info[TILE]; };
 
 template <class Meta>
 __device__ __forceinline__ void group_level(
-    int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[ITEMS], const uint8_t (&d)[ITEMS], const uint32_t (&rp)[ITEMS],
+    int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[GITEMS], const uint8_t (&d)[GITEMS], const uint32_t (&rp)[GITEMS],
     const uint32_t *__restrict__ tileNext, uint32_t nTiles, const Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa, GroupExchange &xs, uint32_t *shU, uint32_t *sBase,
-    const uint8_t (&mPrev)[ITEMS], const uint8_t (&mNext)[ITEMS], const uint32_t (&tx0)[ITEMS],
-    uint32_t (&F)[ITEMS], uint32_t (&R)[ITEMS])
+    const uint8_t (&mPrev)[GITEMS], const uint8_t (&mNext)[GITEMS], const uint32_t (&tx0)[GITEMS],
+    uint32_t (&F)[GITEMS], uint32_t (&R)[GITEMS])
 {
     const int k = kHigh - lv;
     const int g = group_letters(k);
@@ -1339,20 +1342,20 @@ __device__ __forceinline__ void group_level(
     const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
     const unsigned long long below = (1ull << lane) - 1ull;
     // ---- this thread's special positions and leaders
-    bool sp[ITEMS], leader[ITEMS];
+    bool sp[GITEMS], leader[GITEMS];
     uint32_t firstSp = NOPOS;
     int lastLeader = -1;
 #pragma unroll
-    for (int i = ITEMS - 1; i >= 0; --i) {
+    for (int i = GITEMS - 1; i >= 0; --i) {
         const uint32_t p = base + i;
         sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
         if (sp[i]) firstSp = p;
     }
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < GITEMS; ++i) {
         const bool matched = (base + i < nQ) && d[i] >= k;
         leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));   // first query of a level-k group, or the first matched query of the tile
-        if (leader[i]) lastLeader = t * ITEMS + i;
+        if (leader[i]) lastLeader = t * GITEMS + i;
     }
     // ---- nearest neighbours inside the wavefront
     const unsigned long long mSp = __ballot(firstSp != NOPOS);
@@ -1378,21 +1381,21 @@ __device__ __forceinline__ void group_level(
     }
     __syncthreads();
     if (carry == NOPOS)
-        for (int w = wv + 1; w < TILE_THREADS / 64; ++w) { const uint32_t o = xs.firstSp[w]; if (o != NOPOS) { carry = o; break; } }
+        for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = xs.firstSp[w]; if (o != NOPOS) { carry = o; break; } }
     if (lead < 0)
         for (int w = wv - 1; w >= 0; --w) { const int o = xs.lastLeader[w]; if (o >= 0) { lead = o; break; } }
     if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
 #pragma unroll
-    for (int i = ITEMS - 1; i >= 0; --i) {
+    for (int i = GITEMS - 1; i >= 0; --i) {
         F[i] = carry;
         if (sp[i]) carry = base + i;
     }
     // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
     // with ONE allocation per workgroup and level
-    uint32_t ga[ITEMS], gb[ITEMS], gn[ITEMS], gref[ITEMS];
+    uint32_t ga[GITEMS], gb[GITEMS], gn[GITEMS], gref[GITEMS];
     uint32_t need = 0;
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < GITEMS; ++i) {
         gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
         if (leader[i]) {
             gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
@@ -1407,19 +1410,19 @@ __device__ __forceinline__ void group_level(
         __syncthreads();
         off += *sBase;
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i)
+        for (int i = 0; i < GITEMS; ++i)
             if (leader[i] && gref[i] == 0u) {
                 gref[i] = group_emit(ga[i], gb[i], gn[i], g, meta, tax, pool, poolCap, off);
                 off += gn[i] + 1;
             }
     }
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i)
-        if (leader[i]) xs.info[t * ITEMS + i] = gref[i];
+    for (int i = 0; i < GITEMS; ++i)
+        if (leader[i]) xs.info[t * GITEMS + i] = gref[i];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-        if (leader[i]) lead = t * ITEMS + i;
+    for (int i = 0; i < GITEMS; ++i) {
+        if (leader[i]) lead = t * GITEMS + i;
         const bool matched = (base + i < nQ) && d[i] >= k;
         R[i] = (matched && lead >= 0) ? xs.info[lead] : 0u;
     }
@@ -1428,22 +1431,22 @@ __device__ __forceinline__ void group_level(
 // NKR > 0: all levels of a query are collected in registers and written as one contiguous record (nK <= NKR);
 // NKR == 0: any number of levels, one 8-byte store per level.
 template <int NKR, class Key>
-__global__ __launch_bounds__(TILE_THREADS) void group_kernel(
+__global__ __launch_bounds__(GTHREADS) void group_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
     const uint32_t *__restrict__ tileNext, uint32_t nTiles, const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
     uint32_t nIdx, int kHigh, int kLow, uint2 *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap,
     uint32_t *__restrict__ poolCursor, int coverage, uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
 {
-    __shared__ uint32_t shU[TILE_THREADS];
+    __shared__ uint32_t shU[GTHREADS];
     __shared__ GroupExchange xs[2];                               // levels alternate: no barrier needed before reuse
     __shared__ uint32_t sBase;
     const int nK = kHigh - kLow + 1;
     const int t = threadIdx.x;
-    const uint32_t base = blockIdx.x * TILE + t * ITEMS;         // blocked: this thread owns base..base+3
-    uint8_t ql[ITEMS], d[ITEMS];
-    uint32_t rp[ITEMS];
+    const uint32_t base = blockIdx.x * TILE + t * GITEMS;         // blocked: this thread owns base..base+3
+    uint8_t ql[GITEMS], d[GITEMS];
+    uint32_t rp[GITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < GITEMS; ++i) {
         const uint32_t p = base + i;
         if (p < nQ) {
             const Key q = qKmer[p];
@@ -1455,10 +1458,10 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
     // the index neighbourhood of every matched query, gathered once (it is the same at every level) and for all of the
     // thread's queries at once: twelve independent loads in flight instead of a dependent chain per level
     constexpr int LM = KeyTraits<Key>::META_MASK;
-    uint8_t mPrev[ITEMS], mNext[ITEMS];
-    uint32_t tx0[ITEMS];
+    uint8_t mPrev[GITEMS], mNext[GITEMS];
+    uint32_t tx0[GITEMS];
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < GITEMS; ++i) {
         mPrev[i] = 0; mNext[i] = 0; tx0[i] = 0;
         if (d[i] > 0) {
             const uint32_t j = rp[i];
@@ -1468,17 +1471,17 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
         }
     }
     if constexpr (NKR > 0) {
-        uint32_t allF[NKR][ITEMS], allR[NKR][ITEMS];
+        uint32_t allF[NKR][GITEMS], allR[NKR][GITEMS];
 #pragma unroll
         for (int lv = 0; lv < NKR; ++lv) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
+            for (int i = 0; i < GITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
             if (lv < nK)                                          // uniform: barriers inside are safe
                 group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
                             coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, allF[lv], allR[lv]);
         }
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
+        for (int i = 0; i < GITEMS; ++i) {
             const uint32_t p = base + i;
             if (p >= nQ) continue;
             uint2 *o = rec + (size_t)p * nK;
@@ -1495,11 +1498,11 @@ __global__ __launch_bounds__(TILE_THREADS) void group_kernel(
         }
     } else {
         for (int lv = 0; lv < nK; ++lv) {
-            uint32_t F[ITEMS], R[ITEMS];
+            uint32_t F[GITEMS], R[GITEMS];
             group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
                         coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, F, R);
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i)
+            for (int i = 0; i < GITEMS; ++i)
                 if (base + i < nQ) rec[(size_t)(base + i) * nK + lv] = make_uint2(F[i], R[i]);
         }
     }
@@ -2371,12 +2374,12 @@ static int group_stage(kasa_ctx *c, int coverage)
             const int cov = coverage && attempt == 0;
             if (c->ix->wide) {
                 auto kern = (nK <= 6) ? group_kernel<6, key128> : group_kernel<0, key128>;
-                kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+                kern<<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
                     c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
                     c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
             } else {
                 auto kern = (nK <= 6) ? group_kernel<6, uint64_t> : group_kernel<0, uint64_t>;
-                kern<<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
+                kern<<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
                     c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
                     c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
             }
