@@ -5,8 +5,8 @@ HOST   = kasa_amd/host/kasa_identify
 
 all: $(LIB) $(HOST) oracle
 
-$(LIB): kasa_amd/csrc/kasa_hip.hip include/kasa_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-result -o $@ $<
+$(LIB): kasa_amd/csrc/kasa_hip.hip kasa_amd/csrc/kasa_refbatch.cpp include/kasa_hip.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-result -o $@ kasa_amd/csrc/kasa_hip.hip kasa_amd/csrc/kasa_refbatch.cpp
 
 $(HOST): kasa_amd/host/kasa_identify.cpp kasa_amd/host/grisu_powers.inc include/kasa_hip.h $(LIB)
 	g++ -O2 -std=c++17 -pthread -o $@ $< -Lkasa_amd -lkasa_hip -lz -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib

@@ -177,6 +177,35 @@ int kasa_ctx_device_bytes(kasa_ctx *ctx, uint64_t *bytes);
 int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *totalBytes);
 uint64_t kasa_batch_bytes_per_query(const kasa_ctx *ctx);
 
+/* ---- where the reference cuts its batches (host arithmetic, no device work) ---------------------------------------
+ * Per-read scores are float sums whose order depends on the reads that share a batch, so byte-identical per-read files
+ * need the reference's batch boundaries: `kASA identify -m <GB>` turns -m into a byte budget
+ * (main.cpp:438-447,590-592,1054-1060; Compare.hpp:111-160,182-328,2803-2818,3129-3132) that every read consumes
+ * (Read.hpp:612-630,1147,1165-1195).  A host calls kasa_refbatch_budget once, kasa_refbatch_sequence_cost / _read_overhead per read and
+ * kasa_refbatch_cut per batch; the device takes whatever batch it is handed. */
+typedef struct {
+    int64_t memoryGiB;            /* -m (0: the default, 5) */
+    int threads;                  /* -n */
+    int ram;                      /* -r */
+    int kHigh, kLow;
+    int recordBytes;              /* of the index FILE: 12, 20 (128-bit) or 6 (halved) */
+    uint64_t nRecords;
+    const uint32_t *triePrefix;   /* the `_trie` file's prefixes, ascending */
+    uint64_t nTrie;
+    const uint32_t *taxIds;       /* as for kasa_index_create: entry 0 = 0 */
+    uint32_t nTaxa;
+    uint64_t nameBytes;           /* bytes of all names of the content file after removing ',' (entry 0 not counted) */
+    int identifyMultiple;         /* main.cpp:1118-1334 */
+} kasa_refbatch_params;
+int kasa_refbatch_budget(const kasa_refbatch_params *p, int64_t *budget);
+/* One sequence (a read, or one mate of a pair): K = 12 or 25 (index type), mode 0 = DNA in 3/6 frames, 1 = --one,
+ * 2 = amino acids; strands = 2 with --six.  The read as a whole, when per-read results are kept (-q / --filter):
+ * nameLen = length of the specifier the reference stores (header without its first character + one space; both mates'). */
+int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int64_t rawLen);
+int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa);
+/* Reads of the next batch given the costs of the reads still to come. */
+uint64_t kasa_refbatch_cut(int64_t budget, int firstBatch, const int64_t *cost, uint64_t nReads);
+
 /* Of the last batch: reads scored by the general kernel (score_kernel) instead of the lane-per-read one, and how many of
  * those needed its second pass (full pending window / direct profile adds).  Diagnostics for tests and bench.py. */
 int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPassReads);

@@ -7,6 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "kasa_hip.hip")
+HOST_SRCS = [os.path.join(HERE, "csrc", "kasa_refbatch.cpp")]   # host-only parts of the C ABI
 SO = os.path.join(HERE, "libkasa_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "kasa_hip.h")
 
@@ -19,11 +20,11 @@ def hipcc() -> str:
 
 
 def build(force: bool = False) -> str:
-    newest = max(os.path.getmtime(p) for p in (SRC, HEADER))
+    newest = max(os.path.getmtime(p) for p in [SRC, HEADER] + HOST_SRCS)
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-result", "-o", SO, SRC]
+           "-Wall", "-Wno-unused-result", "-o", SO, SRC] + HOST_SRCS
     subprocess.check_call(cmd)
     return SO
 

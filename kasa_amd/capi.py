@@ -25,6 +25,7 @@ EXPORTS = [
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
+    "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
 ]
 
 
@@ -46,6 +47,12 @@ def lib():
         L.kasa_index_destroy.restype = None
         L.kasa_ctx_destroy.argtypes = [C.c_void_p]
         L.kasa_ctx_destroy.restype = None
+        L.kasa_refbatch_sequence_cost.restype = C.c_int64
+        L.kasa_refbatch_sequence_cost.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
+        L.kasa_refbatch_read_overhead.restype = C.c_int64
+        L.kasa_refbatch_read_overhead.argtypes = [C.c_int64, C.c_uint32]
+        L.kasa_refbatch_cut.restype = C.c_uint64
+        L.kasa_refbatch_cut.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -87,6 +94,61 @@ def _check(rc: int):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class _RefBatchParams(C.Structure):
+    _fields_ = [("memoryGiB", C.c_int64), ("threads", C.c_int), ("ram", C.c_int), ("kHigh", C.c_int), ("kLow", C.c_int),
+                ("recordBytes", C.c_int), ("nRecords", C.c_uint64), ("triePrefix", C.c_void_p), ("nTrie", C.c_uint64),
+                ("taxIds", C.c_void_p), ("nTaxa", C.c_uint32), ("nameBytes", C.c_uint64), ("identifyMultiple", C.c_int)]
+
+
+class RefBatcher:
+    """Where `kASA identify -m <GiB>` cuts its batches (kasa_refbatch_* of the C ABI; host arithmetic only, works
+    without a GPU).  Per-read scores are float sums whose order depends on the reads sharing a batch, so byte-identical
+    per-read files need the reference's boundaries (Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195)."""
+
+    def __init__(self, ix, k_high: int, k_low: int, frames: int = 3, memory_gib: int = 5, threads: int = 1,
+                 ram: bool = False, record_bytes: int = None, identify_multiple: bool = False):
+        tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32)
+        tax = np.ascontiguousarray(ix.content.taxids, dtype=np.uint32)
+        name_bytes = sum(len(n.replace(",", "").encode("latin-1", "replace")) for n in ix.content.names[1:])
+        rb = record_bytes if record_bytes is not None else (20 if ix.K > 12 else 12)
+        prm = _RefBatchParams(int(memory_gib), int(threads), int(bool(ram)), max(k_high, k_low), min(k_high, k_low), rb, int(ix.n),
+                              tp.ctypes.data, len(tp), tax.ctypes.data, len(tax), name_bytes, int(bool(identify_multiple)))
+        b = C.c_int64(0)
+        _check(lib().kasa_refbatch_budget(C.byref(prm), C.byref(b)))
+        self.budget = b.value
+        self.K, self.k_low, self.frames, self.n_taxa = int(ix.K), min(k_high, k_low), frames, len(tax)
+
+    def costs(self, reads, want_per_read: bool = True) -> np.ndarray:
+        """Budget bytes per read of a ReadBatch (paired-end: both mates)."""
+        L = lib()
+        protein = bool(reads.protein)
+        mode = 2 if protein else (1 if self.frames == 1 else 0)
+        strands = 2 if (self.frames == 6 and not protein) else 1
+        seq_len = np.diff(reads.offsets).astype(np.int64)
+        per_seq = np.array([L.kasa_refbatch_sequence_cost(self.K, self.k_low, mode, strands, int(x)) for x in seq_len], dtype=np.int64)
+        if reads.seg_read is not None:
+            cost = np.zeros(reads.n, dtype=np.int64)
+            np.add.at(cost, reads.seg_read.astype(np.int64), per_seq)
+        else:
+            cost = per_seq
+        if want_per_read:
+            cost = cost + np.array([L.kasa_refbatch_read_overhead(len(n.encode("latin-1", "replace")), self.n_taxa) for n in reads.names], dtype=np.int64)
+        return np.ascontiguousarray(cost)
+
+    def boundaries(self, reads, want_per_read: bool = True) -> list:
+        """[0, b1, b2, ..., n]: read indices where the reference starts a new batch."""
+        cost = self.costs(reads, want_per_read)
+        out, done, first = [0], 0, 1
+        while done < len(cost):
+            n = int(lib().kasa_refbatch_cut(self.budget, first, cost[done:].ctypes.data, len(cost) - done))
+            if n == 0:
+                n = 1          # the reference would spin on a budget below 100 MiB; always make progress
+            done += n
+            out.append(done)
+            first = 0
+        return out
 
 
 def device_count() -> int:

@@ -345,6 +345,7 @@ struct Params {
     string codonFile, codonId;                   // -a/--alphabet <gc.prt> <id>
     bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
+    int memoryGiB = 0, refThreads = 1; bool ram = false;   // -m / -n / -r as the reference's batch budget sees them (kasa_refbatch_*)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
@@ -628,9 +629,10 @@ static int run(int argc, char **argv)
         else if (s == "--coverage") p.coverage = true;
         else if (s == "-v" || s == "--verbose") p.verbose = true;
         else if (s == "--device") p.device = std::stoi(next());
-        else if (s == "-r" || s == "--ram") {}                               // the index always lives in HBM
-        else if (s == "-n" || s == "--threads") p.threads = (unsigned)std::max(1, std::stoi(next()));
-        else if (s == "-m" || s == "--memory" || s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
+        else if (s == "-r" || s == "--ram") p.ram = true;                    // the index always lives in HBM; -r only enters the batch budget
+        else if (s == "-n" || s == "--threads") { p.threads = (unsigned)std::max(1, std::stoi(next())); p.refThreads = (int)p.threads; }
+        else if (s == "-m" || s == "--memory") { const string v = next(); p.memoryGiB = v == "inf" ? (1 << 30) : std::stoi(v); }   // main.cpp:438-447
+        else if (s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }
@@ -711,8 +713,28 @@ static int run(int argc, char **argv)
     }
     if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
 
-    // batches: the device takes up to 2^32 k-mers at once; the reference cuts batches by its -m budget instead
-    // (INTEGRATION.md section 4 on what that means for the last float digit)
+    // Batches.  With per-read output the batches are the reference's own: per-read scores are float sums whose order
+    // depends on the reads sharing a batch, so the input is cut exactly where `kASA identify -m` cuts it
+    // (kasa_refbatch_*: Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195).  A reference batch that does
+    // not fit the device (or a profile-only run, where boundaries do not matter) is cut by free HBM instead.
+    const bool wantRows = !p.rtt.empty() || p.filter;
+    int64_t refBudget = 0;
+    vector<int64_t> refCost;
+    if (wantRows && !getenv("KASA_MAX_BATCH_KMERS")) {
+        uint64_t nameBytes = 0;
+        for (size_t t = 1; t < content.names.size(); ++t) nameBytes += content.names[t].size();
+        kasa_refbatch_params bp{p.memoryGiB, p.refThreads, p.ram ? 1 : 0, p.kHigh, p.kLow, recBytes, nRec, tp.data(), tp.size(),
+                                content.taxids.data(), (uint32_t)content.taxids.size(), nameBytes, 0};
+        if (kasa_refbatch_budget(&bp, &refBudget)) throw std::runtime_error("batch budget could not be computed");
+        const int mode = p.protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !p.protein) ? 2 : 1;
+        refCost.resize(nReads);
+        for (uint64_t r = 0; r < nReads; ++r) {
+            int64_t c = kasa_refbatch_read_overhead((int64_t)rs.names[r].size(), (uint32_t)content.taxids.size());
+            for (size_t q = 0; q < seqPerRead; ++q)
+                c += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, rs.off[r * seqPerRead + q + 1] - rs.off[r * seqPerRead + q]);
+            refCost[r] = c;
+        }
+    }
     uint64_t maxKmersPerBatch = 3000000000ull;
     {   // ... and by the HBM that is free next to the index (the per-query footprint grows with the number of levels)
         uint64_t freeB = 0, totalB = 0;
@@ -726,13 +748,20 @@ static int run(int argc, char **argv)
     double tDevice = 0.0, tText = 0.0;
     vector<uint64_t> contaminants;              // --filter: read numbers, ascending
     while (done < nReads || (nReads == 0 && done == 0)) {
-        uint64_t end = done, est = 0;
-        while (end < nReads) {
+        uint64_t end = done, est = 0, refEnd = nReads;
+        if (!refCost.empty() && nReads) {
+            const uint64_t n = kasa_refbatch_cut(refBudget, done == 0 ? 1 : 0, refCost.data() + done, nReads - done);
+            refEnd = done + std::max<uint64_t>(1, n);
+        }
+        while (end < refEnd) {
             const uint64_t len = (uint64_t)(rs.off[(end + 1) * seqPerRead] - rs.off[end * seqPerRead]);
             const uint64_t k = (len + 64 * seqPerRead) * (p.frames == 6 ? 2 : 1);
             if (end > done && est + k > maxKmersPerBatch) break;
             est += k; ++end;
         }
+        if (!refCost.empty() && end < refEnd)
+            std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
+        if (p.verbose) std::cout << "OUT: Batch of " << (end - done) << " reads" << std::endl;
         uint64_t nk = 0;
         const auto tDev = std::chrono::steady_clock::now();
         if (segRead.empty()) {
@@ -744,7 +773,6 @@ static int run(int argc, char **argv)
         }
         if (kasa_batch_encode(ctx, &nk)) throwLast();
         if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
-        const bool wantRows = !p.rtt.empty() || p.filter;
         if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
         totalKmers += nk;
         if (wantRows) {

@@ -6,8 +6,10 @@
     after the file: profile CSV (Compare.hpp:3466-3665)
 
 Batch boundaries matter for the last float digit of per-read scores (the flush order depends on
-which reads share a batch): `batch_reads=None` processes the whole input as one
-batch, which is what the reference does whenever the input fits its -m budget.
+which reads share a batch).  `memory_gib` (the reference's -m) cuts the batches exactly
+where `kASA identify -m <GiB>` cuts them (capi.RefBatcher, kasa_refbatch_* of the C ABI), which makes the per-read file
+byte-identical to the reference's for any input size; without it (`batch_reads=None`) the whole input is one batch,
+which is what the reference does whenever the input fits its -m budget.
 """
 from __future__ import annotations
 
@@ -36,7 +38,8 @@ class Identify:
     def close(self):
         self.ctx.close()
 
-    def run(self, reads: ReadBatch, want_per_read: bool = True, batch_reads: int = None, coverage: bool = False):
+    def run(self, reads: ReadBatch, want_per_read: bool = True, batch_reads: int = None, coverage: bool = False,
+            memory_gib: int = None, threads: int = 1, ram: bool = False):
         """-> (per-read text or None, profile CSV text, list of CSR batches)."""
         ix = self.index
         writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts)
@@ -55,9 +58,16 @@ class Identify:
             per_read = (int(reads.offsets[-1] - reads.offsets[0]) // reads.n + 64) * (2 if self.frames == 6 else 1)
             fit = self.ctx.max_queries_per_batch(self.ctx.dix.device if hasattr(self.ctx.dix, "device") else 0) // max(1, per_read)
             step = max(1, min(reads.n, fit))
+        bounds = None
+        if memory_gib is not None and want_per_read and reads.n:
+            # the reference's own batch boundaries (-m): the per-read float sums depend on them
+            bounds = capi.RefBatcher(ix, self.k_high, self.k_low, self.frames, memory_gib, threads, ram,
+                                     record_bytes=getattr(ix, "record_bytes", None)).boundaries(reads, True)
+        self.batch_sizes = []
         a = 0
         while a < reads.n or (a == 0 and reads.n == 0):
-            b = min(reads.n, a + max(step, 1))
+            b = min(reads.n, a + max(step, 1)) if bounds is None else bounds[len(self.batch_sizes) + 1]
+            self.batch_sizes.append(b - a)
             part = reads.slice(a, b)
             self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique, part.seg_read, part.n)
             self.n_kmers += self.ctx.n_kmers

@@ -294,6 +294,110 @@ def case_clones(out):
     run(base + ["-p", "prof_only.csv"], out)
 
 
+def build_probe():
+    """tests/golden/batch_probe.c -> a preload library that counts the reads of every reference batch."""
+    so = os.path.join(tempfile.gettempdir(), "kasa_batch_probe.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "batch_probe.c"), "-ldl"])
+    return so
+
+
+def run_probed(args, cwd, n_taxa, probe):
+    """Run the reference and return the number of reads in each of its batches (see batch_probe.c)."""
+    tmp = os.path.join(cwd, "tmp")
+    os.makedirs(tmp, exist_ok=True)
+    log = os.path.join(tmp, "probe.txt")
+    env = dict(os.environ, LD_PRELOAD=probe, KASA_PROBE_BYTES=str(4 * n_taxa), KASA_PROBE_OUT=log)
+    p = subprocess.run(KASA + args + ["-t", tmp + "/"], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout)
+        raise SystemExit("reference failed: " + " ".join(args))
+    return [int(x) for x in open(log).read().split()]
+
+
+def check_no_crowded_prefix(d):
+    """Ground truth from the index the reference built: no scorable 7-letter prefix with more than 3 distinct taxa."""
+    n = int(open(os.path.join(d, "idx_info.txt")).read().split()[0])
+    pairs = set()
+    with open(os.path.join(d, "idx"), "rb") as f:
+        raw = f.read(n * 12)
+    for i in range(n):
+        kmer = int.from_bytes(raw[i * 12:i * 12 + 8], "little")
+        if any(((kmer >> (5 * (11 - j))) & 31) == 30 for j in range(7)):
+            continue                                           # '^' (genome tail): a query never matches past it
+        pairs.add((kmer >> 25, raw[i * 12 + 8:i * 12 + 12]))
+    per = {}
+    for pre, tax in pairs:
+        per[pre] = per.get(pre, 0) + 1
+    worst = max(per.values())
+    if worst > 3:
+        raise SystemExit("index has a 7-letter prefix shared by %d taxa" % worst)
+
+
+def gz(path):
+    with open(path, "rb") as f, gzip.GzipFile(path + ".gz", "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
+    os.remove(path)
+
+
+def case_batches(out):
+    """An input the reference cuts into several batches (row A11): the -m budget is consumed mostly by the reads x taxa
+    score matrix (Read.hpp:1192), so 100 000 placeholder taxa in the content file make a batch ~2 300 reads long and
+    6 000 reads span three batches.  12 taxa x 10 kb with 2 % read errors leave enough unmatched stretches that the flush
+    order of some reads really depends on their batch.  The per-read files differ between the budgets
+    in the last float digit of some reads, which is what the multi-batch tests need to see.  batches.json records the
+    batch sizes the binary really used (observed with batch_probe.c)."""
+    rng = random.Random(11)
+    G, L, DUMMY, NR = 12, 10000, 100000, 6000
+    genomes = []
+    for g in range(G):
+        genomes.append(mutate(genomes[g - 1], 0.03, rng) if g % 2 else "".join(rng.choice("ACGT") for _ in range(L)))
+    # The shipped binary is an AVX build: groups with more than 3 taxa take scoreMatchAVX, which drops increments
+    # (Compare.hpp:534-597, the `clones` case).  Sibling pairs give 1-2 taxa per k-mer; where two pairs collide by chance
+    # on a 7-letter prefix, one base is changed until no (k >= 7)-prefix of the index is shared by more than 3 taxa, so
+    # this case runs the binary's scalar branch throughout -- the branch the device implements.
+    for _ in range(50):
+        seen = {}
+        for g, s in enumerate(genomes):
+            for fr in range(3):
+                aa = translate(s[fr:])
+                for i in range(len(aa) - 6):
+                    seen.setdefault(aa[i:i + 7], {}).setdefault(g, fr + 3 * i)
+        crowded = [v for v in seen.values() if len(v) > 3]
+        if not crowded:
+            break
+        for v in crowded:
+            g = max(v)
+            pos = v[g] + 10                                    # inside the 7-letter window
+            s = genomes[g]
+            genomes[g] = s[:pos] + {"A": "C", "C": "G", "G": "T", "T": "A"}[s[pos]] + s[pos + 1:]
+    else:
+        raise SystemExit("could not thin out the crowded prefixes")
+    write_db(out, genomes)
+    with open(os.path.join(out, "content.txt"), "a") as c:
+        for d in range(DUMMY):
+            c.write("Placeholder %d\t%d\t%d\tDUM%06d.1\n" % (d, 1000 + d, 1000 + d, d))
+    rng = random.Random(12)
+    with open(os.path.join(out, "reads.fastq"), "w") as f:
+        for r in range(NR):
+            g = rng.randrange(G)
+            p = rng.randrange(L - 150)
+            s = mutate(genomes[g][p:p + 150], 0.02, rng)
+            f.write("@read%d_t%d\n%s\n+\n%s\n" % (r, g, s, "I" * 150))
+    run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
+    check_no_crowded_prefix(out)
+    probe = build_probe()
+    base = ["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", "reads.fastq", "--jsonl", "-b", "100"]
+    sizes = {}
+    for name, extra in (("m1", ["-m", "1"]), ("m2", ["-m", "2"]), ("m1_ram", ["-m", "1", "-r"]), ("m1_six", ["-m", "1", "--six"])):
+        sizes[name] = run_probed(base + extra + ["-q", "out_%s.jsonl" % name, "-p", "prof_%s.csv" % name], out, G + DUMMY + 1, probe)
+        assert sum(sizes[name]) == NR and len(sizes[name]) >= 3, sizes
+    with open(os.path.join(out, "batches.json"), "w") as f:
+        json.dump(sizes, f, indent=1)
+    for big in ["content.txt", "idx_f.txt", "reads.fastq", "db.fasta"] + ["out_%s.jsonl" % n for n in sizes]:
+        gz(os.path.join(out, big))
+
+
 def finish(out):
     trim_index(out)
     for junk in ("tmp", "stxxl.log", "stxxl.errlog"):
@@ -308,7 +412,7 @@ def main():
     if not os.path.exists(KASA[1]):
         raise SystemExit("needs /root/reference (development container only)")
     only = sys.argv[1:]
-    for name, fn in (("pairs", case_pairs), ("clones", case_clones)):
+    for name, fn in (("pairs", case_pairs), ("clones", case_clones), ("batches", case_batches)):
         if only and name not in only:
             continue
         out = os.path.join(HERE, name)
