@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "kasa_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void|uint64_t|const char \*)\s*\*?(kasa_[a-z_0-9]+)\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|uint64_t|int64_t|const char \*)\s*\*?(kasa_[a-z_0-9]+)\(", header, re.M))
     L = capi.lib()
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
