@@ -45,7 +45,7 @@ enum {
     KASA_STAGE_SORT = 1,     /* Compare.hpp:1077/1130 sort by k-mer */
     KASA_STAGE_LOOKUP = 2,   /* Compare.hpp:1098-1117 + :803-829,:861-995: prefix table + search */
     KASA_STAGE_GROUP = 3,    /* Compare.hpp:917-955,1005-1041: per-level groups, taxon sets, flush order */
-    KASA_STAGE_REGROUP = 4,  /* the scatter of Compare.hpp:528-530, done as a stable sort back to reads */
+    KASA_STAGE_REGROUP = 4,  /* slots of the queries in read order when the encoder could not rank them (stable sort by read) */
     KASA_STAGE_SCORE = 5,    /* Compare.hpp:516-532 score accumulation in reference order */
     KASA_STAGE_COUNT = 6
 };
@@ -127,16 +127,18 @@ int kasa_batch_lookup_score(kasa_ctx *ctx, int wantPerRead, int coverage);
 
 /* The two halves of kasa_batch_lookup_score as separate steps, with the event records in between exposed, for an index
  * that is range-partitioned over devices (C5; the reference's loadIndex has no such mode, the seam is ours):
- *   kasa_batch_group          per sorted query and level: flush position + taxon-set reference (8 bytes), taxon lists
- *                             that do not fit a reference in a pool of 32-bit words {n, taxa...};
- *   kasa_batch_records_*      size / download of both; import replaces them on a context whose batch is sorted
- *                             (records = nQueries x nLevels entries {u32 flushPosition, u32 reference}, level kHigh first);
+ *   kasa_batch_group          one record per sorted query, in sorted order: 8 (up to 8 levels) or 16 (up to 25 levels)
+ *                             32-bit words {position, last flush position, deepest level | flush order of its events,
+ *                             number of taxon segments, up to 4 (8) segments or the pool offset of a longer list};
+ *                             a segment = taxon | first level << 22 | last level << 27;
+ *   kasa_batch_records_*      size (in 32-bit words) / download of records and pool; import hands records in sorted order
+ *                             to a context whose batch is sorted, which files them by read;
  *   kasa_batch_score          replays the records per read (scores, profile) exactly as kasa_batch_lookup_score does. */
 int kasa_batch_group(kasa_ctx *ctx, int coverage);
 int kasa_batch_score(kasa_ctx *ctx, int wantPerRead);
-int kasa_batch_records_size(kasa_ctx *ctx, uint64_t *nRecords, uint64_t *nPoolWords);
-int kasa_batch_records_fetch(kasa_ctx *ctx, uint64_t *records, uint32_t *pool);
-int kasa_batch_records_import(kasa_ctx *ctx, const uint64_t *records, uint64_t nRecords, const uint32_t *pool, uint64_t nPoolWords);
+int kasa_batch_records_size(kasa_ctx *ctx, uint64_t *nRecordWords, uint64_t *nPoolWords);
+int kasa_batch_records_fetch(kasa_ctx *ctx, uint32_t *records, uint32_t *pool);
+int kasa_batch_records_import(kasa_ctx *ctx, const uint32_t *records, uint64_t nRecordWords, const uint32_t *pool, uint64_t nPoolWords);
 
 /* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
  * scoringFunc scans (Compare.hpp:1501-1522). */
@@ -158,8 +160,10 @@ int kasa_profile_import_limbs(kasa_ctx *ctx, const uint64_t *limbs);
 /* HIP-event time (ms) and launch count of a stage, accumulated since the last reset. */
 int kasa_ctx_stage_ms(kasa_ctx *ctx, int stage, double *ms, uint64_t *launches);
 int kasa_ctx_stage_reset(kasa_ctx *ctx);
-/* HIP-event time of the dominant kernel alone (the lookup kernel), for the roofline line. */
+/* HIP-event time of single kernels alone, for the roofline lines: lookup_tile_kernel (the sorted-index lookup) and
+ * score_fast_kernel (the lane-per-read replay, the largest kernel of the step). */
 int kasa_ctx_lookup_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
+int kasa_ctx_score_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
 /* Number of query records the batch holds right now: the k-mer count of kasa_batch_encode, less the
  * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
 int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);

@@ -23,7 +23,7 @@ EXPORTS = [
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
-    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
+    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_ctx_score_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
 ]
@@ -259,17 +259,22 @@ class Context:
     def score(self, want_per_read: bool = True):
         _check(lib().kasa_batch_score(self.h, C.c_int(int(want_per_read))))
 
+    @property
+    def rec_words(self) -> int:
+        """32-bit words of one event record (include/kasa_hip.h, kasa_batch_group): 8 up to 8 levels, 16 up to 25."""
+        return 8 if self.nK <= 8 else 16
+
     def records(self):
-        """Event records of the batch: (rec u32[nQ, nK, 2] = {flush position, taxon-set reference}, pool u32[])."""
+        """Event records of the batch after group(): (rec u32[nQ, rec_words], pool u32[]), records in sorted order."""
         n, m = C.c_uint64(0), C.c_uint64(0)
         _check(lib().kasa_batch_records_size(self.h, C.byref(n), C.byref(m)))
-        rec = np.zeros((int(n.value), 2), dtype=np.uint32)
+        rec = np.zeros(int(n.value), dtype=np.uint32)
         pool = np.zeros(max(1, int(m.value)), dtype=np.uint32)
         _check(lib().kasa_batch_records_fetch(self.h, _p(rec), _p(pool)))
-        return rec.reshape(-1, self.nK, 2), pool
+        return rec.reshape(-1, self.rec_words), pool
 
     def records_import(self, rec: np.ndarray, pool: np.ndarray):
-        rec = np.ascontiguousarray(rec, dtype=np.uint32).reshape(-1, 2)
+        rec = np.ascontiguousarray(rec, dtype=np.uint32).reshape(-1)
         pool = np.ascontiguousarray(pool, dtype=np.uint32)
         _check(lib().kasa_batch_records_import(self.h, _p(rec), C.c_uint64(rec.shape[0]), _p(pool), C.c_uint64(pool.shape[0])))
 
@@ -325,6 +330,12 @@ class Context:
     def lookup_kernel_ms(self):
         ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
         _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
+        return ms.value, int(n.value), int(q.value)
+
+    def score_kernel_ms(self):
+        """HIP-event time of score_fast_kernel alone: (ms, launches, queries)."""
+        ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().kasa_ctx_score_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
         return ms.value, int(n.value), int(q.value)
 
     def max_queries_per_batch(self, device: int = 0, fraction: float = 0.8) -> int:

@@ -45,8 +45,6 @@ static constexpr int TILE_THREADS = 256;
 static constexpr int ITEMS = TILE / TILE_THREADS; // 4
 static constexpr uint32_t NOPOS = 0xFFFFFFFFu;
 static constexpr int PCAP = 1024;                 // pending (not yet flushed) groups per read
-static constexpr uint32_t REF_SINGLE = 0x80000000u;
-static constexpr uint32_t REF_PAIR = 0x40000000u;
 static constexpr int TLIST = 256;                // touched taxa of a read kept as a list (else dense scan)
 
 static thread_local std::string g_err;
@@ -307,6 +305,7 @@ static int index_create_impl(int device, const void *records, uint64_t nRecords,
     if (nRecords == 0) return fail(KASA_E_ARG, "The index file cannot be found or is empty!");
     if (nRecords >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_index_create: %llu records exceed the 32-bit position range of this build", (unsigned long long)nRecords);
     if (!taxIds || nTaxa < 2) return fail(KASA_E_ARG, "kasa_index_create: content mapping missing");
+    if (nTaxa >= (1u << 22)) return fail(KASA_E_LIMIT, "kasa_index_create: %u taxa exceed the 2^22 taxon indices an event record can name", nTaxa);
     int ndev = 0;
     kasa_device_count(&ndev);
     if (device < 0 || device >= ndev) return fail(KASA_E_HIP, "kasa_index_create: no HIP device %d (found %d)", device, ndev);
@@ -447,6 +446,8 @@ struct kasa_ctx {
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
     bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
+    bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
+    int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
     // buffers
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
     DevBuf seqOff, seqRead;                    // u64[nSeq+1] k-mer offset of every uploaded sequence, u32[nSeq] its read
@@ -455,8 +456,13 @@ struct kasa_ctx {
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
-    DevBuf rec;                                // {u32 F, u32 ref}[nQ][nK]
-    DevBuf pool, plist, sortTmp, misc;         // taxon lists, positions by read, rocPRIM temp, counters
+    DevBuf rec;                                // event records, recWords() u32 each, by slot
+    DevBuf pool, plist, sortTmp, misc;         // taxon segment lists, positions by read (slot fix-up), rocPRIM temp, counters
+    DevBuf recIn;                              // imported records in sorted order, before they go to their slots
+    DevBuf slotBuf;                            // u32[nQ]: slot of every sorted position when it does not come out of the sort
+    const uint32_t *slotOf = nullptr;          // slot of sorted position p (payload of the sort, or slotBuf); NULL: not known yet
+    bool payloadIsSlot = false;                // what the encoder gave the sort as payload: slots (ranked reads) or read ids
+    DevBuf flushOff, flushPos, flushOff2, flushPos2;   // general score kernel: flush positions of the listed reads' queries
     DevBuf ovList;                             // reads the first general pass hands to the second
     uint32_t lastOverflowReads = 0;
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted;           // per-block dense score rows; reads left to the slow kernel
@@ -469,8 +475,9 @@ struct kasa_ctx {
     int K() const { return ix->letters(); }
     template <class Key> Key *keys() const { return static_cast<Key *>(qKmer); }
     StageTimer timers[KASA_STAGE_COUNT];
-    StageTimer lookupKernel;
-    uint64_t lookupQueries = 0;
+    StageTimer lookupKernel, scoreKernel;       // single kernels timed alone: lookup_tile_kernel, score_fast_kernel
+    hipEvent_t skA = nullptr, skB = nullptr;
+    uint64_t lookupQueries = 0, scoreQueries = 0;
     std::vector<int64_t> hostOff;
 };
 
@@ -581,7 +588,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -589,7 +596,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
         for (auto e : t.pool) (void)hipEventDestroy(e);
     };
     for (auto &t : c->timers) drop(t);
-    drop(c->lookupKernel);
+    drop(c->lookupKernel); drop(c->scoreKernel);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -638,7 +645,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     if (nSeq < 0 || nReads < 0 || (nSeq > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
     if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
     const uint64_t nBases = nSeq ? (uint64_t)(offsets[nSeq] - offsets[0]) : 0;
     std::vector<uint64_t> soff((size_t)nSeq + 1), koff((size_t)nReads + 1, 0);
     c->hostOff.assign((size_t)nSeq + 1, 0);
@@ -1117,10 +1124,22 @@ __global__ void unique_scatter_kernel(const Key *__restrict__ kmer, const uint32
     if (i == 0 || sl != slot[i - 1]) { outKmer[sl - 1] = kmer[i]; outRead[sl - 1] = read[i]; }
 }
 
+// read of a slot: slots of read r are kmerOff[r] .. kmerOff[r+1]
+__global__ void slot_to_read_kernel(const uint32_t *__restrict__ slot, uint32_t n, const uint64_t *__restrict__ kmerOff, uint32_t nReads,
+                                    uint32_t *__restrict__ read)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t s = slot[i];
+    uint32_t lo = 0, hi = nReads;                                  // last r with kmerOff[r] <= s
+    while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (kmerOff[mid] <= s) lo = mid; else hi = mid; }
+    read[i] = lo;
+}
+
 template <class Key>
 static int sort_and_range_impl(kasa_ctx *c, int unique)
 {
-    c->grouped = false;
+    c->grouped = false; c->slotOf = nullptr;
     HIPCHK(hipSetDevice(c->ix->device));
     uint64_t nQ = c->nQ;
     int rc;
@@ -1137,6 +1156,12 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
     }
     c->qKmer = c->qKmerB.p;
     c->qRead = c->qReadB.as<uint32_t>();
+    if (c->payloadIsSlot && nQ > 0) {
+        if (unique) {                                                  // -e compares read ids: back from slots to reads
+            slot_to_read_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qReadB.as<uint32_t>(), (uint32_t)nQ, c->kmerOff.as<uint64_t>(), (uint32_t)c->nReads, c->qReadA.as<uint32_t>());
+            HIPCHK(hipMemcpyAsync(c->qReadB.p, c->qReadA.p, nQ * 4, hipMemcpyDeviceToDevice, c->stream));
+        } else c->slotOf = c->qReadB.as<uint32_t>();                   // the payload of the sort IS the slot
+    }
     if (unique && nQ > 1) {
         // -e (Compare.hpp:3167-3178): drop records equal in (k-mer, read id) to their predecessor.  The sort above is
         // stable and the encoder emits reads in ascending order, so every duplicate of a read is adjacent here.
@@ -1210,94 +1235,35 @@ static constexpr int GITEMS = 2;                  // the group kernel gives a th
 static constexpr int GTHREADS = TILE / GITEMS;    // 512
 
 // ------------------------------------------------------------------------------------------------
-// group: per level, per sorted query -> (flush position F, taxon-set reference)
+// event records
 // ------------------------------------------------------------------------------------------------
-// Block-wide scans over the 256 per-thread aggregates of a tile (each thread owns GITEMS consecutive
-// positions).  suffix_min: min over threads to the right; prefix_max: max over threads to the left.
-// suffix_min: min over threads to the right; prefix_max: max over threads to the left.  Each wavefront scans
-// with shuffles, the four wavefront totals are combined through LDS: two barriers per scan.
-__device__ __forceinline__ uint32_t block_excl_suffix_min(uint32_t v, uint32_t *sh)
-{
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t incl = v;                                      // inclusive suffix min inside the wavefront
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(incl, off);
-        if (lane + off < 64 && o < incl) incl = o;
-    }
-    uint32_t excl = __shfl_down(incl, 1);
-    if (lane == 63) excl = NOPOS;
-    if (lane == 0) sh[wv] = incl;
-    __syncthreads();
-    for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = sh[w]; if (o < excl) excl = o; }
-    __syncthreads();
-    return excl;
-}
+// One record per query, RW 32-bit words (RW = 8: up to 8 levels, RW = 16: up to 25), written to the query's SLOT: reads
+// in batch order, the queries of a read in sorted order -- so the score kernels stream a read's records front to back.
+//   [0] p      sorted position of the query
+//   [1] Fmax   the last flush position of its groups (all of them are closed once the stream reaches it)
+//   [2] d | order << 5    d = deepest matched k (0: no match, nothing else is valid); order (RW = 8) = the levels
+//                         lv = kHigh - k of its events in flush order (F ascending, k ascending), 3 bits each
+//   [3] nseg   number of taxon segments
+//   RW = 8 : [4..7]  up to 4 segments, or [4] = pool offset of all of them when nseg > 4
+//   RW = 16: [4..7]  order, 5 bits per event (a 128-bit value, first event in the low bits);  [8..15] up to 8 segments,
+//            or [8] = pool offset
+// A segment is one index entry of the query's kLow-group seen from the query: taxon | kFirst << 22 | kLast << 27 -- the
+// entry puts its taxon into the taxon set T_k of the levels kFirst..kLast (kLast = letters it shares with the query,
+// capped at d; kFirst - 1 = letters it shares with the nearest earlier entry of the same taxon, which represents the
+// taxon up to there).  |T_k| = number of segments covering k.  This replaces the reference's per-level sBitArray sets
+// (Compare.hpp:917-955, BitArray.hpp:98-117) for all levels of a query at once.
+static constexpr uint32_t SEG_TAX_MASK = (1u << 22) - 1u;
+template <int RW> struct RecTraits;
+template <> struct RecTraits<8> { static constexpr int LEVELS = 8, INL = 4, SEG0 = 4, OBITS = 3; };
+template <> struct RecTraits<16> { static constexpr int LEVELS = 25, INL = 8, SEG0 = 8, OBITS = 5; };
+__device__ __forceinline__ bool seg_covers(uint32_t s, uint32_t k) { return ((s >> 22) & 31u) <= k && k <= (s >> 27); }
 
-__device__ __forceinline__ int block_excl_prefix_max(int v, int *sh)
+// levels (bit lv = kHigh - k) at which sorted position p closes the groups before it: a new prefix range closes all of
+// them, otherwise p opens a new matched group at the levels ql < k <= d (ql = letters shared with its predecessor)
+__device__ __forceinline__ uint32_t special_mask(int ql, int d, int kHigh, uint32_t allLv)
 {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl, off);
-        if (lane >= off && o > incl) incl = o;
-    }
-    int excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = -1;
-    if (lane == 63) sh[wv] = incl;
-    __syncthreads();
-    for (int w = 0; w < wv; ++w) { const int o = sh[w]; if (o > excl) excl = o; }
-    __syncthreads();
-    return excl;
-}
-
-// Step 1: bounds [a, b) of the group, its number of distinct taxa, and the 32-bit encoding when it fits
-// inline (0 = needs n + 1 words in the pool).
-// mPrev / mNext / tx0: letters entry j shares with j-1, letters entry j+1 shares with j (0 past the end), taxon of j --
-// the same for every level of a query, so the kernel gathers them once per query, all queries of a thread at once.
-template <class Meta>
-__device__ __forceinline__ uint32_t group_scan(uint32_t j, int g, const Meta *__restrict__ meta,
-                                               const uint32_t *__restrict__ tax, uint32_t nIdx, bool coverage,
-                                               uint64_t *__restrict__ cntTotalLv, int mPrev, int mNext, uint32_t tx0,
-                                               uint32_t &a, uint32_t &b, uint32_t &n)
-{
-    constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;   // KeyTraits::META_MASK / META_SHIFT
-    a = j; b = j + 1;
-    const bool openLeft = (j > 0) && mPrev >= g;
-    const bool openRight = (b < nIdx) && mNext >= g;
-    if (!openLeft && !openRight) {                       // the group is this one entry (the common case)
-        const uint32_t t0 = tx0;
-        if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[t0], 1ull);
-        n = 1;
-        return REF_SINGLE | t0;
-    }
-    if (openLeft) { --a; while (a > 0 && (int)(meta[a] & LM) >= g) --a; }
-    if (openRight) { ++b; while (b < nIdx && (int)(meta[b] & LM) >= g) ++b; }
-    uint32_t t0 = 0, t1 = 0;
-    n = 0;
-    for (uint32_t i = a; i < b; ++i)
-        if ((int)(meta[i] >> DS) < g) {
-            const uint32_t tx = tax[i];
-            if (n == 0) t0 = tx; else if (n == 1) t1 = tx;
-            ++n;
-            if (coverage) atomicAdd((unsigned long long *)&cntTotalLv[tx], 1ull);
-        }
-    if (n == 1) return REF_SINGLE | t0;
-    if (n == 2 && t0 < 32768u && t1 < 32768u) return REF_PAIR | (t0 << 15) | t1;
-    return 0u;
-}
-
-// Step 2: append {n, taxa...} at pool[off]
-template <class Meta>
-__device__ __forceinline__ uint32_t group_emit(uint32_t a, uint32_t b, uint32_t n, int g, const Meta *__restrict__ meta,
-                                               const uint32_t *__restrict__ tax, uint32_t *__restrict__ pool, uint32_t poolCap,
-                                               uint32_t off)
-{
-    if (off + n + 1 > poolCap || off + n + 1 >= REF_PAIR) return REF_PAIR - 1;  // overflow: the host grows the pool and reruns
-    pool[off] = n;
-    uint32_t w = off + 1;
-    for (uint32_t i = a; i < b; ++i)
-        if ((int)(meta[i] >> (sizeof(Meta) == 1 ? 4 : 8)) < g) pool[w++] = tax[i];
-    return off;
+    if (ql < RANGE_LETTERS) return allLv;
+    return (d > ql) ? ((((2u << (d - ql - 1)) - 1u) << (kHigh - d)) & allLv) : 0u;
 }
 
 __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *sh, uint32_t &total)
@@ -1317,500 +1283,208 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
     return before + incl - v;
 }
 
-// One level of the group computation for this thread's GITEMS consecutive queries: flush positions F and the
-// taxon-set references (leaders compute them, members copy them through LDS).
-// One level of the group computation for this thread's GITEMS consecutive queries: flush positions F and the
-// taxon-set references (leaders compute them, members copy them through LDS).
-// Positions grow with the thread index, so "next special position to the right" is the first special of the nearest
-// thread to the right that has one, and "my group's leader" is the last leader of the nearest thread to the left that
-// has one: inside a wavefront a ballot finds that thread, across wavefronts four LDS slots do.  `xs` = exchange slots
-// of this level (levels alternate between two sets, so one barrier per exchange is enough).
-struct GroupExchange { uint32_t firstSp[GTHREADS / 64]; int lastLeader[GTHREADS / 64]; uint32_t info[TILE]; };
-
-template <class Meta>
-__device__ __forceinline__ void group_level(
-    int lv, int t, uint32_t base, uint32_t nQ, const uint8_t (&ql)[GITEMS], const uint8_t (&d)[GITEMS], const uint32_t (&rp)[GITEMS],
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
-    uint32_t nIdx, int kHigh, uint32_t *__restrict__ pool, uint32_t poolCap, uint32_t *__restrict__ poolCursor, int coverage,
-    uint64_t *__restrict__ cntTotal, uint32_t nTaxa, GroupExchange &xs, uint32_t *shU, uint32_t *sBase,
-    const uint8_t (&mPrev)[GITEMS], const uint8_t (&mNext)[GITEMS], const uint32_t (&tx0)[GITEMS],
-    uint32_t (&F)[GITEMS], uint32_t (&R)[GITEMS])
+// The taxon segments of one query: walk the index outwards from `j` (an entry sharing the query's deepest matched
+// prefix) as long as the entries share the kLow-group's letters with the query.  Letters entry i shares with the query
+// = min(d, letters shared by all neighbours between i and j) -- `meta` holds the neighbour counts.  Calls emit(seg).
+template <class Meta, class Emit>
+__device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, const Meta *__restrict__ meta,
+                                              const uint32_t *__restrict__ tax, uint32_t nIdx, Emit emit)
 {
-    const int k = kHigh - lv;
-    const int g = group_letters(k);
-    const int lane = t & 63, wv = t >> 6;
-    const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
-    const unsigned long long below = (1ull << lane) - 1ull;
-    // ---- this thread's special positions and leaders
-    bool sp[GITEMS], leader[GITEMS];
-    uint32_t firstSp = NOPOS;
-    int lastLeader = -1;
-#pragma unroll
-    for (int i = GITEMS - 1; i >= 0; --i) {
-        const uint32_t p = base + i;
-        sp[i] = (p < nQ) && ((ql[i] < RANGE_LETTERS) || (ql[i] < g && d[i] >= k));
-        if (sp[i]) firstSp = p;
+    constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;
+    const int gLow = group_letters(kLow);
+    auto one = [&](uint32_t i, int kLast, uint32_t m) {
+        const int dup = (int)(m >> DS);
+        const int kFirst = dup < RANGE_LETTERS ? kLow : (dup + 1 > kLow ? dup + 1 : kLow);
+        if (kFirst <= kLast) emit(tax[i] | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27));
+    };
+    const uint32_t mj = meta[j];
+    one(j, d, mj);
+    // j shares at least max(d, 6) letters with the query (a match needs the 6-letter range; '^' may cut d below that)
+    const int chain0 = d > RANGE_LETTERS ? d : RANGE_LETTERS;
+    int chain = chain0;
+    uint32_t m = mj;
+    for (uint32_t i = j; i > 0;) {                               // to the left: entry i-1 shares (meta[i] & LM) letters with i
+        const int l = (int)(m & LM);
+        if (l < chain) chain = l;
+        if (chain < gLow) break;
+        --i;
+        m = meta[i];
+        one(i, chain < d ? chain : d, m);
     }
+    chain = chain0;
+    for (uint32_t i = j + 1; i < nIdx; ++i) {
+        m = meta[i];
+        const int l = (int)(m & LM);
+        if (l < chain) chain = l;
+        if (chain < gLow) break;
+        one(i, chain < d ? chain : d, m);
+    }
+}
+
+// group: one workgroup per tile of TILE sorted queries, a thread owns GITEMS consecutive ones.
+//   1. flush positions F_k(p) = next position after p that closes level k: inside the wavefront from two ballots per
+//      level, across wavefronts through one LDS table (one barrier), across tiles from tileNext;
+//   2. the flush order of the query's events and Fmax;
+//   3. the taxon segments (walk_segments), the first INL of them inline, longer lists in the pool with one allocation
+//      per workgroup;
+//   4. the record goes to rec[slot]: slotOf[p], or p itself when slotOf is NULL (records exported in sorted order).
+template <int RW, class Key>
+__global__ __launch_bounds__(GTHREADS) void group_kernel(
+    const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
+    const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
+    const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
+    uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int coverage,
+    uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
+{
+    typedef RecTraits<RW> RT;
+    constexpr int NL = RT::LEVELS, INL = RT::INL;
+    __shared__ uint32_t shU[GTHREADS / 64];
+    __shared__ uint32_t sFirst[GTHREADS / 64][NL];                 // first closing position of a wavefront, per level
+    __shared__ uint32_t sBase;
+    const int nK = kHigh - kLow + 1;
+    const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t base = blockIdx.x * TILE + t * GITEMS;
+    int d[GITEMS];
+    uint32_t rp[GITEMS], sp[GITEMS];
 #pragma unroll
     for (int i = 0; i < GITEMS; ++i) {
-        const bool matched = (base + i < nQ) && d[i] >= k;
-        leader[i] = matched && (ql[i] < g || (t == 0 && i == 0));   // first query of a level-k group, or the first matched query of the tile
-        if (leader[i]) lastLeader = t * GITEMS + i;
+        const uint32_t p = base + i;
+        d[i] = 0; rp[i] = 0; sp[i] = 0;
+        if (p < nQ) {
+            const Key q = qKmer[p];
+            const int ql = (p == 0) ? 0 : lcp_letters<Key>(qKmer[p - 1], q);
+            d[i] = depth[p];
+            rp[i] = rep[p];
+            sp[i] = special_mask(ql, d[i], kHigh, allLv);
+        }
     }
-    // ---- nearest neighbours inside the wavefront
-    const unsigned long long mSp = __ballot(firstSp != NOPOS);
-    const unsigned long long mLd = __ballot(lastLeader >= 0);
-    uint32_t carry = NOPOS;
-    {
-        const unsigned long long hi = mSp & above;
-        const int src = hi ? (__ffsll((long long)hi) - 1) : lane;
-        const uint32_t v = __shfl(firstSp, src);
-        if (hi) carry = v;
-    }
-    int lead = -1;
-    {
-        const unsigned long long lo = mLd & below;
-        const int src = lo ? (63 - __clzll((long long)lo)) : lane;
-        const int v = __shfl(lastLeader, src);
-        if (lo) lead = v;
-    }
-    {
-        const uint32_t wFirst = __shfl(firstSp, mSp ? (__ffsll((long long)mSp) - 1) : 0);
-        const int wLast = __shfl(lastLeader, mLd ? (63 - __clzll((long long)mLd)) : 0);
-        if (lane == 0) { xs.firstSp[wv] = mSp ? wFirst : NOPOS; xs.lastLeader[wv] = mLd ? wLast : -1; }
+    // ---- 1. flush positions
+    const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    uint32_t F[GITEMS][NL];
+    uint32_t open0 = 0, open1 = 0;                               // levels not closed inside the wavefront
+#pragma unroll
+    for (int lv = 0; lv < NL; ++lv) {
+        F[0][lv] = NOPOS; F[1][lv] = NOPOS;
+        if (lv >= nK) continue;
+        const unsigned long long b0 = __ballot((sp[0] >> lv) & 1u), b1 = __ballot((sp[1] >> lv) & 1u);
+        const unsigned long long any = b0 | b1;
+        uint32_t next = NOPOS;                                    // first closing position in the lanes above
+        const unsigned long long hi = any & above;
+        if (hi) {
+            const int l2 = __ffsll((long long)hi) - 1;
+            next = blockIdx.x * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u);
+        }
+        F[1][lv] = next;
+        F[0][lv] = ((sp[1] >> lv) & 1u) ? base + 1 : next;
+        if (next == NOPOS) { open1 |= 1u << lv; if (!((sp[1] >> lv) & 1u)) open0 |= 1u << lv; }
+        if (lane == 0) {
+            uint32_t first = NOPOS;
+            if (any) { const int l2 = __ffsll((long long)any) - 1; first = blockIdx.x * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u); }
+            sFirst[wv][lv] = first;
+        }
     }
     __syncthreads();
-    if (carry == NOPOS)
-        for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = xs.firstSp[w]; if (o != NOPOS) { carry = o; break; } }
-    if (lead < 0)
-        for (int w = wv - 1; w >= 0; --w) { const int o = xs.lastLeader[w]; if (o >= 0) { lead = o; break; } }
-    if (carry == NOPOS) carry = tileNext[(size_t)lv * nTiles + blockIdx.x];
+    if (open1) {
 #pragma unroll
-    for (int i = GITEMS - 1; i >= 0; --i) {
-        F[i] = carry;
-        if (sp[i]) carry = base + i;
+        for (int lv = 0; lv < NL; ++lv) {
+            if (!((open1 >> lv) & 1u)) continue;
+            uint32_t v = NOPOS;
+            for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = sFirst[w][lv]; if (o != NOPOS) { v = o; break; } }
+            if (v == NOPOS) v = tileNext[(size_t)lv * nTiles + blockIdx.x];
+            F[1][lv] = v;
+            if ((open0 >> lv) & 1u) F[0][lv] = v;
+        }
     }
-    // taxon sets of the leaders' index groups; sets that do not fit the 32-bit encoding go to the pool,
-    // with ONE allocation per workgroup and level
-    uint32_t ga[GITEMS], gb[GITEMS], gn[GITEMS], gref[GITEMS];
+    // ---- 2. + 3. per query: order of its events, taxon segments
+    uint32_t w2[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
+    unsigned __int128 ord[GITEMS];
     uint32_t need = 0;
 #pragma unroll
     for (int i = 0; i < GITEMS; ++i) {
-        gref[i] = 0; gn[i] = 0; ga[i] = 0; gb[i] = 0;
-        if (leader[i]) {
-            gref[i] = group_scan(rp[i], g, meta, tax, nIdx, coverage && ql[i] < g, cntTotal + (size_t)lv * nTaxa,
-                                 (int)mPrev[i], (int)mNext[i], tx0[i], ga[i], gb[i], gn[i]);
-            if (gref[i] == 0u) need += gn[i] + 1;
+        w2[i] = 0; fmax[i] = 0; nseg[i] = 0;
+#pragma unroll
+        for (int s = 0; s < INL; ++s) seg[i][s] = 0;
+        ord[i] = 0;
+        if (d[i] == 0) continue;
+        const int lvTop = kHigh - d[i];                           // events: levels lvTop .. nK-1
+        uint32_t fm = 0;
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) {
+            if (lv < lvTop || lv >= nK) continue;
+            const uint32_t f = F[i][lv];
+            if (f > fm) fm = f;
+            uint32_t rank = 0;                                    // events flushed before this one: smaller F, or equal F and smaller k
+#pragma unroll
+            for (int l2 = 0; l2 < NL; ++l2)
+                if (l2 >= lvTop && l2 < nK && l2 != lv && (F[i][l2] < f || (F[i][l2] == f && l2 > lv))) ++rank;
+            ord[i] |= (unsigned __int128)(uint32_t)lv << (RT::OBITS * rank);
+        }
+        fmax[i] = fm;
+        w2[i] = (uint32_t)d[i] | (RW == 8 ? ((uint32_t)ord[i] << 5) : 0u);
+        uint32_t n = 0;
+        walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+#pragma unroll
+            for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
+            ++n;
+        });
+        nseg[i] = n;
+        if (n > (uint32_t)INL) need += n;
+        if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
+            const Key q = qKmer[base + i];
+            const int ql = (base + i == 0) ? 0 : lcp_letters<Key>(qKmer[base + i - 1], q);
+            walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+                for (int k = (int)((s >> 22) & 31u); k <= (int)(s >> 27); ++k)
+                    if (ql < group_letters(k)) atomicAdd((unsigned long long *)&cntTotal[(size_t)(kHigh - k) * nTaxa + (s & SEG_TAX_MASK)], 1ull);
+            });
         }
     }
-    if (__syncthreads_or(need != 0u)) {                             // uniform across the workgroup
+    if (__syncthreads_or(need != 0u)) {                              // uniform across the workgroup
         uint32_t total = 0;
         uint32_t off = block_excl_prefix_sum(need, shU, total);
-        if (t == 0) *sBase = atomicAdd(poolCursor, total);
+        if (t == 0) {                                                // 64-bit cursor: the host sees how much was asked for, even beyond 2^32
+            const unsigned long long at = atomicAdd(poolCursor, (unsigned long long)total);
+            sBase = at + total <= (unsigned long long)poolCap ? (uint32_t)at : NOPOS;
+        }
         __syncthreads();
-        off += *sBase;
+        const bool fits = sBase != NOPOS;
+        off += fits ? sBase : 0u;
 #pragma unroll
         for (int i = 0; i < GITEMS; ++i)
-            if (leader[i] && gref[i] == 0u) {
-                gref[i] = group_emit(ga[i], gb[i], gn[i], g, meta, tax, pool, poolCap, off);
-                off += gn[i] + 1;
+            if (nseg[i] > (uint32_t)INL) {
+                if (!fits) { seg[i][0] = 0; }                        // overflow: the host grows the pool and reruns
+                else {
+                    uint32_t w = off;
+                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) { pool[w++] = s; });
+                    seg[i][0] = off;
+                }
+                off += nseg[i];
             }
     }
-#pragma unroll
-    for (int i = 0; i < GITEMS; ++i)
-        if (leader[i]) xs.info[t * GITEMS + i] = gref[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < GITEMS; ++i) {
-        if (leader[i]) lead = t * GITEMS + i;
-        const bool matched = (base + i < nQ) && d[i] >= k;
-        R[i] = (matched && lead >= 0) ? xs.info[lead] : 0u;
-    }
-}
-
-// NKR > 0: all levels of a query are collected in registers and written as one contiguous record (nK <= NKR);
-// NKR == 0: any number of levels, one 8-byte store per level.
-template <int NKR, class Key>
-__global__ __launch_bounds__(GTHREADS) void group_kernel(
-    const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep, uint32_t nQ,
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax,
-    uint32_t nIdx, int kHigh, int kLow, uint2 *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap,
-    uint32_t *__restrict__ poolCursor, int coverage, uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
-{
-    __shared__ uint32_t shU[GTHREADS];
-    __shared__ GroupExchange xs[2];                               // levels alternate: no barrier needed before reuse
-    __shared__ uint32_t sBase;
-    const int nK = kHigh - kLow + 1;
-    const int t = threadIdx.x;
-    const uint32_t base = blockIdx.x * TILE + t * GITEMS;         // blocked: this thread owns base..base+3
-    uint8_t ql[GITEMS], d[GITEMS];
-    uint32_t rp[GITEMS];
+    // ---- 4. the record
 #pragma unroll
     for (int i = 0; i < GITEMS; ++i) {
         const uint32_t p = base + i;
-        if (p < nQ) {
-            const Key q = qKmer[p];
-            ql[i] = (p == 0) ? 0 : (uint8_t)lcp_letters<Key>(qKmer[p - 1], q);
-            d[i] = depth[p];
-            rp[i] = rep[p];
-        } else { ql[i] = 0; d[i] = 0; rp[i] = 0; }
-    }
-    // the index neighbourhood of every matched query, gathered once (it is the same at every level) and for all of the
-    // thread's queries at once: twelve independent loads in flight instead of a dependent chain per level
-    constexpr int LM = KeyTraits<Key>::META_MASK;
-    uint8_t mPrev[GITEMS], mNext[GITEMS];
-    uint32_t tx0[GITEMS];
-#pragma unroll
-    for (int i = 0; i < GITEMS; ++i) {
-        mPrev[i] = 0; mNext[i] = 0; tx0[i] = 0;
-        if (d[i] > 0) {
-            const uint32_t j = rp[i];
-            mPrev[i] = (uint8_t)(meta[j] & LM);
-            if (j + 1 < nIdx) mNext[i] = (uint8_t)(meta[j + 1] & LM);
-            tx0[i] = tax[j];
-        }
-    }
-    if constexpr (NKR > 0) {
-        uint32_t allF[NKR][GITEMS], allR[NKR][GITEMS];
-#pragma unroll
-        for (int lv = 0; lv < NKR; ++lv) {
-#pragma unroll
-            for (int i = 0; i < GITEMS; ++i) { allF[lv][i] = 0; allR[lv][i] = 0; }
-            if (lv < nK)                                          // uniform: barriers inside are safe
-                group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                            coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, allF[lv], allR[lv]);
-        }
-#pragma unroll
-        for (int i = 0; i < GITEMS; ++i) {
-            const uint32_t p = base + i;
-            if (p >= nQ) continue;
-            uint2 *o = rec + (size_t)p * nK;
-            if (NKR == 6 && nK == 6) {                             // 48-byte record: three 16-byte stores
-                uint4 *o4 = reinterpret_cast<uint4 *>(o);
-                o4[0] = make_uint4(allF[0][i], allR[0][i], allF[1][i], allR[1][i]);
-                o4[1] = make_uint4(allF[2][i], allR[2][i], allF[3][i], allR[3][i]);
-                o4[2] = make_uint4(allF[4][i], allR[4][i], allF[5][i], allR[5][i]);
-            } else {
-#pragma unroll
-                for (int lv = 0; lv < NKR; ++lv)
-                    if (lv < nK) o[lv] = make_uint2(allF[lv][i], allR[lv][i]);
-            }
-        }
-    } else {
-        for (int lv = 0; lv < nK; ++lv) {
-            uint32_t F[GITEMS], R[GITEMS];
-            group_level(lv, t, base, nQ, ql, d, rp, tileNext, nTiles, meta, tax, nIdx, kHigh, pool, poolCap, poolCursor,
-                        coverage, cntTotal, nTaxa, xs[lv & 1], shU, &sBase, mPrev, mNext, tx0, F, R);
-#pragma unroll
-            for (int i = 0; i < GITEMS; ++i)
-                if (base + i < nQ) rec[(size_t)(base + i) * nK + lv] = make_uint2(F[i], R[i]);
+        if (p >= nQ) continue;
+        const uint32_t slot = slotOf ? slotOf[p] : p;
+        uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * RW);
+        if constexpr (RW == 8) {
+            o[0] = make_uint4(p, fmax[i], w2[i], nseg[i]);
+            o[1] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
+        } else {
+            o[0] = make_uint4(p, fmax[i], w2[i], nseg[i]);
+            o[1] = make_uint4((uint32_t)ord[i], (uint32_t)(ord[i] >> 32), (uint32_t)(ord[i] >> 64), (uint32_t)(ord[i] >> 96));
+            o[2] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
+            o[3] = make_uint4(seg[i][4], seg[i][5], seg[i][6], seg[i][7]);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// score: one wavefront per read, events replayed in flush order
-// ------------------------------------------------------------------------------------------------
-struct ScoreArgs {
-    const uint32_t *plist; const uint64_t *kmerOff; const uint2 *rec; const uint32_t *pool;
-    uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
-    float *scratch;                              // per block: nTaxa floats, all zero between reads
-    uint64_t *cntUnique, *cntAllHi, *cntAllMid, *cntAllLo;
-    uint32_t *rowPos, *rowLen; uint2 *st; uint32_t stCap; uint32_t *stCursor;   // staging rows: {taxon, score bits}
-    uint32_t *errFlag; int wantPerRead;
-    int addProfile;                              // 0 on a rerun that only re-emits rows
-    const uint32_t *list; uint32_t nList;        // slow kernel: reads to process (NULL = all)
-    uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the slow kernel
-    uint32_t *ovList, *ovCount;                  // slow kernel, first pass: reads it hands to the second pass (NULL = last pass)
-    uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
-    uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
-};
-
-// c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
-// x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
-// with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
-// terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
-__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint64_t c, uint32_t n)
-{
-    if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
-    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
-    if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
-    const uint64_t lo64 = c * R;
-    const uint64_t hi = __umul64hi(c, R);
-    const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
-    if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
-    if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
-    if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
-}
-
-static constexpr int AGG = 256;                                   // per-read profile aggregation table (LDS)
-static constexpr int PCAP_SMALL = 96;                              // pending window of the first pass (small LDS footprint: many wavefronts per CU)
-static constexpr unsigned long long AGG_EMPTY = ~0ull;
-
-__device__ __forceinline__ void profile_add(const ScoreArgs &A, int lv, uint32_t tx, uint32_t n, unsigned long long c)
-{
-    const size_t cell = (size_t)lv * A.nTaxa + tx;
-    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], c);
-    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c, n);
-}
-
-// PC = capacity of the pending window.  The kernel is latency-bound (dependent gathers per query and per taxon
-// list), so the first pass runs with a small window -- little LDS, many resident wavefronts -- and hands the rare
-// read that overflows it (or the aggregation table) to a second pass with the full window.  A read that is handed on
-// leaves nothing behind: its score cells are cleared again and its profile counts never left LDS.
-template <int PC>
-__global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
-{
-    __shared__ unsigned long long aKey[AGG];
-    __shared__ uint32_t aCnt[AGG];
-    __shared__ uint32_t pF[PC], pRef[PC];
-    __shared__ uint32_t pCnt[PC];
-    __shared__ uint8_t pK[PC];
-    __shared__ uint32_t sTouched;
-    __shared__ uint32_t sList[TLIST];
-    const int lane = threadIdx.x;
-    const int nK = A.kHigh - A.kLow + 1;
-    float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
-
-    for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
-    const uint32_t nWork = A.list ? A.nList : A.nReads;
-    for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
-        const uint32_t r = A.list ? A.list[wi] : wi;
-        const uint64_t o0 = A.kmerOff[r];
-        const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
-        int head = 0, tail = 0;            // pending window [head, tail), sorted by (F, k) ascending
-        uint32_t cTax = 0xFFFFFFFFu;       // this lane's cached score cell (taxa with tx % 64 == lane live here)
-        float cVal = 0.0f;
-        const bool mayHandOn = A.ovList != nullptr;
-        bool ovf = false;                  // this read does not fit this pass (per lane; combined with a ballot)
-        if (lane == 0) sTouched = 0;
-        __syncthreads();
-
-        // c hits for the score cell of taxon tx; called by the lane that owns the cell (tx % 64 == lane).  The lane keeps
-        // the cell it touched last in a register: a read's events go almost all to one or two taxa, and a
-        // load-add-store chain through global memory per event would cost a round trip each.
-        auto cellAdd = [&](const uint32_t tx, const float sc, const uint32_t c) {
-            if (cTax != tx) {
-                if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
-                cVal = score[tx];
-                cTax = tx;
-                if (cVal == 0.0f) { const uint32_t ti = atomicAdd(&sTouched, 1u); if (ti < (uint32_t)TLIST) sList[ti] = tx; }
-            }
-            for (uint32_t j = 0; j < c; ++j) cVal = __fadd_rn(cVal, sc);      // Compare.hpp:528-530, one add per hit
-        };
-        // profile counts of this read are summed per (level, |T|, taxon) in LDS first and leave as one set of atomics
-        // per distinct key at the end of the read (device-scope atomics are the scarce resource); any lane may call it
-        auto aggAdd = [&](const int lv, const uint32_t n, const uint32_t tx, const uint32_t c) {
-            const unsigned long long key = ((unsigned long long)lv << 52) | ((unsigned long long)n << 32) | tx;
-            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (AGG - 1);
-            for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (AGG - 1)) {
-                const unsigned long long seen = atomicCAS(&aKey[h], AGG_EMPTY, key);
-                if (seen == AGG_EMPTY || seen == key) { atomicAdd(&aCnt[h], c); return; }
-            }
-            if (mayHandOn) ovf = true; else profile_add(A, lv, tx, n, c);
-        };
-        // one flushed group (level k, taxon-set reference, c hits of this read); all lanes call it with the same values
-        auto applyVals = [&](const int k, const uint32_t ref, const uint32_t c) {
-            const int lv = A.kHigh - k;
-            uint32_t n; const uint32_t *list; uint32_t single = 0, pairB = 0;
-            if (ref & REF_SINGLE) { n = 1; single = ref & 0x7FFFFFFFu; list = nullptr; }
-            else if (ref & REF_PAIR) { n = 2; single = (ref >> 15) & 0x7FFFu; pairB = ref & 0x7FFFu; list = nullptr; }
-            else { n = A.pool[ref]; list = A.pool + ref + 1; }
-            const float w = (float)(k * k) / 625.0f;                         // Compare.hpp:392
-            const float s = __fmul_rn(w, __fdiv_rn(1.0f, (float)n));         // Compare.hpp:924
-            for (uint32_t i = 0; i < n; ++i) {
-                const uint32_t tx = list ? list[i] : (i == 0 ? single : pairB);
-                if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
-                if (A.wantPerRead) cellAdd(tx, s, c);
-                if (A.addProfile) aggAdd(lv, n, tx, c);
-            }
-        };
-        auto apply = [&](int e) { applyVals((int)pK[e], pRef[e], pCnt[e]); };   // the pending entry at `e`
-
-        uint32_t pnext = cnt ? A.plist[o0] : 0u;
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t p = pnext;
-            pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
-            if (mayHandOn && __ballot(ovf) != 0ull) { ovf = true; break; }
-            // everything that flushes at or before p precedes all events of this and later queries
-            while (head < tail && pF[head] <= p) { apply(head); ++head; }
-            if (head == tail) head = tail = 0;
-            uint32_t myF = 0, myRef = 0;
-            if (lane < nK) { const uint2 v = A.rec[(size_t)p * nK + lane]; myF = v.x; myRef = v.y; }
-            // The usual case: nothing is pending and every group of this query closes before the read's next query.
-            // Then its events need no window.  Lane o holds the event of level k = kHigh - o: every lane decodes its own
-            // event and files its profile counts (lane-parallel); only the float additions are replayed one event at a
-            // time, in (F, k) order, each by the lane that owns the cell.
-            const bool has = myRef != 0u;                                    // lanes >= nK hold 0
-            if (head == tail && __ballot(has && myF > pnext) == 0ull) {
-                uint32_t rank = 0;
-                for (int o = 0; o < nK; ++o) {
-                    const uint32_t oF = __shfl(myF, o), oR = __shfl(myRef, o);
-                    if (oR != 0u && (oF < myF || (oF == myF && o > lane))) ++rank;
-                }
-                uint32_t eN = 0, eT0 = 0, eT1 = 0;
-                float eS = 0.0f;
-                bool isList = false;
-                if (has) {
-                    if (myRef & REF_SINGLE) { eN = 1; eT0 = myRef & 0x7FFFFFFFu; }
-                    else if (myRef & REF_PAIR) { eN = 2; eT0 = (myRef >> 15) & 0x7FFFu; eT1 = myRef & 0x7FFFu; }
-                    else { eN = A.pool[myRef]; isList = true; }
-                    const int k = A.kHigh - lane;
-                    eS = __fmul_rn((float)(k * k) / 625.0f, __fdiv_rn(1.0f, (float)eN));   // Compare.hpp:392,924
-                    if (A.addProfile && !isList) { aggAdd(lane, eN, eT0, 1u); if (eN == 2) aggAdd(lane, 2u, eT1, 1u); }
-                }
-                const int nEv = __popcll(__ballot(has));
-                for (int rk = 0; rk < nEv; ++rk) {
-                    const int src = __ffsll((long long)__ballot(has && rank == (uint32_t)rk)) - 1;
-                    const uint32_t n = __shfl(eN, src);
-                    const float sc = __shfl(eS, src);
-                    if (!__shfl((int)isList, src)) {
-                        const uint32_t t0 = __shfl(eT0, src), t1 = __shfl(eT1, src);
-                        if (A.wantPerRead) {
-                            if ((t0 & 63u) == (uint32_t)lane) cellAdd(t0, sc, 1u);
-                            if (n == 2 && (t1 & 63u) == (uint32_t)lane) cellAdd(t1, sc, 1u);
-                        }
-                    } else {
-                        const uint32_t ref = __shfl(myRef, src);
-                        for (uint32_t b0 = 0; b0 < n; b0 += 64) {             // the taxon list, 64 entries at a time
-                            const uint32_t cntHere = (n - b0 < 64u) ? n - b0 : 64u;
-                            const uint32_t tx = ((uint32_t)lane < cntHere) ? A.pool[ref + 1 + b0 + lane] : 0xFFFFFFFFu;
-                            if (A.addProfile && tx != 0xFFFFFFFFu) aggAdd(src, n, tx, 1u);
-                            if (A.wantPerRead)
-                                for (uint32_t i = 0; i < cntHere; ++i) {
-                                    const uint32_t t = __shfl(tx, (int)i);
-                                    if ((t & 63u) == (uint32_t)lane) cellAdd(t, sc, 1u);
-                                }
-                        }
-                    }
-                }
-                continue;
-            }
-            for (int lv = nK - 1; lv >= 0; --lv) {                            // k ascending
-                const uint32_t F = __shfl(myF, lv);
-                const uint32_t ref = __shfl(myRef, lv);
-                if (ref == 0) continue;
-                const int k = A.kHigh - lv;
-                // position of (F, k) in the sorted window; equal key = same group: bump its count
-                int pos = tail;
-                bool same = false;
-                for (int b0 = head; b0 < tail; b0 += 64) {
-                    const int e = b0 + lane;
-                    bool ge = false, eq = false;
-                    if (e < tail) {
-                        const uint32_t eF = pF[e]; const int eK = pK[e];
-                        ge = (eF > F) || (eF == F && eK >= k);
-                        eq = (eF == F && eK == k);
-                    }
-                    const unsigned long long m = __ballot(ge);
-                    if (m) { pos = b0 + __ffsll((long long)m) - 1; same = (__ballot(eq) != 0ull); break; }
-                }
-                if (same) {
-                    if (lane == 0) pCnt[pos] = pCnt[pos] + 1;
-                    __syncthreads();
-                    continue;
-                }
-                if (tail >= PC) {
-                    if (head > 0) {                                           // compact the window to the front
-                        for (int b0 = head; b0 < tail; b0 += 64) {
-                            const int e = b0 + lane;
-                            uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
-                            if (e < tail) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
-                            __syncthreads();
-                            if (e < tail) { pF[e - head] = f; pRef[e - head] = rf; pCnt[e - head] = cc; pK[e - head] = kk; }
-                            __syncthreads();
-                        }
-                        pos -= head; tail -= head; head = 0;
-                    }
-                    if (tail >= PC) { if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
-                }
-                for (int hi = tail; hi > pos; hi -= 64) {                     // shift [pos, tail) right by one
-                    const int e = hi - 1 - lane;
-                    uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
-                    if (e >= pos) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
-                    __syncthreads();
-                    if (e >= pos) { pF[e + 1] = f; pRef[e + 1] = rf; pCnt[e + 1] = cc; pK[e + 1] = kk; }
-                    __syncthreads();
-                }
-                if (lane == 0) { pF[pos] = F; pRef[pos] = ref; pCnt[pos] = 1; pK[pos] = (uint8_t)k; }
-                ++tail;
-                __syncthreads();
-            }
-        }
-        if (!ovf) while (head < tail) { apply(head); ++head; }
-        ovf = mayHandOn && (__ballot(ovf) != 0ull);
-        if (ovf) {                                                            // hand the read on, leave no trace
-            __syncthreads();
-            const uint32_t m = sTouched;
-            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
-            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
-            for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
-            if (lane == 0) A.ovList[atomicAdd(A.ovCount, 1u)] = r;
-            __syncthreads();
-            continue;
-        }
-        if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
-        __threadfence_block();
-        __syncthreads();
-        if (A.addProfile)
-            for (int i = lane; i < AGG; i += 64) {
-                const unsigned long long key = aKey[i];
-                if (key == AGG_EMPTY) continue;
-                profile_add(A, (int)(key >> 52), (uint32_t)key, (uint32_t)(key >> 32) & 0xFFFFFu, aCnt[i]);
-                aKey[i] = AGG_EMPTY; aCnt[i] = 0u;
-            }
-
-        // ---- emit the row (taxon ascending) and clear the dense row
-        if (A.wantPerRead) {
-            const uint32_t m = sTouched;
-            uint32_t start = 0;
-            if (lane == 0) {
-                start = m ? atomicAdd(A.stCursor, m) : 0u;
-                A.rowPos[r] = start; A.rowLen[r] = m;
-            }
-            start = __shfl(start, 0);
-            __threadfence_block();
-            if (m && start + m <= A.stCap) {
-                if (m <= 64) {
-                    const uint32_t mine = (lane < (int)m) ? sList[lane] : 0xFFFFFFFFu;
-                    uint32_t rank = 0;
-                    for (uint32_t i = 0; i < m; ++i) rank += (__shfl(mine, (int)i) < mine) ? 1u : 0u;
-                    if (lane < (int)m) A.st[start + rank] = make_uint2(mine, __float_as_uint(score[mine]));
-                } else {
-                    uint32_t w = start;
-                    for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) {
-                        const uint32_t tx = b0 + lane;
-                        const float v = (tx < A.nTaxa) ? score[tx] : 0.0f;
-                        const unsigned long long mk = __ballot(v > 0.0f);
-                        if (v > 0.0f) {
-                            const uint32_t o = w + __popcll(mk & ((1ull << lane) - 1ull));
-                            A.st[o] = make_uint2(tx, __float_as_uint(v));
-                        }
-                        w += __popcll(mk);
-                    }
-                }
-            }
-            __syncthreads();
-            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
-            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
-            __syncthreads();
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain, so
-// 64 reads run side by side in a wavefront; the small per-read state (pending groups, a handful of
-// taxa with their score and per-level profile counters) lives in LDS, strided by lane.  A read that
-// does not fit (more than FPL groups pending, more than FTA taxa, a taxon set larger than 4, more
-// than 25 levels) is handed to score_kernel untouched: nothing of it has reached global memory.
-// ------------------------------------------------------------------------------------------------
-static constexpr int FPL = 64;      // groups a read may keep pending (rare: only when a group outlives the read's next query)
 static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
 static constexpr int FLOG = 960;    // contributions to all other taxa, logged per read and resolved by row_merge_kernel
 static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * 6 * 4 + FLOG; the fast kernel hands longer rows to score_kernel)
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
-static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG + 4 * FPL); // u32 words per block
+static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG); // u32 words per block: one log per lane
 
 // One wavefront working alone on LDS: LDS instructions of a wave execute in order, so only the compiler has
 // to be kept from moving them across the point (a workgroup barrier would also drain pending global stores).
@@ -1868,24 +1542,350 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 }
 
 // ------------------------------------------------------------------------------------------------
-// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain per
-// (read, taxon), so 64 reads run side by side in a wavefront.  The (up to) two taxa a read really comes
-// from -- those with a deep match -- live in registers with their per-level hit counters in LDS; every
-// other contribution (chance matches of short prefixes, ~150 per read against a 4e8-record index) is
-// appended to a per-lane log as an 8-byte record and resolved later, per read, by row_merge_kernel.
-// The kernel performs no atomics on the profile tables: everything it finds leaves as records, so it can
-// be rerun.  A read it cannot hold is handed to score_kernel untouched.
+// score
 // ------------------------------------------------------------------------------------------------
-// NKF = levels the instantiation holds in registers (its per-query sort is a bubble network over NKF slots).  With 6
-// levels a (taxon, level) counter holds four 16-bit fields (|T| = 1..4); with more levels two (|T| = 1, 2), to keep the
-// LDS footprint of a wavefront small -- larger sets leave as profile records through the log.
-// PERREAD = false (no -q: profile only): the order of a read's events does not matter for the profile, so the per-query
-// sort, the pending list and the float chain are left out; what remains is counting hits per (level, |T|, taxon).
-template <int NKF, bool PERREAD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void score_fast_kernel(ScoreArgs A)
+struct ScoreArgs {
+    const uint32_t *rec; const uint64_t *kmerOff; const uint32_t *pool;   // records by slot; slots of read r: kmerOff[r] .. kmerOff[r+1]
+    uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
+    float *scratch;                              // per block: nTaxa floats, all zero between reads
+    uint64_t *cntUnique, *cntAllHi, *cntAllMid, *cntAllLo;
+    uint32_t *rowPos, *rowLen; uint2 *st; uint32_t stCap; unsigned long long *stCursor;   // staging rows: {taxon, score bits}
+    uint32_t *errFlag; int wantPerRead;
+    int addProfile;                              // 0 on a rerun that only re-emits rows
+    const uint32_t *list; uint32_t nList;        // general kernel: reads to process (NULL = all)
+    const uint32_t *flushPos; const uint64_t *flushOff;   // general kernel: F per level of the listed reads' queries; first query of list entry wi
+    uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the general kernel
+    uint32_t *ovList, *ovCount;                  // general kernel, first pass: reads it hands to the second pass (NULL = last pass)
+    uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
+    uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
+};
+
+// c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
+// x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
+// with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
+// terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
+__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint64_t c, uint32_t n)
 {
-    typedef typename std::conditional<NKF <= 6, unsigned long long, uint32_t>::type Counter;
-    constexpr uint32_t CNT_FIELDS = NKF <= 6 ? 4u : 2u;
+    if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
+    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
+    if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
+    const uint64_t lo64 = c * R;
+    const uint64_t hi = __umul64hi(c, R);
+    const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
+    if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
+    if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
+    if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
+}
+
+static constexpr int AGG = 256;                                   // per-read profile aggregation table (LDS)
+static constexpr int PCAP_SMALL = 96;                              // pending window of the first pass (small LDS footprint: many wavefronts per CU)
+static constexpr unsigned long long AGG_EMPTY = ~0ull;
+
+__device__ __forceinline__ void profile_add(const ScoreArgs &A, int lv, uint32_t tx, uint32_t n, unsigned long long c)
+{
+    const size_t cell = (size_t)lv * A.nTaxa + tx;
+    if (n == 1) atomicAdd((unsigned long long *)&A.cntUnique[cell], c);
+    fixed_add(A.cntAllHi, A.cntAllMid, A.cntAllLo, cell, c, n);
+}
+
+// Flush positions of single queries, for the reads the general kernel replays: F_k(p) for every level of every query of
+// the listed reads, recomputed the way group_kernel computes them (scan of the rest of p's tile, then tileNext).  The
+// records keep only the ORDER of a query's own events; the general kernel also needs the order between queries.
+// One wavefront per query; out[(flushOff[wi] + j) * nK + lv].
+template <int RW, class Key>
+__global__ __launch_bounds__(256) void flush_positions_kernel(
+    const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ flushOff, const uint64_t *__restrict__ kmerOff,
+    const uint32_t *__restrict__ rec, const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, uint32_t nQ,
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, int kHigh, int kLow, uint32_t *__restrict__ out)
+{
+    const int nK = kHigh - kLow + 1;
+    const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t wi = blockIdx.x; wi < nList; wi += gridDim.x) {
+        const uint32_t r = list ? list[wi] : wi;
+        const uint64_t o0 = kmerOff[r];
+        const uint32_t cnt = (uint32_t)(kmerOff[r + 1] - o0);
+        const uint64_t f0 = flushOff[wi];
+        for (uint32_t j = wv; j < cnt; j += 4) {
+            const uint32_t *w = rec + (o0 + j) * RW;
+            const uint32_t p = w[0];
+            const int d = (int)(w[2] & 31u);
+            uint32_t myF = NOPOS;                                     // lane lv holds F of level lv
+            if (d > 0) {
+                const uint32_t tile = p / TILE;
+                const uint32_t tileEnd = ((uint64_t)(tile + 1) * TILE < nQ) ? (tile + 1) * TILE : nQ;
+                uint32_t todo = allLv & ~((1u << (kHigh - d)) - 1u);  // levels kLow..d
+                for (uint32_t b0 = p + 1; b0 < tileEnd && todo; b0 += 64) {
+                    const uint32_t pp = b0 + lane;
+                    uint32_t m = 0;
+                    if (pp < tileEnd) {
+                        const int ql = lcp_letters<Key>(qKmer[pp - 1], qKmer[pp]);
+                        m = special_mask(ql, (int)depth[pp], kHigh, allLv);
+                    }
+                    for (int lv = 0; lv < nK; ++lv) {
+                        if (!((todo >> lv) & 1u)) continue;
+                        const unsigned long long b = __ballot((m >> lv) & 1u);
+                        if (b) { if (lane == lv) myF = b0 + (uint32_t)(__ffsll((long long)b) - 1); todo &= ~(1u << lv); }
+                    }
+                }
+                if (lane < nK && ((todo >> lane) & 1u)) myF = tileNext[(size_t)lane * nTiles + tile];
+            }
+            if (lane < nK) out[(f0 + j) * nK + lane] = myF;
+        }
+    }
+}
+
+// General kernel: one wavefront per read, events replayed in flush order through a pending window -- any number of
+// levels, any taxon-set size, groups that stay open across the read's later queries (equal (F, k) = same group: its
+// hit count grows).  PC = capacity of the pending window.  The kernel is latency-bound (dependent gathers per query and
+// per taxon list), so the first pass runs with a small window -- little LDS, many resident wavefronts -- and hands the
+// rare read that overflows it (or the aggregation table) to a second pass with the full window.  A read that is handed
+// on leaves nothing behind: its score cells are cleared again and its profile counts never left LDS.
+template <int PC, int RW>
+__global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
+{
+    typedef RecTraits<RW> RT;
+    __shared__ unsigned long long aKey[AGG];
+    __shared__ uint32_t aCnt[AGG];
+    __shared__ uint32_t pF[PC], pRef[PC];
+    __shared__ uint32_t pCnt[PC];
+    __shared__ uint8_t pK[PC];
+    __shared__ uint32_t sTouched;
+    __shared__ uint32_t sList[TLIST];
+    const int lane = threadIdx.x;
+    const int nK = A.kHigh - A.kLow + 1;
+    float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
+
+    for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
+    const uint32_t nWork = A.list ? A.nList : A.nReads;
+    for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
+        const uint32_t r = A.list ? A.list[wi] : wi;
+        const uint64_t o0 = A.kmerOff[r];
+        const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
+        const uint64_t f0 = A.flushOff[wi];
+        int head = 0, tail = 0;            // pending window [head, tail), sorted by (F, k) ascending
+        uint32_t cTax = 0xFFFFFFFFu;       // this lane's cached score cell (taxa with tx % 64 == lane live here)
+        float cVal = 0.0f;
+        const bool mayHandOn = A.ovList != nullptr;
+        bool ovf = false;                  // this read does not fit this pass (per lane; combined with a ballot)
+        if (lane == 0) sTouched = 0;
+        __syncthreads();
+
+        // c hits for the score cell of taxon tx; called by the lane that owns the cell (tx % 64 == lane).  The lane keeps
+        // the cell it touched last in a register: a read's events go almost all to one or two taxa, and a
+        // load-add-store chain through global memory per event would cost a round trip each.
+        auto cellAdd = [&](const uint32_t tx, const float sc, const uint32_t c) {
+            if (cTax != tx) {
+                if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
+                cVal = score[tx];
+                cTax = tx;
+                if (cVal == 0.0f) { const uint32_t ti = atomicAdd(&sTouched, 1u); if (ti < (uint32_t)TLIST) sList[ti] = tx; }
+            }
+            for (uint32_t j = 0; j < c; ++j) cVal = __fadd_rn(cVal, sc);      // Compare.hpp:528-530, one add per hit
+        };
+        // profile counts of this read are summed per (level, |T|, taxon) in LDS first and leave as one set of atomics
+        // per distinct key at the end of the read (device-scope atomics are the scarce resource); any lane may call it
+        auto aggAdd = [&](const int lv, const uint32_t n, const uint32_t tx, const uint32_t c) {
+            const unsigned long long key = ((unsigned long long)lv << 56) | ((unsigned long long)n << 32) | tx;
+            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (AGG - 1);
+            for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (AGG - 1)) {
+                const unsigned long long seen = atomicCAS(&aKey[h], AGG_EMPTY, key);
+                if (seen == AGG_EMPTY || seen == key) { atomicAdd(&aCnt[h], c); return; }
+            }
+            if (mayHandOn) ovf = true; else profile_add(A, lv, tx, n, c);
+        };
+        // one flushed group: level k of the query at `slot`, c hits of this read; all lanes call it with the same values.
+        // |T| = the segments covering k; every taxon is handled by the lane that owns its cell.
+        auto applyVals = [&](const int k, const uint32_t slot, const uint32_t c) {
+            const uint32_t *w = A.rec + (size_t)slot * RW;
+            const uint32_t nseg = w[3];
+            const uint32_t *seg = nseg > (uint32_t)RT::INL ? A.pool + w[RT::SEG0] : w + RT::SEG0;
+            uint32_t n = 0;
+            for (uint32_t b0 = 0; b0 < nseg; b0 += 64) {
+                const uint32_t s = (b0 + lane < nseg) ? seg[b0 + lane] : 0u;
+                n += (uint32_t)__popcll(__ballot(b0 + lane < nseg && seg_covers(s, (uint32_t)k)));
+            }
+            const float sc = event_score(k, n);
+            const int lv = A.kHigh - k;
+            for (uint32_t i = 0; i < nseg; ++i) {
+                const uint32_t s = seg[i];
+                if (!seg_covers(s, (uint32_t)k)) continue;
+                const uint32_t tx = s & SEG_TAX_MASK;
+                if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
+                if (A.wantPerRead) cellAdd(tx, sc, c);
+                if (A.addProfile) aggAdd(lv, n, tx, c);
+            }
+        };
+        auto apply = [&](int e) { applyVals((int)pK[e], pRef[e], pCnt[e]); };   // the pending entry at `e`
+
+        uint32_t pnext = cnt ? A.rec[(size_t)o0 * RW] : 0u;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t p = pnext;
+            const uint32_t slot = (uint32_t)(o0 + j);
+            pnext = (j + 1 < cnt) ? A.rec[(size_t)(slot + 1) * RW] : 0xFFFFFFFFu;
+            if (mayHandOn && __ballot(ovf) != 0ull) { ovf = true; break; }
+            // everything that flushes at or before p precedes all events of this and later queries
+            while (head < tail && pF[head] <= p) { apply(head); ++head; }
+            if (head == tail) head = tail = 0;
+            const int d = (int)(A.rec[(size_t)slot * RW + 2] & 31u);
+            if (d == 0) continue;
+            // lane lv holds the event of level k = kHigh - lv
+            const bool has = lane < nK && (A.kHigh - lane) <= d;
+            const uint32_t myF = has ? A.flushPos[(f0 + j) * nK + lane] : 0u;
+            // The usual case: nothing is pending and every group of this query closes before the read's next query.
+            // Then its events need no window: they are replayed at once in (F, k) order.
+            if (head == tail && __ballot(has && myF > pnext) == 0ull) {
+                uint32_t rank = 0;
+                for (int o = 0; o < nK; ++o) {
+                    const uint32_t oF = __shfl(myF, o);
+                    const bool oHas = (A.kHigh - o) <= d;
+                    if (oHas && (oF < myF || (oF == myF && o > lane))) ++rank;
+                }
+                const int nEv = d - A.kLow + 1;
+                for (int rk = 0; rk < nEv; ++rk) {
+                    const int src = __ffsll((long long)__ballot(has && rank == (uint32_t)rk)) - 1;
+                    applyVals(A.kHigh - src, slot, 1u);
+                }
+                continue;
+            }
+            for (int lv = nK - 1; lv >= 0; --lv) {                            // k ascending
+                const int k = A.kHigh - lv;
+                if (k > d) break;
+                const uint32_t F = __shfl(myF, lv);
+                // position of (F, k) in the sorted window; equal key = same group: bump its count
+                int pos = tail;
+                bool same = false;
+                for (int b0 = head; b0 < tail; b0 += 64) {
+                    const int e = b0 + lane;
+                    bool ge = false, eq = false;
+                    if (e < tail) {
+                        const uint32_t eF = pF[e]; const int eK = pK[e];
+                        ge = (eF > F) || (eF == F && eK >= k);
+                        eq = (eF == F && eK == k);
+                    }
+                    const unsigned long long m = __ballot(ge);
+                    if (m) { pos = b0 + __ffsll((long long)m) - 1; same = (__ballot(eq) != 0ull); break; }
+                }
+                if (same) {
+                    if (lane == 0) pCnt[pos] = pCnt[pos] + 1;
+                    __syncthreads();
+                    continue;
+                }
+                if (tail >= PC) {
+                    if (head > 0) {                                           // compact the window to the front
+                        for (int b0 = head; b0 < tail; b0 += 64) {
+                            const int e = b0 + lane;
+                            uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
+                            if (e < tail) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
+                            __syncthreads();
+                            if (e < tail) { pF[e - head] = f; pRef[e - head] = rf; pCnt[e - head] = cc; pK[e - head] = kk; }
+                            __syncthreads();
+                        }
+                        pos -= head; tail -= head; head = 0;
+                    }
+                    if (tail >= PC) { if (mayHandOn) ovf = true; else if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
+                }
+                for (int hi = tail; hi > pos; hi -= 64) {                     // shift [pos, tail) right by one
+                    const int e = hi - 1 - lane;
+                    uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
+                    if (e >= pos) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
+                    __syncthreads();
+                    if (e >= pos) { pF[e + 1] = f; pRef[e + 1] = rf; pCnt[e + 1] = cc; pK[e + 1] = kk; }
+                    __syncthreads();
+                }
+                if (lane == 0) { pF[pos] = F; pRef[pos] = slot; pCnt[pos] = 1; pK[pos] = (uint8_t)k; }
+                ++tail;
+                __syncthreads();
+            }
+        }
+        ovf = mayHandOn && (__ballot(ovf) != 0ull);
+        if (!ovf) while (head < tail) { apply(head); ++head; }
+        ovf = mayHandOn && (__ballot(ovf) != 0ull);
+        if (ovf) {                                                            // hand the read on, leave no trace
+            __syncthreads();
+            const uint32_t m = sTouched;
+            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
+            for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
+            if (lane == 0) A.ovList[atomicAdd(A.ovCount, 1u)] = r;
+            __syncthreads();
+            continue;
+        }
+        if (cTax != 0xFFFFFFFFu) score[cTax] = cVal;
+        __threadfence_block();
+        __syncthreads();
+        if (A.addProfile)
+            for (int i = lane; i < AGG; i += 64) {
+                const unsigned long long key = aKey[i];
+                if (key == AGG_EMPTY) continue;
+                profile_add(A, (int)(key >> 56), (uint32_t)key, (uint32_t)(key >> 32) & 0xFFFFFFu, aCnt[i]);
+                aKey[i] = AGG_EMPTY; aCnt[i] = 0u;
+            }
+
+        // ---- emit the row (taxon ascending) and clear the dense row
+        if (A.wantPerRead) {
+            const uint32_t m = sTouched;
+            unsigned long long start = 0;
+            if (lane == 0) {
+                start = m ? atomicAdd(A.stCursor, (unsigned long long)m) : 0ull;
+                const bool fits = start + m <= (unsigned long long)A.stCap;
+                A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? m : 0u;
+                if (!fits) start = ~0ull;
+            }
+            start = __shfl(start, 0);
+            __threadfence_block();
+            if (m && start != ~0ull) {
+                if (m <= 64) {
+                    const uint32_t mine = (lane < (int)m) ? sList[lane] : 0xFFFFFFFFu;
+                    uint32_t rank = 0;
+                    for (uint32_t i = 0; i < m; ++i) rank += (__shfl(mine, (int)i) < mine) ? 1u : 0u;
+                    if (lane < (int)m) A.st[start + rank] = make_uint2(mine, __float_as_uint(score[mine]));
+                } else {
+                    uint64_t w = start;
+                    for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) {
+                        const uint32_t tx = b0 + lane;
+                        const float v = (tx < A.nTaxa) ? score[tx] : 0.0f;
+                        const unsigned long long mk = __ballot(v > 0.0f);
+                        if (v > 0.0f) {
+                            const uint64_t o = w + __popcll(mk & ((1ull << lane) - 1ull));
+                            A.st[o] = make_uint2(tx, __float_as_uint(v));
+                        }
+                        w += __popcll(mk);
+                    }
+                }
+            }
+            __syncthreads();
+            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain per
+// (read, taxon), so 64 reads run side by side in a wavefront.  A read's records lie in its slots in sorted
+// order; the lane streams them front to back.  As long as every query's groups are closed before the read's
+// next matched query (Fmax <= next p: the overwhelmingly common case), the read's flush order is simply
+// query by query, each query's events in the order its record gives -- no pending list, no sorting.  A read
+// that breaks the rule (it repeats a k-mer prefix of its own) is handed to score_kernel untouched.
+// The (up to) two taxa a read really comes from -- those with a deep match -- live in registers with their
+// per-level hit counters in LDS; every other contribution (chance matches of short prefixes, ~150 per read
+// against a 4e8-record index) is appended to a per-lane log as an 8-byte record and resolved later, per read,
+// by row_merge_kernel.  The kernel performs no atomics on the profile tables: everything it finds leaves as
+// records, so it can be rerun.
+// ------------------------------------------------------------------------------------------------
+// RW = record width.  With up to 8 levels a (taxon, level) counter holds four 16-bit fields (|T| = 1..4); with more
+// levels two (|T| = 1, 2), to keep the LDS footprint of a wavefront small -- larger sets leave as profile records
+// through the log.  PERREAD = false (no -q: profile only): the order of a read's events does not matter for the
+// profile, so the float chain and the order rule are left out; what remains is counting hits per (level, |T|, taxon).
+template <int RW, bool PERREAD>
+__global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
+{
+    typedef RecTraits<RW> RT;
+    constexpr int NKF = RT::LEVELS, INL = RT::INL;
+    typedef typename std::conditional<RW == 8, unsigned long long, uint32_t>::type Counter;
+    constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
     __shared__ Counter cnt64[FTA][NKF][64];                          // 16-bit hit counters per (taxon, level, |T|)
     __shared__ EventTables evT;
     event_tables_init(evT);
@@ -1894,143 +1894,110 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     const uint32_t stride = gridDim.x * 64u;
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
     // per-block scratch; every lane owns a CONTIGUOUS log (records are appended one by one, so consecutive
-    // 8-byte stores of a lane fill whole sectors) and a contiguous pending list
+    // 8-byte stores of a lane fill whole sectors)
     uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
     uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;
-    uint4 *pend = reinterpret_cast<uint4 *>(blk + 64 * 2 * FLOG) + (size_t)lane * FPL;   // {F, ref, k | hits << 8, -}
     for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
         bool fb = false;
-        int np = 0, na = 0, nl = 0;
+        int na = 0, nl = 0;
         uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu;
         float mS0 = 0.0f, mS1 = 0.0f;
 #pragma unroll
         for (int e = 0; e < FTA; ++e)
-#pragma unroll
-            for (int l2 = 0; l2 < NKF; ++l2) cnt64[e][l2][lane] = 0;
+            for (int l2 = 0; l2 < nK; ++l2) cnt64[e][l2][lane] = 0;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
             if (cnt > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
 
-            auto applyEvent = [&](uint32_t k, uint32_t ref, uint32_t c) {
-                const int lv = A.kHigh - (int)k;
-                uint32_t n, t0 = 0, t1 = 0;
-                const uint32_t *list = nullptr;
-                if (ref & REF_SINGLE) { n = 1; t0 = ref & 0x7FFFFFFFu; }
-                else if (ref & REF_PAIR) { n = 2; t0 = (ref >> 15) & 0x7FFFu; t1 = ref & 0x7FFFu; }
-                else { n = A.pool[ref]; list = A.pool + ref + 1; }
-                if (n >= (1u << 13) || c >= (1u << 16)) { fb = true; atomicAdd(&A.why[3], 1u); return; }
-                const float s = event_score(evT, (int)k, n);
-                for (uint32_t i = 0; i < n && !fb; ++i) {
-                    const uint32_t t = list ? list[i] : (i == 0 ? t0 : t1);
-                    int e = -1;
-                    if (t == mTax0) e = 0;
-                    else if (t == mTax1) e = 1;
-                    else if (na < FTA && (int)k >= kPromote) {
-                        // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
-                        // slot.  If shallow matches already started its chain in the log, replay them first.
-                        float v0 = 0.0f;
-                        for (int q = 0; PERREAD && q < nl; ++q) {
-                            uint2 e2 = lg[q];
-                            if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
-                            const float s2 = event_score(evT, A.kHigh - (int)rk_level(e2.x), e2.y >> 16);
-                            for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
-                            e2.x |= RK_CONSUMED;
-                            lg[q] = e2;
-                        }
-                        e = na;
-                        if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
-                        ++na;
+            // one (event, taxon) contribution: level lv, |T| = n, score s of one hit
+            auto contribute = [&](uint32_t t, int lv, uint32_t n, float s) {
+                int e = -1;
+                if (t == mTax0) e = 0;
+                else if (t == mTax1) e = 1;
+                else if (na < FTA && A.kHigh - lv >= kPromote) {
+                    // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
+                    // slot.  If shallow matches already started its chain in the log, replay them first.
+                    float v0 = 0.0f;
+                    for (int q = 0; PERREAD && q < nl; ++q) {
+                        uint2 e2 = lg[q];
+                        if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
+                        const float s2 = event_score(evT, A.kHigh - (int)rk_level(e2.x), e2.y >> 16);
+                        for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
+                        e2.x |= RK_CONSUMED;
+                        lg[q] = e2;
                     }
-                    uint32_t kind = 0xFFFFFFFFu;                               // record to log, if any
-                    if (e >= 0) {
-                        if (PERREAD) {
-                            float v = (e == 0) ? mS0 : mS1;
-                            for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, s);  // Compare.hpp:528-530, one add per hit
-                            if (e == 0) mS0 = v; else mS1 = v;
-                        }
-                        if (n <= CNT_FIELDS) cnt64[e][lv][lane] += (Counter)c << (16 * (n - 1));
-                        else kind = RK_PROFILE;
-                    } else kind = PERREAD ? 0u : RK_PROFILE;
-                    if (kind != 0xFFFFFFFFu) {
-                        if (nl == FLOG || t >= (1u << 20)) { fb = true; atomicAdd(&A.why[2], 1u); break; }
-                        lg[nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | c);
-                        ++nl;
-                    }
+                    e = na;
+                    if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
+                    ++na;
+                }
+                uint32_t kind = 0xFFFFFFFFu;                               // record to log, if any
+                if (e >= 0) {
+                    if (PERREAD) { if (e == 0) mS0 = __fadd_rn(mS0, s); else mS1 = __fadd_rn(mS1, s); }   // Compare.hpp:528-530
+                    if (n <= CNT_FIELDS) cnt64[e][lv][lane] += (Counter)1 << (16 * (n - 1));
+                    else kind = RK_PROFILE;
+                } else kind = PERREAD ? 0u : RK_PROFILE;
+                if (kind != 0xFFFFFFFFu) {
+                    if (nl == FLOG) { fb = true; atomicAdd(&A.why[2], 1u); return; }
+                    lg[nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | 1u);
+                    ++nl;
                 }
             };
 
-            uint32_t pcur = cnt ? A.plist[o0] : 0u;
-            for (uint32_t j = 0; j < cnt && !fb; ++j) {
-                const uint32_t pnext = (j + 1 < cnt) ? A.plist[o0 + j + 1] : 0xFFFFFFFFu;
-                const uint2 *rp = A.rec + (size_t)pcur * nK;
-                // the (up to) 6 events of this query, k ascending; absent levels sink to the end
-                uint32_t eF[NKF], eR[NKF], eK[NKF];
-                bool early = true;
-#pragma unroll
-                for (int i = 0; i < NKF; ++i) {
-                    const int lv = nK - 1 - i;
-                    uint2 v = make_uint2(0xFFFFFFFFu, 0u);
-                    if (lv >= 0) v = rp[lv];
-                    if (v.y == 0u) v.x = 0xFFFFFFFFu;
-                    eF[i] = v.x; eR[i] = v.y; eK[i] = (uint32_t)(A.kHigh - lv);
-                    if (v.y != 0u && v.x > pnext) early = false;
+            uint32_t prevF = 0;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
+            for (uint32_t j = 0; j < cnt && !fb; ++j, rp += RW / 4) {
+                const uint4 h = rp[0];                                       // p, Fmax, d | order, nseg
+                const int d = (int)(h.z & 31u);
+                if (d == 0) continue;
+                if (PERREAD) {
+                    if (prevF > h.x) { fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
+                    prevF = h.y;
                 }
-                if (!PERREAD) {                                                // any order will do
-#pragma unroll
-                    for (int i = 0; i < NKF; ++i)
-                        if (eR[i] != 0u && !fb) applyEvent(eK[i], eR[i], 1u);
-                    pcur = pnext;
-                    continue;
-                }
-#pragma unroll
-                for (int a2 = 0; a2 < NKF - 1; ++a2)                           // stable: ties keep k ascending
-#pragma unroll
-                    for (int b2 = 0; b2 < NKF - 1 - a2; ++b2)
-                        if (eF[b2] > eF[b2 + 1]) {
-                            uint32_t x = eF[b2]; eF[b2] = eF[b2 + 1]; eF[b2 + 1] = x;
-                            x = eR[b2]; eR[b2] = eR[b2 + 1]; eR[b2 + 1] = x;
-                            x = eK[b2]; eK[b2] = eK[b2 + 1]; eK[b2 + 1] = x;
-                        }
-                if (np == 0 && early) {
-                    // every group of this query closes before the read's next query: replay at once
-#pragma unroll
-                    for (int i = 0; i < NKF; ++i)
-                        if (eR[i] != 0u && !fb) applyEvent(eK[i], eR[i], 1u);
+                const uint32_t nseg = h.w;
+                if (nseg >= (1u << 13)) { fb = true; atomicAdd(&A.why[3], 1u); break; }
+                const int nEv = d - A.kLow + 1;
+                uint32_t sg[INL];
+                unsigned __int128 order;
+                if constexpr (RW == 8) {
+                    const uint4 b = rp[1];
+                    sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w;
+                    order = h.z >> 5;
                 } else {
-                    // general case: merge into the pending list (sorted by (F, k)), then flush what closes
+                    const uint4 o4 = rp[1], b = rp[2], c4 = rp[3];
+                    order = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
+                    sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w; sg[4] = c4.x; sg[5] = c4.y; sg[6] = c4.z; sg[7] = c4.w;
+                }
+                if (nseg <= (uint32_t)INL) {
+                    for (int ev = 0; ev < nEv && !fb; ++ev) {
+                        const int lv = (int)((uint32_t)order & ((1u << RT::OBITS) - 1u));
+                        order >>= RT::OBITS;
+                        const uint32_t k = (uint32_t)(A.kHigh - lv);
+                        uint32_t n = 0;
 #pragma unroll
-                    for (int i = 0; i < NKF; ++i) {
-                        if (eR[i] == 0u || fb) continue;
-                        int pos = np;
-                        while (pos > 0) {
-                            const uint4 e4 = pend[pos - 1];
-                            if (e4.x > eF[i] || (e4.x == eF[i] && (e4.z & 255u) > eK[i])) --pos; else break;
-                        }
-                        if (pos > 0) {
-                            uint4 e4 = pend[pos - 1];
-                            if (e4.x == eF[i] && (e4.z & 255u) == eK[i]) { e4.z += 256u; pend[pos - 1] = e4; continue; }
-                        }
-                        if (np == FPL) { fb = true; atomicAdd(&A.why[4], 1u); continue; }
-                        for (int q = np; q > pos; --q) pend[q] = pend[q - 1];
-                        pend[pos] = make_uint4(eF[i], eR[i], eK[i] | 256u, 0u);
-                        ++np;
+                        for (int q = 0; q < INL; ++q) n += ((uint32_t)q < nseg && seg_covers(sg[q], k)) ? 1u : 0u;
+                        const float s = event_score(evT, (int)k, n);
+#pragma unroll
+                        for (int q = 0; q < INL; ++q)
+                            if ((uint32_t)q < nseg && seg_covers(sg[q], k) && !fb) contribute(sg[q] & SEG_TAX_MASK, lv, n, s);
                     }
-                    int nf = 0;
-                    while (nf < np && !fb) {
-                        const uint4 e4 = pend[nf];
-                        if (e4.x > pnext) break;
-                        applyEvent(e4.z & 255u, e4.y, e4.z >> 8);
-                        ++nf;
-                    }
-                    if (nf) {
-                        for (int q = nf; q < np; ++q) pend[q - nf] = pend[q];
-                        np -= nf;
+                } else {
+                    const uint32_t *seg = A.pool + sg[0];
+                    for (int ev = 0; ev < nEv && !fb; ++ev) {
+                        const int lv = (int)((uint32_t)order & ((1u << RT::OBITS) - 1u));
+                        order >>= RT::OBITS;
+                        const uint32_t k = (uint32_t)(A.kHigh - lv);
+                        uint32_t n = 0;
+                        for (uint32_t q = 0; q < nseg; ++q) n += seg_covers(seg[q], k) ? 1u : 0u;
+                        const float s = event_score(evT, (int)k, n);
+                        for (uint32_t q = 0; q < nseg && !fb; ++q) {
+                            const uint32_t sq = seg[q];
+                            if (seg_covers(sq, k)) contribute(sq & SEG_TAX_MASK, lv, n, s);
+                        }
                     }
                 }
-                pcur = pnext;
             }
         }
         // ---- the read's staging row: final scores of the register taxa, their counters as profile records, the log
@@ -2050,13 +2017,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
             if (lane >= off) incl += o;
         }
         const uint32_t total = __shfl(incl, 63);
-        uint32_t start = 0;
-        if (lane == 0 && total) start = atomicAdd(A.stCursor, total);
-        start = __shfl(start, 0) + (incl - m);
+        unsigned long long start = 0;
+        if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
+        start = __shfl(start, 0);
+        const bool fits = start + total <= (unsigned long long)A.stCap;
+        start += incl - m;
         if (active && !fb) {
-            A.rowPos[r] = start; A.rowLen[r] = m | (m ? ROW_MERGE : 0u);
-            if (start + m <= A.stCap) {
-                uint32_t w = start;
+            A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? (m | (m ? ROW_MERGE : 0u)) : 0u;
+            if (fits) {
+                uint32_t w = (uint32_t)start;
                 if (PERREAD && na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
                 if (PERREAD && na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
                 for (int e = 0; e < na; ++e) {
@@ -2343,70 +2312,129 @@ __global__ void widen_kernel(const uint32_t *__restrict__ in, uint64_t *__restri
     if (i < n) out[i] = in[i] & 0x7FFFFFFFu;   // bit 31 = ROW_MERGE
 }
 
-// lookup_score = group (per-level taxon sets and flush positions of every sorted query -> event records + taxon-list pool)
-// followed by score (records replayed per read).  The two halves are separate entry points so that the records can
-// travel: with a range-partitioned index the partition owner runs `group` on a slice of
-// another rank's sorted queries, and the read owner runs `score` on the records it gets back.
-static int group_stage(kasa_ctx *c, int coverage)
+__global__ void invert_kernel(const uint32_t *__restrict__ plist, uint32_t n, uint32_t *__restrict__ slotOf)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slotOf[plist[i]] = i;
+}
+
+// Slots from read ids (payload mode READ: kasa_batch_set_queries, -e, reads too long for the encoder's ranking): a stable
+// sort of the sorted positions by read id lists every read's queries in sorted order; the inverse is the slot.
+static int slots_from_reads(kasa_ctx *c)
+{
+    const uint64_t nQ = c->nQ;
+    int rc;
+    if ((rc = c->plist.reserve(nQ * 4 + 64)) || (rc = c->slotBuf.reserve(nQ * 4 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
+    hipEvent_t a, b;
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_REGROUP], &a, &b))) return rc;
+    if (nQ) {
+        unsigned bits = 1;
+        while ((1ull << bits) < (uint64_t)std::max<int64_t>(c->nReads, 1)) ++bits;
+        rocprim::counting_iterator<uint32_t> iota(0);
+        size_t tmpBytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
+                                         (size_t)nQ, 0u, bits, c->stream));
+        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
+                                         (size_t)nQ, 0u, bits, c->stream));
+        invert_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->plist.as<uint32_t>(), (uint32_t)nQ, c->slotBuf.as<uint32_t>());
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_REGROUP], a, b))) return rc;
+    c->slotOf = c->slotBuf.as<uint32_t>();
+    return KASA_OK;
+}
+
+template <int RW>
+static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, int cov, unsigned long long *cursor)
+{
+    const uint64_t nQ = c->nQ;
+    if (c->ix->wide)
+        group_kernel<RW, key128><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+    else
+        group_kernel<RW, uint64_t><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+    HIPCHK(hipGetLastError());
+    return KASA_OK;
+}
+
+// lookup_score = group (per sorted query: flush order of its events + taxon segments -> one record per query, in the query's
+// read-major slot) followed by score (records replayed per read).  The two halves are separate entry points so that the
+// records can travel: with a range-partitioned index the partition owner runs `group` on a slice
+// of another rank's sorted queries and exports the records in sorted order, the read owner imports them into their slots
+// and runs `score`.
+static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
 {
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_group: batch not sorted");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint64_t nQ = c->nQ;
-    const uint32_t nTaxa = c->ix->nTaxa;
-    const int nK = c->nK;
+    const int RW = c->recWords();
     int rc;
-    c->haveScores = false; c->nnz = 0; c->grouped = false; c->poolUsed = 1;
+    c->haveScores = false; c->nnz = 0; c->grouped = false; c->poolUsed = 1; c->recSorted = exportSorted;
     if (nQ == 0) { c->grouped = true; return KASA_OK; }
+    if (!exportSorted && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
-    if ((rc = c->rec.reserve(nQ * (size_t)nK * 8 + 64))) return rc;
-    uint32_t *counters = c->misc.as<uint32_t>(); // [0] pool cursor, [1] staging cursor, [2] error flags
+    if ((rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
+    unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging
     hipEvent_t a, b;
-
-    // ---- group
-    if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ / 2);
+    if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ / 4);
     for (int attempt = 0;; ++attempt) {
         if ((rc = c->pool.reserve(c->poolCap * 4))) return rc;
-        const uint32_t one = 1;
-        HIPCHK(hipMemcpyAsync(counters, &one, 4, hipMemcpyHostToDevice, c->stream)); // offset 0 means "no match"
+        const unsigned long long one = 1;
+        HIPCHK(hipMemcpyAsync(cursor, &one, 8, hipMemcpyHostToDevice, c->stream)); // offset 0 is never handed out
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
-        {
-            const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0x3FFFFFF0ull);
-            const int cov = coverage && attempt == 0;
-            if (c->ix->wide) {
-                auto kern = (nK <= 6) ? group_kernel<6, key128> : group_kernel<0, key128>;
-                kern<<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
-                    c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-                    c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
-            } else {
-                auto kern = (nK <= 6) ? group_kernel<6, uint64_t> : group_kernel<0, uint64_t>;
-                kern<<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), (uint32_t)nQ,
-                    c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-                    c->kHigh, c->kLow, c->rec.as<uint2>(), c->pool.as<uint32_t>(), cap, counters, cov, c->cntTotal.as<uint64_t>(), nTaxa);
-            }
-        }
-        HIPCHK(hipGetLastError());
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
+        const int cov = coverage && attempt == 0;
+        const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
+        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, cov, cursor) : launch_group<16>(c, slotOf, nTiles, cap, cov, cursor)))) return rc;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
-        uint32_t used = 0;
-        HIPCHK(hipMemcpyAsync(&used, counters, 4, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long used = 0;
+        HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (used <= c->poolCap) { c->poolUsed = used; break; }
-        if ((uint64_t)used >= 0x3FFFFFF0ull) return fail(KASA_E_LIMIT, "taxon-list pool exceeds 2^30 entries in one batch; split the batch");
-        c->poolCap = (uint64_t)used + used / 8 + 1024;
+        if (used <= c->poolCap) { c->poolUsed = (uint32_t)used; break; }
+        if (used >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the taxon lists of this batch need %llu pool entries (limit 2^32); split the batch", used);
+        c->poolCap = used + used / 8 + 1024;
         if (attempt > 3) return fail(KASA_E_LIMIT, "taxon-list pool did not converge");
     }
-
     c->grouped = true;
     return KASA_OK;
+}
+
+template <int RW>
+static int launch_flush(kasa_ctx *c, const uint32_t *list, uint32_t nList, const uint64_t *flushOff, uint32_t *out)
+{
+    const uint32_t nTiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
+    const unsigned blocks = std::min<uint32_t>(nList, 256u * 32u);
+    if (c->ix->wide)
+        flush_positions_kernel<RW, key128><<<blocks, 256, 0, c->stream>>>(list, nList, flushOff, c->kmerOff.as<uint64_t>(), c->rec.as<uint32_t>(),
+            c->keys<key128>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out);
+    else
+        flush_positions_kernel<RW, uint64_t><<<blocks, 256, 0, c->stream>>>(list, nList, flushOff, c->kmerOff.as<uint64_t>(), c->rec.as<uint32_t>(),
+            c->keys<uint64_t>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out);
+    HIPCHK(hipGetLastError());
+    return KASA_OK;
+}
+
+__global__ void list_counts_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ kmerOff, uint64_t *__restrict__ cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nList) { const uint32_t r = list[i]; cnt[i] = kmerOff[r + 1] - kmerOff[r]; }
+    if (i == nList) cnt[i] = 0;
 }
 
 static int score_stage(kasa_ctx *c, int wantPerRead)
 {
     if (c->state < 3 || !c->grouped) return fail(KASA_E_STATE, "kasa_batch_score: no event records (call kasa_batch_group or kasa_batch_records_import)");
+    if (c->recSorted) return fail(KASA_E_STATE, "kasa_batch_score: the records of this batch were exported in sorted order; import them on the read owner");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint64_t nQ = c->nQ;
     const uint32_t nReads = (uint32_t)c->nReads;
     const uint32_t nTaxa = c->ix->nTaxa;
     const int nK = c->nK;
+    const int RW = c->recWords();
     int rc;
     c->haveScores = false; c->nnz = 0;
     if (nQ == 0 || nReads == 0) {
@@ -2419,84 +2447,87 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         c->state = 4;
         return KASA_OK;
     }
-    uint32_t *counters = c->misc.as<uint32_t>(); // [0] pool cursor, [1] staging cursor, [2] error flags
+    uint32_t *counters = c->misc.as<uint32_t>(); // [2] error flags, [3] fallback count, [5] second-pass count, [8..15] reasons; u64 [16] pool cursor, [17] staging cursor
+    unsigned long long *stCursor = c->misc.as<unsigned long long>() + 17;
     hipEvent_t a, b;
 
-    // ---- regroup: sorted positions by read, stable (so each read sees its queries in sorted order)
-    if ((rc = c->plist.reserve(nQ * 4 + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
-    if ((rc = timer_begin(c, c->timers[KASA_STAGE_REGROUP], &a, &b))) return rc;
-    {
-        unsigned bits = 1;
-        while ((1ull << bits) < (uint64_t)nReads) ++bits;
-        rocprim::counting_iterator<uint32_t> iota(0);
-        size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
-                                         (size_t)nQ, 0u, bits, c->stream));
-        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qRead, c->qReadA.as<uint32_t>(), iota, c->plist.as<uint32_t>(),
-                                         (size_t)nQ, 0u, bits, c->stream));
-    }
-    if ((rc = timer_end(c, c->timers[KASA_STAGE_REGROUP], a, b))) return rc;
-
-    // ---- score
     if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
         (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)) || (rc = c->fbList.reserve((size_t)nReads * 4 + 64)))
         return rc;
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
-    const bool fast = nK <= 25 && !c->forceSlowScore;
+    const bool fast = nK <= 25 && nTaxa <= (1u << 20) && !c->forceSlowScore;   // staging records keep the taxon in 20 bits
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
     c->lastOverflowReads = 0;
-    uint32_t staged = 0;
+    uint64_t staged = 0;
     ScoreArgs A;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 4) return fail(KASA_E_LIMIT, "score staging did not converge");
+        if (c->stCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the score rows of this batch need %llu staging records (limit 2^32); split the batch", (unsigned long long)c->stCap);
         if ((rc = c->st.reserve(c->stCap * 8))) return rc;
-        HIPCHK(hipMemsetAsync(counters + 1, 0, 12, c->stream)); // staging cursor, error flags, fallback count
+        HIPCHK(hipMemsetAsync(counters + 2, 0, 8, c->stream));  // error flags, fallback count
         HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
+        HIPCHK(hipMemsetAsync(stCursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
-        A.plist = c->plist.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.rec = c->rec.as<uint2>();
+        A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.fastScratch = nullptr;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.st = c->st.as<uint2>();
-        A.stCap = (uint32_t)std::min<uint64_t>(c->stCap, 0xFFFFFFF0ull); A.stCursor = counters + 1; A.errFlag = counters + 2;
+        A.stCap = (uint32_t)c->stCap; A.stCursor = stCursor; A.errFlag = counters + 2;
         A.wantPerRead = wantPerRead ? 1 : 0;
         A.addProfile = slowProfileDone ? 0 : 1;
-        A.list = nullptr; A.nList = 0;
+        A.list = nullptr; A.nList = 0; A.flushPos = nullptr; A.flushOff = nullptr;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
         A.ovList = nullptr; A.ovCount = nullptr;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
-        uint32_t h[3] = {0, 0, 0};
         if (fast) {
             const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 32u);
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
+            if ((rc = timer_begin(c, c->scoreKernel, &c->skA, &c->skB))) return rc;
             if (wantPerRead) {
-                if (nK <= 6) score_fast_kernel<6, true><<<fblocks, 64, 0, c->stream>>>(A);
-                else if (nK <= 12) score_fast_kernel<12, true><<<fblocks, 64, 0, c->stream>>>(A);
-                else if (nK <= 19) score_fast_kernel<19, true><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast_kernel<25, true><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) score_fast_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A);
             } else {
-                if (nK <= 6) score_fast_kernel<6, false><<<fblocks, 64, 0, c->stream>>>(A);
-                else if (nK <= 12) score_fast_kernel<12, false><<<fblocks, 64, 0, c->stream>>>(A);
-                else if (nK <= 19) score_fast_kernel<19, false><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast_kernel<25, false><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) score_fast_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A);
             }
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(h, counters + 1, 12, hipMemcpyDeviceToHost, c->stream));
+            if ((rc = timer_end(c, c->scoreKernel, c->skA, c->skB))) return rc;
+            c->scoreQueries += nQ;
+            uint32_t h3 = 0; unsigned long long want = 0;
+            HIPCHK(hipMemcpyAsync(&h3, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&want, stCursor, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            nSlow = h[2];
-            if ((uint64_t)h[0] > c->stCap) {          // the fast kernel has no side effects: grow and rerun
+            nSlow = h3;
+            if (want > c->stCap) {                    // the fast kernel has no side effects: grow and rerun
                 if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
-                c->stCap = (uint64_t)h[0] + h[0] / 8 + (uint64_t)nSlow * 64 + 1024;
+                c->stCap = want + want / 8 + (uint64_t)nSlow * 64 + 1024;
                 continue;
             }
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         if (nSlow > 0) {
+            // flush positions of the listed reads' queries (the records hold only the order inside a query)
+            const uint64_t *flushOff = c->kmerOff.as<uint64_t>();
+            uint64_t nFq = nQ;
+            if (A.list) {
+                if ((rc = c->flushOff.reserve(((size_t)nSlow + 1) * 8 + 64))) return rc;
+                list_counts_kernel<<<blocks_for((uint64_t)nSlow + 1, 256), 256, 0, c->stream>>>(A.list, nSlow, c->kmerOff.as<uint64_t>(), c->flushOff.as<uint64_t>());
+                size_t tmpBytes = 0;
+                HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->flushOff.as<uint64_t>(), c->flushOff.as<uint64_t>(), (uint64_t)0, (size_t)nSlow + 1, rocprim::plus<uint64_t>(), c->stream));
+                if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+                HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, c->flushOff.as<uint64_t>(), c->flushOff.as<uint64_t>(), (uint64_t)0, (size_t)nSlow + 1, rocprim::plus<uint64_t>(), c->stream));
+                HIPCHK(hipMemcpyAsync(&nFq, c->flushOff.as<uint64_t>() + nSlow, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                flushOff = c->flushOff.as<uint64_t>();
+            }
+            if ((rc = c->flushPos.reserve(nFq * (size_t)nK * 4 + 64))) return rc;
+            if ((rc = (RW == 8 ? launch_flush<8>(c, A.list, nSlow, flushOff, c->flushPos.as<uint32_t>()) : launch_flush<16>(c, A.list, nSlow, flushOff, c->flushPos.as<uint32_t>())))) return rc;
+            A.flushPos = c->flushPos.as<uint32_t>(); A.flushOff = flushOff;
             const uint64_t rowBytes = (uint64_t)nTaxa * 4;
             const uint32_t maxBlocks = (uint32_t)std::max<uint64_t>(1024, std::min<uint64_t>(256u * 32u, (8ull << 30) / rowBytes));
             const uint32_t blocks = std::min<uint32_t>(nSlow, maxBlocks);
@@ -2505,15 +2536,34 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             HIPCHK(hipMemsetAsync(counters + 5, 0, 4, c->stream));
             A.scratch = c->scratch.as<float>();
             A.ovList = c->ovList.as<uint32_t>(); A.ovCount = counters + 5;
-            score_kernel<PCAP_SMALL><<<blocks, 64, 0, c->stream>>>(A);      // leaves every score row zeroed again
+            if (RW == 8) score_kernel<PCAP_SMALL, 8><<<blocks, 64, 0, c->stream>>>(A);      // leaves every score row zeroed again
+            else score_kernel<PCAP_SMALL, 16><<<blocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             uint32_t nOver = 0;
             HIPCHK(hipMemcpyAsync(&nOver, counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             if (nOver > 0) {
-                A.list = c->ovList.as<uint32_t>(); A.nList = nOver;
+                // second pass: the same reads' flush positions are addressed through the first list, so the second pass
+                // walks that list again and skips what the first pass finished (rowLen / ovList membership is not kept):
+                // simpler -- recompute offsets for the overflow list
+                const uint32_t *ov = c->ovList.as<uint32_t>();
+                if ((rc = c->flushOff2.reserve(((size_t)nOver + 1) * 8 + 64))) return rc;
+                list_counts_kernel<<<blocks_for((uint64_t)nOver + 1, 256), 256, 0, c->stream>>>(ov, nOver, c->kmerOff.as<uint64_t>(), c->flushOff2.as<uint64_t>());
+                size_t tmpBytes = 0;
+                HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)nOver + 1, rocprim::plus<uint64_t>(), c->stream));
+                if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+                HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)nOver + 1, rocprim::plus<uint64_t>(), c->stream));
+                uint64_t nFq2 = 0;
+                HIPCHK(hipMemcpyAsync(&nFq2, c->flushOff2.as<uint64_t>() + nOver, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if ((rc = c->flushPos2.reserve(nFq2 * (size_t)nK * 4 + 64))) return rc;
+                if ((rc = (RW == 8 ? launch_flush<8>(c, ov, nOver, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>()) : launch_flush<16>(c, ov, nOver, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>())))) return rc;
+                A.list = ov; A.nList = nOver;
+                A.flushPos = c->flushPos2.as<uint32_t>(); A.flushOff = c->flushOff2.as<uint64_t>();
                 A.ovList = nullptr; A.ovCount = nullptr;
-                score_kernel<PCAP><<<std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u)), 64, 0, c->stream>>>(A);
+                const uint32_t b2 = std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u));
+                if (RW == 8) score_kernel<PCAP, 8><<<b2, 64, 0, c->stream>>>(A);
+                else score_kernel<PCAP, 16><<<b2, 64, 0, c->stream>>>(A);
                 HIPCHK(hipGetLastError());
             }
             c->lastOverflowReads = std::max(c->lastOverflowReads, nOver);   // over the staging retries of this batch
@@ -2521,17 +2571,19 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         }
         c->lastSlowReads = nSlow;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
-        HIPCHK(hipMemcpyAsync(h, counters + 1, 8, hipMemcpyDeviceToHost, c->stream));
+        uint32_t err = 0; unsigned long long want = 0;
+        HIPCHK(hipMemcpyAsync(&err, counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&want, stCursor, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (h[1] & 2u) return fail(KASA_E_LIMIT, "a read keeps more than %d distinct groups pending; this build cannot order it", PCAP);
-        if ((uint64_t)h[0] <= c->stCap) { staged = h[0]; break; }
-        c->stCap = (uint64_t)h[0] + h[0] / 8 + 1024;
+        if (err & 2u) return fail(KASA_E_LIMIT, "a read keeps more than %d distinct groups pending; this build cannot order it", PCAP);
+        if (want <= c->stCap) { staged = want; break; }
+        c->stCap = want + want / 8 + 1024;
     }
     // ---- resolve the fast kernel's records: per-read merge, then the profile contributions by sort + reduce
     if (fast && staged > 0) {
         const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
-        if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;
+        if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;   // staged < 2^32
         HIPCHK(hipMemsetAsync(c->profKeys.p, 0xFF, (size_t)staged * 8, c->stream));
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
@@ -2551,7 +2603,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
         HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
         profile_reduce_kernel<<<std::min<unsigned>(blocks_for(staged, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
-            c->profSorted.as<uint64_t>(), staged, nTaxa,
+            c->profSorted.as<uint64_t>(), (uint32_t)staged, nTaxa,
             c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
@@ -2588,7 +2640,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_lookup_score: batch not sorted");
-    int rc = group_stage(c, coverage);
+    int rc = group_stage(c, coverage, false);
     if (rc) return rc;
     return score_stage(c, wantPerRead);
 }
@@ -2596,7 +2648,7 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
 extern "C" int kasa_batch_group(kasa_ctx *c, int coverage)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    return group_stage(c, coverage);
+    return group_stage(c, coverage, true);
 }
 
 extern "C" int kasa_batch_score(kasa_ctx *c, int wantPerRead)
@@ -2605,23 +2657,23 @@ extern "C" int kasa_batch_score(kasa_ctx *c, int wantPerRead)
     return score_stage(c, wantPerRead);
 }
 
-extern "C" int kasa_batch_records_size(kasa_ctx *c, uint64_t *nRecords, uint64_t *nPoolWords)
+extern "C" int kasa_batch_records_size(kasa_ctx *c, uint64_t *nRecordWords, uint64_t *nPoolWords)
 {
-    if (!c || !nRecords || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_size: NULL argument");
-    if (!c->grouped) return fail(KASA_E_STATE, "kasa_batch_records_size: no event records");
-    *nRecords = c->nQ * (uint64_t)c->nK;
+    if (!c || !nRecordWords || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_size: NULL argument");
+    if (!c->grouped || !c->recSorted) return fail(KASA_E_STATE, "kasa_batch_records_size: no exported event records (call kasa_batch_group)");
+    *nRecordWords = c->nQ * (uint64_t)c->recWords();
     *nPoolWords = c->poolUsed;
     return KASA_OK;
 }
 
-extern "C" int kasa_batch_records_fetch(kasa_ctx *c, uint64_t *records, uint32_t *pool)
+extern "C" int kasa_batch_records_fetch(kasa_ctx *c, uint32_t *records, uint32_t *pool)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    if (!c->grouped) return fail(KASA_E_STATE, "kasa_batch_records_fetch: no event records");
+    if (!c->grouped || !c->recSorted) return fail(KASA_E_STATE, "kasa_batch_records_fetch: no exported event records (call kasa_batch_group)");
     HIPCHK(hipSetDevice(c->ix->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const uint64_t n = c->nQ * (uint64_t)c->nK;
-    if (n && records) HIPCHK(hipMemcpy(records, c->rec.p, n * 8, hipMemcpyDeviceToHost));
+    const uint64_t n = c->nQ * (uint64_t)c->recWords();
+    if (n && records) HIPCHK(hipMemcpy(records, c->rec.p, n * 4, hipMemcpyDeviceToHost));
     if (pool && c->poolUsed) {
         if (c->nQ) HIPCHK(hipMemcpy(pool, c->pool.p, (size_t)c->poolUsed * 4, hipMemcpyDeviceToHost));
         pool[0] = 0;                                                   // word 0 is the cursor's start: never referenced
@@ -2629,21 +2681,68 @@ extern "C" int kasa_batch_records_fetch(kasa_ctx *c, uint64_t *records, uint32_t
     return KASA_OK;
 }
 
-extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint64_t *records, uint64_t nRecords, const uint32_t *pool, uint64_t nPoolWords)
+// records in sorted order -> their slots; the depth of every sorted position comes with them (the importing context
+// did not look these queries up itself)
+template <int RW>
+__global__ void place_records_kernel(const uint4 *__restrict__ in, const uint32_t *__restrict__ slotOf, uint32_t n, uint4 *__restrict__ rec,
+                                     uint8_t *__restrict__ depth)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t s = slotOf[p];
+    depth[p] = (uint8_t)(in[(size_t)p * (RW / 4)].z & 31u);
+#pragma unroll
+    for (int w = 0; w < RW / 4; ++w) rec[(size_t)s * (RW / 4) + w] = in[(size_t)p * (RW / 4) + w];
+}
+
+// first closing position of every tile and level from the sorted queries and their depths (what the lookup kernels
+// emit on the way; needed again when the depths were imported)
+template <class Key>
+__global__ __launch_bounds__(TILE_THREADS) void tile_first_kernel(const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, uint32_t nQ,
+                                                                  int kHigh, int kLow, uint32_t *__restrict__ tileFirst, uint32_t nTiles)
+{
+    __shared__ uint32_t sFirst[MAX_LEVELS];
+    const int nK = kHigh - kLow + 1;
+    const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
+    if (threadIdx.x < MAX_LEVELS) sFirst[threadIdx.x] = NOPOS;
+    __syncthreads();
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t p = blockIdx.x * TILE + it * TILE_THREADS + threadIdx.x;
+        if (p >= nQ) continue;
+        const int ql = (p == 0) ? 0 : lcp_letters<Key>(qKmer[p - 1], qKmer[p]);
+        const uint32_t m = special_mask(ql, (int)depth[p], kHigh, allLv);
+        for (int lv = 0; lv < nK; ++lv) if ((m >> lv) & 1u) atomicMin(&sFirst[lv], p);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
+}
+
+extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint32_t *records, uint64_t nRecordWords, const uint32_t *pool, uint64_t nPoolWords)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_records_import: batch not sorted");
-    if (nRecords != c->nQ * (uint64_t)c->nK) return fail(KASA_E_ARG, "kasa_batch_records_import: %llu records for %llu queries x %d levels", (unsigned long long)nRecords, (unsigned long long)c->nQ, c->nK);
-    if ((nRecords && !records) || (nPoolWords && !pool) || nPoolWords >= 0x3FFFFFF0ull) return fail(KASA_E_ARG, "kasa_batch_records_import: bad arguments");
+    const int RW = c->recWords();
+    if (nRecordWords != c->nQ * (uint64_t)RW) return fail(KASA_E_ARG, "kasa_batch_records_import: %llu record words for %llu queries x %d words", (unsigned long long)nRecordWords, (unsigned long long)c->nQ, RW);
+    if ((nRecordWords && !records) || (nPoolWords && !pool) || nPoolWords >= 0xFFFFFFF0ull) return fail(KASA_E_ARG, "kasa_batch_records_import: bad arguments");
     HIPCHK(hipSetDevice(c->ix->device));
     int rc;
-    if ((rc = c->rec.reserve(nRecords * 8 + 64)) || (rc = c->pool.reserve((nPoolWords + 1) * 4))) return rc;
+    if (c->nQ && !c->slotOf && (rc = slots_from_reads(c))) return rc;
+    if ((rc = c->rec.reserve(nRecordWords * 4 + 64)) || (rc = c->recIn.reserve(nRecordWords * 4 + 64)) || (rc = c->pool.reserve((nPoolWords + 1) * 4))) return rc;
     c->poolCap = std::max<uint64_t>(c->poolCap, nPoolWords + 1);
-    if (nRecords) HIPCHK(hipMemcpyAsync(c->rec.p, records, nRecords * 8, hipMemcpyHostToDevice, c->stream));
+    if (nRecordWords) {
+        HIPCHK(hipMemcpyAsync(c->recIn.p, records, nRecordWords * 4, hipMemcpyHostToDevice, c->stream));
+        if (RW == 8) place_records_kernel<8><<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(c->recIn.as<uint4>(), c->slotOf, (uint32_t)c->nQ, c->rec.as<uint4>(), c->depth.as<uint8_t>());
+        else place_records_kernel<16><<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(c->recIn.as<uint4>(), c->slotOf, (uint32_t)c->nQ, c->rec.as<uint4>(), c->depth.as<uint8_t>());
+        const uint32_t nTiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
+        if (c->ix->wide) tile_first_kernel<key128><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->kHigh, c->kLow, c->tileFirst.as<uint32_t>(), nTiles);
+        else tile_first_kernel<uint64_t><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->kHigh, c->kLow, c->tileFirst.as<uint32_t>(), nTiles);
+        tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)c->nQ);
+        HIPCHK(hipGetLastError());
+    }
     if (nPoolWords) HIPCHK(hipMemcpyAsync(c->pool.p, pool, nPoolWords * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->poolUsed = (uint32_t)std::max<uint64_t>(1, nPoolWords);
-    c->grouped = true; c->haveScores = false;
+    c->grouped = true; c->recSorted = false; c->haveScores = false;
     return KASA_OK;
 }
 
@@ -2765,6 +2864,18 @@ extern "C" int kasa_ctx_lookup_kernel_ms(kasa_ctx *c, double *ms, uint64_t *laun
     return KASA_OK;
 }
 
+extern "C" int kasa_ctx_score_kernel_ms(kasa_ctx *c, double *ms, uint64_t *launches, uint64_t *queries)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = timer_resolve(c->scoreKernel);
+    if (rc) return rc;
+    if (ms) *ms = c->scoreKernel.ms;
+    if (launches) *launches = c->scoreKernel.launches;
+    if (queries) *queries = c->scoreQueries;
+    return KASA_OK;
+}
+
 extern "C" int kasa_ctx_stage_reset(kasa_ctx *c)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
@@ -2772,6 +2883,8 @@ extern "C" int kasa_ctx_stage_reset(kasa_ctx *c)
     for (auto &t : c->timers) { int rc = timer_resolve(t); if (rc) return rc; t.ms = 0; t.launches = 0; }
     int rc = timer_resolve(c->lookupKernel); if (rc) return rc;
     c->lookupKernel.ms = 0; c->lookupKernel.launches = 0; c->lookupQueries = 0;
+    rc = timer_resolve(c->scoreKernel); if (rc) return rc;
+    c->scoreKernel.ms = 0; c->scoreKernel.launches = 0; c->scoreQueries = 0;
     return KASA_OK;
 }
 
@@ -2801,7 +2914,7 @@ extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false;
     std::vector<uint64_t> koff((size_t)nReads + 1, 0);
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -2842,7 +2955,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
@@ -2878,11 +2991,11 @@ extern "C" int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *tot
 }
 
 // Device bytes one query (k-mer of a read) costs while its batch is in flight: both sort buffers, depth + index
-// position, the nK event records, the positions by read, and a share for pool, staging rows and the CSR.
+// position, its event record, slot + position list (slot fix-up), and a share for pool, staging rows and the CSR.
 extern "C" uint64_t kasa_batch_bytes_per_query(const kasa_ctx *c)
 {
     if (!c) return 0;
-    return 2 * (c->keyBytes() + 4) + 5 + 8ull * (uint64_t)c->nK + 4 + 40;
+    return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)c->recWords() + 8 + 40;
 }
 
 extern "C" int kasa_ctx_counters(kasa_ctx *c, uint32_t *generalReads, uint32_t *secondPassReads)

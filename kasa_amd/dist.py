@@ -85,8 +85,7 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
         pool_out.append(pool)
     rec_back = all_to_all_arrays(rec_out)
     pool_back = all_to_all_arrays(pool_out)
-    nk = ctx.nK
-    parts = [(rec_back[j].reshape(-1, nk, 2), pool_back[j]) for j in range(world)]
+    parts = [(rec_back[j].reshape(-1, ctx.rec_words), pool_back[j]) for j in range(world)]
     rec, pool = partition.assemble_records(parts, starts)
     ctx.records_import(rec, pool)
     ctx.score(want_per_read)

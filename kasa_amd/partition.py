@@ -8,8 +8,8 @@ The sorted index is cut at 30-bit prefix boundaries -- a prefix range of the ref
               cut the sorted queries at the same prefixes: slice j is contiguous
     worker j: group slice j against partition j                       (kasa_batch_set_queries/sort_and_range/group,
                                                                         kasa_batch_records_fetch)
-    owner   : concatenate the event records in partition order (= global sorted order), shift flush
-              positions by the slice start and list references by the pool offset, score
+    owner   : concatenate the event records in partition order (= global sorted order), shift positions
+              by the slice start and segment-list offsets by the pool offset, file them by read, score
                                                                         (kasa_batch_records_import/score)
 
 A slice is a batch of its own for the worker: its first query opens a new prefix range, so nothing of
@@ -24,7 +24,9 @@ import numpy as np
 
 from . import capi, formats
 
-REF_INLINE = np.uint32(0xC0000000)   # REF_SINGLE | REF_PAIR: the reference holds the taxa itself
+def _inline_segments(rec_words: int):
+    """(segments a record holds itself, word of the first segment / of the pool offset) -- include/kasa_hip.h"""
+    return (4, 4) if rec_words == 8 else (8, 8)
 
 
 def split_index(ix: formats.Index, n_parts: int):
@@ -55,19 +57,21 @@ def slice_starts(km_sorted: np.ndarray, cuts: np.ndarray, K: int) -> np.ndarray:
 
 
 def assemble_records(parts, starts):
-    """parts[j] = (rec u32[n_j, nK, 2], pool u32[m_j]) of slice j -> one (rec, pool) for the whole batch."""
+    """parts[j] = (rec u32[n_j, W], pool u32[m_j]) of slice j -> one (rec, pool) for the whole batch, sorted order."""
     recs, pools, base = [], [np.zeros(1, dtype=np.uint32)], 1
     for j, (rec, pool) in enumerate(parts):
         rec = rec.copy()
-        rec[:, :, 0] += np.uint32(starts[j])                       # flush positions: slice-local -> batch
-        ref = rec[:, :, 1]
-        lists = (ref != 0) & ((ref & REF_INLINE) == 0)              # offsets into the slice's pool (word 0 unused)
-        ref[lists] += np.uint32(base - 1)
+        inl, seg0 = _inline_segments(rec.shape[1])
+        matched = (rec[:, 2] & np.uint32(31)) != 0
+        rec[:, 0] += np.uint32(starts[j])                           # sorted position: slice-local -> batch
+        rec[matched, 1] += np.uint32(starts[j])                     # last flush position
+        lists = matched & (rec[:, 3] > np.uint32(inl))              # segments live in the slice's pool (word 0 unused)
+        rec[lists, seg0] += np.uint32(base - 1)
         recs.append(rec)
         pools.append(pool[1:])
         base += pool.shape[0] - 1
-    nk = parts[0][0].shape[1] if parts else 1
-    rec_all = np.concatenate(recs) if recs else np.zeros((0, nk, 2), dtype=np.uint32)
+    w = parts[0][0].shape[1] if parts else 8
+    rec_all = np.concatenate(recs) if recs else np.zeros((0, w), dtype=np.uint32)
     return rec_all, np.concatenate(pools)
 
 
