@@ -1242,21 +1242,44 @@ static constexpr int GTHREADS = TILE / GITEMS;    // 512
 //   [0] p      sorted position of the query
 //   [1] Fmax   the last flush position of its groups (all of them are closed once the stream reaches it)
 //   [2] d | order << 5    d = deepest matched k (0: no match, nothing else is valid); order (RW = 8) = the levels
-//                         lv = kHigh - k of its events in flush order (F ascending, k ascending), 3 bits each
-//   [3] nseg   number of taxon segments
-//   RW = 8 : [4..7]  up to 4 segments, or [4] = pool offset of all of them when nseg > 4
-//   RW = 16: [4..7]  order, 5 bits per event (a 128-bit value, first event in the low bits);  [8..15] up to 8 segments,
-//            or [8] = pool offset
+//                         lv = kHigh - k of its events in flush order (F ascending, k ascending), 3 bits each;
+//                         bit 29 (RW = 8): REC_SPLIT
+//   [3] nseg   number of taxon segments (RW = 8: low byte, 255 = "255 or more"; the upper 24 bits hold |T_k| of the
+//                 levels lv = 0..7, 3 bits each, 7 = "7 or more")
+//   RW = 8 : [4..7]  the segments when there are at most 4; else 3 segments and [7] = pool offset of the others
+//   RW = 16: [4..7]  order, 5 bits per event (a 128-bit value, first event in the low bits);  [8..15] the segments when
+//            there are at most 8; else 7 segments and [15] = pool offset of the others
+//   pool block: {nseg, segments INL-1 ...}.  Segments come in descending order of their last level: the taxa the
+//   query really matches first, chance matches of its short prefixes last.
 // A segment is one index entry of the query's kLow-group seen from the query: taxon | kFirst << 22 | kLast << 27 -- the
 // entry puts its taxon into the taxon set T_k of the levels kFirst..kLast (kLast = letters it shares with the query,
 // capped at d; kFirst - 1 = letters it shares with the nearest earlier entry of the same taxon, which represents the
 // taxon up to there).  |T_k| = number of segments covering k.  This replaces the reference's per-level sBitArray sets
 // (Compare.hpp:917-955, BitArray.hpp:98-117) for all levels of a query at once.
 static constexpr uint32_t SEG_TAX_MASK = (1u << 22) - 1u;
+static constexpr uint32_t REC_SPLIT = 1u << 29;   // RW = 8, word [2]: some segment starts above kLow, i.e. a taxon may own several segments
 template <int RW> struct RecTraits;
 template <> struct RecTraits<8> { static constexpr int LEVELS = 8, INL = 4, SEG0 = 4, OBITS = 3; };
 template <> struct RecTraits<16> { static constexpr int LEVELS = 25, INL = 8, SEG0 = 8, OBITS = 5; };
 __device__ __forceinline__ bool seg_covers(uint32_t s, uint32_t k) { return ((s >> 22) & 31u) <= k && k <= (s >> 27); }
+// levels of a segment as a mask over lv = kHigh - k
+__device__ __forceinline__ uint32_t seg_level_mask(uint32_t s, int kHigh)
+{
+    const int lvLo = kHigh - (int)(s >> 27), lvHi = kHigh - (int)((s >> 22) & 31u);      // kLast -> lowest lv
+    return ((2u << lvHi) - 1u) & ~((1u << lvLo) - 1u);
+}
+// record readers (w = the record's words)
+template <int RW> __device__ __forceinline__ uint32_t rec_nseg(const uint32_t *w, const uint32_t *__restrict__ pool)
+{
+    if constexpr (RW == 8) { const uint32_t n = w[3] & 255u; return n == 255u ? pool[w[7]] : n; }
+    else return w[3];
+}
+template <int RW> __device__ __forceinline__ uint32_t rec_seg(const uint32_t *w, const uint32_t *__restrict__ pool, uint32_t nseg, uint32_t i)
+{
+    typedef RecTraits<RW> RT;
+    if (nseg <= (uint32_t)RT::INL || i < (uint32_t)RT::INL - 1u) return w[RT::SEG0 + i];
+    return pool[w[RT::SEG0 + RT::INL - 1] + 1u + i - ((uint32_t)RT::INL - 1u)];
+}
 
 // levels (bit lv = kHigh - k) at which sorted position p closes the groups before it: a new prefix range closes all of
 // them, otherwise p opens a new matched group at the levels ql < k <= d (ql = letters shared with its predecessor)
@@ -1285,7 +1308,8 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 
 // The taxon segments of one query: walk the index outwards from `j` (an entry sharing the query's deepest matched
 // prefix) as long as the entries share the kLow-group's letters with the query.  Letters entry i shares with the query
-// = min(d, letters shared by all neighbours between i and j) -- `meta` holds the neighbour counts.  Calls emit(seg).
+// = min(d, letters shared by all neighbours between i and j) -- `meta` holds the neighbour counts.  Both directions are
+// merged so that the segments come in descending order of their last level.  Calls emit(seg).
 template <class Meta, class Emit>
 __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, const Meta *__restrict__ meta,
                                               const uint32_t *__restrict__ tax, uint32_t nIdx, Emit emit)
@@ -1301,23 +1325,23 @@ __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, const
     one(j, d, mj);
     // j shares at least max(d, 6) letters with the query (a match needs the 6-letter range; '^' may cut d below that)
     const int chain0 = d > RANGE_LETTERS ? d : RANGE_LETTERS;
-    int chain = chain0;
-    uint32_t m = mj;
-    for (uint32_t i = j; i > 0;) {                               // to the left: entry i-1 shares (meta[i] & LM) letters with i
-        const int l = (int)(m & LM);
-        if (l < chain) chain = l;
-        if (chain < gLow) break;
-        --i;
-        m = meta[i];
-        one(i, chain < d ? chain : d, m);
-    }
-    chain = chain0;
-    for (uint32_t i = j + 1; i < nIdx; ++i) {
-        m = meta[i];
-        const int l = (int)(m & LM);
-        if (l < chain) chain = l;
-        if (chain < gLow) break;
-        one(i, chain < d ? chain : d, m);
+    uint32_t li = j, ri = j + 1;                                  // next to the left: li - 1; next to the right: ri
+    uint32_t mli = mj;                                            // meta[li]: letters li shares with li - 1
+    uint32_t mri = ri < nIdx ? (uint32_t)meta[ri] : 0u;           // meta[ri]: letters ri shares with ri - 1
+    int lc = li > 0 ? ((int)(mli & LM) < chain0 ? (int)(mli & LM) : chain0) : -1;   // letters the next left entry shares with the query
+    int rc = ri < nIdx ? ((int)(mri & LM) < chain0 ? (int)(mri & LM) : chain0) : -1;
+    while (lc >= gLow || rc >= gLow) {
+        if (lc >= rc) {
+            --li;
+            mli = meta[li];
+            one(li, lc < d ? lc : d, mli);
+            const int l = (int)(mli & LM);
+            lc = li > 0 ? (l < lc ? l : lc) : -1;
+        } else {
+            one(ri, rc < d ? rc : d, mri);
+            ++ri;
+            if (ri < nIdx) { mri = meta[ri]; const int l = (int)(mri & LM); rc = l < rc ? l : rc; } else rc = -1;
+        }
     }
 }
 
@@ -1397,12 +1421,12 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         }
     }
     // ---- 2. + 3. per query: order of its events, taxon segments
-    uint32_t w2[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
+    uint32_t w2[GITEMS], w3[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
     unsigned __int128 ord[GITEMS];
     uint32_t need = 0;
 #pragma unroll
     for (int i = 0; i < GITEMS; ++i) {
-        w2[i] = 0; fmax[i] = 0; nseg[i] = 0;
+        w2[i] = 0; w3[i] = 0; fmax[i] = 0; nseg[i] = 0;
 #pragma unroll
         for (int s = 0; s < INL; ++s) seg[i][s] = 0;
         ord[i] = 0;
@@ -1422,14 +1446,21 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         }
         fmax[i] = fm;
         w2[i] = (uint32_t)d[i] | (RW == 8 ? ((uint32_t)ord[i] << 5) : 0u);
-        uint32_t n = 0;
+        uint32_t n = 0, nlev = 0;                                 // nlev: |T_k| per level, 3 bits each, saturating at 7 (RW = 8)
+        bool split = false;                                       // a taxon may own several segments (an entry continues an earlier one of its taxon)
         walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
 #pragma unroll
             for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
             ++n;
+            if ((int)((s >> 22) & 31u) > kLow) split = true;
+            if constexpr (RW == 8)
+                for (int lv = kHigh - (int)(s >> 27); lv <= kHigh - (int)((s >> 22) & 31u); ++lv)
+                    if (((nlev >> (3 * lv)) & 7u) < 7u) nlev += 1u << (3 * lv);
         });
         nseg[i] = n;
-        if (n > (uint32_t)INL) need += n;
+        w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
+        if (RW == 8 && split) w2[i] |= REC_SPLIT;
+        if (n > (uint32_t)INL) need += n - (uint32_t)(INL - 1) + 1u;   // pool block: {nseg, segments INL-1 ...}
         if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
             const Key q = qKmer[base + i];
             const int ql = (base + i == 0) ? 0 : lcp_letters<Key>(qKmer[base + i - 1], q);
@@ -1452,13 +1483,13 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
 #pragma unroll
         for (int i = 0; i < GITEMS; ++i)
             if (nseg[i] > (uint32_t)INL) {
-                if (!fits) { seg[i][0] = 0; }                        // overflow: the host grows the pool and reruns
-                else {
-                    uint32_t w = off;
-                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) { pool[w++] = s; });
-                    seg[i][0] = off;
+                if (fits) {                                          // (else: the host grows the pool and reruns)
+                    pool[off] = nseg[i];
+                    uint32_t w = off + 1, idx = 0;
+                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) { if (idx >= (uint32_t)(INL - 1)) pool[w++] = s; ++idx; });
                 }
-                off += nseg[i];
+                seg[i][INL - 1] = off;
+                off += nseg[i] - (uint32_t)(INL - 1) + 1u;
             }
     }
     // ---- 4. the record
@@ -1469,10 +1500,10 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         const uint32_t slot = slotOf ? slotOf[p] : p;
         uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * RW);
         if constexpr (RW == 8) {
-            o[0] = make_uint4(p, fmax[i], w2[i], nseg[i]);
+            o[0] = make_uint4(p, fmax[i], w2[i], w3[i]);
             o[1] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
         } else {
-            o[0] = make_uint4(p, fmax[i], w2[i], nseg[i]);
+            o[0] = make_uint4(p, fmax[i], w2[i], w3[i]);
             o[1] = make_uint4((uint32_t)ord[i], (uint32_t)(ord[i] >> 32), (uint32_t)(ord[i] >> 64), (uint32_t)(ord[i] >> 96));
             o[2] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
             o[3] = make_uint4(seg[i][4], seg[i][5], seg[i][6], seg[i][7]);
@@ -1558,6 +1589,7 @@ struct ScoreArgs {
     uint32_t *ovList, *ovCount;                  // general kernel, first pass: reads it hands to the second pass (NULL = last pass)
     uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
+    uint32_t *workCursor;                        // fast kernel: next read a wavefront takes
 };
 
 // c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
@@ -1698,17 +1730,17 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         // |T| = the segments covering k; every taxon is handled by the lane that owns its cell.
         auto applyVals = [&](const int k, const uint32_t slot, const uint32_t c) {
             const uint32_t *w = A.rec + (size_t)slot * RW;
-            const uint32_t nseg = w[3];
-            const uint32_t *seg = nseg > (uint32_t)RT::INL ? A.pool + w[RT::SEG0] : w + RT::SEG0;
+            const uint32_t nseg = rec_nseg<RW>(w, A.pool);
             uint32_t n = 0;
             for (uint32_t b0 = 0; b0 < nseg; b0 += 64) {
-                const uint32_t s = (b0 + lane < nseg) ? seg[b0 + lane] : 0u;
-                n += (uint32_t)__popcll(__ballot(b0 + lane < nseg && seg_covers(s, (uint32_t)k)));
+                const bool in = b0 + lane < nseg;
+                const uint32_t s = in ? rec_seg<RW>(w, A.pool, nseg, b0 + lane) : 0u;
+                n += (uint32_t)__popcll(__ballot(in && seg_covers(s, (uint32_t)k)));
             }
             const float sc = event_score(k, n);
             const int lv = A.kHigh - k;
             for (uint32_t i = 0; i < nseg; ++i) {
-                const uint32_t s = seg[i];
+                const uint32_t s = rec_seg<RW>(w, A.pool, nseg, i);
                 if (!seg_covers(s, (uint32_t)k)) continue;
                 const uint32_t tx = s & SEG_TAX_MASK;
                 if ((tx & 63u) != (uint32_t)lane) continue;                  // a cell always lives on one lane
@@ -1874,180 +1906,332 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // against a 4e8-record index) is appended to a per-lane log as an 8-byte record and resolved later, per read,
 // by row_merge_kernel.  The kernel performs no atomics on the profile tables: everything it finds leaves as
 // records, so it can be rerun.
+//
+// What one lane does rarely the wavefront does almost always (64 reads), so the per-query work is kept free of
+// per-event branches: a query's segments are classified once (register taxon 0 / 1 / other), the register taxa get a
+// level mask each, |T_k| comes out of the record, and the event loop is two selects and two LDS adds per event; the
+// other taxa's contributions are logged segment by segment, outside that loop (only the order among one taxon's
+// contributions matters).
 // ------------------------------------------------------------------------------------------------
-// RW = record width.  With up to 8 levels a (taxon, level) counter holds four 16-bit fields (|T| = 1..4); with more
-// levels two (|T| = 1, 2), to keep the LDS footprint of a wavefront small -- larger sets leave as profile records
-// through the log.  PERREAD = false (no -q: profile only): the order of a read's events does not matter for the
-// profile, so the float chain and the order rule are left out; what remains is counting hits per (level, |T|, taxon).
-template <int RW, bool PERREAD>
-__global__ __launch_bounds__(64) void score_fast_kernel(ScoreArgs A)
+struct FastLane {                                       // per-read state of a lane
+    int na, nl;
+    uint32_t mTax0, mTax1;
+    float mS0, mS1;
+    bool fb;
+};
+
+// A taxon gets a register slot: if shallow matches already started its chain in the log, replay them first.
+template <bool PERREAD>
+__device__ __forceinline__ void fast_promote(FastLane &L, uint32_t t, uint2 *lg, const EventTables &evT, int kHigh)
 {
-    typedef RecTraits<RW> RT;
-    constexpr int NKF = RT::LEVELS, INL = RT::INL;
-    typedef typename std::conditional<RW == 8, unsigned long long, uint32_t>::type Counter;
-    constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
-    __shared__ Counter cnt64[FTA][NKF][64];                          // 16-bit hit counters per (taxon, level, |T|)
+    float v0 = 0.0f;
+    for (int q = 0; PERREAD && q < L.nl; ++q) {
+        uint2 e2 = lg[q];
+        if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
+        const float s2 = event_score(evT, kHigh - (int)rk_level(e2.x), e2.y >> 16);
+        for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
+        e2.x |= RK_CONSUMED;
+        lg[q] = e2;
+    }
+    if (L.na == 0) { L.mTax0 = t; L.mS0 = v0; } else { L.mTax1 = t; L.mS1 = v0; }
+    ++L.na;
+}
+
+__device__ __forceinline__ void fast_log(FastLane &L, uint2 *lg, uint32_t t, int lv, uint32_t n, uint32_t kind, uint32_t *why)
+{
+    if (L.nl == FLOG) { if (!L.fb) atomicAdd(&why[2], 1u); L.fb = true; return; }
+    lg[L.nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | 1u);
+    ++L.nl;
+}
+
+// The end of a read in both fast kernels: its staging row = final scores of the register taxa, their counters as
+// profile records, the log; reads that do not fit go to the general kernel's list.
+template <bool PERREAD, class Counter>
+__device__ __forceinline__ void fast_finish(const ScoreArgs &A, FastLane &L, bool active, uint32_t r, int nK, int lane,
+                                            Counter (*cnt)[64], int cntStride, const uint2 *lg)
+{
+    uint32_t nprof = 0;
+    if (active && !L.fb)
+        for (int e = 0; e < L.na; ++e)
+            for (int lv = 0; lv < nK; ++lv) {
+                const unsigned long long pk = cnt[e * cntStride + lv][lane];
+                nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
+            }
+    if (active && !L.fb && (PERREAD ? (uint32_t)L.na : 0u) + nprof + (uint32_t)L.nl > (uint32_t)RMAX) { L.fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
+    const uint32_t nFinal = PERREAD ? (uint32_t)L.na : 0u;
+    const uint32_t m = (active && !L.fb) ? nFinal + nprof + (uint32_t)L.nl : 0u;
+    uint32_t incl = m;
+    for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = __shfl(incl, 63);
+    unsigned long long start = 0;
+    if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
+    start = __shfl(start, 0);
+    const bool fits = start + total <= (unsigned long long)A.stCap;
+    start += incl - m;
+    if (active && !L.fb) {
+        A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? (m | (m ? ROW_MERGE : 0u)) : 0u;
+        if (fits) {
+            uint32_t w = (uint32_t)start;
+            if (PERREAD && L.na > 0) A.st[w++] = make_uint2(L.mTax0 | RK_FINAL, __float_as_uint(L.mS0));
+            if (PERREAD && L.na > 1) A.st[w++] = make_uint2(L.mTax1 | RK_FINAL, __float_as_uint(L.mS1));
+            for (int e = 0; e < L.na; ++e) {
+                const uint32_t t = (e == 0) ? L.mTax0 : L.mTax1;
+                for (int lv = 0; lv < nK; ++lv) {
+                    const unsigned long long pk = cnt[e * cntStride + lv][lane];
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
+                        if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
+                    }
+                }
+            }
+            for (int i = 0; i < L.nl; ++i) A.st[w + i] = lg[i];
+        }
+    }
+    const unsigned long long fbMask = __ballot(active && L.fb);
+    if (fbMask) {
+        uint32_t fbBase = 0;
+        if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
+        fbBase = __shfl(fbBase, 0);
+        if (active && L.fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
+    }
+}
+
+// Up to 8 levels (32-byte records).  PERREAD = false (no -q: profile only): the order of a read's events does not
+// matter for the profile, so the float chain and the order rule are left out.
+template <bool PERREAD>
+__global__ __launch_bounds__(64) void score_fast8_kernel(ScoreArgs A)
+{
+    typedef RecTraits<8> RT;
+    __shared__ unsigned long long cnt64[FTA * 8][64];                // four 16-bit hit counters (|T| = 1..4) per (taxon, level)
+    __shared__ float sTab[8][8];                                     // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
-    const uint32_t stride = gridDim.x * 64u;
+    {
+        const int lv = lane >> 3, n = lane & 7, k = A.kHigh - lv;
+        sTab[lv][n] = (n > 0 && k >= 1) ? event_score(k, (uint32_t)n) : 0.0f;
+    }
+    __syncthreads();
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
-    // per-block scratch; every lane owns a CONTIGUOUS log (records are appended one by one, so consecutive
-    // 8-byte stores of a lane fill whole sectors)
     uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
-    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;
-    for (uint32_t base = blockIdx.x * 64u; base < A.nReads; base += stride) {
+    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;   // every lane owns a contiguous log
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.workCursor, 64u);          // persistent wavefronts take 64 reads at a time
+        base = __shfl(base, 0);
+        if (base >= A.nReads) break;
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
-        bool fb = false;
-        int na = 0, nl = 0;
-        uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu;
-        float mS0 = 0.0f, mS1 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < FTA; ++e)
-            for (int l2 = 0; l2 < nK; ++l2) cnt64[e][l2][lane] = 0;
+        FastLane L{0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0.0f, false};
+        for (int l2 = 0; l2 < FTA * 8; ++l2) cnt64[l2][lane] = 0;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
             const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
-            if (cnt > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
-
-            // one (event, taxon) contribution: level lv, |T| = n, score s of one hit
-            auto contribute = [&](uint32_t t, int lv, uint32_t n, float s) {
-                int e = -1;
-                if (t == mTax0) e = 0;
-                else if (t == mTax1) e = 1;
-                else if (na < FTA && A.kHigh - lv >= kPromote) {
-                    // a deep match: this taxon is (almost surely) where the read comes from -- give it a register
-                    // slot.  If shallow matches already started its chain in the log, replay them first.
-                    float v0 = 0.0f;
-                    for (int q = 0; PERREAD && q < nl; ++q) {
-                        uint2 e2 = lg[q];
-                        if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
-                        const float s2 = event_score(evT, A.kHigh - (int)rk_level(e2.x), e2.y >> 16);
-                        for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
-                        e2.x |= RK_CONSUMED;
-                        lg[q] = e2;
-                    }
-                    e = na;
-                    if (na == 0) { mTax0 = t; mS0 = v0; } else { mTax1 = t; mS1 = v0; }
-                    ++na;
-                }
-                uint32_t kind = 0xFFFFFFFFu;                               // record to log, if any
-                if (e >= 0) {
-                    if (PERREAD) { if (e == 0) mS0 = __fadd_rn(mS0, s); else mS1 = __fadd_rn(mS1, s); }   // Compare.hpp:528-530
-                    if (n <= CNT_FIELDS) cnt64[e][lv][lane] += (Counter)1 << (16 * (n - 1));
-                    else kind = RK_PROFILE;
-                } else kind = PERREAD ? 0u : RK_PROFILE;
-                if (kind != 0xFFFFFFFFu) {
-                    if (nl == FLOG) { fb = true; atomicAdd(&A.why[2], 1u); return; }
-                    lg[nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | 1u);
-                    ++nl;
-                }
-            };
-
+            if (cnt > 60000u) { L.fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
             uint32_t prevF = 0;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
-            for (uint32_t j = 0; j < cnt && !fb; ++j, rp += RW / 4) {
-                const uint4 h = rp[0];                                       // p, Fmax, d | order, nseg
+            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * 2;
+            uint4 h = make_uint4(0, 0, 0, 0), b = h;
+            if (cnt && !L.fb) { h = rp[0]; b = rp[1]; }
+            for (uint32_t j = 0; j < cnt && !L.fb; ++j) {
+                const uint4 hc = h, bc = b;
+                rp += 2;
+                if (j + 1 < cnt) { h = rp[0]; b = rp[1]; }                      // the next record is on its way while this one is replayed
+                const int d = (int)(hc.z & 31u);
+                if (d == 0) continue;
+                if (PERREAD) {
+                    if (prevF > hc.x) { L.fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
+                    prevF = hc.y;
+                }
+                const uint32_t nseg = hc.w & 255u, nlev = hc.w >> 8;
+                if (nseg == 255u) { L.fb = true; atomicAdd(&A.why[3], 1u); break; }
+                const uint32_t order0 = (hc.z >> 5) & 0xFFFFFFu;
+                const bool split = (hc.z & REC_SPLIT) != 0u;
+                const int nEv = d - A.kLow + 1;
+                const uint32_t sg[4] = {bc.x, bc.y, bc.z, bc.w};
+                const uint32_t nInl = nseg <= 4u ? nseg : 3u;
+                const uint32_t *more = A.pool + bc.w + 1u;                       // segments 3.. when nseg > 4
+                const uint32_t nMore = nseg <= 4u ? 0u : nseg - 3u;
+                // |T| of a level: from the record, or counted when the record says "7 or more"
+                auto setSize = [&](int lv) -> uint32_t {
+                    uint32_t n = (nlev >> (3 * lv)) & 7u;
+                    if (n == 7u) {
+                        const uint32_t k = (uint32_t)(A.kHigh - lv);
+                        n = 0;
+                        for (uint32_t q = 0; q < nInl; ++q) n += seg_covers(sg[q], k) ? 1u : 0u;
+                        for (uint32_t q = 0; q < nMore; ++q) n += seg_covers(more[q], k) ? 1u : 0u;
+                    }
+                    return n;
+                };
+                // 1. taxa with a deep match get a register slot before any event of this query is replayed
+                if (L.na < FTA) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t t = sg[q] & SEG_TAX_MASK;
+                        if ((uint32_t)q < nInl && (int)(sg[q] >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1 && L.na < FTA)
+                            fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
+                    }
+                    for (uint32_t q = 0; q < nMore && L.na < FTA; ++q) {
+                        const uint32_t sq = more[q], t = sq & SEG_TAX_MASK;
+                        if ((int)(sq >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1) fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
+                    }
+                }
+                // 2. classify: level masks of the register taxa; the other taxa's contributions go to the log, segment by segment
+                uint32_t mask0 = 0, mask1 = 0;
+                auto other = [&](uint32_t sq, uint32_t m) {
+                    const uint32_t t = sq & SEG_TAX_MASK;
+                    const uint32_t kind = PERREAD ? 0u : RK_PROFILE;
+                    if (PERREAD && split) return;                               // several segments may share a taxon: logged in event order below
+                    if ((m & (m - 1u)) == 0u) {                                 // one level (a chance match of the shortest prefix, usually)
+                        const int lv = __ffs((int)m) - 1;
+                        fast_log(L, lg, t, lv, setSize(lv), kind, A.why);
+                    } else {
+                        uint32_t o = order0;
+                        for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
+                            const int lv = (int)(o & 7u);
+                            if ((m >> lv) & 1u) fast_log(L, lg, t, lv, setSize(lv), kind, A.why);
+                        }
+                    }
+                };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if ((uint32_t)q >= nInl) continue;
+                    const uint32_t t = sg[q] & SEG_TAX_MASK, m = seg_level_mask(sg[q], A.kHigh);
+                    if (t == L.mTax0) mask0 |= m;
+                    else if (t == L.mTax1) mask1 |= m;
+                    else other(sg[q], m);
+                }
+                for (uint32_t q = 0; q < nMore; ++q) {
+                    const uint32_t sq = more[q], t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+                    if (t == L.mTax0) mask0 |= m;
+                    else if (t == L.mTax1) mask1 |= m;
+                    else other(sq, m);
+                }
+                if (PERREAD && split) {                                         // the rare query whose taxa may own several segments
+                    uint32_t o = order0;
+                    for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
+                        const int lv = (int)(o & 7u);
+                        const uint32_t k = (uint32_t)(A.kHigh - lv);
+                        for (uint32_t q = 0; q < nInl + nMore; ++q) {
+                            const uint32_t sq = q < nInl ? (q == 0 ? sg[0] : q == 1 ? sg[1] : q == 2 ? sg[2] : sg[3]) : more[q - nInl];
+                            const uint32_t t = sq & SEG_TAX_MASK;
+                            if (t != L.mTax0 && t != L.mTax1 && seg_covers(sq, k)) fast_log(L, lg, t, lv, setSize(lv), 0u, A.why);
+                        }
+                    }
+                }
+                // 3. the events of the register taxa, in flush order
+                if (mask0 | mask1) {
+                    uint32_t o = order0;
+                    for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
+                        const int lv = (int)(o & 7u);
+                        const uint32_t in0 = (mask0 >> lv) & 1u, in1 = (mask1 >> lv) & 1u;
+                        const uint32_t n = setSize(lv);
+                        const float s = n < 8u ? sTab[lv][n] : event_score(evT, A.kHigh - lv, n);
+                        if (PERREAD) {                                           // Compare.hpp:528-530; + 0.0f leaves a score as it is
+                            L.mS0 = __fadd_rn(L.mS0, in0 ? s : 0.0f);
+                            L.mS1 = __fadd_rn(L.mS1, in1 ? s : 0.0f);
+                        }
+                        if (n <= 4u) {
+                            const unsigned long long one = 1ull << (16 * (n - 1u));
+                            cnt64[lv][lane] += in0 ? one : 0ull;
+                            cnt64[8 + lv][lane] += in1 ? one : 0ull;
+                        } else {
+                            if (in0) fast_log(L, lg, L.mTax0, lv, n, RK_PROFILE, A.why);
+                            if (in1) fast_log(L, lg, L.mTax1, lv, n, RK_PROFILE, A.why);
+                        }
+                    }
+                }
+            }
+        }
+        fast_finish<PERREAD, unsigned long long>(A, L, active, r, nK, lane, cnt64, 8, lg);
+    }
+}
+
+// Up to 25 levels (64-byte records): the same replay written with loops over levels and segments.  A (taxon, level)
+// counter holds two 16-bit fields (|T| = 1, 2) to keep the LDS footprint of a wavefront small; larger sets leave as
+// profile records through the log.
+template <bool PERREAD>
+__global__ __launch_bounds__(64) void score_fast16_kernel(ScoreArgs A)
+{
+    typedef RecTraits<16> RT;
+    constexpr int NKF = RT::LEVELS, INL = RT::INL;
+    __shared__ uint32_t cnt32[FTA * NKF][64];
+    __shared__ EventTables evT;
+    event_tables_init(evT);
+    const int lane = threadIdx.x;
+    const int nK = A.kHigh - A.kLow + 1;
+    const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;
+    uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
+    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(A.workCursor, 64u);
+        base = __shfl(base, 0);
+        if (base >= A.nReads) break;
+        const uint32_t r = base + lane;
+        const bool active = r < A.nReads;
+        FastLane L{0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0.0f, false};
+        for (int l2 = 0; l2 < FTA * NKF; ++l2) cnt32[l2][lane] = 0;
+        if (active) {
+            const uint64_t o0 = A.kmerOff[r];
+            const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
+            if (cnt > 60000u) { L.fb = true; atomicAdd(&A.why[0], 1u); }
+            uint32_t prevF = 0;
+            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * 4;
+            for (uint32_t j = 0; j < cnt && !L.fb; ++j, rp += 4) {
+                const uint4 h = rp[0];
                 const int d = (int)(h.z & 31u);
                 if (d == 0) continue;
                 if (PERREAD) {
-                    if (prevF > h.x) { fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
+                    if (prevF > h.x) { L.fb = true; atomicAdd(&A.why[4], 1u); break; }
                     prevF = h.y;
                 }
                 const uint32_t nseg = h.w;
-                if (nseg >= (1u << 13)) { fb = true; atomicAdd(&A.why[3], 1u); break; }
+                if (nseg >= (1u << 13)) { L.fb = true; atomicAdd(&A.why[3], 1u); break; }
                 const int nEv = d - A.kLow + 1;
-                uint32_t sg[INL];
-                unsigned __int128 order;
-                if constexpr (RW == 8) {
-                    const uint4 b = rp[1];
-                    sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w;
-                    order = h.z >> 5;
-                } else {
-                    const uint4 o4 = rp[1], b = rp[2], c4 = rp[3];
-                    order = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
-                    sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w; sg[4] = c4.x; sg[5] = c4.y; sg[6] = c4.z; sg[7] = c4.w;
-                }
-                if (nseg <= (uint32_t)INL) {
-                    for (int ev = 0; ev < nEv && !fb; ++ev) {
-                        const int lv = (int)((uint32_t)order & ((1u << RT::OBITS) - 1u));
-                        order >>= RT::OBITS;
-                        const uint32_t k = (uint32_t)(A.kHigh - lv);
-                        uint32_t n = 0;
+                const uint4 o4 = rp[1], s0 = rp[2], s1 = rp[3];
+                const unsigned __int128 order0 = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
+                const uint32_t sg[INL] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                const uint32_t nInl = nseg <= (uint32_t)INL ? nseg : (uint32_t)INL - 1u;
+                const uint32_t *more = A.pool + s1.w + 1u;
+                const uint32_t nMore = nseg <= (uint32_t)INL ? 0u : nseg - ((uint32_t)INL - 1u);
+                auto segAt = [&](uint32_t q) -> uint32_t {
+                    if (q >= nInl) return more[q - nInl];
+                    uint32_t v = sg[0];
 #pragma unroll
-                        for (int q = 0; q < INL; ++q) n += ((uint32_t)q < nseg && seg_covers(sg[q], k)) ? 1u : 0u;
-                        const float s = event_score(evT, (int)k, n);
-#pragma unroll
-                        for (int q = 0; q < INL; ++q)
-                            if ((uint32_t)q < nseg && seg_covers(sg[q], k) && !fb) contribute(sg[q] & SEG_TAX_MASK, lv, n, s);
+                    for (int i = 1; i < INL; ++i) v = (q == (uint32_t)i) ? sg[i] : v;
+                    return v;
+                };
+                if (L.na < FTA)
+                    for (uint32_t q = 0; q < nseg && L.na < FTA; ++q) {
+                        const uint32_t sq = segAt(q), t = sq & SEG_TAX_MASK;
+                        if ((int)(sq >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1) fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
                     }
-                } else {
-                    const uint32_t *seg = A.pool + sg[0];
-                    for (int ev = 0; ev < nEv && !fb; ++ev) {
-                        const int lv = (int)((uint32_t)order & ((1u << RT::OBITS) - 1u));
-                        order >>= RT::OBITS;
-                        const uint32_t k = (uint32_t)(A.kHigh - lv);
-                        uint32_t n = 0;
-                        for (uint32_t q = 0; q < nseg; ++q) n += seg_covers(seg[q], k) ? 1u : 0u;
-                        const float s = event_score(evT, (int)k, n);
-                        for (uint32_t q = 0; q < nseg && !fb; ++q) {
-                            const uint32_t sq = seg[q];
-                            if (seg_covers(sq, k)) contribute(sq & SEG_TAX_MASK, lv, n, s);
-                        }
+                unsigned __int128 o = order0;
+                for (int ev = 0; ev < nEv && !L.fb; ++ev, o >>= 5) {
+                    const int lv = (int)((uint32_t)o & 31u);
+                    const uint32_t k = (uint32_t)(A.kHigh - lv);
+                    uint32_t n = 0;
+                    for (uint32_t q = 0; q < nseg; ++q) n += seg_covers(segAt(q), k) ? 1u : 0u;
+                    const float s = event_score(evT, (int)k, n);
+                    for (uint32_t q = 0; q < nseg; ++q) {
+                        const uint32_t sq = segAt(q);
+                        if (!seg_covers(sq, k)) continue;
+                        const uint32_t t = sq & SEG_TAX_MASK;
+                        const int e = t == L.mTax0 ? 0 : (t == L.mTax1 ? 1 : -1);
+                        if (e >= 0) {
+                            if (PERREAD) { if (e == 0) L.mS0 = __fadd_rn(L.mS0, s); else L.mS1 = __fadd_rn(L.mS1, s); }
+                            if (n <= 2u) cnt32[e * NKF + lv][lane] += 1u << (16 * (n - 1u));
+                            else fast_log(L, lg, t, lv, n, RK_PROFILE, A.why);
+                        } else fast_log(L, lg, t, lv, n, PERREAD ? 0u : RK_PROFILE, A.why);
                     }
                 }
             }
         }
-        // ---- the read's staging row: final scores of the register taxa, their counters as profile records, the log
-        uint32_t nprof = 0;
-        if (active && !fb)
-            for (int e = 0; e < na; ++e)
-                for (int lv = 0; lv < nK; ++lv) {
-                    const unsigned long long pk = cnt64[e][lv][lane];
-                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
-                }
-        if (active && !fb && (PERREAD ? (uint32_t)na : 0u) + nprof + (uint32_t)nl > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
-        const uint32_t nFinal = PERREAD ? (uint32_t)na : 0u;
-        const uint32_t m = (active && !fb) ? nFinal + nprof + (uint32_t)nl : 0u;
-        uint32_t incl = m;
-        for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
-            const uint32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        const uint32_t total = __shfl(incl, 63);
-        unsigned long long start = 0;
-        if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
-        start = __shfl(start, 0);
-        const bool fits = start + total <= (unsigned long long)A.stCap;
-        start += incl - m;
-        if (active && !fb) {
-            A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? (m | (m ? ROW_MERGE : 0u)) : 0u;
-            if (fits) {
-                uint32_t w = (uint32_t)start;
-                if (PERREAD && na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
-                if (PERREAD && na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
-                for (int e = 0; e < na; ++e) {
-                    const uint32_t t = (e == 0) ? mTax0 : mTax1;
-                    for (int lv = 0; lv < nK; ++lv) {
-                        const unsigned long long pk = cnt64[e][lv][lane];
-                        for (uint32_t q = 0; q < 4; ++q) {
-                            const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
-                            if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
-                        }
-                    }
-                }
-                for (int i = 0; i < nl; ++i) A.st[w + i] = lg[i];
-            }
-        }
-        const unsigned long long fbMask = __ballot(active && fb);
-        if (fbMask) {
-            uint32_t fbBase = 0;
-            if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
-            fbBase = __shfl(fbBase, 0);
-            if (active && fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
-        }
+        fast_finish<PERREAD, uint32_t>(A, L, active, r, nK, lane, cnt32, NKF, lg);
     }
 }
 
@@ -2479,21 +2663,29 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         A.addProfile = slowProfileDone ? 0 : 1;
         A.list = nullptr; A.nList = 0; A.flushPos = nullptr; A.flushOff = nullptr;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
-        A.ovList = nullptr; A.ovCount = nullptr;
+        A.ovList = nullptr; A.ovCount = nullptr; A.workCursor = nullptr;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
         if (fast) {
-            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, 256u * 32u);
+            // persistent wavefronts: as many as are resident at once, each takes 64 reads at a time from a work counter
+            int perCu = 0, nCu = 0;
+            const void *kern = RW == 8 ? (wantPerRead ? (const void *)score_fast8_kernel<true> : (const void *)score_fast8_kernel<false>)
+                                       : (wantPerRead ? (const void *)score_fast16_kernel<true> : (const void *)score_fast16_kernel<false>);
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, 64, 0));
+            HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
+            const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, (uint32_t)std::max(1, perCu) * (uint32_t)std::max(1, nCu));
             const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
             if ((rc = c->fastScratch.reserve(words * 4))) return rc;
             A.fastScratch = c->fastScratch.as<uint32_t>();
+            A.workCursor = counters + 6;
+            HIPCHK(hipMemsetAsync(counters + 6, 0, 4, c->stream));
             if ((rc = timer_begin(c, c->scoreKernel, &c->skA, &c->skB))) return rc;
             if (wantPerRead) {
-                if (RW == 8) score_fast_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) score_fast8_kernel<true><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast16_kernel<true><<<fblocks, 64, 0, c->stream>>>(A);
             } else {
-                if (RW == 8) score_fast_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) score_fast8_kernel<false><<<fblocks, 64, 0, c->stream>>>(A);
+                else score_fast16_kernel<false><<<fblocks, 64, 0, c->stream>>>(A);
             }
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->scoreKernel, c->skA, c->skB))) return rc;

@@ -24,11 +24,6 @@ import numpy as np
 
 from . import capi, formats
 
-def _inline_segments(rec_words: int):
-    """(segments a record holds itself, word of the first segment / of the pool offset) -- include/kasa_hip.h"""
-    return (4, 4) if rec_words == 8 else (8, 8)
-
-
 def split_index(ix: formats.Index, n_parts: int):
     """-> (list of formats.Index, cuts u64[n_parts]): partition j holds the entries whose 30-bit prefix p
     satisfies cuts[j] <= p < cuts[j+1]; about equal record counts, cut only between `_trie` entries."""
@@ -57,16 +52,19 @@ def slice_starts(km_sorted: np.ndarray, cuts: np.ndarray, K: int) -> np.ndarray:
 
 
 def assemble_records(parts, starts):
-    """parts[j] = (rec u32[n_j, W], pool u32[m_j]) of slice j -> one (rec, pool) for the whole batch, sorted order."""
+    """parts[j] = (rec u32[n_j, W], pool u32[m_j]) of slice j -> one (rec, pool) for the whole batch, sorted order.
+    Record layout: include/kasa_hip.h (kasa_batch_group)."""
     recs, pools, base = [], [np.zeros(1, dtype=np.uint32)], 1
     for j, (rec, pool) in enumerate(parts):
         rec = rec.copy()
-        inl, seg0 = _inline_segments(rec.shape[1])
+        w = rec.shape[1]
+        inl, last = (4, 7) if w == 8 else (8, 15)                  # segments a record holds itself; word of the pool offset
+        nseg = (rec[:, 3] & np.uint32(255)) if w == 8 else rec[:, 3]
         matched = (rec[:, 2] & np.uint32(31)) != 0
         rec[:, 0] += np.uint32(starts[j])                           # sorted position: slice-local -> batch
         rec[matched, 1] += np.uint32(starts[j])                     # last flush position
-        lists = matched & (rec[:, 3] > np.uint32(inl))              # segments live in the slice's pool (word 0 unused)
-        rec[lists, seg0] += np.uint32(base - 1)
+        lists = matched & (nseg > np.uint32(inl))                   # further segments live in the slice's pool (word 0 unused)
+        rec[lists, last] += np.uint32(base - 1)
         recs.append(rec)
         pools.append(pool[1:])
         base += pool.shape[0] - 1
