@@ -467,9 +467,9 @@ struct kasa_ctx {
     uint32_t lastOverflowReads = 0;
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted;           // per-block dense score rows; reads left to the slow kernel
     bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
-    DevBuf rowPos, rowLen, rowOff, st, outTax, outScore;
+    DevBuf rowPos, rowLen, rowKey, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
-    uint64_t poolCap = 0, stCap = 0, nnz = 0;
+    uint64_t poolCap = 0, stCap = 0, keyCap = 0, nnz = 0;
     void *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays; keys are u64 or key128 as the index
     size_t keyBytes() const { return ix->wide ? 16 : 8; }
     int K() const { return ix->letters(); }
@@ -588,7 +588,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
@@ -710,18 +710,25 @@ extern "C" int kasa_batch_upload_segments(kasa_ctx *c, const uint8_t *bases, con
 // amino-acid input: ws 1, ls 1 and the letters are the input itself, Read.hpp:60-81).
 static constexpr int ENC_CHUNK = 512;                       // windows per chunk
 static constexpr int ENC_WAVES = 4;
+static constexpr int ENC_RANK_MAX = 512;                    // k-mers of a read the encoder ranks itself (payload = slot)
 
 template <class Key>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
     const uint32_t *__restrict__ seqRead, int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG,
-    Key *__restrict__ outKmer, uint32_t *__restrict__ outRead)
+    Key *__restrict__ outKmer, uint32_t *__restrict__ outRead, int rankSlots)
 {
     constexpr int KLETTERS = KeyTraits<Key>::LETTERS;
     constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;      // bases needed for one chunk (+ slack)
     __shared__ uint8_t sLut[384];
     __shared__ uint8_t sCode[ENC_WAVES][ENC_SPAN + 8];
     __shared__ uint8_t sLetter[ENC_WAVES][ENC_SPAN + 8];
+    // rankSlots: the payload of a k-mer is its SLOT -- the read's first slot (= its first k-mer's index) plus the rank of the
+    // k-mer among the read's k-mers (ties in window order, as the stable sort would leave them) -- so that after the sort
+    // every query knows its place in the read-major, sorted-within-read record array (group_kernel writes there).  All
+    // k-mers of a read (both strands) wait in LDS for that; the host enables it when every read has at most ENC_RANK_MAX.
+    __shared__ Key sKey[ENC_WAVES][ENC_RANK_MAX];
+    __shared__ uint32_t sTaken[ENC_WAVES][ENC_RANK_MAX];
     for (int i = threadIdx.x; i < 366; i += blockDim.x) sLut[i] = lutG[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -784,11 +791,55 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                     for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
-                    outRead[o] = rid;
+                    if (rankSlots) sKey[wv][s * (int)cnt + i] = v;         // (one chunk per strand: cnt <= ENC_RANK_MAX)
+                    else outRead[o] = rid;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+        if (rankSlots) {
+            // rank = k-mers of the read that are smaller; every lane holds up to ENC_RANK_MAX / 64 of them and compares them
+            // with each of the read's k-mers (one broadcast LDS read per k-mer).  Equal k-mers share that count: they are
+            // told apart by their index afterwards (rare: a read repeating one of its own k-mers).
+            const int n = strands * (int)cnt;
+            constexpr int PER = ENC_RANK_MAX / 64;
+            Key mine[PER];
+            uint32_t rank[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; mine[q] = i < n ? sKey[wv][i] : (Key)0; rank[q] = 0; if (i < n) sTaken[wv][i] = 0; }
+            const int groups = (n + 63) / 64;                        // items per lane that exist at all (uniform)
+            auto count = [&](auto G) {                               // the loop for G items per lane
+                for (int j = 0; j < n; ++j) {
+                    const Key kj = sKey[wv][j];
+#pragma unroll
+                    for (int q = 0; q < decltype(G)::value; ++q) rank[q] += (kj < mine[q]) ? 1u : 0u;
+                }
+            };
+            switch (groups) {
+            case 1: count(std::integral_constant<int, 1>()); break;
+            case 2: count(std::integral_constant<int, 2>()); break;
+            case 3: count(std::integral_constant<int, 3>()); break;
+            case 4: count(std::integral_constant<int, 4>()); break;
+            default: count(std::integral_constant<int, PER>()); break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; if (i < n) atomicAdd(&sTaken[wv][rank[q]], 1u); }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+                const int i = lane + 64 * q;
+                if (i >= n) continue;
+                uint32_t rk = rank[q];
+                if (sTaken[wv][rk] > 1u)                              // equal k-mers: window order decides, as in a stable sort
+                    for (int j = 0; j < i; ++j) rk += (sKey[wv][j] == mine[q]) ? 1u : 0u;
+                outRead[o0 + (uint64_t)i] = (uint32_t)(o0 + rk);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -803,16 +854,20 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     if ((rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64))) return rc;
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_ENCODE], &a, &b))) return rc;
+    // the encoder ranks a read's k-mers itself (payload of the sort = slot) when every read is one sequence with few enough
+    // k-mers; else the payload is the read id and the slots come from a stable sort by read (slots_from_reads)
+    const int rankSlots = (!c->haveSeqRead && c->maxCnt <= (uint32_t)ENC_RANK_MAX && !(c->debugFlags & 8)) ? 1 : 0;
+    c->payloadIsSlot = rankSlots != 0;
     if (c->nSeq > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide)
             encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>());
+                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
         else
             encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>());
+                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
         HIPCHK(hipGetLastError());
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_ENCODE], a, b))) return rc;
@@ -1160,6 +1215,7 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         if (unique) {                                                  // -e compares read ids: back from slots to reads
             slot_to_read_kernel<<<blocks_for(nQ, 256), 256, 0, c->stream>>>(c->qReadB.as<uint32_t>(), (uint32_t)nQ, c->kmerOff.as<uint64_t>(), (uint32_t)c->nReads, c->qReadA.as<uint32_t>());
             HIPCHK(hipMemcpyAsync(c->qReadB.p, c->qReadA.p, nQ * 4, hipMemcpyDeviceToDevice, c->stream));
+            c->payloadIsSlot = false;
         } else c->slotOf = c->qReadB.as<uint32_t>();                   // the payload of the sort IS the slot
     }
     if (unique && nQ > 1) {
@@ -1243,7 +1299,7 @@ static constexpr int GTHREADS = TILE / GITEMS;    // 512
 //   [1] Fmax   the last flush position of its groups (all of them are closed once the stream reaches it)
 //   [2] d | order << 5    d = deepest matched k (0: no match, nothing else is valid); order (RW = 8) = the levels
 //                         lv = kHigh - k of its events in flush order (F ascending, k ascending), 3 bits each;
-//                         bit 29 (RW = 8): REC_SPLIT
+//                         bits 29, 30 (RW = 8): REC_SPLIT, REC_SAT
 //   [3] nseg   number of taxon segments (RW = 8: low byte, 255 = "255 or more"; the upper 24 bits hold |T_k| of the
 //                 levels lv = 0..7, 3 bits each, 7 = "7 or more")
 //   RW = 8 : [4..7]  the segments when there are at most 4; else 3 segments and [7] = pool offset of the others
@@ -1258,6 +1314,7 @@ static constexpr int GTHREADS = TILE / GITEMS;    // 512
 // (Compare.hpp:917-955, BitArray.hpp:98-117) for all levels of a query at once.
 static constexpr uint32_t SEG_TAX_MASK = (1u << 22) - 1u;
 static constexpr uint32_t REC_SPLIT = 1u << 29;   // RW = 8, word [2]: some segment starts above kLow, i.e. a taxon may own several segments
+static constexpr uint32_t REC_SAT = 1u << 30;     // RW = 8, word [2]: some level has 7 or more taxa (its 3-bit count is saturated)
 template <int RW> struct RecTraits;
 template <> struct RecTraits<8> { static constexpr int LEVELS = 8, INL = 4, SEG0 = 4, OBITS = 3; };
 template <> struct RecTraits<16> { static constexpr int LEVELS = 25, INL = 8, SEG0 = 8, OBITS = 5; };
@@ -1460,6 +1517,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         nseg[i] = n;
         w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
         if (RW == 8 && split) w2[i] |= REC_SPLIT;
+        if (RW == 8 && (nlev & (nlev >> 1) & (nlev >> 2) & 0x249249u)) w2[i] |= REC_SAT;
         if (n > (uint32_t)INL) need += n - (uint32_t)(INL - 1) + 1u;   // pool block: {nseg, segments INL-1 ...}
         if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
             const Key q = qKmer[base + i];
@@ -1512,21 +1570,21 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
 }
 
 static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
-static constexpr int FLOG = 960;    // contributions to all other taxa, logged per read and resolved by row_merge_kernel
-static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel sorts (>= FTA + FTA * 6 * 4 + FLOG; the fast kernel hands longer rows to score_kernel)
+static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel handles; the fast kernels hand reads with longer rows to score_kernel
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
-static constexpr size_t FAST_SCRATCH_WORDS = (size_t)64 * (2 * FLOG); // u32 words per block: one log per lane
 
 // One wavefront working alone on LDS: LDS instructions of a wave execute in order, so only the compiler has
 // to be kept from moving them across the point (a workgroup barrier would also drain pending global stores).
 #define LDS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// A staging record (8 bytes).  x = taxon (20 bits) | level << 23 (5 bits) | consumed << 28 | kind << 30
-//   kind 0  event:        y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
-//                         `consumed`: its score already went into a register slot (profile still counts it).
-//   kind 1  final score:  y = float bits (a register-slot taxon)
-//   kind 2  profile only: y = |T| << 16 | hits
-static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_CONSUMED = 1u << 28;
+// A staging record (8 bytes).  x = taxon (20 bits) | ... | kind << 30
+//   kind 0  event:        x |= level << 23; y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
+//   kind 1  final score:  y = float bits (a register taxon)
+//   kind 2  profile only: as kind 0, but the score is already in a register taxon's final score
+//   kind 3  segment:      x |= kFirst << 20 | RK_SEG_DESC; y = kLast | sizes << 8.  All events of one taxon segment of one
+//                         query: the levels kFirst..kLast in ascending order of k (descending with RK_SEG_DESC), one hit
+//                         each, |T| of level lv = kHigh - k in bits 3 lv .. 3 lv + 2 of `sizes` (always below 7)
+static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_SEG = 3u << 30, RK_SEG_DESC = 1u << 29;
 static constexpr int RK_LV_SHIFT = 23;
 static constexpr uint32_t RK_LV_MASK = 31u;
 __device__ __forceinline__ uint32_t rk_level(uint32_t x) { return (x >> RK_LV_SHIFT) & RK_LV_MASK; }
@@ -1545,6 +1603,11 @@ static inline ProfLayout prof_layout(uint32_t nTaxa, int nK)
     L.lb = 1; while ((1u << L.lb) < (uint32_t)nK) ++L.lb;
     return L;
 }
+__device__ __forceinline__ uint64_t profile_key_of(uint32_t lv, uint32_t n, uint32_t tax, uint32_t hits, ProfLayout L)
+{
+    const uint64_t f = ((uint64_t)lv << (L.tb + L.nb)) | ((uint64_t)n << L.tb) | tax;
+    return (f << 16) | hits;
+}
 __device__ __forceinline__ uint64_t profile_key(uint2 e, ProfLayout L)
 {
     const uint64_t f = ((uint64_t)rk_level(e.x) << (L.tb + L.nb)) | ((uint64_t)(e.y >> 16) << L.tb) | (e.x & 0xFFFFFu);
@@ -1555,6 +1618,13 @@ __device__ __forceinline__ float event_score(int k, uint32_t n)
 {
     const float w = (float)(k * k) / 625.0f;                       // Compare.hpp:392
     return __fmul_rn(w, __fdiv_rn(1.0f, (float)n));                // Compare.hpp:924
+}
+
+// profile keys a staging record yields
+__device__ __forceinline__ uint32_t record_keys(uint2 e)
+{
+    const uint32_t kind = e.x >> 30;
+    return kind == 1u ? 0u : (kind == 3u ? (e.y & 31u) - ((e.x >> 20) & 31u) + 1u : 1u);
 }
 
 // The same two correctly rounded divisions, done once per workgroup: w_k for every k and 1/n for n < EV_INV.
@@ -1587,7 +1657,10 @@ struct ScoreArgs {
     const uint32_t *flushPos; const uint64_t *flushOff;   // general kernel: F per level of the listed reads' queries; first query of list entry wi
     uint32_t *fbList, *fbCount;                  // fast kernel: reads it hands to the general kernel
     uint32_t *ovList, *ovCount;                  // general kernel, first pass: reads it hands to the second pass (NULL = last pass)
-    uint32_t *fastScratch;                       // fast kernel: FAST_SCRATCH_WORDS u32 per block
+    uint32_t *mainOut;                           // fast kernels: {taxon 0, taxon 1, position, count} per read, main -> other
+    uint32_t *otherOff64;                        // fast kernels: records of the other taxa a read has yielded before slot 64 i
+    uint32_t *rowKey; uint32_t keyCap; unsigned long long *keyCursor;   // fast kernels: profile-key slots of a read's row (key buffer, its capacity, its cursor)
+    uint32_t nQ;
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
     uint32_t *workCursor;                        // fast kernel: next read a wavefront takes
 };
@@ -1895,130 +1968,108 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// score, fast path: one LANE per read.  The replay of a read's events is a sequential float chain per
-// (read, taxon), so 64 reads run side by side in a wavefront.  A read's records lie in its slots in sorted
-// order; the lane streams them front to back.  As long as every query's groups are closed before the read's
-// next matched query (Fmax <= next p: the overwhelmingly common case), the read's flush order is simply
-// query by query, each query's events in the order its record gives -- no pending list, no sorting.  A read
-// that breaks the rule (it repeats a k-mer prefix of its own) is handed to score_kernel untouched.
-// The (up to) two taxa a read really comes from -- those with a deep match -- live in registers with their
-// per-level hit counters in LDS; every other contribution (chance matches of short prefixes, ~150 per read
-// against a 4e8-record index) is appended to a per-lane log as an 8-byte record and resolved later, per read,
-// by row_merge_kernel.  The kernel performs no atomics on the profile tables: everything it finds leaves as
-// records, so it can be rerun.
+// score, fast path.  Two kernels over the same records:
 //
-// What one lane does rarely the wavefront does almost always (64 reads), so the per-query work is kept free of
-// per-event branches: a query's segments are classified once (register taxon 0 / 1 / other), the register taxa get a
-// level mask each, |T_k| comes out of the record, and the event loop is two selects and two LDS adds per event; the
-// other taxa's contributions are logged segment by segment, outside that loop (only the order among one taxon's
-// contributions matters).
+//   score_main_kernel   one LANE per read.  The replay of a read's events is a sequential float chain per (read,
+//       taxon), so 64 reads run side by side in a wavefront.  A read's records lie in its slots in sorted order; the
+//       lane streams them front to back.  As long as every query's groups are closed before the read's next matched
+//       query (Fmax <= next p: the overwhelmingly common case), the read's flush order is simply query by query, each
+//       query's events in the order its record gives -- no pending list, no sorting.  A read that breaks the rule (it
+//       repeats a k-mer prefix of its own) is handed to score_kernel untouched.  The lane first finds the (up to) two
+//       taxa the read really comes from -- the first ones with a deep match -- and then replays ONLY their chains:
+//       per query a level mask per taxon, |T_k| out of the record, two selects and two LDS adds per event.  What one
+//       lane does rarely the wavefront does almost always, so nothing else happens in that loop; the contributions to
+//       all other taxa (chance matches of short prefixes, ~150 per read against a 4e8-record index) are only counted.
+//   score_other_kernel  one WAVEFRONT per read, a lane per query (coalesced 32-byte records): every contribution to
+//       the other taxa becomes an 8-byte record in the read's staging row, in flush order (a prefix sum over the lanes'
+//       counts places them), where row_merge_kernel resolves them per taxon.
+//
+// Neither kernel touches the profile tables: everything leaves as records, so both can be rerun.
 // ------------------------------------------------------------------------------------------------
-struct FastLane {                                       // per-read state of a lane
-    int na, nl;
-    uint32_t mTax0, mTax1;
-    float mS0, mS1;
-    bool fb;
+// |T_k| of a level and the decoded record of one query, for both record widths
+template <int RW> struct QueryRec {
+    typedef RecTraits<RW> RT;
+    uint32_t p, fmax, nseg, nlev, split;
+    int d;
+    unsigned __int128 order;
+    uint32_t sg[RT::INL];
+    uint32_t nInl, nMore;
+    const uint32_t *more;
+    __device__ __forceinline__ void decode(const uint4 *rp, const uint32_t *__restrict__ pool)
+    {
+        uint4 v[RW / 4];
+#pragma unroll
+        for (int i = 0; i < RW / 4; ++i) v[i] = rp[i];
+        decode_regs(v, pool);
+    }
+    __device__ __forceinline__ void decode_regs(const uint4 (&v)[RW / 4], const uint32_t *__restrict__ pool)
+    {
+        const uint4 h = v[0];
+        p = h.x; fmax = h.y; d = (int)(h.z & 31u);
+        if constexpr (RW == 8) {
+            const uint4 b = v[1];
+            order = (h.z >> 5) & 0xFFFFFFu; split = h.z & REC_SPLIT;
+            nseg = h.w & 255u; nlev = h.w >> 8;
+            sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w;
+        } else {
+            const uint4 o4 = v[1], s0 = v[2], s1 = v[3];
+            order = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
+            split = 1u; nseg = h.w; nlev = 0;
+            sg[0] = s0.x; sg[1] = s0.y; sg[2] = s0.z; sg[3] = s0.w; sg[4] = s1.x; sg[5] = s1.y; sg[6] = s1.z; sg[7] = s1.w;
+        }
+        finish(pool);
+    }
+    __device__ __forceinline__ void finish(const uint32_t *__restrict__ pool)
+    {
+        nInl = nseg <= (uint32_t)RT::INL ? nseg : (uint32_t)RT::INL - 1u;
+        nMore = nseg <= (uint32_t)RT::INL ? 0u : nseg - ((uint32_t)RT::INL - 1u);
+        more = pool + sg[RT::INL - 1] + 1u;                            // valid when nMore > 0
+        if (RW == 8 && nseg == 255u) { nseg = pool[sg[RT::INL - 1]]; nMore = nseg - ((uint32_t)RT::INL - 1u); }
+    }
+    __device__ __forceinline__ uint32_t set_size(int lv, int kHigh) const
+    {
+        uint32_t n = RW == 8 ? ((nlev >> (3 * lv)) & 7u) : 7u;
+        if (n == 7u) {                                               // "7 or more" (or not recorded): count
+            const uint32_t k = (uint32_t)(kHigh - lv);
+            n = 0;
+#pragma unroll
+            for (int q = 0; q < RT::INL; ++q) n += ((uint32_t)q < nInl && seg_covers(sg[q], k)) ? 1u : 0u;
+            for (uint32_t q = 0; q < nMore; ++q) n += seg_covers(more[q], k) ? 1u : 0u;
+        }
+        return n;
+    }
 };
 
-// A taxon gets a register slot: if shallow matches already started its chain in the log, replay them first.
-template <bool PERREAD>
-__device__ __forceinline__ void fast_promote(FastLane &L, uint32_t t, uint2 *lg, const EventTables &evT, int kHigh)
+// per read, from score_main_kernel to score_other_kernel
+struct MainOut { uint32_t tax0, tax1, otherAt, nOther; };             // otherAt: staging position of the other taxa's records
+
+// Staging records one segment of another taxon yields (both fast kernels must agree): one segment record when it has at
+// most two levels and every |T| fits its 3 bits, else one event record per level.  Wide records (RW = 16) carry no sizes.
+template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t levelMask, bool saturated)
 {
-    float v0 = 0.0f;
-    for (int q = 0; PERREAD && q < L.nl; ++q) {
-        uint2 e2 = lg[q];
-        if ((e2.x & 0xC07FFFFFu) != t || (e2.x & RK_CONSUMED)) continue;   // kind 0, this taxon
-        const float s2 = event_score(evT, kHigh - (int)rk_level(e2.x), e2.y >> 16);
-        for (uint32_t j = 0; j < (e2.y & 0xFFFFu); ++j) v0 = __fadd_rn(v0, s2);
-        e2.x |= RK_CONSUMED;
-        lg[q] = e2;
-    }
-    if (L.na == 0) { L.mTax0 = t; L.mS0 = v0; } else { L.mTax1 = t; L.mS1 = v0; }
-    ++L.na;
+    const uint32_t pc = (uint32_t)__popc(levelMask);
+    return (RW == 8 && pc <= 2u && !saturated) ? (pc ? 1u : 0u) : pc;
 }
 
-__device__ __forceinline__ void fast_log(FastLane &L, uint2 *lg, uint32_t t, int lv, uint32_t n, uint32_t kind, uint32_t *why)
+template <int RW, bool PERREAD>
+__global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
 {
-    if (L.nl == FLOG) { if (!L.fb) atomicAdd(&why[2], 1u); L.fb = true; return; }
-    lg[L.nl] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (n << 16) | 1u);
-    ++L.nl;
-}
-
-// The end of a read in both fast kernels: its staging row = final scores of the register taxa, their counters as
-// profile records, the log; reads that do not fit go to the general kernel's list.
-template <bool PERREAD, class Counter>
-__device__ __forceinline__ void fast_finish(const ScoreArgs &A, FastLane &L, bool active, uint32_t r, int nK, int lane,
-                                            Counter (*cnt)[64], int cntStride, const uint2 *lg)
-{
-    uint32_t nprof = 0;
-    if (active && !L.fb)
-        for (int e = 0; e < L.na; ++e)
-            for (int lv = 0; lv < nK; ++lv) {
-                const unsigned long long pk = cnt[e * cntStride + lv][lane];
-                nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
-            }
-    if (active && !L.fb && (PERREAD ? (uint32_t)L.na : 0u) + nprof + (uint32_t)L.nl > (uint32_t)RMAX) { L.fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge sorts
-    const uint32_t nFinal = PERREAD ? (uint32_t)L.na : 0u;
-    const uint32_t m = (active && !L.fb) ? nFinal + nprof + (uint32_t)L.nl : 0u;
-    uint32_t incl = m;
-    for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
-    const uint32_t total = __shfl(incl, 63);
-    unsigned long long start = 0;
-    if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
-    start = __shfl(start, 0);
-    const bool fits = start + total <= (unsigned long long)A.stCap;
-    start += incl - m;
-    if (active && !L.fb) {
-        A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? (m | (m ? ROW_MERGE : 0u)) : 0u;
-        if (fits) {
-            uint32_t w = (uint32_t)start;
-            if (PERREAD && L.na > 0) A.st[w++] = make_uint2(L.mTax0 | RK_FINAL, __float_as_uint(L.mS0));
-            if (PERREAD && L.na > 1) A.st[w++] = make_uint2(L.mTax1 | RK_FINAL, __float_as_uint(L.mS1));
-            for (int e = 0; e < L.na; ++e) {
-                const uint32_t t = (e == 0) ? L.mTax0 : L.mTax1;
-                for (int lv = 0; lv < nK; ++lv) {
-                    const unsigned long long pk = cnt[e * cntStride + lv][lane];
-                    for (uint32_t q = 0; q < 4; ++q) {
-                        const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
-                        if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
-                    }
-                }
-            }
-            for (int i = 0; i < L.nl; ++i) A.st[w + i] = lg[i];
-        }
-    }
-    const unsigned long long fbMask = __ballot(active && L.fb);
-    if (fbMask) {
-        uint32_t fbBase = 0;
-        if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
-        fbBase = __shfl(fbBase, 0);
-        if (active && L.fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
-    }
-}
-
-// Up to 8 levels (32-byte records).  PERREAD = false (no -q: profile only): the order of a read's events does not
-// matter for the profile, so the float chain and the order rule are left out.
-template <bool PERREAD>
-__global__ __launch_bounds__(64) void score_fast8_kernel(ScoreArgs A)
-{
-    typedef RecTraits<8> RT;
-    __shared__ unsigned long long cnt64[FTA * 8][64];                // four 16-bit hit counters (|T| = 1..4) per (taxon, level)
-    __shared__ float sTab[8][8];                                     // score of one hit by (level, |T| < 8)
+    typedef RecTraits<RW> RT;
+    constexpr int NL = RT::LEVELS, OB = RT::OBITS;
+    typedef typename std::conditional<RW == 8, unsigned long long, uint32_t>::type Counter;   // 16-bit hit counters per |T|: 4 (2) fields
+    constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
+    __shared__ Counter cnt[FTA * NL][64];
+    __shared__ float sTab[NL][8];                                    // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
-    {
-        const int lv = lane >> 3, n = lane & 7, k = A.kHigh - lv;
+    for (int i = lane; i < NL * 8; i += 64) {
+        const int lv = i >> 3, n = i & 7, k = A.kHigh - lv;
         sTab[lv][n] = (n > 0 && k >= 1) ? event_score(k, (uint32_t)n) : 0.0f;
     }
     __syncthreads();
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
-    uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
-    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;   // every lane owns a contiguous log
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.workCursor, 64u);          // persistent wavefronts take 64 reads at a time
@@ -2026,212 +2077,315 @@ __global__ __launch_bounds__(64) void score_fast8_kernel(ScoreArgs A)
         if (base >= A.nReads) break;
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
-        FastLane L{0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0.0f, false};
-        for (int l2 = 0; l2 < FTA * 8; ++l2) cnt64[l2][lane] = 0;
+        bool fb = false;
+        int na = 0;
+        uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu, nOther = 0, nKeys = 0;   // records / profile keys of the other taxa
+        float mS0 = 0.0f, mS1 = 0.0f;
+        for (int l2 = 0; l2 < FTA * nK; ++l2) cnt[(l2 / nK) * NL + (l2 % nK)][lane] = 0;
         if (active) {
             const uint64_t o0 = A.kmerOff[r];
-            const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
-            if (cnt > 60000u) { L.fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
+            const uint32_t cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
+            if (cnt0 > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
+            const uint4 *rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
+            // ---- A. the taxa that get the register slots: the first two with a deep match
+            for (uint32_t j = 0; j < cnt0 && na < FTA && !fb; ++j) {
+                const uint4 h = rp0[(size_t)j * (RW / 4)];
+                if ((h.z & 31u) == 0u) continue;
+                QueryRec<RW> Q;
+                Q.decode(rp0 + (size_t)j * (RW / 4), A.pool);
+#pragma unroll
+                for (int q = 0; q < RT::INL; ++q) {
+                    const uint32_t t = Q.sg[q] & SEG_TAX_MASK;
+                    if ((uint32_t)q < Q.nInl && (int)(Q.sg[q] >> 27) >= kPromote && t != mTax0 && na < FTA) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                }
+                for (uint32_t q = 0; q < Q.nMore && na < FTA; ++q) {
+                    const uint32_t t = Q.more[q] & SEG_TAX_MASK;
+                    if ((int)(Q.more[q] >> 27) >= kPromote && t != mTax0) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                }
+            }
+            // ---- B. their chains, query by query
             uint32_t prevF = 0;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * 2;
-            uint4 h = make_uint4(0, 0, 0, 0), b = h;
-            if (cnt && !L.fb) { h = rp[0]; b = rp[1]; }
-            for (uint32_t j = 0; j < cnt && !L.fb; ++j) {
-                const uint4 hc = h, bc = b;
-                rp += 2;
-                if (j + 1 < cnt) { h = rp[0]; b = rp[1]; }                      // the next record is on its way while this one is replayed
-                const int d = (int)(hc.z & 31u);
-                if (d == 0) continue;
+            const uint4 *rp = rp0;
+            for (uint32_t j = 0; j < cnt0 && !fb; ++j, rp += RW / 4) {
+                if (((o0 + j) & 63u) == 0u) A.otherOff64[(o0 + j) >> 6] = nOther;   // for score_other_kernel: the count so far at a wavefront's first slot
+                if ((rp[0].z & 31u) == 0u) continue;
+                QueryRec<RW> Q;
+                Q.decode(rp, A.pool);
                 if (PERREAD) {
-                    if (prevF > hc.x) { L.fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
-                    prevF = hc.y;
+                    if (prevF > Q.p) { fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
+                    prevF = Q.fmax;
                 }
-                const uint32_t nseg = hc.w & 255u, nlev = hc.w >> 8;
-                if (nseg == 255u) { L.fb = true; atomicAdd(&A.why[3], 1u); break; }
-                const uint32_t order0 = (hc.z >> 5) & 0xFFFFFFu;
-                const bool split = (hc.z & REC_SPLIT) != 0u;
-                const int nEv = d - A.kLow + 1;
-                const uint32_t sg[4] = {bc.x, bc.y, bc.z, bc.w};
-                const uint32_t nInl = nseg <= 4u ? nseg : 3u;
-                const uint32_t *more = A.pool + bc.w + 1u;                       // segments 3.. when nseg > 4
-                const uint32_t nMore = nseg <= 4u ? 0u : nseg - 3u;
-                // |T| of a level: from the record, or counted when the record says "7 or more"
-                auto setSize = [&](int lv) -> uint32_t {
-                    uint32_t n = (nlev >> (3 * lv)) & 7u;
-                    if (n == 7u) {
-                        const uint32_t k = (uint32_t)(A.kHigh - lv);
-                        n = 0;
-                        for (uint32_t q = 0; q < nInl; ++q) n += seg_covers(sg[q], k) ? 1u : 0u;
-                        for (uint32_t q = 0; q < nMore; ++q) n += seg_covers(more[q], k) ? 1u : 0u;
-                    }
-                    return n;
-                };
-                // 1. taxa with a deep match get a register slot before any event of this query is replayed
-                if (L.na < FTA) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const uint32_t t = sg[q] & SEG_TAX_MASK;
-                        if ((uint32_t)q < nInl && (int)(sg[q] >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1 && L.na < FTA)
-                            fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
-                    }
-                    for (uint32_t q = 0; q < nMore && L.na < FTA; ++q) {
-                        const uint32_t sq = more[q], t = sq & SEG_TAX_MASK;
-                        if ((int)(sq >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1) fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
-                    }
-                }
-                // 2. classify: level masks of the register taxa; the other taxa's contributions go to the log, segment by segment
+                if (Q.nseg >= (1u << 13)) { fb = true; atomicAdd(&A.why[3], 1u); break; }
+                const int nEv = Q.d - A.kLow + 1;
+                const bool sat = RW == 8 && (rp[0].z & (REC_SAT | REC_SPLIT)) != 0u;   // then: one event record per level (seg_records)
                 uint32_t mask0 = 0, mask1 = 0;
-                auto other = [&](uint32_t sq, uint32_t m) {
-                    const uint32_t t = sq & SEG_TAX_MASK;
-                    const uint32_t kind = PERREAD ? 0u : RK_PROFILE;
-                    if (PERREAD && split) return;                               // several segments may share a taxon: logged in event order below
-                    if ((m & (m - 1u)) == 0u) {                                 // one level (a chance match of the shortest prefix, usually)
-                        const int lv = __ffs((int)m) - 1;
-                        fast_log(L, lg, t, lv, setSize(lv), kind, A.why);
-                    } else {
-                        uint32_t o = order0;
-                        for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
-                            const int lv = (int)(o & 7u);
-                            if ((m >> lv) & 1u) fast_log(L, lg, t, lv, setSize(lv), kind, A.why);
-                        }
-                    }
-                };
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((uint32_t)q >= nInl) continue;
-                    const uint32_t t = sg[q] & SEG_TAX_MASK, m = seg_level_mask(sg[q], A.kHigh);
-                    if (t == L.mTax0) mask0 |= m;
-                    else if (t == L.mTax1) mask1 |= m;
-                    else other(sg[q], m);
+                for (int q = 0; q < RT::INL; ++q) {
+                    if ((uint32_t)q >= Q.nInl) continue;
+                    const uint32_t t = Q.sg[q] & SEG_TAX_MASK, m = seg_level_mask(Q.sg[q], A.kHigh);
+                    if (t == mTax0) mask0 |= m;
+                    else if (t == mTax1) mask1 |= m;
+                    else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
                 }
-                for (uint32_t q = 0; q < nMore; ++q) {
-                    const uint32_t sq = more[q], t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
-                    if (t == L.mTax0) mask0 |= m;
-                    else if (t == L.mTax1) mask1 |= m;
-                    else other(sq, m);
+                for (uint32_t q = 0; q < Q.nMore; ++q) {
+                    const uint32_t sq = Q.more[q], t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+                    if (t == mTax0) mask0 |= m;
+                    else if (t == mTax1) mask1 |= m;
+                    else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
                 }
-                if (PERREAD && split) {                                         // the rare query whose taxa may own several segments
-                    uint32_t o = order0;
-                    for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
-                        const int lv = (int)(o & 7u);
-                        const uint32_t k = (uint32_t)(A.kHigh - lv);
-                        for (uint32_t q = 0; q < nInl + nMore; ++q) {
-                            const uint32_t sq = q < nInl ? (q == 0 ? sg[0] : q == 1 ? sg[1] : q == 2 ? sg[2] : sg[3]) : more[q - nInl];
-                            const uint32_t t = sq & SEG_TAX_MASK;
-                            if (t != L.mTax0 && t != L.mTax1 && seg_covers(sq, k)) fast_log(L, lg, t, lv, setSize(lv), 0u, A.why);
-                        }
+                if ((mask0 | mask1) == 0u) continue;
+                unsigned __int128 o = Q.order;
+                for (int ev = 0; ev < nEv; ++ev, o >>= OB) {
+                    const int lv = (int)((uint32_t)o & ((1u << OB) - 1u));
+                    const uint32_t in0 = (mask0 >> lv) & 1u, in1 = (mask1 >> lv) & 1u;
+                    if ((in0 | in1) == 0u) continue;
+                    const uint32_t n = Q.set_size(lv, A.kHigh);
+                    const float s = n < 8u ? sTab[lv][n] : event_score(evT, A.kHigh - lv, n);
+                    if (PERREAD) {                                           // Compare.hpp:528-530; + 0.0f leaves a score as it is
+                        mS0 = __fadd_rn(mS0, in0 ? s : 0.0f);
+                        mS1 = __fadd_rn(mS1, in1 ? s : 0.0f);
                     }
-                }
-                // 3. the events of the register taxa, in flush order
-                if (mask0 | mask1) {
-                    uint32_t o = order0;
-                    for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
-                        const int lv = (int)(o & 7u);
-                        const uint32_t in0 = (mask0 >> lv) & 1u, in1 = (mask1 >> lv) & 1u;
-                        const uint32_t n = setSize(lv);
-                        const float s = n < 8u ? sTab[lv][n] : event_score(evT, A.kHigh - lv, n);
-                        if (PERREAD) {                                           // Compare.hpp:528-530; + 0.0f leaves a score as it is
-                            L.mS0 = __fadd_rn(L.mS0, in0 ? s : 0.0f);
-                            L.mS1 = __fadd_rn(L.mS1, in1 ? s : 0.0f);
-                        }
-                        if (n <= 4u) {
-                            const unsigned long long one = 1ull << (16 * (n - 1u));
-                            cnt64[lv][lane] += in0 ? one : 0ull;
-                            cnt64[8 + lv][lane] += in1 ? one : 0ull;
-                        } else {
-                            if (in0) fast_log(L, lg, L.mTax0, lv, n, RK_PROFILE, A.why);
-                            if (in1) fast_log(L, lg, L.mTax1, lv, n, RK_PROFILE, A.why);
-                        }
-                    }
+                    if (n <= CNT_FIELDS) {
+                        const Counter one = (Counter)1 << (16 * (n - 1u));
+                        cnt[lv][lane] += in0 ? one : (Counter)0;
+                        cnt[NL + lv][lane] += in1 ? one : (Counter)0;
+                    } else { nOther += in0 + in1; nKeys += in0 + in1; }       // a profile record, written by score_other_kernel
                 }
             }
         }
-        fast_finish<PERREAD, unsigned long long>(A, L, active, r, nK, lane, cnt64, 8, lg);
+        // ---- the read's staging row: final scores of the register taxa, their counters as profile records, then room
+        // for the other taxa's records
+        uint32_t nprof = 0;
+        if (active && !fb)
+            for (int e = 0; e < na; ++e)
+                for (int lv = 0; lv < nK; ++lv) {
+                    const unsigned long long pk = cnt[e * NL + lv][lane];
+                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
+                }
+        const uint32_t nFinal = PERREAD ? (uint32_t)na : 0u;
+        if (active && !fb && nFinal + nprof + nOther > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge handles
+        const uint32_t m = (active && !fb) ? nFinal + nprof + nOther : 0u;
+        uint32_t incl = m;
+        for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t total = __shfl(incl, 63);
+        unsigned long long start = 0;
+        if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
+        start = __shfl(start, 0);
+        start += incl - m;
+        // ... and its profile keys: one per counter record and per event of the other taxa
+        const uint32_t mk = (active && !fb) ? nprof + nKeys : 0u;
+        uint32_t inclK = mk;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inclK, off);
+            if (lane >= off) inclK += o;
+        }
+        const uint32_t totalK = __shfl(inclK, 63);
+        unsigned long long startK = 0;
+        if (lane == 0 && totalK) startK = atomicAdd(A.keyCursor, (unsigned long long)totalK);
+        startK = __shfl(startK, 0);
+        const bool fits = start - (incl - m) + total <= (unsigned long long)A.stCap && startK + totalK <= (unsigned long long)A.keyCap;
+        startK += inclK - mk;
+        if (active) {
+            MainOut mo{mTax0, mTax1, 0u, 0u};
+            if (!fb) {
+                A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? (m | (m ? ROW_MERGE : 0u)) : 0u;
+                A.rowKey[r] = fits ? (uint32_t)startK : 0u;
+                if (fits) {
+                    uint32_t w = (uint32_t)start;
+                    if (PERREAD && na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
+                    if (PERREAD && na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
+                    for (int e = 0; e < na; ++e) {
+                        const uint32_t t = (e == 0) ? mTax0 : mTax1;
+                        for (int lv = 0; lv < nK; ++lv) {
+                            const unsigned long long pk = cnt[e * NL + lv][lane];
+                            for (uint32_t q = 0; q < 4; ++q) {
+                                const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
+                                if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
+                            }
+                        }
+                    }
+                    mo.otherAt = w; mo.nOther = nOther;
+                }
+            }
+            reinterpret_cast<uint4 *>(A.mainOut)[r] = make_uint4(mo.tax0, mo.tax1, mo.otherAt, mo.nOther);
+        }
+        const unsigned long long fbMask = __ballot(active && fb);
+        if (fbMask) {
+            uint32_t fbBase = 0;
+            if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
+            fbBase = __shfl(fbBase, 0);
+            if (active && fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
+        }
     }
 }
 
-// Up to 25 levels (64-byte records): the same replay written with loops over levels and segments.  A (taxon, level)
-// counter holds two 16-bit fields (|T| = 1, 2) to keep the LDS footprint of a wavefront small; larger sets leave as
-// profile records through the log.
-template <bool PERREAD>
-__global__ __launch_bounds__(64) void score_fast16_kernel(ScoreArgs A)
+// The other taxa's contributions of the reads score_main_kernel kept: one THREAD per query (slot), a wavefront = 64
+// consecutive slots (coalesced 32-byte records, every lane busy, reads may begin and end inside a wavefront).  A lane
+// counts the staging records its query yields -- one per segment, as a rule (seg_records) -- and a segmented prefix sum
+// (restarting at every read's first slot) places them behind the read's `otherAt`; for the read that began before the
+// wavefront, score_main_kernel left the running count at the wavefront's first slot (otherOff64).  So a row holds the
+// records in the read's flush order: query by query (inside a query only the order among one taxon's records matters,
+// and a taxon owns one segment unless the query is marked REC_SPLIT).  row_merge_kernel expands segment records.
+template <int RW, bool PERREAD>
+__global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
 {
-    typedef RecTraits<16> RT;
-    constexpr int NKF = RT::LEVELS, INL = RT::INL;
-    __shared__ uint32_t cnt32[FTA * NKF][64];
-    __shared__ EventTables evT;
-    event_tables_init(evT);
-    const int lane = threadIdx.x;
-    const int nK = A.kHigh - A.kLow + 1;
-    const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;
-    uint32_t *blk = A.fastScratch + (size_t)blockIdx.x * FAST_SCRATCH_WORDS;
-    uint2 *lg = reinterpret_cast<uint2 *>(blk) + (size_t)lane * FLOG;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(A.workCursor, 64u);
-        base = __shfl(base, 0);
-        if (base >= A.nReads) break;
-        const uint32_t r = base + lane;
-        const bool active = r < A.nReads;
-        FastLane L{0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, 0.0f, 0.0f, false};
-        for (int l2 = 0; l2 < FTA * NKF; ++l2) cnt32[l2][lane] = 0;
-        if (active) {
-            const uint64_t o0 = A.kmerOff[r];
-            const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
-            if (cnt > 60000u) { L.fb = true; atomicAdd(&A.why[0], 1u); }
-            uint32_t prevF = 0;
-            const uint4 *rp = reinterpret_cast<const uint4 *>(A.rec) + o0 * 4;
-            for (uint32_t j = 0; j < cnt && !L.fb; ++j, rp += 4) {
-                const uint4 h = rp[0];
-                const int d = (int)(h.z & 31u);
-                if (d == 0) continue;
-                if (PERREAD) {
-                    if (prevF > h.x) { L.fb = true; atomicAdd(&A.why[4], 1u); break; }
-                    prevF = h.y;
-                }
-                const uint32_t nseg = h.w;
-                if (nseg >= (1u << 13)) { L.fb = true; atomicAdd(&A.why[3], 1u); break; }
-                const int nEv = d - A.kLow + 1;
-                const uint4 o4 = rp[1], s0 = rp[2], s1 = rp[3];
-                const unsigned __int128 order0 = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
-                const uint32_t sg[INL] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-                const uint32_t nInl = nseg <= (uint32_t)INL ? nseg : (uint32_t)INL - 1u;
-                const uint32_t *more = A.pool + s1.w + 1u;
-                const uint32_t nMore = nseg <= (uint32_t)INL ? 0u : nseg - ((uint32_t)INL - 1u);
-                auto segAt = [&](uint32_t q) -> uint32_t {
-                    if (q >= nInl) return more[q - nInl];
-                    uint32_t v = sg[0];
+    typedef RecTraits<RW> RT;
+    constexpr int OB = RT::OBITS;
+    constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
+    typedef typename std::conditional<RW == 8, uint32_t, unsigned __int128>::type Order;
+    const int lane = threadIdx.x & 63;
+    const uint32_t kindOther = PERREAD ? 0u : RK_PROFILE;
+    const uint32_t stride = gridDim.x * 256u;
+    const double readsPerSlot = (double)A.nReads / (double)A.nQ;
+    const uint32_t nQup = (A.nQ + 63u) & ~63u;                             // whole wavefronts take part in the prefix sums
+    // A wavefront's records leave through LDS: a lane's 8-byte stores would reach the row as ~50 partial-line write requests
+    // per wavefront (measured: 4/5 of the kernel); staged, consecutive lanes write consecutive records.
+    constexpr uint32_t STAGE = 512;                                        // records a wavefront stages; larger (rare) batches are written directly
+    __shared__ uint2 sRec[4][STAGE];
+    __shared__ uint32_t sAt[4][STAGE];
+    const int wv = threadIdx.x >> 6;
+    for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < nQup; slot += stride) {
+        const bool inRange = slot < A.nQ;
+        uint4 cur[RW / 4];
 #pragma unroll
-                    for (int i = 1; i < INL; ++i) v = (q == (uint32_t)i) ? sg[i] : v;
-                    return v;
-                };
-                if (L.na < FTA)
-                    for (uint32_t q = 0; q < nseg && L.na < FTA; ++q) {
-                        const uint32_t sq = segAt(q), t = sq & SEG_TAX_MASK;
-                        if ((int)(sq >> 27) >= kPromote && t != L.mTax0 && t != L.mTax1) fast_promote<PERREAD>(L, t, lg, evT, A.kHigh);
-                    }
-                unsigned __int128 o = order0;
-                for (int ev = 0; ev < nEv && !L.fb; ++ev, o >>= 5) {
-                    const int lv = (int)((uint32_t)o & 31u);
-                    const uint32_t k = (uint32_t)(A.kHigh - lv);
-                    uint32_t n = 0;
-                    for (uint32_t q = 0; q < nseg; ++q) n += seg_covers(segAt(q), k) ? 1u : 0u;
-                    const float s = event_score(evT, (int)k, n);
-                    for (uint32_t q = 0; q < nseg; ++q) {
-                        const uint32_t sq = segAt(q);
-                        if (!seg_covers(sq, k)) continue;
-                        const uint32_t t = sq & SEG_TAX_MASK;
-                        const int e = t == L.mTax0 ? 0 : (t == L.mTax1 ? 1 : -1);
-                        if (e >= 0) {
-                            if (PERREAD) { if (e == 0) L.mS0 = __fadd_rn(L.mS0, s); else L.mS1 = __fadd_rn(L.mS1, s); }
-                            if (n <= 2u) cnt32[e * NKF + lv][lane] += 1u << (16 * (n - 1u));
-                            else fast_log(L, lg, t, lv, n, RK_PROFILE, A.why);
-                        } else fast_log(L, lg, t, lv, n, PERREAD ? 0u : RK_PROFILE, A.why);
-                    }
-                }
+        for (int i = 0; i < RW / 4; ++i) cur[i] = make_uint4(0, 0, 0, 0);
+        uint32_t r = 0;
+        uint64_t readStart = 0;
+        uint4 mo = make_uint4(0, 0, 0, 0);
+        if (inRange) {
+#pragma unroll
+            for (int i = 0; i < RW / 4; ++i) cur[i] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (RW / 4) + i];
+            // the read of this slot: reads are mostly equally long, so the proportional guess is right; else search
+            r = (uint32_t)((double)slot * readsPerSlot);
+            if (r >= A.nReads) r = A.nReads - 1u;
+            readStart = A.kmerOff[r];
+            if (!(readStart <= slot && slot < A.kmerOff[r + 1])) {
+                uint32_t lo = 0, hi = A.nReads;                                // last r with kmerOff[r] <= slot
+                while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (A.kmerOff[mid] <= slot) lo = mid; else hi = mid; }
+                r = lo;
+                readStart = A.kmerOff[r];
             }
+            mo = reinterpret_cast<const uint4 *>(A.mainOut)[r];
         }
-        fast_finish<PERREAD, uint32_t>(A, L, active, r, nK, lane, cnt32, NKF, lg);
+        const bool live = inRange && mo.w != 0u && (cur[0].z & 31u) != 0u;     // a matched query of a read the fast path kept
+        const uint32_t mTax0 = mo.x, mTax1 = mo.y;
+        QueryRec<RW> Q;
+        Q.decode_regs(cur, A.pool);
+        if (!live) { Q.d = 0; Q.nInl = 0; Q.nMore = 0; Q.split = 0; }
+        const bool sat = RW == 8 && (cur[0].z & (REC_SAT | REC_SPLIT)) != 0u;   // then: one event record per level (seg_records)
+        const int nEv = Q.d ? Q.d - A.kLow + 1 : 0;
+        // the pool segments of the query, the first four in registers (their loads go out together)
+        uint32_t xs[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if ((uint32_t)i < Q.nMore) xs[i] = Q.more[i];
+        auto extra = [&](uint32_t q) -> uint32_t { return q == 0 ? xs[0] : q == 1 ? xs[1] : q == 2 ? xs[2] : q == 3 ? xs[3] : Q.more[q]; };
+        // levels with |T| > CNT_FIELDS: there the register taxa leave profile records instead of counting in LDS
+        uint32_t bigLv = 0;
+        if constexpr (RW == 8) {
+            const uint32_t x = Q.nlev, f = (x >> 2) & ((x >> 1) | x) & 0x249249u;      // field >= 5, one bit per 3-bit field
+            bigLv = (f & 1u) | ((f >> 2) & 2u) | ((f >> 4) & 4u) | ((f >> 6) & 8u) | ((f >> 8) & 16u) | ((f >> 10) & 32u) | ((f >> 12) & 64u) | ((f >> 14) & 128u);
+        } else {
+            for (int lv = 0; lv < nEv; ++lv) { const int l2 = A.kHigh - A.kLow - lv; if (Q.set_size(l2, A.kHigh) > CNT_FIELDS) bigLv |= 1u << l2; }
+        }
+        // levels at which a segment leaves records (all of them: another taxon; those with a large |T|: register taxon)
+        // and how many records that makes
+        auto emitMask = [&](uint32_t sq, bool valid) -> uint32_t {
+            const uint32_t t = sq & SEG_TAX_MASK, m = valid ? seg_level_mask(sq, A.kHigh) : 0u;
+            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+        };
+        auto records = [&](uint32_t sq, uint32_t m) -> uint32_t {
+            const uint32_t t = sq & SEG_TAX_MASK;
+            return (t != mTax0 && t != mTax1) ? seg_records<RW>(m, sat) : (uint32_t)__popc(m);
+        };
+        uint32_t em[RT::INL];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < RT::INL; ++q) { em[q] = emitMask(Q.sg[q], (uint32_t)q < Q.nInl); mine += records(Q.sg[q], em[q]); }
+        for (uint32_t q = 0; q < Q.nMore; ++q) { const uint32_t sq = extra(q); mine += records(sq, emitMask(sq, true)); }
+        // segmented inclusive prefix sum over the wavefront: a segment starts at every read's first slot
+        const bool head = inRange && (uint64_t)slot == readStart;
+        uint32_t incl = mine;
+        bool started = head;                                                   // a read starts at or before this lane, inside the wavefront
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            const bool s2 = __shfl_up((int)started, off) != 0;
+            if (lane >= off && !started) { incl += o; started = s2; }
+        }
+        // place in the wavefront's staging area: a plain prefix sum
+        uint32_t lincl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(lincl, off);
+            if (lane >= off) lincl += o;
+        }
+        const uint32_t total = __shfl(lincl, 63);
+        if (total == 0u) continue;                                           // uniform
+        const bool staged = total <= STAGE;
+        uint32_t lp = lincl - mine;
+        // reads that began before the wavefront continue from the count score_main_kernel left at the wavefront's first slot
+        uint32_t w = mine ? mo.z + incl - mine + (started ? 0u : A.otherOff64[slot >> 6]) : 0u;
+        auto emit = [&](uint2 rec) {
+            if (staged) { sRec[wv][lp] = rec; sAt[wv][lp] = w; ++lp; ++w; }
+            else A.st[w++] = rec;
+        };
+        // position of level lv in the query's flush order (three bits per event: the field that equals lv, found without a loop)
+        auto posOf = [&](int lv) -> int {
+            if constexpr (RW == 8) {
+                const uint32_t x = ((uint32_t)Q.order ^ ((uint32_t)lv * 0x249249u)) | (nEv < 8 ? (0xFFFFFFFFu << (3 * nEv)) : 0u);
+                const uint32_t z = ~(x | (x >> 1) | (x >> 2)) & 0x249249u;       // bit 3 i set iff field i is zero
+                return (__ffs((int)z) - 1) / 3;
+            } else {
+                Order o = (Order)Q.order;
+                int pos = 0;
+                for (int ev = 0; ev < nEv; ++ev, o >>= OB) if ((int)((uint32_t)o & ((1u << OB) - 1u)) == lv) pos = ev;
+                return pos;
+            }
+        };
+        auto putEvent = [&](uint32_t sq, int lv) {
+            const uint32_t t = sq & SEG_TAX_MASK;
+            const uint32_t kind = (t == mTax0 || t == mTax1) ? RK_PROFILE : kindOther;
+            emit(make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (Q.set_size(lv, A.kHigh) << 16) | 1u));
+        };
+        auto putSeg = [&](uint32_t sq, uint32_t m) {
+            if (m == 0u) return;
+            const uint32_t t = sq & SEG_TAX_MASK;
+            const uint32_t pc = (uint32_t)__popc(m);
+            if (pc == 1u && (RW != 8 || t == mTax0 || t == mTax1 || sat)) { putEvent(sq, __ffs((int)m) - 1); return; }   // one event, one record
+            if (RW == 8 && t != mTax0 && t != mTax1 && pc <= 2u && !sat) {   // one segment record (seg_records)
+                const int lvLo = __ffs((int)m) - 1, lvHi = 31 - __clz((int)m);   // lvLo = the deeper level (larger k)
+                const bool desc = pc == 2u && posOf(lvLo) < posOf(lvHi);          // the larger k flushes first
+                emit(make_uint2(t | ((uint32_t)(A.kHigh - lvHi) << 20) | (desc ? RK_SEG_DESC : 0u) | RK_SEG,
+                                (uint32_t)(A.kHigh - lvLo) | (Q.nlev << 8)));
+                return;
+            }
+            Order o = (Order)Q.order;                                        // one event record per level, in flush order
+            for (int ev = 0; ev < nEv; ++ev, o >>= OB) {
+                const int lv = (int)((uint32_t)o & ((1u << OB) - 1u));
+                if ((m >> lv) & 1u) putEvent(sq, lv);
+            }
+        };
+        if (mine == 0u) {}
+        else if (Q.split) {
+            // a taxon may own several segments: its records must follow the query's flush order across them -- event by event
+            Order o = (Order)Q.order;
+            for (int ev = 0; ev < nEv; ++ev, o >>= OB) {
+                const int lv = (int)((uint32_t)o & ((1u << OB) - 1u));
+#pragma unroll
+                for (int q = 0; q < RT::INL; ++q) if ((em[q] >> lv) & 1u) putEvent(Q.sg[q], lv);
+                for (uint32_t q = 0; q < Q.nMore; ++q) { const uint32_t sq = extra(q); if ((emitMask(sq, true) >> lv) & 1u) putEvent(sq, lv); }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RT::INL; ++q) putSeg(Q.sg[q], em[q]);
+            for (uint32_t q = 0; q < Q.nMore; ++q) { const uint32_t sq = extra(q); putSeg(sq, emitMask(sq, true)); }
+        }
+        if (staged) {
+            LDS_WAVE_SYNC();
+            for (uint32_t x = lane; x < total; x += 64) A.st[sAt[wv][x]] = sRec[wv][x];
+            LDS_WAVE_SYNC();
+        }
     }
 }
 
@@ -2242,6 +2396,7 @@ __global__ __launch_bounds__(64) void score_fast16_kernel(ScoreArgs A)
 // also leaves as a 64-bit profile key {level:5 | |T|:13 | taxon:20 | hits:16} for the sort-reduce below.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
+                                                       const uint32_t *__restrict__ rowKey,
                                                        uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
                                                        int kHigh, ProfLayout PL)
 {
@@ -2256,15 +2411,33 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
         const uint32_t s0 = rowPos[r];
         uint32_t n2 = 2;
         while (n2 < m) n2 <<= 1;
-        for (uint32_t i = lane; i < n2; i += 64) {
+        uint32_t keyAt = rowKey[r];
+        for (uint32_t i0 = 0; i0 < n2; i0 += 64) {
+            const uint32_t i = i0 + lane;
             uint32_t key = 0xFFFFFFFFu;
+            uint2 e = make_uint2(RK_FINAL, 0u);
             if (i < m) {
-                const uint2 e = st[s0 + i];
+                e = st[s0 + i];
                 sRec[i] = e;
                 const uint32_t kind = e.x >> 30;
                 if (kind != 2u) key = ((e.x & 0xFFFFFu) << 11) | (kind == 1u ? 0u : (i & 0x7FFu));   // final score first in its run
-                if (kind != 1u)
-                    profKeys[s0 + i] = profile_key(e, PL);
+            }
+            const uint32_t nk = i < m ? record_keys(e) : 0u;          // every event leaves as a profile key
+            uint32_t incl = nk;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            uint32_t kw = keyAt + incl - nk;
+            keyAt += __shfl(incl, 63);
+            if (nk) {
+                if ((e.x >> 30) == 3u) {
+                    const uint32_t sizes = e.y >> 8;
+                    for (uint32_t k = (e.x >> 20) & 31u; k <= (e.y & 31u); ++k) {
+                        const uint32_t lv = (uint32_t)kHigh - k;
+                        profKeys[kw++] = profile_key_of(lv, (sizes >> (3u * lv)) & 7u, e.x & 0xFFFFFu, 1u, PL);
+                    }
+                } else profKeys[kw] = profile_key(e, PL);
             }
             sKey[i] = key;
             sIdx[i] = (uint16_t)i;
@@ -2300,7 +2473,14 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                     for (uint32_t q = i; q < m && sKey[q] != 0xFFFFFFFFu && (sKey[q] >> 11) == tax; ++q) {
                         const uint2 e = sRec[sIdx[q]];
                         if ((e.x >> 30) == 1u) { v = __uint_as_float(e.y); any = true; }
-                        else if (!(e.x & RK_CONSUMED)) {
+                        else if ((e.x >> 30) == 3u) {                  // a segment: its levels in ascending or descending order of k
+                            const int kF = (int)((e.x >> 20) & 31u), kL = (int)(e.y & 31u);
+                            const uint32_t sizes = e.y >> 8;
+                            const int step = (e.x & RK_SEG_DESC) ? -1 : 1;
+                            for (int k = step > 0 ? kF : kL, c = kL - kF; c >= 0; --c, k += step)
+                                v = __fadd_rn(v, event_score(k, (sizes >> (3 * (kHigh - k))) & 7u));
+                            any = true;
+                        } else {
                             const float s = event_score(kHigh - (int)rk_level(e.x), e.y >> 16);
                             for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, s);
                             any = true;
@@ -2328,6 +2508,7 @@ static constexpr int BM_WORDS = 512;
 
 template <int RCAP, int BMW>
 __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
+                                                              const uint32_t *__restrict__ rowKey,
                                                               uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
                                                               int kHigh, uint32_t nTaxa, uint32_t mLo, ProfLayout PL)
 {
@@ -2347,13 +2528,32 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
         for (uint32_t w = lane; w < W; w += 64) bm[w] = 0u;
         for (uint32_t i = lane; i < m; i += 64) { val[i] = 0.0f; claim[i] = 0xFFFFFFFFu; }
         LDS_WAVE_SYNC();
-        // pass 1: the row's taxa as a bitmap; every event / profile record leaves as a profile key
-        for (uint32_t i = lane; i < m; i += 64) {
-            const uint2 e = st[s0 + i];
+        // pass 1: the row's taxa as a bitmap; every event leaves as a profile key (a prefix sum places the keys of a chunk)
+        uint32_t keyAt = rowKey[r];
+        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint2 e = make_uint2(RK_FINAL, 0u);
+            if (i < m) e = st[s0 + i];
             const uint32_t kind = e.x >> 30;
             const uint32_t t = e.x & 0xFFFFFu;
-            if (kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
-            if (kind != 1u) profKeys[s0 + i] = profile_key(e, PL);
+            if (i < m && kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
+            const uint32_t nk = i < m ? record_keys(e) : 0u;
+            uint32_t incl = nk;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            uint32_t kw = keyAt + incl - nk;
+            keyAt += __shfl(incl, 63);
+            if (nk) {
+                if (kind == 3u) {
+                    const uint32_t sizes = e.y >> 8;
+                    for (uint32_t k = (e.x >> 20) & 31u; k <= (e.y & 31u); ++k) {
+                        const uint32_t lv = (uint32_t)kHigh - k;
+                        profKeys[kw++] = profile_key_of(lv, (sizes >> (3u * lv)) & 7u, t, 1u, PL);
+                    }
+                } else profKeys[kw] = profile_key(e, PL);
+            }
         }
         LDS_WAVE_SYNC();
         uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
@@ -2385,8 +2585,8 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                     const uint32_t t = e.x & 0xFFFFFu;
                     slot = pre[t >> 5] + (uint32_t)__popc(bm[t >> 5] & ((1u << (t & 31u)) - 1u));
                     slotTax[slot] = t;                                 // every record of the slot writes the same value
-                    if (kind == 1u) val[slot] = __uint_as_float(e.y);  // the register taxon's final score: its log records are all consumed
-                    else if (!(e.x & RK_CONSUMED)) { pending = true; sc = event_score(evT, kHigh - (int)rk_level(e.x), e.y >> 16); }
+                    if (kind == 1u) val[slot] = __uint_as_float(e.y);  // a register taxon's final score: all its events are in it
+                    else { pending = true; if (kind == 0u) sc = event_score(evT, kHigh - (int)rk_level(e.x), e.y >> 16); }
                 }
             }
             while (__ballot(pending) != 0ull) {
@@ -2394,7 +2594,14 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                 LDS_WAVE_SYNC();
                 if (pending && claim[slot] == (uint32_t)lane) {
                     float v = val[slot];
-                    for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
+                    if ((e.x >> 30) == 3u) {                           // a segment: its levels in ascending or descending order of k
+                        const int kF = (int)((e.x >> 20) & 31u), kL = (int)(e.y & 31u);
+                        const uint32_t sizes = e.y >> 8;
+                        const int step = (e.x & RK_SEG_DESC) ? -1 : 1;
+                        for (int k = step > 0 ? kF : kL, c = kL - kF; c >= 0; --c, k += step)
+                            v = __fadd_rn(v, event_score(evT, k, (sizes >> (3 * (kHigh - k))) & 7u));
+                    } else
+                        for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
                     val[slot] = v;
                     claim[slot] = 0xFFFFFFFFu;
                     pending = false;
@@ -2632,33 +2839,36 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         return KASA_OK;
     }
     uint32_t *counters = c->misc.as<uint32_t>(); // [2] error flags, [3] fallback count, [5] second-pass count, [8..15] reasons; u64 [16] pool cursor, [17] staging cursor
-    unsigned long long *stCursor = c->misc.as<unsigned long long>() + 17;
+    unsigned long long *stCursor = c->misc.as<unsigned long long>() + 17, *keyCursor = c->misc.as<unsigned long long>() + 18;
     hipEvent_t a, b;
 
-    if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) ||
+    if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowKey.reserve((size_t)nReads * 4 + 64)) ||
         (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)) || (rc = c->fbList.reserve((size_t)nReads * 4 + 64)))
         return rc;
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
+    if (c->keyCap == 0) c->keyCap = c->stCap;
     const bool fast = nK <= 25 && nTaxa <= (1u << 20) && !c->forceSlowScore;   // staging records keep the taxon in 20 bits
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
     c->lastOverflowReads = 0;
-    uint64_t staged = 0;
+    uint64_t staged = 0, nKeys = 0;
     ScoreArgs A;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 4) return fail(KASA_E_LIMIT, "score staging did not converge");
         if (c->stCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the score rows of this batch need %llu staging records (limit 2^32); split the batch", (unsigned long long)c->stCap);
-        if ((rc = c->st.reserve(c->stCap * 8))) return rc;
+        if (c->keyCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the profile of this batch needs %llu keys (limit 2^32); split the batch", (unsigned long long)c->keyCap);
+        if ((rc = c->st.reserve(c->stCap * 8)) || (rc = c->profKeys.reserve(c->keyCap * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(counters + 2, 0, 8, c->stream));  // error flags, fallback count
         HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
-        HIPCHK(hipMemsetAsync(stCursor, 0, 8, c->stream));
+        HIPCHK(hipMemsetAsync(stCursor, 0, 16, c->stream));            // staging and key cursors
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
         A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
-        A.scratch = nullptr; A.fastScratch = nullptr;
+        A.scratch = nullptr; A.mainOut = nullptr; A.otherOff64 = nullptr; A.nQ = (uint32_t)nQ;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.st = c->st.as<uint2>();
         A.stCap = (uint32_t)c->stCap; A.stCursor = stCursor; A.errFlag = counters + 2;
+        A.rowKey = c->rowKey.as<uint32_t>(); A.keyCap = (uint32_t)c->keyCap; A.keyCursor = keyCursor;
         A.wantPerRead = wantPerRead ? 1 : 0;
         A.addProfile = slowProfileDone ? 0 : 1;
         A.list = nullptr; A.nList = 0; A.flushPos = nullptr; A.flushOff = nullptr;
@@ -2669,37 +2879,41 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (fast) {
             // persistent wavefronts: as many as are resident at once, each takes 64 reads at a time from a work counter
             int perCu = 0, nCu = 0;
-            const void *kern = RW == 8 ? (wantPerRead ? (const void *)score_fast8_kernel<true> : (const void *)score_fast8_kernel<false>)
-                                       : (wantPerRead ? (const void *)score_fast16_kernel<true> : (const void *)score_fast16_kernel<false>);
+            const void *kern = RW == 8 ? (wantPerRead ? (const void *)score_main_kernel<8, true> : (const void *)score_main_kernel<8, false>)
+                                       : (wantPerRead ? (const void *)score_main_kernel<16, true> : (const void *)score_main_kernel<16, false>);
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, 64, 0));
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
             const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, (uint32_t)std::max(1, perCu) * (uint32_t)std::max(1, nCu));
-            const size_t words = (size_t)fblocks * FAST_SCRATCH_WORDS;
-            if ((rc = c->fastScratch.reserve(words * 4))) return rc;
-            A.fastScratch = c->fastScratch.as<uint32_t>();
+            if ((rc = c->fastScratch.reserve((size_t)nReads * 16 + 64))) return rc;
+            A.mainOut = c->fastScratch.as<uint32_t>();
+            if ((rc = c->plist.reserve((nQ / 64 + 2) * 4 + 64))) return rc;      // (free once the slots are known)
+            A.otherOff64 = c->plist.as<uint32_t>();
             A.workCursor = counters + 6;
             HIPCHK(hipMemsetAsync(counters + 6, 0, 4, c->stream));
             if ((rc = timer_begin(c, c->scoreKernel, &c->skA, &c->skB))) return rc;
+            const unsigned oblocks = std::min<unsigned>(blocks_for(nQ, 256), 256u * 64u);
             if (wantPerRead) {
-                if (RW == 8) score_fast8_kernel<true><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast16_kernel<true><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) { score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); }
+                else { score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
             } else {
-                if (RW == 8) score_fast8_kernel<false><<<fblocks, 64, 0, c->stream>>>(A);
-                else score_fast16_kernel<false><<<fblocks, 64, 0, c->stream>>>(A);
+                if (RW == 8) { score_main_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); }
+                else { score_main_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
             }
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->scoreKernel, c->skA, c->skB))) return rc;
             c->scoreQueries += nQ;
-            uint32_t h3 = 0; unsigned long long want = 0;
+            uint32_t h3 = 0; unsigned long long want[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(&h3, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(&want, stCursor, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(want, stCursor, 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             nSlow = h3;
-            if (want > c->stCap) {                    // the fast kernel has no side effects: grow and rerun
+            if (want[0] > c->stCap || want[1] > c->keyCap) {   // the fast kernels have no side effects: grow and rerun
                 if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
-                c->stCap = want + want / 8 + (uint64_t)nSlow * 64 + 1024;
+                if (want[0] > c->stCap) c->stCap = want[0] + want[0] / 8 + (uint64_t)nSlow * 64 + 1024;
+                if (want[1] > c->keyCap) c->keyCap = want[1] + want[1] / 8 + 1024;
                 continue;
             }
+            nKeys = want[1];
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         if (nSlow > 0) {
@@ -2771,33 +2985,34 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (want <= c->stCap) { staged = want; break; }
         c->stCap = want + want / 8 + 1024;
     }
-    // ---- resolve the fast kernel's records: per-read merge, then the profile contributions by sort + reduce
+    // ---- resolve the fast kernels' records: per-read merge, then the profile contributions by sort + reduce
     if (fast && staged > 0) {
         const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
-        if ((rc = c->profKeys.reserve((size_t)staged * 8 + 64)) || (rc = c->profSorted.reserve((size_t)staged * 8 + 64))) return rc;   // staged < 2^32
-        HIPCHK(hipMemsetAsync(c->profKeys.p, 0xFF, (size_t)staged * 8, c->stream));
+        if ((rc = c->profSorted.reserve((size_t)nKeys * 8 + 64))) return rc;   // nKeys < 2^32; profKeys holds keyCap >= nKeys entries
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
                 row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                    c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
                 mLo = 512;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                c->rowLen.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo, PL);
+                c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo, PL);
         } else
-            row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), nReads,
-                c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, PL);
+            row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(),
+                c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, PL);
         HIPCHK(hipGetLastError());
-        size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
-        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)staged, 16u, 16u + PL.bits(), c->stream));
-        profile_reduce_kernel<<<std::min<unsigned>(blocks_for(staged, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
-            c->profSorted.as<uint64_t>(), (uint32_t)staged, nTaxa,
-            c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
-        HIPCHK(hipGetLastError());
+        if (nKeys > 0) {
+            size_t tmpBytes = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)nKeys, 16u, 16u + PL.bits(), c->stream));
+            if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+            HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)nKeys, 16u, 16u + PL.bits(), c->stream));
+            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nKeys, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
+                c->profSorted.as<uint64_t>(), (uint32_t)nKeys, nTaxa,
+                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
+            HIPCHK(hipGetLastError());
+        }
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
     }
     if (wantPerRead) {
@@ -3096,7 +3311,18 @@ extern "C" int kasa_batch_fetch_queries(kasa_ctx *c, void *kmers, uint32_t *read
     HIPCHK(hipSetDevice(c->ix->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n && kmers) HIPCHK(hipMemcpy(kmers, c->qKmer, n * c->keyBytes(), hipMemcpyDeviceToHost));
-    if (n && reads) HIPCHK(hipMemcpy(reads, c->qRead, n * 4, hipMemcpyDeviceToHost));
+    if (n && reads) {
+        const uint32_t *src = c->qRead;
+        if (c->payloadIsSlot) {                                       // the payload is the slot: back to read ids for the caller
+            int rc = c->plist.reserve(n * 4 + 64);
+            if (rc) return rc;
+            slot_to_read_kernel<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->qRead, (uint32_t)n, c->kmerOff.as<uint64_t>(), (uint32_t)c->nReads, c->plist.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            src = c->plist.as<uint32_t>();
+        }
+        HIPCHK(hipMemcpy(reads, src, n * 4, hipMemcpyDeviceToHost));
+    }
     return KASA_OK;
 }
 
@@ -3147,7 +3373,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;

@@ -277,7 +277,7 @@ def test_long_reads_and_mixed_lengths():
 
 
 @pytest.mark.parametrize("frames", [3, 6])
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 8])   # 8: slots from a sort by read id instead of the encoder's ranking
 def test_unique_drops_repeats_inside_reads(frames, flags):
     """-e: tandem-repeat reads (the same k-mer many times in one read, also shared between reads) across several
     tiles; per-read k-mer counts change, so the per-read offsets are recomputed on the device."""
@@ -549,7 +549,8 @@ def test_index_build_matches_reference_files(stem, K, tmp_path):
         assert _read(out + suffix) == _read(os.path.join(d, stem + suffix)), suffix
 
 
-@pytest.mark.parametrize("case", [(12, 7, 3, 12, 0), (12, 7, 6, 12, 0), (25, 7, 3, 25, 0), (12, 1, 3, 12, 0), (12, 7, 3, 12, 1)])
+@pytest.mark.parametrize("case", [(12, 7, 3, 12, 0), (12, 7, 6, 12, 0), (25, 7, 3, 25, 0), (12, 1, 3, 12, 0), (12, 7, 3, 12, 1), (12, 7, 3, 12, 8),
+                                  (25, 7, 6, 25, 8)])
 def test_profile_only_equals_per_read_run(case):
     """Without -q (kasa_batch_lookup_score(wantPerRead = 0)) the fast kernel skips ordering and float sums; the profile
     tables must be the same integers as those of the full run, and equal the oracle's."""
@@ -604,7 +605,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4]))
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9]))
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
