@@ -160,10 +160,19 @@ int kasa_profile_import_limbs(kasa_ctx *ctx, const uint64_t *limbs);
 /* HIP-event time (ms) and launch count of a stage, accumulated since the last reset. */
 int kasa_ctx_stage_ms(kasa_ctx *ctx, int stage, double *ms, uint64_t *launches);
 int kasa_ctx_stage_reset(kasa_ctx *ctx);
-/* HIP-event time of single kernels alone, for the roofline lines: lookup_tile_kernel (the sorted-index lookup) and
- * score_fast_kernel (the lane-per-read replay, the largest kernel of the step). */
-int kasa_ctx_lookup_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
-int kasa_ctx_score_kernel_ms(kasa_ctx *ctx, double *ms, uint64_t *launches, uint64_t *queries);
+/* HIP-event time of single kernels alone (accumulated since the last kasa_ctx_stage_reset), for the roofline lines. */
+enum {
+    KASA_KERNEL_LOOKUP = 0,       /* lookup_tile_kernel: the sorted-index lookup */
+    KASA_KERNEL_GROUP = 1,        /* group_kernel: flush order + taxon segments, one record per query */
+    KASA_KERNEL_SCORE_MAIN = 2,   /* score_main_kernel: the float chains of a read's register taxa */
+    KASA_KERNEL_SCORE_OTHER = 3,  /* score_other_kernel: staging records of all other taxa */
+    KASA_KERNEL_ROW_MERGE = 4,    /* row_merge_*: staging rows -> final {taxon, score} rows + profile keys */
+    KASA_KERNEL_COUNT = 5
+};
+int kasa_ctx_kernel_ms(kasa_ctx *ctx, int kernel, double *ms, uint64_t *launches);
+/* Of the last batch: {queries, staging records, profile keys, pool words, reads on the general kernel, of those on its
+ * second pass, non-zero score cells, 1 if the encoder ranked the reads' k-mers (no slot fix-up)}. */
+int kasa_ctx_batch_stats(kasa_ctx *ctx, uint64_t *stats8);
 /* Number of query records the batch holds right now: the k-mer count of kasa_batch_encode, less the
  * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
 int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);

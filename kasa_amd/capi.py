@@ -23,7 +23,7 @@ EXPORTS = [
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs",
-    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_lookup_kernel_ms", "kasa_ctx_score_kernel_ms", "kasa_batch_query_count", "kasa_batch_fetch_queries",
+    "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
 ]
@@ -327,16 +327,22 @@ class Context:
     def stage_reset(self):
         _check(lib().kasa_ctx_stage_reset(self.h))
 
-    def lookup_kernel_ms(self):
-        ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        _check(lib().kasa_ctx_lookup_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
-        return ms.value, int(n.value), int(q.value)
+    KERNELS = ("lookup_tile_kernel", "group_kernel", "score_main_kernel", "score_other_kernel", "row_merge_kernel")
 
-    def score_kernel_ms(self):
-        """HIP-event time of score_fast_kernel alone: (ms, launches, queries)."""
-        ms, n, q = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        _check(lib().kasa_ctx_score_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(q)))
-        return ms.value, int(n.value), int(q.value)
+    def kernel_ms(self):
+        """HIP-event time of single kernels alone since stage_reset(): {name: (ms, launches)}."""
+        out = {}
+        for i, name in enumerate(self.KERNELS):
+            ms, n = C.c_double(0), C.c_uint64(0)
+            _check(lib().kasa_ctx_kernel_ms(self.h, C.c_int(i), C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, int(n.value))
+        return out
+
+    def batch_stats(self):
+        st = np.zeros(8, dtype=np.uint64)
+        _check(lib().kasa_ctx_batch_stats(self.h, _p(st)))
+        keys = ("queries", "staging_records", "profile_keys", "pool_words", "general_reads", "second_pass_reads", "nnz", "encoder_ranked")
+        return {k: int(v) for k, v in zip(keys, st)}
 
     def max_queries_per_batch(self, device: int = 0, fraction: float = 0.8) -> int:
         """How many query k-mers fit one batch in the HBM that is free right now (at most 2^32 - 16)."""

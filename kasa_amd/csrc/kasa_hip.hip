@@ -475,9 +475,8 @@ struct kasa_ctx {
     int K() const { return ix->letters(); }
     template <class Key> Key *keys() const { return static_cast<Key *>(qKmer); }
     StageTimer timers[KASA_STAGE_COUNT];
-    StageTimer lookupKernel, scoreKernel;       // single kernels timed alone: lookup_tile_kernel, score_fast_kernel
-    hipEvent_t skA = nullptr, skB = nullptr;
-    uint64_t lookupQueries = 0, scoreQueries = 0;
+    StageTimer kernels[KASA_KERNEL_COUNT];      // single kernels timed alone (kasa_ctx_kernel_ms)
+    uint64_t lastStaged = 0, lastKeys = 0, lastContrib = 0;   // of the last batch: staging records, profile keys, (event, taxon) contributions
     std::vector<int64_t> hostOff;
 };
 
@@ -596,7 +595,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
         for (auto e : t.pool) (void)hipEventDestroy(e);
     };
     for (auto &t : c->timers) drop(t);
-    drop(c->lookupKernel); drop(c->scoreKernel);
+    for (auto &t : c->kernels) drop(t);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1257,21 +1256,20 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
     if (nQ > 0) {
         hipEvent_t ka, kb;
         if (c->lookupMode == 1) {
-            if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_LOOKUP], &ka, &kb))) return rc;
             lookup_kernel<Key><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->depth.as<uint8_t>(), c->rep.as<uint32_t>(),
                 c->tileFirst.as<uint32_t>(), nTiles);
         } else {
             tile_bounds_kernel<Key><<<blocks_for(2ull * nTiles, 256), 256, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(),
                 c->ix->table.as<uint32_t>(), c->ix->tb, nTiles, c->tileBounds.as<uint32_t>());
-            if ((rc = timer_begin(c, c->lookupKernel, &ka, &kb))) return rc;   // the roofline kernel alone
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_LOOKUP], &ka, &kb))) return rc;   // lookup_tile_kernel alone
             lookup_tile_kernel<Key><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<Key>(), (uint32_t)nQ, c->ix->kmer.as<Key>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->tileBounds.as<uint32_t>(), c->kHigh, c->kLow, c->depth.as<uint8_t>(),
                 c->rep.as<uint32_t>(), c->tileFirst.as<uint32_t>(), nTiles);
         }
         HIPCHK(hipGetLastError());
-        if ((rc = timer_end(c, c->lookupKernel, ka, kb))) return rc;
-        c->lookupQueries += nQ;
+        if ((rc = timer_end(c, c->kernels[KASA_KERNEL_LOOKUP], ka, kb))) return rc;
         tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)nQ);
         HIPCHK(hipGetLastError());
     }
@@ -2780,7 +2778,10 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
         const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
         const int cov = coverage && attempt == 0;
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
+        hipEvent_t ka, kb;
+        if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;
         if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, cov, cursor) : launch_group<16>(c, slotOf, nTiles, cap, cov, cursor)))) return rc;
+        if ((rc = timer_end(c, c->kernels[KASA_KERNEL_GROUP], ka, kb))) return rc;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
         unsigned long long used = 0;
         HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2890,18 +2891,18 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             A.otherOff64 = c->plist.as<uint32_t>();
             A.workCursor = counters + 6;
             HIPCHK(hipMemsetAsync(counters + 6, 0, 4, c->stream));
-            if ((rc = timer_begin(c, c->scoreKernel, &c->skA, &c->skB))) return rc;
             const unsigned oblocks = std::min<unsigned>(blocks_for(nQ, 256), 256u * 64u);
-            if (wantPerRead) {
-                if (RW == 8) { score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); }
-                else { score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
-            } else {
-                if (RW == 8) { score_main_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); }
-                else { score_main_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A); score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
-            }
+            hipEvent_t ka, kb;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_MAIN], &ka, &kb))) return rc;
+            if (wantPerRead) { if (RW == 8) score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); }
+            else { if (RW == 8) score_main_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A); }
             HIPCHK(hipGetLastError());
-            if ((rc = timer_end(c, c->scoreKernel, c->skA, c->skB))) return rc;
-            c->scoreQueries += nQ;
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_MAIN], ka, kb))) return rc;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_OTHER], &ka, &kb))) return rc;
+            if (wantPerRead) { if (RW == 8) score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
+            else { if (RW == 8) score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
+            HIPCHK(hipGetLastError());
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_OTHER], ka, kb))) return rc;
             uint32_t h3 = 0; unsigned long long want[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(&h3, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(want, stCursor, 16, hipMemcpyDeviceToHost, c->stream));
@@ -2990,6 +2991,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         if ((rc = c->profSorted.reserve((size_t)nKeys * 8 + 64))) return rc;   // nKeys < 2^32; profKeys holds keyCap >= nKeys entries
+        hipEvent_t ka, kb;
+        if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_ROW_MERGE], &ka, &kb))) return rc;
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
@@ -3003,6 +3006,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(),
                 c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, PL);
         HIPCHK(hipGetLastError());
+        if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
+        c->lastStaged = staged; c->lastKeys = nKeys;
         if (nKeys > 0) {
             size_t tmpBytes = 0;
             HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)nKeys, 16u, 16u + PL.bits(), c->stream));
@@ -3259,27 +3264,22 @@ extern "C" int kasa_ctx_stage_ms(kasa_ctx *c, int stage, double *ms, uint64_t *l
     return KASA_OK;
 }
 
-extern "C" int kasa_ctx_lookup_kernel_ms(kasa_ctx *c, double *ms, uint64_t *launches, uint64_t *queries)
+extern "C" int kasa_ctx_kernel_ms(kasa_ctx *c, int kernel, double *ms, uint64_t *launches)
 {
-    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (!c || kernel < 0 || kernel >= KASA_KERNEL_COUNT) return fail(KASA_E_ARG, "kasa_ctx_kernel_ms: bad argument");
     HIPCHK(hipSetDevice(c->ix->device));
-    int rc = timer_resolve(c->lookupKernel);
+    int rc = timer_resolve(c->kernels[kernel]);
     if (rc) return rc;
-    if (ms) *ms = c->lookupKernel.ms;
-    if (launches) *launches = c->lookupKernel.launches;
-    if (queries) *queries = c->lookupQueries;
+    if (ms) *ms = c->kernels[kernel].ms;
+    if (launches) *launches = c->kernels[kernel].launches;
     return KASA_OK;
 }
 
-extern "C" int kasa_ctx_score_kernel_ms(kasa_ctx *c, double *ms, uint64_t *launches, uint64_t *queries)
+extern "C" int kasa_ctx_batch_stats(kasa_ctx *c, uint64_t *stats)
 {
-    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
-    HIPCHK(hipSetDevice(c->ix->device));
-    int rc = timer_resolve(c->scoreKernel);
-    if (rc) return rc;
-    if (ms) *ms = c->scoreKernel.ms;
-    if (launches) *launches = c->scoreKernel.launches;
-    if (queries) *queries = c->scoreQueries;
+    if (!c || !stats) return fail(KASA_E_ARG, "kasa_ctx_batch_stats: NULL argument");
+    stats[0] = c->nQ; stats[1] = c->lastStaged; stats[2] = c->lastKeys; stats[3] = c->poolUsed;
+    stats[4] = c->lastSlowReads; stats[5] = c->lastOverflowReads; stats[6] = c->nnz; stats[7] = c->payloadIsSlot ? 1 : 0;
     return KASA_OK;
 }
 
@@ -3288,10 +3288,7 @@ extern "C" int kasa_ctx_stage_reset(kasa_ctx *c)
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     HIPCHK(hipSetDevice(c->ix->device));
     for (auto &t : c->timers) { int rc = timer_resolve(t); if (rc) return rc; t.ms = 0; t.launches = 0; }
-    int rc = timer_resolve(c->lookupKernel); if (rc) return rc;
-    c->lookupKernel.ms = 0; c->lookupKernel.launches = 0; c->lookupQueries = 0;
-    rc = timer_resolve(c->scoreKernel); if (rc) return rc;
-    c->scoreKernel.ms = 0; c->scoreKernel.launches = 0; c->scoreQueries = 0;
+    for (auto &t : c->kernels) { int rc = timer_resolve(t); if (rc) return rc; t.ms = 0; t.launches = 0; }
     return KASA_OK;
 }
 

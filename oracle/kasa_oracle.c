@@ -652,3 +652,143 @@ double ko_error_score(float bestScore, float kmerScore)
     const float e = (bestScore - kmerScore) / bestScore;
     return (double)e;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * The batch with the reference's threading model (-n): for bench.py's cpu_baseline.
+ * Compare.hpp:3107-3124 + Read.hpp:763-827: reads split over the worker threads for translation;
+ * Compare.hpp:1123-1132: parallel sort of the queries (here: stable bucket pass on the top byte, buckets sorted by the
+ * threads); Compare.hpp:1098-1117: ranges per thread; Compare.hpp:3263-3283: the sorted queries cut into one slice per
+ * thread on prefix-range boundaries, every thread merges its slice with PRIVATE count tables (:922) into the SHARED
+ * score matrix (unsynchronised `+=`, as in the reference: per-read floats may differ in their last digits between
+ * runs); Compare.hpp:3445-3454: the count tables summed.
+ * ------------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+
+typedef struct {
+    const ko_params *p; const ko_index *ix; const uint8_t *bases; const int64_t *off; const uint8_t *lut;
+    int nThreads, tid;
+    int64_t r0, r1;               /* reads of this thread */
+    int64_t *kcount;              /* k-mers per thread */
+    ko_key *km, *km2; uint32_t *rd, *rd2; uint64_t nQ; uint64_t *koff;   /* koff[t] = first query of thread t */
+    uint64_t *hist;               /* [nThreads][256] */
+    uint64_t *bucketStart;        /* [257] */
+    volatile int *nextBucket;
+    uint64_t *rs; uint32_t *rl;
+    uint64_t s0, s1;              /* slice of the sorted queries */
+    uint64_t nReads; double *ca; uint64_t *cu, *ct; float *M;
+    pthread_barrier_t *bar;
+    uint64_t *cuts;
+} ko_job;
+
+static int key_top_byte(ko_key k, int K) { return (int)((k >> (5 * K - 8)) & 255); }
+
+static void *ko_worker(void *arg)
+{
+    ko_job *j = (ko_job *)arg;
+    const int T = j->nThreads, t = j->tid;
+    /* 1. translate my reads */
+    const int64_t n = j->r1 - j->r0;
+    j->kcount[t] = n > 0 ? ko_encode_batch(j->bases, j->off + j->r0, n, j->p, j->lut, NULL, NULL) : 0;
+    pthread_barrier_wait(j->bar);
+    if (t == 0) { uint64_t run = 0; for (int i = 0; i < T; ++i) { j->koff[i] = run; run += (uint64_t)j->kcount[i]; } j->koff[T] = run; }
+    pthread_barrier_wait(j->bar);
+    const uint64_t q0 = j->koff[t], q1 = j->koff[t + 1];
+    if (n > 0) {
+        ko_encode_batch(j->bases, j->off + j->r0, n, j->p, j->lut, j->km + q0, j->rd + q0);
+        for (uint64_t i = q0; i < q1; ++i) j->rd[i] += (uint32_t)j->r0;
+    }
+    /* 2. parallel sort: stable bucket pass on the top byte, then the buckets */
+    uint64_t *h = j->hist + (size_t)t * 256;
+    memset(h, 0, 256 * sizeof(uint64_t));
+    for (uint64_t i = q0; i < q1; ++i) ++h[key_top_byte(j->km[i], j->p->K)];
+    pthread_barrier_wait(j->bar);
+    if (t == 0) {
+        uint64_t run = 0;
+        for (int b = 0; b < 256; ++b) {
+            j->bucketStart[b] = run;
+            for (int i = 0; i < T; ++i) { const uint64_t c = j->hist[(size_t)i * 256 + b]; j->hist[(size_t)i * 256 + b] = run; run += c; }
+        }
+        j->bucketStart[256] = run;
+    }
+    pthread_barrier_wait(j->bar);
+    for (uint64_t i = q0; i < q1; ++i) { const uint64_t d = h[key_top_byte(j->km[i], j->p->K)]++; j->km2[d] = j->km[i]; j->rd2[d] = j->rd[i]; }
+    pthread_barrier_wait(j->bar);
+    for (;;) {
+        const int b = __sync_fetch_and_add(j->nextBucket, 1);
+        if (b >= 256) break;
+        const uint64_t a = j->bucketStart[b], e = j->bucketStart[b + 1];
+        if (e > a) ko_sort_queries(j->km2 + a, j->rd2 + a, e - a);
+    }
+    pthread_barrier_wait(j->bar);
+    /* 3. ranges of my share */
+    const uint64_t nQ = j->nQ, a = nQ * (uint64_t)t / (uint64_t)T, e = nQ * (uint64_t)(t + 1) / (uint64_t)T;
+    if (e > a) ko_ranges(j->ix, j->p, j->km2 + a, e - a, j->rs + a, j->rl + a);
+    pthread_barrier_wait(j->bar);
+    /* 4. slices on range boundaries (Compare.hpp:3263-3283), private tables, shared matrix */
+    if (t == 0) {
+        j->cuts[0] = 0;
+        for (int i = 1; i < T; ++i) {
+            uint64_t c = nQ * (uint64_t)i / (uint64_t)T;
+            if (c < j->cuts[i - 1]) c = j->cuts[i - 1];
+            while (c > 0 && c < nQ && j->rs[c] == j->rs[c - 1] && j->rs[c] != KO_RANGE_NONE) ++c;
+            j->cuts[i] = c;
+        }
+        j->cuts[T] = nQ;
+    }
+    pthread_barrier_wait(j->bar);
+    const uint64_t s0 = j->cuts[t], s1 = j->cuts[t + 1];
+    if (s1 > s0)
+        ko_compare_sequential(j->p, j->ix, j->km2 + s0, j->rd2 + s0, j->rs + s0, j->rl + s0, s1 - s0, j->nReads, j->ca, j->cu, j->ct, j->M);
+    return NULL;
+}
+
+int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *bases, const int64_t *off, int64_t nReads,
+                         const uint8_t lut[366], int nThreads, double *countAll, uint64_t *countUnique, float *M, uint64_t *nQueries)
+{
+    if (nThreads < 1) nThreads = 1;
+    const int T = nThreads;
+    const int64_t total = ko_encode_batch(bases, off, nReads, p, lut, NULL, NULL);   /* sizes only (the reference knows them from its info pass) */
+    const uint64_t nQ = (uint64_t)total;
+    const int nK = p->kHigh - p->kLow + 1;
+    const size_t cells = (size_t)nK * ix->nTaxa;
+    ko_key *km = (ko_key *)malloc((nQ + 1) * sizeof(ko_key)), *km2 = (ko_key *)malloc((nQ + 1) * sizeof(ko_key));
+    uint32_t *rd = (uint32_t *)malloc((nQ + 1) * 4), *rd2 = (uint32_t *)malloc((nQ + 1) * 4), *rl = (uint32_t *)malloc((nQ + 1) * 4);
+    uint64_t *rs = (uint64_t *)malloc((nQ + 1) * 8);
+    int64_t *kcount = (int64_t *)calloc((size_t)T, 8);
+    uint64_t *koff = (uint64_t *)calloc((size_t)T + 1, 8), *hist = (uint64_t *)calloc((size_t)T * 256, 8), *cuts = (uint64_t *)calloc((size_t)T + 1, 8);
+    uint64_t bucketStart[257];
+    double *ca = (double *)calloc(cells * (size_t)T, 8);
+    uint64_t *cu = (uint64_t *)calloc(cells * (size_t)T, 8), *ct = (uint64_t *)calloc(cells * (size_t)T, 8);
+    float *Mloc = M ? M : (float *)calloc((size_t)nReads * ix->nTaxa, 4);
+    ko_job *jobs = (ko_job *)calloc((size_t)T, sizeof(ko_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    volatile int nextBucket = 0;
+    int rc = -1;
+    if (km && km2 && rd && rd2 && rl && rs && kcount && koff && hist && cuts && ca && cu && ct && Mloc && jobs && th) {
+        pthread_barrier_init(&bar, NULL, (unsigned)T);
+        for (int t = 0; t < T; ++t) {
+            ko_job *j = &jobs[t];
+            j->p = p; j->ix = ix; j->bases = bases; j->off = off; j->lut = lut; j->nThreads = T; j->tid = t;
+            j->r0 = nReads * t / T; j->r1 = nReads * (t + 1) / T;
+            j->kcount = kcount; j->km = km; j->km2 = km2; j->rd = rd; j->rd2 = rd2; j->nQ = nQ; j->koff = koff;
+            j->hist = hist; j->bucketStart = bucketStart; j->nextBucket = &nextBucket; j->rs = rs; j->rl = rl;
+            j->nReads = (uint64_t)nReads; j->ca = ca + cells * (size_t)t; j->cu = cu + cells * (size_t)t; j->ct = ct + cells * (size_t)t;
+            j->M = Mloc; j->bar = &bar; j->cuts = cuts;
+            pthread_create(&th[t], NULL, ko_worker, j);
+        }
+        for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&bar);
+        for (size_t i = 0; i < cells; ++i) {                       /* Compare.hpp:3445-3454 */
+            double a = 0; uint64_t u = 0;
+            for (int t = 0; t < T; ++t) { a += ca[cells * (size_t)t + i]; u += cu[cells * (size_t)t + i]; }
+            if (countAll) countAll[i] = a;
+            if (countUnique) countUnique[i] = u;
+        }
+        if (nQueries) *nQueries = nQ;
+        rc = 0;
+    }
+    free(km); free(km2); free(rd); free(rd2); free(rl); free(rs); free(kcount); free(koff); free(hist); free(cuts);
+    free(ca); free(cu); free(ct); if (!M) free(Mloc); free(jobs); free(th);
+    return rc;
+}

@@ -100,6 +100,13 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key 
                            const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
                            double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);
 
+/* The whole batch with the reference's threading model (-n worker threads; Read.hpp:763-827, Compare.hpp:1123-1132,
+ * :3263-3283, :3445-3454): translation per read chunk, parallel sort, lookup + score over range-aligned slices with
+ * private count tables and the shared, unsynchronised score matrix.  For bench.py's cpu_baseline.  countAll /
+ * countUnique / M may be NULL. */
+int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *bases, const int64_t *off, int64_t nReads,
+                         const uint8_t lut[366], int nThreads, double *countAll, uint64_t *countUnique, float *M, uint64_t *nQueries);
+
 /* Compare.hpp:1452-1481 */
 float ko_best_score(uint64_t readLen, const ko_params *p);
 /* Compare.hpp:1510 -- relative score of one (read, taxon) cell. */

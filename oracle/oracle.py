@@ -184,6 +184,24 @@ def identify_batch(ix, bases, offsets, p: Params, want_reads=True, closed_form=F
     return res, n_in
 
 
+def identify_threaded(iv: IndexView, bases, offsets, p: Params, threads: int, want_tables: bool = False, lut=None):
+    """The whole batch with the reference's threading model (ko_identify_threaded): for bench.py's cpu_baseline.
+    -> (countAll, countUnique, nQueries) when want_tables, else nQueries."""
+    L = lib(p.K)
+    lut = codon_table() if lut is None else lut
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.shape[0] - 1
+    nK = p.kHigh - p.kLow + 1
+    ca = np.zeros((nK, iv.n_taxa), dtype=np.float64) if want_tables else None
+    cu = np.zeros((nK, iv.n_taxa), dtype=np.uint64) if want_tables else None
+    nq = C.c_uint64(0)
+    rc = L.ko_identify_threaded(C.byref(p), C.byref(iv.c), _p(bases), _p(offsets), C.c_int64(n), _p(lut), C.c_int(int(threads)),
+                                _p(ca) if want_tables else None, _p(cu) if want_tables else None, None, C.byref(nq))
+    assert rc == 0
+    return (ca, cu, int(nq.value)) if want_tables else int(nq.value)
+
+
 def best_score(length: int, p: Params) -> np.float32:
     return np.float32(lib(p.K).ko_best_score(C.c_uint64(int(length)), C.byref(p)))
 

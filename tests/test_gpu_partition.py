@@ -121,3 +121,24 @@ def test_two_ranks_one_partition_each(tmp_path):
     assert np.array_equal(cu_r, total[1])
     np.testing.assert_allclose(ca_r, total[0], rtol=1e-12)
     dix.close()
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (fresh processes, before
+    anything touches a GPU) and rank 0 prints the one JSON line.  On a one-GPU box both ranks share device 0 and the
+    reduce runs over gloo (KASA_BENCH_SHARE_GPU=1: the multi-rank code path, not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    assert capi.device_count() > 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KASA_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "20000",
+                        "--taxa", "8", "--genome-len", "20000", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["kernel"]

@@ -56,3 +56,22 @@ def test_closed_form_equals_sequential(seed):
     c = oracle.compare(iv, p, q, rd, rs, rl, n_reads, False, closed_form=False)
     assert np.array_equal(a.count_unique, c.count_unique)
     assert np.array_equal(a.count_all.view(np.uint64), c.count_all.view(np.uint64))
+
+
+def test_threaded_batch_equals_the_single_threaded_one():
+    """ko_identify_threaded (bench.py's cpu_baseline: the reference's -n threading model) computes the same profile as
+    the plain sequence encode -> sort -> ranges -> compare; per-read floats are racy there as in the reference, so only
+    the order-independent tables are compared."""
+    import os
+    from kasa_amd import reads
+    from tests import helpers
+    d, ix = helpers.load_case("pairs")
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    p = oracle.params(12, 7, 3)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    iv = oracle.IndexView(ix)
+    for threads in (1, 3, 8):
+        ca, cu, n = oracle.identify_threaded(iv, batch.bases, batch.offsets, p, threads, want_tables=True)
+        assert n == nq
+        assert np.array_equal(cu, res.count_unique)
+        np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
