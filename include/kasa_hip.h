@@ -152,9 +152,15 @@ int kasa_profile_reset(kasa_ctx *ctx);
 int kasa_profile_fetch(kasa_ctx *ctx, double *countAll, uint64_t *countUnique, uint64_t *countTotal);
 /* The same tables as 6 integer limbs per cell {unique, total, all[0..3] (32 bits each, little
  * endian)} so that ranks can be summed with a plain integer reduce (the thread reduce of
- * Compare.hpp:3445-3454 across GPUs); import adds limbs back in. */
+ * Compare.hpp:3445-3454 across GPUs); import REPLACES the context's tables by the limbs handed in
+ * (the sum over all ranks, after the reduce). */
 int kasa_profile_export_limbs(kasa_ctx *ctx, uint64_t *limbs);
 int kasa_profile_import_limbs(kasa_ctx *ctx, const uint64_t *limbs);
+/* The whole reduce on the device: limbs packed in HBM, ONE ncclAllReduce (u64, sum; exact and order-independent) on
+ * the context's stream over the communicator handed in (an ncclComm_t of RCCL, passed as void * so that this header
+ * needs no RCCL include), carries folded back.  Afterwards every rank's tables hold the global sums.  Collective:
+ * every rank of the communicator must call it. */
+int kasa_profile_allreduce(kasa_ctx *ctx, void *rcclComm);
 
 /* ---- measurement + test taps ------------------------------------------------------------------ */
 /* HIP-event time (ms) and launch count of a stage, accumulated since the last reset. */

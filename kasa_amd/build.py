@@ -24,7 +24,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-result", "-o", SO, SRC] + HOST_SRCS
+           "-Wall", "-Wno-unused-result", "-o", SO, SRC] + HOST_SRCS + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return SO
 
@@ -39,7 +39,7 @@ def build_host(force: bool = False) -> str:
     newest = max(os.path.getmtime(p) for p in (HOST_SRC, HEADER, os.path.join(HERE, "host", "grisu_powers.inc")))
     if not force and os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) >= newest:
         return HOST_BIN
-    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", HOST_BIN, HOST_SRC, "-L" + HERE, "-lkasa_hip", "-lz",
+    cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", HOST_BIN, HOST_SRC, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L" + HERE, "-lkasa_hip", "-lz", "-L/opt/rocm/lib", "-lrccl",
            "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return HOST_BIN

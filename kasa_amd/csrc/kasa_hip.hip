@@ -32,6 +32,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/kasa_hip.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -69,6 +71,13 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *kasa_last_error(void) { return g_err.c_str(); }
+
+// No C++ exception crosses the C boundary (include/kasa_hip.h): entry points that allocate host memory run under this guard.
+#define KASA_GUARDED(call)                                                                          \
+    try { return (call); }                                                                          \
+    catch (const std::bad_alloc &) { return fail(KASA_E_NOMEM, "host allocation failed"); }         \
+    catch (const std::exception &e_) { return fail(KASA_E_ARG, "%s", e_.what()); }                  \
+    catch (...) { return fail(KASA_E_HIP, "unexpected exception"); }
 
 extern "C" int kasa_device_count(int *count)
 {
@@ -288,8 +297,8 @@ extern "C" int kasa_index_create(int device, const void *records, uint64_t nReco
         if (i != nRecords) return fail(KASA_E_ARG, "kasa_index_create: the trie file counts %llu entries, the index has %llu", (unsigned long long)i, (unsigned long long)nRecords);
         return kasa_index_create(device, full.data(), nRecords, 12, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
     }
-    if (recordBytes == 20) return index_create_impl<key128>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
-    if (recordBytes == 12) return index_create_impl<uint64_t>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out);
+    if (recordBytes == 20) { KASA_GUARDED(index_create_impl<key128>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out)) }
+    if (recordBytes == 12) { KASA_GUARDED(index_create_impl<uint64_t>(device, records, nRecords, triePrefix, trieCount, nTrie, taxIds, nTaxa, out)) }
     return fail(KASA_E_ARG, "kasa_index_create: records are 12 bytes {u64 kmer, u32 taxid}, 20 bytes {u64 low, u64 high, u32 taxid} (k <= 25) or 6 bytes (halved), got %d", recordBytes);
 }
 
@@ -693,14 +702,14 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
 
 extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
 {
-    return upload_impl(c, bases, offsets, nReads, nullptr, nReads);
+    KASA_GUARDED(upload_impl(c, bases, offsets, nReads, nullptr, nReads))
 }
 
 extern "C" int kasa_batch_upload_segments(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSegments,
                                           const uint32_t *segmentRead, int64_t nReads)
 {
     if (nSegments > 0 && !segmentRead) return fail(KASA_E_ARG, "kasa_batch_upload_segments: segmentRead is NULL");
-    return upload_impl(c, bases, offsets, nSegments, segmentRead, nReads);
+    KASA_GUARDED(upload_impl(c, bases, offsets, nSegments, segmentRead, nReads))
 }
 
 // One wavefront per read.  The cleaned bases of a window chunk are staged in LDS as 3-bit codes, the
@@ -3200,7 +3209,7 @@ static int fetch_tables(kasa_ctx *c, std::vector<uint64_t> &u, std::vector<uint6
     return KASA_OK;
 }
 
-extern "C" int kasa_profile_fetch(kasa_ctx *c, double *countAll, uint64_t *countUnique, uint64_t *countTotal)
+static int profile_fetch_impl(kasa_ctx *c, double *countAll, uint64_t *countUnique, uint64_t *countTotal)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     std::vector<uint64_t> u, t, hi, lo;
@@ -3214,7 +3223,12 @@ extern "C" int kasa_profile_fetch(kasa_ctx *c, double *countAll, uint64_t *count
     return KASA_OK;
 }
 
-extern "C" int kasa_profile_export_limbs(kasa_ctx *c, uint64_t *limbs)
+extern "C" int kasa_profile_fetch(kasa_ctx *c, double *countAll, uint64_t *countUnique, uint64_t *countTotal)
+{
+    KASA_GUARDED(profile_fetch_impl(c, countAll, countUnique, countTotal))
+}
+
+static int profile_export_limbs_impl(kasa_ctx *c, uint64_t *limbs)
 {
     if (!c || !limbs) return fail(KASA_E_ARG, "kasa_profile_export_limbs: NULL argument");
     std::vector<uint64_t> u, t, hi, lo;
@@ -3228,7 +3242,12 @@ extern "C" int kasa_profile_export_limbs(kasa_ctx *c, uint64_t *limbs)
     return KASA_OK;
 }
 
-extern "C" int kasa_profile_import_limbs(kasa_ctx *c, const uint64_t *limbs)
+extern "C" int kasa_profile_export_limbs(kasa_ctx *c, uint64_t *limbs)
+{
+    KASA_GUARDED(profile_export_limbs_impl(c, limbs))
+}
+
+static int profile_import_limbs_impl(kasa_ctx *c, const uint64_t *limbs)
 {
     if (!c || !limbs) return fail(KASA_E_ARG, "kasa_profile_import_limbs: NULL argument");
     HIPCHK(hipSetDevice(c->ix->device));
@@ -3247,6 +3266,58 @@ extern "C" int kasa_profile_import_limbs(kasa_ctx *c, const uint64_t *limbs)
     for (size_t i = 0; i < cells; ++i) { mid[i] = lo[i] >> 32; lo[i] &= 0xFFFFFFFFull; }
     HIPCHK(hipMemcpy(c->cntAllLo.p, lo.data(), cells * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->cntAllMid.p, mid.data(), cells * 8, hipMemcpyHostToDevice));
+    return KASA_OK;
+}
+
+extern "C" int kasa_profile_import_limbs(kasa_ctx *c, const uint64_t *limbs)
+{
+    KASA_GUARDED(profile_import_limbs_impl(c, limbs))
+}
+
+// ---- the multi-GPU reduce of the profile tables (Compare.hpp:3445-3454 across devices) -----------------------------
+// Every cell leaves as six u64 limbs {unique, total, all[0..3] (32 bits each)}; integer sums of limbs are exact and
+// independent of the order in which ranks arrive, so one ncclAllReduce(u64, sum) over xGMI gives every rank the same
+// global tables; the carries are folded back on the device.
+__global__ void limbs_pack_kernel(const uint64_t *__restrict__ u, const uint64_t *__restrict__ t, const uint64_t *__restrict__ hi,
+                                  const uint64_t *__restrict__ mid, const uint64_t *__restrict__ lo, size_t cells, uint64_t *__restrict__ limbs)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const unsigned __int128 v = ((unsigned __int128)hi[i] << 64) + ((unsigned __int128)mid[i] << 32) + lo[i];
+    uint64_t *o = limbs + i * 6;
+    o[0] = u[i]; o[1] = t[i];
+    o[2] = (uint64_t)v & 0xFFFFFFFFull; o[3] = (uint64_t)(v >> 32) & 0xFFFFFFFFull;
+    o[4] = (uint64_t)(v >> 64) & 0xFFFFFFFFull; o[5] = (uint64_t)(v >> 96);
+}
+
+__global__ void limbs_unpack_kernel(const uint64_t *__restrict__ limbs, size_t cells, uint64_t *__restrict__ u, uint64_t *__restrict__ t,
+                                    uint64_t *__restrict__ hi, uint64_t *__restrict__ mid, uint64_t *__restrict__ lo)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const uint64_t *o = limbs + i * 6;
+    const unsigned __int128 v = (unsigned __int128)o[2] + ((unsigned __int128)o[3] << 32) + ((unsigned __int128)o[4] << 64) + ((unsigned __int128)o[5] << 96);
+    u[i] = o[0]; t[i] = o[1];
+    hi[i] = (uint64_t)(v >> 64); mid[i] = (uint64_t)v >> 32; lo[i] = (uint64_t)v & 0xFFFFFFFFull;
+}
+
+extern "C" int kasa_profile_allreduce(kasa_ctx *c, void *rcclComm)
+{
+    if (!c || !rcclComm) return fail(KASA_E_ARG, "kasa_profile_allreduce: NULL argument");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const size_t cells = (size_t)c->nK * c->ix->nTaxa;
+    int rc = c->profSorted.reserve(cells * 6 * 8 + 64);                 // (free between batches)
+    if (rc) return rc;
+    uint64_t *limbs = c->profSorted.as<uint64_t>();
+    limbs_pack_kernel<<<blocks_for(cells, 256), 256, 0, c->stream>>>(c->cntUnique.as<uint64_t>(), c->cntTotal.as<uint64_t>(), c->cntAllHi.as<uint64_t>(),
+        c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), cells, limbs);
+    HIPCHK(hipGetLastError());
+    const ncclResult_t nr = ncclAllReduce(limbs, limbs, cells * 6, ncclUint64, ncclSum, static_cast<ncclComm_t>(rcclComm), c->stream);
+    if (nr != ncclSuccess) return fail(KASA_E_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(nr));
+    limbs_unpack_kernel<<<blocks_for(cells, 256), 256, 0, c->stream>>>(limbs, cells, c->cntUnique.as<uint64_t>(), c->cntTotal.as<uint64_t>(),
+        c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
     return KASA_OK;
 }
 
@@ -3323,7 +3394,7 @@ extern "C" int kasa_batch_fetch_queries(kasa_ctx *c, void *kmers, uint32_t *read
     return KASA_OK;
 }
 
-extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
+static int batch_set_queries_impl(kasa_ctx *c, const void *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
@@ -3351,6 +3422,11 @@ extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint
     c->qKmer = c->qKmerA.p; c->qRead = c->qReadA.as<uint32_t>();
     c->state = 2;
     return KASA_OK;
+}
+
+extern "C" int kasa_batch_set_queries(kasa_ctx *c, const void *kmers, const uint32_t *reads, uint64_t n, int64_t nReads)
+{
+    KASA_GUARDED(batch_set_queries_impl(c, kmers, reads, n, nReads))
 }
 
 extern "C" int kasa_batch_fetch_lookup(kasa_ctx *c, uint8_t *depth, uint32_t *indexPos, uint64_t n)

@@ -6,8 +6,16 @@
 // (source/modes/Compare.hpp:2733) does per batch on the CPU is delegated to libkasa_hip.so; everything in this
 // file is host logic: argument parsing, file formats, FASTA/FASTQ reading, ranking, text.
 //
+// Modes: identify and identify_multiple (main.cpp:979-1334); --devices a,b,... shards the batches of a file over several GPUs
+// (index replicated, one RCCL all-reduce of the profile tables).  Input is streamed in chunks, batches are cut where the
+// reference cuts them (-m) and parsed / computed / written in a pipeline.
 // Not supported here (reported as errors, never silently ignored): --coherence/--visualize.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -25,11 +33,14 @@
 #include <tuple>
 #include <vector>
 
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include <rccl/rccl.h>
 
 #include "../../include/kasa_hip.h"
 
@@ -338,9 +349,107 @@ static ReadSet readInput(const string &path, bool verbose, unsigned threads)
 // ---------------------------------------------------------------------------------------------------
 // ranking + text (Compare.hpp:1452-1890) and profile (Compare.hpp:3466-3665)
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// input: streamed in chunks of whole records (N1) -- never the whole file in memory
+// ---------------------------------------------------------------------------------------------------
+// Reads a FASTA/FASTQ(.gz) file block by block (gz members inflate as they come) and hands out chunks that end at a record
+// boundary; a chunk is parsed by all host threads (parseRecords over runs cut at safe record starts).
+struct ChunkReader {
+    gzFile g = nullptr;
+    string carry;
+    bool fasta = false, protein = false, eof = false, first = true;
+    size_t blockBytes = 64u << 20;
+    explicit ChunkReader(const string &path)
+    {
+        g = gzopen(path.c_str(), "rb");
+        if (!g) throw std::runtime_error("Input file not found");
+        gzbuffer(g, 1u << 20);
+        if (const char *e = getenv("KASA_READ_BLOCK")) blockBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small blocks
+    }
+    ~ChunkReader() { if (g) gzclose(g); }
+    // next chunk of whole records ("" at the end of the file)
+    bool next(string &chunk, bool verbose)
+    {
+        chunk.clear();
+        while (!eof) {
+            string data = std::move(carry);
+            carry.clear();
+            const size_t had = data.size();
+            data.resize(had + blockBytes);
+            size_t got = 0;
+            while (got < blockBytes) {
+                const int n = gzread(g, &data[had + got], (unsigned)std::min<size_t>(blockBytes - got, 1u << 30));
+                if (n <= 0) { eof = true; break; }
+                got += (size_t)n;
+            }
+            data.resize(had + got);
+            if (first && !data.empty()) {
+                if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
+                fasta = data[0] == '>';
+                protein = detectProtein(data, verbose);
+                first = false;
+            }
+            if (eof) { chunk = std::move(data); return !chunk.empty(); }
+            // cut at the last safe record start; what follows waits for the next block
+            size_t cut = string::npos, from = data.size() > (4u << 20) ? data.size() - (4u << 20) : 0;
+            for (;;) {
+                const size_t p = findRecordStart(data, from, fasta);
+                if (p == string::npos) break;
+                cut = p; from = p;
+            }
+            if (cut == string::npos || cut == 0) { carry = std::move(data); continue; }   // no boundary in sight: keep reading
+            carry.assign(data, cut, string::npos);
+            data.resize(cut);
+            chunk = std::move(data);
+            return true;
+        }
+        if (!carry.empty()) { chunk = std::move(carry); carry.clear(); return true; }
+        return false;
+    }
+};
+
+// a chunk of whole records parsed by several threads, appended to `out`
+static void parseChunk(const string &data, bool fasta, unsigned threads, ReadSet &out)
+{
+    size_t minRun = 8u << 20;
+    if (const char *e = getenv("KASA_PARSE_CHUNK")) minRun = std::max<size_t>(1, (size_t)atoll(e));   // tests force small runs
+    const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, data.size() / minRun));
+    vector<size_t> cut{0};
+    for (size_t c = 1; c < want; ++c) {
+        const size_t p = findRecordStart(data, std::max(cut.back(), data.size() / want * c), fasta);
+        if (p != string::npos && p > cut.back()) cut.push_back(p);
+    }
+    cut.push_back(data.size());
+    const size_t nc = cut.size() - 1;
+    vector<ReadSet> part(nc);
+    if (nc == 1) parseRecords(data, 0, data.size(), fasta, part[0]);
+    else {
+        vector<std::exception_ptr> err(nc);
+        vector<std::thread> pool;
+        for (size_t c = 0; c < nc; ++c)
+            pool.emplace_back([&, c] { try { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); } catch (...) { err[c] = std::current_exception(); } });
+        for (auto &t : pool) t.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
+    }
+    for (auto &q : part) {
+        const int64_t b0 = (int64_t)out.bases.size();
+        out.bases.insert(out.bases.end(), q.bases.begin(), q.bases.end());
+        for (size_t r = 0; r < q.names.size(); ++r) {
+            out.names.push_back(std::move(q.names[r]));
+            out.lengths.push_back(q.lengths[r]);
+            out.off.push_back(b0 + q.off[r + 1]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one input file (CompareWithLib_partialSort, Compare.hpp:2733-3766) over one or several devices
+// ---------------------------------------------------------------------------------------------------
 struct Params {
+    string mode = "identify";
     string content, index, input, input2, rtt, profile;   // input2: second file of paired-end input (-1 / -2)
-    int kHigh = 12, kLow = 7, beasts = 3, frames = 3, device = 0, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
+    int kHigh = 12, kLow = 7, beasts = 3, frames = 3, K = 12;   // K: letters per index k-mer (25 for a 128-bit index)
+    vector<int> devices{0};                      // --device d / --devices a,b,...: read shards go to the devices in turn (index replicated)
     bool kSetByUser = false;
     string codonFile, codonId;                   // -a/--alphabet <gc.prt> <id>
     bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
@@ -349,10 +458,21 @@ struct Params {
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
+    bool coherence = false; float coherenceThreshold = 0.f;
+};
+
+struct IndexFiles {                               // what Compare::ReadIndex loads (Compare.hpp:49-363), shared by every worker
+    Content content;
+    vector<uint64_t> freqAll, freq;
+    uint64_t nRec = 0; int recBytes = 12;
+    vector<uint32_t> tp; vector<uint64_t> tc;
+    vector<uint8_t> lut;
+    uint64_t nameBytes = 0;
+    vector<kasa_index *> onDevice;                // one immutable index object per device, shared by all contexts there
+    ~IndexFiles() { for (auto *ix : onDevice) kasa_index_destroy(ix); }
 };
 
 static float weightOf(int k) { return (float)(k * k) / 625.f; }
-
 static float bestScore(uint64_t len, const Params &p) // Compare.hpp:1452-1481
 {
     float best = 0.f;
@@ -593,6 +713,348 @@ static void filterReads(const Params &p, const vector<uint64_t> &flagged)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// the batch pipeline of one input file
+// ---------------------------------------------------------------------------------------------------
+struct Batch {
+    uint64_t id = 0, firstRead = 0;
+    ReadSet rs;                                   // the batch's reads (offsets start at 0)
+    vector<uint32_t> segRead;                     // paired-end: read of every sequence
+    string text;                                  // per-read output of the batch
+    vector<uint64_t> flagged;                     // --filter: read numbers of contaminants
+    uint64_t kmers = 0;
+    bool done = false;
+};
+
+// Cuts the reads of one input into batches.  With per-read output the batches are the reference's own: per-read scores
+// are float sums whose order depends on the reads sharing a batch, so the input is cut exactly where `kASA identify -m`
+// cuts it (kasa_refbatch_*: Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195).  A profile-only run
+// (boundaries do not matter there) and a reference batch that does not fit the device are cut by free HBM instead.
+struct Batcher {
+    const Params &p; const IndexFiles &ixf;
+    bool wantRows, paired;
+    std::unique_ptr<ChunkReader> reader;          // single-end input is streamed
+    ReadSet pending; size_t pendPos = 0;          // parsed reads not yet handed out
+    vector<uint32_t> pendSeg;                     // paired-end: the whole (merged) input sits in `pending`
+    uint64_t nextRead = 0, nextId = 0;
+    int64_t refBudget = 0; bool useRef = false, firstBatch = true, warned = false;
+    uint64_t maxKmersPerBatch;
+    double parseSeconds = 0;
+    bool protein = false;
+
+    Batcher(const Params &pp, const IndexFiles &f, bool rows, uint64_t maxKmers) : p(pp), ixf(f), wantRows(rows), paired(!pp.input2.empty()), maxKmersPerBatch(maxKmers)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (paired) {
+            // paired-end (Read.hpp:834-1049): mate r of both files forms read r; the two sequences stay separate (no k-mer
+            // spans the junction) but score into one row; specifier = both names, length = the sum
+            ReadSet r1 = readInput(p.input, p.verbose, p.threads), r2 = readInput(p.input2, false, p.threads);
+            if (r2.names.size() != r1.names.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
+            pending.protein = r1.protein;
+            for (size_t r = 0; r < r1.names.size(); ++r) {
+                for (const ReadSet *x : {&r1, &r2}) {
+                    pending.bases.insert(pending.bases.end(), x->bases.begin() + x->off[r], x->bases.begin() + x->off[r + 1]);
+                    pending.off.push_back((int64_t)pending.bases.size());
+                    pendSeg.push_back((uint32_t)r);
+                }
+                pending.names.push_back(r1.names[r] + r2.names[r]);
+                pending.lengths.push_back(r1.lengths[r] + r2.lengths[r]);
+            }
+            protein = pending.protein;
+        } else {
+            reader.reset(new ChunkReader(p.input));
+            refill();
+            protein = reader->protein;
+        }
+        parseSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (wantRows && !getenv("KASA_MAX_BATCH_KMERS")) {
+            kasa_refbatch_params bp{p.memoryGiB, p.refThreads, p.ram ? 1 : 0, p.kHigh, p.kLow, ixf.recBytes, ixf.nRec, ixf.tp.data(), ixf.tp.size(),
+                                    ixf.content.taxids.data(), (uint32_t)ixf.content.taxids.size(), ixf.nameBytes, p.mode == "identify_multiple" ? 1 : 0};
+            if (kasa_refbatch_budget(&bp, &refBudget)) throw std::runtime_error("batch budget could not be computed");
+            useRef = true;
+        }
+    }
+    size_t seqPerRead() const { return paired ? 2 : 1; }
+    size_t pendingReads() const { return pending.names.size() - pendPos; }
+    void refill()                                  // parse the next chunk of the file behind the pending reads
+    {
+        if (!reader) return;
+        if (pendPos > 0 && pendPos == pending.names.size()) { pending = ReadSet(); pendPos = 0; }
+        string chunk;
+        if (!reader->next(chunk, p.verbose)) return;
+        if (pendPos > 0) {                          // drop what was handed out, keep the rest
+            ReadSet rest;
+            const int64_t b0 = pending.off[pendPos];
+            rest.bases.assign(pending.bases.begin() + b0, pending.bases.end());
+            for (size_t r = pendPos; r < pending.names.size(); ++r) {
+                rest.names.push_back(std::move(pending.names[r])); rest.lengths.push_back(pending.lengths[r]);
+                rest.off.push_back(pending.off[r + 1] - b0);
+            }
+            pending = std::move(rest); pendPos = 0;
+        }
+        parseChunk(chunk, reader->fasta, p.threads, pending);
+    }
+    // the next batch; false at the end of the input
+    bool next(Batch &b)
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        b = Batch();
+        b.id = nextId++; b.firstRead = nextRead;
+        const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
+        const size_t spr = seqPerRead();
+        int64_t left = refBudget;
+        if (useRef && !firstBatch && refBudget - (int64_t)(refBudget * 0.001) > 0) left -= (int64_t)(refBudget * 0.001);   // Compare.hpp:3129-3132
+        uint64_t est = 0, n = 0;
+        bool deviceFull = false;
+        for (;;) {
+            if (pendingReads() == 0) { refill(); if (pendingReads() == 0) break; }
+            if (useRef && left <= 100ll * 1024 * 1024 && n > 0) break;                               // Read.hpp:1147
+            const size_t r = pendPos;
+            uint64_t len = 0;
+            int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), (uint32_t)ixf.content.taxids.size()) : 0;
+            for (size_t q = 0; q < spr; ++q) {
+                const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
+                len += (uint64_t)l;
+                if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l);
+            }
+            const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
+            if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; break; }
+            est += k; left -= cost; ++n;
+            // move the read into the batch
+            const int64_t s0 = pending.off[r * spr], s1 = pending.off[(r + 1) * spr];
+            const int64_t base = (int64_t)b.rs.bases.size();
+            b.rs.bases.insert(b.rs.bases.end(), pending.bases.begin() + s0, pending.bases.begin() + s1);
+            for (size_t q = 0; q < spr; ++q) { b.rs.off.push_back(base + pending.off[r * spr + q + 1] - s0); if (paired) b.segRead.push_back((uint32_t)(n - 1)); }
+            b.rs.names.push_back(std::move(pending.names[r]));
+            b.rs.lengths.push_back(pending.lengths[r]);
+            ++pendPos;
+        }
+        if (useRef && deviceFull && !warned) {
+            std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
+            warned = true;
+        }
+        firstBatch = false;
+        nextRead += n;
+        parseSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return n > 0;
+    }
+};
+
+// Everything one device does for one batch: upload -> encode -> sort -> lookup/score on the device (the calls
+// CompareWithLib_partialSort makes per batch, Compare.hpp:3107-3310), CSR back, ranking + text by all host threads (N2).
+static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText)
+{
+    const auto tDev = std::chrono::steady_clock::now();
+    auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    const uint64_t nr = b.rs.names.size();
+    if (b.segRead.empty()) { if (kasa_batch_upload(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)nr)) throwLast(); }
+    else if (kasa_batch_upload_segments(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)b.segRead.size(), b.segRead.data(), (int64_t)nr)) throwLast();
+    uint64_t nk = 0;
+    if (kasa_batch_encode(ctx, &nk)) throwLast();
+    if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
+    if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
+    b.kmers = nk;
+    if (!wantRows) { tDevice += secondsSince(tDev); return; }
+    uint64_t nnz = 0;
+    if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
+    vector<uint64_t> ro(nr + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
+    if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
+    tDevice += secondsSince(tDev);
+    const auto tTxt = std::chrono::steady_clock::now();
+    const uint64_t slab = 1u << 15;
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, (nr + slab - 1) / slab));
+    const uint64_t nSlabs = (nr + slab - 1) / slab;
+    vector<string> texts(nSlabs);
+    vector<vector<uint64_t>> flagged(nSlabs);
+    vector<std::exception_ptr> err(nt);
+    std::atomic<uint64_t> nextSlab{0};
+    auto work = [&](unsigned t) {
+        try {
+            Writer w(p, ixf.content, ixf.freq);
+            for (;;) {
+                const uint64_t sidx = nextSlab.fetch_add(1);
+                if (sidx >= nSlabs) break;
+                const uint64_t a = sidx * slab, e = std::min<uint64_t>(nr, a + slab);
+                string &text = texts[sidx];
+                text.reserve((size_t)(e - a) * 320);
+                for (uint64_t r = a; r < e; ++r) {
+                    w.read(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
+                    if (p.filter && w.lastContaminated) flagged[sidx].push_back(b.firstRead + r);
+                }
+            }
+        } catch (...) { err[t] = std::current_exception(); }
+    };
+    if (nt == 1) work(0);
+    else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+    size_t total = 0;
+    for (auto &t : texts) total += t.size();
+    b.text.reserve(total);
+    for (auto &t : texts) b.text += t;
+    for (auto &f : flagged) b.flagged.insert(b.flagged.end(), f.begin(), f.end());
+    tText += secondsSince(tTxt);
+}
+
+// One input file: batches are formed by this thread while the device workers (one per device, each with its own context
+// over the device's shared index) process the previous ones; per-read text leaves in batch order.  The profile tables of
+// the devices are summed with one RCCL all-reduce (kasa_profile_allreduce) before the CSV is written.
+static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &devSlots, const string &input, const string &input2,
+                         const string &rtt, const string &profile)
+{
+    p.input = input; p.input2 = input2; p.rtt = rtt; p.profile = profile;
+    const auto tStart = std::chrono::steady_clock::now();
+    const bool wantRows = !p.rtt.empty() || p.filter;
+    const size_t nDev = devSlots.size();
+    vector<kasa_ctx *> ctx(nDev, nullptr);
+    struct CtxGuard { vector<kasa_ctx *> &c; ~CtxGuard() { for (auto *x : c) kasa_ctx_destroy(x); } } guard{ctx};
+    for (size_t d = 0; d < nDev; ++d)
+        if (kasa_ctx_create(ixf.onDevice[(size_t)devSlots[d]], p.kHigh, p.kLow, p.frames, ixf.lut.empty() ? nullptr : ixf.lut.data(), &ctx[d])) throwLast();
+    // device batches: up to 2^32 k-mers, and what fits the HBM that is free next to the index
+    uint64_t maxKmersPerBatch = 3000000000ull;
+    {
+        uint64_t freeB = 0, totalB = 0;
+        if (kasa_device_memory(p.devices[(size_t)devSlots[0]], &freeB, &totalB)) throwLast();
+        const uint64_t per = kasa_batch_bytes_per_query(ctx[0]);
+        if (per) maxKmersPerBatch = std::max<uint64_t>(1u << 20, std::min<uint64_t>(maxKmersPerBatch, (uint64_t)(0.8 * (double)freeB) / per));
+        if (const char *e = getenv("KASA_MAX_BATCH_KMERS")) maxKmersPerBatch = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: force several batches
+    }
+    Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
+    p.protein = batcher.protein;
+    for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
+    std::ofstream out;
+    if (!p.rtt.empty()) {
+        out.open(p.rtt, std::ios::binary);
+        if (!out) throw std::runtime_error("Readwise output file could not be created!");
+        if (p.fmt == Params::Tsv) out << "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n";
+        else if (p.fmt == Params::Json) out << "[\n";
+    }
+    if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
+
+    // queue of formed batches (bounded: one waiting per device) and results that leave in batch order
+    std::mutex mu;
+    std::condition_variable cvWork, cvSpace, cvDone;
+    std::deque<std::unique_ptr<Batch>> todo;
+    std::map<uint64_t, std::unique_ptr<Batch>> finished;
+    bool noMore = false;
+    std::exception_ptr failure;
+    vector<double> tDevice(nDev, 0.0), tText(nDev, 0.0);
+    std::atomic<uint64_t> totalKmers{0};
+    auto worker = [&](size_t d) {
+        try {
+            for (;;) {
+                std::unique_ptr<Batch> b;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cvWork.wait(lk, [&] { return !todo.empty() || noMore || failure; });
+                    if (failure || todo.empty()) return;
+                    b = std::move(todo.front()); todo.pop_front();
+                    cvSpace.notify_all();
+                }
+                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d]);
+                totalKmers += b->kmers;
+                b->rs = ReadSet();                                   // the reads are done with
+                std::lock_guard<std::mutex> lk(mu);
+                finished[b->id] = std::move(b);
+                cvDone.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!failure) failure = std::current_exception();       // like Compare.hpp:1060-1067: parked, rethrown by the driver thread
+            cvDone.notify_all(); cvSpace.notify_all(); cvWork.notify_all();
+        }
+    };
+    vector<std::thread> pool;
+    for (size_t d = 0; d < nDev; ++d) pool.emplace_back(worker, d);
+    vector<uint64_t> contaminants;              // --filter: read numbers, ascending
+    uint64_t nBatches = 0, written = 0;
+    auto drain = [&](bool all) {                 // write finished batches in order (caller holds no lock)
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            auto it = finished.find(written);
+            if (it == finished.end()) {
+                if (!all || written == nBatches || failure) return;
+                cvDone.wait(lk, [&] { return finished.count(written) || failure; });
+                continue;
+            }
+            std::unique_ptr<Batch> b = std::move(it->second);
+            finished.erase(it);
+            lk.unlock();
+            if (!p.rtt.empty()) out.write(b->text.data(), (std::streamsize)b->text.size());
+            contaminants.insert(contaminants.end(), b->flagged.begin(), b->flagged.end());
+            ++written;
+            lk.lock();
+        }
+    };
+    try {
+        for (;;) {
+            std::unique_ptr<Batch> b(new Batch());
+            if (!batcher.next(*b)) break;
+            if (p.verbose) std::cout << "OUT: Batch of " << b->rs.names.size() << " reads" << std::endl;
+            ++nBatches;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cvSpace.wait(lk, [&] { return todo.size() < nDev || failure; });
+                if (failure) break;
+                todo.push_back(std::move(b));
+                cvWork.notify_one();
+            }
+            drain(false);
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failure) failure = std::current_exception();
+    }
+    { std::lock_guard<std::mutex> lk(mu); noMore = true; cvWork.notify_all(); }
+    drain(true);
+    for (auto &t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+    const uint64_t nReads = batcher.nextRead;
+    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
+    if (p.filter) filterReads(p, contaminants);
+    // profile: one RCCL all-reduce over the devices' tables, then device 0's copy
+    if (nDev > 1 || getenv("KASA_FORCE_ALLREDUCE")) {        // (the variable: tests run the reduce with a single rank)
+        vector<ncclComm_t> comms(nDev);
+        vector<int> devs;
+        for (size_t d = 0; d < nDev; ++d) devs.push_back(p.devices[(size_t)devSlots[d]]);
+        if (ncclCommInitAll(comms.data(), (int)nDev, devs.data()) != ncclSuccess) throw std::runtime_error("RCCL communicator could not be created");
+        vector<std::thread> red; vector<int> rcs(nDev, 0); vector<string> msgs(nDev);
+        for (size_t d = 0; d < nDev; ++d) red.emplace_back([&, d] { rcs[d] = kasa_profile_allreduce(ctx[d], comms[d]); if (rcs[d]) msgs[d] = kasa_last_error(); });
+        for (auto &t : red) t.join();
+        for (auto &c : comms) ncclCommDestroy(c);
+        for (size_t d = 0; d < nDev; ++d) if (rcs[d]) throw std::runtime_error(msgs[d]);
+    }
+    const int nK = p.kHigh - p.kLow + 1;
+    vector<double> all((size_t)nK * ixf.content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
+    if (kasa_profile_fetch(ctx[0], all.data(), uniq.data(), tot.data())) throwLast();
+    if (!p.profile.empty()) writeProfile(p.profile, p, ixf.content, all, uniq, tot, ixf.freqAll, totalKmers.load(), nReads);
+    if (p.verbose) {
+        double ident = 0; for (size_t t = 1; t < ixf.content.names.size(); ++t) ident += all[(size_t)(nK - 1) * ixf.content.names.size() + t];
+        double dev = 0, txt = 0; for (size_t d = 0; d < nDev; ++d) { dev = std::max(dev, tDevice[d]); txt = std::max(txt, tText[d]); }
+        std::cout << "OUT: Number of k-mers in input: " << totalKmers.load() << " of which " << ident / (double)totalKmers.load() * 100. << " % were identified." << std::endl;
+        std::cout << "OUT: Time fastq: " << batcher.parseSeconds << " s (" << p.threads << " threads)\nOUT: Time compare: " << dev << " s (" << nDev << " device" << (nDev > 1 ? "s" : "")
+                  << ")\nOUT: Time output: " << txt << " s\nOUT: Time file: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s" << std::endl;   // Compare.hpp:3689-3690
+    }
+}
+
+// Utilities::gatherFilesFromPath (Utilities.hpp:154-264): a path ending in '/' names every file of that folder
+static vector<string> gatherFiles(const string &path)
+{
+    vector<string> files;
+    if (!path.empty() && path.back() == '/') {
+        if (DIR *d = opendir(path.c_str())) {
+            while (dirent *e = readdir(d)) { const string n(e->d_name); if (n != "." && n != "..") files.push_back(path + n); }
+            closedir(d);
+        }
+        std::sort(files.begin(), files.end());
+    } else files.push_back(path);
+    return files;
+}
+
+static const char *formatEnding(Params::Fmt f)    // Compare.hpp:367-381
+{
+    switch (f) { case Params::Kraken: return ".ktsv"; case Params::Json: return ".json"; case Params::JsonL: return ".jsonl"; default: return ".tsv"; }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // main
 // ---------------------------------------------------------------------------------------------------
 static int run(int argc, char **argv)
@@ -601,15 +1063,16 @@ static int run(int argc, char **argv)
     std::cout << "OUT: kasa_identify (MI355X path of kASA identify)\nOUT: ";
     for (auto &s : a) std::cout << s << " ";
     std::cout << std::endl;
-    if (argc < 2 || a[1] != "identify") throw std::runtime_error("only the mode `identify` is available on this path");
+    if (argc < 2 || (a[1] != "identify" && a[1] != "identify_multiple")) throw std::runtime_error("only the modes `identify` and `identify_multiple` are available on this path");
     Params p;
+    p.mode = a[1];
     int frameFlags = 0;
     for (int i = 2; i < argc; ++i) {
         const string &s = a[i];
         auto next = [&]() -> string { if (i + 1 >= argc) throw std::runtime_error("missing value after " + s); return a[++i]; };
         if (s == "-c" || s == "--content") p.content = next();
         else if (s == "-d" || s == "--database") p.index = next();
-        else if (s == "-i" || s == "--input" || s == "-1") { p.input = next(); if (!std::ifstream(p.input)) throw std::runtime_error("Input file not found"); }
+        else if (s == "-i" || s == "--input" || s == "-1") { p.input = next(); if (!std::ifstream(p.input) && p.input.back() != '/') throw std::runtime_error("Input file not found"); }
         else if (s == "-2") { p.input2 = next(); if (!std::ifstream(p.input2)) throw std::runtime_error("Input file not found"); }
         else if (s == "-q" || s == "--rtt") p.rtt = next();
         else if (s == "-p" || s == "--profile") p.profile = next();
@@ -628,7 +1091,13 @@ static int run(int argc, char **argv)
         else if (s == "-e" || s == "--unique") p.unique = true;
         else if (s == "--coverage") p.coverage = true;
         else if (s == "-v" || s == "--verbose") p.verbose = true;
-        else if (s == "--device") p.device = std::stoi(next());
+        else if (s == "--device") p.devices = {std::stoi(next())};
+        else if (s == "--devices") {                                          // read shards over several GPUs, index replicated
+            p.devices.clear();
+            std::stringstream ss(next()); string tok;
+            while (std::getline(ss, tok, ',')) if (!tok.empty()) p.devices.push_back(std::stoi(tok));
+            if (p.devices.empty()) throw std::runtime_error("--devices needs a list like 0,1,2,3");
+        }
         else if (s == "-r" || s == "--ram") p.ram = true;                    // the index always lives in HBM; -r only enters the batch budget
         else if (s == "-n" || s == "--threads") { p.threads = (unsigned)std::max(1, std::stoi(next())); p.refThreads = (int)p.threads; }
         else if (s == "-m" || s == "--memory") { const string v = next(); p.memoryGiB = v == "inf" ? (1 << 30) : std::stoi(v); }   // main.cpp:438-447
@@ -636,15 +1105,16 @@ static int run(int argc, char **argv)
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }
-        else if (s == "--coherence" || s == "--visualize" || s == "-z")
+        else if (s == "--coherence" || s == "--coherenceThreshold" || s == "--visualize" || s == "-z")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }
     if (frameFlags >= 2) throw std::runtime_error("You'll have to decide between using one, three, or six frames. Currently, more than one option was chosen. Please check your parameters!"); // main.cpp:618-620
     std::ifstream info(p.index + "_info.txt");
     if (!info) throw std::runtime_error("Info file for this index can not be found!");
-    uint64_t nRec = 0, vecType = 0; info >> nRec; info >> vecType;
-    const int recBytes = vecType == 128 ? 20 : (vecType == 3 ? 6 : 12);   // 128: k <= 25 index, 3: halved index of shrink strategy 2
+    IndexFiles ixf;
+    uint64_t vecType = 0; info >> ixf.nRec; info >> vecType;
+    ixf.recBytes = vecType == 128 ? 20 : (vecType == 3 ? 6 : 12);   // 128: k <= 25 index, 3: halved index of shrink strategy 2
     if (vecType == 128) {
         p.K = 25;
         if (!p.kSetByUser) p.kHigh = 25;                               // main.cpp:1065-1067
@@ -653,179 +1123,75 @@ static int run(int argc, char **argv)
         if (p.kLow > 12) p.kLow = 12;
     }
     if (p.content.empty()) p.content = p.index + "_content.txt";
-    const Content content = loadContent(p.content);
-    const vector<uint64_t> freqAll = loadFreq(p.index, content.names.size(), p.kHigh, p.kLow);
-    const vector<uint64_t> freq(freqAll.begin(), freqAll.begin() + (std::ptrdiff_t)content.names.size());   // level 0: k = kHigh
+    ixf.content = loadContent(p.content);
+    ixf.freqAll = loadFreq(p.index, ixf.content.names.size(), p.kHigh, p.kLow);
+    ixf.freq.assign(ixf.freqAll.begin(), ixf.freqAll.begin() + (std::ptrdiff_t)ixf.content.names.size());   // level 0: k = kHigh
+    for (size_t t = 1; t < ixf.content.names.size(); ++t) ixf.nameBytes += ixf.content.names[t].size();
+    if (!p.codonFile.empty()) ixf.lut = codonTableFromFile(p.codonFile, p.codonId);
 
-    // index + trie files as they are on disk
+    // index + trie files as they are on disk, once per device (the index object is immutable and shared by every context there)
     const int fd = open(p.index.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("The index file cannot be found!");
-    void *rec = mmap(nullptr, nRec * recBytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    void *rec = mmap(nullptr, ixf.nRec * ixf.recBytes, PROT_READ, MAP_PRIVATE, fd, 0);
     if (rec == MAP_FAILED) throw std::runtime_error("The index file cannot be mapped!");
-    vector<uint32_t> tp; vector<uint64_t> tc;
     {
         std::ifstream ts(p.index + "_trie.txt"); std::ifstream tf(p.index + "_trie", std::ios::binary);
         if (!ts || !tf) throw std::runtime_error("The trie file cannot be found!");
-        uint64_t m = 0; ts >> m; tp.resize(m); tc.resize(m);
+        uint64_t m = 0; ts >> m; ixf.tp.resize(m); ixf.tc.resize(m);
         vector<char> raw(m * 12); tf.read(raw.data(), (std::streamsize)raw.size());
-        for (uint64_t i = 0; i < m; ++i) { memcpy(&tc[i], &raw[i * 12], 8); memcpy(&tp[i], &raw[i * 12 + 8], 4); }
+        for (uint64_t i = 0; i < m; ++i) { memcpy(&ixf.tc[i], &raw[i * 12], 8); memcpy(&ixf.tp[i], &raw[i * 12 + 8], 4); }
     }
-    kasa_index *ix = nullptr;
-    if (kasa_index_create(p.device, rec, nRec, recBytes, tp.data(), tc.data(), tp.size(), content.taxids.data(), (uint32_t)content.taxids.size(), &ix)) throwLast();
-    munmap(rec, nRec * recBytes); close(fd);
-    kasa_ctx *ctx = nullptr;
-    vector<uint8_t> lut;
-    if (!p.codonFile.empty()) lut = codonTableFromFile(p.codonFile, p.codonId);
-    if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, lut.empty() ? nullptr : lut.data(), &ctx)) throwLast();
-
+    for (int dev : p.devices) {
+        kasa_index *ix = nullptr;
+        if (kasa_index_create(dev, rec, ixf.nRec, ixf.recBytes, ixf.tp.data(), ixf.tc.data(), ixf.tp.size(), ixf.content.taxids.data(),
+                              (uint32_t)ixf.content.taxids.size(), &ix)) throwLast();
+        ixf.onDevice.push_back(ix);
+    }
+    munmap(rec, ixf.nRec * ixf.recBytes); close(fd);
     if (p.threads == 0) p.threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const auto tStart = std::chrono::steady_clock::now();
-    auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    ReadSet rs = readInput(p.input, p.verbose, p.threads);
-    // paired-end (Read.hpp:834-1049): mate r of both files forms read r; the two sequences stay separate (no k-mer spans
-    // the junction) but score into one row; specifier = both names, length = the sum
-    vector<uint32_t> segRead;
-    if (!p.input2.empty()) {
-        ReadSet r2 = readInput(p.input2, false, p.threads);
-        if (r2.names.size() != rs.names.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
-        ReadSet m; m.protein = rs.protein;
-        for (size_t r = 0; r < rs.names.size(); ++r) {
-            for (const ReadSet *x : {&rs, &r2}) {
-                m.bases.insert(m.bases.end(), x->bases.begin() + x->off[r], x->bases.begin() + x->off[r + 1]);
-                m.off.push_back((int64_t)m.bases.size());
-                segRead.push_back((uint32_t)r);
-            }
-            m.names.push_back(rs.names[r] + r2.names[r]);
-            m.lengths.push_back(rs.lengths[r] + r2.lengths[r]);
-        }
-        rs = std::move(m);
-    }
-    const size_t seqPerRead = segRead.empty() ? 1 : 2;
-    p.protein = rs.protein;
-    if (kasa_ctx_set_protein(ctx, p.protein ? 1 : 0)) throwLast();
-    const uint64_t nReads = rs.names.size();
-    std::ofstream out;
-    if (!p.rtt.empty()) {
-        out.open(p.rtt, std::ios::binary);
-        if (!out) throw std::runtime_error("Readwise output file could not be created!");
-        if (p.fmt == Params::Tsv) out << "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n";
-        else if (p.fmt == Params::Json) out << "[\n";
-    }
-    if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
 
-    // Batches.  With per-read output the batches are the reference's own: per-read scores are float sums whose order
-    // depends on the reads sharing a batch, so the input is cut exactly where `kASA identify -m` cuts it
-    // (kasa_refbatch_*: Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195).  A reference batch that does
-    // not fit the device (or a profile-only run, where boundaries do not matter) is cut by free HBM instead.
-    const bool wantRows = !p.rtt.empty() || p.filter;
-    int64_t refBudget = 0;
-    vector<int64_t> refCost;
-    if (wantRows && !getenv("KASA_MAX_BATCH_KMERS")) {
-        uint64_t nameBytes = 0;
-        for (size_t t = 1; t < content.names.size(); ++t) nameBytes += content.names[t].size();
-        kasa_refbatch_params bp{p.memoryGiB, p.refThreads, p.ram ? 1 : 0, p.kHigh, p.kLow, recBytes, nRec, tp.data(), tp.size(),
-                                content.taxids.data(), (uint32_t)content.taxids.size(), nameBytes, 0};
-        if (kasa_refbatch_budget(&bp, &refBudget)) throw std::runtime_error("batch budget could not be computed");
-        const int mode = p.protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !p.protein) ? 2 : 1;
-        refCost.resize(nReads);
-        for (uint64_t r = 0; r < nReads; ++r) {
-            int64_t c = kasa_refbatch_read_overhead((int64_t)rs.names[r].size(), (uint32_t)content.taxids.size());
-            for (size_t q = 0; q < seqPerRead; ++q)
-                c += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, rs.off[r * seqPerRead + q + 1] - rs.off[r * seqPerRead + q]);
-            refCost[r] = c;
+    vector<int> allSlots;
+    for (size_t d = 0; d < p.devices.size(); ++d) allSlots.push_back((int)d);
+    const vector<string> files = gatherFiles(p.input);
+    if (files.empty()) throw std::runtime_error("Input file not found");
+    auto outputsOf = [&](const string &file, string &rtt, string &prof) {   // main.cpp:1296-1313, Compare.hpp:3052
+        string name = file.substr(p.input.back() == '/' ? p.input.size() : 0);
+        const size_t dot = name.rfind('.');
+        if (dot != string::npos && dot > 0) name.resize(dot);
+        rtt = p.rtt.empty() ? "" : p.rtt + name + formatEnding(p.fmt);
+        prof = p.profile.empty() ? "" : p.profile + name + ".csv";
+    };
+    if (p.mode == "identify") {
+        // one file (or every file of a folder, one after the other): every batch goes to the next free device
+        for (const string &f : files) {
+            string rtt = p.rtt, prof = p.profile;
+            if (files.size() > 1) outputsOf(f, rtt, prof);
+            identifyFile(p, ixf, allSlots, f, files.size() > 1 ? "" : p.input2, rtt, prof);
         }
+    } else {
+        // identify_multiple (main.cpp:1118-1334): the files are a job queue; every worker runs a whole file with a context of
+        // its own over the shared index of its device (two workers per device keep it busy while the other one parses / writes)
+        std::atomic<size_t> nextFile{0};
+        std::mutex mu; std::exception_ptr failure;
+        const size_t nWorkers = std::min(files.size(), p.devices.size() * 2);
+        Params pw = p;
+        pw.threads = std::max(1u, p.threads / (unsigned)nWorkers);
+        vector<std::thread> pool;
+        for (size_t w = 0; w < nWorkers; ++w)
+            pool.emplace_back([&, w] {
+                try {
+                    for (;;) {
+                        const size_t i = nextFile.fetch_add(1);
+                        if (i >= files.size()) return;
+                        string rtt, prof;
+                        outputsOf(files[i], rtt, prof);
+                        identifyFile(pw, ixf, {(int)(w % p.devices.size())}, files[i], "", rtt, prof);
+                    }
+                } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!failure) failure = std::current_exception(); }
+            });
+        for (auto &t : pool) t.join();
+        if (failure) std::rethrow_exception(failure);
     }
-    uint64_t maxKmersPerBatch = 3000000000ull;
-    {   // ... and by the HBM that is free next to the index (the per-query footprint grows with the number of levels)
-        uint64_t freeB = 0, totalB = 0;
-        if (kasa_device_memory(p.device, &freeB, &totalB)) throwLast();
-        const uint64_t per = kasa_batch_bytes_per_query(ctx);
-        if (per) maxKmersPerBatch = std::max<uint64_t>(1u << 20, std::min<uint64_t>(maxKmersPerBatch, (uint64_t)(0.8 * (double)freeB) / per));
-        if (const char *e = getenv("KASA_MAX_BATCH_KMERS")) maxKmersPerBatch = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: force several batches
-    }
-    uint64_t totalKmers = 0, done = 0;
-    const double tParse = secondsSince(tStart);
-    double tDevice = 0.0, tText = 0.0;
-    vector<uint64_t> contaminants;              // --filter: read numbers, ascending
-    while (done < nReads || (nReads == 0 && done == 0)) {
-        uint64_t end = done, est = 0, refEnd = nReads;
-        if (!refCost.empty() && nReads) {
-            const uint64_t n = kasa_refbatch_cut(refBudget, done == 0 ? 1 : 0, refCost.data() + done, nReads - done);
-            refEnd = done + std::max<uint64_t>(1, n);
-        }
-        while (end < refEnd) {
-            const uint64_t len = (uint64_t)(rs.off[(end + 1) * seqPerRead] - rs.off[end * seqPerRead]);
-            const uint64_t k = (len + 64 * seqPerRead) * (p.frames == 6 ? 2 : 1);
-            if (end > done && est + k > maxKmersPerBatch) break;
-            est += k; ++end;
-        }
-        if (!refCost.empty() && end < refEnd)
-            std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
-        if (p.verbose) std::cout << "OUT: Batch of " << (end - done) << " reads" << std::endl;
-        uint64_t nk = 0;
-        const auto tDev = std::chrono::steady_clock::now();
-        if (segRead.empty()) {
-            if (kasa_batch_upload(ctx, rs.bases.data(), rs.off.data() + done, (int64_t)(end - done))) throwLast();
-        } else {
-            vector<uint32_t> local(segRead.begin() + (std::ptrdiff_t)(done * 2), segRead.begin() + (std::ptrdiff_t)(end * 2));
-            for (auto &v : local) v -= (uint32_t)done;
-            if (kasa_batch_upload_segments(ctx, rs.bases.data(), rs.off.data() + done * 2, (int64_t)((end - done) * 2), local.data(), (int64_t)(end - done))) throwLast();
-        }
-        if (kasa_batch_encode(ctx, &nk)) throwLast();
-        if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
-        if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
-        totalKmers += nk;
-        if (wantRows) {
-            uint64_t nnz = 0;
-            if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
-            vector<uint64_t> ro(end - done + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
-            if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
-            tDevice += secondsSince(tDev);
-            // ranking + text (N2): the reads of the batch are split over the threads in slabs, written out in order
-            const auto tTxt = std::chrono::steady_clock::now();
-            const uint64_t slab = 1u << 15;
-            for (uint64_t s0 = done; s0 < end; s0 += slab * p.threads) {
-                const unsigned nt = (unsigned)std::min<uint64_t>(p.threads, (end - s0 + slab - 1) / slab);
-                vector<string> texts(nt);
-                vector<vector<uint64_t>> flagged(nt);
-                vector<std::exception_ptr> err(nt);
-                auto work = [&](unsigned t) {
-                    try {
-                        Writer w(p, content, freq);
-                        const uint64_t a = s0 + t * slab, b = std::min<uint64_t>(end, a + slab);
-                        string &text = texts[t];
-                        text.reserve((size_t)(b - a) * 320);
-                        for (uint64_t r = a; r < b; ++r) {
-                            const uint64_t lo = ro[r - done], hi = ro[r - done + 1];
-                            w.read(text, r, rs.names[r], rs.lengths[r], tx.data() + lo, sc.data() + lo, hi - lo);
-                            if (p.filter && w.lastContaminated) flagged[t].push_back(r);
-                        }
-                    } catch (...) { err[t] = std::current_exception(); }
-                };
-                if (nt == 1) work(0);
-                else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
-                for (auto &e : err) if (e) std::rethrow_exception(e);
-                if (!p.rtt.empty()) for (auto &t : texts) out.write(t.data(), (std::streamsize)t.size());
-                for (auto &f : flagged) contaminants.insert(contaminants.end(), f.begin(), f.end());
-            }
-            tText += secondsSince(tTxt);
-        } else tDevice += secondsSince(tDev);
-        done = end;
-        if (nReads == 0) break;
-    }
-    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
-    if (p.filter) filterReads(p, contaminants);
-    const int nK = p.kHigh - p.kLow + 1;
-    vector<double> all((size_t)nK * content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
-    if (kasa_profile_fetch(ctx, all.data(), uniq.data(), tot.data())) throwLast();
-    if (!p.profile.empty()) writeProfile(p.profile, p, content, all, uniq, tot, freqAll, totalKmers, nReads);
-    if (p.verbose) {
-        double ident = 0; for (size_t t = 1; t < content.names.size(); ++t) ident += all[(size_t)(nK - 1) * content.names.size() + t];
-        std::cout << "OUT: Number of k-mers in input: " << totalKmers << " of which " << ident / totalKmers * 100. << " % were identified." << std::endl;
-        std::cout << "OUT: Time fastq: " << tParse << " s (" << p.threads << " threads)\nOUT: Time compare: " << tDevice << " s\nOUT: Time output: " << tText << " s" << std::endl;   // Compare.hpp:3689-3690
-    }
-    kasa_ctx_destroy(ctx);
-    kasa_index_destroy(ix);
     return 0;
 }
 

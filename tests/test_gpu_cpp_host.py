@@ -156,3 +156,58 @@ def test_cpp_host_several_batches(tmp_path):
     assert _read(prof) == _read(os.path.join(d, "prof_b100.csv"))
     strip = lambda t: re.sub(r'"(k-mer Score|Relative Score|Error)": [-0-9.e+infa]+', r'"\1": x', t)
     assert strip(_read(out)) == strip(_read(os.path.join(d, "out_b100.jsonl")))
+
+
+def _run_host(args, env=None, timeout=600):
+    exe = hipbuild.build_host()
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.mark.parametrize("infile,stem", [("reads.fastq", "b100"), ("reads.fasta", "fasta"), ("edge_noeol.fasta", "edge_noeol")])
+def test_cpp_host_streams_the_input_in_chunks(infile, stem, tmp_path):
+    """N1: the input is read block by block, cut at record boundaries and parsed by several threads; tiny blocks here so
+    that the golden input spans dozens of chunks.  Same bytes as the reference."""
+    assert capi.device_count() > 0
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    _run_host(["identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile), "-q", out, "-p", prof,
+               "--jsonl", "-b", "100", "-n", "4"], env={"KASA_READ_BLOCK": "1500", "KASA_PARSE_CHUNK": "400"})
+    assert _read(out) == _read(os.path.join(d, "out_" + stem + ".jsonl"))
+    assert _read(prof) == _read(os.path.join(d, "prof_" + stem + ".csv"))
+
+
+def test_cpp_host_identify_multiple(tmp_path):
+    """identify_multiple (main.cpp:1118-1334): several input files as a job queue over ONE shared index object, one
+    context per worker; outputs named <prefix><file name><format ending> / <prefix><file name>.csv."""
+    import shutil
+    assert capi.device_count() > 0
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    ind = tmp_path / "in"
+    ind.mkdir()
+    src = {"sampleA.fastq": ("reads.fastq", "b100"), "sampleB.fasta": ("reads.fasta", "fasta"), "sampleC.fastq": ("reads_dup.fastq", "dup"),
+           "sampleD.fasta": ("exampleInput.fasta", "exampleInput")}
+    cases = {}
+    for f, (orig, stem) in src.items():
+        shutil.copy(os.path.join(d, orig), str(ind / f))
+        cases[f] = stem
+    _run_host(["identify_multiple", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", str(ind) + "/",
+               "-q", str(tmp_path / "rtt_"), "-p", str(tmp_path / "prof_"), "--jsonl", "-b", "100", "-n", "2"])
+    for f, stem in cases.items():
+        name = f.rsplit(".", 1)[0]
+        assert _read(str(tmp_path / ("rtt_" + name + ".jsonl"))) == _read(os.path.join(d, "out_" + stem + ".jsonl")), f
+        assert _read(str(tmp_path / ("prof_" + name + ".csv"))) == _read(os.path.join(d, "prof_" + stem + ".csv")), f
+
+
+def test_cpp_host_rccl_reduce_with_one_rank(tmp_path):
+    """kasa_profile_allreduce (limbs packed on the device, ncclAllReduce, carries folded back) with a one-rank RCCL
+    communicator: the profile must be what it was.  More ranks need more GPUs than this box has."""
+    assert capi.device_count() > 0
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    _run_host(["identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"), "-q", out, "-p", prof,
+               "--jsonl", "-b", "100", "-n", "2", "--devices", "0", "--coverage"], env={"KASA_FORCE_ALLREDUCE": "1"})
+    assert _read(out) == _read(os.path.join(d, "out_cov.jsonl"))
+    assert _read(prof) == _read(os.path.join(d, "prof_cov.csv"))
