@@ -232,7 +232,8 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row
  * merge instead of the bitmap one, bit 3 = the encoder does not rank the k-mers of a read (slots come from
- * a stable sort by read id, as for long or paired reads); lastSlowReads (may be
+ * a stable sort by read id, as for long or paired reads), bit 4 = the profile keys are sorted and reduced even
+ * when the LDS counting table would fit; lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

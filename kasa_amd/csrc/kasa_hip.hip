@@ -2689,6 +2689,66 @@ __global__ __launch_bounds__(PR_THREADS) void profile_reduce_kernel(const uint64
     }
 }
 
+// The profile keys summed WITHOUT sorting them, when a (level, |T| <= NN, taxon) table of 32-bit counters fits the LDS
+// of a workgroup: persistent workgroups stream the keys and count with LDS atomics (1.9e9 keys in ~3 ms).  Keys the table
+// has no cell for -- a larger |T|, more than 127 hits; a few per cent -- must not go to the global tables one by one
+// (same-address atomics serialise: 200 ms): they collect in an LDS buffer that leaves with one cursor add per 1024+ keys,
+// and only that short list is sorted and reduced.  At the end every workgroup adds its non-zero cells to the 64.64 tables.
+// Per workgroup at most 2^32 / gridDim keys x 127 hits: no counter can wrap.
+static constexpr int PT_THREADS = 1024, PT_LEFT = 2048;
+__global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, uint32_t NN,
+                                                                   uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
+                                                                   uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL,
+                                                                   uint64_t *__restrict__ leftOut, unsigned long long *__restrict__ leftCursor)
+{
+    extern __shared__ uint32_t tab[];                                  // [nK][NN][nTaxa]
+    __shared__ uint64_t sLeft[PT_LEFT];
+    __shared__ uint32_t sLeftN;
+    __shared__ unsigned long long sLeftBase;
+    const uint32_t cells = (uint32_t)nK * NN * nTaxa;
+    for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) tab[i] = 0u;
+    if (threadIdx.x == 0) sLeftN = 0;
+    __syncthreads();
+    const uint64_t mask = (1ull << PL.bits()) - 1ull;
+    auto flush = [&]() {                                               // all threads; the buffer goes to the list
+        const uint32_t n = sLeftN;
+        if (threadIdx.x == 0) sLeftBase = atomicAdd(leftCursor, (unsigned long long)n);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += PT_THREADS) leftOut[sLeftBase + i] = sLeft[i];   // (the list holds nKeys entries)
+        __syncthreads();
+        if (threadIdx.x == 0) sLeftN = 0;
+        __syncthreads();
+    };
+    const uint64_t step = (uint64_t)gridDim.x * PT_THREADS;
+    const uint64_t rounds = ((uint64_t)nKeys + step - 1) / step;       // the same for every workgroup: barriers inside
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        const uint64_t i = rd * step + (uint64_t)blockIdx.x * PT_THREADS + threadIdx.x;
+        if (i < nKeys) {
+            const uint64_t key = keys[i];
+            const uint64_t f = (key >> 16) & mask;
+            const uint32_t hits = (uint32_t)(key & 0xFFFFull);
+            const uint32_t tax = (uint32_t)(f & ((1ull << PL.tb) - 1ull));
+            if (hits != 0u && tax != (1u << PL.tb) - 1u) {               // (else: unused slot)
+                const uint32_t n = (uint32_t)((f >> PL.tb) & ((1ull << PL.nb) - 1ull));
+                const uint32_t lv = (uint32_t)(f >> (PL.tb + PL.nb));
+                if (n >= 1u && n <= NN && hits <= 127u) atomicAdd(&tab[(lv * NN + (n - 1u)) * nTaxa + tax], hits);
+                else sLeft[atomicAdd(&sLeftN, 1u)] = key;
+            }
+        }
+        __syncthreads();
+        if (sLeftN > (uint32_t)(PT_LEFT - PT_THREADS)) flush();        // uniform: read after the barrier
+    }
+    flush();
+    for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) {
+        const uint32_t c = tab[i];
+        if (!c) continue;
+        const uint32_t tax = i % nTaxa, n = (i / nTaxa) % NN + 1u, lv = i / (nTaxa * NN);
+        const size_t cell = (size_t)lv * nTaxa + tax;
+        if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
+        fixed_add(hiTab, midTab, loTab, cell, c, n);
+    }
+}
+
 // final rows -> CSR in read order (rows are already {taxon, score}, taxon ascending)
 __global__ __launch_bounds__(256) void row_copy_kernel(const uint32_t *__restrict__ rowPos, const uint32_t *__restrict__ rowLen,
                                 const uint64_t *__restrict__ rowOff, uint32_t nReads, const uint2 *__restrict__ st,
@@ -3017,13 +3077,34 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
         c->lastStaged = staged; c->lastKeys = nKeys;
-        if (nKeys > 0) {
+        // the keys summed per (level, |T|, taxon): counted in LDS when the table fits a workgroup, else sorted and reduced
+        const uint64_t tableWords = (uint64_t)nK * nTaxa;
+        const uint32_t NN = (uint32_t)std::min<uint64_t>(4, tableWords ? ((160u * 1024u - PT_LEFT * 8u - 1024u) / 4u) / tableWords : 0);
+        uint64_t *sortIn = c->profKeys.as<uint64_t>(), *sortOut = c->profSorted.as<uint64_t>();
+        uint64_t nSort = nKeys;
+        if (nKeys > 0 && NN >= 1 && !(c->debugFlags & 16)) {
+            int nCu = 0;
+            HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
+            const size_t shBytes = (size_t)tableWords * NN * 4;
+            unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
+            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream));
+            HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
+            profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, NN,
+                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
+                c->profSorted.as<uint64_t>(), leftCursor);
+            HIPCHK(hipGetLastError());
+            unsigned long long nLeft = 0;
+            HIPCHK(hipMemcpyAsync(&nLeft, leftCursor, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            nSort = nLeft; sortIn = c->profSorted.as<uint64_t>(); sortOut = c->profKeys.as<uint64_t>();   // what is left, sorted back into the key buffer
+        }
+        if (nSort > 0) {
             size_t tmpBytes = 0;
-            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)nKeys, 16u, 16u + PL.bits(), c->stream));
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, sortIn, sortOut, (size_t)nSort, 16u, 16u + PL.bits(), c->stream));
             if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-            HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, c->profKeys.as<uint64_t>(), c->profSorted.as<uint64_t>(), (size_t)nKeys, 16u, 16u + PL.bits(), c->stream));
-            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nKeys, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
-                c->profSorted.as<uint64_t>(), (uint32_t)nKeys, nTaxa,
+            HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, sortIn, sortOut, (size_t)nSort, 16u, 16u + PL.bits(), c->stream));
+            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
+                sortOut, (uint32_t)nSort, nTaxa,
                 c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
             HIPCHK(hipGetLastError());
         }

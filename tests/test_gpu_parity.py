@@ -550,7 +550,7 @@ def test_index_build_matches_reference_files(stem, K, tmp_path):
 
 
 @pytest.mark.parametrize("case", [(12, 7, 3, 12, 0), (12, 7, 6, 12, 0), (25, 7, 3, 25, 0), (12, 1, 3, 12, 0), (12, 7, 3, 12, 1), (12, 7, 3, 12, 8),
-                                  (25, 7, 6, 25, 8)])
+                                  (25, 7, 6, 25, 8), (12, 7, 3, 12, 16), (25, 7, 3, 25, 16)])
 def test_profile_only_equals_per_read_run(case):
     """Without -q (kasa_batch_lookup_score(wantPerRead = 0)) the fast kernel skips ordering and float sums; the profile
     tables must be the same integers as those of the full run, and equal the oracle's."""
@@ -605,7 +605,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9]))
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20]))
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
