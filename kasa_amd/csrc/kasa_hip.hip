@@ -2691,21 +2691,39 @@ __global__ __launch_bounds__(PR_THREADS) void profile_reduce_kernel(const uint64
 
 // The profile keys summed WITHOUT sorting them, when a (level, |T| <= NN, taxon) table of 32-bit counters fits the LDS
 // of a workgroup: persistent workgroups stream the keys and count with LDS atomics (1.9e9 keys in ~3 ms).  Keys the table
-// has no cell for -- a larger |T|, more than 127 hits; a few per cent -- must not go to the global tables one by one
+// has no cell for -- a larger |T|, or so many hits that a 32-bit counter could wrap; a few per cent -- must not go to the global tables one by one
 // (same-address atomics serialise: 200 ms): they collect in an LDS buffer that leaves with one cursor add per 1024+ keys,
 // and only that short list is sorted and reduced.  At the end every workgroup adds its non-zero cells to the 64.64 tables.
-// Per workgroup at most 2^32 / gridDim keys x 127 hits: no counter can wrap.
 static constexpr int PT_THREADS = 1024, PT_LEFT = 2048;
-__global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, uint32_t NN,
+// Largest |T| the table counts per level, and where a level's cells start (in units of nTaxa): shallow levels have large
+// taxon sets (chance matches of short prefixes), deep ones one or two taxa, so the cells are dealt out unevenly.
+struct ProfTableLayout { uint8_t nn[MAX_LEVELS]; uint16_t first[MAX_LEVELS + 1]; };
+static ProfTableLayout prof_table_layout(int nK, uint32_t nTaxa, uint64_t budgetCells)
+{
+    ProfTableLayout L;
+    memset(&L, 0, sizeof(L));
+    const uint64_t perTaxon = nTaxa ? budgetCells / nTaxa : 0;         // cells every taxon can have over all levels
+    if (perTaxon < (uint64_t)nK) return L;                              // not even |T| = 1 everywhere: no table
+    uint64_t left = perTaxon - (uint64_t)nK;
+    for (int lv = 0; lv < nK; ++lv) L.nn[lv] = 1;
+    auto grow = [&](int lv, uint64_t upTo) { while (lv >= 0 && lv < nK && L.nn[lv] < upTo && left > 0) { ++L.nn[lv]; --left; } };
+    for (int lv = 0; lv < nK; ++lv) grow(lv, 2);                        // pairs (sibling taxa) at every level
+    grow(nK - 2, 4);
+    grow(nK - 1, 24);                                                   // the shallowest level takes what is left
+    grow(nK - 2, 8);
+    for (int lv = 0; lv < nK; ++lv) L.first[lv + 1] = (uint16_t)(L.first[lv] + L.nn[lv]);
+    return L;
+}
+__global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, ProfTableLayout TL,
                                                                    uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
                                                                    uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL,
                                                                    uint64_t *__restrict__ leftOut, unsigned long long *__restrict__ leftCursor)
 {
-    extern __shared__ uint32_t tab[];                                  // [nK][NN][nTaxa]
+    extern __shared__ uint32_t tab[];                                  // [level][|T| - 1][nTaxa], TL.nn[level] values of |T| per level
     __shared__ uint64_t sLeft[PT_LEFT];
     __shared__ uint32_t sLeftN;
     __shared__ unsigned long long sLeftBase;
-    const uint32_t cells = (uint32_t)nK * NN * nTaxa;
+    const uint32_t cells = (uint32_t)TL.first[nK] * nTaxa;
     for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) tab[i] = 0u;
     if (threadIdx.x == 0) sLeftN = 0;
     __syncthreads();
@@ -2720,6 +2738,8 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
         __syncthreads();
     };
     const uint64_t step = (uint64_t)gridDim.x * PT_THREADS;
+    // a workgroup sees at most `rounds * PT_THREADS` keys: with hits <= maxHits no 32-bit counter can wrap
+    const uint32_t maxHits = (uint32_t)std::min<uint64_t>(65535ull, 0xFFFFFFFFull / std::max<uint64_t>(1, (((uint64_t)nKeys + step - 1) / step) * PT_THREADS));
     const uint64_t rounds = ((uint64_t)nKeys + step - 1) / step;       // the same for every workgroup: barriers inside
     for (uint64_t rd = 0; rd < rounds; ++rd) {
         const uint64_t i = rd * step + (uint64_t)blockIdx.x * PT_THREADS + threadIdx.x;
@@ -2731,7 +2751,7 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
             if (hits != 0u && tax != (1u << PL.tb) - 1u) {               // (else: unused slot)
                 const uint32_t n = (uint32_t)((f >> PL.tb) & ((1ull << PL.nb) - 1ull));
                 const uint32_t lv = (uint32_t)(f >> (PL.tb + PL.nb));
-                if (n >= 1u && n <= NN && hits <= 127u) atomicAdd(&tab[(lv * NN + (n - 1u)) * nTaxa + tax], hits);
+                if (n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
                 else sLeft[atomicAdd(&sLeftN, 1u)] = key;
             }
         }
@@ -2742,7 +2762,10 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
     for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) {
         const uint32_t c = tab[i];
         if (!c) continue;
-        const uint32_t tax = i % nTaxa, n = (i / nTaxa) % NN + 1u, lv = i / (nTaxa * NN);
+        const uint32_t tax = i % nTaxa, row = i / nTaxa;
+        uint32_t lv = 0;
+        while (row >= (uint32_t)TL.first[lv + 1]) ++lv;
+        const uint32_t n = row - (uint32_t)TL.first[lv] + 1u;
         const size_t cell = (size_t)lv * nTaxa + tax;
         if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
         fixed_add(hiTab, midTab, loTab, cell, c, n);
@@ -3078,18 +3101,18 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
         c->lastStaged = staged; c->lastKeys = nKeys;
         // the keys summed per (level, |T|, taxon): counted in LDS when the table fits a workgroup, else sorted and reduced
-        const uint64_t tableWords = (uint64_t)nK * nTaxa;
-        const uint32_t NN = (uint32_t)std::min<uint64_t>(4, tableWords ? ((160u * 1024u - PT_LEFT * 8u - 1024u) / 4u) / tableWords : 0);
+        const ProfTableLayout TL = prof_table_layout(nK, nTaxa, (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u);
+        const uint32_t NN = TL.first[nK];
         uint64_t *sortIn = c->profKeys.as<uint64_t>(), *sortOut = c->profSorted.as<uint64_t>();
         uint64_t nSort = nKeys;
         if (nKeys > 0 && NN >= 1 && !(c->debugFlags & 16)) {
             int nCu = 0;
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
-            const size_t shBytes = (size_t)tableWords * NN * 4;
+            const size_t shBytes = (size_t)NN * nTaxa * 4;
             unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
             HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream));
             HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
-            profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, NN,
+            profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
                 c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
                 c->profSorted.as<uint64_t>(), leftCursor);
             HIPCHK(hipGetLastError());
