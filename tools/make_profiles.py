@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Collect the round's profile evidence on the GPU box (run from the repo root; writes into gpurun_out/profiles/):
+  * rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1 --no-cpu --no-e2e` -> <tag>_kernel_stats_bench_10M.{csv,md}
+  * PMC passes (separate runs, counters only) for the hand-written kernels of one 10 M-read step -> <tag>_kernel_pmc.json:
+    FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE = HBM bytes per launch, SQ_INSTS_VALU / SALU,
+    SQ_WAVES, SQ_BUSY_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY
+  * the bench lines (headline, and with --secondary the 128-bit configuration) -> <tag>_bench_1gpu.json
+    python3 tools/make_profiles.py r02 [--secondary]
+"""
+import csv, glob, json, os, re, subprocess, sys, collections
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+out = "gpurun_out/profiles"
+os.makedirs(out, exist_ok=True)
+env = dict(os.environ, TMPDIR="/tmp")
+KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel"
+
+
+def run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    return subprocess.run(cmd, env=env, **kw)
+
+
+# 1. kernel stats
+d = os.path.join(out, "stats")
+with open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w") as f:
+    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
+         "--no-cpu", "--no-e2e"], stdout=f, stderr=subprocess.DEVNULL)
+src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(src)))
+with open(os.path.join(out, tag + "_kernel_stats_bench_10M.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    for r in rows:
+        w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
+open(os.path.join(out, tag + "_kernel_stats_bench_10M.md"), "w").write(
+    "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e` on one MI355X\n"
+    "(10 M reads x 150 bp, 419,951,000-record index).  The run holds the index build (one call of encode / lookup of its own) plus 1 warm-up\n"
+    "and 3 timed steps.  The warm-up step launches score_main / score_other twice (the first attempt sizes the staging rows, stops early\n"
+    "and is repeated with the capacity it asked for): their 5th call is that short one, so their averages here are below the per-launch\n"
+    "averages of bench.py's HIP events (total = 4 full launches + 1 short one).  Full names: the .csv next to this file.\n\n" + md)
+
+# 2. PMC passes (counters only; one step of 10 M reads)
+passes = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS",
+          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA", "FETCH_SIZE", "WRITE_SIZE"]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for i, p in enumerate(passes):
+    dd = os.path.join(out, "pmc%d" % i)
+    run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", dd, "--", "python3", "bench.py",
+         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = re.sub(r"[<(].*", "", row["Kernel_Name"]).replace("void ", "")
+            acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+res = {"command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e",
+       "workload": "10M x 150bp reads vs 419951000-record index (bench.py default); per kernel the LARGEST dispatch (the 1.3e9-query batch; the index build "
+                   "launches encode/lookup once on its own input)",
+       "correction": "hbm_bytes_per_launch = FETCH_SIZE[KB] x 1024 x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM; exact for "
+                     "16-B-per-lane streaming reads, uncalibrated for narrower ones) + WRITE_SIZE[KB] x 1024"}
+for name, cs in acc.items():
+    e = {c: max(v) for c, v in cs.items()}
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2
+        e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
+        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    res[name if name != "row_merge_bitmap_kernel" else "row_merge_kernel"] = e
+json.dump(res, open(os.path.join(out, tag + "_kernel_pmc.json"), "w"), indent=1)
+
+# 3. the bench line(s)
+args = ["python3", "bench.py", "--steps", "5", "--warmup", "2"] + (["--secondary"] if "--secondary" in sys.argv else [])
+with open(os.path.join(out, tag + "_bench_1gpu.json"), "w") as f:
+    run(args, stdout=f, stderr=subprocess.DEVNULL)
+print(open(os.path.join(out, tag + "_bench_1gpu.json")).read()[:600])
