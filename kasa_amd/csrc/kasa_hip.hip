@@ -1312,8 +1312,9 @@ static constexpr int GTHREADS = TILE / GITEMS;    // 512
 //   RW = 8 : [4..7]  the segments when there are at most 4; else 3 segments and [7] = pool offset of the others
 //   RW = 16: [4..7]  order, 5 bits per event (a 128-bit value, first event in the low bits);  [8..15] the segments when
 //            there are at most 8; else 7 segments and [15] = pool offset of the others
-//   pool block: {nseg, segments INL-1 ...}.  Segments come in descending order of their last level: the taxa the
-//   query really matches first, chance matches of its short prefixes last.
+//   pool block: {nseg, [sizes: 4 words, only with REC_SAT], segments INL-1 ...}.  Segments come in descending order of
+//   their last level: the taxa the query really matches first, chance matches of its short prefixes last.  sizes: the
+//   exact |T_k| of the levels lv = 0..7, 16 bits each (two per word) -- the 3-bit counts of word [3] stop at 7.
 // A segment is one index entry of the query's kLow-group seen from the query: taxon | kFirst << 22 | kLast << 27 -- the
 // entry puts its taxon into the taxon set T_k of the levels kFirst..kLast (kLast = letters it shares with the query,
 // capped at d; kFirst - 1 = letters it shares with the nearest earlier entry of the same taxon, which represents the
@@ -1338,11 +1339,13 @@ template <int RW> __device__ __forceinline__ uint32_t rec_nseg(const uint32_t *w
     if constexpr (RW == 8) { const uint32_t n = w[3] & 255u; return n == 255u ? pool[w[7]] : n; }
     else return w[3];
 }
+static constexpr uint32_t POOL_SIZES = 4;         // words of exact level sizes in the pool block of a REC_SAT record
 template <int RW> __device__ __forceinline__ uint32_t rec_seg(const uint32_t *w, const uint32_t *__restrict__ pool, uint32_t nseg, uint32_t i)
 {
     typedef RecTraits<RW> RT;
     if (nseg <= (uint32_t)RT::INL || i < (uint32_t)RT::INL - 1u) return w[RT::SEG0 + i];
-    return pool[w[RT::SEG0 + RT::INL - 1] + 1u + i - ((uint32_t)RT::INL - 1u)];
+    const uint32_t skip = (RW == 8 && (w[2] & REC_SAT)) ? POOL_SIZES : 0u;
+    return pool[w[RT::SEG0 + RT::INL - 1] + 1u + skip + i - ((uint32_t)RT::INL - 1u)];
 }
 
 // levels (bit lv = kHigh - k) at which sorted position p closes the groups before it: a new prefix range closes all of
@@ -1525,7 +1528,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
         if (RW == 8 && split) w2[i] |= REC_SPLIT;
         if (RW == 8 && (nlev & (nlev >> 1) & (nlev >> 2) & 0x249249u)) w2[i] |= REC_SAT;
-        if (n > (uint32_t)INL) need += n - (uint32_t)(INL - 1) + 1u;   // pool block: {nseg, segments INL-1 ...}
+        if (n > (uint32_t)INL) need += n - (uint32_t)(INL - 1) + 1u + ((w2[i] & REC_SAT) ? POOL_SIZES : 0u);   // pool block: {nseg, [sizes], segments INL-1 ...}
         if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
             const Key q = qKmer[base + i];
             const int ql = (base + i == 0) ? 0 : lcp_letters<Key>(qKmer[base + i - 1], q);
@@ -1548,13 +1551,23 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
 #pragma unroll
         for (int i = 0; i < GITEMS; ++i)
             if (nseg[i] > (uint32_t)INL) {
+                const bool sat = RW == 8 && (w2[i] & REC_SAT) != 0u;
                 if (fits) {                                          // (else: the host grows the pool and reruns)
                     pool[off] = nseg[i];
-                    uint32_t w = off + 1, idx = 0;
-                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) { if (idx >= (uint32_t)(INL - 1)) pool[w++] = s; ++idx; });
+                    uint32_t w = off + 1 + (sat ? POOL_SIZES : 0u), idx = 0;
+                    unsigned long long cA = 0, cB = 0;               // exact |T| of the levels 0..3 and 4..7, 16 bits each
+                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+                        if (idx >= (uint32_t)(INL - 1)) pool[w++] = s;
+                        ++idx;
+                        if (sat)
+                            for (int lv = kHigh - (int)(s >> 27); lv <= kHigh - (int)((s >> 22) & 31u); ++lv) {
+                                if (lv < 4) cA += 1ull << (16 * lv); else cB += 1ull << (16 * (lv - 4));
+                            }
+                    });
+                    if (sat) { pool[off + 1] = (uint32_t)cA; pool[off + 2] = (uint32_t)(cA >> 32); pool[off + 3] = (uint32_t)cB; pool[off + 4] = (uint32_t)(cB >> 32); }
                 }
                 seg[i][INL - 1] = off;
-                off += nseg[i] - (uint32_t)(INL - 1) + 1u;
+                off += nseg[i] - (uint32_t)(INL - 1) + 1u + (sat ? POOL_SIZES : 0u);
             }
     }
     // ---- 4. the record
@@ -1588,10 +1601,11 @@ static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row hol
 //   kind 0  event:        x |= level << 23; y = |T| << 16 | hits.  One (event, taxon) contribution, in the read's flush order.
 //   kind 1  final score:  y = float bits (a register taxon)
 //   kind 2  profile only: as kind 0, but the score is already in a register taxon's final score
-//   kind 3  segment:      x |= kFirst << 20 | RK_SEG_DESC; y = kLast | sizes << 8.  All events of one taxon segment of one
-//                         query: the levels kFirst..kLast in ascending order of k (descending with RK_SEG_DESC), one hit
-//                         each, |T| of level lv = kHigh - k in bits 3 lv .. 3 lv + 2 of `sizes` (always below 7)
+//   kind 3  segment:      x |= kFirst << 20 | RK_SEG_DESC; y = kLast | |T_kFirst| << 5 | |T_kLast| << 18.  All events of one
+//                         taxon segment of one query: its one or two levels kFirst..kLast in ascending order of k
+//                         (descending with RK_SEG_DESC), one hit each; the sizes are 13 bits each
 static constexpr uint32_t RK_FINAL = 1u << 30, RK_PROFILE = 2u << 30, RK_SEG = 3u << 30, RK_SEG_DESC = 1u << 29;
+__device__ __forceinline__ uint32_t seg_size(uint32_t y, bool first) { return (first ? (y >> 5) : (y >> 18)) & 0x1FFFu; }
 static constexpr int RK_LV_SHIFT = 23;
 static constexpr uint32_t RK_LV_MASK = 31u;
 __device__ __forceinline__ uint32_t rk_level(uint32_t x) { return (x >> RK_LV_SHIFT) & RK_LV_MASK; }
@@ -2001,7 +2015,7 @@ template <int RW> struct QueryRec {
     unsigned __int128 order;
     uint32_t sg[RT::INL];
     uint32_t nInl, nMore;
-    const uint32_t *more;
+    const uint32_t *more, *sizes;                                      // pool: further segments; exact level sizes (REC_SAT)
     __device__ __forceinline__ void decode(const uint4 *rp, const uint32_t *__restrict__ pool)
     {
         uint4 v[RW / 4];
@@ -2015,7 +2029,7 @@ template <int RW> struct QueryRec {
         p = h.x; fmax = h.y; d = (int)(h.z & 31u);
         if constexpr (RW == 8) {
             const uint4 b = v[1];
-            order = (h.z >> 5) & 0xFFFFFFu; split = h.z & REC_SPLIT;
+            order = (h.z >> 5) & 0xFFFFFFu; split = h.z & (REC_SPLIT | REC_SAT);
             nseg = h.w & 255u; nlev = h.w >> 8;
             sg[0] = b.x; sg[1] = b.y; sg[2] = b.z; sg[3] = b.w;
         } else {
@@ -2030,13 +2044,16 @@ template <int RW> struct QueryRec {
     {
         nInl = nseg <= (uint32_t)RT::INL ? nseg : (uint32_t)RT::INL - 1u;
         nMore = nseg <= (uint32_t)RT::INL ? 0u : nseg - ((uint32_t)RT::INL - 1u);
-        more = pool + sg[RT::INL - 1] + 1u;                            // valid when nMore > 0
+        sizes = pool + sg[RT::INL - 1] + 1u;                           // valid with REC_SAT
+        more = sizes + ((RW == 8 && (split & REC_SAT)) ? POOL_SIZES : 0u);   // valid when nMore > 0
         if (RW == 8 && nseg == 255u) { nseg = pool[sg[RT::INL - 1]]; nMore = nseg - ((uint32_t)RT::INL - 1u); }
+        split &= REC_SPLIT;
     }
     __device__ __forceinline__ uint32_t set_size(int lv, int kHigh) const
     {
         uint32_t n = RW == 8 ? ((nlev >> (3 * lv)) & 7u) : 7u;
-        if (n == 7u) {                                               // "7 or more" (or not recorded): count
+        if (RW == 8) return n < 7u ? n : ((sizes[lv >> 1] >> (16 * (lv & 1))) & 0xFFFFu);   // "7 or more": the exact size is in the pool
+        if (n == 7u) {                                               // not recorded: count
             const uint32_t k = (uint32_t)(kHigh - lv);
             n = 0;
 #pragma unroll
@@ -2124,7 +2141,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                 }
                 if (Q.nseg >= (1u << 13)) { fb = true; atomicAdd(&A.why[3], 1u); break; }
                 const int nEv = Q.d - A.kLow + 1;
-                const bool sat = RW == 8 && (rp[0].z & (REC_SAT | REC_SPLIT)) != 0u;   // then: one event record per level (seg_records)
+                const bool sat = RW == 8 && (rp[0].z & REC_SPLIT) != 0u;   // then: one event record per level (seg_records)
                 uint32_t mask0 = 0, mask1 = 0;
 #pragma unroll
                 for (int q = 0; q < RT::INL; ++q) {
@@ -2282,7 +2299,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         QueryRec<RW> Q;
         Q.decode_regs(cur, A.pool);
         if (!live) { Q.d = 0; Q.nInl = 0; Q.nMore = 0; Q.split = 0; }
-        const bool sat = RW == 8 && (cur[0].z & (REC_SAT | REC_SPLIT)) != 0u;   // then: one event record per level (seg_records)
+        const bool sat = RW == 8 && (cur[0].z & REC_SPLIT) != 0u;   // then: one event record per level (seg_records)
         const int nEv = Q.d ? Q.d - A.kLow + 1 : 0;
         // the pool segments of the query, the first four in registers (their loads go out together)
         uint32_t xs[4] = {0u, 0u, 0u, 0u};
@@ -2364,7 +2381,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
                 const int lvLo = __ffs((int)m) - 1, lvHi = 31 - __clz((int)m);   // lvLo = the deeper level (larger k)
                 const bool desc = pc == 2u && posOf(lvLo) < posOf(lvHi);          // the larger k flushes first
                 emit(make_uint2(t | ((uint32_t)(A.kHigh - lvHi) << 20) | (desc ? RK_SEG_DESC : 0u) | RK_SEG,
-                                (uint32_t)(A.kHigh - lvLo) | (Q.nlev << 8)));
+                                (uint32_t)(A.kHigh - lvLo) | (Q.set_size(lvHi, A.kHigh) << 5) | (Q.set_size(lvLo, A.kHigh) << 18)));
                 return;
             }
             Order o = (Order)Q.order;                                        // one event record per level, in flush order
@@ -2439,11 +2456,9 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
             keyAt += __shfl(incl, 63);
             if (nk) {
                 if ((e.x >> 30) == 3u) {
-                    const uint32_t sizes = e.y >> 8;
-                    for (uint32_t k = (e.x >> 20) & 31u; k <= (e.y & 31u); ++k) {
-                        const uint32_t lv = (uint32_t)kHigh - k;
-                        profKeys[kw++] = profile_key_of(lv, (sizes >> (3u * lv)) & 7u, e.x & 0xFFFFFu, 1u, PL);
-                    }
+                    const uint32_t kF = (e.x >> 20) & 31u;
+                    for (uint32_t k = kF; k <= (e.y & 31u); ++k)
+                        profKeys[kw++] = profile_key_of((uint32_t)kHigh - k, seg_size(e.y, k == kF), e.x & 0xFFFFFu, 1u, PL);
                 } else profKeys[kw] = profile_key(e, PL);
             }
             sKey[i] = key;
@@ -2482,10 +2497,9 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                         if ((e.x >> 30) == 1u) { v = __uint_as_float(e.y); any = true; }
                         else if ((e.x >> 30) == 3u) {                  // a segment: its levels in ascending or descending order of k
                             const int kF = (int)((e.x >> 20) & 31u), kL = (int)(e.y & 31u);
-                            const uint32_t sizes = e.y >> 8;
                             const int step = (e.x & RK_SEG_DESC) ? -1 : 1;
                             for (int k = step > 0 ? kF : kL, c = kL - kF; c >= 0; --c, k += step)
-                                v = __fadd_rn(v, event_score(k, (sizes >> (3 * (kHigh - k))) & 7u));
+                                v = __fadd_rn(v, event_score(k, seg_size(e.y, k == kF)));
                             any = true;
                         } else {
                             const float s = event_score(kHigh - (int)rk_level(e.x), e.y >> 16);
@@ -2554,11 +2568,9 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             keyAt += __shfl(incl, 63);
             if (nk) {
                 if (kind == 3u) {
-                    const uint32_t sizes = e.y >> 8;
-                    for (uint32_t k = (e.x >> 20) & 31u; k <= (e.y & 31u); ++k) {
-                        const uint32_t lv = (uint32_t)kHigh - k;
-                        profKeys[kw++] = profile_key_of(lv, (sizes >> (3u * lv)) & 7u, t, 1u, PL);
-                    }
+                    const uint32_t kF = (e.x >> 20) & 31u;
+                    for (uint32_t k = kF; k <= (e.y & 31u); ++k)
+                        profKeys[kw++] = profile_key_of((uint32_t)kHigh - k, seg_size(e.y, k == kF), t, 1u, PL);
                 } else profKeys[kw] = profile_key(e, PL);
             }
         }
@@ -2603,10 +2615,9 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                     float v = val[slot];
                     if ((e.x >> 30) == 3u) {                           // a segment: its levels in ascending or descending order of k
                         const int kF = (int)((e.x >> 20) & 31u), kL = (int)(e.y & 31u);
-                        const uint32_t sizes = e.y >> 8;
                         const int step = (e.x & RK_SEG_DESC) ? -1 : 1;
                         for (int k = step > 0 ? kF : kL, c = kL - kF; c >= 0; --c, k += step)
-                            v = __fadd_rn(v, event_score(evT, k, (sizes >> (3 * (kHigh - k))) & 7u));
+                            v = __fadd_rn(v, event_score(evT, k, seg_size(e.y, k == kF)));
                     } else
                         for (uint32_t j = 0; j < (e.y & 0xFFFFu); ++j) v = __fadd_rn(v, sc);
                     val[slot] = v;
@@ -3455,6 +3466,80 @@ extern "C" int kasa_ctx_batch_stats(kasa_ctx *c, uint64_t *stats)
     if (!c || !stats) return fail(KASA_E_ARG, "kasa_ctx_batch_stats: NULL argument");
     stats[0] = c->nQ; stats[1] = c->lastStaged; stats[2] = c->lastKeys; stats[3] = c->poolUsed;
     stats[4] = c->lastSlowReads; stats[5] = c->lastOverflowReads; stats[6] = c->nnz; stats[7] = c->payloadIsSlot ? 1 : 0;
+    return KASA_OK;
+}
+
+
+// ---- diagnostic (not part of the ABI): shape of the records score_other_kernel sees, RW = 8 only
+__global__ __launch_bounds__(256) void record_stats_kernel(ScoreArgs A, unsigned long long *out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const bool inRange = slot < A.nQ;
+    uint4 cur[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint4 mo = make_uint4(0, 0, 0, 0);
+    if (inRange) {
+        cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2]; cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2 + 1];
+        uint32_t lo = 0, hi = A.nReads;
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (A.kmerOff[mid] <= slot) lo = mid; else hi = mid; }
+        mo = reinterpret_cast<const uint4 *>(A.mainOut)[lo];
+    }
+    const bool live = inRange && mo.w != 0u && (cur[0].z & 31u) != 0u;
+    QueryRec<8> Q;
+    Q.decode_regs(cur, A.pool);
+    if (!live) { Q.d = 0; Q.nInl = 0; Q.nMore = 0; Q.split = 0; Q.nseg = 0; }
+    const bool sat = (cur[0].z & REC_SAT) != 0u, split = live && (cur[0].z & REC_SPLIT) != 0u;
+    const int nEv = Q.d ? Q.d - A.kLow + 1 : 0;
+    unsigned long long v[32];
+    for (int i = 0; i < 32; ++i) v[i] = 0;
+    v[0] = live; v[1] = live && Q.nMore > 0; v[2] = split; v[3] = live && sat; v[4] = Q.nseg;
+    uint32_t nOtherSeg = 0, rec = 0;
+    for (uint32_t q = 0; q < Q.nseg; ++q) {
+        const uint32_t sq = q < Q.nInl ? Q.sg[q] : Q.more[q - Q.nInl];
+        const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+        const uint32_t pc = __popc(m);
+        if (t != mo.x && t != mo.y) {
+            ++nOtherSeg; v[5]++; v[6] += pc == 1; v[7] += pc == 2; v[8] += pc >= 3;
+            if (!split && !sat) v[16] += pc >= 3;
+            rec += seg_records<8>(m, split);
+        }
+    }
+    v[18] = rec; v[10] = split ? rec : 0; v[11] = (live && sat) ? rec : 0; v[17] = live && rec == 0; v[19] = Q.nMore;
+    // order monotone?
+    bool asc = true, desc = true;
+    { uint32_t o = (uint32_t)Q.order; int prev = -1; for (int ev = 0; ev < nEv; ++ev, o >>= 3) { const int lv = o & 7; if (prev >= 0) { if (lv < prev) asc = false; if (lv > prev) desc = false; } prev = lv; } }
+    v[14] = live && (asc || desc);
+    v[20] = live && nOtherSeg == 0; v[21] = live && nOtherSeg == 1; v[22] = live && nOtherSeg == 2; v[23] = live && nOtherSeg >= 3;
+    v[24] = live && Q.nseg == 1; v[25] = live && Q.nseg == 2; v[26] = live && Q.nseg == 3; v[27] = live && Q.nseg == 4; v[28] = live && Q.nseg > 4 && Q.nseg <= 8; v[29] = live && Q.nseg > 8;
+    // wavefront maxima
+    uint32_t mx = Q.nMore, ms = Q.nseg, mo2 = nOtherSeg;
+    for (int off = 32; off; off >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, off)); ms = max(ms, (uint32_t)__shfl_xor((int)ms, off)); mo2 = max(mo2, (uint32_t)__shfl_xor((int)mo2, off)); }
+    v[12] = lane == 0 ? mx : 0; v[13] = lane == 0 ? ms : 0; v[15] = lane == 0; v[30] = lane == 0 ? mo2 : 0;
+    v[31] = lane == 0 && __ballot(split) != 0ull;
+    for (int i = 0; i < 32; ++i) {
+        unsigned long long x = v[i];
+        for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0 && x) atomicAdd(&out[i], x);
+    }
+}
+
+extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
+{
+    if (!c || !out32) return fail(KASA_E_ARG, "kasa_debug_record_stats: NULL argument");
+    if (c->state < 4 || c->recWords() != 8) return fail(KASA_E_STATE, "kasa_debug_record_stats: needs a scored batch with 32-byte records");
+    HIPCHK(hipSetDevice(c->ix->device));
+    DevBuf tmp;
+    int rc = tmp.reserve(32 * 8);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(tmp.p, 0, 32 * 8, c->stream));
+    ScoreArgs A;
+    memset(&A, 0, sizeof(A));
+    A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
+    A.nReads = (uint32_t)c->nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nQ = (uint32_t)c->nQ; A.mainOut = c->fastScratch.as<uint32_t>();
+    record_stats_kernel<<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(A, tmp.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out32, tmp.p, 32 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return KASA_OK;
 }
 
