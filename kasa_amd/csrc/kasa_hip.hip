@@ -1296,6 +1296,8 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 
 static constexpr int GITEMS = 2;                  // the group kernel gives a thread two queries of the tile
 static constexpr int GTHREADS = TILE / GITEMS;    // 512
+static constexpr int GSPAN = 3072;                // index entries around the tile's matches staged in LDS (taxon + neighbour counts)
+static constexpr uint32_t GMARGIN = 96;           // ... this many beyond the first and last representative
 
 // ------------------------------------------------------------------------------------------------
 // event records
@@ -1377,37 +1379,37 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 // prefix) as long as the entries share the kLow-group's letters with the query.  Letters entry i shares with the query
 // = min(d, letters shared by all neighbours between i and j) -- `meta` holds the neighbour counts.  Both directions are
 // merged so that the segments come in descending order of their last level.  Calls emit(seg).
-template <class Meta, class Emit>
-__device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, const Meta *__restrict__ meta,
-                                              const uint32_t *__restrict__ tax, uint32_t nIdx, Emit emit)
+// `meta(i)` / `tax(i)` read the index arrays (group_kernel serves them from the tile's span staged in LDS).
+template <class Meta, class GetMeta, class GetTax, class Emit>
+__device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, GetMeta meta, GetTax tax, uint32_t nIdx, Emit emit)
 {
     constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;
     const int gLow = group_letters(kLow);
     auto one = [&](uint32_t i, int kLast, uint32_t m) {
         const int dup = (int)(m >> DS);
         const int kFirst = dup < RANGE_LETTERS ? kLow : (dup + 1 > kLow ? dup + 1 : kLow);
-        if (kFirst <= kLast) emit(tax[i] | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27));
+        if (kFirst <= kLast) emit(tax(i) | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27));
     };
-    const uint32_t mj = meta[j];
+    const uint32_t mj = meta(j);
     one(j, d, mj);
     // j shares at least max(d, 6) letters with the query (a match needs the 6-letter range; '^' may cut d below that)
     const int chain0 = d > RANGE_LETTERS ? d : RANGE_LETTERS;
     uint32_t li = j, ri = j + 1;                                  // next to the left: li - 1; next to the right: ri
     uint32_t mli = mj;                                            // meta[li]: letters li shares with li - 1
-    uint32_t mri = ri < nIdx ? (uint32_t)meta[ri] : 0u;           // meta[ri]: letters ri shares with ri - 1
+    uint32_t mri = ri < nIdx ? (uint32_t)meta(ri) : 0u;           // meta[ri]: letters ri shares with ri - 1
     int lc = li > 0 ? ((int)(mli & LM) < chain0 ? (int)(mli & LM) : chain0) : -1;   // letters the next left entry shares with the query
     int rc = ri < nIdx ? ((int)(mri & LM) < chain0 ? (int)(mri & LM) : chain0) : -1;
     while (lc >= gLow || rc >= gLow) {
         if (lc >= rc) {
             --li;
-            mli = meta[li];
+            mli = meta(li);
             one(li, lc < d ? lc : d, mli);
             const int l = (int)(mli & LM);
             lc = li > 0 ? (l < lc ? l : lc) : -1;
         } else {
             one(ri, rc < d ? rc : d, mri);
             ++ri;
-            if (ri < nIdx) { mri = meta[ri]; const int l = (int)(mri & LM); rc = l < rc ? l : rc; } else rc = -1;
+            if (ri < nIdx) { mri = meta(ri); const int l = (int)(mri & LM); rc = l < rc ? l : rc; } else rc = -1;
         }
     }
 }
@@ -1419,7 +1421,7 @@ __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, const
 //   3. the taxon segments (walk_segments), the first INL of them inline, longer lists in the pool with one allocation
 //      per workgroup;
 //   4. the record goes to rec[slot]: slotOf[p], or p itself when slotOf is NULL (records exported in sorted order).
-template <int RW, class Key>
+template <int RW, class Key, int NKT>                              // NKT: kHigh - kLow + 1 when known at compile time, else 0
 __global__ __launch_bounds__(GTHREADS) void group_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
@@ -1428,11 +1430,17 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
 {
     typedef RecTraits<RW> RT;
-    constexpr int NL = RT::LEVELS, INL = RT::INL;
+    constexpr int NL = NKT ? NKT : RT::LEVELS, INL = RT::INL;       // levels the unrolled loops run over
     __shared__ uint32_t shU[GTHREADS / 64];
     __shared__ uint32_t sFirst[GTHREADS / 64][NL];                 // first closing position of a wavefront, per level
     __shared__ uint32_t sBase;
-    const int nK = kHigh - kLow + 1;
+    // the index entries the tile's walks visit (their taxa and neighbour counts), staged once: the walks are chains of
+    // dependent reads, from LDS they cost tens of cycles instead of a trip to L2/HBM each
+    typedef typename KeyTraits<Key>::Meta Meta;
+    __shared__ uint32_t sTax[GSPAN];
+    __shared__ Meta sMeta[GSPAN];
+    __shared__ uint32_t sRepLo[GTHREADS / 64], sRepHi[GTHREADS / 64];
+    const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const uint32_t base = blockIdx.x * TILE + t * GITEMS;
@@ -1449,6 +1457,18 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             rp[i] = rep[p];
             sp[i] = special_mask(ql, d[i], kHigh, allLv);
         }
+    }
+    {   // span of the representatives (nearly monotone in p): first and last matched query of the wavefront
+        const unsigned long long m0 = __ballot(d[0] != 0), m1 = __ballot(d[1] != 0);
+        const unsigned long long any = m0 | m1;
+        uint32_t lo = NOPOS, hi = 0;
+        if (any) {
+            const int lf = __ffsll((long long)any) - 1, ll = 63 - __clzll((long long)any);
+            const uint32_t a0 = __shfl(rp[0], lf), a1 = __shfl(rp[1], lf), b0 = __shfl(rp[0], ll), b1 = __shfl(rp[1], ll);
+            lo = ((m0 >> lf) & 1ull) ? a0 : a1;
+            hi = ((m1 >> ll) & 1ull) ? b1 : b0;
+        }
+        if (lane == 0) { sRepLo[wv] = lo; sRepHi[wv] = hi; }
     }
     // ---- 1. flush positions
     const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
@@ -1487,6 +1507,18 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             if ((open0 >> lv) & 1u) F[0][lv] = v;
         }
     }
+    uint32_t spanLo = NOPOS, spanHi = 0;
+    for (int w = 0; w < GTHREADS / 64; ++w) { spanLo = min(spanLo, sRepLo[w]); spanHi = max(spanHi, sRepHi[w]); }
+    uint32_t spanN = 0;
+    if (spanLo != NOPOS) {
+        spanLo = spanLo > GMARGIN ? spanLo - GMARGIN : 0u;
+        spanHi = min(spanHi + GMARGIN + 1u, nIdx);
+        spanN = min(spanHi - spanLo, (uint32_t)GSPAN);                // what lies beyond is read from global memory
+        for (uint32_t x = t; x < spanN; x += GTHREADS) { sTax[x] = tax[spanLo + x]; sMeta[x] = meta[spanLo + x]; }
+    }
+    __syncthreads();
+    auto getMeta = [&](uint32_t i) -> uint32_t { const uint32_t x = i - spanLo; return x < spanN ? (uint32_t)sMeta[x] : (uint32_t)meta[i]; };
+    auto getTax = [&](uint32_t i) -> uint32_t { const uint32_t x = i - spanLo; return x < spanN ? sTax[x] : tax[i]; };
     // ---- 2. + 3. per query: order of its events, taxon segments
     uint32_t w2[GITEMS], w3[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
     unsigned __int128 ord[GITEMS];
@@ -1500,29 +1532,41 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         if (d[i] == 0) continue;
         const int lvTop = kHigh - d[i];                           // events: levels lvTop .. nK-1
         uint32_t fm = 0;
+        // rank of an event = events flushed before it: smaller F, or equal F and smaller k (larger lv); one comparison per pair
+        uint32_t rank[NL];
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) rank[lv] = 0;
+#pragma unroll
+        for (int a = 0; a < NL; ++a)
+#pragma unroll
+            for (int b2 = a + 1; b2 < NL; ++b2) {
+                const bool both = a >= lvTop && b2 < nK;
+                const bool aFirst = F[i][a] < F[i][b2];           // a tie goes to b2 (the smaller k)
+                rank[b2] += (both && aFirst) ? 1u : 0u;
+                rank[a] += (both && !aFirst) ? 1u : 0u;
+            }
 #pragma unroll
         for (int lv = 0; lv < NL; ++lv) {
             if (lv < lvTop || lv >= nK) continue;
             const uint32_t f = F[i][lv];
             if (f > fm) fm = f;
-            uint32_t rank = 0;                                    // events flushed before this one: smaller F, or equal F and smaller k
-#pragma unroll
-            for (int l2 = 0; l2 < NL; ++l2)
-                if (l2 >= lvTop && l2 < nK && l2 != lv && (F[i][l2] < f || (F[i][l2] == f && l2 > lv))) ++rank;
-            ord[i] |= (unsigned __int128)(uint32_t)lv << (RT::OBITS * rank);
+            if constexpr (RW == 8) ord[i] |= (unsigned __int128)((uint32_t)lv << (RT::OBITS * rank[lv]));
+            else ord[i] |= (unsigned __int128)(uint32_t)lv << (RT::OBITS * rank[lv]);
         }
         fmax[i] = fm;
         w2[i] = (uint32_t)d[i] | (RW == 8 ? ((uint32_t)ord[i] << 5) : 0u);
         uint32_t n = 0, nlev = 0;                                 // nlev: |T_k| per level, 3 bits each, saturating at 7 (RW = 8)
         bool split = false;                                       // a taxon may own several segments (an entry continues an earlier one of its taxon)
-        walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+        walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
 #pragma unroll
             for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
             ++n;
             if ((int)((s >> 22) & 31u) > kLow) split = true;
-            if constexpr (RW == 8)
-                for (int lv = kHigh - (int)(s >> 27); lv <= kHigh - (int)((s >> 22) & 31u); ++lv)
-                    if (((nlev >> (3 * lv)) & 7u) < 7u) nlev += 1u << (3 * lv);
+            if constexpr (RW == 8) {                                  // + 1 in the 3-bit fields of its levels that are below 7
+                const int lvLo = kHigh - (int)(s >> 27), lvHi = kHigh - (int)((s >> 22) & 31u);
+                const uint32_t fields = ((lvHi >= 7 ? 0u : (1u << (3 * (lvHi + 1)))) - (1u << (3 * lvLo))) & 0x249249u;
+                nlev += fields & ~(nlev & (nlev >> 1) & (nlev >> 2));
+            }
         });
         nseg[i] = n;
         w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
@@ -1532,7 +1576,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
             const Key q = qKmer[base + i];
             const int ql = (base + i == 0) ? 0 : lcp_letters<Key>(qKmer[base + i - 1], q);
-            walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+            walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
                 for (int k = (int)((s >> 22) & 31u); k <= (int)(s >> 27); ++k)
                     if (ql < group_letters(k)) atomicAdd((unsigned long long *)&cntTotal[(size_t)(kHigh - k) * nTaxa + (s & SEG_TAX_MASK)], 1ull);
             });
@@ -1556,7 +1600,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                     pool[off] = nseg[i];
                     uint32_t w = off + 1 + (sat ? POOL_SIZES : 0u), idx = 0;
                     unsigned long long cA = 0, cB = 0;               // exact |T| of the levels 0..3 and 4..7, 16 bits each
-                    walk_segments(rp[i], d[i], kLow, meta, tax, nIdx, [&](uint32_t s) {
+                    walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
                         if (idx >= (uint32_t)(INL - 1)) pool[w++] = s;
                         ++idx;
                         if (sat)
@@ -2114,7 +2158,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
             // ---- A. the taxa that get the register slots: the first two with a deep match
             for (uint32_t j = 0; j < cnt0 && na < FTA && !fb; ++j) {
                 const uint4 h = rp0[(size_t)j * (RW / 4)];
-                if ((h.z & 31u) == 0u) continue;
+                if ((int)(h.z & 31u) < kPromote) continue;                 // no segment reaches deeper than d (unmatched: d = 0)
                 QueryRec<RW> Q;
                 Q.decode(rp0 + (size_t)j * (RW / 4), A.pool);
 #pragma unroll
@@ -2123,8 +2167,9 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                     if ((uint32_t)q < Q.nInl && (int)(Q.sg[q] >> 27) >= kPromote && t != mTax0 && na < FTA) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
                 }
                 for (uint32_t q = 0; q < Q.nMore && na < FTA; ++q) {
-                    const uint32_t t = Q.more[q] & SEG_TAX_MASK;
-                    if ((int)(Q.more[q] >> 27) >= kPromote && t != mTax0) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                    const uint32_t sq = Q.more[q], t = sq & SEG_TAX_MASK;
+                    if ((int)(sq >> 27) < kPromote) break;                     // segments come in descending order of their last level
+                    if (t != mTax0) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
                 }
             }
             // ---- B. their chains, query by query
@@ -2842,11 +2887,15 @@ static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, ui
 {
     const uint64_t nQ = c->nQ;
     if (c->ix->wide)
-        group_kernel<RW, key128><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+        group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
             c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+    else if (RW == 8 && c->nK == 6)                                  // the default -k 12 7: loops over exactly six levels
+        group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
     else
-        group_kernel<RW, uint64_t><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+        group_kernel<RW, uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
             c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
     HIPCHK(hipGetLastError());

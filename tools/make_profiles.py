@@ -21,25 +21,29 @@ def run(cmd, **kw):
     return subprocess.run(cmd, env=env, **kw)
 
 
+PMC_ONLY = "--pmc-only" in sys.argv
 # 1. kernel stats
 d = os.path.join(out, "stats")
-with open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w") as f:
-    run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
-         "--no-cpu", "--no-e2e"], stdout=f, stderr=subprocess.DEVNULL)
-src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(src)))
-with open(os.path.join(out, tag + "_kernel_stats_bench_10M.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
-    for r in rows:
-        w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
-md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
-open(os.path.join(out, tag + "_kernel_stats_bench_10M.md"), "w").write(
-    "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e` on one MI355X\n"
-    "(10 M reads x 150 bp, 419,951,000-record index).  The run holds the index build (one call of encode / lookup of its own) plus 1 warm-up\n"
-    "and 3 timed steps.  The warm-up step launches score_main / score_other twice (the first attempt sizes the staging rows, stops early\n"
-    "and is repeated with the capacity it asked for): their 5th call is that short one, so their averages here are below the per-launch\n"
-    "averages of bench.py's HIP events (total = 4 full launches + 1 short one).  Full names: the .csv next to this file.\n\n" + md)
+if PMC_ONLY:
+    pass
+else:
+  with open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w") as f:
+      run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
+           "--no-cpu", "--no-e2e"], stdout=f, stderr=subprocess.DEVNULL)
+  src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
+  rows = list(csv.DictReader(open(src)))
+  with open(os.path.join(out, tag + "_kernel_stats_bench_10M.csv"), "w") as f:
+      w = csv.writer(f)
+      w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+      for r in rows:
+          w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+  md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
+  open(os.path.join(out, tag + "_kernel_stats_bench_10M.md"), "w").write(
+      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e` on one MI355X\n"
+      "(10 M reads x 150 bp, 419,951,000-record index).  The run holds the index build (one call of encode / lookup of its own) plus 1 warm-up\n"
+      "and 3 timed steps.  The warm-up step launches score_main / score_other twice (the first attempt sizes the staging rows, stops early\n"
+      "and is repeated with the capacity it asked for): their 5th call is that short one, so their averages here are below the per-launch\n"
+      "averages of bench.py's HIP events (total = 4 full launches + 1 short one).  Full names: the .csv next to this file.\n\n" + md)
 
 # 2. PMC passes (counters only; one step of 10 M reads)
 passes = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS",
@@ -68,6 +72,12 @@ for name, cs in acc.items():
 json.dump(res, open(os.path.join(out, tag + "_kernel_pmc.json"), "w"), indent=1)
 
 # 3. the bench line(s)
+if PMC_ONLY:
+    for k, e in res.items():
+        if isinstance(e, dict) and "SQ_INSTS_VALU" in e:
+            ins = e["SQ_INSTS_VALU"] + e["SQ_INSTS_SALU"]
+            print("%-24s insts %.2fe9 -> %.1f ms at 4 cycles; HBM %.1f GB" % (k, ins / 1e9, ins * 4 / (1024 * 2.4e9) * 1e3, e.get("hbm_bytes_per_launch", 0) / 1e9))
+    sys.exit(0)
 args = ["python3", "bench.py", "--steps", "5", "--warmup", "2"] + (["--secondary"] if "--secondary" in sys.argv else [])
 with open(os.path.join(out, tag + "_bench_1gpu.json"), "w") as f:
     run(args, stdout=f, stderr=subprocess.DEVNULL)
