@@ -2458,6 +2458,181 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
     }
 }
 
+// The same for 32-byte records, flattened: the work items of a wavefront are the SEGMENTS of its 64 queries, dealt out
+// evenly to the lanes (64 items per round) -- a query has 1 to hundreds of segments, and a lane that walks its own list
+// keeps the other 63 waiting (the wavefront pays the longest list, and every rare case, each time).  The queries' fields
+// an item needs sit in LDS; the owner of item i is found by bisection over the prefix sums of the segment counts.  An
+// item knows how many records it yields (seg_records), so a segmented prefix sum over the items -- restarting where a
+// new read begins -- gives each record its place in the read's row, and neighbouring lanes write neighbouring records.
+// Queries marked REC_SPLIT (rare) are one item: their owner lane writes their records event by event afterwards.
+template <bool PERREAD>
+__global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
+{
+    constexpr int WV = 4;
+    __shared__ uint32_t sBase[WV][65];                                    // exclusive prefix sums of the queries' item counts
+    __shared__ uint32_t sSg[WV][4][64];                                    // inline segments / pool offset
+    __shared__ uint32_t sW2[WV][64], sW3[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t kindOther = PERREAD ? 0u : RK_PROFILE;
+    const uint32_t stride = gridDim.x * 256u;
+    const double readsPerSlot = (double)A.nReads / (double)A.nQ;
+    const uint32_t nQup = (A.nQ + 63u) & ~63u;
+    const unsigned long long upTo = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes 0..lane
+    for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < nQup; slot += stride) {
+        const bool inRange = slot < A.nQ;
+        uint4 cur[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        uint32_t r = 0;
+        uint64_t readStart = 0;
+        uint4 mo = make_uint4(0, 0, 0, 0);
+        if (inRange) {
+            cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2];
+            cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2 + 1];
+            r = (uint32_t)((double)slot * readsPerSlot);                       // reads are mostly equally long: the guess is right, else search
+            if (r >= A.nReads) r = A.nReads - 1u;
+            readStart = A.kmerOff[r];
+            if (!(readStart <= slot && slot < A.kmerOff[r + 1])) {
+                uint32_t lo = 0, hi = A.nReads;
+                while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (A.kmerOff[mid] <= slot) lo = mid; else hi = mid; }
+                r = lo;
+                readStart = A.kmerOff[r];
+            }
+            mo = reinterpret_cast<const uint4 *>(A.mainOut)[r];
+        }
+        const bool live = inRange && mo.w != 0u && (cur[0].z & 31u) != 0u;     // a matched query of a read the fast path kept
+        const uint32_t mTax0 = mo.x, mTax1 = mo.y;
+        QueryRec<8> Q;
+        Q.decode_regs(cur, A.pool);
+        if (!live) { Q.d = 0; Q.nInl = 0; Q.nMore = 0; Q.split = 0; Q.nseg = 0; }
+        const bool split = Q.split != 0u;
+        const int nEvMine = Q.d ? Q.d - A.kLow + 1 : 0;
+        // levels with |T| > 4: there the register taxa leave profile records instead of counting in LDS (score_main_kernel)
+        const uint32_t xl = Q.nlev, fl = (xl >> 2) & ((xl >> 1) | xl) & 0x249249u;   // field >= 5, one bit per 3-bit field
+        const uint32_t bigLv = (fl & 1u) | ((fl >> 2) & 2u) | ((fl >> 4) & 4u) | ((fl >> 6) & 8u) | ((fl >> 8) & 16u) | ((fl >> 10) & 32u) | ((fl >> 12) & 64u) | ((fl >> 14) & 128u);
+        auto emitMask = [&](uint32_t sq) -> uint32_t {
+            const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+        };
+        uint32_t mineSplit = 0;                                                // a split query's records: one per (segment, level)
+        if (__ballot(split) != 0ull && split) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if ((uint32_t)q < Q.nInl) mineSplit += (uint32_t)__popc(emitMask(Q.sg[q]));
+            for (uint32_t q = 0; q < Q.nMore; ++q) mineSplit += (uint32_t)__popc(emitMask(Q.more[q]));
+        }
+        const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : Q.nseg;
+        uint32_t incl = nFlat;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t S = __shfl(incl, 63);
+        if (S == 0u) continue;                                                 // uniform
+        const bool head = inRange && (uint64_t)slot == readStart;
+        const unsigned long long H = __ballot(head);
+        const bool started = (H & upTo) != 0ull;                               // a read starts at or before this lane, inside the wavefront
+        sBase[wv][lane] = incl - nFlat;
+        if (lane == 63) sBase[wv][64] = S;
+        sSg[wv][0][lane] = Q.sg[0]; sSg[wv][1][lane] = Q.sg[1]; sSg[wv][2][lane] = Q.sg[2]; sSg[wv][3][lane] = Q.sg[3];
+        sW2[wv][lane] = cur[0].z; sW3[wv][lane] = cur[0].w; sT0[wv][lane] = mTax0; sT1[wv][lane] = mTax1; sBig[wv][lane] = bigLv;
+        // reads that began before the wavefront continue from the count score_main_kernel left at the wavefront's first slot
+        sRow[wv][lane] = live ? mo.z + (started ? 0u : A.otherOff64[slot >> 6]) : 0u;
+        sSplit[wv][lane] = mineSplit;
+        LDS_WAVE_SYNC();
+        uint32_t carry = 0;
+        int prevOwnCarry = -1;
+        for (uint32_t b0 = 0; b0 < S; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            const bool act = i < S;
+            uint32_t own = 0;                                                  // the last query whose items start at or before i
+#pragma unroll
+            for (int step = 32; step; step >>= 1) if (sBase[wv][own + step] <= i) own += step;
+            if (!act) own = 63u;
+            const uint32_t first = sBase[wv][own], idx = i - first, nsegOwn = sBase[wv][own + 1] - first;
+            const uint32_t w2 = sW2[wv][own], w3 = sW3[wv][own], poolAt = sSg[wv][3][own];
+            const bool isSplit = (w2 & REC_SPLIT) != 0u;
+            uint32_t sq = 0;
+            const bool seg = act && !isSplit;
+            if (seg) {
+                const uint32_t nInl = nsegOwn <= 4u ? nsegOwn : 3u;
+                if (idx < nInl) sq = sSg[wv][idx][own];
+                else sq = A.pool[poolAt + 1u + ((w2 & REC_SAT) ? POOL_SIZES : 0u) + idx - 3u];
+            }
+            const uint32_t t = sq & SEG_TAX_MASK;
+            const bool isMain = t == sT0[wv][own] || t == sT1[wv][own];
+            const uint32_t m = seg ? seg_level_mask(sq, A.kHigh) : 0u;
+            const uint32_t em = isMain ? (m & sBig[wv][own]) : m;
+            const uint32_t pc = (uint32_t)__popc(em);
+            const bool segRec = !isMain && pc <= 2u;                           // one segment record (seg_records)
+            uint32_t c = segRec ? (pc ? 1u : 0u) : pc;
+            if (act && isSplit) c = sSplit[wv][own];
+            // does a read begin between the previous item's query and this one's?  Then the count restarts here.
+            int prevOwn = __shfl_up((int)own, 1);
+            if (lane == 0) prevOwn = prevOwnCarry;
+            const unsigned long long toOwn = own == 63u ? ~0ull : ((2ull << own) - 1ull);
+            const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
+            bool f = act && (H & toOwn & ~toPrev) != 0ull;
+            uint32_t v = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(v, off);
+                const bool fo = __shfl_up((int)f, off) != 0;
+                if (lane >= off && !f) { v += o; f = fo; }
+            }
+            uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
+            carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
+            prevOwnCarry = __shfl((int)own, 63);
+            const int nEv = (int)(w2 & 31u) - A.kLow + 1;
+            const uint32_t order = (w2 >> 5) & 0xFFFFFFu;
+            auto sizeOf = [&](int lv) -> uint32_t {
+                const uint32_t n = (w3 >> (8 + 3 * lv)) & 7u;
+                return n < 7u ? n : ((A.pool[poolAt + 1u + (uint32_t)(lv >> 1)] >> (16 * (lv & 1))) & 0xFFFFu);
+            };
+            if (act && c) {
+                if (isSplit) sSplit[wv][own] = w;                             // its owner writes them below
+                else if (segRec) {
+                    const int lvLo = __ffs((int)em) - 1, lvHi = 31 - __clz((int)em);   // lvLo = the deeper level (larger k)
+                    // position of a level in the query's flush order (three bits per event): the field that equals lv
+                    auto posOf = [&](int lv) -> int {
+                        const uint32_t x = (order ^ ((uint32_t)lv * 0x249249u)) | (nEv < 8 ? (0xFFFFFFFFu << (3 * nEv)) : 0u);
+                        const uint32_t z = ~(x | (x >> 1) | (x >> 2)) & 0x249249u;
+                        return (__ffs((int)z) - 1) / 3;
+                    };
+                    const bool desc = pc == 2u && posOf(lvLo) < posOf(lvHi);   // the larger k flushes first
+                    A.st[w] = make_uint2(t | ((uint32_t)(A.kHigh - lvHi) << 20) | (desc ? RK_SEG_DESC : 0u) | RK_SEG,
+                                         (uint32_t)(A.kHigh - lvLo) | (sizeOf(lvHi) << 5) | (sizeOf(lvLo) << 18));
+                }
+            }
+            const bool multi = act && c != 0u && !isSplit && !segRec;          // one event record per level, in flush order
+            if (__ballot(multi) != 0ull && multi) {
+                const uint32_t kind = isMain ? RK_PROFILE : kindOther;
+                uint32_t o = order;
+                for (int ev = 0; ev < nEv; ++ev, o >>= 3) {
+                    const int lv = (int)(o & 7u);
+                    if ((em >> lv) & 1u) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (sizeOf(lv) << 16) | 1u);
+                }
+            }
+        }
+        if (__ballot(split && mineSplit) != 0ull) {
+            LDS_WAVE_SYNC();
+            if (split && mineSplit) {
+                // a taxon may own several segments: its records must follow the query's flush order across them -- event by event
+                uint32_t w = sSplit[wv][lane];
+                uint32_t o = (uint32_t)Q.order;
+                auto putEvent = [&](uint32_t sq, int lv) {
+                    const uint32_t t = sq & SEG_TAX_MASK;
+                    const uint32_t kind = (t == mTax0 || t == mTax1) ? RK_PROFILE : kindOther;
+                    A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (Q.set_size(lv, A.kHigh) << 16) | 1u);
+                };
+                for (int ev = 0; ev < nEvMine; ++ev, o >>= 3) {
+                    const int lv = (int)(o & 7u);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if ((uint32_t)q < Q.nInl && ((emitMask(Q.sg[q]) >> lv) & 1u)) putEvent(Q.sg[q], lv);
+                    for (uint32_t q = 0; q < Q.nMore; ++q) { const uint32_t sq = Q.more[q]; if ((emitMask(sq) >> lv) & 1u) putEvent(sq, lv); }
+                }
+            }
+        }
+        LDS_WAVE_SYNC();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // row_merge: one wavefront per staging row written by score_fast_kernel.  Sorts the row's records by
 // (taxon, position) in LDS, sums each taxon's event scores IN THAT ORDER (= the read's flush order), and
@@ -3051,8 +3226,9 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_MAIN], ka, kb))) return rc;
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_OTHER], &ka, &kb))) return rc;
-            if (wantPerRead) { if (RW == 8) score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
-            else { if (RW == 8) score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
+            const bool flat = RW == 8 && !(c->debugFlags & 32);              // debug flag 32: the per-lane kernel for narrow records too
+            if (wantPerRead) { if (flat) score_other_flat_kernel<true><<<oblocks, 256, 0, c->stream>>>(A); else if (RW == 8) score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
+            else { if (flat) score_other_flat_kernel<false><<<oblocks, 256, 0, c->stream>>>(A); else if (RW == 8) score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_OTHER], ka, kb))) return rc;
             uint32_t h3 = 0; unsigned long long want[2] = {0, 0};

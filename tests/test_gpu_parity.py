@@ -140,7 +140,7 @@ def test_medium_synthetic_vs_oracle():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    for slow in (0, 1, 2, 4):
+    for slow in (0, 1, 2, 4, 32):                               # 32: score_other_kernel per lane instead of flattened
         ctx.debug_flags(slow)
         ctx.profile_reset()
         ctx.run_batch(batch.bases, batch.offsets, True)
@@ -349,6 +349,7 @@ def test_many_taxa_per_read_and_large_content():
     batch = reads.synthetic_reads(genomes, 64, 150, 77)
     slow = _check_against_oracle(ix, batch, 12, 7, 3)
     _check_against_oracle(ix, batch, 12, 7, 3, flags=4)
+    _check_against_oracle(ix, batch, 12, 7, 3, flags=32)
     _check_against_oracle(ix, batch, 12, 7, 3, flags=1)
     assert slow >= 0
 
@@ -550,7 +551,7 @@ def test_index_build_matches_reference_files(stem, K, tmp_path):
 
 
 @pytest.mark.parametrize("case", [(12, 7, 3, 12, 0), (12, 7, 6, 12, 0), (25, 7, 3, 25, 0), (12, 1, 3, 12, 0), (12, 7, 3, 12, 1), (12, 7, 3, 12, 8),
-                                  (25, 7, 6, 25, 8), (12, 7, 3, 12, 16), (25, 7, 3, 25, 16)])
+                                  (25, 7, 6, 25, 8), (12, 7, 3, 12, 16), (25, 7, 3, 25, 16), (12, 7, 3, 12, 32)])
 def test_profile_only_equals_per_read_run(case):
     """Without -q (kasa_batch_lookup_score(wantPerRead = 0)) the fast kernel skips ordering and float sums; the profile
     tables must be the same integers as those of the full run, and equal the oracle's."""
@@ -605,7 +606,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20]))
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40]))
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
