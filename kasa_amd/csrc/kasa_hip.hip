@@ -2470,8 +2470,8 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
 {
     constexpr int WV = 4;
     __shared__ uint32_t sBase[WV][65];                                    // exclusive prefix sums of the queries' item counts
-    __shared__ uint32_t sSg[WV][4][64];                                    // inline segments / pool offset
-    __shared__ uint32_t sW2[WV][64], sW3[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64];
+    __shared__ uint32_t sSg[WV][4][64];                                    // the inline segments that leave records, compacted
+    __shared__ uint32_t sW2[WV][64], sW3[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64], sPool[WV][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t kindOther = PERREAD ? 0u : RK_PROFILE;
     const uint32_t stride = gridDim.x * 256u;
@@ -2518,7 +2518,12 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
             for (int q = 0; q < 4; ++q) if ((uint32_t)q < Q.nInl) mineSplit += (uint32_t)__popc(emitMask(Q.sg[q]));
             for (uint32_t q = 0; q < Q.nMore; ++q) mineSplit += (uint32_t)__popc(emitMask(Q.more[q]));
         }
-        const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : Q.nseg;
+        // items: the inline segments that leave records (most belong to the register taxa and do not) and all pool segments
+        uint32_t emInl = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if ((uint32_t)q < Q.nInl && emitMask(Q.sg[q]) != 0u) emInl |= 1u << q;
+        const uint32_t nEmInl = (uint32_t)__popc(emInl);
+        const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
         uint32_t incl = nFlat;
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
@@ -2531,8 +2536,11 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
         const bool started = (H & upTo) != 0ull;                               // a read starts at or before this lane, inside the wavefront
         sBase[wv][lane] = incl - nFlat;
         if (lane == 63) sBase[wv][64] = S;
-        sSg[wv][0][lane] = Q.sg[0]; sSg[wv][1][lane] = Q.sg[1]; sSg[wv][2][lane] = Q.sg[2]; sSg[wv][3][lane] = Q.sg[3];
-        sW2[wv][lane] = cur[0].z; sW3[wv][lane] = cur[0].w; sT0[wv][lane] = mTax0; sT1[wv][lane] = mTax1; sBig[wv][lane] = bigLv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if ((emInl >> q) & 1u) sSg[wv][__popc(emInl & ((1u << q) - 1u))][lane] = Q.sg[q];
+        sPool[wv][lane] = Q.sg[3];                                             // pool block of the query (when it has one)
+        sW2[wv][lane] = cur[0].z; sW3[wv][lane] = (cur[0].w & ~255u) | (nEmInl << 4) | (Q.nMore ? 1u : 0u);   // low byte: items in LDS; has a pool block
+        sT0[wv][lane] = mTax0; sT1[wv][lane] = mTax1; sBig[wv][lane] = bigLv;
         // reads that began before the wavefront continue from the count score_main_kernel left at the wavefront's first slot
         sRow[wv][lane] = live ? mo.z + (started ? 0u : A.otherOff64[slot >> 6]) : 0u;
         sSplit[wv][lane] = mineSplit;
@@ -2546,15 +2554,15 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
 #pragma unroll
             for (int step = 32; step; step >>= 1) if (sBase[wv][own + step] <= i) own += step;
             if (!act) own = 63u;
-            const uint32_t first = sBase[wv][own], idx = i - first, nsegOwn = sBase[wv][own + 1] - first;
-            const uint32_t w2 = sW2[wv][own], w3 = sW3[wv][own], poolAt = sSg[wv][3][own];
+            const uint32_t idx = i - sBase[wv][own];
+            const uint32_t w2 = sW2[wv][own], w3 = sW3[wv][own], poolAt = sPool[wv][own];
             const bool isSplit = (w2 & REC_SPLIT) != 0u;
             uint32_t sq = 0;
             const bool seg = act && !isSplit;
             if (seg) {
-                const uint32_t nInl = nsegOwn <= 4u ? nsegOwn : 3u;
+                const uint32_t nInl = (w3 >> 4) & 7u;
                 if (idx < nInl) sq = sSg[wv][idx][own];
-                else sq = A.pool[poolAt + 1u + ((w2 & REC_SAT) ? POOL_SIZES : 0u) + idx - 3u];
+                else sq = A.pool[poolAt + 1u + ((w2 & REC_SAT) ? POOL_SIZES : 0u) + idx - nInl];
             }
             const uint32_t t = sq & SEG_TAX_MASK;
             const bool isMain = t == sT0[wv][own] || t == sT1[wv][own];
