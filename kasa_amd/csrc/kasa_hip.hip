@@ -2129,6 +2129,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
     __shared__ Counter cnt[FTA * NL][64];
     __shared__ float sTab[NL][8];                                    // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
+    __shared__ uint32_t sPB[65], sPPtr[64], sPT0[64], sPT1[64], sPM0[64], sPM1[64], sPRec[64], sPKey[64];   // pool segments of the current queries
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
@@ -2150,59 +2151,120 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu, nOther = 0, nKeys = 0;   // records / profile keys of the other taxa
         float mS0 = 0.0f, mS1 = 0.0f;
         for (int l2 = 0; l2 < FTA * nK; ++l2) cnt[(l2 / nK) * NL + (l2 % nK)][lane] = 0;
+        uint64_t o0 = 0;
+        uint32_t cnt0 = 0;
+        const uint4 *rp0 = reinterpret_cast<const uint4 *>(A.rec);
         if (active) {
-            const uint64_t o0 = A.kmerOff[r];
-            const uint32_t cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
+            o0 = A.kmerOff[r];
+            cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
             if (cnt0 > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
-            const uint4 *rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
-            // ---- A. the taxa that get the register slots: the first two with a deep match
+            rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
+            // ---- A. the taxa that get the register slots: the first two with a deep match (segments come in descending
+            // order of their last level: the search of a query ends at the first shallow one)
             for (uint32_t j = 0; j < cnt0 && na < FTA && !fb; ++j) {
-                const uint4 h = rp0[(size_t)j * (RW / 4)];
+                const uint4 *q4 = rp0 + (size_t)j * (RW / 4);
+                const uint4 h = q4[0];
                 if ((int)(h.z & 31u) < kPromote) continue;                 // no segment reaches deeper than d (unmatched: d = 0)
-                QueryRec<RW> Q;
-                Q.decode(rp0 + (size_t)j * (RW / 4), A.pool);
+                uint32_t sg[RT::INL];
+                if constexpr (RW == 8) { const uint4 b4 = q4[1]; sg[0] = b4.x; sg[1] = b4.y; sg[2] = b4.z; sg[3] = b4.w; }
+                else { const uint4 s0 = q4[2], s1 = q4[3]; sg[0] = s0.x; sg[1] = s0.y; sg[2] = s0.z; sg[3] = s0.w; sg[4] = s1.x; sg[5] = s1.y; sg[6] = s1.z; sg[7] = s1.w; }
+                const uint32_t ns = RW == 8 ? (h.w & 255u) : h.w;
+                const uint32_t nInl = ns <= (uint32_t)RT::INL ? ns : (uint32_t)RT::INL - 1u;
 #pragma unroll
                 for (int q = 0; q < RT::INL; ++q) {
-                    const uint32_t t = Q.sg[q] & SEG_TAX_MASK;
-                    if ((uint32_t)q < Q.nInl && (int)(Q.sg[q] >> 27) >= kPromote && t != mTax0 && na < FTA) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                    const uint32_t t = sg[q] & SEG_TAX_MASK;
+                    if ((uint32_t)q < nInl && (int)(sg[q] >> 27) >= kPromote && t != mTax0 && na < FTA) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
                 }
-                for (uint32_t q = 0; q < Q.nMore && na < FTA; ++q) {
-                    const uint32_t sq = Q.more[q], t = sq & SEG_TAX_MASK;
-                    if ((int)(sq >> 27) < kPromote) break;                     // segments come in descending order of their last level
-                    if (t != mTax0) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                if (ns > (uint32_t)RT::INL && na < FTA && (int)(sg[RT::INL - 2] >> 27) >= kPromote) {   // rare: the deep segments go on in the pool
+                    const uint32_t *more = A.pool + sg[RT::INL - 1] + 1u + ((RW == 8 && (h.z & REC_SAT)) ? POOL_SIZES : 0u);
+                    const uint32_t nAll = (RW == 8 && ns == 255u) ? A.pool[sg[RT::INL - 1]] : ns;
+                    for (uint32_t q = 0; q + (uint32_t)(RT::INL - 1) < nAll && na < FTA; ++q) {
+                        const uint32_t sq = more[q], t = sq & SEG_TAX_MASK;
+                        if ((int)(sq >> 27) < kPromote) break;
+                        if (t != mTax0) { if (na == 0) mTax0 = t; else mTax1 = t; ++na; }
+                    }
                 }
             }
-            // ---- B. their chains, query by query
+        }
+        // ---- B. their chains, query by query.  All lanes step together (the pool segments of the 64 current queries are
+        // dealt out to the lanes: one dependent pool read per step instead of one per segment of the longest list).
+        sPT0[lane] = mTax0; sPT1[lane] = mTax1;
+        uint32_t maxCnt = (active && !fb) ? cnt0 : 0u;
+        for (int off = 32; off; off >>= 1) maxCnt = max(maxCnt, (uint32_t)__shfl_xor((int)maxCnt, off));
+        {
             uint32_t prevF = 0;
-            const uint4 *rp = rp0;
-            for (uint32_t j = 0; j < cnt0 && !fb; ++j, rp += RW / 4) {
-                if (((o0 + j) & 63u) == 0u) A.otherOff64[(o0 + j) >> 6] = nOther;   // for score_other_kernel: the count so far at a wavefront's first slot
-                if ((rp[0].z & 31u) == 0u) continue;
-                QueryRec<RW> Q;
-                Q.decode(rp, A.pool);
-                if (PERREAD) {
-                    if (prevF > Q.p) { fb = true; atomicAdd(&A.why[4], 1u); break; }   // an earlier group is still open here
-                    prevF = Q.fmax;
+            uint4 nxt[RW / 4];
+#pragma unroll
+            for (int i = 0; i < RW / 4; ++i) nxt[i] = make_uint4(0, 0, 0, 0);
+            if (active && !fb && cnt0 > 0) {
+#pragma unroll
+                for (int i = 0; i < RW / 4; ++i) nxt[i] = rp0[i];
+            }
+            for (uint32_t j = 0; j < maxCnt; ++j) {
+                const bool has = active && !fb && j < cnt0;
+                uint4 v[RW / 4];
+#pragma unroll
+                for (int i = 0; i < RW / 4; ++i) v[i] = nxt[i];
+                if (active && !fb && j + 1u < cnt0) {                          // the next record is on its way while this one is replayed
+#pragma unroll
+                    for (int i = 0; i < RW / 4; ++i) nxt[i] = rp0[(size_t)(j + 1u) * (RW / 4) + i];
                 }
-                if (Q.nseg >= (1u << 13)) { fb = true; atomicAdd(&A.why[3], 1u); break; }
-                const int nEv = Q.d - A.kLow + 1;
-                const bool sat = RW == 8 && (rp[0].z & REC_SPLIT) != 0u;   // then: one event record per level (seg_records)
+                if (has && ((o0 + j) & 63u) == 0u) A.otherOff64[(o0 + j) >> 6] = nOther;   // for score_other_kernel: the count so far at a wavefront's first slot
+                bool live = has && (v[0].z & 31u) != 0u;
+                if (!live) {
+#pragma unroll
+                    for (int i = 0; i < RW / 4; ++i) v[i] = make_uint4(0, 0, 0, 0);
+                }
+                QueryRec<RW> Q;
+                Q.decode_regs(v, A.pool);
+                if (PERREAD && live) {
+                    if (prevF > Q.p) { fb = true; live = false; atomicAdd(&A.why[4], 1u); }   // an earlier group is still open here
+                    else prevF = Q.fmax;
+                }
+                if (live && Q.nseg >= (1u << 13)) { fb = true; live = false; atomicAdd(&A.why[3], 1u); }
+                const bool sat = RW == 8 && (v[0].z & REC_SPLIT) != 0u;        // then: one event record per level (seg_records)
                 uint32_t mask0 = 0, mask1 = 0;
 #pragma unroll
                 for (int q = 0; q < RT::INL; ++q) {
-                    if ((uint32_t)q >= Q.nInl) continue;
+                    if (!live || (uint32_t)q >= Q.nInl) continue;
                     const uint32_t t = Q.sg[q] & SEG_TAX_MASK, m = seg_level_mask(Q.sg[q], A.kHigh);
                     if (t == mTax0) mask0 |= m;
                     else if (t == mTax1) mask1 |= m;
                     else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
                 }
-                for (uint32_t q = 0; q < Q.nMore; ++q) {
-                    const uint32_t sq = Q.more[q], t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
-                    if (t == mTax0) mask0 |= m;
-                    else if (t == mTax1) mask1 |= m;
-                    else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
+                const uint32_t nm = live ? Q.nMore : 0u;
+                if (__ballot(nm != 0u) != 0ull) {
+                    uint32_t incl = nm;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t o = __shfl_up(incl, off);
+                        if (lane >= off) incl += o;
+                    }
+                    const uint32_t S = __shfl(incl, 63);
+                    const unsigned long long satMask = __ballot(sat);
+                    sPB[lane] = incl - nm;
+                    if (lane == 63) sPB[64] = S;
+                    sPPtr[lane] = (uint32_t)(Q.more - A.pool);
+                    sPM0[lane] = 0u; sPM1[lane] = 0u; sPRec[lane] = 0u; sPKey[lane] = 0u;
+                    LDS_WAVE_SYNC();
+                    for (uint32_t b0 = 0; b0 < S; b0 += 64) {
+                        const uint32_t i = b0 + lane;
+                        if (i < S) {
+                            uint32_t own = 0;
+#pragma unroll
+                            for (int step = 32; step; step >>= 1) if (sPB[own + step] <= i) own += step;
+                            const uint32_t sq = A.pool[sPPtr[own] + (i - sPB[own])];
+                            const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+                            if (t == sPT0[own]) atomicOr(&sPM0[own], m);
+                            else if (t == sPT1[own]) atomicOr(&sPM1[own], m);
+                            else { atomicAdd(&sPRec[own], seg_records<RW>(m, ((satMask >> own) & 1ull) != 0ull)); atomicAdd(&sPKey[own], (uint32_t)__popc(m)); }
+                        }
+                    }
+                    LDS_WAVE_SYNC();
+                    mask0 |= sPM0[lane]; mask1 |= sPM1[lane]; nOther += sPRec[lane]; nKeys += sPKey[lane];
+                    LDS_WAVE_SYNC();
                 }
                 if ((mask0 | mask1) == 0u) continue;
+                const int nEv = Q.d - A.kLow + 1;
                 unsigned __int128 o = Q.order;
                 for (int ev = 0; ev < nEv; ++ev, o >>= OB) {
                     const int lv = (int)((uint32_t)o & ((1u << OB) - 1u));
