@@ -145,6 +145,29 @@ int kasa_batch_records_import(kasa_ctx *ctx, const uint32_t *records, uint64_t n
 int kasa_batch_scores_size(kasa_ctx *ctx, uint64_t *nnz);
 int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxIdx, float *score);
 
+/* Ranking on the device (Compare::scoringFunc, Compare.hpp:1495-1594 and the printing loops
+ * :1721-1754): instead of the whole CSR only what the per-read file can print leaves the device.
+ *   den        [nClasses][nTaxa] doubles, row c = 1 + log2(freq[t] * double(uint32(len_c - 3K + 1))) for the c-th distinct
+ *              read length of the batch (len_c - K + 1 for protein input), computed by the host with libm exactly as
+ *              Compare.hpp:1506-1511 does; readClass[r] = the row of read r
+ *   threshold  -t (relative scores below it are dropped), beasts = -b
+ * Per read the hits are taken in the order (relative score descending, taxon ascending) for as long as the TSV or the
+ * JSON / JSONL / Kraken writer would print another one.  kasa_batch_rank_fetch delivers
+ *   meta[4 r .. 4 r + 3] = { first entry, number of entries | flag << 31, float bits of the largest k-mer score among
+ *                            the hits, number of hits }
+ *   entries[i]           = { uint32 taxIdx, float kmerScore, double relativeScore }   (16 bytes)
+ * A writer that runs the reference's loops over these entries (as if they were all hits, with the delivered maximum)
+ * prints what it would print from the full row.  flag: the read has more than 16 hits and its printed prefix touches a
+ * tie in the relative score (std::sort is only stable up to 16 elements), or the prefix is longer than 64 entries: the
+ * host ranks such a read from its full row (kasa_batch_scores_fetch).  nFlagged counts them. */
+int kasa_batch_rank(kasa_ctx *ctx, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
+                    uint64_t *nEntries, uint32_t *nFlagged);
+int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);
+
+/* Page-locked host memory for buffers that cross PCIe (reads in, ranked hits or CSR out).  NULL when it cannot be had. */
+void *kasa_host_alloc(size_t bytes);
+void kasa_host_free(void *p);
+
 /* ---- profile tables: vCount_all / vCount_unique / vCount_total (Compare.hpp:2830-2839) ---------- */
 int kasa_profile_reset(kasa_ctx *ctx);
 /* countAll as double (exact 64.64 fixed-point sums rounded once), countUnique, countTotal; any may

@@ -26,6 +26,7 @@ EXPORTS = [
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
+    "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
 ]
 
 
@@ -53,6 +54,12 @@ def lib():
         L.kasa_refbatch_read_overhead.argtypes = [C.c_int64, C.c_uint32]
         L.kasa_refbatch_cut.restype = C.c_uint64
         L.kasa_refbatch_cut.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_uint64]
+        L.kasa_host_alloc.restype = C.c_void_p
+        L.kasa_host_alloc.argtypes = [C.c_size_t]
+        L.kasa_host_free.restype = None
+        L.kasa_host_free.argtypes = [C.c_void_p]
+        L.kasa_batch_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.kasa_batch_rank_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -149,6 +156,23 @@ class RefBatcher:
             out.append(done)
             first = 0
         return out
+
+
+RANK_ENTRY = np.dtype([("tax", np.uint32), ("score", np.float32), ("rel", np.float64)])
+
+
+def pinned_empty(n: int, dtype) -> np.ndarray:
+    """numpy array over page-locked memory (kasa_host_alloc): PCIe transfers to and from it run at link rate.  The block
+    is freed when the array (and every view of it) is gone."""
+    import weakref
+    dtype = np.dtype(dtype)
+    nbytes = max(1, int(n) * dtype.itemsize)
+    ptr = lib().kasa_host_alloc(C.c_size_t(nbytes))
+    if not ptr:
+        raise MemoryError(f"kasa_host_alloc({nbytes}) failed")
+    arr = np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype, count=int(n))
+    weakref.finalize(arr, lib().kasa_host_free, C.c_void_p(ptr))
+    return arr
 
 
 def device_count() -> int:
@@ -278,15 +302,39 @@ class Context:
         pool = np.ascontiguousarray(pool, dtype=np.uint32)
         _check(lib().kasa_batch_records_import(self.h, _p(rec), C.c_uint64(rec.shape[0]), _p(pool), C.c_uint64(pool.shape[0])))
 
-    def scores(self):
-        """CSR (offsets u64[nReads+1], taxIdx u32[nnz], score f32[nnz])."""
+    def scores(self, pinned: bool = False, out=None):
+        """CSR (offsets u64[nReads+1], taxIdx u32[nnz], score f32[nnz]); pinned: into page-locked memory (link rate);
+        out = (off, tax, sc): buffers of a long-lived host (page-locking 10 GB takes about a second), at least as large."""
         nnz = C.c_uint64(0)
         _check(lib().kasa_batch_scores_size(self.h, C.byref(nnz)))
-        off = np.zeros(self.n_reads + 1, dtype=np.uint64)
-        tax = np.zeros(nnz.value, dtype=np.uint32)
-        sc = np.zeros(nnz.value, dtype=np.float32)
+        if out is not None:
+            off, tax, sc = out[0][:self.n_reads + 1], out[1][:nnz.value], out[2][:nnz.value]
+            assert off.shape[0] == self.n_reads + 1 and tax.shape[0] == nnz.value and sc.shape[0] == nnz.value
+            _check(lib().kasa_batch_scores_fetch(self.h, _p(off), _p(tax), _p(sc)))
+            return off, tax, sc
+        alloc = pinned_empty if pinned else (lambda n, dt: np.zeros(n, dtype=dt))
+        off = alloc(self.n_reads + 1, np.uint64)
+        tax = alloc(nnz.value, np.uint32)
+        sc = alloc(nnz.value, np.float32)
         _check(lib().kasa_batch_scores_fetch(self.h, _p(off), _p(tax), _p(sc)))
         return off, tax, sc
+
+    def rank(self, den: np.ndarray, read_class: np.ndarray, threshold: float, beasts: int, pinned: bool = True, out=None):
+        """kasa_batch_rank + fetch: (meta u32[nReads, 4], entries RANK_ENTRY[nEntries], nFlagged).  den: float64
+        [nClasses, nTaxa]; read_class: uint32[nReads]; out = (meta u32[4 nReads], entries) buffers to reuse."""
+        den = np.ascontiguousarray(den, dtype=np.float64)
+        read_class = np.ascontiguousarray(read_class, dtype=np.uint32)
+        n_ent, n_flag = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().kasa_batch_rank(self.h, _p(den), C.c_uint32(den.shape[0]), _p(read_class), C.c_float(threshold),
+                                     C.c_uint32(beasts), C.byref(n_ent), C.byref(n_flag)))
+        alloc = pinned_empty if pinned else (lambda n, dt: np.empty(n, dtype=dt))
+        if out is not None and out[1].shape[0] >= n_ent.value:
+            meta, ent = out[0][:self.n_reads * 4], out[1][:n_ent.value]
+        else:
+            meta = alloc(self.n_reads * 4, np.uint32)
+            ent = alloc(n_ent.value, RANK_ENTRY)
+        _check(lib().kasa_batch_rank_fetch(self.h, _p(meta), _p(ent)))
+        return meta.reshape(-1, 4), ent, n_flag.value
 
     def run_batch(self, bases, offsets, want_per_read=True, coverage=False, unique=False, seg_read=None, n_reads=None):
         self.upload(bases, offsets, seg_read, n_reads)

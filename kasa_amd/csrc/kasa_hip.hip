@@ -454,6 +454,7 @@ struct kasa_ctx {
     uint32_t maxCnt = 0;
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
+    DevBuf rankDen, rankClass, rankMeta, rankOut; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
     bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
     bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
@@ -3595,6 +3596,166 @@ extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint3
     if (c->nnz && score) HIPCHK(hipMemcpy(score, c->outScore.p, c->nnz * 4, hipMemcpyDeviceToHost));
     return KASA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ranking on the device: what the per-read file can print, instead of the whole CSR, crosses PCIe
+// ------------------------------------------------------------------------------------------------
+// Compare::scoringFunc (Compare.hpp:1495-1594, 1721-1754) per read: relative score = k-mer score / (1 + log2(freq * span)),
+// threshold, sort by relative score (descending), "top hits" while score / max > 0.8f, "further hits" until -b distinct
+// k-mer scores were seen.  The denominators come from the host (libm's log2, one row per distinct read length); the
+// division is IEEE double on both sides.  One wavefront per read selects the next-best hit (relative score descending,
+// taxon ascending = what a stable sort gives) until neither output format would print another one, and emits that
+// prefix.  std::sort is only stable up to 16 elements: a read with more hits whose printed prefix touches a tie in the
+// relative score is flagged and ranked by the host from its full row (so is one whose prefix exceeds RANK_CAP).
+static constexpr int RANK_CAP = 64, RANK_CACHE = 256;
+struct RankEntry { uint32_t tax; float score; double rel; };
+__global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
+                                                   uint32_t nReads, const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
+                                                   double thr, uint32_t beasts, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
+                                                   unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged)
+{
+    __shared__ RankEntry sOut[4][RANK_CAP];
+    __shared__ double sRel[4][RANK_CACHE];                             // relative scores of the row's first cells (NaN: no hit)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += gridDim.x * 4u) {
+        const uint64_t lo = rowOff[r];
+        const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
+        const double *dr = den + (size_t)readClass[r] * nTaxa;
+        auto relOf = [&](uint32_t i) -> double {                       // NaN unless cell i is a hit
+            const float sc = rowScore[lo + i];
+            const double rel = (double)sc / dr[rowTax[lo + i]];
+            return (sc > 0.0f && rel >= thr) ? rel : qnan;
+        };
+        uint32_t cnt = 0;
+        float maxV = 0.0f;
+        for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            double rel = qnan;
+            if (i < m) { rel = relOf(i); if (i < (uint32_t)RANK_CACHE) sRel[wv][i] = rel; }
+            const bool ok = rel == rel;
+            cnt += (uint32_t)__popcll(__ballot(ok));
+            if (ok) maxV = fmaxf(maxV, rowScore[lo + i]);
+        }
+        for (int off = 32; off; off >>= 1) maxV = fmaxf(maxV, __shfl_xor(maxV, off));
+        LDS_WAVE_SYNC();
+        auto relAt = [&](uint32_t i) -> double { return i < (uint32_t)RANK_CACHE ? sRel[wv][i] : relOf(i); };
+        // selection, in step with the two printing loops (JSON / JSONL / Kraken: top + further hits; TSV: one list)
+        uint32_t nOut = 0, top = 0, jJ = 0, jT = 0;
+        float beforeJ = 0.0f, beforeT = 0.0f;
+        bool topDone = false, doneJ = false, doneT = false, flag = false;
+        double lastRel = 0.0; uint32_t lastTax = 0;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            // the next hit after (lastRel, lastTax) in the order (relative score descending, taxon ascending)
+            double bRel = qnan; uint32_t bTax = 0xFFFFFFFFu; float bScore = 0.0f;
+            for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                if (i >= m) continue;
+                const double rel = relAt(i);
+                if (!(rel == rel)) continue;
+                const uint32_t t = rowTax[lo + i];
+                if (k > 0 && !(rel < lastRel || (rel == lastRel && t > lastTax))) continue;   // selected before
+                if (!(bRel == bRel) || rel > bRel || (rel == bRel && t < bTax)) { bRel = rel; bTax = t; bScore = rowScore[lo + i]; }
+            }
+            for (int off = 32; off; off >>= 1) {
+                const double oRel = __shfl_xor(bRel, off); const uint32_t oTax = (uint32_t)__shfl_xor((int)bTax, off); const float oSc = __shfl_xor(bScore, off);
+                if ((oRel == oRel) && (!(bRel == bRel) || oRel > bRel || (oRel == bRel && oTax < bTax))) { bRel = oRel; bTax = oTax; bScore = oSc; }
+            }
+            // ties: other remaining hits with the same relative score (their order is only defined for stable sorts)
+            uint32_t same = 0;
+            for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+                const uint32_t i = c0 + lane;
+                bool eq = false;
+                if (i < m) { const double rel = relAt(i); eq = rel == bRel && rowTax[lo + i] > bTax; }
+                same += (uint32_t)__popcll(__ballot(eq));
+            }
+            // would a writer print hit k?
+            bool printed = false;
+            if (!doneT) { if (jT >= beasts) doneT = true; else { printed = true; if (beforeT != bScore) { beforeT = bScore; ++jT; } } }
+            if (!topDone) {
+                if (k == 0) { top = 1; printed = true; }
+                else if (k < beasts && bScore / maxV > 0.8f) { ++top; printed = true; }
+                else { topDone = true; jJ = top; }
+            }
+            if (topDone && !doneJ) { if (jJ >= beasts) doneJ = true; else { printed = true; if (beforeJ != bScore) { beforeJ = bScore; ++jJ; } } }
+            if (!printed) break;
+            if (same && cnt > 16u) flag = true;
+            if (nOut >= (uint32_t)RANK_CAP) { flag = true; break; }
+            if (lane == 0) sOut[wv][nOut] = RankEntry{bTax, bScore, bRel};
+            ++nOut;
+            lastRel = bRel; lastTax = bTax;
+        }
+        unsigned long long at = 0;
+        if (lane == 0 && nOut) at = atomicAdd(cursor, (unsigned long long)nOut);
+        at = __shfl(at, 0);
+        LDS_WAVE_SYNC();
+        if (at + nOut <= cap) for (uint32_t x = lane; x < nOut; x += 64) entries[at + x] = sOut[wv][x];
+        if (lane == 0) {
+            meta[r] = make_uint4((uint32_t)at, nOut | (flag ? 0x80000000u : 0u), __float_as_uint(maxV), cnt);
+            if (flag) atomicAdd(nFlagged, 1u);
+        }
+        LDS_WAVE_SYNC();
+    }
+}
+
+extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
+                               uint64_t *nEntries, uint32_t *nFlagged)
+{
+    if (!c || !den || !readClass || !nEntries || !nFlagged) return fail(KASA_E_ARG, "kasa_batch_rank: NULL argument");
+    if (!c->haveScores) return fail(KASA_E_STATE, "kasa_batch_rank: no per-read scores (call kasa_batch_lookup_score with wantPerRead)");
+    if (nClasses == 0) return fail(KASA_E_ARG, "kasa_batch_rank: no denominator rows");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t nTaxa = c->ix->nTaxa, nReads = (uint32_t)c->nReads;
+    int rc;
+    if ((rc = c->rankDen.reserve((size_t)nClasses * nTaxa * 8)) || (rc = c->rankClass.reserve((size_t)nReads * 4 + 64)) ||
+        (rc = c->rankMeta.reserve((size_t)nReads * 16 + 64)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(c->rankDen.p, den, (size_t)nClasses * nTaxa * 8, hipMemcpyHostToDevice, c->stream));
+    if (nReads) HIPCHK(hipMemcpyAsync(c->rankClass.p, readClass, (size_t)nReads * 4, hipMemcpyHostToDevice, c->stream));
+    unsigned long long *cursor = c->misc.as<unsigned long long>() + 20;
+    uint32_t *flagged = c->misc.as<uint32_t>() + 42;
+    if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1024, (uint64_t)nReads * 4);
+    c->rankEntries = 0; *nEntries = 0; *nFlagged = 0;
+    if (nReads == 0) return KASA_OK;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if ((rc = c->rankOut.reserve(c->rankCap * sizeof(RankEntry)))) return rc;
+        HIPCHK(hipMemsetAsync(cursor, 0, 8, c->stream));
+        HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
+        const unsigned blocks = std::min<unsigned>(blocks_for(nReads, 4), 256u * 32u);
+        rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->outTax.as<uint32_t>(), c->outScore.as<float>(), nReads,
+                                                   c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
+                                                   c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged);
+        HIPCHK(hipGetLastError());
+        unsigned long long used = 0; uint32_t nf = 0;
+        HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (used <= c->rankCap) { c->rankEntries = used; *nEntries = used; *nFlagged = nf; return KASA_OK; }
+        c->rankCap = used + used / 8 + 1024;                               // the kernel has no side effects: grow and rerun
+    }
+    return fail(KASA_E_LIMIT, "kasa_batch_rank: output did not converge");
+}
+
+extern "C" int kasa_batch_rank_fetch(kasa_ctx *c, uint32_t *meta, void *entries)
+{
+    if (!c || !meta) return fail(KASA_E_ARG, "kasa_batch_rank_fetch: NULL argument");
+    if (!c->haveScores) return fail(KASA_E_STATE, "kasa_batch_rank_fetch: no ranked batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (c->nReads) HIPCHK(hipMemcpyAsync(meta, c->rankMeta.p, (size_t)c->nReads * 16, hipMemcpyDeviceToHost, c->stream));
+    if (c->rankEntries && entries) HIPCHK(hipMemcpyAsync(entries, c->rankOut.p, c->rankEntries * sizeof(RankEntry), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+// Page-locked host memory for the buffers that cross PCIe (reads in, ranked hits or CSR out): transfers from pageable
+// memory are staged by the runtime at a fraction of the link rate.
+extern "C" void *kasa_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void kasa_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 // ------------------------------------------------------------------------------------------------
 // profile tables

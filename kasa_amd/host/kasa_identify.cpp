@@ -454,6 +454,7 @@ struct Params {
     string codonFile, codonId;                   // -a/--alphabet <gc.prt> <id>
     bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
+    bool hostRank = false;                         // --host-rank: the whole CSR comes back and the host ranks every read
     int memoryGiB = 0, refThreads = 1; bool ram = false;   // -m / -n / -r as the reference's batch budget sees them (kasa_refbatch_*)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
@@ -505,17 +506,35 @@ struct Writer {
     }
 
     bool lastContaminated = false;   // --filter: the read just written comes within --errorThreshold of the perfect score
+    // host ranking of one read from its full row (Compare.hpp:1501-1524)
     void read(string &o, uint64_t number, const string &name, uint32_t len, const uint32_t *tax, const float *score, uint64_t n)
     {
-        lastContaminated = false;
-        using numtext::dtoa; using numtext::itoa;
-        const float best = bestScore(len, p);
         int64_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
             if (!(score[i] > 0.f)) continue;
             const double rel = score[i] / (1.0 + log2(freq[tax[i]] * double(uint32_t(len - (p.protein ? p.K : p.K * 3) + 1)))); // Compare.hpp:1506-1511
             if (rel >= p.threshold) { res[cnt] = std::make_tuple((size_t)tax[i], score[i], rel); ++cnt; }
         }
+        if (cnt > 0)
+            std::sort(res.begin(), res.begin() + cnt, [](const std::tuple<size_t, float, double> &a, const std::tuple<size_t, float, double> &b) { return std::get<2>(a) > std::get<2>(b); });
+        float maxV = 0.f;
+        for (int64_t i = 0; i < cnt; ++i) maxV = std::max(maxV, std::get<1>(res[i]));
+        print(o, number, name, len, cnt, maxV);
+    }
+    // a read ranked on the device (kasa_batch_rank): its printable hits in order, and the largest k-mer score of all its hits
+    struct DeviceHit { uint32_t tax; float score; double rel; };
+    void readRanked(string &o, uint64_t number, const string &name, uint32_t len, const DeviceHit *hits, uint32_t n, float maxV)
+    {
+        if (res.size() < n) res.resize(n);
+        for (uint32_t i = 0; i < n; ++i) res[i] = std::make_tuple((size_t)hits[i].tax, hits[i].score, hits[i].rel);
+        print(o, number, name, len, (int64_t)n, maxV);
+    }
+    // res[0 .. cnt) = the hits in printing order (Compare.hpp:1526-1872)
+    void print(string &o, uint64_t number, const string &name, uint32_t len, int64_t cnt, float maxV)
+    {
+        lastContaminated = false;
+        using numtext::dtoa; using numtext::itoa;
+        const float best = bestScore(len, p);
         if (cnt == 0) {
             switch (p.fmt) {
             case Params::Tsv: itoa(number, o); o += "\t"; o += name; o += "\t-\t-\t-\t-\n"; break;
@@ -530,9 +549,6 @@ struct Writer {
             }
             return;
         }
-        std::sort(res.begin(), res.begin() + cnt, [](const std::tuple<size_t, float, double> &a, const std::tuple<size_t, float, double> &b) { return std::get<2>(a) > std::get<2>(b); });
-        float maxV = 0.f;
-        for (int64_t i = 0; i < cnt; ++i) maxV = std::max(maxV, std::get<1>(res[i]));
         int64_t top = 1;
         for (int64_t i = 1; i < cnt && i < p.beasts; ++i) { if (std::get<1>(res[i]) / maxV > 0.8f) ++top; else break; }
         lastContaminated = (best - double(maxV)) / best < p.errorThreshold;          // Compare.hpp:1597-1599
@@ -715,6 +731,31 @@ static void filterReads(const Params &p, const vector<uint64_t> &flagged)
 // ---------------------------------------------------------------------------------------------------
 // the batch pipeline of one input file
 // ---------------------------------------------------------------------------------------------------
+// A host buffer that crosses PCIe: page-locked (kasa_host_alloc) when it can be had -- transfers from pageable memory are
+// staged by the runtime at a fraction of the link rate.
+template <class T> struct PcieBuf {
+    T *p = nullptr; size_t n = 0; bool pinned = false;
+    PcieBuf() {}
+    PcieBuf(const PcieBuf &) = delete;
+    PcieBuf &operator=(const PcieBuf &) = delete;
+    ~PcieBuf() { release(); }
+    void release() { if (p) { if (pinned) kasa_host_free(p); else std::free(p); } p = nullptr; n = 0; }
+    void resize(size_t count)
+    {
+        release();
+        n = count;
+        const size_t bytes = std::max<size_t>(1, count * sizeof(T));
+        p = (T *)kasa_host_alloc(bytes);
+        pinned = p != nullptr;
+        if (!p) p = (T *)std::malloc(bytes);
+        if (!p) throw std::bad_alloc();
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct Batch {
     uint64_t id = 0, firstRead = 0;
     ReadSet rs;                                   // the batch's reads (offsets start at 0)
@@ -722,6 +763,7 @@ struct Batch {
     string text;                                  // per-read output of the batch
     vector<uint64_t> flagged;                     // --filter: read numbers of contaminants
     uint64_t kmers = 0;
+    uint32_t flaggedByDevice = 0;                 // reads kasa_batch_rank handed back to the host's std::sort
     bool done = false;
 };
 
@@ -854,10 +896,42 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
     b.kmers = nk;
     if (!wantRows) { tDevice += secondsSince(tDev); return; }
-    uint64_t nnz = 0;
-    if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
-    vector<uint64_t> ro(nr + 1); vector<uint32_t> tx(nnz); vector<float> sc(nnz);
-    if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
+    // Ranking on the device (kasa_batch_rank): the host supplies libm's denominators, one row per distinct read length,
+    // and gets back only what the writer can print; the full rows come back when the device flags a read (a tie under
+    // std::sort's unstable regime) or when there are too many distinct lengths for a table.
+    PcieBuf<uint32_t> meta; PcieBuf<Writer::DeviceHit> hits;
+    uint32_t nFlagged = 0;
+    bool deviceRank = nr > 0 && !p.hostRank;
+    if (deviceRank) {
+        std::map<uint32_t, uint32_t> classOf;
+        for (uint64_t r = 0; r < nr; ++r) classOf.emplace(b.rs.lengths[r], 0u);
+        const size_t nT = ixf.content.names.size();
+        if (classOf.size() * nT > (size_t)4000000) deviceRank = false;
+        else {
+            vector<double> den(classOf.size() * nT);
+            uint32_t ci = 0;
+            for (auto &kv : classOf) {
+                kv.second = ci;
+                for (size_t t = 0; t < nT; ++t)
+                    den[(size_t)ci * nT + t] = 1.0 + log2(ixf.freq[t] * double(uint32_t(kv.first - (p.protein ? p.K : p.K * 3) + 1)));   // Compare.hpp:1506-1511
+                ++ci;
+            }
+            vector<uint32_t> rclass(nr);
+            for (uint64_t r = 0; r < nr; ++r) rclass[r] = classOf[b.rs.lengths[r]];
+            uint64_t nEntries = 0;
+            if (kasa_batch_rank(ctx, den.data(), (uint32_t)classOf.size(), rclass.data(), p.threshold, (uint32_t)std::max(0, p.beasts), &nEntries, &nFlagged)) throwLast();
+            meta.resize(nr * 4); hits.resize(nEntries);
+            if (kasa_batch_rank_fetch(ctx, meta.data(), hits.data())) throwLast();
+        }
+    }
+    PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
+    if (!deviceRank || nFlagged) {
+        uint64_t nnz = 0;
+        if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
+        ro.resize(nr + 1); tx.resize(nnz); sc.resize(nnz);
+        if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
+    }
+    b.flaggedByDevice = nFlagged;
     tDevice += secondsSince(tDev);
     const auto tTxt = std::chrono::steady_clock::now();
     const uint64_t slab = 1u << 15;
@@ -877,7 +951,11 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 string &text = texts[sidx];
                 text.reserve((size_t)(e - a) * 320);
                 for (uint64_t r = a; r < e; ++r) {
-                    w.read(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
+                    if (deviceRank && !(meta[4 * r + 1] >> 31)) {
+                        float maxV; std::memcpy(&maxV, &meta[4 * r + 2], 4);
+                        w.readRanked(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], hits.data() + meta[4 * r], meta[4 * r + 1], maxV);
+                    } else
+                        w.read(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
                     if (p.filter && w.lastContaminated) flagged[sidx].push_back(b.firstRead + r);
                 }
             }
@@ -1102,6 +1180,7 @@ static int run(int argc, char **argv)
         else if (s == "-n" || s == "--threads") { p.threads = (unsigned)std::max(1, std::stoi(next())); p.refThreads = (int)p.threads; }
         else if (s == "-m" || s == "--memory") { const string v = next(); p.memoryGiB = v == "inf" ? (1 << 30) : std::stoi(v); }   // main.cpp:438-447
         else if (s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
+        else if (s == "--host-rank") p.hostRank = true;
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }

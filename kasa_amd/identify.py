@@ -34,13 +34,15 @@ class Identify:
         self.error_threshold = 0.5
         self.n_kmers = 0
         self.n_reads = 0
+        self.device_rank = True         # kasa_batch_rank; False: the whole CSR comes back and the host ranks every read
+        self.flagged_reads = 0          # reads the device handed back to the host's std::sort emulation
 
     def close(self):
         self.ctx.close()
 
     def run(self, reads: ReadBatch, want_per_read: bool = True, batch_reads: int = None, coverage: bool = False,
-            memory_gib: int = None, threads: int = 1, ram: bool = False):
-        """-> (per-read text or None, profile CSV text, list of CSR batches)."""
+            memory_gib: int = None, threads: int = 1, ram: bool = False, keep_csr: bool = False):
+        """-> (per-read text or None, profile CSV text, list of CSR batches (with keep_csr))."""
         ix = self.index
         writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts)
         freq = ix.freq_at(self.k_high)
@@ -51,6 +53,7 @@ class Identify:
         self.ctx.set_protein(protein)
         self.n_kmers = 0
         self.n_reads = 0
+        self.flagged_reads = 0
         self.contaminants = []
         step = reads.n if not batch_reads else batch_reads
         if not batch_reads and reads.n:
@@ -72,14 +75,34 @@ class Identify:
             self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique, part.seg_read, part.n)
             self.n_kmers += self.ctx.n_kmers
             if want_per_read:
-                off, tax, sc = self.ctx.scores()
-                csr.append((off, tax, sc))
+                # ranked on the device (kasa_batch_rank): only what the writer can print crosses PCIe; the full CSR comes
+                # back for the reads the device flags (ties under an unstable sort) or on request (keep_csr)
+                meta = ent = None
+                device_rank = self.device_rank and part.n > 0 and np.unique(part.lengths).shape[0] * len(freq) <= 4_000_000
+                flagged = 0
+                if device_rank:
+                    den, rclass = report.rank_denominators(freq, part.lengths, ix.K, protein)
+                    meta, ent, flagged = self.ctx.rank(den, rclass, float(np.float32(self.threshold)), self.beasts)
+                self.flagged_reads += flagged
+                off = tax = sc = None
+                if keep_csr or not device_rank or flagged:
+                    off, tax, sc = self.ctx.scores(pinned=not keep_csr)
+                    if keep_csr:
+                        csr.append((off, tax, sc))
                 for r in range(part.n):
-                    lo, hi = int(off[r]), int(off[r + 1])
-                    rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(part.lengths[r]), freq, self.k_high,
-                                          self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
-                    out.append(writer.read(self.n_reads + r, part.names[r], int(part.lengths[r]), rk))
-                    if rk.hits and report.is_contaminant(rk.best, max(h.score for h in rk.hits), self.error_threshold):
+                    length = int(part.lengths[r])
+                    if device_rank and not (int(meta[r, 1]) >> 31):
+                        a0, n0 = int(meta[r, 0]), int(meta[r, 1]) & 0x7FFFFFFF
+                        max_score = np.uint32(meta[r, 2]).view(np.float32)
+                        rk = report.ranked_from_prefix(ent[a0:a0 + n0], max_score, length, self.k_high, self.k_low, self.frames,
+                                                       self.beasts, protein)
+                    else:
+                        lo, hi = int(off[r]), int(off[r + 1])
+                        rk = report.rank_read(tax[lo:hi], sc[lo:hi], length, freq, self.k_high,
+                                              self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
+                        max_score = max((h.score for h in rk.hits), default=np.float32(0))
+                    out.append(writer.read(self.n_reads + r, part.names[r], length, rk))
+                    if rk.hits and report.is_contaminant(rk.best, max_score, self.error_threshold):
                         self.contaminants.append(self.n_reads + r)
             self.n_reads += part.n
             a = b

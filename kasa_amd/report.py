@@ -101,6 +101,40 @@ def rank_read(tax_idx, scores, length: int, freq_khigh, k_high: int, k_low: int,
     return Ranked(hits, n_top, best)
 
 
+def rank_denominators(freq_khigh, lengths, K: int = K64, protein: bool = False):
+    """The host's part of kasa_batch_rank: one row of denominators 1 + log2(freq * span) (Compare.hpp:1506-1511, libm's
+    log2 as the reference uses it) per distinct read length.  Returns (den float64[nClasses, nTaxa], class of each read)."""
+    lengths = np.asarray(lengths)
+    distinct, read_class = np.unique(lengths, return_inverse=True)
+    den = np.empty((max(1, distinct.shape[0]), len(freq_khigh)), dtype=np.float64)
+    den[:] = np.nan
+    for c, length in enumerate(distinct):
+        span = (int(length) - (K if protein else 3 * K) + 1) & 0xFFFFFFFF
+        for t, f in enumerate(freq_khigh):
+            prod = float(int(f)) * float(span)
+            lg = math.log2(prod) if prod > 0.0 else (-math.inf if prod == 0.0 else math.nan)
+            den[c, t] = 1.0 + lg
+    return den, read_class.astype(np.uint32)
+
+
+def ranked_from_prefix(entries, max_score, length: int, k_high: int, k_low: int, frames: int, beasts: int,
+                       protein: bool = False) -> Ranked:
+    """A read ranked on the device (kasa_batch_rank): `entries` = the hits a writer can print, in order; `max_score` = the
+    largest k-mer score among ALL its hits.  Same top-hit rule as rank_read."""
+    best = best_score(length, k_high, k_low, frames, protein)
+    hits = [Hit(int(e["tax"]), _F32(e["score"]), float(e["rel"])) for e in entries]
+    n_top = 0
+    if hits:
+        max_score = _F32(max_score)
+        n_top = 1
+        for i in range(1, min(len(hits), beasts)):
+            if _F32(hits[i].score / max_score) > _F32(0.8):
+                n_top += 1
+            else:
+                break
+    return Ranked(hits, n_top, best)
+
+
 def _error(best: np.float32, score: np.float32) -> float:
     return float(_F32(_F32(best - score) / best))
 

@@ -1,0 +1,132 @@
+"""Ranking on the device (kasa_batch_rank): only the hits the per-read file can print cross
+PCIe.  The text written from them must be the text the host writes after ranking the full rows itself
+(report.rank_read = Compare::scoringFunc, Compare.hpp:1495-1594, 1721-1754) -- for every output format, -b, threshold,
+mixed read lengths, and for the reads the device hands back (ties among more than 16 hits)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from kasa_amd import build as hipbuild, capi, formats, identify, reads, report
+from oracle import oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_lengths(genomes, seed):
+    parts = [reads.synthetic_reads(genomes, n, L, seed + i) for i, (n, L) in enumerate([(300, 150), (200, 100), (100, 251), (50, 40)])]
+    bases = np.concatenate([p.bases for p in parts])
+    off, names, lens, at = [0], [], [], 0
+    for p in parts:
+        for r in range(p.n):
+            at += int(p.offsets[r + 1] - p.offsets[r])
+            off.append(at)
+            names.append(f"m{len(names)} ")
+            lens.append(int(p.lengths[r]))
+    return reads.ReadBatch(bases, np.asarray(off, dtype=np.int64), names, np.asarray(lens, dtype=np.uint32))
+
+
+def _world(kind):
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    if kind == "crowd":                       # 300 taxa around one root: dozens of hits per read
+        root = alphabet[rng.integers(0, 4, size=900)]
+        genomes = []
+        for g in range(300):
+            s = root.copy()
+            m = rng.random(900) < 0.1
+            s[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+            genomes.append(s)
+    if kind == "clones":                      # 40 identical genomes: equal k-mer scores, equal frequencies, equal relative scores
+        one = alphabet[rng.integers(0, 4, size=3000)]
+        genomes = [one.copy() for _ in range(40)]
+    if kind == "pairs":                       # sibling genomes: two or three close hits per read
+        rs = np.random.default_rng(23)
+        genomes = []
+        for g in range(12):
+            if g % 2 == 1:
+                s = genomes[g - 1].copy()
+                m = rs.random(6000) < 0.03
+                s[m] = alphabet[rs.integers(0, 4, size=int(m.sum()))]
+            else:
+                s = alphabet[rs.integers(0, 4, size=6000)]
+            genomes.append(s)
+    content = formats.Content(["non_unique"] + [f"Taxon, {g}" for g in range(len(genomes))],
+                              np.concatenate(([0], 100 + np.arange(len(genomes)))).astype(np.uint32))
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for g, s in enumerate(genomes):
+        km, _ = oracle.encode(s, np.array([0, s.shape[0]], dtype=np.int64), p)
+        kms.append(km)
+        tids.append(np.full(km.shape[0], 100 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    return ix, _mixed_lengths(genomes, 40)
+
+
+@pytest.mark.parametrize("kind", ["pairs", "crowd", "clones"])
+def test_device_rank_writes_the_hosts_text(kind):
+    assert capi.device_count() > 0
+    ix, batch = _world(kind)
+    dix = capi.DeviceIndex(ix)
+    flagged = 0
+    for fmt in ("json", "jsonl", "tsv", "kraken"):
+        for beasts, thr in ((1, 0.0), (3, 0.0), (7, 0.03), (100, 0.0)):
+            texts = []
+            for on in (True, False):
+                run = identify.Identify(ix, 0, 12, 7, 3, thr, beasts, fmt, dix=dix)
+                run.device_rank = on
+                text, prof, _ = run.run(batch, True)
+                texts.append((text, prof))
+                if on:
+                    flagged += run.flagged_reads
+                run.close()
+            assert texts[0] == texts[1], (fmt, beasts, thr)
+    if kind == "clones":
+        assert flagged > 0                    # 40 tied hits per read: the device leaves those reads to the host
+    if kind == "pairs":
+        assert flagged == 0
+    dix.close()
+
+
+def test_rank_entries_against_rank_read():
+    """The raw ABI: entries = a prefix of the host's sorted hits, meta = (first, count | flag, max k-mer score, hits)."""
+    ix, batch = _world("crowd")
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    off, tax, sc = ctx.scores()
+    freq = ix.freq_at(12)
+    den, rclass = report.rank_denominators(freq, batch.lengths, ix.K, False)
+    for beasts in (0, 1, 3, 50):
+        meta, ent, n_flag = ctx.rank(den, rclass, 0.0, beasts, pinned=(beasts != 1))
+        assert meta.shape == (batch.n, 4)
+        for r in range(batch.n):
+            lo, hi = int(off[r]), int(off[r + 1])
+            rk = report.rank_read(tax[lo:hi], sc[lo:hi], int(batch.lengths[r]), freq, 12, 7, 3, 0.0, beasts, K=ix.K)
+            assert int(meta[r, 3]) == len(rk.hits)
+            if int(meta[r, 1]) >> 31:
+                continue
+            a, n = int(meta[r, 0]), int(meta[r, 1])
+            assert n <= len(rk.hits) and (n >= min(len(rk.hits), max(beasts, 1)))
+            got = [(int(e["tax"]), float(e["score"]), float(e["rel"])) for e in ent[a:a + n]]
+            want = [(h.tax_idx, float(h.score), h.rel) for h in rk.hits[:n]]
+            assert got == want                # bit-equal doubles: IEEE division on both sides, libm's log2 from the host
+            if rk.hits:
+                assert np.uint32(meta[r, 2]).view(np.float32) == max(h.score for h in rk.hits)
+    ctx.close(); dix.close()
+
+
+def test_cpp_host_device_rank_equals_host_rank(tmp_path):
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    outs = []
+    for extra in ([], ["--host-rank"]):
+        out, prof = str(tmp_path / ("out" + str(len(outs)))), str(tmp_path / "prof.csv")
+        cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
+               "-q", out, "-p", prof, "--json", "-b", "5", "-n", "2"] + extra
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
