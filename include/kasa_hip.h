@@ -140,6 +140,27 @@ int kasa_batch_records_size(kasa_ctx *ctx, uint64_t *nRecordWords, uint64_t *nPo
 int kasa_batch_records_fetch(kasa_ctx *ctx, uint32_t *records, uint32_t *pool);
 int kasa_batch_records_import(kasa_ctx *ctx, const uint32_t *records, uint64_t nRecordWords, const uint32_t *pool, uint64_t nPoolWords);
 
+/* The same exchange without the host: slices of the sorted queries and the records made from
+ * them are handed over as DEVICE pointers, so the caller's collective (RCCL all_to_all over xGMI) moves them from HBM to
+ * HBM.  Pointers returned by the *_device getters point into the context's own buffers and stay valid until its next
+ * batch call; pointers passed in may live on the context's device or on a peer whose memory it can address.
+ *   kasa_batch_queries_device         the sorted k-mers of the batch (8 or 16 bytes each) and their number
+ *   kasa_batch_slice_starts           starts[j] = first sorted query whose 30-bit prefix is >= cuts[j] (starts[0] = 0,
+ *                                     starts[nParts] = number of queries): slice j goes to the owner of partition j
+ *   kasa_batch_set_sorted_device      installs a slice of sorted k-mers as a batch of its own and looks it up
+ *                                     (kasa_batch_set_queries + kasa_batch_sort_and_range without the sort);
+ *                                     kasa_batch_group then makes its records
+ *   kasa_batch_records_device         records (sorted order) and pool of the grouped slice
+ *   kasa_batch_records_import_device  the slices' records, in partition order, become the batch's records: positions
+ *                                     move by the slice starts and pool offsets by the pool bases on the device
+ *                                     (what kasa_amd/partition.py:assemble_records does for the host path) */
+int kasa_batch_queries_device(kasa_ctx *ctx, const void **kmers, uint64_t *n);
+int kasa_batch_slice_starts(kasa_ctx *ctx, const uint64_t *cuts, uint32_t nParts, uint64_t *starts);
+int kasa_batch_set_sorted_device(kasa_ctx *ctx, const void *kmersDev, uint64_t n);
+int kasa_batch_records_device(kasa_ctx *ctx, const uint32_t **records, uint64_t *nRecordWords, const uint32_t **pool, uint64_t *nPoolWords);
+int kasa_batch_records_import_device(kasa_ctx *ctx, uint32_t nParts, const uint32_t *const *records, const uint64_t *nRecordWords,
+                                     const uint32_t *const *pool, const uint64_t *nPoolWords);
+
 /* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
  * scoringFunc scans (Compare.hpp:1501-1522). */
 int kasa_batch_scores_size(kasa_ctx *ctx, uint64_t *nnz);

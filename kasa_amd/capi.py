@@ -27,6 +27,8 @@ EXPORTS = [
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
+    "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
+    "kasa_batch_records_import_device",
 ]
 
 
@@ -301,6 +303,38 @@ class Context:
         rec = np.ascontiguousarray(rec, dtype=np.uint32).reshape(-1)
         pool = np.ascontiguousarray(pool, dtype=np.uint32)
         _check(lib().kasa_batch_records_import(self.h, _p(rec), C.c_uint64(rec.shape[0]), _p(pool), C.c_uint64(pool.shape[0])))
+
+    # ---- device-resident exchange (C5): device pointers as plain integers
+    def queries_device(self):
+        """(device pointer of the sorted k-mers, number of queries, bytes per k-mer)."""
+        p, n = C.c_void_p(0), C.c_uint64(0)
+        _check(lib().kasa_batch_queries_device(self.h, C.byref(p), C.byref(n)))
+        return int(p.value or 0), int(n.value), (16 if self.dix.wide else 8)
+
+    def slice_starts(self, cuts: np.ndarray) -> np.ndarray:
+        cuts = np.ascontiguousarray(cuts, dtype=np.uint64)
+        starts = np.zeros(cuts.shape[0] + 1, dtype=np.uint64)
+        _check(lib().kasa_batch_slice_starts(self.h, _p(cuts), C.c_uint32(cuts.shape[0]), _p(starts)))
+        return starts.astype(np.int64)
+
+    def set_sorted_device(self, ptr: int, n: int):
+        _check(lib().kasa_batch_set_sorted_device(self.h, C.c_void_p(ptr), C.c_uint64(n)))
+        self.n_kmers = int(n)
+
+    def records_device(self):
+        """(records pointer, record words, pool pointer, pool words) of the grouped slice, all on the device."""
+        r, p, nr, npw = C.c_void_p(0), C.c_void_p(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().kasa_batch_records_device(self.h, C.byref(r), C.byref(nr), C.byref(p), C.byref(npw)))
+        return int(r.value or 0), int(nr.value), int(p.value or 0), int(npw.value)
+
+    def records_import_device(self, parts):
+        """parts[j] = (records pointer, record words, pool pointer, pool words) of slice j, in partition order."""
+        n = len(parts)
+        rp = (C.c_void_p * n)(*[C.c_void_p(a[0]) for a in parts])
+        pp = (C.c_void_p * n)(*[C.c_void_p(a[2]) for a in parts])
+        rw = (C.c_uint64 * n)(*[a[1] for a in parts])
+        pw = (C.c_uint64 * n)(*[a[3] for a in parts])
+        _check(lib().kasa_batch_records_import_device(self.h, C.c_uint32(n), rp, rw, pp, pw))
 
     def scores(self, pinned: bool = False, out=None):
         """CSR (offsets u64[nReads+1], taxIdx u32[nnz], score f32[nnz]); pinned: into page-locked memory (link rate);

@@ -1200,6 +1200,8 @@ __global__ void slot_to_read_kernel(const uint32_t *__restrict__ slot, uint32_t 
     read[i] = lo;
 }
 
+template <class Key> static int lookup_part(kasa_ctx *c);
+
 template <class Key>
 static int sort_and_range_impl(kasa_ctx *c, int unique)
 {
@@ -1256,6 +1258,16 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, ko, ko, (uint64_t)0, (size_t)c->nReads + 1, rocprim::plus<uint64_t>(), c->stream));
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_SORT], a, b))) return rc;
+    return lookup_part<Key>(c);
+}
+
+// depth and representative of every sorted query, first closing positions per tile: the batch is "sorted and ranged"
+template <class Key>
+static int lookup_part(kasa_ctx *c)
+{
+    const uint64_t nQ = c->nQ;
+    int rc;
+    hipEvent_t a, b;
     if ((rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64))) return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
     if ((rc = c->tileFirst.reserve((size_t)c->nK * (nTiles + 1) * 4)) || (rc = c->tileNext.reserve((size_t)c->nK * (nTiles + 1) * 4)) ||
@@ -3549,6 +3561,8 @@ __global__ __launch_bounds__(TILE_THREADS) void tile_first_kernel(const Key *__r
     if ((int)threadIdx.x < nK) tileFirst[(size_t)threadIdx.x * nTiles + blockIdx.x] = sFirst[threadIdx.x];
 }
 
+static int import_tail(kasa_ctx *c, uint64_t nRecordWords, uint64_t nPoolWords);
+
 extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint32_t *records, uint64_t nRecordWords, const uint32_t *pool, uint64_t nPoolWords)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
@@ -3561,8 +3575,16 @@ extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint32_t *records, u
     if (c->nQ && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     if ((rc = c->rec.reserve(nRecordWords * 4 + 64)) || (rc = c->recIn.reserve(nRecordWords * 4 + 64)) || (rc = c->pool.reserve((nPoolWords + 1) * 4))) return rc;
     c->poolCap = std::max<uint64_t>(c->poolCap, nPoolWords + 1);
+    if (nRecordWords) HIPCHK(hipMemcpyAsync(c->recIn.p, records, nRecordWords * 4, hipMemcpyHostToDevice, c->stream));
+    if (nPoolWords) HIPCHK(hipMemcpyAsync(c->pool.p, pool, nPoolWords * 4, hipMemcpyHostToDevice, c->stream));
+    return import_tail(c, nRecordWords, nPoolWords);
+}
+
+// recIn (sorted order) and pool are in place: file the records by slot, rebuild depths and the per-tile tables
+static int import_tail(kasa_ctx *c, uint64_t nRecordWords, uint64_t nPoolWords)
+{
+    const int RW = c->recWords();
     if (nRecordWords) {
-        HIPCHK(hipMemcpyAsync(c->recIn.p, records, nRecordWords * 4, hipMemcpyHostToDevice, c->stream));
         if (RW == 8) place_records_kernel<8><<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(c->recIn.as<uint4>(), c->slotOf, (uint32_t)c->nQ, c->rec.as<uint4>(), c->depth.as<uint8_t>());
         else place_records_kernel<16><<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(c->recIn.as<uint4>(), c->slotOf, (uint32_t)c->nQ, c->rec.as<uint4>(), c->depth.as<uint8_t>());
         const uint32_t nTiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
@@ -3571,11 +3593,143 @@ extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint32_t *records, u
         tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)c->nQ);
         HIPCHK(hipGetLastError());
     }
-    if (nPoolWords) HIPCHK(hipMemcpyAsync(c->pool.p, pool, nPoolWords * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->poolUsed = (uint32_t)std::max<uint64_t>(1, nPoolWords);
     c->grouped = true; c->recSorted = false; c->haveScores = false;
     return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident exchange for the range-partitioned index (C5): slices of sorted queries and the event records made
+// from them move between contexts (devices) as device pointers; the caller's collective (RCCL all_to_all) carries them
+// ------------------------------------------------------------------------------------------------
+extern "C" int kasa_batch_queries_device(kasa_ctx *c, const void **kmers, uint64_t *n)
+{
+    if (!c || !kmers || !n) return fail(KASA_E_ARG, "kasa_batch_queries_device: NULL argument");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_queries_device: batch not sorted");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *kmers = c->qKmer; *n = c->nQ;
+    return KASA_OK;
+}
+
+template <class Key>
+__global__ void slice_starts_kernel(const Key *__restrict__ qKmer, uint32_t nQ, const uint64_t *__restrict__ cuts, uint32_t nParts, int shift,
+                                    uint64_t *__restrict__ starts)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nParts) return;
+    if (j == nParts) { starts[j] = nQ; return; }
+    if (j == 0) { starts[0] = 0; return; }
+    uint32_t lo = 0, hi = nQ;                                          // first query whose 30-bit prefix is >= cuts[j]
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)(qKmer[mid] >> shift) < cuts[j]) lo = mid + 1; else hi = mid; }
+    starts[j] = lo;
+}
+
+extern "C" int kasa_batch_slice_starts(kasa_ctx *c, const uint64_t *cuts, uint32_t nParts, uint64_t *starts)
+{
+    if (!c || !cuts || !starts || nParts == 0) return fail(KASA_E_ARG, "kasa_batch_slice_starts: bad arguments");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_slice_starts: batch not sorted");
+    HIPCHK(hipSetDevice(c->ix->device));
+    DevBuf tmp;
+    int rc = tmp.reserve(((size_t)nParts * 2 + 1) * 8);
+    if (rc) return rc;
+    uint64_t *dCuts = tmp.as<uint64_t>(), *dStarts = dCuts + nParts;
+    HIPCHK(hipMemcpyAsync(dCuts, cuts, (size_t)nParts * 8, hipMemcpyHostToDevice, c->stream));
+    const int shift = 5 * (c->K() - RANGE_LETTERS);
+    if (c->ix->wide) slice_starts_kernel<key128><<<blocks_for(nParts + 1, 64), 64, 0, c->stream>>>(c->keys<key128>(), (uint32_t)c->nQ, dCuts, nParts, shift, dStarts);
+    else slice_starts_kernel<uint64_t><<<blocks_for(nParts + 1, 64), 64, 0, c->stream>>>(c->keys<uint64_t>(), (uint32_t)c->nQ, dCuts, nParts, shift, dStarts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(starts, dStarts, ((size_t)nParts + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_set_sorted_device(kasa_ctx *c, const void *kmersDev, uint64_t n)
+{
+    if (!c || (n && !kmersDev)) return fail(KASA_E_ARG, "kasa_batch_set_sorted_device: bad arguments");
+    if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_sorted_device: too many queries for one batch");
+    HIPCHK(hipSetDevice(c->ix->device));
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false;
+    int rc;
+    if ((rc = c->qKmerB.reserve(n * c->keyBytes() + 64))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->qKmerB.p, kmersDev, n * c->keyBytes(), hipMemcpyDefault, c->stream));   // same device or a peer's memory
+    c->nReads = 0; c->nSeq = 0; c->nQ = n; c->maxCnt = 0;
+    c->qKmer = c->qKmerB.p; c->qRead = nullptr;
+    rc = c->ix->wide ? lookup_part<key128>(c) : lookup_part<uint64_t>(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_device(kasa_ctx *c, const uint32_t **records, uint64_t *nRecordWords, const uint32_t **pool, uint64_t *nPoolWords)
+{
+    if (!c || !records || !nRecordWords || !pool || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_device: NULL argument");
+    if (!c->grouped || !c->recSorted) return fail(KASA_E_STATE, "kasa_batch_records_device: no exported event records (call kasa_batch_group)");
+    HIPCHK(hipSetDevice(c->ix->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *records = c->rec.as<uint32_t>(); *nRecordWords = c->nQ * (uint64_t)c->recWords();
+    *pool = c->pool.as<uint32_t>(); *nPoolWords = c->poolUsed;
+    return KASA_OK;
+}
+
+// records of one slice into the batch: sorted positions move by the slice start, pool offsets by the pool base
+template <int RW>
+__global__ void shift_records_kernel(const uint4 *__restrict__ in, uint32_t n, uint32_t start, uint32_t poolShift, uint4 *__restrict__ out)
+{
+    typedef RecTraits<RW> RT;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint4 v[RW / 4];
+#pragma unroll
+    for (int w = 0; w < RW / 4; ++w) v[w] = in[(size_t)p * (RW / 4) + w];
+    const bool matched = (v[0].z & 31u) != 0u;
+    v[0].x += start;
+    if (matched) v[0].y += start;
+    const uint32_t nseg = RW == 8 ? (v[0].w & 255u) : v[0].w;
+    if (matched && nseg > (uint32_t)RT::INL) v[RW / 4 - 1].w += poolShift;
+#pragma unroll
+    for (int w = 0; w < RW / 4; ++w) out[(size_t)p * (RW / 4) + w] = v[w];
+}
+
+extern "C" int kasa_batch_records_import_device(kasa_ctx *c, uint32_t nParts, const uint32_t *const *records, const uint64_t *nRecordWords,
+                                                const uint32_t *const *pool, const uint64_t *nPoolWords)
+{
+    if (!c || !records || !nRecordWords || !pool || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_import_device: NULL argument");
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_records_import_device: batch not sorted");
+    const int RW = c->recWords();
+    uint64_t totalRec = 0, totalPool = 1;                                 // pool word 0 is never referenced
+    for (uint32_t j = 0; j < nParts; ++j) {
+        if (nRecordWords[j] % (uint64_t)RW) return fail(KASA_E_ARG, "kasa_batch_records_import_device: part %u is not a whole number of records", j);
+        totalRec += nRecordWords[j];
+        totalPool += nPoolWords[j] ? nPoolWords[j] - 1 : 0;
+    }
+    if (totalRec != c->nQ * (uint64_t)RW) return fail(KASA_E_ARG, "kasa_batch_records_import_device: %llu record words for %llu queries x %d words", (unsigned long long)totalRec, (unsigned long long)c->nQ, RW);
+    if (totalPool >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_records_import_device: pool exceeds 2^32 words");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc;
+    if (c->nQ && !c->slotOf && (rc = slots_from_reads(c))) return rc;
+    if ((rc = c->rec.reserve(totalRec * 4 + 64)) || (rc = c->recIn.reserve(totalRec * 4 + 64)) || (rc = c->pool.reserve((totalPool + 1) * 4))) return rc;
+    c->poolCap = std::max<uint64_t>(c->poolCap, totalPool + 1);
+    uint64_t start = 0, base = 1;
+    HIPCHK(hipMemsetAsync(c->pool.p, 0, 4, c->stream));
+    for (uint32_t j = 0; j < nParts; ++j) {
+        const uint64_t n = nRecordWords[j] / (uint64_t)RW;
+        if (n) {
+            if (!records[j]) return fail(KASA_E_ARG, "kasa_batch_records_import_device: part %u has no records pointer", j);
+            uint4 *out = c->recIn.as<uint4>() + start * (RW / 4);
+            if (RW == 8) shift_records_kernel<8><<<blocks_for(n, 256), 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(records[j]), (uint32_t)n, (uint32_t)start, (uint32_t)(base - 1), out);
+            else shift_records_kernel<16><<<blocks_for(n, 256), 256, 0, c->stream>>>(reinterpret_cast<const uint4 *>(records[j]), (uint32_t)n, (uint32_t)start, (uint32_t)(base - 1), out);
+            HIPCHK(hipGetLastError());
+        }
+        if (nPoolWords[j] > 1) {
+            if (!pool[j]) return fail(KASA_E_ARG, "kasa_batch_records_import_device: part %u has no pool pointer", j);
+            HIPCHK(hipMemcpyAsync(c->pool.as<uint32_t>() + base, pool[j] + 1, (nPoolWords[j] - 1) * 4, hipMemcpyDefault, c->stream));
+            base += nPoolWords[j] - 1;
+        }
+        start += n;
+    }
+    return import_tail(c, totalRec, totalPool);
 }
 
 extern "C" int kasa_batch_scores_size(kasa_ctx *c, uint64_t *nnz)

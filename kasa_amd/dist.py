@@ -63,11 +63,88 @@ def all_to_all_arrays(send):
     return [t.cpu().numpy().view(dtype) for t in rx]
 
 
+_hip = None
+
+
+def _device_copy(dst: int, src: int, nbytes: int):
+    """hipMemcpy between two device pointers (the library's buffers <-> torch tensors)."""
+    global _hip
+    import ctypes as C
+    if nbytes == 0:
+        return
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = _hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 4)   # hipMemcpyDefault
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed ({rc})")
+
+
+def _all_to_all_device(send, send_counts, unit: int):
+    """One all_to_all of byte tensors on the device: send = uint8 tensor holding the slices for rank 0, 1, ... back to
+    back, send_counts[j] = elements of `unit` bytes for rank j.  Returns (recv tensor, counts received from every rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = send.device
+    mine = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    theirs = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(theirs, mine)
+    recv_counts = [int(x) for x in theirs.cpu()]
+    recv = torch.empty(sum(recv_counts) * unit, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, send, [n * unit for n in recv_counts], [n * unit for n in send_counts])
+    return recv, recv_counts
+
+
+def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool = True, unique: bool = False):
+    """partitioned_batch with every slice and every record staying in HBM: the sorted k-mers leave through
+    kasa_batch_queries_device, travel in ONE RCCL all_to_all (8 or 16 bytes per query; the read ids stay at home --
+    grouping does not need them), come back as records + pools in two more, and kasa_batch_records_import_device
+    shifts and files them on the device.  Nothing of the exchange touches host memory."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ctx = owner_ctx
+    ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)
+    ctx.encode()
+    ctx.sort_and_range(unique)
+    ptr, n, kb = ctx.queries_device()
+    starts = ctx.slice_starts(cuts)
+    send = torch.empty(n * kb, dtype=torch.uint8, device=dev)
+    _device_copy(send.data_ptr(), ptr, n * kb)
+    km_in, n_in = _all_to_all_device(send, [int(starts[j + 1] - starts[j]) for j in range(world)], kb)
+    del send
+    rw = ctx.rec_words * 4
+    recs, pools, rec_counts, pool_counts, at = [], [], [], [], 0
+    for s in range(world):                                        # the slices of every rank, against my partition
+        rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s])
+        at += n_in[s]
+        r = torch.empty(nrw * 4, dtype=torch.uint8, device=dev)
+        p = torch.empty(npw * 4, dtype=torch.uint8, device=dev)
+        _device_copy(r.data_ptr(), rp, nrw * 4)                   # the worker's buffers are reused by the next slice
+        _device_copy(p.data_ptr(), pp, npw * 4)
+        recs.append(r); pools.append(p); rec_counts.append(nrw * 4 // rw); pool_counts.append(npw)
+    rec_back, rec_n = _all_to_all_device(torch.cat(recs) if recs else torch.empty(0, dtype=torch.uint8, device=dev), rec_counts, rw)
+    pool_back, pool_n = _all_to_all_device(torch.cat(pools) if pools else torch.empty(0, dtype=torch.uint8, device=dev), pool_counts, 4)
+    parts, ra, pa = [], 0, 0
+    for j in range(world):
+        parts.append((rec_back.data_ptr() + ra * rw, rec_n[j] * ctx.rec_words, pool_back.data_ptr() + pa * 4, pool_n[j]))
+        ra += rec_n[j]; pa += pool_n[j]
+    ctx.records_import_device(parts)
+    ctx.score(want_per_read)
+    return ctx
+
+
 def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: bool = True, unique: bool = False):
     """One batch against an index that is range-partitioned over the ranks (rank j holds partition j; see
-    kasa_amd/partition.py): two exchanges of query slices and two of event records.  Returns `owner_ctx`, scored."""
+    kasa_amd/partition.py): two exchanges of query slices and two of event records.  Returns `owner_ctx`, scored.
+    With RCCL (`nccl`) the exchange is device-resident (partitioned_batch_device); the host-staged form below serves
+    gloo (CPU tensors, tests)."""
     import torch.distributed as dist
     from . import partition
+    if dist.get_backend() == "nccl":
+        return partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read, unique)
     world = dist.get_world_size()
     ctx = owner_ctx
     ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)

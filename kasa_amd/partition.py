@@ -85,6 +85,13 @@ class Worker:
         self.ctx.group()
         return self.ctx.records()
 
+    def group_slice_device(self, ptr: int, n: int):
+        """The same for a slice that is already in device memory (`ptr`: its sorted k-mers); returns device pointers
+        (records pointer, record words, pool pointer, pool words), valid until the worker's next slice."""
+        self.ctx.set_sorted_device(ptr, n)
+        self.ctx.group()
+        return self.ctx.records_device()
+
     def close(self):
         self.ctx.close()
 
@@ -92,8 +99,9 @@ class Worker:
 class LocalExchange:
     """All partitions in this process (one GPU): the reference implementation of the exchange, used by the tests."""
 
-    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0):
+    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0, device_resident: bool = False):
         self.cuts = cuts
+        self.device_resident = device_resident      # slices and records never leave HBM (kasa_batch_*_device)
         self.K = parts[0].K
         self.dix = [capi.DeviceIndex(p, device) for p in parts]
         self.workers = [Worker(d, k_high, k_low, frames) for d in self.dix]
@@ -104,6 +112,13 @@ class LocalExchange:
         ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)
         ctx.encode()
         ctx.sort_and_range(unique)
+        if self.device_resident:
+            ptr, n, kb = ctx.queries_device()
+            starts = ctx.slice_starts(self.cuts)
+            parts = [w.group_slice_device(ptr + int(starts[j]) * kb, int(starts[j + 1] - starts[j])) for j, w in enumerate(self.workers)]
+            ctx.records_import_device(parts)
+            ctx.score(want_per_read)
+            return ctx
         km, rd = ctx.queries()
         starts = slice_starts(km, self.cuts, self.K)
         parts = [w.group_slice(km[starts[j]:starts[j + 1]], rd[starts[j]:starts[j + 1]], ctx.n_reads)

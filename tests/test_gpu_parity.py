@@ -417,7 +417,8 @@ def test_full_size_properties():
         reduction relies on);
       * conservation: per level, sum over taxa of countAll = number of sorted queries whose match reaches that level;
       * shard invariance of the per-read taxon sets (scores may move in the last float digit with the batch);
-      * a random sample of reads against the CPU oracle on the same 5 GB index."""
+      * a random sample of reads against the CPU oracle on the same 5 GB index;
+      * the first 300 000 reads as a batch of their own: every score bit-equal to the oracle's on the same index."""
     _gpu_or_fail()
     from kasa_amd import synth
     n_reads = int(os.environ.get("KASA_TEST_FULL_READS", "10000000"))
@@ -478,6 +479,22 @@ def test_full_size_properties():
         lo, hi = int(off1[r]), int(off1[r + 1])
         assert np.array_equal(tax1[lo:hi], t), r
         np.testing.assert_allclose(sc1[lo:hi], res.M[i, t], rtol=2e-5, atol=0)
+    del res
+    # a whole batch, bit for bit: the first reads as a batch of their own on the device and in the oracle (per-read
+    # float sums depend on the reads that share a batch, so only equal batches can be compared exactly)
+    n_exact = min(batch.n, int(os.environ.get("KASA_TEST_EXACT_READS", "300000")))
+    part = batch.slice(0, n_exact)
+    ctx.profile_reset()
+    o, t, v = run(part)
+    ca_g, cu_g, _ = ctx.profile()
+    res, nq = oracle.identify_batch(ix, part.bases, part.offsets, oracle.params(12, 7, 3), True)
+    assert ctx.n_kmers == nq
+    assert np.array_equal(cu_g, res.count_unique)
+    np.testing.assert_allclose(ca_g, res.count_all, rtol=1e-12, atol=0)
+    rows, cols = np.nonzero(res.M[:, 1:] > 0)                     # row-major: reads ascending, taxa ascending
+    assert np.array_equal(o, np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=part.n)))).astype(np.uint64))
+    assert np.array_equal(t, (cols + 1).astype(np.uint32))
+    assert np.array_equal(v.view(np.uint32), res.M[rows, cols + 1].astype(np.float32).view(np.uint32))   # every float, every bit
     ctx.close(); dix.close()
 
 

@@ -21,15 +21,16 @@ def _whole(ix, batch, kh, kl, frames, unique=False):
     return out
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
 @pytest.mark.parametrize("n_parts", [2, 3, 7])
-def test_golden_index_in_partitions(n_parts):
+def test_golden_index_in_partitions(n_parts, resident):
     assert capi.device_count() > 0
     d, ix = helpers.load_case("pairs")
     batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
     parts, cuts = partition.split_index(ix, n_parts)
     assert sum(p.n for p in parts) == ix.n and all(p.n > 0 for p in parts)
     (off, tax, sc), limbs = _whole(ix, batch, 12, 7, 3)
-    ex = partition.LocalExchange(parts, cuts, 12, 7, 3)
+    ex = partition.LocalExchange(parts, cuts, 12, 7, 3, device_resident=resident)
     ctx = ex.run_batch(batch)
     o2, t2, s2 = ctx.scores()
     assert np.array_equal(off, o2) and np.array_equal(tax, t2) and np.array_equal(sc.view(np.uint32), s2.view(np.uint32))
@@ -47,13 +48,14 @@ def test_golden_index_in_partitions(n_parts):
     ex.close()
 
 
+@pytest.mark.parametrize("resident", [False, True], ids=["host", "device"])
 @pytest.mark.parametrize("case", [(12, 7, 3, False, 12), (12, 7, 6, True, 12), (25, 7, 3, False, 25), (10, 5, 3, False, 12)])
-def test_synthetic_partitions(case):
+def test_synthetic_partitions(case, resident):
     kh, kl, frames, unique, K = case
     ix, batch = synthetic_world(83, 10, 9000, 2500, K=K)
     parts, cuts = partition.split_index(ix, 4)
     (off, tax, sc), limbs = _whole(ix, batch, kh, kl, frames, unique)
-    ex = partition.LocalExchange(parts, cuts, kh, kl, frames)
+    ex = partition.LocalExchange(parts, cuts, kh, kl, frames, device_resident=resident)
     ctx = ex.run_batch(batch, unique=unique)
     assert_csr_equal(csr_rows(*ctx.scores()), csr_rows(off, tax, sc))
     assert np.array_equal(limbs, ctx.profile_limbs())
@@ -83,6 +85,54 @@ np.savez(os.path.join(sys.argv[2], f"rank{rank}.npz"), off=off, tax=tax, sc=sc, 
 dist.barrier()
 dist.destroy_process_group()
 """
+
+
+RCCL_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from kasa_amd import capi, partition, dist as kdist
+from tests.test_gpu_parity import synthetic_world
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ix, batch = synthetic_world(97, 8, 7000, 1800)
+parts, cuts = partition.split_index(ix, 1)
+dix = capi.DeviceIndex(parts[0])
+owner = capi.Context(dix, 12, 7, 3)
+worker = partition.Worker(dix, 12, 7, 3)
+owner.queries = owner.records = None                      # the RCCL path must never stage through the host
+worker.ctx.queries = worker.ctx.records = None
+ctx = kdist.partitioned_batch(owner, worker, cuts, ix.K, batch)
+off, tax, sc = ctx.scores()
+np.savez(os.path.join(sys.argv[2], "rccl.npz"), off=off, tax=tax, sc=sc, limbs=ctx.profile_limbs())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_device_resident_exchange_over_rccl(tmp_path):
+    """kasa_amd/dist.py:partitioned_batch on the `nccl` backend (RCCL): the slices and the records travel as device
+    tensors through all_to_all_single and the kasa_batch_*_device entry points -- Context.queries()/records() are
+    removed in the worker process, so any host staging would fail.  One rank (this box has one GPU; RCCL refuses two
+    ranks on one device): the collective degenerates, the plumbing does not."""
+    import socket
+    import subprocess
+    import sys
+    assert capi.device_count() > 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, str(script), root, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / "rccl.npz")
+    ix, batch = synthetic_world(97, 8, 7000, 1800)
+    (off, tax, sc), limbs = _whole(ix, batch, 12, 7, 3)
+    assert np.array_equal(off, z["off"]) and np.array_equal(tax, z["tax"]) and np.array_equal(sc.view(np.uint32), z["sc"].view(np.uint32))
+    assert np.array_equal(limbs, z["limbs"])
 
 
 def test_two_ranks_one_partition_each(tmp_path):
