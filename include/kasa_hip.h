@@ -177,10 +177,13 @@ int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxI
  *   meta[4 r .. 4 r + 3] = { first entry, number of entries | flag << 31, float bits of the largest k-mer score among
  *                            the hits, number of hits }
  *   entries[i]           = { uint32 taxIdx, float kmerScore, double relativeScore }   (16 bytes)
+ * (nEntries = length of the entries array; reads own disjoint ranges of it, handed out in slabs, so some entries
+ * between them are unused)
  * A writer that runs the reference's loops over these entries (as if they were all hits, with the delivered maximum)
  * prints what it would print from the full row.  flag: the read has more than 16 hits and its printed prefix touches a
- * tie in the relative score (std::sort is only stable up to 16 elements), or the prefix is longer than 64 entries: the
- * host ranks such a read from its full row (kasa_batch_scores_fetch).  nFlagged counts them. */
+ * tie in the relative score (std::sort is only stable up to 16 elements), or it has more than 256 hits, or the prefix is
+ * longer than 64 entries: it gets no entries and the host ranks it from its full row (kasa_batch_scores_fetch).  nFlagged
+ * counts such reads. */
 int kasa_batch_rank(kasa_ctx *ctx, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
                     uint64_t *nEntries, uint32_t *nFlagged);
 int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);

@@ -3760,67 +3760,73 @@ extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint3
 // division is IEEE double on both sides.  One wavefront per read selects the next-best hit (relative score descending,
 // taxon ascending = what a stable sort gives) until neither output format would print another one, and emits that
 // prefix.  std::sort is only stable up to 16 elements: a read with more hits whose printed prefix touches a tie in the
-// relative score is flagged and ranked by the host from its full row (so is one whose prefix exceeds RANK_CAP).
-static constexpr int RANK_CAP = 64, RANK_CACHE = 256;
+// relative score is flagged and ranked by the host from its full row (so is one with more than RANK_ROWS hits or a
+// prefix beyond RANK_CAP).
+static constexpr int RANK_CAP = 64, RANK_ROWS = 256, RANK_SLAB = 256;
 struct RankEntry { uint32_t tax; float score; double rel; };
 __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
                                                    uint32_t nReads, const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
                                                    double thr, uint32_t beasts, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
                                                    unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged)
 {
+    // the read's hits, compacted (taxon ascending, as in the row): everything after the first pass runs out of LDS
+    __shared__ uint32_t sTax[4][RANK_ROWS];
+    __shared__ float sScore[4][RANK_ROWS];
+    __shared__ double sRel[4][RANK_ROWS];
     __shared__ RankEntry sOut[4][RANK_CAP];
-    __shared__ double sRel[4][RANK_CACHE];                             // relative scores of the row's first cells (NaN: no hit)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // output space comes in slabs of RANK_SLAB entries per wavefront: one atomic per slab, not per read (ten million
+    // atomics on one address would take longer than everything else here); what a slab has left when the next read does
+    // not fit stays unused
+    unsigned long long slabAt = 0;
+    uint32_t slabLeft = 0, flaggedMine = 0;
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += gridDim.x * 4u) {
         const uint64_t lo = rowOff[r];
         const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
         const double *dr = den + (size_t)readClass[r] * nTaxa;
-        auto relOf = [&](uint32_t i) -> double {                       // NaN unless cell i is a hit
-            const float sc = rowScore[lo + i];
-            const double rel = (double)sc / dr[rowTax[lo + i]];
-            return (sc > 0.0f && rel >= thr) ? rel : qnan;
-        };
         uint32_t cnt = 0;
         float maxV = 0.0f;
         for (uint32_t c0 = 0; c0 < m; c0 += 64) {
             const uint32_t i = c0 + lane;
-            double rel = qnan;
-            if (i < m) { rel = relOf(i); if (i < (uint32_t)RANK_CACHE) sRel[wv][i] = rel; }
-            const bool ok = rel == rel;
-            cnt += (uint32_t)__popcll(__ballot(ok));
-            if (ok) maxV = fmaxf(maxV, rowScore[lo + i]);
+            bool ok = false; float sc = 0.0f; uint32_t t = 0; double rel = 0.0;
+            if (i < m) {
+                sc = rowScore[lo + i]; t = rowTax[lo + i];
+                rel = (double)sc / dr[t];                                     // Compare.hpp:1506-1511, the denominator is the host's
+                ok = sc > 0.0f && rel >= thr;
+            }
+            const unsigned long long mk = __ballot(ok);
+            const uint32_t at = cnt + (uint32_t)__popcll(mk & below);
+            if (ok && at < (uint32_t)RANK_ROWS) { sTax[wv][at] = t; sScore[wv][at] = sc; sRel[wv][at] = rel; }
+            if (ok) maxV = fmaxf(maxV, sc);
+            cnt += (uint32_t)__popcll(mk);
         }
         for (int off = 32; off; off >>= 1) maxV = fmaxf(maxV, __shfl_xor(maxV, off));
         LDS_WAVE_SYNC();
-        auto relAt = [&](uint32_t i) -> double { return i < (uint32_t)RANK_CACHE ? sRel[wv][i] : relOf(i); };
         // selection, in step with the two printing loops (JSON / JSONL / Kraken: top + further hits; TSV: one list)
         uint32_t nOut = 0, top = 0, jJ = 0, jT = 0;
         float beforeJ = 0.0f, beforeT = 0.0f;
-        bool topDone = false, doneJ = false, doneT = false, flag = false;
+        bool topDone = false, doneJ = false, doneT = false, flag = cnt > (uint32_t)RANK_ROWS;
         double lastRel = 0.0; uint32_t lastTax = 0;
-        for (uint32_t k = 0; k < cnt; ++k) {
+        for (uint32_t k = 0; k < cnt && !flag; ++k) {
             // the next hit after (lastRel, lastTax) in the order (relative score descending, taxon ascending)
-            double bRel = qnan; uint32_t bTax = 0xFFFFFFFFu; float bScore = 0.0f;
-            for (uint32_t c0 = 0; c0 < m; c0 += 64) {
-                const uint32_t i = c0 + lane;
-                if (i >= m) continue;
-                const double rel = relAt(i);
-                if (!(rel == rel)) continue;
-                const uint32_t t = rowTax[lo + i];
+            bool have = false; double bRel = 0.0; uint32_t bTax = 0xFFFFFFFFu; float bScore = 0.0f;
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                const double rel = sRel[wv][i];
+                const uint32_t t = sTax[wv][i];
                 if (k > 0 && !(rel < lastRel || (rel == lastRel && t > lastTax))) continue;   // selected before
-                if (!(bRel == bRel) || rel > bRel || (rel == bRel && t < bTax)) { bRel = rel; bTax = t; bScore = rowScore[lo + i]; }
+                if (!have || rel > bRel || (rel == bRel && t < bTax)) { have = true; bRel = rel; bTax = t; bScore = sScore[wv][i]; }
             }
             for (int off = 32; off; off >>= 1) {
-                const double oRel = __shfl_xor(bRel, off); const uint32_t oTax = (uint32_t)__shfl_xor((int)bTax, off); const float oSc = __shfl_xor(bScore, off);
-                if ((oRel == oRel) && (!(bRel == bRel) || oRel > bRel || (oRel == bRel && oTax < bTax))) { bRel = oRel; bTax = oTax; bScore = oSc; }
+                const double oRel = __shfl_xor(bRel, off); const uint32_t oTax = (uint32_t)__shfl_xor((int)bTax, off);
+                const float oSc = __shfl_xor(bScore, off); const bool oHave = __shfl_xor((int)have, off) != 0;
+                if (oHave && (!have || oRel > bRel || (oRel == bRel && oTax < bTax))) { have = true; bRel = oRel; bTax = oTax; bScore = oSc; }
             }
             // ties: other remaining hits with the same relative score (their order is only defined for stable sorts)
             uint32_t same = 0;
-            for (uint32_t c0 = 0; c0 < m; c0 += 64) {
-                const uint32_t i = c0 + lane;
-                bool eq = false;
-                if (i < m) { const double rel = relAt(i); eq = rel == bRel && rowTax[lo + i] > bTax; }
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool eq = i < cnt && sRel[wv][i] == bRel && sTax[wv][i] > bTax;
                 same += (uint32_t)__popcll(__ballot(eq));
             }
             // would a writer print hit k?
@@ -3839,17 +3845,22 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
             ++nOut;
             lastRel = bRel; lastTax = bTax;
         }
-        unsigned long long at = 0;
-        if (lane == 0 && nOut) at = atomicAdd(cursor, (unsigned long long)nOut);
-        at = __shfl(at, 0);
+        if (flag) nOut = 0;                                                // the host ranks this read from its full row
+        if (nOut > slabLeft) {                                             // uniform
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(cursor, (unsigned long long)RANK_SLAB);
+            slabAt = __shfl(got, 0);
+            slabLeft = (uint32_t)RANK_SLAB;
+        }
+        const unsigned long long at = slabAt;
+        slabAt += nOut; slabLeft -= nOut;
         LDS_WAVE_SYNC();
         if (at + nOut <= cap) for (uint32_t x = lane; x < nOut; x += 64) entries[at + x] = sOut[wv][x];
-        if (lane == 0) {
-            meta[r] = make_uint4((uint32_t)at, nOut | (flag ? 0x80000000u : 0u), __float_as_uint(maxV), cnt);
-            if (flag) atomicAdd(nFlagged, 1u);
-        }
+        if (lane == 0) meta[r] = make_uint4((uint32_t)at, nOut | (flag ? 0x80000000u : 0u), __float_as_uint(maxV), cnt);
+        flaggedMine += flag ? 1u : 0u;
         LDS_WAVE_SYNC();
     }
+    if (lane == 0 && flaggedMine) atomicAdd(nFlagged, flaggedMine);
 }
 
 extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
@@ -3868,7 +3879,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
     if (nReads) HIPCHK(hipMemcpyAsync(c->rankClass.p, readClass, (size_t)nReads * 4, hipMemcpyHostToDevice, c->stream));
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 20;
     uint32_t *flagged = c->misc.as<uint32_t>() + 42;
-    if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1024, (uint64_t)nReads * 4);
+    if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1 << 20, (uint64_t)nReads * 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u);
     c->rankEntries = 0; *nEntries = 0; *nFlagged = 0;
     if (nReads == 0) return KASA_OK;
     for (int attempt = 0; attempt < 3; ++attempt) {
