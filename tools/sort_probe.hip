@@ -47,11 +47,14 @@ int main()
     CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&va, n * 4)); CK(hipMalloc(&vb, n * 4)); CK(hipMalloc(&bad, 4));
     fill<<<4096, 256>>>(a, va, n);
     if (one<rocprim::default_config>("default", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<8, 512, 10>>("8 bits match 512x10", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<9, 512, 10>>("9 bits match 512x10", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<9, 256, 12>>("9 bits match 256x12", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<10, 512, 10>>("10 bits match 512x10", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<10, 1024, 8>>("10 bits match 1024x8", a, b, va, vb, n, bad)) return 1;
-    if (one<Cfg<10, 512, 16>>("10 bits match 512x16", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 512, 16>>("8 bits match 512x16", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 512, 20>>("8 bits match 512x20", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 1024, 8>>("8 bits match 1024x8", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 1024, 10>>("8 bits match 1024x10", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 256, 24>>("8 bits match 256x24", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<8, 256, 32>>("8 bits match 256x32", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<9, 512, 20>>("9 bits match 512x20", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<9, 1024, 10>>("9 bits match 1024x10", a, b, va, vb, n, bad)) return 1;
+    if (one<Cfg<10, 1024, 10>>("10 bits match 1024x10", a, b, va, vb, n, bad)) return 1;
     return 0;
 }
