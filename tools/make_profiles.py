@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = "gpurun_out/profiles"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel"
+KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel"
 
 
 def run(cmd, **kw):
@@ -68,7 +68,7 @@ for name, cs in acc.items():
         e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2
         e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-    res[name if name != "row_merge_bitmap_kernel" else "row_merge_kernel"] = e
+    res[{"row_merge_bitmap_kernel": "row_merge_kernel", "score_other_flat_kernel": "score_other_kernel"}.get(name, name)] = e
 json.dump(res, open(os.path.join(out, tag + "_kernel_pmc.json"), "w"), indent=1)
 
 # 3. the bench line(s)
