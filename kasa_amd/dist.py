@@ -169,6 +169,29 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
     return ctx
 
 
+def partitioned_batches(owner_ctx, worker, cuts, K: int, batches, want_per_read: bool = True, unique: bool = False):
+    """partitioned_batch for a rank's whole list of batches.  The exchange is a collective: ranks may hold different numbers
+    of batches (read shards of different sizes, other `-m` cuts), so before every round the ranks agree (one all-reduce of
+    a flag) whether anybody still has a batch, and a rank that has run out takes part with an empty one -- its partition
+    is still needed by the others.  Yields `owner_ctx` after each of this rank's own batches."""
+    import torch
+    import torch.distributed as dist
+    from .reads import ReadBatch
+    nccl = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    it = iter(batches)
+    empty = ReadBatch(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64), [], np.zeros(0, dtype=np.uint32))
+    while True:
+        batch = next(it, None)
+        flag = torch.tensor([1 if batch is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) == 0:
+            return
+        ctx = partitioned_batch(owner_ctx, worker, cuts, K, batch if batch is not None else empty, want_per_read, unique)
+        if batch is not None:
+            yield ctx
+
+
 def limbs_to_tables(limbs: np.ndarray, n_k: int, n_taxa: int):
     """limbs[nK*nTaxa, 6] -> (countAll f64, countUnique u64, countTotal u64), each [nK, nTaxa]."""
     limbs = limbs.reshape(n_k * n_taxa, 6)

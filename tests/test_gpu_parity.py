@@ -354,6 +354,30 @@ def test_many_taxa_per_read_and_large_content():
     assert slow >= 0
 
 
+def test_more_than_2_20_taxa():
+    """A content file with more than 1 048 576 entries: staging records keep the taxon in 20 bits, so such an index must
+    take the general score kernel for every read (and still give the oracle's numbers)."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(21)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_taxa = (1 << 20) + 5000
+    hot = [7, 1 << 19, (1 << 20) - 1, 1 << 20, (1 << 20) + 4321]   # the taxa that own k-mers (dense index = position in the content)
+    genomes = [alphabet[rng.integers(0, 4, size=1500)] for _ in hot]
+    genomes[3] = genomes[2].copy(); genomes[3][::40] = alphabet[rng.integers(0, 4, size=len(genomes[3][::40]))]   # siblings across the 2^20 line
+    content = formats.Content(["non_unique"] + [f"T{g}" for g in range(n_taxa)], np.arange(n_taxa + 1, dtype=np.uint32) + np.uint32(10))
+    content.taxids[0] = 0
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for t, s in zip(hot, genomes):
+        km, _ = oracle.encode(s, np.array([0, s.shape[0]], dtype=np.int64), p)
+        kms.append(km)
+        tids.append(np.full(km.shape[0], content.taxids[t], dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, 24, 150, 5)
+    slow = _check_against_oracle(ix, batch, 12, 7, 3)
+    assert slow == batch.n                                       # nothing may take the 20-bit fast path
+
+
 # ---- 128-bit index (k <= 25) ----------------------------------------------------------------------------------------
 from tests.test_oracle_golden import WIDE  # noqa: E402
 

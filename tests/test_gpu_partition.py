@@ -78,10 +78,16 @@ mine = batch.slice(a, b)
 dix = capi.DeviceIndex(parts[rank])                       # this rank holds ONE partition
 owner = capi.Context(dix, 12, 7, 3)
 worker = partition.Worker(dix, 12, 7, 3)
-ctx = kdist.partitioned_batch(owner, worker, cuts, ix.K, mine)
-off, tax, sc = ctx.scores()
-limbs = kdist.allreduce_limbs(ctx.profile_limbs())
-np.savez(os.path.join(sys.argv[2], f"rank{rank}.npz"), off=off, tax=tax, sc=sc, limbs=limbs, a=a, b=b)
+# rank 0 runs its reads as one batch, rank 1 cuts its own into two: the ranks hold different numbers of batches
+cut = [0, mine.n] if rank == 0 else [0, mine.n // 3, mine.n]
+offs, taxs, scs, base = [np.zeros(1, dtype=np.uint64)], [], [], 0
+for ctx in kdist.partitioned_batches(owner, worker, cuts, ix.K, [mine.slice(x, y) for x, y in zip(cut[:-1], cut[1:])]):
+    o, t, v = ctx.scores()
+    offs.append(o[1:] + np.uint64(base)); taxs.append(t); scs.append(v)
+    base += int(o[-1])
+off, tax, sc = np.concatenate(offs), np.concatenate(taxs), np.concatenate(scs)
+limbs = kdist.allreduce_limbs(owner.profile_limbs())
+np.savez(os.path.join(sys.argv[2], f"rank{rank}.npz"), off=off, tax=tax, sc=sc, limbs=limbs, a=a, b=b, cut=np.asarray(cut))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -159,8 +165,15 @@ def test_two_ranks_one_partition_each(tmp_path):
         z = np.load(tmp_path / f"rank{rank}.npz")
         part = batch.slice(int(z["a"]), int(z["b"]))
         ctx = capi.Context(dix, 12, 7, 3)
-        ctx.run_batch(part.bases, part.offsets, True)
-        off, tax, sc = ctx.scores()
+        cut = [int(x) for x in z["cut"]]
+        offs, taxs, scs, base = [np.zeros(1, dtype=np.uint64)], [], [], 0
+        for x, y in zip(cut[:-1], cut[1:]):                       # the same batches on the whole index
+            sub = part.slice(x, y)
+            ctx.run_batch(sub.bases, sub.offsets, True)
+            o, t, v = ctx.scores()
+            offs.append(o[1:] + np.uint64(base)); taxs.append(t); scs.append(v)
+            base += int(o[-1])
+        off, tax, sc = np.concatenate(offs), np.concatenate(taxs), np.concatenate(scs)
         assert np.array_equal(off, z["off"]) and np.array_equal(tax, z["tax"])
         assert np.array_equal(sc.view(np.uint32), z["sc"].view(np.uint32))
         from kasa_amd import dist as kdist
