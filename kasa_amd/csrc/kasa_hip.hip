@@ -1202,6 +1202,65 @@ __global__ void slot_to_read_kernel(const uint32_t *__restrict__ slot, uint32_t 
 
 template <class Key> static int lookup_part(kasa_ctx *c);
 
+// Second half of the query sort.  The pairs arrive ordered (stably) by the top SORT_TOP bits of the key; queries that
+// share those bits -- a *bucket*: eight letters, i.e. little more than the copies of one k-mer prefix the reads' coverage brings --
+// are contiguous.  Every query finds its place inside its bucket by counting: the bucket members before it with a key
+// not larger, those after it with a smaller key (= the stable order).  One pass over the pairs instead of the remaining
+// 20 (85) bits' worth of radix passes.  A query whose bucket extends SORT_BUCKET_LIMIT positions to either side gives
+// up and raises `big`: the caller then sorts the rest the long way.
+static constexpr unsigned SORT_TOP = 40;
+static constexpr uint32_t SORT_BUCKET_LIMIT = 1024;
+static constexpr uint32_t RANK_TILE = 2048, RANK_HALO = 128;
+template <class Key>
+__global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
+                                                          uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big)
+{
+    // A tile of keys plus a short halo in LDS: a query looks at its neighbours four at a time (independent LDS reads; one
+    // at a time the scan is a chain of round trips, and from global memory it is bound by the load-issue rate).  Members
+    // of a bucket that reaches beyond the staged window are read from global memory.
+    __shared__ Key sK[RANK_TILE + 2 * RANK_HALO];
+    const uint32_t base = blockIdx.x * RANK_TILE;
+    const uint32_t lo = base >= RANK_HALO ? base - RANK_HALO : 0u;
+    const uint32_t hi = (uint64_t)base + RANK_TILE + RANK_HALO < (uint64_t)n ? base + RANK_TILE + RANK_HALO : n;
+    const uint32_t win = hi - lo;
+    for (uint32_t x = threadIdx.x; x < win; x += 256u) sK[x] = kin[lo + x];
+    __syncthreads();
+    auto keyAt = [&](uint32_t q) -> Key { const uint32_t x = q - lo; return x < win ? sK[x] : kin[q]; };
+    bool isBig = false;
+    for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
+        const uint32_t p = base + e;
+        if (p >= n) break;
+        const Key k = sK[p - lo];
+        const uint64_t top = (uint64_t)(k >> shift);
+        uint32_t rank = 0, L = 0, R = 0;
+        bool open = true;
+        for (uint32_t b0 = 0; open && L < SORT_BUCKET_LIMIT; b0 += 4) {
+            Key o[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) o[j] = (p >= 1u + b0 + j) ? keyAt(p - 1u - b0 - j) : k;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (open && (p < 1u + b0 + j || (uint64_t)(o[j] >> shift) != top)) open = false;
+                if (open) { ++L; rank += (o[j] <= k) ? 1u : 0u; }
+            }
+        }
+        open = true;
+        for (uint32_t b0 = 0; open && R < SORT_BUCKET_LIMIT; b0 += 4) {
+            Key o[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) o[j] = ((uint64_t)p + 1u + b0 + j < (uint64_t)n) ? keyAt(p + 1u + b0 + j) : k;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (open && ((uint64_t)p + 1u + b0 + j >= (uint64_t)n || (uint64_t)(o[j] >> shift) != top)) open = false;
+                if (open) { ++R; rank += (o[j] < k) ? 1u : 0u; }
+            }
+        }
+        if (L >= SORT_BUCKET_LIMIT || R >= SORT_BUCKET_LIMIT) isBig = true;
+        else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
+    }
+    if (__ballot(isBig) != 0ull && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile uint32_t *>(big) == 0u) atomicExch(big, 1u);
+}
+
 template <class Key>
 static int sort_and_range_impl(kasa_ctx *c, int unique)
 {
@@ -1213,12 +1272,35 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
     hipEvent_t a, b;
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_SORT], &a, &b))) return rc;
     if (nQ > 0) {
-        size_t tmpBytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->qKmerA.as<Key>(), c->qKmerB.as<Key>(),
-                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KeyTraits<Key>::BITS, c->stream));
-        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerA.as<Key>(), c->qKmerB.as<Key>(),
-                                         c->qReadA.as<uint32_t>(), c->qReadB.as<uint32_t>(), (size_t)nQ, 0u, (unsigned)KeyTraits<Key>::BITS, c->stream));
+        const unsigned BITS = (unsigned)KeyTraits<Key>::BITS;
+        auto radix = [&](DevBuf &kIn, DevBuf &vIn, DevBuf &kOut, DevBuf &vOut, unsigned lo, unsigned hi) -> int {
+            size_t tmpBytes = 0;
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, kIn.as<Key>(), kOut.as<Key>(), vIn.as<uint32_t>(), vOut.as<uint32_t>(), (size_t)nQ, lo, hi, c->stream));
+            int rc2 = c->sortTmp.reserve(tmpBytes);
+            if (rc2) return rc2;
+            HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, kIn.as<Key>(), kOut.as<Key>(), vIn.as<uint32_t>(), vOut.as<uint32_t>(), (size_t)nQ, lo, hi, c->stream));
+            return KASA_OK;
+        };
+        if (c->debugFlags & 64) {                                       // test tap: the library sort over all key bits
+            if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, 0u, BITS))) return rc;
+        } else {
+            // radix passes over the top 40 bits only (5 of the 8 resp. 16 passes), then every query finds its place
+            // inside its bucket (bucket_rank_kernel)
+            uint32_t *big = c->misc.as<uint32_t>() + 43;
+            if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
+            HIPCHK(hipMemsetAsync(big, 0, 4, c->stream));
+            bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
+                                                                                c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big);
+            HIPCHK(hipGetLastError());
+            uint32_t hBig = 0;
+            HIPCHK(hipMemcpyAsync(&hBig, big, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            // a bucket too long to rank by counting (an input that repeats itself): the rest the long way -- B is a stable
+            // rearrangement of the input, so the full sort of B is the full sort of the input
+            if (hBig && (rc = radix(c->qKmerB, c->qReadB, c->qKmerA, c->qReadA, 0u, BITS))) return rc;
+            std::swap(c->qKmerA, c->qKmerB);                            // the sorted pairs are in "B" again
+            std::swap(c->qReadA, c->qReadB);
+        }
     }
     c->qKmer = c->qKmerB.p;
     c->qRead = c->qReadB.as<uint32_t>();

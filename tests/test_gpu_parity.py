@@ -140,7 +140,7 @@ def test_medium_synthetic_vs_oracle():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    for slow in (0, 1, 2, 4, 32):                               # 32: score_other_kernel per lane instead of flattened
+    for slow in (0, 1, 2, 4, 32, 64):                           # 32: score_other_kernel per lane instead of flattened; 64: library sort over all bits
         ctx.debug_flags(slow)
         ctx.profile_reset()
         ctx.run_batch(batch.bases, batch.offsets, True)
@@ -352,6 +352,35 @@ def test_many_taxa_per_read_and_large_content():
     _check_against_oracle(ix, batch, 12, 7, 3, flags=32)
     _check_against_oracle(ix, batch, 12, 7, 3, flags=1)
     assert slow >= 0
+
+
+@pytest.mark.parametrize("K", [12, 25])
+def test_repeated_reads_fill_a_sort_bucket(K):
+    """The query sort ranks the members of a bucket (equal top 32 key bits) by counting; a batch that repeats one read
+    3000 times makes buckets of 3000 equal k-mers -- beyond SORT_BUCKET_LIMIT, so the sort finishes the long way.  The
+    sorted stream and everything after it must not notice (ties keep their batch order: the sort is stable)."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(61, 6, 5000, 700, K=K)
+    one = batch.slice(3, 4)
+    rep_b = np.concatenate([batch.bases] + [one.bases] * 3000)
+    lens = [int(batch.offsets[r + 1] - batch.offsets[r]) for r in range(batch.n)] + [int(one.offsets[1])] * 3000
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    big = reads.ReadBatch(rep_b, off, [f"x{i} " for i in range(len(lens))], np.asarray([l + 1 for l in lens], dtype=np.uint32))
+    kh = 12 if K == 12 else 25
+    p = oracle.params(kh, 7, 3, K=K)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, kh, 7, 3)
+    outs = []
+    for flags in (0, 64):
+        ctx.debug_flags(flags)
+        ctx.upload(big.bases, big.offsets); ctx.encode(); ctx.sort_and_range()
+        km, rd = ctx.queries()
+        outs.append((km.copy(), rd.copy()))
+    km_o, rd_o = oracle.sort_queries(*oracle.encode(big.bases, big.offsets, p))
+    for km, rd in outs:
+        assert np.array_equal(km, km_o) and np.array_equal(rd, rd_o)
+    ctx.close(); dix.close()
+    _check_against_oracle(ix, big.slice(0, 1200), kh, 7, 3)
 
 
 def test_more_than_2_20_taxa():
@@ -647,7 +676,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40]))
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40, 64, 72]))
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
