@@ -1391,6 +1391,7 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 
 static constexpr int GITEMS = 2;                  // the group kernel gives a thread two queries of the tile
 static constexpr int GTHREADS = TILE / GITEMS;    // 512
+static constexpr int GOVF = 2048;                 // segments beyond the inline ones a tile can park in LDS (narrow records)
 static constexpr int GSPAN = 3072;                // index entries around the tile's matches staged in LDS (taxon + neighbour counts)
 static constexpr uint32_t GMARGIN = 96;           // ... this many beyond the first and last representative
 
@@ -1535,6 +1536,12 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     __shared__ uint32_t sTax[GSPAN];
     __shared__ Meta sMeta[GSPAN];
     __shared__ uint32_t sRepLo[GTHREADS / 64], sRepHi[GTHREADS / 64];
+    // narrow records: the segments beyond the inline ones wait here until the workgroup's pool block is allocated (one walk
+    // per query instead of two); {segment, owner query | index in its pool list << 10}
+    __shared__ uint2 sOvf[RW == 8 ? GOVF : 1];
+    __shared__ uint32_t sOvfDst[RW == 8 ? TILE : 1];                 // per query of the tile: pool word of its first overflow segment
+    __shared__ uint32_t sOvfN;
+    if (threadIdx.x == 0) sOvfN = 0u;
     const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1617,6 +1624,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     auto getTax = [&](uint32_t i) -> uint32_t { const uint32_t x = i - spanLo; return x < spanN ? sTax[x] : tax[i]; };
     // ---- 2. + 3. per query: order of its events, taxon segments
     uint32_t w2[GITEMS], w3[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
+    unsigned long long cnt8x[GITEMS] = {0ull, 0ull};
     unsigned __int128 ord[GITEMS];
     uint32_t need = 0;
 #pragma unroll
@@ -1665,18 +1673,28 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         fmax[i] = fm;
         w2[i] = (uint32_t)d[i] | (RW == 8 ? ((uint32_t)ord[i] << 5) : 0u);
         uint32_t n = 0, nlev = 0;                                 // nlev: |T_k| per level, 3 bits each, saturating at 7 (RW = 8)
+        unsigned long long cnt8 = 0;                              // |T_k| per level, 8 bits each (exact below 255 segments)
         bool split = false;                                       // a taxon may own several segments (an entry continues an earlier one of its taxon)
         walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
 #pragma unroll
             for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
+            if constexpr (RW == 8) {
+                if (n >= (uint32_t)(INL - 1)) {                       // may end up in the pool (it does when there are more than INL)
+                    const uint32_t at = atomicAdd(&sOvfN, 1u);
+                    if (at < (uint32_t)GOVF) sOvf[at] = make_uint2(s, (uint32_t)(t * GITEMS + i) | ((n - (uint32_t)(INL - 1)) << 10));
+                }
+                const int lvLo = kHigh - (int)(s >> 27), lvHi = kHigh - (int)((s >> 22) & 31u);   // + 1 in the fields of its levels
+                const unsigned long long upTo = lvHi >= 7 ? ~0ull : ((1ull << (8 * (lvHi + 1))) - 1ull);
+                cnt8 += upTo & ~((1ull << (8 * lvLo)) - 1ull) & 0x0101010101010101ull;
+            }
             ++n;
             if ((int)((s >> 22) & 31u) > kLow) split = true;
-            if constexpr (RW == 8) {                                  // + 1 in the 3-bit fields of its levels that are below 7
-                const int lvLo = kHigh - (int)(s >> 27), lvHi = kHigh - (int)((s >> 22) & 31u);
-                const uint32_t fields = ((lvHi >= 7 ? 0u : (1u << (3 * (lvHi + 1)))) - (1u << (3 * lvLo))) & 0x249249u;
-                nlev += fields & ~(nlev & (nlev >> 1) & (nlev >> 2));
-            }
         });
+        if constexpr (RW == 8) {
+#pragma unroll
+            for (int lv = 0; lv < 8; ++lv) { const uint32_t cl = (uint32_t)(cnt8 >> (8 * lv)) & 255u; nlev |= (cl < 7u ? cl : 7u) << (3 * lv); }
+            cnt8x[i] = cnt8;
+        }
         nseg[i] = n;
         w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
         if (RW == 8 && split) w2[i] |= REC_SPLIT;
@@ -1701,9 +1719,48 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         __syncthreads();
         const bool fits = sBase != NOPOS;
         off += fits ? sBase : 0u;
+        // fast way (narrow records): headers by the owners, the waiting segments by everybody.  Not when the buffer
+        // overflowed or a query has 255 or more segments (8-bit counts): then the lists are walked again, below.
+        bool again = true;
+        if constexpr (RW == 8) {
+            bool mineOk = true;
+#pragma unroll
+            for (int i = 0; i < GITEMS; ++i) if (nseg[i] >= 255u) mineOk = false;
+            again = __syncthreads_or((!mineOk || sOvfN > (uint32_t)GOVF) ? 1 : 0) != 0;
+            if (!again) {
+#pragma unroll
+                for (int i = 0; i < GITEMS; ++i) {
+                    uint32_t dst = NOPOS;
+                    if (nseg[i] > (uint32_t)INL) {
+                        const bool sat = (w2[i] & REC_SAT) != 0u;
+                        if (fits) {
+                            pool[off] = nseg[i];
+                            if (sat) {
+                                uint32_t wds[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    wds[q] = ((uint32_t)(cnt8x[i] >> (16 * q)) & 255u) | (((uint32_t)(cnt8x[i] >> (16 * q + 8)) & 255u) << 16);
+                                pool[off + 1] = wds[0]; pool[off + 2] = wds[1]; pool[off + 3] = wds[2]; pool[off + 4] = wds[3];
+                            }
+                            dst = off + 1u + (sat ? POOL_SIZES : 0u);
+                        }
+                        seg[i][INL - 1] = off;
+                        off += nseg[i] - (uint32_t)(INL - 1) + 1u + (sat ? POOL_SIZES : 0u);
+                    }
+                    sOvfDst[t * GITEMS + i] = dst;
+                }
+                __syncthreads();
+                const uint32_t nOvf = sOvfN;
+                for (uint32_t x = t; x < nOvf; x += GTHREADS) {
+                    const uint2 e = sOvf[x];
+                    const uint32_t dst = sOvfDst[e.y & 1023u];
+                    if (dst != NOPOS) pool[dst + (e.y >> 10)] = e.x;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < GITEMS; ++i)
-            if (nseg[i] > (uint32_t)INL) {
+            if (again && nseg[i] > (uint32_t)INL) {
                 const bool sat = RW == 8 && (w2[i] & REC_SAT) != 0u;
                 if (fits) {                                          // (else: the host grows the pool and reruns)
                     pool[off] = nseg[i];
