@@ -2996,21 +2996,30 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const uint32_t W = (nTaxa + 31u) >> 5;
-    for (uint32_t r = blockIdx.x; r < nReads; r += gridDim.x) {
-        const uint32_t raw = rowLen[r];
+    constexpr int HELD = 4;                                            // chunks of a row kept in registers between the passes
+    // the row's whereabouts are fetched one row ahead: the kernel is a chain of dependent round trips per row
+    uint32_t r = blockIdx.x;
+    uint32_t nRaw = r < nReads ? rowLen[r] : 0u, nPos = r < nReads ? rowPos[r] : 0u, nKey = r < nReads ? rowKey[r] : 0u;
+    for (; r < nReads; r += gridDim.x) {
+        const uint32_t raw = nRaw, s0 = nPos, key0 = nKey;
+        const uint32_t rNext = r + gridDim.x;
+        if (rNext < nReads) { nRaw = rowLen[rNext]; nPos = rowPos[rNext]; nKey = rowKey[rNext]; }
         if (!(raw & ROW_MERGE)) continue;                              // uniform per block
         const uint32_t m = raw & ~ROW_MERGE;
         if (m <= mLo || m > (uint32_t)RCAP) continue;
-        const uint32_t s0 = rowPos[r];
+        uint2 held[HELD];                                              // all loads of the first chunks go out together
+#pragma unroll
+        for (int c = 0; c < HELD; ++c) {
+            const uint32_t i = (uint32_t)c * 64u + lane;
+            held[c] = i < m ? st[s0 + i] : make_uint2(RK_FINAL, 0u);
+        }
         for (uint32_t w = lane; w < W; w += 64) bm[w] = 0u;
         for (uint32_t i = lane; i < m; i += 64) { val[i] = 0.0f; claim[i] = 0xFFFFFFFFu; }
         LDS_WAVE_SYNC();
         // pass 1: the row's taxa as a bitmap; every event leaves as a profile key (a prefix sum places the keys of a chunk)
-        uint32_t keyAt = rowKey[r];
-        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        uint32_t keyAt = key0;
+        auto pass1 = [&](uint32_t i0, uint2 e) {
             const uint32_t i = i0 + lane;
-            uint2 e = make_uint2(RK_FINAL, 0u);
-            if (i < m) e = st[s0 + i];
             const uint32_t kind = e.x >> 30;
             const uint32_t t = e.x & 0xFFFFFu;
             if (i < m && kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
@@ -3029,6 +3038,12 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                         profKeys[kw++] = profile_key_of((uint32_t)kHigh - k, seg_size(e.y, k == kF), t, 1u, PL);
                 } else profKeys[kw] = profile_key(e, PL);
             }
+        };
+#pragma unroll
+        for (int c = 0; c < HELD; ++c) if ((uint32_t)c * 64u < m) pass1((uint32_t)c * 64u, held[c]);
+        for (uint32_t i0 = HELD * 64u; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            pass1(i0, i < m ? st[s0 + i] : make_uint2(RK_FINAL, 0u));
         }
         LDS_WAVE_SYNC();
         uint32_t carry = 0;                                            // exclusive popcount prefix over the bitmap words
@@ -3047,14 +3062,12 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
         LDS_WAVE_SYNC();
         // pass 2: 64 records at a time, in row order (= the read's flush order).  A record adds its hits to the running
         // score of its taxon's slot; two records of one chunk that share a slot take turns in lane order.
-        for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        auto pass2 = [&](uint32_t i0, uint2 e) {
             const uint32_t i = i0 + lane;
-            uint2 e = make_uint2(0u, 0u);
             bool pending = false;
             uint32_t slot = 0;
             float sc = 0.0f;
             if (i < m) {
-                e = st[s0 + i];                                        // (L2-hot: read in pass 1 a moment ago)
                 const uint32_t kind = e.x >> 30;
                 if (kind != 2u) {
                     const uint32_t t = e.x & 0xFFFFFu;
@@ -3082,6 +3095,12 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
                 }
                 LDS_WAVE_SYNC();
             }
+        };
+#pragma unroll
+        for (int c = 0; c < HELD; ++c) if ((uint32_t)c * 64u < m) pass2((uint32_t)c * 64u, held[c]);
+        for (uint32_t i0 = HELD * 64u; i0 < m; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            pass2(i0, i < m ? st[s0 + i] : make_uint2(0u, 0u));       // (L2-hot: read in pass 1 a moment ago)
         }
         LDS_WAVE_SYNC();
         for (uint32_t sl = lane; sl < nSlots; sl += 64) st[s0 + sl] = make_uint2(slotTax[sl], __float_as_uint(val[sl]));
