@@ -128,9 +128,15 @@ int kasa_batch_lookup_score(kasa_ctx *ctx, int wantPerRead, int coverage);
 /* The two halves of kasa_batch_lookup_score as separate steps, with the event records in between exposed, for an index
  * that is range-partitioned over devices (C5; the reference's loadIndex has no such mode, the seam is ours):
  *   kasa_batch_group          one record per sorted query, in sorted order: 8 (up to 8 levels) or 16 (up to 25 levels)
- *                             32-bit words {position, last flush position, deepest level | flush order of its events,
- *                             number of taxon segments, up to 4 (8) segments or the pool offset of a longer list};
- *                             a segment = taxon | first level << 22 | last level << 27;
+ *                             32-bit words {position, last flush position, deepest level | flush order of its events |
+ *                             flags, number of taxon segments | sizes of the taxon sets per level (narrow records),
+ *                             [wide: the flush order, 4 words], up to 4 (8) segments -- or 3 (7) and the pool offset of a
+ *                             longer list: pool block = {number of segments, [4 words of exact set sizes when the
+ *                             record's "crowded" flag is set], the further segments}};
+ *                             a segment = taxon | first level << 22 | last level << 27, so an index may name at most
+ *                             2^22 taxa (layout: kasa_amd/csrc/kasa_hip.hip "event records", DESIGN.md sections 3-4).
+ *                             Records and pools are opaque to a caller that only moves them; they are NOT a stable
+ *                             format across versions of this library;
  *   kasa_batch_records_*      size (in 32-bit words) / download of records and pool; import hands records in sorted order
  *                             to a context whose batch is sorted, which files them by read;
  *   kasa_batch_score          replays the records per read (scores, profile) exactly as kasa_batch_lookup_score does. */
