@@ -2253,6 +2253,9 @@ template <int RW> struct QueryRec {
     uint32_t sg[RT::INL];
     uint32_t nInl, nMore;
     const uint32_t *more, *sizes;                                      // pool: further segments; exact level sizes (REC_SAT)
+    // wide records carry no |T_k|: a kernel may build them once per query (level_sizes_*) and hang the table in here
+    const uint32_t *tab = nullptr;
+    int tabStride = 0;
     __device__ __forceinline__ void decode(const uint4 *rp, const uint32_t *__restrict__ pool)
     {
         uint4 v[RW / 4];
@@ -2290,6 +2293,7 @@ template <int RW> struct QueryRec {
     {
         uint32_t n = RW == 8 ? ((nlev >> (3 * lv)) & 7u) : 7u;
         if (RW == 8) return n < 7u ? n : ((sizes[lv >> 1] >> (16 * (lv & 1))) & 0xFFFFu);   // "7 or more": the exact size is in the pool
+        if (tab) return tab[lv * tabStride];
         if (n == 7u) {                                               // not recorded: count
             const uint32_t k = (uint32_t)(kHigh - lv);
             n = 0;
@@ -2323,6 +2327,9 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
     __shared__ float sTab[NL][8];                                    // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
     __shared__ uint32_t sPB[65], sPPtr[64], sPT0[64], sPT1[64], sPM0[64], sPM1[64], sPRec[64], sPKey[64];   // pool segments of the current queries
+    // wide records: |T_k| of the current query of every lane -- +1 / -1 at the ends of each segment's level range, then a
+    // running sum over the levels (counting the segments again for every event cost seven times as much)
+    __shared__ uint32_t sLvN[RW == 16 ? NL + 2 : 1][64];
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
@@ -2425,6 +2432,15 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                     else if (t == mTax1) mask1 |= m;
                     else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
                 }
+                if constexpr (RW == 16) {
+                    for (int lv = 0; lv <= nK; ++lv) sLvN[lv][lane] = 0u;
+#pragma unroll
+                    for (int q = 0; q < RT::INL; ++q) {
+                        if (!live || (uint32_t)q >= Q.nInl) continue;
+                        sLvN[A.kHigh - (int)(Q.sg[q] >> 27)][lane] += 1u;
+                        sLvN[A.kHigh - (int)((Q.sg[q] >> 22) & 31u) + 1][lane] -= 1u;
+                    }
+                }
                 const uint32_t nm = live ? Q.nMore : 0u;
                 if (__ballot(nm != 0u) != 0ull) {
                     uint32_t incl = nm;
@@ -2447,6 +2463,10 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                             for (int step = 32; step; step >>= 1) if (sPB[own + step] <= i) own += step;
                             const uint32_t sq = A.pool[sPPtr[own] + (i - sPB[own])];
                             const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+                            if constexpr (RW == 16) {
+                                atomicAdd(&sLvN[A.kHigh - (int)(sq >> 27)][own], 1u);
+                                atomicSub(&sLvN[A.kHigh - (int)((sq >> 22) & 31u) + 1][own], 1u);
+                            }
                             if (t == sPT0[own]) atomicOr(&sPM0[own], m);
                             else if (t == sPT1[own]) atomicOr(&sPM1[own], m);
                             else { atomicAdd(&sPRec[own], seg_records<RW>(m, ((satMask >> own) & 1ull) != 0ull)); atomicAdd(&sPKey[own], (uint32_t)__popc(m)); }
@@ -2457,6 +2477,12 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                     LDS_WAVE_SYNC();
                 }
                 if ((mask0 | mask1) == 0u) continue;
+                if constexpr (RW == 16) {
+                    LDS_WAVE_SYNC();
+                    uint32_t running = 0;
+                    for (int lv = 0; lv < nK; ++lv) { running += sLvN[lv][lane]; sLvN[lv][lane] = running; }
+                    Q.tab = &sLvN[0][lane]; Q.tabStride = 64;
+                }
                 const int nEv = Q.d - A.kLow + 1;
                 unsigned __int128 o = Q.order;
                 for (int ev = 0; ev < nEv; ++ev, o >>= OB) {
@@ -2570,6 +2596,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
     constexpr uint32_t STAGE = 512;                                        // records a wavefront stages; larger (rare) batches are written directly
     __shared__ uint2 sRec[4][STAGE];
     __shared__ uint32_t sAt[4][STAGE];
+    __shared__ uint32_t sLvN[RW == 16 ? RT::LEVELS + 2 : 1][256];        // wide records: |T_k| of this thread's query (QueryRec::tab)
     const int wv = threadIdx.x >> 6;
     for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < nQup; slot += stride) {
         const bool inRange = slot < A.nQ;
@@ -2606,6 +2633,26 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
 #pragma unroll
         for (int i = 0; i < 4; ++i) if ((uint32_t)i < Q.nMore) xs[i] = Q.more[i];
         auto extra = [&](uint32_t q) -> uint32_t { return q == 0 ? xs[0] : q == 1 ? xs[1] : q == 2 ? xs[2] : q == 3 ? xs[3] : Q.more[q]; };
+        if constexpr (RW == 16) {
+            if (live) {                                                        // + 1 / - 1 at the ends of every segment's level range, running sum
+                const int nKl = A.kHigh - A.kLow + 1, me = (int)threadIdx.x;
+                for (int lv = 0; lv <= nKl; ++lv) sLvN[lv][me] = 0u;
+#pragma unroll
+                for (int q = 0; q < RT::INL; ++q) {
+                    if ((uint32_t)q >= Q.nInl) continue;
+                    sLvN[A.kHigh - (int)(Q.sg[q] >> 27)][me] += 1u;
+                    sLvN[A.kHigh - (int)((Q.sg[q] >> 22) & 31u) + 1][me] -= 1u;
+                }
+                for (uint32_t q = 0; q < Q.nMore; ++q) {
+                    const uint32_t sq = extra(q);
+                    sLvN[A.kHigh - (int)(sq >> 27)][me] += 1u;
+                    sLvN[A.kHigh - (int)((sq >> 22) & 31u) + 1][me] -= 1u;
+                }
+                uint32_t running = 0;
+                for (int lv = 0; lv < nKl; ++lv) { running += sLvN[lv][me]; sLvN[lv][me] = running; }
+                Q.tab = &sLvN[0][me]; Q.tabStride = 256;
+            }
+        }
         // levels with |T| > CNT_FIELDS: there the register taxa leave profile records instead of counting in LDS
         uint32_t bigLv = 0;
         if constexpr (RW == 8) {
