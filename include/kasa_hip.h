@@ -288,7 +288,8 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * a stable sort by read id, as for long or paired reads), bit 4 = the profile keys are sorted and reduced even
  * when the LDS counting table would fit, bit 5 = score_other_kernel (one lane per query) instead of
  * score_other_flat_kernel (work items = segments) for 32-byte records, bit 6 = the library's radix sort over all
- * key bits instead of 4 passes + bucket_rank_kernel; lastSlowReads (may be
+ * key bits instead of 5 passes + bucket_rank_kernel, bit 7 = long sort buckets are not sorted one by one but by the
+ * library over all bits (the path for inputs with too many or too long ones); lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

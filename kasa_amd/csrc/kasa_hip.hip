@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/functional.hpp>
@@ -464,6 +465,7 @@ struct kasa_ctx {
     DevBuf seqOff, seqRead;                    // u64[nSeq+1] k-mer offset of every uploaded sequence, u32[nSeq] its read
     int64_t nSeq = 0; bool haveSeqRead = false;
     DevBuf qKmerA, qKmerB, qReadA, qReadB;     // double buffers of the query arrays
+    DevBuf sortBig;                            // heads / begins / ends of the long buckets (sort_and_range)
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
@@ -1233,14 +1235,17 @@ template <class Key> static int lookup_part(kasa_ctx *c);
 // share those bits -- a *bucket*: eight letters, i.e. little more than the copies of one k-mer prefix the reads' coverage brings --
 // are contiguous.  Every query finds its place inside its bucket by counting: the bucket members before it with a key
 // not larger, those after it with a smaller key (= the stable order).  One pass over the pairs instead of the remaining
-// 20 (85) bits' worth of radix passes.  A query whose bucket extends SORT_BUCKET_LIMIT positions to either side gives
-// up and raises `big`: the caller then sorts the rest the long way.
+// 20 (85) bits' worth of radix passes.  Buckets of more than SORT_BUCKET_LIMIT members (an input that repeats itself) are
+// copied through and listed in `bigHead`; the caller sorts each of them by its remaining bits.
 static constexpr unsigned SORT_TOP = 40;
 static constexpr uint32_t SORT_BUCKET_LIMIT = 1024;
+static constexpr uint32_t SORT_BIG_CAP = 1u << 18;     // long buckets sorted one by one; more of them (or one beyond SORT_BIG_LONGEST): the library over all bits
+static constexpr uint32_t SORT_BIG_LONGEST = 1u << 20;
 static constexpr uint32_t RANK_TILE = 2048, RANK_HALO = 128;
 template <class Key>
 __global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
-                                                          uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big)
+                                                          uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big,
+                                                          uint32_t *__restrict__ bigHead)
 {
     // A tile of keys plus a short halo in LDS: a query looks at its neighbours four at a time (independent LDS reads; one
     // at a time the scan is a chain of round trips, and from global memory it is bound by the load-issue rate).  Members
@@ -1253,7 +1258,6 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict_
     for (uint32_t x = threadIdx.x; x < win; x += 256u) sK[x] = kin[lo + x];
     __syncthreads();
     auto keyAt = [&](uint32_t q) -> Key { const uint32_t x = q - lo; return x < win ? sK[x] : kin[q]; };
-    bool isBig = false;
     for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
         const uint32_t p = base + e;
         if (p >= n) break;
@@ -1282,10 +1286,28 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict_
                 if (open) { ++R; rank += (o[j] < k) ? 1u : 0u; }
             }
         }
-        if (L >= SORT_BUCKET_LIMIT || R >= SORT_BUCKET_LIMIT) isBig = true;
-        else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
+        // a bucket of more than SORT_BUCKET_LIMIT members stays as it is (every member decides the same way: it sees both
+        // ends of the bucket or knows it is longer); its first member files it for the segmented sort that follows
+        if (L + R + 1u > SORT_BUCKET_LIMIT) {
+            kout[p] = k; vout[p] = vin[p];
+            if (L == 0u) { const uint32_t at = atomicAdd(big, 1u); if (at < SORT_BIG_CAP) bigHead[at] = p; }
+        } else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
     }
-    if (__ballot(isBig) != 0ull && (threadIdx.x & 63) == 0 && *reinterpret_cast<volatile uint32_t *>(big) == 0u) atomicExch(big, 1u);
+}
+
+// [begin, end) of the listed buckets: the end by bisection over the top bits (the pairs are ordered by them)
+template <class Key>
+__global__ void bucket_bounds_kernel(const Key *__restrict__ kin, uint32_t n, int shift, const uint32_t *__restrict__ head, uint32_t nHead,
+                                     uint32_t *__restrict__ begin, uint32_t *__restrict__ end, uint32_t *__restrict__ longest)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nHead) return;
+    const uint32_t p = head[x];
+    const uint64_t top = (uint64_t)(kin[p] >> shift);
+    uint32_t lo = p, hi = n;                                              // first position whose top bits are larger
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)(kin[mid] >> shift) <= top) lo = mid + 1; else hi = mid; }
+    begin[x] = p; end[x] = lo;
+    atomicMax(longest, lo - p);
 }
 
 template <class Key>
@@ -1313,18 +1335,39 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         } else {
             // radix passes over the top 40 bits only (5 of the 8 resp. 16 passes), then every query finds its place
             // inside its bucket (bucket_rank_kernel)
-            uint32_t *big = c->misc.as<uint32_t>() + 43;
+            uint32_t *big = c->misc.as<uint32_t>() + 43, *longest = c->misc.as<uint32_t>() + 44;
+            if ((rc = c->sortBig.reserve((size_t)SORT_BIG_CAP * 12 + 64))) return rc;
+            uint32_t *bigHead = c->sortBig.as<uint32_t>(), *segBegin = bigHead + SORT_BIG_CAP, *segEnd = segBegin + SORT_BIG_CAP;
             if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
-            HIPCHK(hipMemsetAsync(big, 0, 4, c->stream));
+            HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
             bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
-                                                                                c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big);
+                                                                                      c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
             HIPCHK(hipGetLastError());
             uint32_t hBig = 0;
             HIPCHK(hipMemcpyAsync(&hBig, big, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            // a bucket too long to rank by counting (an input that repeats itself): the rest the long way -- B is a stable
-            // rearrangement of the input, so the full sort of B is the full sort of the input
-            if (hBig && (rc = radix(c->qKmerB, c->qReadB, c->qKmerA, c->qReadA, 0u, BITS))) return rc;
+            if (hBig) {
+                // buckets too long to rank by counting (an input that repeats itself) were copied through as they are:
+                // each of them is sorted by the remaining bits on its own (segmented radix sort, B -> A in place of the
+                // copy).  Too many of them, or one too long for a single workgroup: the library over all bits instead --
+                // B is a stable rearrangement of the input, so its full sort is the full sort of the input.
+                uint32_t hLongest = 0;
+                if (hBig <= SORT_BIG_CAP) {
+                    bucket_bounds_kernel<Key><<<blocks_for(hBig, 256), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), bigHead, hBig,
+                                                                                         segBegin, segEnd, longest);
+                    HIPCHK(hipGetLastError());
+                    HIPCHK(hipMemcpyAsync(&hLongest, longest, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                }
+                if (hBig <= SORT_BIG_CAP && hLongest <= SORT_BIG_LONGEST && !(c->debugFlags & 128)) {   // (test tap 128: the last resort)
+                    size_t tmpBytes = 0;
+                    HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, tmpBytes, c->qKmerB.as<Key>(), c->qKmerA.as<Key>(), c->qReadB.as<uint32_t>(), c->qReadA.as<uint32_t>(),
+                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - SORT_TOP, c->stream));
+                    if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+                    HIPCHK(rocprim::segmented_radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerB.as<Key>(), c->qKmerA.as<Key>(), c->qReadB.as<uint32_t>(), c->qReadA.as<uint32_t>(),
+                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - SORT_TOP, c->stream));
+                } else if ((rc = radix(c->qKmerB, c->qReadB, c->qKmerA, c->qReadA, 0u, BITS))) return rc;
+            }
             std::swap(c->qKmerA, c->qKmerB);                            // the sorted pairs are in "B" again
             std::swap(c->qReadA, c->qReadB);
         }

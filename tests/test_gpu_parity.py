@@ -357,7 +357,8 @@ def test_many_taxa_per_read_and_large_content():
 @pytest.mark.parametrize("K", [12, 25])
 def test_repeated_reads_fill_a_sort_bucket(K):
     """The query sort ranks the members of a bucket (equal top 32 key bits) by counting; a batch that repeats one read
-    3000 times makes buckets of 3000 equal k-mers -- beyond SORT_BUCKET_LIMIT, so the sort finishes the long way.  The
+    3000 times makes buckets of 3000 equal k-mers -- beyond SORT_BUCKET_LIMIT: they are sorted one by one (segmented
+    radix sort), or, with debug flag 128, by the library over all bits (the last resort for too many / too long ones).  The
     sorted stream and everything after it must not notice (ties keep their batch order: the sort is stable)."""
     _gpu_or_fail()
     ix, batch = synthetic_world(61, 6, 5000, 700, K=K)
@@ -371,7 +372,7 @@ def test_repeated_reads_fill_a_sort_bucket(K):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, 7, 3)
     outs = []
-    for flags in (0, 64):
+    for flags in (0, 64, 128):
         ctx.debug_flags(flags)
         ctx.upload(big.bases, big.offsets); ctx.encode(); ctx.sort_and_range()
         km, rd = ctx.queries()
