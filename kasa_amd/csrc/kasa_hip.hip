@@ -3300,21 +3300,28 @@ __global__ __launch_bounds__(PR_THREADS) void profile_reduce_kernel(const uint64
 static constexpr int PT_THREADS = 1024, PT_LEFT = 2048;
 // Largest |T| the table counts per level, and where a level's cells start (in units of nTaxa): shallow levels have large
 // taxon sets (chance matches of short prefixes), deep ones one or two taxa, so the cells are dealt out unevenly.
-struct ProfTableLayout { uint8_t nn[MAX_LEVELS]; uint16_t first[MAX_LEVELS + 1]; };
-static ProfTableLayout prof_table_layout(int nK, uint32_t nTaxa, uint64_t budgetCells)
+// One launch counts the keys of the levels lvLo .. lvHi - 1 (the others are skipped): with many levels (-k 25 7: 19) the
+// cells of one workgroup do not go round, and several passes over the keys are far cheaper than sorting them all.
+struct ProfTableLayout { uint8_t nn[MAX_LEVELS]; uint16_t first[MAX_LEVELS + 1]; int lvLo, lvHi; };
+static ProfTableLayout prof_table_layout(int nK, int lvLo, int lvHi, uint32_t nTaxa, uint64_t budgetCells)
 {
     ProfTableLayout L;
     memset(&L, 0, sizeof(L));
-    const uint64_t perTaxon = nTaxa ? budgetCells / nTaxa : 0;         // cells every taxon can have over all levels
-    if (perTaxon < (uint64_t)nK) return L;                              // not even |T| = 1 everywhere: no table
-    uint64_t left = perTaxon - (uint64_t)nK;
-    for (int lv = 0; lv < nK; ++lv) L.nn[lv] = 1;
-    auto grow = [&](int lv, uint64_t upTo) { while (lv >= 0 && lv < nK && L.nn[lv] < upTo && left > 0) { ++L.nn[lv]; --left; } };
-    for (int lv = 0; lv < nK; ++lv) grow(lv, 2);                        // pairs (sibling taxa) at every level
-    grow(nK - 2, 4);
-    grow(nK - 1, 24);                                                   // the shallowest level takes what is left
-    grow(nK - 2, 8);
-    for (int lv = 0; lv < nK; ++lv) L.first[lv + 1] = (uint16_t)(L.first[lv] + L.nn[lv]);
+    L.lvLo = lvLo; L.lvHi = lvHi;
+    const uint64_t perTaxon = nTaxa ? budgetCells / nTaxa : 0;         // cells every taxon can have over the window's levels
+    const int nW = lvHi - lvLo;
+    if (nW <= 0 || perTaxon < (uint64_t)nW) { L.lvHi = lvLo; return L; }   // not even |T| = 1 everywhere: no table
+    uint64_t left = perTaxon - (uint64_t)nW;
+    for (int lv = lvLo; lv < lvHi; ++lv) L.nn[lv] = 1;
+    auto grow = [&](int lv, uint64_t upTo) { while (lv >= lvLo && lv < lvHi && L.nn[lv] < upTo && left > 0) { ++L.nn[lv]; --left; } };
+    for (int lv = lvLo; lv < lvHi; ++lv) grow(lv, 2);                   // pairs (sibling taxa) at every level
+    if (lvHi == nK) {                                                   // the window with the shallowest levels: large taxon sets
+        grow(nK - 2, 4);
+        grow(nK - 1, 24);                                               // the shallowest level takes what is left
+        grow(nK - 2, 8);
+    }
+    for (uint64_t upTo = 3; upTo <= 8; ++upTo) for (int lv = lvHi - 1; lv >= lvLo; --lv) grow(lv, upTo);   // what is left: evenly, shallow first
+    for (int lv = 0; lv < MAX_LEVELS; ++lv) L.first[lv + 1] = (uint16_t)(L.first[lv] + L.nn[lv]);
     return L;
 }
 __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, ProfTableLayout TL,
@@ -3326,7 +3333,7 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
     __shared__ uint64_t sLeft[PT_LEFT];
     __shared__ uint32_t sLeftN;
     __shared__ unsigned long long sLeftBase;
-    const uint32_t cells = (uint32_t)TL.first[nK] * nTaxa;
+    const uint32_t cells = (uint32_t)TL.first[MAX_LEVELS] * nTaxa;
     for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) tab[i] = 0u;
     if (threadIdx.x == 0) sLeftN = 0;
     __syncthreads();
@@ -3354,7 +3361,8 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
             if (hits != 0u && tax != (1u << PL.tb) - 1u) {               // (else: unused slot)
                 const uint32_t n = (uint32_t)((f >> PL.tb) & ((1ull << PL.nb) - 1ull));
                 const uint32_t lv = (uint32_t)(f >> (PL.tb + PL.nb));
-                if (n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
+                if ((int)lv < TL.lvLo || (int)lv >= TL.lvHi) {}                // another pass counts this level
+                else if (n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
                 else sLeft[atomicAdd(&sLeftN, 1u)] = key;
             }
         }
@@ -3709,21 +3717,32 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
         c->lastStaged = staged; c->lastKeys = nKeys;
         // the keys summed per (level, |T|, taxon): counted in LDS when the table fits a workgroup, else sorted and reduced
-        const ProfTableLayout TL = prof_table_layout(nK, nTaxa, (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u);
-        const uint32_t NN = TL.first[nK];
+        // Up to 8 levels: one pass; more: the four shallowest levels (large taxon sets) in one pass, the deeper ones eight at
+        // a time.  Keys no pass has a cell for collect in one list, which is sorted and reduced.
+        const uint64_t budgetCells = (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u;
+        std::vector<ProfTableLayout> passes;
+        if (nK <= 8) passes.push_back(prof_table_layout(nK, 0, nK, nTaxa, budgetCells));
+        else {
+            passes.push_back(prof_table_layout(nK, nK - 4, nK, nTaxa, budgetCells));
+            for (int hi = nK - 4; hi > 0; hi -= 8) passes.push_back(prof_table_layout(nK, std::max(0, hi - 8), hi, nTaxa, budgetCells));
+        }
+        bool tables = nKeys > 0 && !(c->debugFlags & 16);
+        for (const auto &TL : passes) if (TL.lvHi <= TL.lvLo) tables = false;      // a window without cells: everything is sorted
         uint64_t *sortIn = c->profKeys.as<uint64_t>(), *sortOut = c->profSorted.as<uint64_t>();
         uint64_t nSort = nKeys;
-        if (nKeys > 0 && NN >= 1 && !(c->debugFlags & 16)) {
+        if (tables) {
             int nCu = 0;
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
-            const size_t shBytes = (size_t)NN * nTaxa * 4;
             unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
             HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream));
-            HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
-            profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
-                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
-                c->profSorted.as<uint64_t>(), leftCursor);
-            HIPCHK(hipGetLastError());
+            for (const auto &TL : passes) {
+                const size_t shBytes = (size_t)TL.first[MAX_LEVELS] * nTaxa * 4;
+                HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
+                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
+                    c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
+                    c->profSorted.as<uint64_t>(), leftCursor);
+                HIPCHK(hipGetLastError());
+            }
             unsigned long long nLeft = 0;
             HIPCHK(hipMemcpyAsync(&nLeft, leftCursor, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
