@@ -3441,7 +3441,11 @@ template <int RW>
 static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, int cov, unsigned long long *cursor)
 {
     const uint64_t nQ = c->nQ;
-    if (c->ix->wide)
+    if (c->ix->wide && RW == 16 && c->nK == 19)                       // the default -k 25 7 of a 128-bit index: loops over exactly 19 levels
+        group_kernel<RW, key128, RW == 16 ? 19 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
+            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+    else if (c->ix->wide)
         group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
             c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
