@@ -1295,6 +1295,72 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict_
     }
 }
 
+// The same for 64-bit keys, where the bits below the bucket's fit 32: LDS holds one word per query -- those bits and a flag
+// "first of its bucket" -- so a member is one 4-byte read and one 32-bit compare (half the LDS traffic, no 64-bit
+// arithmetic in the scans).  A bucket that reaches beyond the staged window is scanned in global memory (rare).
+__global__ __launch_bounds__(256) void bucket_rank32_kernel(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
+                                                            uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big,
+                                                            uint32_t *__restrict__ bigHead)
+{
+    __shared__ uint32_t sW[RANK_TILE + 2 * RANK_HALO];
+    const uint32_t base = blockIdx.x * RANK_TILE;
+    const uint32_t lo = base >= RANK_HALO ? base - RANK_HALO : 0u;
+    const uint32_t hi = (uint64_t)base + RANK_TILE + RANK_HALO < (uint64_t)n ? base + RANK_TILE + RANK_HALO : n;
+    const uint32_t win = hi - lo;
+    const uint32_t lowMask = (1u << shift) - 1u;
+    for (uint32_t x = threadIdx.x; x < win; x += 256u) {
+        const uint32_t q = lo + x;
+        const uint64_t k = kin[q];
+        const bool head = q == 0u || (kin[q - 1u] >> shift) != (k >> shift);
+        sW[x] = ((uint32_t)k & lowMask) | (head ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
+        const uint32_t p = base + e;
+        if (p >= n) break;
+        const uint32_t i0 = p - lo, my = sW[i0], myLow = my & lowMask;
+        uint32_t rank = 0, L = 0, R = 0;
+        bool edge = false;
+        bool open = (my >> 31) == 0u;                                     // members before me, down to the first of the bucket
+        for (uint32_t b0 = 0; open && L < SORT_BUCKET_LIMIT; b0 += 4) {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) w[j] = (i0 >= 1u + b0 + j) ? sW[i0 - 1u - b0 - j] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (!open) continue;
+                if (i0 < 1u + b0 + j) { edge = true; open = false; continue; }
+                ++L; rank += ((w[j] & lowMask) <= myLow) ? 1u : 0u;
+                if (w[j] >> 31) open = false;
+            }
+        }
+        open = true;                                                      // members after me, up to the first of the next bucket
+        for (uint32_t b0 = 0; open && R < SORT_BUCKET_LIMIT; b0 += 4) {
+            uint32_t w[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) w[j] = (i0 + 1u + b0 + j < win) ? sW[i0 + 1u + b0 + j] : 0x80000000u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (!open) continue;
+                if (i0 + 1u + b0 + j >= win) { edge = hi < n; open = false; continue; }
+                if (w[j] >> 31) { open = false; continue; }
+                ++R; rank += ((w[j] & lowMask) < myLow) ? 1u : 0u;
+            }
+        }
+        const uint64_t k = kin[p];
+        if (edge) {                                                       // the bucket leaves the window: the whole scan again, from global memory
+            const uint64_t top = k >> shift;
+            rank = 0; L = 0; R = 0;
+            for (uint32_t q = p; q > 0 && L < SORT_BUCKET_LIMIT;) { --q; const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++L; rank += (o <= k) ? 1u : 0u; }
+            for (uint32_t q = p + 1; q < n && R < SORT_BUCKET_LIMIT; ++q) { const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++R; rank += (o < k) ? 1u : 0u; }
+        }
+        if (L + R + 1u > SORT_BUCKET_LIMIT) {
+            kout[p] = k; vout[p] = vin[p];
+            if (L == 0u) { const uint32_t at = atomicAdd(big, 1u); if (at < SORT_BIG_CAP) bigHead[at] = p; }
+        } else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
+    }
+}
+
 // [begin, end) of the listed buckets: the end by bisection over the top bits (the pairs are ordered by them)
 template <class Key>
 __global__ void bucket_bounds_kernel(const Key *__restrict__ kin, uint32_t n, int shift, const uint32_t *__restrict__ head, uint32_t nHead,
@@ -1340,8 +1406,12 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
             uint32_t *bigHead = c->sortBig.as<uint32_t>(), *segBegin = bigHead + SORT_BIG_CAP, *segEnd = segBegin + SORT_BIG_CAP;
             if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
-            bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
+            if constexpr (sizeof(Key) == 8)
+                bucket_rank32_kernel<<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<uint64_t>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<uint64_t>(),
                                                                                       c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
+            else
+                bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
+                                                                                          c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
             HIPCHK(hipGetLastError());
             uint32_t hBig = 0;
             HIPCHK(hipMemcpyAsync(&hBig, big, 4, hipMemcpyDeviceToHost, c->stream));
