@@ -1559,7 +1559,7 @@ static constexpr uint32_t GMARGIN = 96;           // ... this many beyond the fi
 // taxon up to there).  |T_k| = number of segments covering k.  This replaces the reference's per-level sBitArray sets
 // (Compare.hpp:917-955, BitArray.hpp:98-117) for all levels of a query at once.
 static constexpr uint32_t SEG_TAX_MASK = (1u << 22) - 1u;
-static constexpr uint32_t REC_SPLIT = 1u << 29;   // RW = 8, word [2]: some segment starts above kLow, i.e. a taxon may own several segments
+static constexpr uint32_t REC_SPLIT = 1u << 29;   // word [2]: some segment starts above kLow, i.e. a taxon may own several segments
 static constexpr uint32_t REC_SAT = 1u << 30;     // RW = 8, word [2]: some level has 7 or more taxa (its 3-bit count is saturated)
 template <int RW> struct RecTraits;
 template <> struct RecTraits<8> { static constexpr int LEVELS = 8, INL = 4, SEG0 = 4, OBITS = 3; };
@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         }
         nseg[i] = n;
         w3[i] = RW == 8 ? ((n < 255u ? n : 255u) | (nlev << 8)) : n;
-        if (RW == 8 && split) w2[i] |= REC_SPLIT;
+        if (split) w2[i] |= REC_SPLIT;                           // (wide records: bit 29 of word [2] is free as well)
         if (RW == 8 && (nlev & (nlev >> 1) & (nlev >> 2) & 0x249249u)) w2[i] |= REC_SAT;
         if (n > (uint32_t)INL) need += n - (uint32_t)(INL - 1) + 1u + ((w2[i] & REC_SAT) ? POOL_SIZES : 0u);   // pool block: {nseg, [sizes], segments INL-1 ...}
         if (coverage) {                                           // Compare.hpp:926-927: once per matched group, by its first query
@@ -2388,7 +2388,7 @@ template <int RW> struct QueryRec {
         } else {
             const uint4 o4 = v[1], s0 = v[2], s1 = v[3];
             order = ((unsigned __int128)o4.w << 96) | ((unsigned __int128)o4.z << 64) | ((unsigned __int128)o4.y << 32) | o4.x;
-            split = 1u; nseg = h.w; nlev = 0;
+            split = h.z & REC_SPLIT; nseg = h.w; nlev = 0;
             sg[0] = s0.x; sg[1] = s0.y; sg[2] = s0.z; sg[3] = s0.w; sg[4] = s1.x; sg[5] = s1.y; sg[6] = s1.z; sg[7] = s1.w;
         }
         finish(pool);
