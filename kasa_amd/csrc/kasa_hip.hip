@@ -3056,6 +3056,207 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
     }
 }
 
+// The flattened kernel for 64-byte records (up to 25 levels).  Wide records carry no |T_k|, so there are two sweeps over
+// the segments of a wavefront's 64 queries: the first adds +1 / -1 at the ends of every segment's level range into the
+// owner's column of an LDS table (a running sum over the levels then gives |T_k|, and the crowded levels of the register
+// taxa), the second emits: every record of a wide query is an event record, a segment's levels leave in the query's flush
+// order (5 bits per event in the record's 128-bit order field).
+template <bool PERREAD>
+__global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
+{
+    typedef RecTraits<16> RT;
+    constexpr int WV = 2, INL = RT::INL, NLW = RT::LEVELS;
+    constexpr uint32_t CNT_FIELDS = 2u;
+    __shared__ uint32_t sBase[WV][65];
+    __shared__ uint32_t sSg[WV][INL][64];                                  // inline segments (sweep 1: all; sweep 2: those that leave records)
+    __shared__ uint32_t sOrd[WV][4][64];                                   // flush order, 5 bits per event
+    __shared__ uint32_t sW2[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64], sPool[WV][64], sNInl[WV][64];
+    __shared__ uint32_t sLvN[WV][NLW + 2][64];                             // |T_k| of every lane's query (QueryRec::tab)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t kindOther = PERREAD ? 0u : RK_PROFILE;
+    const uint32_t stride = gridDim.x * 128u;
+    const double readsPerSlot = (double)A.nReads / (double)A.nQ;
+    const uint32_t nQup = (A.nQ + 63u) & ~63u;
+    const unsigned long long upTo = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const int nK = A.kHigh - A.kLow + 1;
+    for (uint32_t slot = blockIdx.x * 128u + threadIdx.x; slot < nQup; slot += stride) {
+        const bool inRange = slot < A.nQ;
+        uint4 cur[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[i] = make_uint4(0, 0, 0, 0);
+        uint32_t r = 0;
+        uint64_t readStart = 0;
+        uint4 mo = make_uint4(0, 0, 0, 0);
+        if (inRange) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 4 + i];
+            r = (uint32_t)((double)slot * readsPerSlot);
+            if (r >= A.nReads) r = A.nReads - 1u;
+            readStart = A.kmerOff[r];
+            if (!(readStart <= slot && slot < A.kmerOff[r + 1])) {
+                uint32_t lo = 0, hi = A.nReads;
+                while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (A.kmerOff[mid] <= slot) lo = mid; else hi = mid; }
+                r = lo;
+                readStart = A.kmerOff[r];
+            }
+            mo = reinterpret_cast<const uint4 *>(A.mainOut)[r];
+        }
+        const bool live = inRange && mo.w != 0u && (cur[0].z & 31u) != 0u;
+        const uint32_t mTax0 = mo.x, mTax1 = mo.y;
+        QueryRec<16> Q;
+        Q.decode_regs(cur, A.pool);
+        if (!live) { Q.d = 0; Q.nInl = 0; Q.nMore = 0; Q.split = 0; Q.nseg = 0; }
+        const bool split = Q.split != 0u;
+        const int nEvMine = Q.d ? Q.d - A.kLow + 1 : 0;
+        // ---- sweep 1: |T_k| of every query
+        for (int lv = 0; lv <= nK; ++lv) sLvN[wv][lv][lane] = 0u;
+        uint32_t incl = Q.nseg;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t S1 = __shfl(incl, 63);
+        if (S1 == 0u) continue;                                                // uniform: no live query
+        sBase[wv][lane] = incl - Q.nseg;
+        if (lane == 63) sBase[wv][64] = S1;
+#pragma unroll
+        for (int q = 0; q < INL; ++q) sSg[wv][q][lane] = Q.sg[q];
+        sNInl[wv][lane] = Q.nInl;
+        sPool[wv][lane] = Q.sg[INL - 1];
+        LDS_WAVE_SYNC();
+        for (uint32_t b0 = 0; b0 < S1; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            if (i < S1) {
+                uint32_t own = 0;
+#pragma unroll
+                for (int step = 32; step; step >>= 1) if (sBase[wv][own + step] <= i) own += step;
+                const uint32_t idx = i - sBase[wv][own], nInl = sNInl[wv][own];
+                const uint32_t sq = idx < nInl ? sSg[wv][idx][own] : A.pool[sPool[wv][own] + 1u + idx - nInl];
+                atomicAdd(&sLvN[wv][A.kHigh - (int)(sq >> 27)][own], 1u);
+                atomicSub(&sLvN[wv][A.kHigh - (int)((sq >> 22) & 31u) + 1][own], 1u);
+            }
+        }
+        LDS_WAVE_SYNC();
+        uint32_t bigLv = 0;                                                    // levels where the register taxa leave profile records
+        {
+            uint32_t running = 0;
+            for (int lv = 0; lv < nK; ++lv) { running += sLvN[wv][lv][lane]; sLvN[wv][lv][lane] = running; if (running > CNT_FIELDS) bigLv |= 1u << lv; }
+        }
+        Q.tab = &sLvN[wv][0][lane]; Q.tabStride = 64;
+        auto emitMask = [&](uint32_t sq) -> uint32_t {
+            const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
+            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+        };
+        // ---- sweep 2: the records
+        uint32_t mineSplit = 0;
+        if (__ballot(split) != 0ull && split) {
+#pragma unroll
+            for (int q = 0; q < INL; ++q) if ((uint32_t)q < Q.nInl) mineSplit += (uint32_t)__popc(emitMask(Q.sg[q]));
+            for (uint32_t q = 0; q < Q.nMore; ++q) mineSplit += (uint32_t)__popc(emitMask(Q.more[q]));
+        }
+        uint32_t emInl = 0;
+#pragma unroll
+        for (int q = 0; q < INL; ++q) if ((uint32_t)q < Q.nInl && emitMask(Q.sg[q]) != 0u) emInl |= 1u << q;
+        const uint32_t nEmInl = (uint32_t)__popc(emInl);
+        const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
+        incl = nFlat;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t S = __shfl(incl, 63);
+        if (S == 0u) { LDS_WAVE_SYNC(); continue; }                            // uniform
+        const bool head = inRange && (uint64_t)slot == readStart;
+        const unsigned long long H = __ballot(head);
+        const bool started = (H & upTo) != 0ull;
+        LDS_WAVE_SYNC();                                                       // sweep 1's readers are done with sBase / sSg
+        sBase[wv][lane] = incl - nFlat;
+        if (lane == 63) sBase[wv][64] = S;
+#pragma unroll
+        for (int q = 0; q < INL; ++q) if ((emInl >> q) & 1u) sSg[wv][__popc(emInl & ((1u << q) - 1u))][lane] = Q.sg[q];
+        sNInl[wv][lane] = nEmInl;
+        sOrd[wv][0][lane] = cur[1].x; sOrd[wv][1][lane] = cur[1].y; sOrd[wv][2][lane] = cur[1].z; sOrd[wv][3][lane] = cur[1].w;
+        sW2[wv][lane] = cur[0].z; sT0[wv][lane] = mTax0; sT1[wv][lane] = mTax1; sBig[wv][lane] = bigLv;
+        sRow[wv][lane] = live ? mo.z + (started ? 0u : A.otherOff64[slot >> 6]) : 0u;
+        sSplit[wv][lane] = mineSplit;
+        LDS_WAVE_SYNC();
+        uint32_t carry = 0;
+        int prevOwnCarry = -1;
+        for (uint32_t b0 = 0; b0 < S; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            const bool act = i < S;
+            uint32_t own = 0;
+#pragma unroll
+            for (int step = 32; step; step >>= 1) if (sBase[wv][own + step] <= i) own += step;
+            if (!act) own = 63u;
+            const uint32_t idx = i - sBase[wv][own];
+            const uint32_t w2 = sW2[wv][own];
+            const bool isSplit = (w2 & REC_SPLIT) != 0u;
+            uint32_t sq = 0;
+            const bool seg = act && !isSplit;
+            if (seg) {
+                const uint32_t nInl = sNInl[wv][own];
+                sq = idx < nInl ? sSg[wv][idx][own] : A.pool[sPool[wv][own] + 1u + (INL - 1) + (idx - nInl) - (INL - 1)];
+            }
+            const uint32_t t = sq & SEG_TAX_MASK;
+            const bool isMain = t == sT0[wv][own] || t == sT1[wv][own];
+            const uint32_t m = seg ? seg_level_mask(sq, A.kHigh) : 0u;
+            const uint32_t em = isMain ? (m & sBig[wv][own]) : m;
+            uint32_t c = (uint32_t)__popc(em);
+            if (act && isSplit) c = sSplit[wv][own];
+            int prevOwn = __shfl_up((int)own, 1);
+            if (lane == 0) prevOwn = prevOwnCarry;
+            const unsigned long long toOwn = own == 63u ? ~0ull : ((2ull << own) - 1ull);
+            const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
+            bool f = act && (H & toOwn & ~toPrev) != 0ull;
+            uint32_t v = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(v, off);
+                const bool fo = __shfl_up((int)f, off) != 0;
+                if (lane >= off && !f) { v += o; f = fo; }
+            }
+            uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
+            carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
+            prevOwnCarry = __shfl((int)own, 63);
+            if (act && c) {
+                const uint32_t kind = isMain ? RK_PROFILE : kindOther;
+                if (isSplit) sSplit[wv][own] = w;
+                else if (c == 1u) {
+                    const int lv = __ffs((int)em) - 1;
+                    A.st[w] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (sLvN[wv][lv][own] << 16) | 1u);
+                } else {                                                       // its levels in the query's flush order
+                    const int nEv = (int)(w2 & 31u) - A.kLow + 1;
+                    unsigned __int128 o = ((unsigned __int128)sOrd[wv][3][own] << 96) | ((unsigned __int128)sOrd[wv][2][own] << 64) |
+                                          ((unsigned __int128)sOrd[wv][1][own] << 32) | sOrd[wv][0][own];
+                    for (int ev = 0; ev < nEv; ++ev, o >>= 5) {
+                        const int lv = (int)((uint32_t)o & 31u);
+                        if ((em >> lv) & 1u) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (sLvN[wv][lv][own] << 16) | 1u);
+                    }
+                }
+            }
+        }
+        if (__ballot(split && mineSplit) != 0ull) {
+            LDS_WAVE_SYNC();
+            if (split && mineSplit) {                                          // a taxon may own several segments: event by event
+                uint32_t w = sSplit[wv][lane];
+                unsigned __int128 o = Q.order;
+                auto putEvent = [&](uint32_t sq, int lv) {
+                    const uint32_t t = sq & SEG_TAX_MASK;
+                    const uint32_t kind = (t == mTax0 || t == mTax1) ? RK_PROFILE : kindOther;
+                    A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (Q.set_size(lv, A.kHigh) << 16) | 1u);
+                };
+                for (int ev = 0; ev < nEvMine; ++ev, o >>= 5) {
+                    const int lv = (int)((uint32_t)o & 31u);
+#pragma unroll
+                    for (int q = 0; q < INL; ++q) if ((uint32_t)q < Q.nInl && ((emitMask(Q.sg[q]) >> lv) & 1u)) putEvent(Q.sg[q], lv);
+                    for (uint32_t q = 0; q < Q.nMore; ++q) { const uint32_t sq = Q.more[q]; if ((emitMask(sq) >> lv) & 1u) putEvent(sq, lv); }
+                }
+            }
+        }
+        LDS_WAVE_SYNC();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // row_merge: one wavefront per staging row written by score_fast_kernel.  Sorts the row's records by
 // (taxon, position) in LDS, sums each taxon's event scores IN THAT ORDER (= the read's flush order), and
@@ -3680,7 +3881,12 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_MAIN], ka, kb))) return rc;
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_OTHER], &ka, &kb))) return rc;
-            const bool flat = RW == 8 && !(c->debugFlags & 32);              // debug flag 32: the per-lane kernel for narrow records too
+            const bool flat = RW == 8 && !(c->debugFlags & 32);              // debug flag 32: the per-lane kernels
+            if (RW == 16 && !(c->debugFlags & 32)) {
+                const unsigned fblocks16 = std::min<unsigned>(blocks_for(nQ, 128), 256u * 128u);
+                if (wantPerRead) score_other_flat16_kernel<true><<<fblocks16, 128, 0, c->stream>>>(A);
+                else score_other_flat16_kernel<false><<<fblocks16, 128, 0, c->stream>>>(A);
+            } else
             if (wantPerRead) { if (flat) score_other_flat_kernel<true><<<oblocks, 256, 0, c->stream>>>(A); else if (RW == 8) score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
             else { if (flat) score_other_flat_kernel<false><<<oblocks, 256, 0, c->stream>>>(A); else if (RW == 8) score_other_kernel<8, false><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, false><<<oblocks, 256, 0, c->stream>>>(A); }
             HIPCHK(hipGetLastError());
