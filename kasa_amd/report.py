@@ -74,6 +74,65 @@ class Ranked:
     best: np.float32
 
 
+def _stdsort_order(n: int, less):
+    """Ids 0..n-1 in the order libstdc++'s std::sort leaves them (less(x, y): x goes before y): introsort with the median
+    of three moved to the front, unguarded partition, ranges of at most 16 left to one final insertion sort -- the same
+    comparisons and moves as kasa_amd/csrc/stdsort_order.h (checked against std::sort itself in tests/test_host_cpu.py).
+    Returns None where libstdc++ would switch to its heap sort (2 log2(n) partitioning levels used up)."""
+    a = list(range(n))
+    if n <= 1:
+        return a
+    stack = [(0, n, 2 * (n.bit_length() - 1))]
+    while stack:
+        first, last, depth = stack.pop()
+        while last - first > 16:
+            if depth == 0:
+                return None
+            depth -= 1
+            mid = first + (last - first) // 2
+            A, B, C = first + 1, mid, last - 1
+            if less(a[A], a[B]):
+                pick = B if less(a[B], a[C]) else (C if less(a[A], a[C]) else A)
+            elif less(a[A], a[C]):
+                pick = A
+            else:
+                pick = C if less(a[B], a[C]) else B
+            a[first], a[pick] = a[pick], a[first]
+            lo, hi = first + 1, last
+            while True:
+                while less(a[lo], a[first]):
+                    lo += 1
+                hi -= 1
+                while less(a[first], a[hi]):
+                    hi -= 1
+                if not lo < hi:
+                    break
+                a[lo], a[hi] = a[hi], a[lo]
+                lo += 1
+            stack.append((lo, last, depth))
+            last = lo
+
+    def insert_unguarded(i):
+        v = a[i]
+        j = i - 1
+        while less(v, a[j]):
+            a[j + 1] = a[j]
+            j -= 1
+        a[j + 1] = v
+
+    guarded = min(n, 16)
+    for i in range(1, guarded):
+        if less(a[i], a[0]):
+            v = a[i]
+            a[1:i + 1] = a[0:i]
+            a[0] = v
+        else:
+            insert_unguarded(i)
+    for i in range(guarded, n):
+        insert_unguarded(i)
+    return a
+
+
 def rank_read(tax_idx, scores, length: int, freq_khigh, k_high: int, k_low: int, frames: int,
               threshold: float, beasts: int, K: int = K64, protein: bool = False) -> Ranked:
     """Compare.hpp:1495-1594.  `tax_idx` ascending, `scores` > 0 (the cells the reference scans)."""
@@ -87,8 +146,13 @@ def rank_read(tax_idx, scores, length: int, freq_khigh, k_high: int, k_low: int,
         rel = relative_score(s, int(freq_khigh[int(t)]), length, K, protein)
         if rel >= thr:
             hits.append(Hit(int(t), s, rel))
-    # std::sort on `rel` descending; libstdc++ uses insertion sort up to 16 elements, i.e. stable there
-    hits.sort(key=lambda h: -h.rel)
+    # std::sort on `rel` descending: not stable beyond 16 elements, but deterministic -- tied hits end up where
+    # libstdc++'s introsort leaves them (_stdsort_order); up to 16 elements it is an insertion sort, i.e. stable
+    order = _stdsort_order(len(hits), lambda x, y: hits[x].rel > hits[y].rel) if len(hits) > 16 else None
+    if order is not None:
+        hits = [hits[i] for i in order]
+    else:
+        hits.sort(key=lambda h: -h.rel)
     n_top = 0
     if hits:
         max_score = max(h.score for h in hits)

@@ -109,3 +109,36 @@ def test_halved_index_writer_matches_reference_shrink(tmp_path):
     for suffix in ("", "_trie", "_trie.txt", "_info.txt", "_f.txt"):
         with open(out + suffix, "rb") as a, open(os.path.join(d, "idx_half" + suffix), "rb") as b:
             assert a.read() == b.read(), suffix
+
+
+def _build_stdsort_check(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stdsort_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "stdsort_check.cpp")], check=True)
+    return exe
+
+
+def test_stdsort_order_equals_libstdcxx(tmp_path):
+    """kasa_amd/csrc/stdsort_order.h (the order std::sort leaves tied hits in, restated for the device ranking) against
+    std::sort itself: 60 000 arrays of 1..1500 elements with many, some and no ties, sorted and reversed inputs."""
+    import subprocess
+    r = subprocess.run([_build_stdsort_check(tmp_path)], stdout=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK "), r.stdout
+
+
+def test_python_stdsort_order_equals_libstdcxx(tmp_path):
+    """... and the Python restatement (kasa_amd/report.py:_stdsort_order, used by rank_read for more than 16 hits) against
+    std::sort's order on 300 tie-heavy arrays printed by the same program."""
+    import subprocess
+    from kasa_amd import report
+    r = subprocess.run([_build_stdsort_check(tmp_path), "dump"], stdout=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 300
+    for line in lines:
+        rels, ids = line.split("|")
+        rel = [float(x) for x in rels.split()]
+        want = [int(x) for x in ids.split()]
+        got = report._stdsort_order(len(rel), lambda x, y: rel[x] > rel[y])
+        assert got == want
