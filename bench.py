@@ -200,6 +200,7 @@ def pcie_inclusive(ctx, reads, want, ix, k_high):
         nnz = int(ctx.batch_stats()["nnz"])                                # a long-lived host keeps its page-locked buffers
         csr_buf = (capi.pinned_empty(reads.n + 1, np.uint64), capi.pinned_empty(nnz, np.uint32), capi.pinned_empty(nnz, np.float32))
         rank_buf = (capi.pinned_empty(reads.n * 4, np.uint32), capi.pinned_empty(reads.n * 8, capi.RANK_ENTRY))
+        ctx.rank(den, rclass, 0.0, 3, out=rank_buf)                          # ... and the context its device buffers (the batch is scored)
         t0 = time.perf_counter()
         ctx.upload(bases, offsets)
         ctx.encode()

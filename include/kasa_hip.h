@@ -186,10 +186,11 @@ int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxI
  * (nEntries = length of the entries array; reads own disjoint ranges of it, handed out in slabs, so some entries
  * between them are unused)
  * A writer that runs the reference's loops over these entries (as if they were all hits, with the delivered maximum)
- * prints what it would print from the full row.  flag: the read has more than 16 hits and its printed prefix touches a
- * tie in the relative score (std::sort is only stable up to 16 elements), or it has more than 256 hits, or the prefix is
- * longer than 64 entries: it gets no entries and the host ranks it from its full row (kasa_batch_scores_fetch).  nFlagged
- * counts such reads. */
+ * prints what it would print from the full row.  Where more than 16 hits meet a tie in the relative score inside the
+ * printed prefix, the order is std::sort's own (not stable, but deterministic): those reads are ranked by a second kernel
+ * that walks libstdc++'s introsort over the hits (kasa_amd/csrc/stdsort_order.h).  flag: the read could not be ranked on
+ * the device (std::sort would have switched to its heap sort, or the row has 65 536 or more cells): it gets no entries
+ * and the host ranks it from its full row (kasa_batch_scores_fetch).  nFlagged counts such reads. */
 int kasa_batch_rank(kasa_ctx *ctx, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
                     uint64_t *nEntries, uint32_t *nFlagged);
 int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);
@@ -289,7 +290,8 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * when the LDS counting table would fit, bit 5 = score_other_kernel (one lane per query) instead of
  * score_other_flat_kernel (work items = segments) for 32-byte records, bit 6 = the library's radix sort over all
  * key bits instead of 5 passes + bucket_rank_kernel, bit 7 = long sort buckets are not sorted one by one but by the
- * library over all bits (the path for inputs with too many or too long ones); lastSlowReads (may be
+ * library over all bits (the path for inputs with too many or too long ones), bit 8 = kasa_batch_rank leaves reads with
+ * tied hits to the host instead of ranking them with std::sort's order on the device; lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

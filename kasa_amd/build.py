@@ -10,6 +10,7 @@ SRC = os.path.join(HERE, "csrc", "kasa_hip.hip")
 HOST_SRCS = [os.path.join(HERE, "csrc", "kasa_refbatch.cpp")]   # host-only parts of the C ABI
 SO = os.path.join(HERE, "libkasa_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "kasa_hip.h")
+CSRC_HEADERS = [os.path.join(HERE, "csrc", "stdsort_order.h")]
 
 
 def hipcc() -> str:
@@ -20,7 +21,7 @@ def hipcc() -> str:
 
 
 def build(force: bool = False) -> str:
-    newest = max(os.path.getmtime(p) for p in [SRC, HEADER] + HOST_SRCS)
+    newest = max(os.path.getmtime(p) for p in [SRC, HEADER] + HOST_SRCS + CSRC_HEADERS)
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

@@ -37,6 +37,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/kasa_hip.h"
+#include "stdsort_order.h"
 
 // ------------------------------------------------------------------------------------------------
 // constants
@@ -456,7 +457,7 @@ struct kasa_ctx {
     uint32_t maxCnt = 0;
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
-    DevBuf rankDen, rankClass, rankMeta, rankOut; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
+    DevBuf rankDen, rankClass, rankMeta, rankOut, rankList, rankScratch; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
     bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
     bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
@@ -4355,7 +4356,8 @@ struct RankEntry { uint32_t tax; float score; double rel; };
 __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
                                                    uint32_t nReads, const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
                                                    double thr, uint32_t beasts, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
-                                                   unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged)
+                                                   unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged,
+                                                   RankEntry *__restrict__ handOver, uint16_t *__restrict__ handKey)
 {
     // the read's hits, compacted (taxon ascending, as in the row): everything after the first pass runs out of LDS
     __shared__ uint32_t sTax[4][RANK_ROWS];
@@ -4433,7 +4435,17 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
             ++nOut;
             lastRel = bRel; lastTax = bTax;
         }
-        if (flag) nOut = 0;                                                // the host ranks this read from its full row
+        if (flag) {                                                        // rank_exact_kernel (or the host) ranks this read
+            nOut = 0;
+            if (handOver && cnt <= (uint32_t)RANK_ROWS)                        // its hits, compacted, where the row lies (16 bytes per cell)
+                for (uint32_t i = lane; i < cnt; i += 64) {
+                    const double mine = sRel[wv][i];
+                    uint32_t larger = 0;                                       // order key: hits with a larger relative score (ties share it)
+                    for (uint32_t j = 0; j < cnt; ++j) larger += (sRel[wv][j] > mine) ? 1u : 0u;
+                    handOver[lo + i] = RankEntry{sTax[wv][i], sScore[wv][i], mine};
+                    handKey[lo + i] = (uint16_t)larger;
+                }
+        }
         if (nOut > slabLeft) {                                             // uniform
             unsigned long long got = 0;
             if (lane == 0) got = atomicAdd(cursor, (unsigned long long)RANK_SLAB);
@@ -4449,6 +4461,132 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
         LDS_WAVE_SYNC();
     }
     if (lane == 0 && flaggedMine) atomicAdd(nFlagged, flaggedMine);
+}
+
+// The reads rank_kernel left: a tie among more than 16 hits inside the printed prefix (std::sort's own order decides who is
+// printed), more hits than its LDS holds, or a prefix beyond RANK_CAP.  One THREAD per such read: the hits compacted into
+// scratch that parallels the CSR (relative score, position in the row, id), libstdc++'s std::sort walked over the ids
+// (stdsort_order.h: the same comparisons and moves, so tied taxa end up where the reference leaves them), the printing
+// loops walked over the result, the prefix written out.  A read stays flagged only where std::sort would switch to its
+// heap sort or with 65 536 or more cells.
+__global__ void rank_list_kernel(const uint4 *__restrict__ meta, uint32_t nReads, uint32_t *__restrict__ list, uint32_t *__restrict__ nList)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool f = r < nReads && (meta[r].y >> 31) != 0u;
+    const unsigned long long mk = __ballot(f);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0 && mk) base = atomicAdd(nList, (uint32_t)__popcll(mk));
+    base = __shfl(base, 0);
+    if (f) list[base + (uint32_t)__popcll(mk & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
+}
+
+struct PrintWalk {                                                         // the writers' loops (Compare.hpp:1582-1594, 1721-1754), hit by hit
+    uint32_t top = 0, jJ = 0, jT = 0;
+    float beforeJ = 0.0f, beforeT = 0.0f;
+    bool topDone = false, doneJ = false, doneT = false;
+    __device__ __forceinline__ bool step(uint32_t k, float score, float maxV, uint32_t beasts)
+    {
+        bool printed = false;
+        if (!doneT) { if (jT >= beasts) doneT = true; else { printed = true; if (beforeT != score) { beforeT = score; ++jT; } } }
+        if (!topDone) {
+            if (k == 0) { top = 1; printed = true; }
+            else if (k < beasts && score / maxV > 0.8f) { ++top; printed = true; }
+            else { topDone = true; jJ = top; }
+        }
+        if (topDone && !doneJ) { if (jJ >= beasts) doneJ = true; else { printed = true; if (beforeJ != score) { beforeJ = score; ++jJ; } } }
+        return printed;
+    }
+};
+
+// One thread's column of an LDS array ([element][lane]) or a piece of global memory, indexed alike.
+struct LaneIds {
+    uint16_t *p; int stride;
+    __device__ __forceinline__ uint16_t &operator[](int i) const { return p[(size_t)i * stride]; }
+};
+static constexpr int RANK_EXACT_LANES = 64;                                 // reads per workgroup
+static constexpr size_t RANK_EXACT_SHMEM = (size_t)RANK_ROWS * RANK_EXACT_LANES * (2 + 2);
+__global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ rowOff,
+                                                        const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
+                                                        const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
+                                                        double thr, uint32_t beasts, RankEntry *__restrict__ hits, uint16_t *__restrict__ keyS,
+                                                        uint16_t *__restrict__ idS, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
+                                                        unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged)
+{
+    // The sort is a chain of dependent, scattered accesses to the read's hits: what it compares -- an order key per hit
+    // (the number of hits with a larger relative score, from rank_kernel: equal scores, equal keys) -- and the ids live in
+    // this thread's columns of two LDS arrays (from global scratch the same took 0.5 s for 3.3 M reads).  Reads with more
+    // than RANK_ROWS hits (rank_kernel handed nothing over) compact their row themselves and sort in global memory.
+    extern __shared__ unsigned char shRaw[];
+    uint16_t *shKey = reinterpret_cast<uint16_t *>(shRaw), *shId = shKey + RANK_ROWS * RANK_EXACT_LANES;
+    const uint32_t x = blockIdx.x * RANK_EXACT_LANES + threadIdx.x;
+    const int lane = threadIdx.x;
+    const bool have = x < nList;
+    uint32_t r = 0, cnt = 0, nOut = 0;
+    uint64_t lo = 0;
+    float maxV = 0.0f;
+    bool ok = false, inLds = true;
+    if (have) {
+        r = list[x];
+        lo = rowOff[r];
+        const uint4 mt = meta[r];
+        cnt = mt.w; maxV = __uint_as_float(mt.z);
+        inLds = cnt <= (uint32_t)RANK_ROWS;
+        const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
+        if (inLds) {
+            for (uint32_t i = 0; i < cnt; ++i) { shKey[(size_t)i * RANK_EXACT_LANES + lane] = keyS[lo + i]; shId[(size_t)i * RANK_EXACT_LANES + lane] = (uint16_t)i; }
+        } else if (m < 65536u) {                                           // a long row: compacted here, in place
+            const double *dr = den + (size_t)readClass[r] * nTaxa;
+            uint32_t n = 0;
+            for (uint32_t i = 0; i < m; ++i) {
+                const float sc = rowScore[lo + i];
+                const uint32_t t = rowTax[lo + i];
+                const double rel = (double)sc / dr[t];
+                if (sc > 0.0f && rel >= thr) { hits[lo + n] = RankEntry{t, sc, rel}; idS[lo + n] = (uint16_t)n; ++n; }
+            }
+        }
+        if (inLds || m < 65536u) {
+            const RankEntry *hs = hits + lo;
+            const uint16_t *ky = shKey + lane;
+            const LaneIds ids{inLds ? shId + lane : idS + lo, inLds ? RANK_EXACT_LANES : 1};
+            // only the hits a writer prints have to be in std::sort's order: the first RANK_CAP positions, as a rule
+            int covered = 0;
+            auto sortIds = [&](int need) -> bool {
+                if (inLds) return stdsort_order(ids, (int)cnt, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; }, need, &covered);
+                return stdsort_order(ids, (int)cnt, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; }, need, &covered);
+            };
+            ok = sortIds(RANK_CAP);
+            for (int pass = 0; ok && pass < 2; ++pass) {
+                PrintWalk w;                                               // how many hits a writer prints
+                bool more = false;
+                nOut = 0;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    if (k >= (uint32_t)covered) { more = true; break; }
+                    if (!w.step(k, hs[ids[(int)k]].score, maxV, beasts)) break;
+                    ++nOut;
+                }
+                if (!more) break;
+                for (uint32_t i = 0; i < cnt; ++i) ids[(int)i] = (uint16_t)i;   // it prints beyond what is final: all of it, from the start
+                ok = sortIds((int)cnt);
+            }
+        }
+    }
+    uint32_t incl = nOut;                                                  // one allocation per wavefront
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const uint32_t total = __shfl(incl, RANK_EXACT_LANES - 1);
+    unsigned long long at = 0;
+    if (lane == 0 && total) at = atomicAdd(cursor, (unsigned long long)total);
+    at = __shfl(at, 0) + incl - nOut;
+    if (have && ok) {
+        const LaneIds ids{inLds ? shId + lane : idS + lo, inLds ? RANK_EXACT_LANES : 1};
+        if (at + nOut <= cap)
+            for (uint32_t k = 0; k < nOut; ++k) entries[at + k] = hits[lo + ids[(int)k]];
+        meta[r] = make_uint4((uint32_t)at, nOut, __float_as_uint(maxV), cnt);
+    }
+    const unsigned long long left = __ballot(have && !ok);
+    if (lane == 0 && left) atomicAdd(nFlagged, (uint32_t)__popcll(left));
 }
 
 extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
@@ -4474,15 +4612,36 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         if ((rc = c->rankOut.reserve(c->rankCap * sizeof(RankEntry)))) return rc;
         HIPCHK(hipMemsetAsync(cursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
+        // reads with tied hits are handed to rank_exact_kernel: their compacted hits wait where the row lies (16 bytes per cell)
+        const bool exact = c->nnz > 0 && !(c->debugFlags & 256);           // (test tap 256: leave them to the host)
+        if (exact && (rc = c->rankScratch.reserve(c->nnz * 20 + 64))) return rc;
+        RankEntry *handOver = exact ? c->rankScratch.as<RankEntry>() : nullptr;
+        uint16_t *handKey = exact ? reinterpret_cast<uint16_t *>(handOver + c->nnz) : nullptr, *idS = handKey ? handKey + c->nnz : nullptr;
         const unsigned blocks = std::min<unsigned>(blocks_for(nReads, 4), 256u * 32u);
         rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->outTax.as<uint32_t>(), c->outScore.as<float>(), nReads,
                                                    c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
-                                                   c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged);
+                                                   c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged, handOver, handKey);
         HIPCHK(hipGetLastError());
         unsigned long long used = 0; uint32_t nf = 0;
         HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (nf > 0 && used <= c->rankCap && exact) {
+            // the reads the wavefront-per-read kernel left: std::sort's own order, one thread per read (rank_exact_kernel)
+            if ((rc = c->rankList.reserve((size_t)nf * 4 + 64))) return rc;
+            uint32_t *nList = c->misc.as<uint32_t>() + 45;
+            HIPCHK(hipMemsetAsync(nList, 0, 4, c->stream));
+            HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
+            rank_list_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rankMeta.as<uint4>(), nReads, c->rankList.as<uint32_t>(), nList);
+            HIPCHK(hipFuncSetAttribute((const void *)rank_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANK_EXACT_SHMEM));
+            rank_exact_kernel<<<blocks_for(nf, RANK_EXACT_LANES), RANK_EXACT_LANES, RANK_EXACT_SHMEM, c->stream>>>(c->rankList.as<uint32_t>(), nf, c->rowOff.as<uint64_t>(),
+                c->outTax.as<uint32_t>(), c->outScore.as<float>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
+                handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
         if (used <= c->rankCap) { c->rankEntries = used; *nEntries = used; *nFlagged = nf; return KASA_OK; }
         c->rankCap = used + used / 8 + 1024;                               // the kernel has no side effects: grow and rerun
     }

@@ -19,9 +19,15 @@
 #endif
 
 // less(x, y): the element with id x goes before the one with id y.  a[0 .. n) = the ids in input order, n < 65536.
+// need: only the positions [0, need) have to come out as std::sort leaves them (the device wants the few hits a writer
+// prints).  The partitioning leaves everything right of a cut not smaller than everything left of it, and neither the
+// sorting of a right-hand range nor the final insertion of its elements moves anything across the cut; so the ranges
+// are finished from the left and the rest is dropped once `need` positions are covered.  *covered (may be NULL) receives
+// how many leading positions are final (>= min(need, n)).
 template <class Ids, class Less>
-__host__ __device__ inline bool stdsort_order(Ids a, int n, Less less)
+__host__ __device__ inline bool stdsort_order(Ids a, int n, Less less, int need = 0x7fffffff, int *covered = nullptr)
 {
+    if (covered) *covered = n;
     if (n <= 1) return true;
     auto swap_at = [&](int x, int y) { const uint16_t t = a[x]; a[x] = a[y]; a[y] = t; };
     int lg = 0;
@@ -61,7 +67,9 @@ __host__ __device__ inline bool stdsort_order(Ids a, int n, Less less)
             ++top;
             last = lo;
         }
+        if (last >= need && last < n) { n = last; break; }             // [0, last) is partitioned into small ranges: enough
     }
+    if (covered) *covered = n;
     // one insertion sort over everything: guarded for the first 16, unguarded after (something not larger is to the left)
     auto insert_unguarded = [&](int i) {
         const uint16_t v = a[i];

@@ -36,6 +36,14 @@ int main(int argc, char **)
         if (!ok) { ++heap; continue; }
         for (int i = 0; i < n; ++i)
             if (ids[i] != (uint16_t)std::get<0>(res[i])) { std::printf("MISMATCH round %d n %d at %d\n", round, n, i); return 1; }
+        // ... and the prefix-only form: the first `need` positions, whatever is done with the rest
+        const int need = 1 + (int)(rng() % (round % 2 ? 8 : 80));
+        for (int i = 0; i < n; ++i) ids[i] = (uint16_t)i;
+        int covered = 0;
+        if (!stdsort_order(ids.data(), n, [&](uint16_t x, uint16_t y) { return rel[x] > rel[y]; }, need, &covered)) { std::printf("PREFIX gave up, round %d\n", round); return 1; }
+        if (covered < std::min(need, n)) { std::printf("PREFIX covers %d of %d, round %d\n", covered, need, round); return 1; }
+        for (int i = 0; i < covered; ++i)
+            if (ids[i] != (uint16_t)std::get<0>(res[i])) { std::printf("PREFIX MISMATCH round %d n %d need %d at %d\n", round, n, need, i); return 1; }
         ++checked;
     }
     if (argc > 1) return 0;

@@ -70,23 +70,25 @@ def test_device_rank_writes_the_hosts_text(kind):
     assert capi.device_count() > 0
     ix, batch = _world(kind)
     dix = capi.DeviceIndex(ix)
-    flagged = 0
+    flagged = handed_back = 0
     for fmt in ("json", "jsonl", "tsv", "kraken"):
         for beasts, thr in ((1, 0.0), (3, 0.0), (7, 0.03), (100, 0.0)):
             texts = []
-            for on in (True, False):
+            for mode in ("device", "device, ties to the host", "host"):
                 run = identify.Identify(ix, 0, 12, 7, 3, thr, beasts, fmt, dix=dix)
-                run.device_rank = on
+                run.device_rank = mode != "host"
+                run.ctx.debug_flags(256 if mode == "device, ties to the host" else 0)
                 text, prof, _ = run.run(batch, True)
                 texts.append((text, prof))
-                if on:
+                if mode == "device":
                     flagged += run.flagged_reads
+                if mode == "device, ties to the host":
+                    handed_back += run.flagged_reads
                 run.close()
-            assert texts[0] == texts[1], (fmt, beasts, thr)
+            assert texts[0] == texts[1] == texts[2], (fmt, beasts, thr)
+    assert flagged == 0                       # ties among more than 16 hits take std::sort's own order on the device
     if kind == "clones":
-        assert flagged > 0                    # 40 tied hits per read: the device leaves those reads to the host
-    if kind == "pairs":
-        assert flagged == 0
+        assert handed_back > 0                # 40 tied hits per read: with the test tap those reads go back to the host
     dix.close()
 
 
