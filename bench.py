@@ -309,7 +309,10 @@ def main():
         if rank == 0:
             if world == 1 and not args.no_e2e:
                 out0 = report(args, ctx, reads, ix, world, dt, wide, None)     # (stats of the timed run, before the extra pass)
-                pcie = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
+                try:                                               # an extra pass: it must never cost the headline line
+                    pcie = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
+                except Exception as ex:                            # e.g. no memory left for the page-locked buffers
+                    pcie = {"error": str(ex)[:300]}
                 out0["e2e"] = pcie
                 out = out0
             else:

@@ -190,7 +190,9 @@ int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxI
  * printed prefix, the order is std::sort's own (not stable, but deterministic): those reads are ranked by a second kernel
  * that walks libstdc++'s introsort over the hits (kasa_amd/csrc/stdsort_order.h).  flag: the read could not be ranked on
  * the device (std::sort would have switched to its heap sort, or the row has 65 536 or more cells): it gets no entries
- * and the host ranks it from its full row (kasa_batch_scores_fetch).  nFlagged counts such reads. */
+ * and the host ranks it from its full row (kasa_batch_scores_fetch).  nFlagged counts such reads.
+ * The call may use the batch's event records as scratch: kasa_batch_group has to run again before another kasa_batch_score
+ * of the same batch (the scores themselves, kasa_batch_scores_fetch, stay valid). */
 int kasa_batch_rank(kasa_ctx *ctx, const double *den, uint32_t nClasses, const uint32_t *readClass, float threshold, uint32_t beasts,
                     uint64_t *nEntries, uint32_t *nFlagged);
 int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);

@@ -4614,8 +4614,12 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
         // reads with tied hits are handed to rank_exact_kernel: their compacted hits wait where the row lies (16 bytes per cell)
         const bool exact = c->nnz > 0 && !(c->debugFlags & 256);           // (test tap 256: leave them to the host)
-        if (exact && (rc = c->rankScratch.reserve(c->nnz * 20 + 64))) return rc;
-        RankEntry *handOver = exact ? c->rankScratch.as<RankEntry>() : nullptr;
+        // (20 bytes per CSR cell.  The event records are dead once the batch is scored: their buffer serves when it is large
+        // enough -- 32 bytes per query against 20 per cell -- and the batch then has to be grouped again before another score.)
+        DevBuf *scratch = &c->rankScratch;
+        if (exact && c->rec.cap >= c->nnz * 20 + 64) { scratch = &c->rec; c->grouped = false; }
+        else if (exact && (rc = c->rankScratch.reserve(c->nnz * 20 + 64))) return rc;
+        RankEntry *handOver = exact ? scratch->as<RankEntry>() : nullptr;
         uint16_t *handKey = exact ? reinterpret_cast<uint16_t *>(handOver + c->nnz) : nullptr, *idS = handKey ? handKey + c->nnz : nullptr;
         const unsigned blocks = std::min<unsigned>(blocks_for(nReads, 4), 256u * 32u);
         rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->outTax.as<uint32_t>(), c->outScore.as<float>(), nReads,
@@ -4894,7 +4898,7 @@ __global__ __launch_bounds__(256) void record_stats_kernel(ScoreArgs A, unsigned
 extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
 {
     if (!c || !out32) return fail(KASA_E_ARG, "kasa_debug_record_stats: NULL argument");
-    if (c->state < 4 || c->recWords() != 8) return fail(KASA_E_STATE, "kasa_debug_record_stats: needs a scored batch with 32-byte records");
+    if (c->state < 4 || !c->grouped || c->recWords() != 8) return fail(KASA_E_STATE, "kasa_debug_record_stats: needs a scored batch with 32-byte records (before kasa_batch_rank)");
     HIPCHK(hipSetDevice(c->ix->device));
     DevBuf tmp;
     int rc = tmp.reserve(32 * 8);
