@@ -113,6 +113,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+struct ScopedBuf : DevBuf { ~ScopedBuf() { release(); } };   // a function's own scratch (context buffers are released by kasa_ctx_destroy)
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -491,7 +492,7 @@ struct kasa_ctx {
     StageTimer timers[KASA_STAGE_COUNT];
     StageTimer kernels[KASA_KERNEL_COUNT];      // single kernels timed alone (kasa_ctx_kernel_ms)
     uint64_t lastStaged = 0, lastKeys = 0, lastContrib = 0;   // of the last batch: staging records, profile keys, (event, taxon) contributions
-    std::vector<int64_t> hostOff;
+    DevBuf rawOff;                             // the caller's sequence offsets as uploaded
 };
 
 static int timer_begin(kasa_ctx *c, StageTimer &t, hipEvent_t *a, hipEvent_t *b)
@@ -602,7 +603,8 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                      &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
-                     &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo};
+                     &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
+                     &c->rawOff, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
         for (auto &pr : t.open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -649,9 +651,41 @@ __host__ __device__ static inline void enc_geometry(int mode, int KL, int kLow, 
     else cnt = (L > 3 * K + 1) ? L - 3 * K + 1 : 0;
 }
 
+// k-mers of every sequence (enc_geometry) and read, offsets relative to the batch, checks: what the encoder's tables are
+// made of.  raw[] = the caller's offsets as uploaded.  err: bit 0 offsets not ascending, bit 1 bad read id; errAt: where.
+__global__ void upload_geometry_kernel(const int64_t *__restrict__ raw, int64_t nSeq, const uint32_t *__restrict__ seqRead, int64_t nReads,
+                                       int mode, int KL, int kLow, int strands, int64_t *__restrict__ baseOff, uint64_t *__restrict__ seqCnt,
+                                       uint64_t *__restrict__ readCnt, uint32_t *__restrict__ err, unsigned long long *__restrict__ errAt,
+                                       uint32_t *__restrict__ maxCnt)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nSeq) return;
+    baseOff[s] = raw[s] - raw[0];
+    if (s == nSeq) { seqCnt[s] = 0; return; }
+    const int64_t len = raw[s + 1] - raw[s];
+    const uint32_t r = seqRead ? seqRead[s] : (uint32_t)s;
+    const uint32_t prev = s > 0 ? (seqRead ? seqRead[s - 1] : (uint32_t)(s - 1)) : 0u;
+    if (len < 0) { atomicOr(err, 1u); atomicMin(errAt, (unsigned long long)s); seqCnt[s] = 0; return; }
+    if ((int64_t)r >= nReads || r < prev) { atomicOr(err, 2u); atomicMin(errAt + 1, (unsigned long long)s); seqCnt[s] = 0; return; }
+    int64_t body, L, perStrand = 0;
+    if (len > 0) enc_geometry(mode, KL, kLow, len, body, L, perStrand);
+    const uint64_t cnt = (uint64_t)perStrand * (uint64_t)strands;
+    seqCnt[s] = cnt;
+    if (seqRead) atomicAdd((unsigned long long *)&readCnt[r], (unsigned long long)cnt);   // the mates of a pair share a read
+    else readCnt[r] = cnt;
+}
+__global__ void upload_max_kernel(const uint64_t *__restrict__ readCnt, int64_t nReads, uint32_t *__restrict__ maxCnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = r < nReads ? (uint32_t)(readCnt[r] < 0xFFFFFFFFull ? readCnt[r] : 0xFFFFFFFFull) : 0u;
+    for (int off = 32; off; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(maxCnt, v);
+}
+
 // nSeq sequences (offsets[nSeq+1]); seqRead[s] = read the sequence belongs to (ascending; NULL: sequence s is read s).
 // Paired-end input hands both mates of a pair over as two sequences of one read (Read.hpp:834-1049): their k-mers
-// carry the same read id, none spans the junction.
+// carry the same read id, none spans the junction.  The host only copies: the tables (offsets relative to the batch,
+// k-mers before every sequence and read) are made on the device -- the host loop over ten million reads took 0.1 s.
 static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSeq, const uint32_t *seqRead, int64_t nReads)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
@@ -659,74 +693,50 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
     c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
-    const uint64_t nBases = nSeq ? (uint64_t)(offsets[nSeq] - offsets[0]) : 0;
-    std::vector<uint64_t> soff((size_t)nSeq + 1), koff((size_t)nReads + 1, 0);
-    c->hostOff.assign((size_t)nSeq + 1, 0);
-    uint64_t run = 0;
-    const int mode = c->enc_mode();
-    const int strands = c->strands();
-    // k-mers per sequence: by several host threads for large batches (ten million reads take 0.1 s on one)
-    {
-        const unsigned nThreads = nSeq >= (1 << 18) ? std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1u;
-        std::vector<int> bad(nThreads, 0);
-        std::vector<int64_t> badAt(nThreads, -1);
-        auto work = [&](unsigned th) {
-            const int64_t a = nSeq * (int64_t)th / nThreads, b = nSeq * (int64_t)(th + 1) / nThreads;
-            uint32_t prevRead = a > 0 ? (seqRead ? seqRead[a - 1] : (uint32_t)(a - 1)) : 0u;
-            for (int64_t s = a; s < b; ++s) {
-                const int64_t raw = offsets[s + 1] - offsets[s];
-                const uint32_t r = seqRead ? seqRead[s] : (uint32_t)s;
-                if (raw < 0) { bad[th] = 1; badAt[th] = s; return; }
-                if ((int64_t)r >= nReads || r < prevRead) { bad[th] = 2; badAt[th] = s; return; }
-                prevRead = r;
-                c->hostOff[(size_t)s] = offsets[s] - offsets[0];
-                int64_t body, L, perStrand = 0;
-                if (raw > 0) enc_geometry(mode, c->K(), c->kLow, raw, body, L, perStrand);
-                soff[(size_t)s] = (uint64_t)perStrand * strands;       // count; turned into a running sum below
-            }
-        };
-        if (nThreads == 1) work(0);
-        else {
-            std::vector<std::thread> pool;
-            for (unsigned th = 0; th < nThreads; ++th) pool.emplace_back(work, th);
-            for (auto &th : pool) th.join();
-        }
-        for (unsigned th = 0; th < nThreads; ++th) {
-            if (bad[th] == 1) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
-            if (bad[th] == 2) {
-                const int64_t sq = badAt[th];
-                return fail(KASA_E_ARG, "kasa_batch_upload: sequence %lld names read %u (reads: %lld, ids must ascend)", (long long)sq, seqRead ? seqRead[sq] : (uint32_t)sq, (long long)nReads);
-            }
-        }
-    }
-    for (int64_t s = 0; s < nSeq; ++s) {
-        const uint64_t cnt = soff[(size_t)s];
-        const uint32_t r = seqRead ? seqRead[s] : (uint32_t)s;
-        soff[(size_t)s] = run;
-        run += cnt;
-        koff[(size_t)r + 1] += cnt;
-    }
-    soff[(size_t)nSeq] = run;
-    uint32_t maxCnt = 0;
-    for (int64_t r = 0; r < nReads; ++r) {
-        maxCnt = (uint32_t)std::max<uint64_t>(maxCnt, std::min<uint64_t>(koff[(size_t)r + 1], 0xFFFFFFFFull));
-        koff[(size_t)r + 1] += koff[(size_t)r];
-    }
-    c->hostOff[(size_t)nSeq] = (int64_t)nBases;
-    if (run >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: %llu k-mers exceed the 32-bit position range of one batch; split the batch", (unsigned long long)run);
-    c->nQ = run; c->nBases = nBases; c->maxCnt = maxCnt;
+    const int64_t zero = 0;
+    if (nSeq == 0) offsets = &zero;
+    if (offsets[nSeq] < offsets[0]) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
+    const uint64_t nBases = (uint64_t)(offsets[nSeq] - offsets[0]);
     int rc;
     if ((rc = c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nSeq + 1) * 8)) ||
         (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)) || (rc = c->seqOff.reserve(((size_t)nSeq + 1) * 8)) ||
-        (rc = c->seqRead.reserve((size_t)nSeq * 4 + 64)))
+        (rc = c->seqRead.reserve((size_t)nSeq * 4 + 64)) || (rc = c->rawOff.reserve(((size_t)nSeq + 1) * 8)))
         return rc;
     if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->baseOff.p, c->hostOff.data(), ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->kmerOff.p, koff.data(), ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->seqOff.p, soff.data(), ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->rawOff.p, offsets, ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     c->haveSeqRead = seqRead != nullptr;
     if (seqRead && nSeq) HIPCHK(hipMemcpyAsync(c->seqRead.p, seqRead, (size_t)nSeq * 4, hipMemcpyHostToDevice, c->stream));
+    // device: counts, checks, running sums
+    uint32_t *flags = c->misc.as<uint32_t>() + 46;                      // [46] error bits, [47] most k-mers of a read
+    unsigned long long *errAt = c->misc.as<unsigned long long>() + 24;  // [24], [25]: first offending sequence per error
+    HIPCHK(hipMemsetAsync(flags, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(errAt, 0xFF, 16, c->stream));
+    uint64_t *seqCnt = c->seqOff.as<uint64_t>(), *readCnt = c->kmerOff.as<uint64_t>();
+    HIPCHK(hipMemsetAsync(readCnt, 0, ((size_t)nReads + 1) * 8, c->stream));
+    upload_geometry_kernel<<<blocks_for((uint64_t)nSeq + 1, 256), 256, 0, c->stream>>>(c->rawOff.as<int64_t>(), nSeq, seqRead ? c->seqRead.as<uint32_t>() : nullptr, nReads,
+        c->enc_mode(), c->K(), c->kLow, c->strands(), c->baseOff.as<int64_t>(), seqCnt, readCnt, flags, errAt, flags + 1);
+    HIPCHK(hipGetLastError());
+    if (nReads) upload_max_kernel<<<blocks_for((uint64_t)nReads, 256), 256, 0, c->stream>>>(readCnt, nReads, flags + 1);
+    size_t tmpBytes = 0, tmp2 = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, seqCnt, seqCnt, (uint64_t)0, (size_t)nSeq + 1, rocprim::plus<uint64_t>(), c->stream));
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmp2, readCnt, readCnt, (uint64_t)0, (size_t)nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+    if ((rc = c->sortTmp.reserve(std::max(tmpBytes, tmp2)))) return rc;
+    HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, seqCnt, seqCnt, (uint64_t)0, (size_t)nSeq + 1, rocprim::plus<uint64_t>(), c->stream));
+    HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmp2, readCnt, readCnt, (uint64_t)0, (size_t)nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+    uint32_t hFlags[2] = {0, 0};
+    unsigned long long hAt[2] = {0, 0};
+    uint64_t run = 0;
+    HIPCHK(hipMemcpyAsync(hFlags, flags, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hAt, errAt, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&run, seqCnt + nSeq, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (hFlags[0] & 1u) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
+    if (hFlags[0] & 2u) {
+        const int64_t sq = (int64_t)hAt[1];
+        return fail(KASA_E_ARG, "kasa_batch_upload: sequence %lld names read %u (reads: %lld, ids must ascend)", (long long)sq, seqRead ? seqRead[sq] : (uint32_t)sq, (long long)nReads);
+    }
+    if (run >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: %llu k-mers exceed the 32-bit position range of one batch; split the batch", (unsigned long long)run);
+    c->nQ = run; c->nBases = nBases; c->maxCnt = hFlags[1];
     c->state = 1;
     return KASA_OK;
 }
@@ -4220,7 +4230,7 @@ extern "C" int kasa_batch_slice_starts(kasa_ctx *c, const uint64_t *cuts, uint32
     if (!c || !cuts || !starts || nParts == 0) return fail(KASA_E_ARG, "kasa_batch_slice_starts: bad arguments");
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_slice_starts: batch not sorted");
     HIPCHK(hipSetDevice(c->ix->device));
-    DevBuf tmp;
+    ScopedBuf tmp;
     int rc = tmp.reserve(((size_t)nParts * 2 + 1) * 8);
     if (rc) return rc;
     uint64_t *dCuts = tmp.as<uint64_t>(), *dStarts = dCuts + nParts;
@@ -4900,7 +4910,7 @@ extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
     if (!c || !out32) return fail(KASA_E_ARG, "kasa_debug_record_stats: NULL argument");
     if (c->state < 4 || !c->grouped || c->recWords() != 8) return fail(KASA_E_STATE, "kasa_debug_record_stats: needs a scored batch with 32-byte records (before kasa_batch_rank)");
     HIPCHK(hipSetDevice(c->ix->device));
-    DevBuf tmp;
+    ScopedBuf tmp;
     int rc = tmp.reserve(32 * 8);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(tmp.p, 0, 32 * 8, c->stream));
@@ -5008,7 +5018,8 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                            &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
-                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllMid, &c->cntAllLo};
+                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
+                           &c->rawOff, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;
