@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=300_000)
     ap.add_argument("--fmt", default="--jsonl")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--memory", type=int, default=0, help="-m <GiB> of the driver (the reference's batch budget; 0 = its default 5)")
     args = ap.parse_args()
     import numpy as np
     from kasa_amd import build, formats, synth
@@ -42,11 +43,19 @@ def main():
            "-q", os.path.join(d, "out.txt"), "-p", os.path.join(d, "prof.csv"), args.fmt, "-v"]
     if args.threads:
         cmd += ["-n", str(args.threads)]
+    if args.memory:
+        cmd += ["-m", str(args.memory)]
+    import resource
     t0 = time.perf_counter()
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     dt = time.perf_counter() - t0
-    print(r.stdout[-1500:])
-    print("driver: %.2f s wall for %d reads = %.0f reads/s; output %d MB" % (dt, args.reads, args.reads / dt, os.path.getsize(os.path.join(d, "out.txt")) >> 20))
+    lines = r.stdout.splitlines()
+    print("\n".join(lines[:4] + ["... %d batches ..." % sum(1 for l in lines if l.startswith("OUT: Batch of "))] + [l for l in lines[-8:] if not l.startswith("OUT: Batch of ")]))
+    rss = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / (1 << 20)
+    print("driver: %.2f s wall for %d reads = %.0f reads/s; output %d MB; largest resident set of the driver %.1f GB (input file %.1f GB)"
+          % (dt, args.reads, args.reads / dt, os.path.getsize(os.path.join(d, "out.txt")) >> 20, rss, os.path.getsize(os.path.join(d, "reads.fastq")) / (1 << 30)))
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
 
 
 if __name__ == "__main__":
