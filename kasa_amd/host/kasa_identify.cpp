@@ -739,10 +739,15 @@ template <class T> struct PcieBuf {
     PcieBuf(const PcieBuf &) = delete;
     PcieBuf &operator=(const PcieBuf &) = delete;
     ~PcieBuf() { release(); }
-    void release() { if (p) { if (pinned) kasa_host_free(p); else std::free(p); } p = nullptr; n = 0; }
+    void release() { if (p) { if (pinned) kasa_host_free(p); else std::free(p); } p = nullptr; n = 0; capacity = 0; }
+    size_t capacity = 0;
+    // grow-only: page-locking memory costs more than the transfer it speeds up, so a worker keeps its buffers over the batches
     void resize(size_t count)
     {
+        if (count <= capacity && p) { n = count; return; }
         release();
+        count += count / 8;
+        capacity = count;
         n = count;
         const size_t bytes = std::max<size_t>(1, count * sizeof(T));
         p = (T *)kasa_host_alloc(bytes);
@@ -883,7 +888,13 @@ struct Batcher {
 
 // Everything one device does for one batch: upload -> encode -> sort -> lookup/score on the device (the calls
 // CompareWithLib_partialSort makes per batch, Compare.hpp:3107-3310), CSR back, ranking + text by all host threads (N2).
-static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText)
+// what crosses PCIe for one worker (device): kept over its batches
+struct WorkerBuffers {
+    PcieBuf<uint32_t> meta; PcieBuf<Writer::DeviceHit> hits;
+    PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
+};
+
+static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb)
 {
     const auto tDev = std::chrono::steady_clock::now();
     auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -899,7 +910,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     // Ranking on the device (kasa_batch_rank): the host supplies libm's denominators, one row per distinct read length,
     // and gets back only what the writer can print; the full rows come back when the device flags a read (a tie under
     // std::sort's unstable regime) or when there are too many distinct lengths for a table.
-    PcieBuf<uint32_t> meta; PcieBuf<Writer::DeviceHit> hits;
+    PcieBuf<uint32_t> &meta = wb.meta; PcieBuf<Writer::DeviceHit> &hits = wb.hits;
     uint32_t nFlagged = 0;
     bool deviceRank = nr > 0 && !p.hostRank;
     if (deviceRank) {
@@ -924,7 +935,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
             if (kasa_batch_rank_fetch(ctx, meta.data(), hits.data())) throwLast();
         }
     }
-    PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
+    PcieBuf<uint64_t> &ro = wb.ro; PcieBuf<uint32_t> &tx = wb.tx; PcieBuf<float> &sc = wb.sc;
     if (!deviceRank || nFlagged) {
         uint64_t nnz = 0;
         if (kasa_batch_scores_size(ctx, &nnz)) throwLast();
@@ -1018,6 +1029,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     std::atomic<uint64_t> totalKmers{0};
     auto worker = [&](size_t d) {
         try {
+            WorkerBuffers wb;
             for (;;) {
                 std::unique_ptr<Batch> b;
                 {
@@ -1027,7 +1039,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
                     b = std::move(todo.front()); todo.pop_front();
                     cvSpace.notify_all();
                 }
-                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d]);
+                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d], wb);
                 totalKmers += b->kmers;
                 b->rs = ReadSet();                                   // the reads are done with
                 std::lock_guard<std::mutex> lk(mu);
