@@ -132,3 +132,26 @@ def test_cpp_host_device_rank_equals_host_rank(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+@pytest.mark.parametrize("kind", ["clones", "crowd"])
+def test_cpp_host_ties_follow_std_sort(kind, tmp_path):
+    """The C++ driver ranks with the real std::sort under --host-rank and with the device's restatement of it by default:
+    on inputs full of tied hits (40 identical genomes; 300 taxa around one root) the files must be the same bytes."""
+    exe = hipbuild.build_host()
+    ix, batch = _world(kind)
+    formats.write_index(ix, str(tmp_path / "idx"), str(tmp_path / "content.txt"))
+    with open(tmp_path / "reads.fastq", "wb") as f:
+        for r in range(batch.n):
+            seq = batch.bases[int(batch.offsets[r]):int(batch.offsets[r + 1])].tobytes()
+            f.write(b"@" + batch.names[r].rstrip().encode() + b"\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n")
+    for fmt, flag in (("jsonl", "--jsonl"), ("tsv", "--tsv")):
+        outs = []
+        for extra in ([], ["--host-rank"]):
+            out = str(tmp_path / ("out_%s_%d" % (fmt, len(outs))))
+            cmd = [exe, "identify", "-c", str(tmp_path / "content.txt"), "-d", str(tmp_path / "idx"), "-i", str(tmp_path / "reads.fastq"),
+                   "-q", out, "-p", str(tmp_path / "prof.csv"), flag, "-b", "5", "-n", "2"] + extra
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr
+            outs.append(open(out, "rb").read())
+        assert outs[0] == outs[1] and len(outs[0]) > 1000, fmt
