@@ -356,17 +356,30 @@ static ReadSet readInput(const string &path, bool verbose, unsigned threads)
 // boundary; a chunk is parsed by all host threads (parseRecords over runs cut at safe record starts).
 struct ChunkReader {
     gzFile g = nullptr;
+    int fd = -1;                                  // plain (not gzip'ed) input is read with read(2): zlib's pass-through copies at 1 GB/s
     string carry;
     bool fasta = false, protein = false, eof = false, first = true;
     size_t blockBytes = 64u << 20;
     explicit ChunkReader(const string &path)
     {
-        g = gzopen(path.c_str(), "rb");
-        if (!g) throw std::runtime_error("Input file not found");
-        gzbuffer(g, 1u << 20);
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("Input file not found");
+        unsigned char magic[2] = {0, 0};
+        const ssize_t m = ::pread(fd, magic, 2, 0);
+        if (m == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            g = gzdopen(fd, "rb");                 // takes the descriptor over
+            if (!g) { ::close(fd); fd = -1; throw std::runtime_error("Input file not found"); }
+            fd = -1;
+            gzbuffer(g, 1u << 20);
+        }
         if (const char *e = getenv("KASA_READ_BLOCK")) blockBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small blocks
     }
-    ~ChunkReader() { if (g) gzclose(g); }
+    ~ChunkReader() { if (g) gzclose(g); if (fd >= 0) ::close(fd); }
+    long readSome(char *dst, size_t want)
+    {
+        if (g) return gzread(g, dst, (unsigned)std::min<size_t>(want, 1u << 30));
+        return (long)::read(fd, dst, std::min<size_t>(want, 1u << 30));
+    }
     // next chunk of whole records ("" at the end of the file)
     bool next(string &chunk, bool verbose)
     {
@@ -378,7 +391,7 @@ struct ChunkReader {
             data.resize(had + blockBytes);
             size_t got = 0;
             while (got < blockBytes) {
-                const int n = gzread(g, &data[had + got], (unsigned)std::min<size_t>(blockBytes - got, 1u << 30));
+                const long n = readSome(&data[had + got], blockBytes - got);
                 if (n <= 0) { eof = true; break; }
                 got += (size_t)n;
             }
