@@ -4479,15 +4479,22 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
 // (stdsort_order.h: the same comparisons and moves, so tied taxa end up where the reference leaves them), the printing
 // loops walked over the result, the prefix written out.  A read stays flagged only where std::sort would switch to its
 // heap sort or with 65 536 or more cells.
-__global__ void rank_list_kernel(const uint4 *__restrict__ meta, uint32_t nReads, uint32_t *__restrict__ list, uint32_t *__restrict__ nList)
+__global__ void rank_list_kernel(const uint4 *__restrict__ meta, uint32_t nReads, uint32_t *__restrict__ list, uint32_t *__restrict__ listKey,
+                                 uint32_t *__restrict__ nList)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool f = r < nReads && (meta[r].y >> 31) != 0u;
+    uint4 mt = make_uint4(0, 0, 0, 0);
+    if (r < nReads) mt = meta[r];
+    const bool f = r < nReads && (mt.y >> 31) != 0u;
     const unsigned long long mk = __ballot(f);
     uint32_t base = 0;
     if ((threadIdx.x & 63) == 0 && mk) base = atomicAdd(nList, (uint32_t)__popcll(mk));
     base = __shfl(base, 0);
-    if (f) list[base + (uint32_t)__popcll(mk & ((1ull << (threadIdx.x & 63)) - 1ull))] = r;
+    if (f) {
+        const uint32_t at = base + (uint32_t)__popcll(mk & ((1ull << (threadIdx.x & 63)) - 1ull));
+        list[at] = r;
+        listKey[at] = mt.w < 0xFFFFu ? mt.w : 0xFFFFu;                     // its number of hits: the list is sorted by it (lanes of a wavefront do alike)
+    }
 }
 
 struct PrintWalk {                                                         // the writers' loops (Compare.hpp:1582-1594, 1721-1754), hit by hit
@@ -4556,28 +4563,30 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
         }
         if (inLds || m < 65536u) {
             const RankEntry *hs = hits + lo;
-            const uint16_t *ky = shKey + lane;
-            const LaneIds ids{inLds ? shId + lane : idS + lo, inLds ? RANK_EXACT_LANES : 1};
-            // only the hits a writer prints have to be in std::sort's order: the first RANK_CAP positions, as a rule
-            int covered = 0;
-            auto sortIds = [&](int need) -> bool {
-                if (inLds) return stdsort_order(ids, (int)cnt, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; }, need, &covered);
-                return stdsort_order(ids, (int)cnt, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; }, need, &covered);
-            };
-            ok = sortIds(RANK_CAP);
-            for (int pass = 0; ok && pass < 2; ++pass) {
-                PrintWalk w;                                               // how many hits a writer prints
-                bool more = false;
-                nOut = 0;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    if (k >= (uint32_t)covered) { more = true; break; }
-                    if (!w.step(k, hs[ids[(int)k]].score, maxV, beasts)) break;
-                    ++nOut;
+            // only the hits a writer prints have to be in std::sort's order: the first RANK_CAP positions, as a rule.
+            // (Two instantiations, so that the LDS columns are reached with LDS instructions, not through flat pointers.)
+            auto rankRead = [&](auto ids, auto less) {
+                int covered = 0;
+                ok = stdsort_order(ids, (int)cnt, less, RANK_CAP, &covered);
+                for (int pass = 0; ok && pass < 2; ++pass) {
+                    PrintWalk w;                                           // how many hits a writer prints
+                    bool more = false;
+                    nOut = 0;
+                    for (uint32_t k = 0; k < cnt; ++k) {
+                        if (k >= (uint32_t)covered) { more = true; break; }
+                        if (!w.step(k, hs[ids[(int)k]].score, maxV, beasts)) break;
+                        ++nOut;
+                    }
+                    if (!more) break;
+                    for (uint32_t i = 0; i < cnt; ++i) ids[(int)i] = (uint16_t)i;   // it prints beyond what is final: all of it, from the start
+                    ok = stdsort_order(ids, (int)cnt, less, (int)cnt, &covered);
                 }
-                if (!more) break;
-                for (uint32_t i = 0; i < cnt; ++i) ids[(int)i] = (uint16_t)i;   // it prints beyond what is final: all of it, from the start
-                ok = sortIds((int)cnt);
-            }
+            };
+            if (inLds) {
+                const uint16_t *ky = shKey + lane;
+                rankRead(LaneIds{shId + lane, RANK_EXACT_LANES}, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; });
+            } else
+                rankRead(LaneIds{idS + lo, 1}, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; });
         }
     }
     uint32_t incl = nOut;                                                  // one allocation per wavefront
@@ -4590,9 +4599,8 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
     if (lane == 0 && total) at = atomicAdd(cursor, (unsigned long long)total);
     at = __shfl(at, 0) + incl - nOut;
     if (have && ok) {
-        const LaneIds ids{inLds ? shId + lane : idS + lo, inLds ? RANK_EXACT_LANES : 1};
         if (at + nOut <= cap)
-            for (uint32_t k = 0; k < nOut; ++k) entries[at + k] = hits[lo + ids[(int)k]];
+            for (uint32_t k = 0; k < nOut; ++k) entries[at + k] = hits[lo + (inLds ? shId[(size_t)k * RANK_EXACT_LANES + lane] : idS[lo + k])];
         meta[r] = make_uint4((uint32_t)at, nOut, __float_as_uint(maxV), cnt);
     }
     const unsigned long long left = __ballot(have && !ok);
@@ -4642,13 +4650,20 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         HIPCHK(hipStreamSynchronize(c->stream));
         if (nf > 0 && used <= c->rankCap && exact) {
             // the reads the wavefront-per-read kernel left: std::sort's own order, one thread per read (rank_exact_kernel)
-            if ((rc = c->rankList.reserve((size_t)nf * 4 + 64))) return rc;
+            if ((rc = c->rankList.reserve((size_t)nf * 16 + 64))) return rc;
+            uint32_t *list0 = c->rankList.as<uint32_t>(), *key0 = list0 + nf, *list1 = key0 + nf, *key1 = list1 + nf;
             uint32_t *nList = c->misc.as<uint32_t>() + 45;
             HIPCHK(hipMemsetAsync(nList, 0, 4, c->stream));
             HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
-            rank_list_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rankMeta.as<uint4>(), nReads, c->rankList.as<uint32_t>(), nList);
+            rank_list_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rankMeta.as<uint4>(), nReads, list0, key0, nList);
+            {
+                size_t tmpBytes = 0;
+                HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, key0, key1, list0, list1, (size_t)nf, 0u, 16u, c->stream));
+                if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
+                HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, key0, key1, list0, list1, (size_t)nf, 0u, 16u, c->stream));
+            }
             HIPCHK(hipFuncSetAttribute((const void *)rank_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANK_EXACT_SHMEM));
-            rank_exact_kernel<<<blocks_for(nf, RANK_EXACT_LANES), RANK_EXACT_LANES, RANK_EXACT_SHMEM, c->stream>>>(c->rankList.as<uint32_t>(), nf, c->rowOff.as<uint64_t>(),
+            rank_exact_kernel<<<blocks_for(nf, RANK_EXACT_LANES), RANK_EXACT_LANES, RANK_EXACT_SHMEM, c->stream>>>(list1, nf, c->rowOff.as<uint64_t>(),
                 c->outTax.as<uint32_t>(), c->outScore.as<float>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
                 handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged);
             HIPCHK(hipGetLastError());
