@@ -29,7 +29,7 @@ s = s[:i] + (f"PCIe-inclusive (`e2e`, never `value`): page-locked reads up, devi
     f"down = {e['pcie_inclusive_s_per_batch']:.2f} s per batch = **{e['pcie_inclusive_reads_per_s']/1e6:.1f} M reads/s** (round 1: 6.2 M). Of that {e['upload_and_device_s']:.2f} s are upload + device\n"
     f"(the offset tables of the batch are made on the device) and {e['rank_and_fetch_s']:.2f} s ranking + {e['downloaded_bytes']/1e9:.2f} GB of hits; {e['reads_ranked_by_host']} reads go back to the\n"
     "host. All 1400 synthetic taxa have the same k-mer frequency, so a third of the reads have tied third-best hits and take\n"
-    "the `std::sort`-order kernel (72 of the 100 ms of ranking); indices with real frequencies have next to no such ties. The\n"
+    "the `std::sort`-order kernel (about half of the ranking time); indices with real frequencies have next to no such ties. The\n"
     f"round-1 path (whole CSR into pageable memory) takes {e['csr_download_s_per_batch']:.2f} s. With 0.7 GB instead of 9.5 GB crossing PCIe, a second\n"
     "stream for the transfers would hide ~40 ms of 400: not built.\n\n") + s[j:]
 s = re.sub(r"Next, in order of what the step time says \(score \d+ / sort \d+ / group \d+ / encode \d+ ms\):", f"Next, in order of what the step time says (score {st['score']:.0f} / sort {st['sort']:.0f} / group {st['group']:.0f} / encode {st['encode']:.0f} ms):", s)
