@@ -2440,13 +2440,17 @@ template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t level
     return (RW == 8 && pc <= 2u && !saturated) ? (pc ? 1u : 0u) : pc;
 }
 
-template <int RW, bool PERREAD>
+// FB: bits of a hit counter.  16 by default; 8 when no read of the batch has more than 255 k-mers (narrow records): the LDS
+// counters are what limits the resident wavefronts of this kernel, and it runs faster the more there are (26 ms at 16 per
+// CU, 40 at 8).
+template <int RW, bool PERREAD, int FB = 16>
 __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
     constexpr int NL = RT::LEVELS, OB = RT::OBITS;
-    typedef typename std::conditional<RW == 8, unsigned long long, uint32_t>::type Counter;   // 16-bit hit counters per |T|: 4 (2) fields
+    typedef typename std::conditional<RW == 8 && FB == 16, unsigned long long, uint32_t>::type Counter;   // hit counters per |T|: 4 (wide records: 2) fields of FB bits
     constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
+    constexpr uint32_t FMASK = (1u << FB) - 1u;
     __shared__ Counter cnt[FTA * NL][64];
     __shared__ float sTab[NL][8];                                    // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
@@ -2481,7 +2485,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         if (active) {
             o0 = A.kmerOff[r];
             cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
-            if (cnt0 > 60000u) { fb = true; atomicAdd(&A.why[0], 1u); }       // 16-bit counters
+            if (cnt0 > (FB == 16 ? 60000u : 255u)) { fb = true; atomicAdd(&A.why[0], 1u); }   // the counters' fields
             rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
             // ---- A. the taxa that get the register slots: the first two with a deep match (segments come in descending
             // order of their last level: the search of a query ends at the first shallow one)
@@ -2620,7 +2624,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                         mS1 = __fadd_rn(mS1, in1 ? s : 0.0f);
                     }
                     if (n <= CNT_FIELDS) {
-                        const Counter one = (Counter)1 << (16 * (n - 1u));
+                        const Counter one = (Counter)1 << (FB * (n - 1u));
                         cnt[lv][lane] += in0 ? one : (Counter)0;
                         cnt[NL + lv][lane] += in1 ? one : (Counter)0;
                     } else { nOther += in0 + in1; nKeys += in0 + in1; }       // a profile record, written by score_other_kernel
@@ -2634,7 +2638,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
             for (int e = 0; e < na; ++e)
                 for (int lv = 0; lv < nK; ++lv) {
                     const unsigned long long pk = cnt[e * NL + lv][lane];
-                    nprof += ((pk & 0xFFFFull) != 0) + (((pk >> 16) & 0xFFFFull) != 0) + (((pk >> 32) & 0xFFFFull) != 0) + ((pk >> 48) != 0);   // the upper fields are 0 with 2-field counters
+                    for (uint32_t q = 0; q < CNT_FIELDS; ++q) nprof += ((pk >> (FB * q)) & FMASK) != 0 ? 1u : 0u;
                 }
         const uint32_t nFinal = PERREAD ? (uint32_t)na : 0u;
         if (active && !fb && nFinal + nprof + nOther > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge handles
@@ -2675,8 +2679,8 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                         const uint32_t t = (e == 0) ? mTax0 : mTax1;
                         for (int lv = 0; lv < nK; ++lv) {
                             const unsigned long long pk = cnt[e * NL + lv][lane];
-                            for (uint32_t q = 0; q < 4; ++q) {
-                                const uint32_t cq = (uint32_t)((pk >> (16 * q)) & 0xFFFFull);
+                            for (uint32_t q = 0; q < CNT_FIELDS; ++q) {
+                                const uint32_t cq = (uint32_t)((pk >> (FB * q)) & FMASK);
                                 if (cq) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | RK_PROFILE, ((q + 1) << 16) | cq);
                             }
                         }
@@ -3873,7 +3877,9 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (fast) {
             // persistent wavefronts: as many as are resident at once, each takes 64 reads at a time from a work counter
             int perCu = 0, nCu = 0;
-            const void *kern = RW == 8 ? (wantPerRead ? (const void *)score_main_kernel<8, true> : (const void *)score_main_kernel<8, false>)
+            const bool fb8 = RW == 8 && c->maxCnt <= 255u;                   // 8-bit counter fields: twice the wavefronts per CU
+            const void *kern = RW == 8 ? (fb8 ? (wantPerRead ? (const void *)score_main_kernel<8, true, 8> : (const void *)score_main_kernel<8, false, 8>)
+                                              : (wantPerRead ? (const void *)score_main_kernel<8, true> : (const void *)score_main_kernel<8, false>))
                                        : (wantPerRead ? (const void *)score_main_kernel<16, true> : (const void *)score_main_kernel<16, false>);
             HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, 64, 0));
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
@@ -3887,7 +3893,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const unsigned oblocks = std::min<unsigned>(blocks_for(nQ, 256), 256u * 64u);
             hipEvent_t ka, kb;
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_MAIN], &ka, &kb))) return rc;
-            if (wantPerRead) { if (RW == 8) score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); }
+            if (fb8) { if (wantPerRead) score_main_kernel<8, true, 8><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<8, false, 8><<<fblocks, 64, 0, c->stream>>>(A); }
+            else if (wantPerRead) { if (RW == 8) score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); }
             else { if (RW == 8) score_main_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A); }
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_MAIN], ka, kb))) return rc;
