@@ -86,11 +86,35 @@ def launch_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # rank 0's line is collected by a reader thread; the launcher polls: a rank that dies (OOM, RCCL init) would leave the
+    # others blocked in a collective for ever -- then the rest is ended and its exit code returned
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("KASA_BENCH_TIMEOUT_S", "3000"))
+    failed = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = abs(bad[0]) if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return failed
 
 
 def measure(args, ctx, reads, ix, world, dist, share, wide, torch, kdist):

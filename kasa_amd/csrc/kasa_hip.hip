@@ -840,7 +840,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                     for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
-                    if (rankSlots) sKey[wv][s * (int)cnt + i] = v;         // (one chunk per strand: cnt <= ENC_RANK_MAX)
+                    if (rankSlots) sKey[wv][s * (int)cnt + (int)w0 + i] = v;   // (--one: several chunks per strand; strands * cnt <= ENC_RANK_MAX)
                     else outRead[o] = rid;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(256) void bucket_rank32_kernel(const uint64_t *__re
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 if (!open) continue;
-                if (i0 + 1u + b0 + j >= win) { edge = hi < n; open = false; continue; }
+                if (i0 + 1u + b0 + j >= win) { edge = edge || (hi < n); open = false; continue; }   // (never clears what the left scan found)
                 if (w[j] >> 31) { open = false; continue; }
                 ++R; rank += ((w[j] & lowMask) < myLow) ? 1u : 0u;
             }
@@ -4273,6 +4273,11 @@ extern "C" int kasa_batch_records_device(kasa_ctx *c, const uint32_t **records, 
     if (!c || !records || !nRecordWords || !pool || !nPoolWords) return fail(KASA_E_ARG, "kasa_batch_records_device: NULL argument");
     if (!c->grouped || !c->recSorted) return fail(KASA_E_STATE, "kasa_batch_records_device: no exported event records (call kasa_batch_group)");
     HIPCHK(hipSetDevice(c->ix->device));
+    if (!c->pool.p) {                                                     // an empty slice never reserved the pool: word 0 (never referenced) must still exist
+        int rc = c->pool.reserve(64);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->pool.p, 0, 64, c->stream));
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     *records = c->rec.as<uint32_t>(); *nRecordWords = c->nQ * (uint64_t)c->recWords();
     *pool = c->pool.as<uint32_t>(); *nPoolWords = c->poolUsed;
@@ -4633,7 +4638,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
     if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1 << 20, (uint64_t)nReads * 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u);
     c->rankEntries = 0; *nEntries = 0; *nFlagged = 0;
     if (nReads == 0) return KASA_OK;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
         if ((rc = c->rankOut.reserve(c->rankCap * sizeof(RankEntry)))) return rc;
         HIPCHK(hipMemsetAsync(cursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
@@ -4679,7 +4684,9 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
             HIPCHK(hipStreamSynchronize(c->stream));
         }
         if (used <= c->rankCap) { c->rankEntries = used; *nEntries = used; *nFlagged = nf; return KASA_OK; }
-        c->rankCap = used + used / 8 + 1024;                               // the kernel has no side effects: grow and rerun
+        // the kernel has no side effects: grow and rerun.  Output space is handed out in slabs per wavefront, so `used` depends a
+        // little on the scheduling: leave a slab for every wavefront that can be in flight on top of the usual slack
+        c->rankCap = used + used / 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u + 1024;
     }
     return fail(KASA_E_LIMIT, "kasa_batch_rank: output did not converge");
 }

@@ -75,7 +75,11 @@ def _device_copy(dst: int, src: int, nbytes: int):
     if _hip is None:
         _hip = C.CDLL("libamdhip64.so")
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    if not dst or not src:
+        raise RuntimeError("device copy with a NULL pointer")
     rc = _hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 4)   # hipMemcpyDefault
+    if rc == 0:
+        rc = _hip.hipDeviceSynchronize()                            # a device-to-device hipMemcpy may return before the copy has landed
     if rc != 0:
         raise RuntimeError(f"hipMemcpy failed ({rc})")
 
@@ -93,6 +97,9 @@ def _all_to_all_device(send, send_counts, unit: int):
     recv_counts = [int(x) for x in theirs.cpu()]
     recv = torch.empty(sum(recv_counts) * unit, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(recv, send, [n * unit for n in recv_counts], [n * unit for n in send_counts])
+    # The collective only orders torch's current stream behind RCCL's; the library reads `recv` through raw pointers on its
+    # own non-blocking stream.  Wait for the data before handing the pointers on (and before `send` can be released).
+    torch.cuda.current_stream(dev).synchronize()
     return recv, recv_counts
 
 

@@ -384,6 +384,59 @@ def test_repeated_reads_fill_a_sort_bucket(K):
     _check_against_oracle(ix, big.slice(0, 1200), kh, 7, 3)
 
 
+@pytest.mark.parametrize("tail", [200, 7, 1500])
+@pytest.mark.parametrize("members", [500, 129, 1024])
+def test_last_sort_bucket_straddles_the_last_tile(tail, members):
+    """Round-2 advisor finding: the bucket pass of the query sort (bucket_rank32_kernel) scans a bucket left and right of
+    every member inside a staged window; a bucket that begins more than the halo before the LAST tile and runs to the end of
+    the batch must still be recognised as leaving the window.  The highest 8-letter prefix is repeated `members` times, the
+    batch ends `tail` queries into its last 2048-query tile."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(900 + tail + members)
+    ix, _ = synthetic_world(71, 4, 3000, 10)
+    n = 3 * 2048 + tail
+    top = np.uint64(0x0F39CE739C) << np.uint64(20)                   # one 8-letter prefix, larger than everything else below
+    q = rng.integers(1, 1 << 58, size=n, dtype=np.uint64)
+    q[q >= top] >>= np.uint64(3)
+    q[n - members:] = top | rng.integers(0, 1 << 20, size=members, dtype=np.uint64)
+    rng.shuffle(q)
+    rd = rng.integers(0, 50, size=n).astype(np.uint32)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    qs, rs_ = oracle.sort_queries(q, rd)
+    for flags in (0, 64):
+        ctx.debug_flags(flags)
+        ctx.set_queries(q, rd, 50)
+        ctx.sort_and_range()
+        km, r2 = ctx.queries()
+        assert np.array_equal(km, qs) and np.array_equal(r2, rs_)
+    ctx.close(); dix.close()
+
+
+def test_one_frame_reads_of_several_encoder_chunks():
+    """Round-2 advisor finding: --one gives the encoder chunks of 170 windows while it ranks up to 512 k-mers of a read
+    itself; reads of 600-1500 bases (171..490 k-mers, no longer read in the batch) span several chunks."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(6)
+    ix, base = synthetic_world(35, 6, 8000, 10)
+    pool = np.concatenate([base.bases] * 8)
+    lens = [600, 640, 777, 900, 1024, 1199, 1200, 1500, 1540, 601]
+    parts, off = [], [0]
+    for L in lens:
+        a = int(rng.integers(0, pool.shape[0] - 1600))
+        parts.append(pool[a:a + L])
+        off.append(off[-1] + L)
+    batch = reads.ReadBatch(np.concatenate(parts), np.asarray(off, dtype=np.int64), None,
+                            np.asarray([l + 1 for l in lens], dtype=np.uint32))
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 1)
+    ctx.upload(batch.bases, batch.offsets); ctx.encode()
+    assert ctx.batch_stats()["encoder_ranked"] == 1               # the path under test
+    ctx.close(); dix.close()
+    _check_against_oracle(ix, batch, 12, 7, 1)
+    _check_against_oracle(ix, batch, 12, 9, 1)
+
+
 def test_more_than_2_20_taxa():
     """A content file with more than 1 048 576 entries: staging records keep the taxon in 20 bits, so such an index must
     take the general score kernel for every read (and still give the oracle's numbers)."""
