@@ -2,10 +2,19 @@
 """bench.py -- reads/s of the `identify` hot path on MI355X (BASELINE.json metric).
 
 One step = one pass of the whole hot path (encode -> sort -> lookup -> group -> score, per-read CSR included) over
-one batch of synthetic reads that is already resident in HBM.  Workload at N=1: BASELINE.json configs[1]: 10 M
-synthetic 150 bp reads against a ~5 GB k<=12 64-bit index (1400 taxa x 300 kb, sibling genomes 3 % apart; 1 % read
-errors; -k 12 7, three frames).  With --gpus N every rank holds the whole index and its own 10 M reads (weak scaling,
-BASELINE.json configs[3]); the per-rank profile tables are summed with one RCCL all-reduce per step.
+synthetic reads that are already resident in HBM.
+
+  N = 1   BASELINE.json configs[1] (C2): ONE batch of 10 M synthetic 150 bp reads against a ~5 GB k<=12 64-bit index
+          (1400 taxa x 300 kb, sibling genomes 3 % apart; 1 % read errors; -k 12 7, three frames).  The same line also
+          carries `secondary` = configs[2] (C3: the same reads against the 128-bit index, -k 25 7), `e2e` (PCIe-inclusive
+          rates and the file-to-file rate of the C++ driver: FASTQ in, JSONL + profile out, index load excluded) and
+          `cpu_baseline` (the oracle with the reference's threading model on the host cores).
+  N > 1   BASELINE.json configs[3] (C4): 100 M reads in all, index replicated, every rank takes 100 M / N reads (kept in
+          its HBM) in batches of at most 10 M; a step = all batches of the rank + ONE RCCL all-reduce of the profile
+          tables through the C ABI (kasa_profile_allreduce on the context's stream; its own communicator, created from
+          an ncclUniqueId that travels over torch.distributed).  `value` = all reads of all ranks / max-over-ranks time.
+  --partitioned   BASELINE.json configs[4] (C5): the index range-partitioned over the ranks (kasa_amd/dist.py), one
+          slice per rank made of the genomes' k-mers of its prefix range plus random filler records.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R] [--taxa G] [--genome-len L]
 
@@ -42,6 +51,42 @@ def cpu_baseline(ix, sample, k_high, k_low, threads):
     oracle.identify_threaded(iv, sample.bases, sample.offsets, p, threads)
     dt = time.perf_counter() - t0
     return sample.n / dt, dt
+
+
+def cpu_baseline_report(ix, reads, k_high, k_low, args):
+    """One thread on a small sample, all cores on a large one (bounded by the host's free memory: the oracle keeps the
+    reference's dense reads x taxa score matrix), and the speed-up between the two."""
+    threads = os.cpu_count() or 1
+    per_read = ix.content.n_taxa * 4 + 130 * 40 + 400                    # score row + query records (two copies, ranges) + text
+    avail = None
+    try:
+        import psutil
+        avail = int(psutil.virtual_memory().available)
+    except Exception:
+        pass
+    n_par = min(reads.n, args.cpu_sample_parallel)
+    if avail is not None:
+        n_par = max(min(n_par, int(0.25 * avail / per_read)), min(reads.n, args.cpu_sample))
+    if threads < 16:
+        n_par = min(n_par, args.cpu_sample)
+    one = reads.slice(0, min(args.cpu_sample, reads.n))
+    v1, s1 = cpu_baseline(ix, one, k_high, k_low, 1)
+    par = reads.slice(0, n_par)
+    vn, sn = cpu_baseline(ix, par, k_high, k_low, threads)
+    cal = {}
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
+    except Exception:
+        pass
+    return {"value": vn, "unit": "reads/s", "cores": threads, "threads": threads, "kind": "port", "cpu": cpu_model(),
+            "single_thread_value": v1, "speedup_over_1": vn / v1 if v1 > 0 else None,
+            "parallel_efficiency": (vn / v1 / threads) if v1 > 0 else None,
+            "sample": f"first {par.n} reads of the same workload with {threads} threads ({sn:.1f} s), first {one.n} reads with one "
+                      f"thread ({s1:.1f} s); same index; oracle/ = C restatement of the reference with its threading model "
+                      "(reads split for the translation, parallel sort, range-aligned slices merged into the shared dense "
+                      "score matrix, private count tables)",
+            "host_memory_available_gb": None if avail is None else avail / 1e9,
+            "calibration": cal}
 
 
 def kernel_bytes(n_q, n_idx, rec_bytes, rec_words, stats):
@@ -117,16 +162,33 @@ def launch_ranks(n):
     return failed
 
 
-def measure(args, ctx, reads, ix, world, dist, share, wide, torch, kdist):
-    """Warm up, time exactly --steps steps between barriers; -> dict of raw measurements."""
+def measure(args, ctx, world, dist, share, torch, kdist, batches=None, comm=0):
+    """Warm up, time exactly --steps steps between barriers -> seconds (max over ranks).
+    batches = None: the one batch already uploaded (N = 1).  Else [(device pointer of the bases, host offsets)]: the rank's
+    reads, resident in HBM, taken batch by batch; the step ends with the profile reduce over the ranks."""
     want = not args.profile_only
 
+    def reduce_profile():
+        if dist is None:
+            return
+        if comm:
+            ctx.profile_allreduce(comm)                                    # C ABI: pack on the device, ncclAllReduce on the context's stream, unpack
+        else:
+            ctx.profile_set_limbs(kdist.allreduce_limbs(ctx.profile_limbs(), device=None if share else "cuda"))   # (shared-GPU test hook / fallback: through torch.distributed)
+
     def step():
-        ctx.encode()
-        ctx.sort_and_range()
-        ctx.lookup_score(want, False)
-        if dist is not None:
-            kdist.allreduce_limbs(ctx.profile_limbs(), device=None if share else "cuda")   # one RCCL sum of integer limbs (exact)
+        if batches is None:
+            ctx.encode()
+            ctx.sort_and_range()
+            ctx.lookup_score(want, False)
+        else:
+            ctx.profile_reset()                                            # a step is a whole "file": its own profile, summed over the ranks at its end
+            for ptr, off in batches:
+                ctx.upload_device(ptr, off)
+                ctx.encode()
+                ctx.sort_and_range()
+                ctx.lookup_score(want, False)
+        reduce_profile()
 
     def fence():
         ctx.synchronize()
@@ -136,11 +198,13 @@ def measure(args, ctx, reads, ix, world, dist, share, wide, torch, kdist):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ctx.profile_reset()
+        if batches is None:
+            ctx.profile_reset()
         step()
     fence()
     ctx.stage_reset()
-    ctx.profile_reset()
+    if batches is None:
+        ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -153,16 +217,17 @@ def measure(args, ctx, reads, ix, world, dist, share, wide, torch, kdist):
     return dt
 
 
-def report(args, ctx, reads, ix, world, dt, wide, pcie):
+def report(args, ctx, reads, ix, world, dt, wide, pcie, reads_per_rank=None, n_batches=1, total_kmers=None, extra_cfg=None):
     k_high, k_low = (25, 7) if wide else (12, 7)
     rec_bytes = 20 if wide else 12
-    n_kmers = ctx.n_kmers
+    n_kmers = ctx.n_kmers                                                 # of the last batch: what the per-kernel byte counts refer to
     stages = ctx.stage_ms()
     kern = ctx.kernel_ms()
     stats = ctx.batch_stats()
     ca, cu, _ = ctx.profile()
-    identified = float(ca[-1].sum()) / max(1, args.steps) / max(1, n_kmers)
-    n_reads = reads.n
+    n_reads = reads.n if reads_per_rank is None else reads_per_rank       # reads of one rank per step
+    kmers_step = n_kmers if total_kmers is None else total_kmers          # k-mers of one rank per step
+    identified = float(ca[-1].sum()) / max(1, args.steps if n_batches == 1 and world == 1 else world) / max(1, kmers_step)
     value = n_reads * world * args.steps / dt
     kb = kernel_bytes(n_kmers, ix.n, rec_bytes, ctx.rec_words, stats)
     kernels = {}
@@ -174,26 +239,32 @@ def report(args, ctx, reads, ix, world, dt, wide, pcie):
     # the roofline line is the kernel with the largest share of the step
     dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"]) if kernels else None
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_kernel_pmc.json")
-    if dom and os.path.exists(pmc) and not wide and n_reads == 10_000_000:   # measured for that workload only
+    pmc = os.path.join(ROOT, "profiles", "r03_kernel_pmc.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r02_kernel_pmc.json")
+    if dom and os.path.exists(pmc) and not wide and n_reads == 10_000_000 and n_batches == 1:   # measured for that workload only (rocprofv3 --pmc passes, tools/make_profiles.py)
         try:
             traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    sb = stage_bytes(n_kmers, n_reads * args.read_len, ix.n, rec_bytes, ctx.rec_words, stats)
+    per_batch_reads = n_reads // max(1, n_batches)
+    sb = stage_bytes(n_kmers, per_batch_reads * args.read_len, ix.n, rec_bytes, ctx.rec_words, stats)
+    sb = {k: v * n_batches for k, v in sb.items()}
     out = {
         "metric": "reads/s in identify (10M x 150bp vs k=12 index)" if not wide else
                   "reads/s in identify (150bp reads vs k<=25 128-bit index)", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u128" if wide else "u64",
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u128" if wide else "u64",
         "data": "synthetic",
-        "config": {"workload": f"{n_reads} synthetic {args.read_len} bp reads per GPU vs {ix.n}-record "
-                               f"({ix.n * rec_bytes / 1e9:.1f} GB) "
-                               + ("k<=25 128-bit index, -k 25 7, 3 frames, " if wide else "k<=12 64-bit index, -k 12 7, 3 frames, ") +
-                               f"{'profile only' if args.profile_only else 'profile + per-read scores'}",
-                   "reads_per_gpu": n_reads, "kmers_per_gpu": n_kmers, "index_records": int(ix.n),
-                   "taxa": args.taxa, "parallelism": f"read-sharded x{world}, index replicated"},
-        "kmers_per_s": n_kmers * world * args.steps / dt,
+        "config": dict({"workload": (f"{n_reads} synthetic {args.read_len} bp reads per GPU" if world == 1 else
+                                     f"{n_reads * world} synthetic {args.read_len} bp reads in all, {n_reads} per GPU in {n_batches} "
+                                     f"batch{'es' if n_batches > 1 else ''}") +
+                                    f" vs {ix.n}-record ({ix.n * rec_bytes / 1e9:.1f} GB) "
+                                    + ("k<=25 128-bit index, -k 25 7, 3 frames, " if wide else "k<=12 64-bit index, -k 12 7, 3 frames, ") +
+                                    f"{'profile only' if args.profile_only else 'profile + per-read scores'}",
+                        "reads_per_gpu": n_reads, "batches_per_step": n_batches, "kmers_per_gpu": kmers_step, "index_records": int(ix.n),
+                        "taxa": args.taxa, "parallelism": f"read-sharded x{world}, index replicated"}, **(extra_cfg or {})),
+        "kmers_per_s": kmers_step * world * args.steps / dt,
         "identified_fraction": identified,
         "batch": stats,
         "stage_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stages.items()},
@@ -262,24 +333,191 @@ def pcie_inclusive(ctx, reads, want, ix, k_high):
     return out
 
 
+def file_to_file(args, ix, reads, device):
+    """The C++ driver (kASA's `identify` command line over the C ABI) as a child process: FASTQ of the same reads and the
+    index files in /dev/shm, JSONL + profile out.  Rate = reads / the driver's own "Time file" (everything but loading the
+    index, as the reference reports it, Compare.hpp:3689-3690).  The parent must have released its device memory."""
+    import shutil
+    import tempfile
+    from kasa_amd import build, formats
+    exe = build.build_host()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="kasa_bench_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        formats.write_index(ix, os.path.join(d, "idx"), os.path.join(d, "content.txt"))
+        L = args.read_len
+        bases = reads.bases.reshape(reads.n, L)
+        fq = os.path.join(d, "reads.fastq")
+        rec = np.empty((reads.n, 2 * L + 16), dtype=np.uint8)          # "@" + 9 digits + "\n" + bases + "\n+\n" + quality + "\n"
+        rec[:, 0] = ord("@")
+        ids = np.arange(reads.n, dtype=np.int64)
+        for c in range(9):
+            rec[:, 9 - c] = (ord("0") + (ids // 10 ** c) % 10).astype(np.uint8)
+        rec[:, 10] = 10
+        rec[:, 11:11 + L] = bases
+        rec[:, 11 + L:14 + L] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, 14 + L:14 + 2 * L] = ord("I")
+        rec[:, 14 + 2 * L] = 10
+        rec = rec[:, :15 + 2 * L]
+        with open(fq, "wb") as f:
+            f.write(np.ascontiguousarray(rec).tobytes())
+        del rec
+        t_files = time.perf_counter() - t0
+        cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", fq,
+               "-q", os.path.join(d, "out.jsonl"), "-p", os.path.join(d, "prof.csv"), "--jsonl", "-v", "-m", str(args.f2f_memory),
+               "--device", str(device)]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stdout[-400:]}
+        t = {}
+        for line in r.stdout.splitlines():
+            for key in ("Time fastq", "Time compare", "Time output", "Time file"):
+                if line.startswith("OUT: " + key + ":"):
+                    t[key] = float(line.split(":")[2].split()[0])
+        n_batches = sum(1 for line in r.stdout.splitlines() if line.startswith("OUT: Batch of "))
+        out = {"file_to_file_reads_per_s": reads.n / t["Time file"] if t.get("Time file") else None,
+               "file_to_file_s": t.get("Time file"), "parse_s": t.get("Time fastq"), "device_s": t.get("Time compare"),
+               "text_s": t.get("Time output"), "child_wall_s_incl_index_load": wall, "batches": n_batches,
+               "input_bytes": os.path.getsize(fq), "output_bytes": os.path.getsize(os.path.join(d, "out.jsonl")),
+               "command": "kasa_identify identify --jsonl -m %d (FASTQ and index in %s; inputs written in %.1f s)" % (args.f2f_memory, base or "tmp", t_files)}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, synth, kdist):
+    """BASELINE.json configs[4] (C5): an index too large for one GPU, range-partitioned over the ranks at 30-bit prefix
+    boundaries (kasa_amd/partition.py, dist.py).  Every rank's slice = the genomes' records of its prefix range plus random
+    filler records (SURVEY.md 8(d): the index is synthesised directly, sorted (kmer, taxid) + unique), made on the device;
+    every rank also owns --reads reads.  A step = one batch per rank through the exchange: sorted k-mers out (8 B per
+    query), event records + taxon lists back (32 B per query + pool), three RCCL all_to_all on device tensors, then the
+    profile reduce.  Batches are sized from the HBM that is free once the slice is loaded."""
+    from kasa_amd import partition
+    k_high, k_low, L = 12, 7, args.read_len
+    dev = torch.device("cuda", local_rank)
+    t0 = time.perf_counter()
+    g = synth.genomes(args.taxa, args.genome_len, seed=11)
+    ix = synth.index_from_genomes(g, device=local_rank)
+    parts, cuts = partition.split_index(ix, world)
+    mine = parts[rank]
+    lo = int(cuts[rank]) << 30
+    hi = (int(cuts[rank + 1]) if rank + 1 < world else (1 << 30)) << 30
+    n_fill = max(0, int(args.part_records) - int(mine.n))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4242 + rank)
+    km = torch.empty(mine.n + n_fill, dtype=torch.int64, device=dev)
+    td = torch.empty(mine.n + n_fill, dtype=torch.int32, device=dev)
+    km[:mine.n] = torch.from_numpy(mine.kmer.astype(np.int64)).to(dev)
+    td[:mine.n] = torch.from_numpy(mine.taxid.astype(np.int32)).to(dev)
+    step = 1 << 28
+    for a in range(mine.n, mine.n + n_fill, step):                       # random 60-bit k-mers of this rank's prefix range, random taxa
+        b = min(mine.n + n_fill, a + step)
+        km[a:b] = torch.randint(lo, hi, (b - a,), dtype=torch.int64, device=dev, generator=gen)
+        td[a:b] = torch.randint(100, 100 + args.taxa, (b - a,), dtype=torch.int32, device=dev, generator=gen)
+    td, order = torch.sort(td, stable=True)                                # (kmer, taxid) order: by taxid first, then stably by k-mer
+    km = km[order]
+    del order
+    km, order = torch.sort(km, stable=True)
+    td = td[order]
+    del order
+    keep = torch.ones(km.shape[0], dtype=torch.bool, device=dev)
+    keep[1:] = (km[1:] != km[:-1]) | (td[1:] != td[:-1])
+    km, td = km[keep], td[keep]
+    del keep
+    n_rec = int(km.shape[0])
+    rec = torch.empty((n_rec, 12), dtype=torch.uint8, device=dev)          # the index file's records: {u64 kmer, u32 taxid}
+    rec[:, :8] = km.view(torch.uint8).view(n_rec, 8)
+    rec[:, 8:] = td.view(torch.uint8).view(n_rec, 4)
+    del km, td
+    torch.cuda.synchronize()
+    dix = capi.DeviceIndex.from_device_records(rec.data_ptr(), n_rec, 12, ix.content.taxids, local_rank)
+    del rec
+    torch.cuda.empty_cache()
+    log(f"[rank {rank}] slice: {n_rec} records ({n_rec * 12 / 1e9:.1f} GB as a file, {dix.device_bytes / 1e9:.1f} GB in HBM), "
+        f"prefixes [{int(cuts[rank])}, {hi >> 30}), {time.perf_counter() - t0:.1f} s")
+    owner = capi.Context(dix, k_high, k_low, 3)
+    worker = partition.Worker(dix, k_high, k_low, 3)
+    free, total = capi.device_memory(local_rank)
+    per_q = capi.bytes_per_query(owner) + 64 + 96                          # owner + worker (keys, depth, rep, records, pool) + exchange tensors
+    q = max(1, L - 3 * k_low + 1)
+    n_reads = int(min(args.reads, max(1000, 0.8 * free / per_q / q)))
+    if world > 1:                                                          # everybody the same batch (collective rounds)
+        t = torch.tensor([n_reads], dtype=torch.int64, device="cpu" if share else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        n_reads = int(t.item())
+    reads = synth.reads_from_genomes(g, n_reads, L, seed=1000 + rank)
+    stats = {}
+
+    def step():
+        kdist.partitioned_batch(owner, worker, cuts, 12, reads, not args.profile_only, False, stats=stats)
+        if world > 1:
+            owner.profile_set_limbs(kdist.allreduce_limbs(owner.profile_limbs(), device=None if share else "cuda"))
+
+    def fence():
+        owner.synchronize(); worker.ctx.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        owner.profile_reset()
+        step()
+    fence()
+    owner.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ca, cu, _ = owner.profile()
+    n_kmers = owner.n_kmers
+    out = {"metric": "reads/s in identify (150bp reads vs range-partitioned k=12 index, cross-rank lookup)",
+           "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+           "data": "synthetic",
+           "config": {"workload": f"{n_reads} synthetic {L} bp reads per GPU vs an index of {world} slices, {n_rec} records "
+                                  f"({n_rec * 12 / 1e9:.1f} GB) on this rank, -k 12 7, 3 frames, reads uploaded inside the step",
+                      "reads_per_gpu": n_reads, "kmers_per_gpu": n_kmers, "slice_records": n_rec, "slice_hbm_bytes": dix.device_bytes,
+                      "free_hbm_after_slice_bytes": free, "bytes_per_query_budgeted": per_q,
+                      "parallelism": f"index range-partitioned x{world}, reads sharded x{world}",
+                      "exchange": "gloo, host-staged (KASA_BENCH_SHARE_GPU test hook)" if share else "RCCL all_to_all on device tensors"},
+           "kmers_per_s": n_kmers * world * args.steps / dt,
+           "identified_fraction": float(ca[-1].sum()) / max(1, args.steps) / max(1, n_kmers * (world if world > 1 else 1)),
+           "exchange_bytes_per_step_this_rank": stats}
+    owner.close(); worker.close(); dix.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads of the one batch at N = 1; the largest batch at N > 1")
+    ap.add_argument("--total-reads", type=int, default=100_000_000, help="N > 1 (BASELINE.json configs[3]): reads of all ranks together")
     ap.add_argument("--taxa", type=int, default=1400)
     ap.add_argument("--genome-len", type=int, default=300_000)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=600_000)
+    ap.add_argument("--cpu-sample", type=int, default=300_000, help="reads of the one-thread CPU run")
+    ap.add_argument("--cpu-sample-parallel", type=int, default=5_000_000, help="reads of the all-cores CPU run (less when the host's memory is short)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive extra pass")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive extra pass and the file-to-file run")
+    ap.add_argument("--no-f2f", action="store_true", help="skip the file-to-file run of the C++ driver")
+    ap.add_argument("--f2f-memory", type=int, default=1024, help="-m of the file-to-file run (GiB; the reference's batch budget)")
     ap.add_argument("--profile-only", action="store_true", help="no per-read scores (kASA without -q)")
     ap.add_argument("--wide", action="store_true",
                     help="BASELINE.json configs[2] as the only measurement: 128-bit index, -k 25 7")
-    ap.add_argument("--secondary", action="store_true",
-                    help="after the headline measurement also run configs[2] (128-bit index, -k 25 7, same reads) and report it "
-                         "as `secondary` inside the one JSON line")
+    ap.add_argument("--secondary", action="store_true", help="(the default at N = 1; kept for older command lines)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="do not run configs[2] (128-bit index, -k 25 7, same reads) after the headline measurement")
+    ap.add_argument("--partitioned", action="store_true", help="BASELINE.json configs[4]: range-partitioned index (see bench_partitioned)")
+    ap.add_argument("--part-records", type=float, default=3.0e9, help="--partitioned: index records per rank (36 GB at 3e9)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -298,9 +536,10 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or args.partitioned:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -313,6 +552,32 @@ def main():
     from kasa_amd import dist as kdist
     assert capi.device_count() > local_rank, "no HIP device for this rank"
 
+    if args.partitioned:
+        out = bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, synth, kdist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    # the C ABI's own RCCL communicator for the profile reduce (N > 1)
+    comm, rccl_ranks, reduce_how = 0, None, None
+    if world > 1 and not share:
+        try:
+            comm, rccl_ranks = kdist.rccl_communicator(rank, world)
+            reduce_how = "kasa_profile_allreduce (C ABI: limbs packed on the device, ncclAllReduce on the context's stream)"
+        except Exception as ex:                          # never lose the measurement to the plumbing: torch.distributed carries the same sum
+            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed: %s)" % str(ex)[:200]
+        ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks the same way
+        if int(ok.item()) == 0 and comm:
+            kdist.rccl_destroy(comm)
+            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed on another rank)"
+    elif world > 1:
+        reduce_how = "gloo all_reduce of the limbs through the host (KASA_BENCH_SHARE_GPU test hook)"
+
+    holder = {}
+
     def one(wide):
         k_high, k_low = (25, 7) if wide else (12, 7)
         rec_bytes = 20 if wide else 12
@@ -322,52 +587,77 @@ def main():
         log(f"[rank {rank}] index: {ix.n} records ({ix.n * rec_bytes / 1e9:.2f} GB on disk layout), "
             f"{ix.trie_prefix.shape[0]} prefixes, {time.perf_counter() - t0:.1f} s")
         t0 = time.perf_counter()
-        reads = synth.reads_from_genomes(g, args.reads, args.read_len, seed=1000 + rank)
-        log(f"[rank {rank}] reads: {reads.n} x {args.read_len} bp, {time.perf_counter() - t0:.1f} s")
         dix = capi.DeviceIndex(ix, local_rank, check_trie=True)
         ctx = capi.Context(dix, k_high, k_low, 3)
-        ctx.upload(reads.bases, reads.offsets)         # inputs resident in HBM before the timed region
-        dt = measure(args, ctx, reads, ix, world, dist, share, wide, torch, kdist)
+        batches, dev_reads, extra_cfg = None, None, None
+        if world == 1:
+            reads = synth.reads_from_genomes(g, args.reads, args.read_len, seed=1000 + rank)
+            per_rank, n_batches, total_kmers = reads.n, 1, None
+            ctx.upload(reads.bases, reads.offsets)         # inputs resident in HBM before the timed region
+        else:
+            # C4: the rank's share of the 100 M reads lies in HBM as one tensor; a step takes it in batches of at most --reads
+            per_rank = args.total_reads // world
+            n_batches = max(1, -(-per_rank // args.reads))
+            per_batch = -(-per_rank // n_batches)
+            L = args.read_len
+            dev_reads = torch.empty(per_rank * L, dtype=torch.uint8, device="cuda")
+            reads = None
+            done = 0
+            while done < per_rank:
+                m = min(args.reads, per_rank - done)
+                part = synth.reads_from_genomes(g, m, L, seed=1000 + rank * 97 + done // max(1, args.reads))
+                dev_reads[done * L:(done + m) * L].copy_(torch.from_numpy(part.bases))
+                if reads is None:
+                    reads = part                             # (kept for the report's shapes)
+                done += m
+            torch.cuda.synchronize()
+            batches = []
+            for b in range(n_batches):
+                a0, a1 = b * per_batch, min(per_rank, (b + 1) * per_batch)
+                batches.append((dev_reads.data_ptr() + a0 * L, np.arange(a1 - a0 + 1, dtype=np.int64) * L))
+            total_kmers = per_rank * max(0, L - 3 * k_low + 1)          # windows of a read: len - 3 kLow + 1 (Read.hpp:36-57,1074-1077)
+            extra_cfg = {"total_reads": per_rank * world, "reduce": reduce_how, "rccl_ranks": rccl_ranks}
+        log(f"[rank {rank}] reads: {per_rank} x {args.read_len} bp in {n_batches} batch(es), {time.perf_counter() - t0:.1f} s")
+        dt = measure(args, ctx, world, dist, share, torch, kdist, batches, comm)
         pcie = None
         out = None
         if rank == 0:
+            out = report(args, ctx, reads, ix, world, dt, wide, None, per_rank, n_batches, total_kmers, extra_cfg)
             if world == 1 and not args.no_e2e:
-                out0 = report(args, ctx, reads, ix, world, dt, wide, None)     # (stats of the timed run, before the extra pass)
                 try:                                               # an extra pass: it must never cost the headline line
                     pcie = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
                 except Exception as ex:                            # e.g. no memory left for the page-locked buffers
                     pcie = {"error": str(ex)[:300]}
-                out0["e2e"] = pcie
-                out = out0
-            else:
-                out = report(args, ctx, reads, ix, world, dt, wide, None)
-            if not args.no_cpu and world == 1 and not wide:   # the CPU baseline is reported at N = 1 only
-                threads = os.cpu_count() or 1
-                sample = reads.slice(0, min(args.cpu_sample, reads.n))
-                v1, s1 = cpu_baseline(ix, sample, k_high, k_low, 1)
-                vn, sn = cpu_baseline(ix, sample, k_high, k_low, threads)
-                cal = {}
-                try:
-                    cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
-                except Exception:
-                    pass
-                out["cpu_baseline"] = {"value": vn, "unit": "reads/s", "cores": threads, "kind": "port",
-                                       "cpu": cpu_model(), "single_thread_value": v1,
-                                       "sample": f"first {sample.n} reads of the same workload, same index, oracle/ (C restatement of "
-                                                 f"the reference with its threading model), {sn:.1f} s with {threads} threads, {s1:.1f} s with 1",
-                                       "calibration": cal}
+                out["e2e"] = pcie
         ctx.close()
         dix.close()
+        del dev_reads
+        if rank == 0 and world == 1 and not wide:
+            holder["ix"], holder["reads"], holder["k"] = ix, reads, (k_high, k_low)
         return out
 
     out = one(args.wide)
-    if args.secondary and not args.wide:
+    if rank == 0 and world == 1 and not args.wide:
+        ix, reads, (k_high, k_low) = holder["ix"], holder["reads"], holder["k"]
+        if not args.no_e2e and not args.no_f2f:
+            try:                                                   # the device is free now: the C++ driver as a child process
+                f2f = file_to_file(args, ix, reads, local_rank)
+            except Exception as ex:
+                f2f = {"error": str(ex)[:300]}
+            out.setdefault("e2e", {}).update(f2f)
+        if not args.no_cpu:                                         # the CPU baseline is reported at N = 1 only
+            out["cpu_baseline"] = cpu_baseline_report(ix, reads, k_high, k_low, args)
+        holder.clear()
+        del ix, reads
+    if world == 1 and not args.wide and not args.no_secondary:
         sec = one(True)
         if rank == 0 and out is not None and sec is not None:
             out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "kmers_per_s",
                                                     "identified_fraction", "batch", "stage_ms_per_step", "roofline", "kernels")}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm:
+        kdist.rccl_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

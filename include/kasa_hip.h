@@ -101,7 +101,9 @@ int kasa_ctx_set_protein(kasa_ctx *ctx, int protein);
 
 /* Hand the raw reads of one batch to the device: concatenated bases and offsets[nReads+1].
  * Replaces the vLines the reference keeps per batch (Read.hpp:612-630).  Cleaning (non-ACGT -> Z),
- * padding and the X marker (Read.hpp:633-675,1068-1078) happen on the device.  H2D copy only. */
+ * padding and the X marker (Read.hpp:633-675,1068-1078) happen on the device.  One copy only; `bases` may also point into
+ * device memory (a host that keeps the reads of a whole file resident, as bench.py does for its multi-batch steps);
+ * `offsets` is host memory. */
 int kasa_batch_upload(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offsets, int64_t nReads);
 
 /* The same for reads made of several sequences: paired-end input (-1/-2; Read::readFastqa_pairedEnd,
@@ -166,11 +168,27 @@ int kasa_batch_set_sorted_device(kasa_ctx *ctx, const void *kmersDev, uint64_t n
 int kasa_batch_records_device(kasa_ctx *ctx, const uint32_t **records, uint64_t *nRecordWords, const uint32_t **pool, uint64_t *nPoolWords);
 int kasa_batch_records_import_device(kasa_ctx *ctx, uint32_t nParts, const uint32_t *const *records, const uint64_t *nRecordWords,
                                      const uint32_t *const *pool, const uint64_t *nPoolWords);
+/* The staging buffer kasa_batch_records_import_device files the records from, with room for nRecordWords words: a caller that
+ * receives the slices' records THERE (back to back, in partition order) and names those places as `records[j]` spares the
+ * batch a second copy of its records (32 or 64 bytes per query); they are then shifted in place. */
+int kasa_batch_records_inbox(kasa_ctx *ctx, uint64_t nRecordWords, uint32_t **records);
 
 /* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
  * scoringFunc scans (Compare.hpp:1501-1522). */
 int kasa_batch_scores_size(kasa_ctx *ctx, uint64_t *nnz);
 int kasa_batch_scores_fetch(kasa_ctx *ctx, uint64_t *readOffsets, uint32_t *taxIdx, float *score);
+
+/* --coherence (Compare::postProcess, Compare.hpp:2607-2728, fed by setMatchLength at :847-848,882-884,912-914,948; printed at
+ * :1662-1665 and used by --filter at :1602-1606).  Per read the reference's coherence score of
+ * the batch that was last sorted (kasa_batch_sort_and_range): the k-mers in the order the reader emitted them (read, strand,
+ * window), match length = the deepest matched level of the k-mer, clusters of overlapping matches walked with the
+ * reference's own state machine -- including what it credits to reads without k-mers and what it skips after a strand
+ * switch.  scores = float[nReads] (host).  *throwsAt = ~0, or the index at which the reference's walk runs off the end of
+ * its vector (std::out_of_range from vector::at, Compare.hpp:2667: with --six, a batch whose last strand switch finds no
+ * further match): then the reference ends with "vector::_M_range_check: __n (which is N) >= this->size() (which is N)",
+ * N = *throwsAt, and the host should do the same.  Single-end batches without -e only (the reference's results for the
+ * others depend on its unstable sorts): KASA_E_ARG otherwise. */
+int kasa_batch_coherence(kasa_ctx *ctx, float *scores, uint64_t *throwsAt);
 
 /* Ranking on the device (Compare::scoringFunc, Compare.hpp:1495-1594 and the printing loops
  * :1721-1754): instead of the whole CSR only what the per-read file can print leaves the device.
@@ -275,9 +293,11 @@ typedef struct {
 int kasa_refbatch_budget(const kasa_refbatch_params *p, int64_t *budget);
 /* One sequence (a read, or one mate of a pair): K = 12 or 25 (index type), mode 0 = DNA in 3/6 frames, 1 = --one,
  * 2 = amino acids; strands = 2 with --six.  The read as a whole, when per-read results are kept (-q / --filter):
- * nameLen = length of the specifier the reference stores (header without its first character + one space; both mates'). */
-int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int64_t rawLen);
-int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa);
+ * nameLen = length of the specifier the reference stores (header without its first character + one space; both mates').
+ * coherence: --coherence widens the k-mer records (InputType::ppTuple, MetaHeader.h:172) and adds a float per read
+ * (Read.hpp:1191-1193). */
+int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int64_t rawLen, int coherence);
+int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa, int coherence);
 /* Reads of the next batch given the costs of the reads still to come. */
 uint64_t kasa_refbatch_cut(int64_t budget, int firstBatch, const int64_t *cost, uint64_t nReads);
 

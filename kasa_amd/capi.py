@@ -28,7 +28,7 @@ EXPORTS = [
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
-    "kasa_batch_records_import_device",
+    "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
 ]
 
 
@@ -51,9 +51,9 @@ def lib():
         L.kasa_ctx_destroy.argtypes = [C.c_void_p]
         L.kasa_ctx_destroy.restype = None
         L.kasa_refbatch_sequence_cost.restype = C.c_int64
-        L.kasa_refbatch_sequence_cost.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]
+        L.kasa_refbatch_sequence_cost.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int]
         L.kasa_refbatch_read_overhead.restype = C.c_int64
-        L.kasa_refbatch_read_overhead.argtypes = [C.c_int64, C.c_uint32]
+        L.kasa_refbatch_read_overhead.argtypes = [C.c_int64, C.c_uint32, C.c_int]
         L.kasa_refbatch_cut.restype = C.c_uint64
         L.kasa_refbatch_cut.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_uint64]
         L.kasa_host_alloc.restype = C.c_void_p
@@ -117,7 +117,8 @@ class RefBatcher:
     per-read files need the reference's boundaries (Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195)."""
 
     def __init__(self, ix, k_high: int, k_low: int, frames: int = 3, memory_gib: int = 5, threads: int = 1,
-                 ram: bool = False, record_bytes: int = None, identify_multiple: bool = False):
+                 ram: bool = False, record_bytes: int = None, identify_multiple: bool = False, coherence: bool = False):
+        self.coherence = int(bool(coherence))
         tp = np.ascontiguousarray(ix.trie_prefix, dtype=np.uint32)
         tax = np.ascontiguousarray(ix.content.taxids, dtype=np.uint32)
         name_bytes = sum(len(n.replace(",", "").encode("latin-1", "replace")) for n in ix.content.names[1:])
@@ -136,14 +137,14 @@ class RefBatcher:
         mode = 2 if protein else (1 if self.frames == 1 else 0)
         strands = 2 if (self.frames == 6 and not protein) else 1
         seq_len = np.diff(reads.offsets).astype(np.int64)
-        per_seq = np.array([L.kasa_refbatch_sequence_cost(self.K, self.k_low, mode, strands, int(x)) for x in seq_len], dtype=np.int64)
+        per_seq = np.array([L.kasa_refbatch_sequence_cost(self.K, self.k_low, mode, strands, int(x), self.coherence) for x in seq_len], dtype=np.int64)
         if reads.seg_read is not None:
             cost = np.zeros(reads.n, dtype=np.int64)
             np.add.at(cost, reads.seg_read.astype(np.int64), per_seq)
         else:
             cost = per_seq
         if want_per_read:
-            cost = cost + np.array([L.kasa_refbatch_read_overhead(len(n.encode("latin-1", "replace")), self.n_taxa) for n in reads.names], dtype=np.int64)
+            cost = cost + np.array([L.kasa_refbatch_read_overhead(len(n.encode("latin-1", "replace")), self.n_taxa, self.coherence) for n in reads.names], dtype=np.int64)
         return np.ascontiguousarray(cost)
 
     def boundaries(self, reads, want_per_read: bool = True) -> list:
@@ -177,6 +178,18 @@ def pinned_empty(n: int, dtype) -> np.ndarray:
     return arr
 
 
+def device_memory(device: int = 0):
+    """(free, total) bytes of HBM (hipMemGetInfo)."""
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().kasa_device_memory(C.c_int(device), C.byref(free), C.byref(total)))
+    return int(free.value), int(total.value)
+
+
+def bytes_per_query(ctx) -> int:
+    """Device bytes one query k-mer of a batch takes in this context (kasa_batch_bytes_per_query)."""
+    return int(lib().kasa_batch_bytes_per_query(ctx.h))
+
+
 def device_count() -> int:
     n = C.c_int(0)
     lib().kasa_device_count(C.byref(n))
@@ -206,6 +219,18 @@ class DeviceIndex:
         self.device = device
         self.n_taxa = int(ids.shape[0])
         self.n = ix.n
+
+    @classmethod
+    def from_device_records(cls, records_ptr: int, n: int, record_bytes: int, taxids, device: int = 0):
+        """An index whose file-layout records ({kmer, taxid}, 12 or 20 bytes each, sorted, unique) already lie in device
+        memory (bench.py synthesises the slices of a range-partitioned index there); no `_trie` cross-check."""
+        self = cls.__new__(cls)
+        ids = np.ascontiguousarray(taxids, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().kasa_index_create(C.c_int(device), C.c_void_p(records_ptr), C.c_uint64(n), C.c_int(record_bytes), None, None,
+                                       C.c_uint64(0), _p(ids), C.c_uint32(ids.shape[0]), C.byref(h)))
+        self.h, self.device, self.n_taxa, self.n, self.wide = h, device, int(ids.shape[0]), int(n), record_bytes == 20
+        return self
 
     @property
     def device_bytes(self) -> int:
@@ -262,6 +287,17 @@ class Context:
             self.n_reads = int(n_reads)
             _check(lib().kasa_batch_upload_segments(self.h, _p(bases), _p(offsets), C.c_int64(n_seq), _p(seg_read),
                                                     C.c_int64(self.n_reads)))
+
+    def upload_device(self, bases_ptr: int, offsets: np.ndarray):
+        """upload() of reads whose bases already lie in device memory at `bases_ptr` (offsets: host, relative to it)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n_reads = int(offsets.shape[0] - 1)
+        _check(lib().kasa_batch_upload(self.h, C.c_void_p(bases_ptr), _p(offsets), C.c_int64(self.n_reads)))
+
+    def profile_allreduce(self, comm: int):
+        """kasa_profile_allreduce: the profile tables summed over the ranks of an RCCL communicator (ncclComm_t as an
+        integer), on the context's stream, no host copy."""
+        _check(lib().kasa_profile_allreduce(self.h, C.c_void_p(comm)))
 
     def encode(self) -> int:
         n = C.c_uint64(0)
@@ -327,6 +363,13 @@ class Context:
         _check(lib().kasa_batch_records_device(self.h, C.byref(r), C.byref(nr), C.byref(p), C.byref(npw)))
         return int(r.value or 0), int(nr.value), int(p.value or 0), int(npw.value)
 
+    def records_inbox(self, n_record_words: int) -> int:
+        """Device pointer of the context's staging buffer for imported records (room for n_record_words u32): records
+        received there are shifted and filed in place by records_import_device."""
+        p = C.c_void_p(0)
+        _check(lib().kasa_batch_records_inbox(self.h, C.c_uint64(n_record_words), C.byref(p)))
+        return int(p.value or 0)
+
     def records_import_device(self, parts):
         """parts[j] = (records pointer, record words, pool pointer, pool words) of slice j, in partition order."""
         n = len(parts)
@@ -369,6 +412,15 @@ class Context:
             ent = alloc(n_ent.value, RANK_ENTRY)
         _check(lib().kasa_batch_rank_fetch(self.h, _p(meta), _p(ent)))
         return meta.reshape(-1, 4), ent, n_flag.value
+
+    def coherence(self) -> np.ndarray:
+        """--coherence scores of the batch (Compare::postProcess): float32[n_reads].  Raises where the reference throws."""
+        sc = np.zeros(self.n_reads, dtype=np.float32)
+        at = C.c_uint64(0)
+        _check(lib().kasa_batch_coherence(self.h, _p(sc), C.byref(at)))
+        if at.value != 0xFFFFFFFFFFFFFFFF:
+            raise RuntimeError(f"vector::_M_range_check: __n (which is {at.value}) >= this->size() (which is {at.value})")
+        return sc
 
     def run_batch(self, bases, offsets, want_per_read=True, coverage=False, unique=False, seg_read=None, n_reads=None):
         self.upload(bases, offsets, seg_read, n_reads)

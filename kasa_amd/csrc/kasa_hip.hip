@@ -344,7 +344,7 @@ static int index_create_impl(int device, const void *records, uint64_t nRecords,
     TRY(ix->tax.reserve(n * 4));
     TRY(ix->meta.reserve(n * sizeof(Meta)));
     TRY(bad.reserve(16));
-    TRYHIP(hipMemcpy(raw.p, records, n * REC, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(raw.p, records, n * REC, hipMemcpyDefault));        // host memory (e.g. the mmap'ed index file) or device memory
     TRYHIP(hipMemset(bad.p, 0, 16));
     unpack_records_kernel<Key><<<blocks_for(n, 256), 256>>>(raw.as<uint8_t>(), n, ix->kmer.as<Key>(), ix->tax.as<uint32_t>());
     index_check_kernel<Key><<<blocks_for(n, 256), 256>>>(ix->kmer.as<Key>(), ix->tax.as<uint32_t>(), n, bad.as<uint32_t>());
@@ -470,6 +470,7 @@ struct kasa_ctx {
     DevBuf sortBig;                            // heads / begins / ends of the long buckets (sort_and_range)
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
+    DevBuf tileChunks;                         // tile_suffix: minima of chunks of 1024 tiles
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // event records, recWords() u32 each, by slot
     DevBuf pool, plist, sortTmp, misc;         // taxon segment lists, positions by read (slot fix-up), rocPRIM temp, counters
@@ -493,6 +494,8 @@ struct kasa_ctx {
     StageTimer kernels[KASA_KERNEL_COUNT];      // single kernels timed alone (kasa_ctx_kernel_ms)
     uint64_t lastStaged = 0, lastKeys = 0, lastContrib = 0;   // of the last batch: staging records, profile keys, (event, taxon) contributions
     DevBuf rawOff;                             // the caller's sequence offsets as uploaded
+    DevBuf cohLen, cohState;                   // kasa_batch_coherence: match length of every emitted k-mer; walk state per chunk of reads + scores
+    uint64_t nEmitted = 0; bool uniqueDone = false, readsUploaded = false;   // k-mers the encoder emitted (nQ shrinks with -e); -e was applied to this batch
 };
 
 static int timer_begin(kasa_ctx *c, StageTimer &t, hipEvent_t *a, hipEvent_t *b)
@@ -601,10 +604,10 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     (void)hipSetDevice(c->device); // the index may already be gone: never touch it here
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                      &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                     &c->rawOff, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
+                     &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
         for (auto &pr : t.open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -702,7 +705,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
         (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)) || (rc = c->seqOff.reserve(((size_t)nSeq + 1) * 8)) ||
         (rc = c->seqRead.reserve((size_t)nSeq * 4 + 64)) || (rc = c->rawOff.reserve(((size_t)nSeq + 1) * 8)))
         return rc;
-    if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyHostToDevice, c->stream));
+    if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyDefault, c->stream));   // `bases` may live in device memory (a host that keeps its reads in HBM)
     HIPCHK(hipMemcpyAsync(c->rawOff.p, offsets, ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
     c->haveSeqRead = seqRead != nullptr;
     if (seqRead && nSeq) HIPCHK(hipMemcpyAsync(c->seqRead.p, seqRead, (size_t)nSeq * 4, hipMemcpyHostToDevice, c->stream));
@@ -736,7 +739,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
         return fail(KASA_E_ARG, "kasa_batch_upload: sequence %lld names read %u (reads: %lld, ids must ascend)", (long long)sq, seqRead ? seqRead[sq] : (uint32_t)sq, (long long)nReads);
     }
     if (run >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: %llu k-mers exceed the 32-bit position range of one batch; split the batch", (unsigned long long)run);
-    c->nQ = run; c->nBases = nBases; c->maxCnt = hFlags[1];
+    c->nQ = run; c->nEmitted = run; c->uniqueDone = false; c->readsUploaded = true; c->nBases = nBases; c->maxCnt = hFlags[1];
     c->state = 1;
     return KASA_OK;
 }
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                     for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
-                    if (rankSlots) sKey[wv][s * (int)cnt + (int)w0 + i] = v;   // (--one: several chunks per strand; strands * cnt <= ENC_RANK_MAX)
+                    if (rankSlots) sKey[wv][s * (int)cnt + (int)w0 + i] = v << KeyTraits<Key>::SHIFT;   // (--one: several chunks per strand; strands * cnt <= ENC_RANK_MAX)
                     else outRead[o] = rid;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -849,18 +852,24 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
         }
         if (rankSlots) {
             // rank = k-mers of the read that are smaller; every lane holds up to ENC_RANK_MAX / 64 of them and compares them
-            // with each of the read's k-mers (one broadcast LDS read per k-mer).  Equal k-mers share that count: they are
-            // told apart by their index afterwards (rare: a read repeating one of its own k-mers).
+            // with each of the read's k-mers (one broadcast LDS read per k-mer).  The keys wait in LDS shifted to the top of
+            // their word, and the count runs over their TOP HALVES only (one 32-bit compare and one add with carry per pair
+            // for 64-bit keys; a 64-bit compare for 128-bit ones): two k-mers of one read that share their first six (twelve)
+            // letters are rare.  k-mers that end up with the same count -- equal top halves -- are counted again in full,
+            // equal k-mers told apart by their index (window order, as the stable sort would leave them).
+            typedef typename std::conditional<sizeof(Key) == 8, uint32_t, uint64_t>::type Half;
+            constexpr int HSH = 8 * (sizeof(Key) - sizeof(Half));
             const int n = strands * (int)cnt;
             constexpr int PER = ENC_RANK_MAX / 64;
-            Key mine[PER];
+            Half mine[PER];
             uint32_t rank[PER];
 #pragma unroll
-            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; mine[q] = i < n ? sKey[wv][i] : (Key)0; rank[q] = 0; if (i < n) sTaken[wv][i] = 0; }
+            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; mine[q] = i < n ? (Half)(sKey[wv][i] >> HSH) : (Half)0; rank[q] = 0; if (i < n) sTaken[wv][i] = 0; }
             const int groups = (n + 63) / 64;                        // items per lane that exist at all (uniform)
+            const Half *sHalf = reinterpret_cast<const Half *>(&sKey[wv][0]) + 1;   // little endian: the top half is the second one
             auto count = [&](auto G) {                               // the loop for G items per lane
                 for (int j = 0; j < n; ++j) {
-                    const Key kj = sKey[wv][j];
+                    const Half kj = sHalf[2 * j];
 #pragma unroll
                     for (int q = 0; q < decltype(G)::value; ++q) rank[q] += (kj < mine[q]) ? 1u : 0u;
                 }
@@ -883,8 +892,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
                 const int i = lane + 64 * q;
                 if (i >= n) continue;
                 uint32_t rk = rank[q];
-                if (sTaken[wv][rk] > 1u)                              // equal k-mers: window order decides, as in a stable sort
-                    for (int j = 0; j < i; ++j) rk += (sKey[wv][j] == mine[q]) ? 1u : 0u;
+                if (sTaken[wv][rk] > 1u) {                            // equal top halves: the whole keys, then the index
+                    const Key me = sKey[wv][i];
+                    rk = 0;
+                    for (int j = 0; j < n; ++j) { const Key kj = sKey[wv][j]; rk += (kj < me || (kj == me && j < i)) ? 1u : 0u; }
+                }
                 outRead[o0 + (uint64_t)i] = (uint32_t)(o0 + rk);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1177,32 +1189,80 @@ __global__ __launch_bounds__(TILE_THREADS) void lookup_tile_kernel(
     if (tid < nK) tileFirst[(size_t)tid * nTiles + blockIdx.x] = sFirst[tid];
 }
 
-// tileNext[lv][t] = first special position in any tile after t (or nQ)
-__global__ void tile_suffix_kernel(const uint32_t *__restrict__ tileFirst, uint32_t *__restrict__ tileNext,
-                                   uint32_t nTiles, uint32_t nQ)
+// tileNext[lv][t] = first special position in any tile after t (or nQ): a suffix minimum over the tiles of a level, in
+// three small steps -- inside chunks of 1024 tiles (one workgroup each), over the chunk minima (one workgroup per level,
+// serial over its chunks), and the two combined.  (One workgroup per level walking all 1.3 M tiles of a 10 M-read batch
+// took 2.2 ms.)
+__device__ __forceinline__ void suffix_min_1024(uint32_t *sh, uint32_t v, uint32_t &excl, uint32_t &all)
+{
+    // threads hold the values in REVERSED order (thread 0 = last element): an inclusive min-scan, then shifted by one
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t o = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : NOPOS;
+        __syncthreads();
+        if (o < sh[threadIdx.x]) sh[threadIdx.x] = o;
+        __syncthreads();
+    }
+    excl = (threadIdx.x == 0) ? NOPOS : sh[threadIdx.x - 1];
+    all = sh[1023];
+    __syncthreads();
+}
+
+// grid (chunks, levels): out = minimum over the later tiles of the same chunk (NOPOS: none), chunkMin = the chunk's minimum
+__global__ __launch_bounds__(1024) void tile_suffix_local_kernel(const uint32_t *__restrict__ tileFirst, uint32_t *__restrict__ tileNext,
+                                                                 uint32_t *__restrict__ chunkMin, uint32_t nTiles, uint32_t nChunks)
+{
+    __shared__ uint32_t sh[1024];
+    const uint32_t lv = blockIdx.y, chunk = blockIdx.x;
+    const uint64_t end = std::min<uint64_t>((uint64_t)(chunk + 1) * 1024u, nTiles);
+    const int64_t t = (int64_t)end - 1 - threadIdx.x;                 // thread 0 takes the last tile of the chunk
+    const bool in = t >= (int64_t)chunk * 1024;
+    uint32_t excl, all;
+    suffix_min_1024(sh, in ? tileFirst[(size_t)lv * nTiles + t] : NOPOS, excl, all);
+    if (in) tileNext[(size_t)lv * nTiles + t] = excl;
+    if (threadIdx.x == 0) chunkMin[(size_t)lv * nChunks + chunk] = all;
+}
+
+// one workgroup per level: chunkNext[c] = minimum over the chunks after c, or `last` (the number of queries)
+__global__ __launch_bounds__(1024) void tile_suffix_kernel(const uint32_t *__restrict__ in0, uint32_t *__restrict__ out0,
+                                                           uint32_t n, uint32_t last)
 {
     __shared__ uint32_t sh[1024];
     const int lv = blockIdx.x;
-    const uint32_t *in = tileFirst + (size_t)lv * nTiles;
-    uint32_t *out = tileNext + (size_t)lv * nTiles;
-    uint32_t carry = nQ;
-    for (int64_t hiT = (int64_t)nTiles; hiT > 0; hiT -= 1024) {
-        const int64_t t = hiT - 1 - threadIdx.x;                    // thread 0 takes the last tile of the chunk
-        uint32_t v = (t >= 0) ? in[t] : NOPOS;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive min-scan in reversed order
-            uint32_t o = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : NOPOS;
-            __syncthreads();
-            if (o < sh[threadIdx.x]) sh[threadIdx.x] = o;
-            __syncthreads();
-        }
-        const uint32_t excl = (threadIdx.x == 0) ? NOPOS : sh[threadIdx.x - 1];
+    const uint32_t *in = in0 + (size_t)lv * n;
+    uint32_t *out = out0 + (size_t)lv * n;
+    uint32_t carry = last;
+    for (int64_t hiT = (int64_t)n; hiT > 0; hiT -= 1024) {
+        const int64_t t = hiT - 1 - threadIdx.x;
+        uint32_t excl, all;
+        suffix_min_1024(sh, (t >= 0) ? in[t] : NOPOS, excl, all);
         if (t >= 0) out[t] = excl < carry ? excl : carry;
-        const uint32_t all = sh[1023];
-        __syncthreads();
         if (all < carry) carry = all;
     }
+}
+
+__global__ void tile_suffix_apply_kernel(uint32_t *__restrict__ tileNext, const uint32_t *__restrict__ chunkNext, uint32_t nTiles, uint32_t nChunks)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lv = blockIdx.y;
+    if (t >= nTiles) return;
+    const size_t at = (size_t)lv * nTiles + t;
+    if (tileNext[at] == NOPOS) tileNext[at] = chunkNext[(size_t)lv * nChunks + (t >> 10)];   // positions ascend with the tile: a later chunk never undercuts this one
+}
+
+// tileFirst -> tileNext for all levels
+static int tile_suffix(kasa_ctx *c, uint32_t nTiles)
+{
+    if (nTiles == 0) return KASA_OK;
+    const uint32_t nChunks = (nTiles + 1023u) / 1024u;
+    int rc = c->tileChunks.reserve((size_t)2 * c->nK * nChunks * 4 + 64);
+    if (rc) return rc;
+    uint32_t *chunkMin = c->tileChunks.as<uint32_t>(), *chunkNext = chunkMin + (size_t)c->nK * nChunks;
+    tile_suffix_local_kernel<<<dim3(nChunks, (unsigned)c->nK), 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), chunkMin, nTiles, nChunks);
+    tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(chunkMin, chunkNext, nChunks, (uint32_t)c->nQ);
+    tile_suffix_apply_kernel<<<dim3(blocks_for(nTiles, 256), (unsigned)c->nK), 256, 0, c->stream>>>(c->tileNext.as<uint32_t>(), chunkNext, nTiles, nChunks);
+    HIPCHK(hipGetLastError());
+    return KASA_OK;
 }
 
 template <class Key>
@@ -1478,7 +1538,7 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         uint32_t kept = 0;
         HIPCHK(hipMemcpyAsync(&kept, slot + (nQ - 1), 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        nQ = c->nQ = kept;
+        nQ = c->nQ = kept; c->uniqueDone = true;
         // back into the "sorted" buffers: later stages reuse the A buffers as scratch
         HIPCHK(hipMemcpyAsync(c->qKmerB.p, c->qKmerA.p, nQ * sizeof(Key), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->qReadB.p, c->qReadA.p, nQ * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -1525,8 +1585,7 @@ static int lookup_part(kasa_ctx *c)
         }
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_LOOKUP], ka, kb))) return rc;
-        tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)nQ);
-        HIPCHK(hipGetLastError());
+        if ((rc = tile_suffix(c, nTiles))) return rc;
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_LOOKUP], a, b))) return rc;
     c->state = 3;
@@ -2517,26 +2576,47 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         // ---- B. their chains, query by query.  All lanes step together (the pool segments of the 64 current queries are
         // dealt out to the lanes: one dependent pool read per step instead of one per segment of the longest list).
         sPT0[lane] = mTax0; sPT1[lane] = mTax1;
-        uint32_t maxCnt = (active && !fb) ? cnt0 : 0u;
+        // A lane streams its read's records a whole 128-byte LINE at a time (4 narrow records, 2 wide ones), line-aligned:
+        // the loads of a line leave together and nothing of it is fetched twice -- one record per step left every line to be
+        // fetched again for the following steps unless a cache kept it (measured: 2-4 x the records' bytes from HBM).  A read
+        // begins `ph` records into its first line; those steps are idle for the lane.  The next line is on its way while
+        // this one is replayed.
+        constexpr uint32_t LN = 32u / (uint32_t)RW, LW = LN * (RW / 4);        // records, 16-byte words of a line
+        const uint32_t ph = (uint32_t)(o0 & (uint64_t)(LN - 1u));
+        const uint4 *lp0 = rp0 - (size_t)ph * (RW / 4);
+        const uint32_t kEnd = (active && !fb) ? cnt0 + ph : 0u;               // this lane's steps: ph .. kEnd - 1
+        uint32_t maxCnt = kEnd;
         for (int off = 32; off; off >>= 1) maxCnt = max(maxCnt, (uint32_t)__shfl_xor((int)maxCnt, off));
         {
             uint32_t prevF = 0;
-            uint4 nxt[RW / 4];
+            uint4 cur[LW], nxt[LW];
+            auto loadLine = [&](uint32_t g) {                                  // records g LN .. g LN + LN - 1 of the lane's lines
 #pragma unroll
-            for (int i = 0; i < RW / 4; ++i) nxt[i] = make_uint4(0, 0, 0, 0);
-            if (active && !fb && cnt0 > 0) {
+                for (uint32_t r2 = 0; r2 < LN; ++r2) {
+                    const uint32_t k = g * LN + r2;
+                    const bool mineRec = !fb && k >= ph && k < kEnd;
 #pragma unroll
-                for (int i = 0; i < RW / 4; ++i) nxt[i] = rp0[i];
-            }
-            for (uint32_t j = 0; j < maxCnt; ++j) {
-                const bool has = active && !fb && j < cnt0;
+                    for (uint32_t i = 0; i < (uint32_t)(RW / 4); ++i)
+                        nxt[r2 * (RW / 4) + i] = mineRec ? lp0[(size_t)k * (RW / 4) + i] : make_uint4(0, 0, 0, 0);
+                }
+            };
+            loadLine(0);
+            for (uint32_t g = 0; g * LN < maxCnt; ++g) {
+#pragma unroll
+            for (uint32_t i = 0; i < LW; ++i) cur[i] = nxt[i];
+            if ((g + 1u) * LN < maxCnt) loadLine(g + 1u);
+            for (uint32_t kk = 0; kk < LN; ++kk) {
+                const uint32_t k = g * LN + kk, j = k - ph;
+                const bool has = active && !fb && k >= ph && k < kEnd;
                 uint4 v[RW / 4];
 #pragma unroll
-                for (int i = 0; i < RW / 4; ++i) v[i] = nxt[i];
-                if (active && !fb && j + 1u < cnt0) {                          // the next record is on its way while this one is replayed
+                for (int i = 0; i < RW / 4; ++i) v[i] = cur[i];
 #pragma unroll
-                    for (int i = 0; i < RW / 4; ++i) nxt[i] = rp0[(size_t)(j + 1u) * (RW / 4) + i];
-                }
+                for (uint32_t r2 = 1; r2 < LN; ++r2)
+                    if (kk == r2) {                                            // (uniform)
+#pragma unroll
+                        for (int i = 0; i < RW / 4; ++i) v[i] = cur[r2 * (RW / 4) + i];
+                    }
                 if (has && ((o0 + j) & 63u) == 0u) A.otherOff64[(o0 + j) >> 6] = nOther;   // for score_other_kernel: the count so far at a wavefront's first slot
                 bool live = has && (v[0].z & 31u) != 0u;
                 if (!live) {
@@ -2629,6 +2709,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                         cnt[NL + lv][lane] += in1 ? one : (Counter)0;
                     } else { nOther += in0 + in1; nKeys += in0 + in1; }       // a profile record, written by score_other_kernel
                 }
+            }
             }
         }
         // ---- the read's staging row: final scores of the register taxa, their counters as profile records, then room
@@ -4196,8 +4277,7 @@ static int import_tail(kasa_ctx *c, uint64_t nRecordWords, uint64_t nPoolWords)
         const uint32_t nTiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
         if (c->ix->wide) tile_first_kernel<key128><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->kHigh, c->kLow, c->tileFirst.as<uint32_t>(), nTiles);
         else tile_first_kernel<uint64_t><<<nTiles, TILE_THREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->kHigh, c->kLow, c->tileFirst.as<uint32_t>(), nTiles);
-        tile_suffix_kernel<<<c->nK, 1024, 0, c->stream>>>(c->tileFirst.as<uint32_t>(), c->tileNext.as<uint32_t>(), nTiles, (uint32_t)c->nQ);
-        HIPCHK(hipGetLastError());
+        { int rc2 = tile_suffix(c, nTiles); if (rc2) return rc2; }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->poolUsed = (uint32_t)std::max<uint64_t>(1, nPoolWords);
@@ -4260,7 +4340,7 @@ extern "C" int kasa_batch_set_sorted_device(kasa_ctx *c, const void *kmersDev, u
     int rc;
     if ((rc = c->qKmerB.reserve(n * c->keyBytes() + 64))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c->qKmerB.p, kmersDev, n * c->keyBytes(), hipMemcpyDefault, c->stream));   // same device or a peer's memory
-    c->nReads = 0; c->nSeq = 0; c->nQ = n; c->maxCnt = 0;
+    c->nReads = 0; c->nSeq = 0; c->nQ = n; c->maxCnt = 0; c->readsUploaded = false;
     c->qKmer = c->qKmerB.p; c->qRead = nullptr;
     rc = c->ix->wide ? lookup_part<key128>(c) : lookup_part<uint64_t>(c);
     if (rc) return rc;
@@ -4285,8 +4365,9 @@ extern "C" int kasa_batch_records_device(kasa_ctx *c, const uint32_t **records, 
 }
 
 // records of one slice into the batch: sorted positions move by the slice start, pool offsets by the pool base
+// (in == out when the records were received in the inbox itself: a thread reads its whole record before it writes it)
 template <int RW>
-__global__ void shift_records_kernel(const uint4 *__restrict__ in, uint32_t n, uint32_t start, uint32_t poolShift, uint4 *__restrict__ out)
+__global__ void shift_records_kernel(const uint4 *in, uint32_t n, uint32_t start, uint32_t poolShift, uint4 *out)
 {
     typedef RecTraits<RW> RT;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -4301,6 +4382,16 @@ __global__ void shift_records_kernel(const uint4 *__restrict__ in, uint32_t n, u
     if (matched && nseg > (uint32_t)RT::INL) v[RW / 4 - 1].w += poolShift;
 #pragma unroll
     for (int w = 0; w < RW / 4; ++w) out[(size_t)p * (RW / 4) + w] = v[w];
+}
+
+extern "C" int kasa_batch_records_inbox(kasa_ctx *c, uint64_t nRecordWords, uint32_t **records)
+{
+    if (!c || !records) return fail(KASA_E_ARG, "kasa_batch_records_inbox: NULL argument");
+    HIPCHK(hipSetDevice(c->ix->device));
+    int rc = c->recIn.reserve(nRecordWords * 4 + 64);
+    if (rc) return rc;
+    *records = c->recIn.as<uint32_t>();
+    return KASA_OK;
 }
 
 extern "C" int kasa_batch_records_import_device(kasa_ctx *c, uint32_t nParts, const uint32_t *const *records, const uint64_t *nRecordWords,
@@ -4702,6 +4793,214 @@ extern "C" int kasa_batch_rank_fetch(kasa_ctx *c, uint32_t *meta, void *entries)
     return KASA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// --coherence (Compare::postProcess, Compare.hpp:2607-2728)
+// ------------------------------------------------------------------------------------------------
+// The reference sorts the batch's k-mers by (read, strand, window) -- the order the encoder emits them in -- and walks
+// them ONCE with a little state machine: per read and strand the clusters of overlapping matches (match length = deepest
+// matched level of the k-mer, what setMatchLength leaves, Compare.hpp:847-948), score = overlap + 1 - 1 / (times the
+// largest overlap occurred), the read keeps the maximum.  The walk carries its read counter itself instead of reading it
+// off the elements: a read without k-mers is credited with the first element of its successor, and after a strand switch
+// the search for the next match runs on into the following reads.  So where the walk stands when read r's turn begins
+// (its ENTRY) depends on the reads before -- but only through that one number: every turn begins with a fresh state.
+//
+// Here: (1) the reads are encoded once more in emission order and every k-mer's depth is looked up on its own;
+// (2) chunks of COH_CHUNK reads are walked in parallel, one thread each, from the entry they would have if the chunk before
+// them ended at its last element (the common case); (3) every chunk then compares its entry with the exit its predecessor
+// really reached and walks again if they differ, until nothing changes (a round or two: a walk forgets its entry as soon
+// as it has seen a match).  The statements of the walk are the reference's, in its order.
+static constexpr uint32_t COH_CHUNK = 64;
+static constexpr unsigned long long COH_NONE = ~0ull;
+
+template <class Key>
+__global__ void coh_depth_kernel(const Key *__restrict__ q, uint64_t nQ, const Key *__restrict__ idxKmer, uint32_t nIdx,
+                                 const uint32_t *__restrict__ table, int tb, int kHigh, int kLow, uint8_t *__restrict__ len,
+                                 unsigned long long *__restrict__ firstMatch)
+{
+    const uint64_t o = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (o >= nQ) return;
+    const Key k = q[o];
+    const uint32_t lo = lower_bound_global<Key>(idxKmer, table, tb, k);
+    const int la = (lo < nIdx) ? lcp_letters<Key>(k, idxKmer[lo]) : 0;
+    const int lb = (lo > 0) ? lcp_letters<Key>(k, idxKmer[lo - 1]) : 0;
+    int L = la >= lb ? la : lb, d = 0;
+    if (L >= RANGE_LETTERS) {                                          // as lookup_kernel: the 6-letter prefix exists, '^' ends the query
+        if (L > kHigh) L = kHigh;
+        d = L;
+        for (int kk = kLow; kk <= L; ++kk)
+            if (((uint32_t)(k >> (5 * (KeyTraits<Key>::LETTERS - kk))) & 31u) == 30u) { d = kk - 1; break; }
+        if (d < kLow) d = 0;
+    }
+    len[o] = (uint8_t)d;
+    if (d) atomicMin(firstMatch, (unsigned long long)o);
+}
+
+// where the walk stands among the emitted k-mers: element idx, the read it belongs to and that read's k-mers
+struct CohCursor {
+    const uint64_t *off; uint32_t nReads; uint32_t strands;
+    uint64_t idx, n;
+    uint32_t er; uint64_t eStart, eEnd; uint32_t per;                  // read of element idx: its elements eStart .. eEnd - 1, `per` per strand
+    __device__ void seek(uint64_t at)
+    {
+        idx = at;
+        if (at >= n) return;
+        uint32_t lo = 0, hi = nReads;                                 // last read whose elements start at or before `at`
+        while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (off[mid] <= at) lo = mid; else hi = mid; }
+        er = lo; eStart = off[er]; eEnd = off[er + 1]; per = (uint32_t)((eEnd - eStart) / strands);
+    }
+    __device__ void next()
+    {
+        ++idx;
+        while (idx >= eEnd && idx < n) { ++er; eStart = eEnd; eEnd = off[er + 1]; per = (uint32_t)((eEnd - eStart) / strands); }
+    }
+    __device__ uint32_t read() const { return er; }
+    __device__ uint32_t frame() const { return (uint32_t)(idx - eStart) >= per ? 1u : 0u; }
+    __device__ uint32_t pos() const { const uint32_t w = (uint32_t)(idx - eStart); return w >= per ? w - per : w; }
+};
+
+// turns of the reads r0 .. r1 - 1 from `entry`; the first-match turn (rid == firstRead) starts behind the first match
+// with its end remembered (Compare.hpp:2637-2648).  Returns the exit (entry of read r1); fail: the reference's
+// vector::at would throw (Compare.hpp:2667 with the index at the end of the batch).
+__device__ unsigned long long coh_walk(CohCursor &C, const uint8_t *__restrict__ len, uint32_t r0, uint32_t r1, unsigned long long entry,
+                                      uint32_t firstRead, unsigned long long firstIdx, uint32_t firstLast, bool six,
+                                      float *__restrict__ scores, bool &fail)
+{
+    fail = false;
+    for (uint32_t r = r0; r < r1; ++r) scores[r] = 0.0f;
+    if (firstIdx == COH_NONE || r1 <= firstRead) return entry;         // no match at all, or none before this chunk ends: no turn
+    uint32_t rid = r0, last = 0xFFFFFFFFu, cur = 0, cnt = 0;
+    if (r0 <= firstRead) { rid = firstRead; last = firstLast; entry = firstIdx + 1ull; }
+    C.seek(entry);
+    auto det = [&](uint32_t nx) { if (nx > cur) { cur = nx; cnt = 1; } else if (nx == cur) cnt++; };              // :2653-2662
+    auto cluster = [&]() { const float v = __fsub_rn(__fadd_rn((float)cur, 1.0f), __fdiv_rn(1.0f, (float)cnt)); if (scores[rid] < v) scores[rid] = v; };
+    for (; rid < r1 && C.idx < C.n; ++rid) {                           // :2665
+        for (uint32_t fb = 0; fb < (six ? 2u : 1u);) {                 // :2667
+            if (C.idx >= C.n) { fail = true; return C.n; }
+            const uint32_t ml = len[C.idx];
+            if (ml != 0u) {
+                const uint32_t ps = C.pos();
+                if (ps <= last) {
+                    if (ps + ml < last) det(ml);
+                    else det((uint32_t)((int32_t)last - (int32_t)ps));
+                } else { cluster(); cur = 0; }
+                last = ps + ml;
+            }
+            C.next();
+            if (C.idx == C.n) { cluster(); break; }
+            if (C.read() != rid) { cluster(); last = 0xFFFFFFFFu; cur = 0; cnt = 0; break; }
+            if (C.frame() != fb) {
+                cluster();
+                cur = 0; cnt = 0;
+                ++fb;
+                while (C.idx < C.n) {
+                    const uint32_t m2 = len[C.idx];
+                    if (m2 != 0u) { last = C.pos() + m2; C.next(); break; }
+                    C.next();
+                }
+            }
+        }
+    }
+    return C.idx;
+}
+
+// round 0: every chunk from its own first element; later rounds: the chunks whose predecessor left somewhere else
+__global__ void coh_chunk_kernel(const uint8_t *__restrict__ len, const uint64_t *__restrict__ kmerOff, uint32_t nReads, uint64_t nQ, uint32_t strands,
+                                 const unsigned long long *__restrict__ firstMatch, int round, unsigned long long *__restrict__ entryUsed,
+                                 unsigned long long *__restrict__ exitIdx, uint32_t *__restrict__ failed, float *__restrict__ scores,
+                                 uint32_t *__restrict__ changed)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nChunks = (nReads + COH_CHUNK - 1) / COH_CHUNK;
+    if (t >= nChunks) return;
+    const uint32_t r0 = t * COH_CHUNK, r1 = min(r0 + COH_CHUNK, nReads);
+    unsigned long long entry = kmerOff[r0];
+    if (round > 0) {
+        if (t == 0) return;
+        entry = exitIdx[t - 1];
+        if (entry == entryUsed[t]) return;
+    }
+    CohCursor C;
+    C.off = kmerOff; C.nReads = nReads; C.strands = strands; C.n = nQ; C.idx = 0; C.er = 0; C.eStart = 0; C.eEnd = 0; C.per = 0;
+    const unsigned long long firstIdx = *firstMatch;
+    uint32_t firstRead = 0, firstLast = 0;
+    if (firstIdx != COH_NONE) { C.seek(firstIdx); firstRead = C.read(); firstLast = C.pos() + len[firstIdx]; }
+    bool fail;
+    const unsigned long long ex = coh_walk(C, len, r0, r1, entry, firstRead, firstIdx, firstLast, strands == 2u, scores, fail);
+    entryUsed[t] = entry;
+    if (round > 0 && (ex != exitIdx[t] || (uint32_t)fail != failed[t])) atomicAdd(changed, 1u);
+    else if (round > 0) atomicAdd(changed + 1, 1u);                    // walked again, same exit
+    exitIdx[t] = ex;
+    failed[t] = fail ? 1u : 0u;
+}
+
+__global__ void coh_any_kernel(const uint32_t *__restrict__ failed, uint32_t n, uint32_t *__restrict__ any)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && failed[t]) atomicOr(any, 1u);
+}
+
+extern "C" int kasa_batch_coherence(kasa_ctx *c, float *scores, uint64_t *throwsAt)
+{
+    if (!c || !scores || !throwsAt) return fail(KASA_E_ARG, "kasa_batch_coherence: NULL argument");
+    *throwsAt = ~0ull;
+    if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_coherence: batch not sorted");
+    if (c->haveSeqRead) return fail(KASA_E_ARG, "kasa_batch_coherence: paired-end input is not supported (the reference's result depends on its unstable sort of the mates' k-mers)");
+    if (c->uniqueDone) return fail(KASA_E_ARG, "kasa_batch_coherence: not together with -e (the reference's result depends on which duplicates its unstable sort leaves)");
+    if (!c->readsUploaded || c->nSeq != c->nReads) return fail(KASA_E_STATE, "kasa_batch_coherence: the batch was not uploaded as reads");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t nReads = (uint32_t)c->nReads;
+    if (nReads == 0) return KASA_OK;
+    // (1) the k-mers once more, in emission order (the sort has consumed them), and the depth of each
+    const uint64_t nE = c->nEmitted;
+    int rc;
+    if ((rc = c->qKmerA.reserve(nE * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nE * 4 + 64)) || (rc = c->cohLen.reserve(nE + 64))) return rc;
+    const uint32_t nChunks = (nReads + COH_CHUNK - 1) / COH_CHUNK;
+    if ((rc = c->cohState.reserve((size_t)nChunks * 20 + (size_t)nReads * 4 + 256))) return rc;
+    unsigned long long *entryUsed = c->cohState.as<unsigned long long>(), *exitIdx = entryUsed + nChunks;
+    uint32_t *failed = reinterpret_cast<uint32_t *>(exitIdx + nChunks);
+    float *dScores = reinterpret_cast<float *>(failed + nChunks + (nChunks & 1u));
+    unsigned long long *firstMatch = c->misc.as<unsigned long long>() + 26;
+    uint32_t *changed = c->misc.as<uint32_t>() + 54;                                   // [54] changed exits, [55] same exits, [56] any failure
+    HIPCHK(hipMemsetAsync(firstMatch, 0xFF, 8, c->stream));
+    HIPCHK(hipMemsetAsync(changed, 0, 12, c->stream));
+    if (nE > 0) {
+        const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
+        if (c->ix->wide) {
+            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
+                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0);
+            coh_depth_kernel<key128><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<key128>(), nE, c->ix->kmer.as<key128>(), (uint32_t)c->ix->n,
+                c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
+        } else {
+            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
+                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0);
+            coh_depth_kernel<uint64_t><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<uint64_t>(), nE, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
+                c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // (2), (3) the walk: all chunks, then the chunks whose entry was not what their predecessor left, until none is
+    const uint64_t *emitOff = c->seqOff.as<uint64_t>();                                // k-mers before every read, as emitted (kmerOff follows -e)
+    for (int round = 0;; ++round) {
+        coh_chunk_kernel<<<blocks_for(nChunks, 64), 64, 0, c->stream>>>(c->cohLen.as<uint8_t>(), emitOff, nReads, nE, (uint32_t)c->strands(), firstMatch, round,
+                                                                        entryUsed, exitIdx, failed, dScores, changed);
+        HIPCHK(hipGetLastError());
+        if (round == 0) continue;                                                      // (round 1 compares with round 0's exits)
+        uint32_t h[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h, changed, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemsetAsync(changed, 0, 8, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (h[0] == 0u) break;                                                         // every recomputed chunk left where it had left before
+        if (round > (int)nChunks + 2) return fail(KASA_E_LIMIT, "kasa_batch_coherence: the walk did not settle");
+    }
+    coh_any_kernel<<<blocks_for(nChunks, 256), 256, 0, c->stream>>>(failed, nChunks, changed + 2);
+    uint32_t anyFail = 0;
+    HIPCHK(hipMemcpyAsync(&anyFail, changed + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(scores, dScores, (size_t)nReads * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (anyFail) *throwsAt = nE;
+    return KASA_OK;
+}
+
 // Page-locked host memory for the buffers that cross PCIe (reads in, ranked hits or CSR out): transfers from pageable
 // memory are staged by the runtime at a fraction of the link rate.
 extern "C" void *kasa_host_alloc(size_t bytes)
@@ -5000,7 +5299,7 @@ static int batch_set_queries_impl(kasa_ctx *c, const void *kmers, const uint32_t
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->readsUploaded = false;
     std::vector<uint64_t> koff((size_t)nReads + 1, 0);
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -5045,10 +5344,10 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 {
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->rec, &c->pool, &c->plist, &c->sortTmp,
+                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                            &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                           &c->rawOff, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
+                           &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;

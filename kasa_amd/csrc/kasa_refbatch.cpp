@@ -97,7 +97,7 @@ extern "C" int kasa_refbatch_budget(const kasa_refbatch_params *p, int64_t *budg
 // What one sequence (a read, or one mate of a pair) takes from the budget (Read.hpp:612-630): per strand its k-mer records
 // and its padded text.  The geometry is the reader's: padding to K letters (Read.hpp:633-654), marker of (K - kLow)
 // letters (Read.hpp:1068-1078), k-mer count (Read.hpp:36-57).  mode: 0 = DNA in 3 or 6 frames, 1 = --one, 2 = amino acids.
-extern "C" int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int64_t rawLen)
+extern "C" int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int64_t rawLen, int coherence)
 {
     const int64_t k = K, unit = mode == 2 ? 1 : 3;
     const int64_t marker = unit * (k - (int64_t)kLow);
@@ -108,16 +108,18 @@ extern "C" int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int st
     if (mode == 2) cnt = L > k + 1 ? L - k + 1 : 0;
     else if (mode == 1) { const int64_t t = L / 3; cnt = t > k + 1 ? t - k + 1 : 0; }
     else cnt = L > 3 * k + 1 ? L - 3 * k + 1 : 0;
-    const int64_t elem = K > 12 ? 32 : 24;                                            // sizeof(InputType::staTuple), MetaHeader.h:167-173
+    // sizeof(InputType::staTuple) = tuple<u64, intType, u32, u32>, or with --coherence sizeof(ppTuple) = tuple<u64, intType, u32,
+    // u32, u32, u8> (MetaHeader.h:167-173,222); intType = u64 or the two-word uint128_t
+    const int64_t elem = coherence ? (K > 12 ? 40 : 32) : (K > 12 ? 32 : 24);
     return (int64_t)strands * (cnt * elem + L + 16);
 }
 
 // ... and what the read as a whole takes when per-read results are kept (-q or --filter; Read.hpp:1165-1195): its entry in
 // vReadNameAndLength and its row of the score matrix.  nameLen = header without its first character plus one space
 // (paired-end: both mates' specifiers).
-extern "C" int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa)
+extern "C" int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa, int coherence)
 {
-    return (int64_t)sizeof(std::pair<std::string, uint32_t>) + nameLen + 4 + (int64_t)nTaxa * 4;
+    return (int64_t)sizeof(std::pair<std::string, uint32_t>) + nameLen + 4 + (int64_t)nTaxa * 4 + (coherence ? 4 : 0);   // Read.hpp:1191-1193
 }
 
 // Number of reads of the next batch: reads are taken while more than 100 MiB of the budget are left (Read.hpp:1147).

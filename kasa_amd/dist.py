@@ -32,6 +32,74 @@ def allreduce_limbs(limbs: np.ndarray, device=None) -> np.ndarray:
     return t.cpu().numpy().astype(np.uint64)
 
 
+class _NcclUniqueId(__import__("ctypes").Structure):
+    _fields_ = [("internal", __import__("ctypes").c_char * 128)]
+
+
+_rccl = None
+
+
+def rccl_lib():
+    """The RCCL library of this process (the one libkasa_hip.so resolved its ncclAllReduce to)."""
+    global _rccl
+    import ctypes as C
+    import os
+    if _rccl is None:
+        err = None
+        cands = ["librccl.so.1", "librccl.so"]
+        try:
+            import torch
+            cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        except Exception:
+            pass
+        cands.append("/opt/rocm/lib/librccl.so")
+        for name in cands:
+            try:
+                _rccl = C.CDLL(name)
+                break
+            except OSError as e:
+                err = e
+        if _rccl is None:
+            raise RuntimeError(f"librccl not found: {err}")
+        _rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        _rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        _rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        _rccl.ncclGetErrorString.restype = C.c_char_p
+    return _rccl
+
+
+def rccl_communicator(rank: int, world: int):
+    """An RCCL communicator of its own for the C ABI (kasa_profile_allreduce(ctx, ncclComm_t)): rank 0 draws the
+    ncclUniqueId, torch.distributed's default group (any backend) carries its 128 bytes to the others, everybody calls
+    ncclCommInitRank on its current device.  -> (comm as int, number of ranks RCCL reports)."""
+    import ctypes as C
+    import torch.distributed as dist
+    L = rccl_lib()
+    uid = _NcclUniqueId()
+    if rank == 0:
+        rc = L.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError("ncclGetUniqueId: " + L.ncclGetErrorString(rc).decode())
+    box = [bytes(uid) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    C.memmove(C.byref(uid), box[0], 128)
+    comm = C.c_void_p()
+    rc = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError("ncclCommInitRank: " + L.ncclGetErrorString(rc).decode())
+    n = C.c_int(0)
+    L.ncclCommCount(comm, C.byref(n))
+    return int(comm.value), int(n.value)
+
+
+def rccl_destroy(comm: int):
+    import ctypes as C
+    if comm:
+        rccl_lib().ncclCommDestroy(C.c_void_p(comm))
+
+
 def all_to_all_arrays(send):
     """send[j] = 1-D numpy array for rank j -> list of the arrays every rank sent to this one (same dtype).
     RCCL (`nccl`) moves them as device tensors with one all_to_all; gloo has no all-to-all, there the same exchange
@@ -84,30 +152,54 @@ def _device_copy(dst: int, src: int, nbytes: int):
         raise RuntimeError(f"hipMemcpy failed ({rc})")
 
 
-def _all_to_all_device(send, send_counts, unit: int):
+def _all_to_all_device(send, send_counts, unit: int, recv=None, recv_counts=None):
     """One all_to_all of byte tensors on the device: send = uint8 tensor holding the slices for rank 0, 1, ... back to
-    back, send_counts[j] = elements of `unit` bytes for rank j.  Returns (recv tensor, counts received from every rank)."""
+    back, send_counts[j] = elements of `unit` bytes for rank j.  Returns (recv tensor, counts received from every rank).
+    recv / recv_counts: a tensor to receive into when the counts are known beforehand (else they are exchanged first)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     dev = send.device
-    mine = torch.tensor(send_counts, dtype=torch.int64, device=dev)
-    theirs = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(theirs, mine)
-    recv_counts = [int(x) for x in theirs.cpu()]
-    recv = torch.empty(sum(recv_counts) * unit, dtype=torch.uint8, device=dev)
+    if recv_counts is None:
+        mine = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        theirs = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(theirs, mine)
+        recv_counts = [int(x) for x in theirs.cpu()]
+    if recv is None:
+        recv = torch.empty(sum(recv_counts) * unit, dtype=torch.uint8, device=dev)
     dist.all_to_all_single(recv, send, [n * unit for n in recv_counts], [n * unit for n in send_counts])
     # The collective only orders torch's current stream behind RCCL's; the library reads `recv` through raw pointers on its
     # own non-blocking stream.  Wait for the data before handing the pointers on (and before `send` can be released).
     torch.cuda.current_stream(dev).synchronize()
-    return recv, recv_counts
+    return recv, list(recv_counts)
 
 
-def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool = True, unique: bool = False):
-    """partitioned_batch with every slice and every record staying in HBM: the sorted k-mers leave through
-    kasa_batch_queries_device, travel in ONE RCCL all_to_all (8 or 16 bytes per query; the read ids stay at home --
-    grouping does not need them), come back as records + pools in two more, and kasa_batch_records_import_device
-    shifts and files them on the device.  Nothing of the exchange touches host memory."""
+class _DevView:
+    """A device pointer as an object torch can wrap without copying (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+
+
+def _device_view(ptr: int, nbytes: int, dev):
+    """uint8 tensor over `nbytes` of device memory at `ptr` (no copy; the owner keeps it alive), or None if torch refuses."""
+    import torch
+    if nbytes == 0:
+        return torch.empty(0, dtype=torch.uint8, device=dev)
+    try:
+        t = torch.as_tensor(_DevView(ptr, nbytes), device=dev)
+        return t if (t.data_ptr() == ptr and t.numel() == nbytes) else None
+    except Exception:
+        return None
+
+
+def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool = True, unique: bool = False, stats=None):
+    """partitioned_batch with every slice and every record staying in HBM: the sorted k-mers travel straight out of the
+    library's buffer (kasa_batch_queries_device) in ONE RCCL all_to_all (8 or 16 bytes per query; the read ids stay at home
+    -- grouping does not need them), the event records come back in a second one straight into the context's inbox
+    (kasa_batch_records_inbox: shifted and filed from there in place), the taxon lists in a third.  Nothing of the
+    exchange touches host memory and no record is copied more often than the collective itself does.
+    stats (dict): bytes this rank sent and received."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size()
@@ -118,32 +210,51 @@ def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool
     ctx.sort_and_range(unique)
     ptr, n, kb = ctx.queries_device()
     starts = ctx.slice_starts(cuts)
-    send = torch.empty(n * kb, dtype=torch.uint8, device=dev)
-    _device_copy(send.data_ptr(), ptr, n * kb)
-    km_in, n_in = _all_to_all_device(send, [int(starts[j + 1] - starts[j]) for j in range(world)], kb)
+    send = _device_view(ptr, n * kb, dev)
+    if send is None:                                              # (a torch without the array interface: one copy)
+        send = torch.empty(n * kb, dtype=torch.uint8, device=dev)
+        _device_copy(send.data_ptr(), ptr, n * kb)
+    out_counts = [int(starts[j + 1] - starts[j]) for j in range(world)]
+    km_in, n_in = _all_to_all_device(send, out_counts, kb)
     del send
     rw = ctx.rec_words * 4
-    recs, pools, rec_counts, pool_counts, at = [], [], [], [], 0
+    total_in = int(sum(n_in))
+    rec_out = torch.empty(total_in * rw, dtype=torch.uint8, device=dev)
+    pools, pool_counts, at = [], [], 0
     for s in range(world):                                        # the slices of every rank, against my partition
         rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s])
-        at += n_in[s]
-        r = torch.empty(nrw * 4, dtype=torch.uint8, device=dev)
+        _device_copy(rec_out.data_ptr() + at * rw, rp, nrw * 4)   # the worker's buffers are reused by the next slice
         p = torch.empty(npw * 4, dtype=torch.uint8, device=dev)
-        _device_copy(r.data_ptr(), rp, nrw * 4)                   # the worker's buffers are reused by the next slice
         _device_copy(p.data_ptr(), pp, npw * 4)
-        recs.append(r); pools.append(p); rec_counts.append(nrw * 4 // rw); pool_counts.append(npw)
-    rec_back, rec_n = _all_to_all_device(torch.cat(recs) if recs else torch.empty(0, dtype=torch.uint8, device=dev), rec_counts, rw)
+        pools.append(p); pool_counts.append(npw)
+        at += n_in[s]
+    del km_in
+    # records: received where kasa_batch_records_import_device files them from (its own staging buffer), shifted in place
+    inbox = ctx.records_inbox(n * ctx.rec_words)
+    rec_recv = _device_view(inbox, n * rw, dev)
+    rec_back, rec_n = _all_to_all_device(rec_out, n_in, rw, recv=rec_recv, recv_counts=out_counts)
+    del rec_out
     pool_back, pool_n = _all_to_all_device(torch.cat(pools) if pools else torch.empty(0, dtype=torch.uint8, device=dev), pool_counts, 4)
+    del pools
     parts, ra, pa = [], 0, 0
     for j in range(world):
         parts.append((rec_back.data_ptr() + ra * rw, rec_n[j] * ctx.rec_words, pool_back.data_ptr() + pa * 4, pool_n[j]))
         ra += rec_n[j]; pa += pool_n[j]
     ctx.records_import_device(parts)
+    if stats is not None:
+        me = dist.get_rank()
+        stats.update({"queries_sent": sum(c for j, c in enumerate(out_counts) if j != me) * kb,
+                      "queries_received": sum(c for j, c in enumerate(n_in) if j != me) * kb,
+                      "records_sent": sum(c for j, c in enumerate(n_in) if j != me) * rw,
+                      "records_received": sum(c for j, c in enumerate(rec_n) if j != me) * rw,
+                      "pool_sent": sum(c for j, c in enumerate(pool_counts) if j != me) * 4,
+                      "pool_received": sum(c for j, c in enumerate(pool_n) if j != me) * 4})
+    del rec_back, pool_back
     ctx.score(want_per_read)
     return ctx
 
 
-def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: bool = True, unique: bool = False):
+def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: bool = True, unique: bool = False, stats=None):
     """One batch against an index that is range-partitioned over the ranks (rank j holds partition j; see
     kasa_amd/partition.py): two exchanges of query slices and two of event records.  Returns `owner_ctx`, scored.
     With RCCL (`nccl`) the exchange is device-resident (partitioned_batch_device); the host-staged form below serves
@@ -151,7 +262,7 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
     import torch.distributed as dist
     from . import partition
     if dist.get_backend() == "nccl":
-        return partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read, unique)
+        return partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read, unique, stats)
     world = dist.get_world_size()
     ctx = owner_ctx
     ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)
@@ -169,6 +280,11 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
         pool_out.append(pool)
     rec_back = all_to_all_arrays(rec_out)
     pool_back = all_to_all_arrays(pool_out)
+    if stats is not None:
+        me = dist.get_rank()
+        stats.update({"queries_sent": sum(int(km[starts[j]:starts[j + 1]].nbytes) for j in range(world) if j != me),
+                      "records_received": sum(int(rec_back[j].nbytes) for j in range(world) if j != me),
+                      "pool_received": sum(int(pool_back[j].nbytes) for j in range(world) if j != me)})
     parts = [(rec_back[j].reshape(-1, ctx.rec_words), pool_back[j]) for j in range(world)]
     rec, pool = partition.assemble_records(parts, starts)
     ctx.records_import(rec, pool)

@@ -9,7 +9,7 @@
 // Modes: identify and identify_multiple (main.cpp:979-1334); --devices a,b,... shards the batches of a file over several GPUs
 // (index replicated, one RCCL all-reduce of the profile tables).  Input is streamed in chunks, batches are cut where the
 // reference cuts them (-m) and parsed / computed / written in a pipeline.
-// Not supported here (reported as errors, never silently ignored): --coherence/--visualize.  128-bit indices (build --kH 25) are read as they are (20-byte records).
+// Not supported here (reported as errors, never silently ignored): --visualize; --coherence together with -e or paired-end input.  128-bit indices (build --kH 25) are read as they are (20-byte records).
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -472,7 +472,7 @@ struct Params {
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
-    bool coherence = false; float coherenceThreshold = 0.f;
+    bool coherence = false; float coherenceThreshold = 11.0f;   // --coherence, --coherenceThreshold (MetaHeader.h:159)
 };
 
 struct IndexFiles {                               // what Compare::ReadIndex loads (Compare.hpp:49-363), shared by every worker
@@ -504,17 +504,22 @@ struct Writer {
     vector<std::tuple<size_t, float, double>> res;
     Writer(const Params &pp, const Content &cc, const vector<uint64_t> &ff) : p(pp), c(cc), freq(ff), res(cc.names.size()) {}
 
+    float coherence = 0.f;           // --coherence: the score of the read being written (Compare.hpp:1662-1665,1711-1715,1792-1796)
     void obj(string &o, const std::tuple<size_t, float, double> &h, float best, bool pretty) const
     {
         using numtext::dtoa; using numtext::itoa;
         if (pretty) {
             o += "\t\t\"tax ID\": \""; itoa(c.taxids[std::get<0>(h)], o); o += "\",\n\t\t\"Name\": \""; o += c.names[std::get<0>(h)];
             o += "\",\n\t\t\"k-mer Score\": "; dtoa(std::get<1>(h), o); o += ",\n\t\t\"Relative Score\": "; dtoa(std::get<2>(h), o);
-            o += ",\n\t\t\"Error\": "; dtoa((best - std::get<1>(h)) / best, o); o += "\n\t}";
+            o += ",\n\t\t\"Error\": "; dtoa((best - std::get<1>(h)) / best, o);
+            if (p.coherence) { o += ",\n\t\t\"Coherence\": "; dtoa(coherence, o); }
+            o += "\n\t}";
         } else {
             o += " \"tax ID\": \""; itoa(c.taxids[std::get<0>(h)], o); o += "\", \"Name\": \""; o += c.names[std::get<0>(h)];
             o += "\", \"k-mer Score\": "; dtoa(std::get<1>(h), o); o += ", \"Relative Score\": "; dtoa(std::get<2>(h), o);
-            o += ", \"Error\": "; dtoa((best - std::get<1>(h)) / best, o); o += "}";
+            o += ", \"Error\": "; dtoa((best - std::get<1>(h)) / best, o);
+            if (p.coherence) { o += ",\"Coherence\": "; dtoa(coherence, o); }
+            o += "}";
         }
     }
 
@@ -550,7 +555,7 @@ struct Writer {
         const float best = bestScore(len, p);
         if (cnt == 0) {
             switch (p.fmt) {
-            case Params::Tsv: itoa(number, o); o += "\t"; o += name; o += "\t-\t-\t-\t-\n"; break;
+            case Params::Tsv: itoa(number, o); o += "\t"; o += name; o += p.coherence ? "\t-\t-\t-\t-\t-\n" : "\t-\t-\t-\t-\n"; break;
             case Params::Json:
                 o += number == 0 ? "{\n" : ",\n{\n"; o += "\t\"Read number\": "; itoa(number, o);
                 o += ",\n\t\"Specifier from input file\": \""; o += name; o += "\",\n\t\"Length\": "; itoa(len, o);
@@ -564,7 +569,8 @@ struct Writer {
         }
         int64_t top = 1;
         for (int64_t i = 1; i < cnt && i < p.beasts; ++i) { if (std::get<1>(res[i]) / maxV > 0.8f) ++top; else break; }
-        lastContaminated = (best - double(maxV)) / best < p.errorThreshold;          // Compare.hpp:1597-1599
+        lastContaminated = (best - double(maxV)) / best < p.errorThreshold ||          // Compare.hpp:1597-1606
+                           (p.coherence && coherence >= p.coherenceThreshold);
         float before = 0;
         switch (p.fmt) {
         case Params::Tsv: {
@@ -577,7 +583,11 @@ struct Writer {
                 if (before != std::get<1>(h)) { before = std::get<1>(h); ++j; }
             }
             for (string *s : {&s1, &s2, &s3, &s4}) if (!s->empty() && s->back() == ';') s->pop_back();
-            if (!s2.empty()) { o += s1; o += "\t"; o += s2; o += "\t"; o += s3; o += "\t"; o += s4; o += "\n"; }
+            if (!s2.empty()) {
+                o += s1; o += "\t"; o += s2; o += "\t"; o += s3; o += "\t"; o += s4;
+                if (p.coherence) { o += "\t"; dtoa(coherence, o); }
+                o += "\n";
+            }
         } break;
         case Params::Json: {
             o += number == 0 ? "{\n" : ",\n{\n"; o += "\t\"Read number\": "; itoa(number, o);
@@ -870,11 +880,11 @@ struct Batcher {
             if (useRef && left <= 100ll * 1024 * 1024 && n > 0) break;                               // Read.hpp:1147
             const size_t r = pendPos;
             uint64_t len = 0;
-            int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), (uint32_t)ixf.content.taxids.size()) : 0;
+            int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), (uint32_t)ixf.content.taxids.size(), p.coherence ? 1 : 0) : 0;
             for (size_t q = 0; q < spr; ++q) {
                 const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
                 len += (uint64_t)l;
-                if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l);
+                if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
             }
             const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
             if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; break; }
@@ -920,6 +930,14 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
     b.kmers = nk;
     if (!wantRows) { tDevice += secondsSince(tDev); return; }
+    vector<float> coherence;                                     // --coherence (Compare::postProcess, Compare.hpp:3317-3321)
+    if (p.coherence) {
+        coherence.assign(nr, 0.f);
+        uint64_t throwsAt = ~0ull;
+        if (kasa_batch_coherence(ctx, coherence.data(), &throwsAt)) throwLast();
+        if (throwsAt != ~0ull)                                   // the reference's walk runs off the end of its vector here (vector::at)
+            throw std::runtime_error("vector::_M_range_check: __n (which is " + std::to_string(throwsAt) + ") >= this->size() (which is " + std::to_string(throwsAt) + ")");
+    }
     // Ranking on the device (kasa_batch_rank): the host supplies libm's denominators, one row per distinct read length,
     // and gets back only what the writer can print; the full rows come back when the device flags a read (a tie under
     // std::sort's unstable regime) or when there are too many distinct lengths for a table.
@@ -975,6 +993,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 string &text = texts[sidx];
                 text.reserve((size_t)(e - a) * 320);
                 for (uint64_t r = a; r < e; ++r) {
+                    if (p.coherence) w.coherence = coherence[r];
                     if (deviceRank && !(meta[4 * r + 1] >> 31)) {
                         float maxV; std::memcpy(&maxV, &meta[4 * r + 2], 4);
                         w.readRanked(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], hits.data() + meta[4 * r], meta[4 * r + 1], maxV);
@@ -1026,7 +1045,8 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     if (!p.rtt.empty()) {
         out.open(p.rtt, std::ios::binary);
         if (!out) throw std::runtime_error("Readwise output file could not be created!");
-        if (p.fmt == Params::Tsv) out << "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n";
+        if (p.fmt == Params::Tsv) out << (p.coherence ? "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\tCoherence\n"
+                                                       : "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n");
         else if (p.fmt == Params::Json) out << "[\n";
     }
     if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
@@ -1209,7 +1229,9 @@ static int run(int argc, char **argv)
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }
-        else if (s == "--coherence" || s == "--coherenceThreshold" || s == "--visualize" || s == "-z")
+        else if (s == "--coherence") p.coherence = true;                                        // main.cpp:576-581
+        else if (s == "--coherenceThreshold") p.coherenceThreshold = std::stof(next());
+        else if (s == "--visualize" || s == "-z")
             throw std::runtime_error("parameter " + s + " is not supported by the MI355X identify path");
         else throw std::runtime_error("Some unknown parameter has been inserted, please check your command line.");
     }

@@ -23,13 +23,15 @@ from .reads import ReadBatch
 class Identify:
     def __init__(self, index: Index, device: int = 0, k_high: int = 12, k_low: int = 7, frames: int = 3,
                  threshold: float = 0.0, beasts: int = 3, fmt: str = "json", dix: capi.DeviceIndex = None,
-                 unique: bool = False, codon_lut=None):
+                 unique: bool = False, codon_lut=None, coherence: bool = False, coherence_threshold: float = 11.0):
         self.index = index
         self.k_high, self.k_low = max(k_high, k_low), min(k_high, k_low)
         self.frames, self.threshold, self.beasts, self.fmt = frames, threshold, beasts, fmt
         self.dix = dix if dix is not None else capi.DeviceIndex(index, device)
         self.ctx = capi.Context(self.dix, self.k_high, self.k_low, frames, codon_lut)
         self.unique = unique
+        self.coherence = coherence      # --coherence (Compare::postProcess): one more number per read, and a second --filter rule
+        self.coherence_threshold = np.float32(coherence_threshold)
         self.contaminants = []          # read numbers --filter would move to the contaminants (report.is_contaminant)
         self.error_threshold = 0.5
         self.n_kmers = 0
@@ -44,7 +46,7 @@ class Identify:
             memory_gib: int = None, threads: int = 1, ram: bool = False, keep_csr: bool = False):
         """-> (per-read text or None, profile CSV text, list of CSR batches (with keep_csr))."""
         ix = self.index
-        writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts)
+        writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts, coherence=self.coherence)
         freq = ix.freq_at(self.k_high)
         out = [writer.header()] if want_per_read else None
         csr = []
@@ -65,7 +67,7 @@ class Identify:
         if memory_gib is not None and want_per_read and reads.n:
             # the reference's own batch boundaries (-m): the per-read float sums depend on them
             bounds = capi.RefBatcher(ix, self.k_high, self.k_low, self.frames, memory_gib, threads, ram,
-                                     record_bytes=getattr(ix, "record_bytes", None)).boundaries(reads, True)
+                                     record_bytes=getattr(ix, "record_bytes", None), coherence=self.coherence).boundaries(reads, True)
         self.batch_sizes = []
         a = 0
         while a < reads.n or (a == 0 and reads.n == 0):
@@ -74,6 +76,7 @@ class Identify:
             part = reads.slice(a, b)
             self.ctx.run_batch(part.bases, part.offsets, want_per_read, coverage, self.unique, part.seg_read, part.n)
             self.n_kmers += self.ctx.n_kmers
+            coh = self.ctx.coherence() if (want_per_read and self.coherence) else None   # Compare.hpp:3317-3321
             if want_per_read:
                 # ranked on the device (kasa_batch_rank): only what the writer can print crosses PCIe; the full CSR comes
                 # back for the reads the device flags (ties under an unstable sort) or on request (keep_csr)
@@ -101,8 +104,9 @@ class Identify:
                         rk = report.rank_read(tax[lo:hi], sc[lo:hi], length, freq, self.k_high,
                                               self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
                         max_score = max((h.score for h in rk.hits), default=np.float32(0))
-                    out.append(writer.read(self.n_reads + r, part.names[r], length, rk))
-                    if rk.hits and report.is_contaminant(rk.best, max_score, self.error_threshold):
+                    out.append(writer.read(self.n_reads + r, part.names[r], length, rk, None if coh is None else coh[r]))
+                    if rk.hits and (report.is_contaminant(rk.best, max_score, self.error_threshold) or
+                                    (coh is not None and coh[r] >= self.coherence_threshold)):   # Compare.hpp:1597-1606
                         self.contaminants.append(self.n_reads + r)
             self.n_reads += part.n
             a = b

@@ -206,13 +206,16 @@ def _error(best: np.float32, score: np.float32) -> float:
 class ReadWriter:
     """Text of the per-read file in one of the reference's four formats (Compare.hpp:1526-1872)."""
 
-    def __init__(self, fmt: str, names, taxids, beasts: int = 3):
+    def __init__(self, fmt: str, names, taxids, beasts: int = 3, coherence: bool = False):
         assert fmt in ("json", "jsonl", "tsv", "kraken")
         self.fmt, self.names, self.taxids, self.beasts = fmt, names, taxids, beasts
+        self.coherence = coherence      # --coherence: one more column / field (Compare.hpp:1532-1534,1662-1665,1711-1715,1792-1796)
+        self.coh = np.float32(0.0)      # ... of the read being written
 
     def header(self) -> str:
         if self.fmt == "tsv":
-            return "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n"
+            return ("#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError"
+                    + ("\tCoherence" if self.coherence else "") + "\n")
         if self.fmt == "json":
             return "[\n"
         return ""
@@ -225,9 +228,11 @@ class ReadWriter:
         if json_pretty:
             return ("\t\t\"tax ID\": \"" + tid + "\",\n\t\t\"Name\": \"" + nm + "\",\n\t\t\"k-mer Score\": "
                     + dtoa(float(h.score)) + ",\n\t\t\"Relative Score\": " + dtoa(h.rel)
-                    + ",\n\t\t\"Error\": " + dtoa(_error(best, h.score)) + "\n\t}")
+                    + ",\n\t\t\"Error\": " + dtoa(_error(best, h.score))
+                    + ((",\n\t\t\"Coherence\": " + dtoa(float(self.coh))) if self.coherence else "") + "\n\t}")
         return (" \"tax ID\": \"" + tid + "\", \"Name\": \"" + nm + "\", \"k-mer Score\": " + dtoa(float(h.score))
-                + ", \"Relative Score\": " + dtoa(h.rel) + ", \"Error\": " + dtoa(_error(best, h.score)) + "}")
+                + ", \"Relative Score\": " + dtoa(h.rel) + ", \"Error\": " + dtoa(_error(best, h.score))
+                + ((",\"Coherence\": " + dtoa(float(self.coh))) if self.coherence else "") + "}")
 
     def _further(self, r: Ranked):
         """Indices printed after the top hits: the -b counter only advances when the k-mer score
@@ -242,11 +247,12 @@ class ReadWriter:
             i += 1
         return out
 
-    def read(self, number: int, name: str, length: int, r: Ranked) -> str:
+    def read(self, number: int, name: str, length: int, r: Ranked, coherence=None) -> str:
         f = self.fmt
+        self.coh = np.float32(0.0 if coherence is None else coherence)
         if not r.hits:
             if f == "tsv":
-                return itoa(number) + "\t" + name + "\t-\t-\t-\t-\n"
+                return itoa(number) + "\t" + name + "\t-\t-\t-\t-" + ("\t-" if self.coherence else "") + "\n"
             if f == "json":
                 return (("{\n" if number == 0 else ",\n{\n") + "\t\"Read number\": " + itoa(number)
                         + ",\n\t\"Specifier from input file\": \"" + name + "\",\n\t\"Length\": " + itoa(length)
@@ -272,7 +278,8 @@ class ReadWriter:
             s1, s2, s3, s4 = (x[:-1] if x.endswith(";") else x for x in (s1, s2, s3, s4))
             if not s2:
                 return ""
-            return itoa(number) + "\t" + name + "\t" + s1 + "\t" + s2 + "\t" + s3 + "\t" + s4 + "\n"
+            return (itoa(number) + "\t" + name + "\t" + s1 + "\t" + s2 + "\t" + s3 + "\t" + s4
+                    + (("\t" + dtoa(float(self.coh))) if self.coherence else "") + "\n")
         if f == "json":
             out = (("{\n" if number == 0 else ",\n{\n") + "\t\"Read number\": " + itoa(number)
                    + ",\n\t\"Specifier from input file\": \"" + name + "\",\n\t\"Length\": " + itoa(length)

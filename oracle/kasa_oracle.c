@@ -404,11 +404,14 @@ static uint64_t lower_bound_shifted(const ko_key *km, uint64_t lo, uint64_t hiEx
  * A6. Compare.hpp:678-1069, statement by statement in the same order (64-bit keys, no spaced masks,
  * no post-processing).  Level index lv: 0 = kHigh ... nK-1 = kLow (kASA.hpp:299-302).
  * ---------------------------------------------------------------------------------------------- */
-int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+static int compare_sequential_impl(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                           const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
                           uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
-                          uint64_t *countTotal, float *M)
+                          uint64_t *countTotal, float *M, uint8_t *ml)
 {
+    /* ml: --coherence (Compare.hpp:847-848,882-884,912-914,948): wherever the read id of a query joins the hit list of a
+     * level, setMatchLength overwrites the query's match length with that level's k; the last write stands. */
+#define KO_ML(level) do { if (ml) ml[qi] = (uint8_t)(p->kHigh - (level)); } while (0)
     (void)nReads;
     cmp_ctx c;
     ctx_init(&c, p, ix, countAll, countUnique, countTotal, M);
@@ -468,7 +471,7 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *
 
             if (KO_EQ(seenKmer, q) || it == re + 1) {  /* :841-853 duplicates / index exhausted */
                 for (int l = low; l >= 0; --l)
-                    if (KO_EQ(q >> shift_of(p, l), c.lv[l].mem)) lv_push(&c, &c.lv[l], rid);
+                    if (KO_EQ(q >> shift_of(p, l), c.lv[l].mem)) { lv_push(&c, &c.lv[l], rid); KO_ML(l); }
                 continue;
             }
             seenKmer = q;                              /* :855 */
@@ -484,7 +487,7 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *
                     if (KO_LT(qs, es)) {               /* :874-893 input smaller */
                         if (inputIterated)
                             for (int u = l; u >= 0; --u) {
-                                if (KO_EQ(q >> shift_of(p, u), c.lv[u].mem)) lv_push(&c, &c.lv[u], rid);
+                                if (KO_EQ(q >> shift_of(p, u), c.lv[u].mem)) { lv_push(&c, &c.lv[u], rid); KO_ML(u); }
                                 else break;
                             }
                         breakOut = 1;
@@ -494,11 +497,12 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *
                         level_state *s = &c.lv[l];
                         if (KO_EQ(qs, s->mem)) {
                             lv_mark(s, tx[it]);
-                            if (inputIterated) lv_push(&c, s, rid);
+                            if (inputIterated) { lv_push(&c, s, rid); KO_ML(l); }
                         } else {
                             flush_level(&c, l);
                             s->hits = 0;
                             lv_push(&c, s, rid);
+                            KO_ML(l);
                             lv_clear_taxa(s);
                             lv_mark(s, tx[it]);
                             s->mem = qs;
@@ -546,8 +550,25 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *
     }
 #undef KO_EQ
 #undef KO_LT
+#undef KO_ML
     ctx_free(&c);
     return 0;
+}
+
+int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                          const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                          uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                          uint64_t *countTotal, float *M)
+{
+    return compare_sequential_impl(p, ix, qKmer, qRead, qRS, qRL, nQ, nReads, countAll, countUnique, countTotal, M, NULL);
+}
+
+int ko_compare_sequential_ml(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                             const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                             uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                             uint64_t *countTotal, float *M, uint8_t *matchLen)
+{
+    return compare_sequential_impl(p, ix, qKmer, qRead, qRS, qRL, nQ, nReads, countAll, countUnique, countTotal, M, matchLen);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -557,10 +578,10 @@ int ko_compare_sequential(const ko_params *p, const ko_index *ix, const ko_key *
  * with all distinct taxa of the index entries carrying P (index order).  This is what the device
  * kernels compute; tests require it to equal ko_compare_sequential bit for bit.
  * ---------------------------------------------------------------------------------------------- */
-int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+static int compare_closed_form_impl(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
                            const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
                            uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
-                           uint64_t *countTotal, float *M)
+                           uint64_t *countTotal, float *M, uint8_t *depth)
 {
     (void)nReads;
     cmp_ctx c;
@@ -588,6 +609,7 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key 
                 b = lower_bound_shifted(km, a, b, sh, P + 1);
                 if (a == b) break;
                 level_state *s = &c.lv[l];
+                if (depth) depth[qi] = (uint8_t)(p->kHigh - l);     /* the deepest matched level: what the device calls d */
                 if (s->nTax && s->mem == P) {
                     lv_push(&c, s, qRead[qi]);
                 } else {
@@ -603,6 +625,85 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key 
         for (int l = low; l >= 0; --l) flush_level(&c, l);
     }
     ctx_free(&c);
+    return 0;
+}
+
+int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                           const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                           uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                           uint64_t *countTotal, float *M)
+{
+    return compare_closed_form_impl(p, ix, qKmer, qRead, qRS, qRL, nQ, nReads, countAll, countUnique, countTotal, M, NULL);
+}
+
+int ko_compare_closed_form_ml(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                              const uint32_t *qRead, const uint64_t *qRS, const uint32_t *qRL,
+                              uint64_t nQ, uint64_t nReads, double *countAll, uint64_t *countUnique,
+                              uint64_t *countTotal, float *M, uint8_t *depth)
+{
+    return compare_closed_form_impl(p, ix, qKmer, qRead, qRS, qRL, nQ, nReads, countAll, countUnique, countTotal, M, depth);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * --coherence: Compare::postProcess (Compare.hpp:2607-2728), statement by statement.  The elements are the batch's
+ * k-mers sorted by (read id, frame, position) (:2609-2630) -- for single-end input that is the order the reader emitted
+ * them in (Read.hpp:128-131,172-175,210-213: position = running window number of the strand, frame = 0 forward / 1 reverse
+ * complement); len = the match length setMatchLength left (0 = unmatched).  One walk over the whole batch: `rid` is advanced
+ * by the loop, not read off the elements, so an element is credited to whatever read the walk believes it is in -- a read
+ * without k-mers takes the first element of its successor, and after a strand switch the search for the next match runs on
+ * into the following reads (:2712-2722).  scores[] must come in zeroed (:3319).
+ * Returns 0, or 1 where the reference throws std::out_of_range (its vector::at at :2667 after the search of :2712-2722 ran
+ * off the end: a batch whose last strand switch finds no further match); *failIdx = the index it asked for.
+ * ---------------------------------------------------------------------------------------------- */
+static inline void coh_set(float *cell, float v) { if (*cell < v) *cell = v; }           /* :2650-2652, std::max */
+
+int ko_coherence(const uint32_t *read, const uint32_t *pos, const uint8_t *frame, const uint8_t *len, uint64_t n,
+                 int sixFrames, float *scores, uint64_t nReads, uint64_t *failIdx)
+{
+    uint32_t rid = 0, last = 0, cur = 0, cnt = 0;                                        /* :2632-2636 */
+    uint64_t idx = 0;
+    while (idx < n) {                                                                    /* :2637-2648 */
+        const uint8_t ml = len[idx];
+        if (ml != 0) { rid = read[idx]; last = pos[idx] + ml; ++idx; break; }
+        ++idx;
+    }
+#define KO_DET(next) do { const uint32_t nx_ = (next); if (nx_ > cur) { cur = nx_; cnt = 1; } else if (nx_ == cur) cnt++; } while (0)   /* :2653-2662 */
+#define KO_CLUSTER() coh_set(&scores[rid], (float)cur + 1.0f - 1.0f / (float)cnt)        /* 1.0f / 0 = inf: the score stays */
+    for (; rid < nReads && idx < n; ++rid) {                                             /* :2665 */
+        for (int fb = 0; fb < 1 + (sixFrames ? 1 : 0);) {                                /* :2667 */
+            if (idx >= n) { if (failIdx) *failIdx = idx; return 1; }                     /* vIn.getLength -> vector::at throws */
+            const uint8_t ml = len[idx];                                                 /* :2670 */
+            if (ml != 0) {
+                if (pos[idx] <= last) {                                                  /* :2673 */
+                    if (pos[idx] + ml < last) KO_DET((uint32_t)ml);                      /* :2674-2676 */
+                    else { const int32_t ov = (int32_t)last - (int32_t)pos[idx]; KO_DET((uint32_t)ov); }   /* :2677-2680 */
+                } else {                                                                 /* :2683-2687 */
+                    KO_CLUSTER();
+                    cur = 0;
+                }
+                last = pos[idx] + ml;                                                    /* :2688 */
+            }
+            ++idx;                                                                       /* :2691 */
+            if (idx == n) { KO_CLUSTER(); break; }                                       /* :2693-2696 */
+            if (read[idx] != rid) {                                                      /* :2699-2706 */
+                KO_CLUSTER();
+                last = UINT32_MAX; cur = 0; cnt = 0;
+                break;
+            }
+            if (frame[idx] != fb) {                                                      /* :2709-2726 */
+                KO_CLUSTER();
+                cur = 0; cnt = 0;
+                ++fb;
+                while (idx < n) {
+                    const uint8_t m2 = len[idx];
+                    if (m2 != 0) { last = pos[idx] + m2; ++idx; break; }
+                    ++idx;
+                }
+            }
+        }
+    }
+#undef KO_DET
+#undef KO_CLUSTER
     return 0;
 }
 
@@ -656,7 +757,7 @@ double ko_error_score(float bestScore, float kmerScore)
 /* ------------------------------------------------------------------------------------------------
  * The batch with the reference's threading model (-n): for bench.py's cpu_baseline.
  * Compare.hpp:3107-3124 + Read.hpp:763-827: reads split over the worker threads for translation;
- * Compare.hpp:1123-1132: parallel sort of the queries (here: stable bucket pass on the top byte, buckets sorted by the
+ * Compare.hpp:1123-1132: parallel sort of the queries (here: stable bucket pass on the top 16 bits, buckets sorted by the
  * threads); Compare.hpp:1098-1117: ranges per thread; Compare.hpp:3263-3283: the sorted queries cut into one slice per
  * thread on prefix-range boundaries, every thread merges its slice with PRIVATE count tables (:922) into the SHARED
  * score matrix (unsynchronised `+=`, as in the reference: per-read floats may differ in their last digits between
@@ -670,8 +771,9 @@ typedef struct {
     int64_t r0, r1;               /* reads of this thread */
     int64_t *kcount;              /* k-mers per thread */
     ko_key *km, *km2; uint32_t *rd, *rd2; uint64_t nQ; uint64_t *koff;   /* koff[t] = first query of thread t */
-    uint64_t *hist;               /* [nThreads][256] */
-    uint64_t *bucketStart;        /* [257] */
+    uint64_t *hist;               /* [nThreads][KO_NB] */
+    uint64_t *bucketStart;        /* [KO_NB + 1] */
+    int zeroM;                    /* the score matrix still has to be cleared */
     volatile int *nextBucket;
     uint64_t *rs; uint32_t *rl;
     uint64_t s0, s1;              /* slice of the sorted queries */
@@ -680,7 +782,12 @@ typedef struct {
     uint64_t *cuts;
 } ko_job;
 
-static int key_top_byte(ko_key k, int K) { return (int)((k >> (5 * K - 8)) & 255); }
+/* Sort buckets = the top KO_BBITS key bits (three letters and a bit): the first letters of amino-acid-like k-mers are far from
+ * uniform, and with the 256 buckets of one byte the largest bucket -- sorted by ONE thread -- held a twentieth of the batch,
+ * which capped the speed-up of the whole run near 1.6 on a 256-thread host.  65 536 buckets are dealt out dynamically. */
+#define KO_BBITS 16
+#define KO_NB (1 << KO_BBITS)
+static int key_bucket(ko_key k, int K) { return (int)((k >> (5 * K - KO_BBITS)) & (KO_NB - 1)); }
 
 static void *ko_worker(void *arg)
 {
@@ -697,27 +804,38 @@ static void *ko_worker(void *arg)
         ko_encode_batch(j->bases, j->off + j->r0, n, j->p, j->lut, j->km + q0, j->rd + q0);
         for (uint64_t i = q0; i < q1; ++i) j->rd[i] += (uint32_t)j->r0;
     }
-    /* 2. parallel sort: stable bucket pass on the top byte, then the buckets */
-    uint64_t *h = j->hist + (size_t)t * 256;
-    memset(h, 0, 256 * sizeof(uint64_t));
-    for (uint64_t i = q0; i < q1; ++i) ++h[key_top_byte(j->km[i], j->p->K)];
+    /* the score matrix is touched first by the workers, a share each: its pages are spread over the memory nodes and the
+     * page faults (3.4 GB at 600 000 reads x 1400 taxa) are not taken one after the other by the thread that merges first */
+    if (j->zeroM) {
+        const uint64_t cellsM = j->nReads * (uint64_t)j->ix->nTaxa, za = cellsM * (uint64_t)t / (uint64_t)T, ze = cellsM * (uint64_t)(t + 1) / (uint64_t)T;
+        memset(j->M + za, 0, (size_t)(ze - za) * 4);
+    }
+    /* 2. parallel sort: stable bucket pass on the top bits, then the buckets */
+    uint64_t *h = j->hist + (size_t)t * KO_NB;
+    memset(h, 0, KO_NB * sizeof(uint64_t));
+    for (uint64_t i = q0; i < q1; ++i) ++h[key_bucket(j->km[i], j->p->K)];
     pthread_barrier_wait(j->bar);
-    if (t == 0) {
-        uint64_t run = 0;
-        for (int b = 0; b < 256; ++b) {
-            j->bucketStart[b] = run;
-            for (int i = 0; i < T; ++i) { const uint64_t c = j->hist[(size_t)i * 256 + b]; j->hist[(size_t)i * 256 + b] = run; run += c; }
-        }
-        j->bucketStart[256] = run;
+    {   /* bucket sizes: every thread sums a share of the buckets over all threads ... */
+        const int b0 = KO_NB * t / T, b1 = KO_NB * (t + 1) / T;
+        for (int b = b0; b < b1; ++b) { uint64_t c = 0; for (int i = 0; i < T; ++i) c += j->hist[(size_t)i * KO_NB + b]; j->bucketStart[b + 1] = c; }
     }
     pthread_barrier_wait(j->bar);
-    for (uint64_t i = q0; i < q1; ++i) { const uint64_t d = h[key_top_byte(j->km[i], j->p->K)]++; j->km2[d] = j->km[i]; j->rd2[d] = j->rd[i]; }
+    if (t == 0) { j->bucketStart[0] = 0; for (int b = 0; b < KO_NB; ++b) j->bucketStart[b + 1] += j->bucketStart[b]; }   /* ... one running sum ... */
     pthread_barrier_wait(j->bar);
-    for (;;) {
-        const int b = __sync_fetch_and_add(j->nextBucket, 1);
-        if (b >= 256) break;
-        const uint64_t a = j->bucketStart[b], e = j->bucketStart[b + 1];
-        if (e > a) ko_sort_queries(j->km2 + a, j->rd2 + a, e - a);
+    {   /* ... and the threads' places inside the buckets, again a share of the buckets each */
+        const int b0 = KO_NB * t / T, b1 = KO_NB * (t + 1) / T;
+        for (int b = b0; b < b1; ++b) { uint64_t run = j->bucketStart[b]; for (int i = 0; i < T; ++i) { const uint64_t c = j->hist[(size_t)i * KO_NB + b]; j->hist[(size_t)i * KO_NB + b] = run; run += c; } }
+    }
+    pthread_barrier_wait(j->bar);
+    for (uint64_t i = q0; i < q1; ++i) { const uint64_t d = h[key_bucket(j->km[i], j->p->K)]++; j->km2[d] = j->km[i]; j->rd2[d] = j->rd[i]; }
+    pthread_barrier_wait(j->bar);
+    for (;;) {                                                     /* runs of 64 buckets at a time */
+        const int b = __sync_fetch_and_add(j->nextBucket, 64);
+        if (b >= KO_NB) break;
+        for (int bb = b; bb < b + 64 && bb < KO_NB; ++bb) {
+            const uint64_t a = j->bucketStart[bb], e = j->bucketStart[bb + 1];
+            if (e > a + 1) ko_sort_queries(j->km2 + a, j->rd2 + a, e - a);
+        }
     }
     pthread_barrier_wait(j->bar);
     /* 3. ranges of my share */
@@ -755,17 +873,17 @@ int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *
     uint32_t *rd = (uint32_t *)malloc((nQ + 1) * 4), *rd2 = (uint32_t *)malloc((nQ + 1) * 4), *rl = (uint32_t *)malloc((nQ + 1) * 4);
     uint64_t *rs = (uint64_t *)malloc((nQ + 1) * 8);
     int64_t *kcount = (int64_t *)calloc((size_t)T, 8);
-    uint64_t *koff = (uint64_t *)calloc((size_t)T + 1, 8), *hist = (uint64_t *)calloc((size_t)T * 256, 8), *cuts = (uint64_t *)calloc((size_t)T + 1, 8);
-    uint64_t bucketStart[257];
+    uint64_t *koff = (uint64_t *)calloc((size_t)T + 1, 8), *hist = (uint64_t *)malloc((size_t)T * KO_NB * 8), *cuts = (uint64_t *)calloc((size_t)T + 1, 8);
+    uint64_t *bucketStart = (uint64_t *)calloc((size_t)KO_NB + 1, 8);
     double *ca = (double *)calloc(cells * (size_t)T, 8);
     uint64_t *cu = (uint64_t *)calloc(cells * (size_t)T, 8), *ct = (uint64_t *)calloc(cells * (size_t)T, 8);
-    float *Mloc = M ? M : (float *)calloc((size_t)nReads * ix->nTaxa, 4);
+    float *Mloc = M ? M : (float *)malloc((size_t)nReads * ix->nTaxa * 4 + 4);   /* cleared by the workers (first touch) */
     ko_job *jobs = (ko_job *)calloc((size_t)T, sizeof(ko_job));
     pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
     pthread_barrier_t bar;
     volatile int nextBucket = 0;
     int rc = -1;
-    if (km && km2 && rd && rd2 && rl && rs && kcount && koff && hist && cuts && ca && cu && ct && Mloc && jobs && th) {
+    if (km && km2 && rd && rd2 && rl && rs && kcount && koff && hist && cuts && ca && cu && ct && Mloc && jobs && th && bucketStart) {
         pthread_barrier_init(&bar, NULL, (unsigned)T);
         for (int t = 0; t < T; ++t) {
             ko_job *j = &jobs[t];
@@ -774,7 +892,7 @@ int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *
             j->kcount = kcount; j->km = km; j->km2 = km2; j->rd = rd; j->rd2 = rd2; j->nQ = nQ; j->koff = koff;
             j->hist = hist; j->bucketStart = bucketStart; j->nextBucket = &nextBucket; j->rs = rs; j->rl = rl;
             j->nReads = (uint64_t)nReads; j->ca = ca + cells * (size_t)t; j->cu = cu + cells * (size_t)t; j->ct = ct + cells * (size_t)t;
-            j->M = Mloc; j->bar = &bar; j->cuts = cuts;
+            j->M = Mloc; j->bar = &bar; j->cuts = cuts; j->zeroM = M ? 0 : 1;
             pthread_create(&th[t], NULL, ko_worker, j);
         }
         for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);
@@ -789,6 +907,6 @@ int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *
         rc = 0;
     }
     free(km); free(km2); free(rd); free(rd2); free(rl); free(rs); free(kcount); free(koff); free(hist); free(cuts);
-    free(ca); free(cu); free(ct); if (!M) free(Mloc); free(jobs); free(th);
+    free(ca); free(cu); free(ct); if (!M) free(Mloc); free(jobs); free(th); free(bucketStart);
     return rc;
 }

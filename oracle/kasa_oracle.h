@@ -100,6 +100,21 @@ int ko_compare_closed_form(const ko_params *p, const ko_index *ix, const ko_key 
                            const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
                            double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M);
 
+/* --coherence.  The two comparison routines again, also reporting per sorted query the match length the reference's
+ * setMatchLength leaves (Compare.hpp:847-848,882-884,912-914,948; sequential) resp. the deepest matched level (closed form):
+ * matchLen / depth = u8[nQ], zeroed by the caller.  ko_coherence = Compare::postProcess (Compare.hpp:2607-2728) over the
+ * batch's k-mers in (read, frame, position) order; returns 1 where the reference throws std::out_of_range. */
+int ko_compare_sequential_ml(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                             const uint32_t *qRead, const uint64_t *qRangeStart,
+                             const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
+                             double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M, uint8_t *matchLen);
+int ko_compare_closed_form_ml(const ko_params *p, const ko_index *ix, const ko_key *qKmer,
+                              const uint32_t *qRead, const uint64_t *qRangeStart,
+                              const uint32_t *qRangeLenM1, uint64_t nQ, uint64_t nReads,
+                              double *countAll, uint64_t *countUnique, uint64_t *countTotal, float *M, uint8_t *depth);
+int ko_coherence(const uint32_t *read, const uint32_t *pos, const uint8_t *frame, const uint8_t *len, uint64_t n,
+                 int sixFrames, float *scores, uint64_t nReads, uint64_t *failIdx);
+
 /* The whole batch with the reference's threading model (-n worker threads; Read.hpp:763-827, Compare.hpp:1123-1132,
  * :3263-3283, :3445-3454): translation per read chunk, parallel sort, lookup + score over range-aligned slices with
  * private count tables and the shared, unsynchronised score matrix.  For bench.py's cpu_baseline.  countAll /

@@ -160,6 +160,73 @@ def compare(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, want_reads=T
     return CompareResult(ca, cu, ct, M)
 
 
+def compare_ml(iv: IndexView, p: Params, km, rd, rs, rl, n_reads: int, closed_form=False):
+    """compare() that also returns, per sorted query, the match length setMatchLength leaves (sequential) or the deepest
+    matched level (closed form): (CompareResult, u8[nQ])."""
+    nK = p.kHigh - p.kLow + 1
+    ca = np.zeros((nK, iv.n_taxa), dtype=np.float64)
+    cu = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
+    ct = np.zeros((nK, iv.n_taxa), dtype=np.uint64)
+    M = np.zeros((n_reads, iv.n_taxa), dtype=np.float32)
+    ml = np.zeros(km.shape[0], dtype=np.uint8)
+    fn = lib(p.K).ko_compare_closed_form_ml if closed_form else lib(p.K).ko_compare_sequential_ml
+    rc = fn(C.byref(p), C.byref(iv.c), _p(km), _p(rd), _p(rs), _p(rl), C.c_uint64(km.shape[0]),
+            C.c_uint64(n_reads), _p(ca), _p(cu), _p(ct), _p(M), _p(ml))
+    assert rc == 0
+    return CompareResult(ca, cu, ct, M), ml
+
+
+class ReferenceThrows(Exception):
+    """The reference ends with an exception on this input (its message: what())."""
+
+
+def emission_geometry(offsets: np.ndarray, p: Params):
+    """(read, frame, position) of every k-mer in emission order (Read.hpp:128-131: position = window number within the
+    strand, frame = 0 forward / 1 reverse complement)."""
+    L = lib(p.K)
+    strands = 2 if (p.frames == 6 and not p.protein) else 1
+    rd, fr, ps = [], [], []
+    for r in range(offsets.shape[0] - 1):
+        raw = int(offsets[r + 1] - offsets[r])
+        cnt = int(L.ko_kmer_count(C.c_int64(L.ko_padded_len(C.c_int64(raw), C.byref(p))), C.byref(p))) if raw > 0 else 0
+        for s_ in range(strands):
+            rd.append(np.full(cnt, r, dtype=np.uint32)); fr.append(np.full(cnt, s_, dtype=np.uint8)); ps.append(np.arange(cnt, dtype=np.uint32))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)
+    return cat(rd, np.uint32), cat(fr, np.uint8), cat(ps, np.uint32)
+
+
+def coherence(rd, pos, frame, ml, six: bool, n_reads: int) -> np.ndarray:
+    """Compare::postProcess (Compare.hpp:2607-2728) -> float32[n_reads]; raises ReferenceThrows where the reference does."""
+    sc = np.zeros(n_reads, dtype=np.float32)
+    rd = np.ascontiguousarray(rd, dtype=np.uint32); pos = np.ascontiguousarray(pos, dtype=np.uint32)
+    frame = np.ascontiguousarray(frame, dtype=np.uint8); ml = np.ascontiguousarray(ml, dtype=np.uint8)
+    fail = C.c_uint64(0)
+    rc = lib().ko_coherence(_p(rd), _p(pos), _p(frame), _p(ml), C.c_uint64(rd.shape[0]), C.c_int(int(six)), _p(sc),
+                            C.c_uint64(n_reads), C.byref(fail))
+    if rc != 0:
+        raise ReferenceThrows(f"vector::_M_range_check: __n (which is {fail.value}) >= this->size() (which is {rd.shape[0]})")
+    return sc
+
+
+def identify_batch_coherence(ix, bases, offsets, p: Params, closed_form=False, lut=None):
+    """identify_batch with --coherence: (CompareResult, nQueries, coherence f32[nReads], matchLen u8[nQ] in emission
+    order).  Single-end input without -e (the reference's result for the other cases hangs on its unstable sorts)."""
+    iv = IndexView(ix)
+    km, rd = encode(bases, offsets, p, lut)
+    n = int(km.shape[0])
+    n_reads = offsets.shape[0] - 1
+    km_s, idx_s = sort_queries(km, np.arange(n, dtype=np.uint32))   # the payload is the emission index
+    rd_s = np.ascontiguousarray(rd[idx_s])
+    rs, rl = ranges(iv, p, km_s)
+    res, ml_s = compare_ml(iv, p, km_s, rd_s, rs, rl, n_reads, closed_form)
+    ml = np.zeros(n, dtype=np.uint8)
+    ml[idx_s] = ml_s
+    erd, efr, eps = emission_geometry(np.asarray(offsets), p)
+    assert np.array_equal(erd, rd)
+    six = p.frames == 6 and not p.protein
+    return res, n, coherence(erd, eps, efr, ml, six, n_reads), ml
+
+
 def unique_queries(km: np.ndarray, rd: np.ndarray):
     """-e (Compare.hpp:3167-3178) on sorted records."""
     km, rd = km.copy(), rd.copy()

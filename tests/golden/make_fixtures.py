@@ -209,6 +209,37 @@ def case_pairs(out):
                 "-q", "out_flta.jsonl", "-p", "prof_flta.csv"], out)
     for junk in ("out_flt.jsonl", "prof_flt.csv", "out_flta.jsonl", "prof_flta.csv"):   # same as b100 / fasta
         os.remove(os.path.join(out, junk))
+    # --coherence (Compare::postProcess): one more column / field per read in every text format but the Kraken one; with
+    # --six on an input whose last read matches on both strands (reads_dup.fastq ends in a palindrome) ...
+    coh = {
+        "coh.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100"],
+        "coh.tsv": ["-i", "reads.fastq", "--tsv", "-b", "3"],
+        "coh.json": ["-i", "reads.fastq", "--json"],
+        "coh.ktsv": ["-i", "reads.fastq", "--kraken"],
+        "coh_fasta.tsv": ["-i", "reads.fasta", "--tsv", "-b", "100"],
+        "coh_one.jsonl": ["-i", "reads.fastq", "--jsonl", "-b", "100", "--one"],
+        "coh_k12_9.tsv": ["-i", "reads.fastq", "--tsv", "-b", "100", "-k", "12", "9"],
+        "coh_prot.jsonl": ["-i", "reads_prot.fasta", "--jsonl", "-b", "100"],
+        "coh_dup.tsv": ["-i", "reads_dup.fastq", "--tsv", "-b", "100"],
+        "coh_dup6.tsv": ["-i", "reads_dup.fastq", "--tsv", "-b", "100", "--six"],
+    }
+    for name, extra in coh.items():
+        run(base + extra + ["--coherence", "-q", "out_" + name, "-p", "prof_" + name.rsplit(".", 1)[0] + ".csv"], out)
+    # ... and on one where the reference's walk runs off the end of its vector after the last strand switch: it ends with
+    # an exception (vector::at); what it printed is the fixture
+    p = subprocess.run(KASA + base + ["-i", "reads.fastq", "--tsv", "--six", "--coherence", "-q", "out_coh_six_throws.tsv", "-p",
+                                      "prof_coh_six_throws.csv", "-t", os.path.join(out, "tmp") + "/"], cwd=out, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=120)
+    with open(os.path.join(out, "coh_six_throws.err"), "w") as f:
+        f.write("".join(l + "\n" for l in p.stdout.splitlines() if l.startswith("ERROR: vector")))
+    for junk in ("out_coh_six_throws.tsv", "prof_coh_six_throws.csv"):
+        if os.path.exists(os.path.join(out, junk)):
+            os.remove(os.path.join(out, junk))
+    # --filter with --coherence: a read also goes to the contaminants when its coherence reaches --coherenceThreshold
+    run(base + ["-i", "reads.fastq", "--jsonl", "-b", "100", "--coherence", "--coherenceThreshold", "11.99", "--errorThreshold", "0.46",
+                "--filter", "cflt_clean", "cflt_cont", "-q", "out_cflt.jsonl", "-p", "prof_cflt.csv"], out)
+    for junk in ("out_cflt.jsonl", "prof_cflt.csv"):
+        os.remove(os.path.join(out, junk))
     # the "halved" index of shrink strategy 2 (6-byte records) and a run on it
     run(["shrink", "-c", "content.txt", "-d", "idx", "-o", "idx_half", "-s", "2", "-m", "4", "-n", "1"], out)
     run(base + ["-d", "idx_half", "-i", "reads.fastq", "--jsonl", "-b", "100", "-q", "out_half.jsonl", "-p", "prof_half.csv"], out)
@@ -219,6 +250,8 @@ def case_pairs(out):
     for name, extra in wide.items():
         run(["identify", "-c", "content.txt", "-d", "idx25", "-m", "4", "-n", "1", "--jsonl", "-b", "100", "-i", "reads.fastq"]
             + extra + ["-q", "out_" + name + ".jsonl", "-p", "prof_" + name + ".csv"], out)
+    run(["identify", "-c", "content.txt", "-d", "idx25", "-m", "4", "-n", "1", "--tsv", "-b", "100", "-i", "reads.fastq", "-k", "25", "7",
+         "--coherence", "-q", "out_coh_w25_7.tsv", "-p", "prof_coh_w25_7.csv"], out)
     # a custom translation table (-a <gc.prt> <id>): index built and queried with the vertebrate mitochondrial code
     with open(os.path.join(out, "gc.prt"), "w") as f:
         f.write(GC_PRT)
@@ -389,7 +422,8 @@ def case_batches(out):
     probe = build_probe()
     base = ["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", "reads.fastq", "--jsonl", "-b", "100"]
     sizes = {}
-    for name, extra in (("m1", ["-m", "1"]), ("m2", ["-m", "2"]), ("m1_ram", ["-m", "1", "-r"]), ("m1_six", ["-m", "1", "--six"])):
+    for name, extra in (("m1", ["-m", "1"]), ("m2", ["-m", "2"]), ("m1_ram", ["-m", "1", "-r"]), ("m1_six", ["-m", "1", "--six"]),
+                        ("m1_coh", ["-m", "1", "--coherence"])):
         sizes[name] = run_probed(base + extra + ["-q", "out_%s.jsonl" % name, "-p", "prof_%s.csv" % name], out, G + DUMMY + 1, probe)
         assert sum(sizes[name]) == NR and len(sizes[name]) >= 3, sizes
     with open(os.path.join(out, "batches.json"), "w") as f:

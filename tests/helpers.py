@@ -25,15 +25,15 @@ def csr_from_dense(M):
 
 
 def render(ix, batch, rows, count_all, count_unique, n_kmers, fmt, k_high, k_low, frames,
-           threshold=0.0, beasts=3, protein=False, count_total=None):
-    w = report.ReadWriter(fmt, ix.content.names, ix.content.taxids, beasts)
+           threshold=0.0, beasts=3, protein=False, count_total=None, coherence=None):
+    w = report.ReadWriter(fmt, ix.content.names, ix.content.taxids, beasts, coherence=coherence is not None)
     freq = ix.freq_at(k_high)
     out = [w.header()]
     for r in range(batch.n):
         t, s = rows[r]
         rk = report.rank_read(t, s, int(batch.lengths[r]), freq, k_high, k_low, frames, threshold, beasts,
                               K=ix.K, protein=protein)
-        out.append(w.read(r, batch.names[r], int(batch.lengths[r]), rk))
+        out.append(w.read(r, batch.names[r], int(batch.lengths[r]), rk, None if coherence is None else coherence[r]))
     out.append(w.footer())
     prof = report.profile_csv(count_all, count_unique, ix.content.names, ix.content.taxids, k_high, k_low,
                               n_kmers, batch.n, 3 if (protein and frames == 6) else frames,

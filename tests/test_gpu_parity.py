@@ -516,8 +516,10 @@ def test_wide_index_synthetic(krange, flags):
 
 
 # ---- BASELINE.json's full size (C2): properties that do not need the oracle to run 1.3e9 queries ---------------------
-def test_full_size_properties():
-    """10 M x 150 bp reads against the 4.2e8-record index of bench.py (scaled down with KASA_TEST_FULL_READS /
+@pytest.mark.parametrize("K", [12, 25], ids=["C2_64bit_k12_7", "C3_128bit_k25_7"])
+def test_full_size_properties(K):
+    """BASELINE.json configs[1] (64-bit index, -k 12 7) and configs[2] (128-bit index, -k 25 7, 64-byte event records) at
+    full size.  10 M x 150 bp reads against the 4.2e8-record index of bench.py (scaled down with KASA_TEST_FULL_READS /
     KASA_TEST_FULL_TAXA when the box is small):
       * determinism: two runs give identical bytes;
       * linearity: the integer profile limbs of the whole batch equal the sum over five read shards (what the multi-GPU
@@ -531,10 +533,14 @@ def test_full_size_properties():
     n_reads = int(os.environ.get("KASA_TEST_FULL_READS", "10000000"))
     n_taxa = int(os.environ.get("KASA_TEST_FULL_TAXA", "1400"))
     g = synth.genomes(n_taxa, 300_000, seed=11)
-    ix = synth.index_from_genomes(g)
+    kh = 12 if K == 12 else 25
+    nK = kh - 7 + 1
+    ix = synth.index_from_genomes(g, K=K)
+    assert ix.K == K
     batch = synth.reads_from_genomes(g, n_reads, 150, seed=1000)
     dix = capi.DeviceIndex(ix)
-    ctx = capi.Context(dix, 12, 7, 3)
+    ctx = capi.Context(dix, kh, 7, 3)
+    assert ctx.rec_words == (8 if K == 12 else 16)
 
     def run(b):
         ctx.run_batch(b.bases, b.offsets, True)
@@ -546,8 +552,8 @@ def test_full_size_properties():
     ca, cu, _ = ctx.profile()
     depth, _ = ctx.lookup()
     # conservation
-    for lv in range(6):
-        k = 12 - lv
+    for lv in range(nK):
+        k = kh - lv
         matched = int(np.count_nonzero(depth >= k))
         assert abs(float(ca[lv].sum()) - matched) <= 1e-9 * max(1, matched), (k, float(ca[lv].sum()), matched)
     assert int(cu.sum()) > 0
@@ -580,7 +586,7 @@ def test_full_size_properties():
     pick = np.sort(rng.choice(batch.n, size=min(1500, batch.n), replace=False))
     sub_b = np.concatenate([batch.bases[int(batch.offsets[r]):int(batch.offsets[r + 1])] for r in pick])
     sub_o = np.concatenate(([0], np.cumsum([int(batch.offsets[r + 1] - batch.offsets[r]) for r in pick]))).astype(np.int64)
-    res, _ = oracle.identify_batch(ix, sub_b, sub_o, oracle.params(12, 7, 3), True)
+    res, _ = oracle.identify_batch(ix, sub_b, sub_o, oracle.params(kh, 7, 3, K=K), True)
     for i, r in enumerate(pick):
         t = (np.flatnonzero(res.M[i, 1:] > 0) + 1).astype(np.uint32)
         lo, hi = int(off1[r]), int(off1[r + 1])
@@ -594,7 +600,7 @@ def test_full_size_properties():
     ctx.profile_reset()
     o, t, v = run(part)
     ca_g, cu_g, _ = ctx.profile()
-    res, nq = oracle.identify_batch(ix, part.bases, part.offsets, oracle.params(12, 7, 3), True)
+    res, nq = oracle.identify_batch(ix, part.bases, part.offsets, oracle.params(kh, 7, 3, K=K), True)
     assert ctx.n_kmers == nq
     assert np.array_equal(cu_g, res.count_unique)
     np.testing.assert_allclose(ca_g, res.count_all, rtol=1e-12, atol=0)
