@@ -56,7 +56,8 @@ def cpu_baseline(ix, sample, k_high, k_low, threads):
 def cpu_baseline_report(ix, reads, k_high, k_low, args):
     """One thread on a small sample, all cores on a large one (bounded by the host's free memory: the oracle keeps the
     reference's dense reads x taxa score matrix), and the speed-up between the two."""
-    threads = os.cpu_count() or 1
+    host = host_cpus()
+    threads = host["usable"]
     per_read = ix.content.n_taxa * 4 + 130 * 40 + 400                    # score row + query records (two copies, ranges) + text
     avail = None
     try:
@@ -78,7 +79,7 @@ def cpu_baseline_report(ix, reads, k_high, k_low, args):
         cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_calibration.json")))
     except Exception:
         pass
-    return {"value": vn, "unit": "reads/s", "cores": threads, "threads": threads, "kind": "port", "cpu": cpu_model(),
+    return {"value": vn, "unit": "reads/s", "cores": threads, "threads": threads, "kind": "port", "cpu": cpu_model(), "host_cpus": host,
             "single_thread_value": v1, "speedup_over_1": vn / v1 if v1 > 0 else None,
             "parallel_efficiency": (vn / v1 / threads) if v1 > 0 else None,
             "sample": f"first {par.n} reads of the same workload with {threads} threads ({sn:.1f} s), first {one.n} reads with one "
@@ -452,6 +453,7 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
     stats = {}
 
     def step():
+        owner.profile_reset()                                              # a step is a whole "file"
         kdist.partitioned_batch(owner, worker, cuts, 12, reads, not args.profile_only, False, stats=stats)
         if world > 1:
             owner.profile_set_limbs(kdist.allreduce_limbs(owner.profile_limbs(), device=None if share else "cuda"))
@@ -463,10 +465,8 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        owner.profile_reset()
         step()
     fence()
-    owner.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -488,7 +488,7 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
                       "parallelism": f"index range-partitioned x{world}, reads sharded x{world}",
                       "exchange": "gloo, host-staged (KASA_BENCH_SHARE_GPU test hook)" if share else "RCCL all_to_all on device tensors"},
            "kmers_per_s": n_kmers * world * args.steps / dt,
-           "identified_fraction": float(ca[-1].sum()) / max(1, args.steps) / max(1, n_kmers * (world if world > 1 else 1)),
+           "identified_fraction": float(ca[-1].sum()) / max(1, n_kmers * world),
            "exchange_bytes_per_step_this_rank": stats}
     owner.close(); worker.close(); dix.close()
     return out
@@ -661,6 +661,37 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def host_cpus():
+    """Logical CPUs the machine has, those this process may run on (affinity mask), and the CPU time a cgroup quota allows
+    per second of wall time -- a container can see 256 CPUs and be throttled to a handful; `usable` is what the CPU baseline
+    starts threads for."""
+    out = {"logical": os.cpu_count() or 1}
+    try:
+        out["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        out["affinity"] = out["logical"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except Exception:
+            continue
+    out["cgroup_quota_cpus"] = quota
+    usable = min(out["logical"], out["affinity"])
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    out["usable"] = usable
+    return out
 
 
 def cpu_model():

@@ -38,6 +38,7 @@
 
 #include "../../include/kasa_hip.h"
 #include "stdsort_order.h"
+#include "kasa_radix.h"
 
 // ------------------------------------------------------------------------------------------------
 // constants
@@ -1475,7 +1476,17 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
             uint32_t *big = c->misc.as<uint32_t>() + 43, *longest = c->misc.as<uint32_t>() + 44;
             if ((rc = c->sortBig.reserve((size_t)SORT_BIG_CAP * 12 + 64))) return rc;
             uint32_t *bigHead = c->sortBig.as<uint32_t>(), *segBegin = bigHead + SORT_BIG_CAP, *segEnd = segBegin + SORT_BIG_CAP;
-            if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
+            if (c->debugFlags & 512) {                                  // test tap: the library's passes over the same bits
+                if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
+            } else {
+                // the hand-written passes (kasa_radix.h): A -> B -> A ... ; five passes end in B
+                static_assert((SORT_TOP / 8) % 2 == 1, "an odd number of passes leaves the pairs in the other buffer");
+                if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<Key>(nQ)))) return rc;
+                Key *kRes; uint32_t *vRes;
+                HIPCHK(kasa_radix::sort_pairs<Key>(c->qKmerA.as<Key>(), c->qReadA.as<uint32_t>(), c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), (uint32_t)nQ,
+                                                   (int)(BITS - SORT_TOP), (int)SORT_TOP, c->sortTmp.p, c->stream, &kRes, &vRes));
+                if (kRes != c->qKmerB.as<Key>()) return fail(KASA_E_HIP, "query sort: unexpected result buffer");
+            }
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
             if constexpr (sizeof(Key) == 8)
                 bucket_rank32_kernel<<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<uint64_t>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<uint64_t>(),
@@ -4128,10 +4139,12 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             nSort = nLeft; sortIn = c->profSorted.as<uint64_t>(); sortOut = c->profKeys.as<uint64_t>();   // what is left, sorted back into the key buffer
         }
         if (nSort > 0) {
-            size_t tmpBytes = 0;
-            HIPCHK(rocprim::radix_sort_keys(nullptr, tmpBytes, sortIn, sortOut, (size_t)nSort, 16u, 16u + PL.bits(), c->stream));
-            if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-            HIPCHK(rocprim::radix_sort_keys(c->sortTmp.p, tmpBytes, sortIn, sortOut, (size_t)nSort, 16u, 16u + PL.bits(), c->stream));
+            // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
+            const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
+            if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(nSort)))) return rc;
+            uint64_t *kRes = nullptr;
+            HIPCHK(kasa_radix::sort_pairs<uint64_t>(sortIn, nullptr, sortOut, nullptr, (uint32_t)nSort, 16, sortBits, c->sortTmp.p, c->stream, &kRes, nullptr));
+            sortOut = kRes;                                            // (wherever the last pass left them)
             profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
                 sortOut, (uint32_t)nSort, nTaxa,
                 c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <chrono>
@@ -359,7 +360,7 @@ struct ChunkReader {
     int fd = -1;                                  // plain (not gzip'ed) input is read with read(2): zlib's pass-through copies at 1 GB/s
     string carry;
     bool fasta = false, protein = false, eof = false, first = true;
-    size_t blockBytes = 64u << 20;
+    size_t blockBytes = 256u << 20;
     explicit ChunkReader(const string &path)
     {
         fd = ::open(path.c_str(), O_RDONLY);
@@ -375,10 +376,29 @@ struct ChunkReader {
         if (const char *e = getenv("KASA_READ_BLOCK")) blockBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small blocks
     }
     ~ChunkReader() { if (g) gzclose(g); if (fd >= 0) ::close(fd); }
+    off_t filePos = 0, fileSize = -1;
     long readSome(char *dst, size_t want)
     {
         if (g) return gzread(g, dst, (unsigned)std::min<size_t>(want, 1u << 30));
-        return (long)::read(fd, dst, std::min<size_t>(want, 1u << 30));
+        // a plain file: its bytes are copied out of the page cache by several threads at known offsets (one read(2) copies
+        // at memory speed of ONE core; 6 GB took seconds)
+        if (fileSize < 0) { struct stat st; fileSize = (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) ? st.st_size : 0; }
+        if (fileSize == 0) return (long)::read(fd, dst, std::min<size_t>(want, 1u << 30));          // a pipe or the like
+        want = (size_t)std::min<off_t>((off_t)std::min<size_t>(want, 1u << 30), fileSize - filePos);
+        if (want == 0) return 0;
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(8, want >> 24));
+        const size_t slice = (want + nt - 1) / nt;
+        vector<long> got(nt, 0);
+        auto one = [&](size_t t) {
+            size_t a = t * slice, e = std::min(want, a + slice);
+            while (a < e) { const ssize_t n = ::pread(fd, dst + a, e - a, filePos + (off_t)a); if (n <= 0) break; a += (size_t)n; got[t] += n; }
+        };
+        if (nt == 1) one(0);
+        else { vector<std::thread> pool; for (size_t t = 0; t < nt; ++t) pool.emplace_back(one, t); for (auto &th : pool) th.join(); }
+        long total = 0;
+        for (size_t t = 0; t < nt; ++t) { total += got[t]; if ((size_t)got[t] < std::min(want, (t + 1) * slice) - t * slice) break; }   // (a short slice ends the data)
+        filePos += total;
+        return total;
     }
     // next chunk of whole records ("" at the end of the file)
     bool next(string &chunk, bool verbose)
@@ -424,7 +444,7 @@ struct ChunkReader {
 // a chunk of whole records parsed by several threads, appended to `out`
 static void parseChunk(const string &data, bool fasta, unsigned threads, ReadSet &out)
 {
-    size_t minRun = 8u << 20;
+    size_t minRun = 1u << 20;
     if (const char *e = getenv("KASA_PARSE_CHUNK")) minRun = std::max<size_t>(1, (size_t)atoll(e));   // tests force small runs
     const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, data.size() / minRun));
     vector<size_t> cut{0};
@@ -435,24 +455,29 @@ static void parseChunk(const string &data, bool fasta, unsigned threads, ReadSet
     cut.push_back(data.size());
     const size_t nc = cut.size() - 1;
     vector<ReadSet> part(nc);
-    if (nc == 1) parseRecords(data, 0, data.size(), fasta, part[0]);
-    else {
+    auto inParallel = [&](const std::function<void(size_t)> &fn) {
+        if (nc == 1) { fn(0); return; }
         vector<std::exception_ptr> err(nc);
         vector<std::thread> pool;
-        for (size_t c = 0; c < nc; ++c)
-            pool.emplace_back([&, c] { try { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); } catch (...) { err[c] = std::current_exception(); } });
+        for (size_t c = 0; c < nc; ++c) pool.emplace_back([&, c] { try { fn(c); } catch (...) { err[c] = std::current_exception(); } });
         for (auto &t : pool) t.join();
         for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
-    }
-    for (auto &q : part) {
-        const int64_t b0 = (int64_t)out.bases.size();
-        out.bases.insert(out.bases.end(), q.bases.begin(), q.bases.end());
+    };
+    inParallel([&](size_t c) { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); });
+    // the runs' reads behind the pending ones: places from running sums, copies by the same threads
+    vector<size_t> b0(nc), r0(nc);
+    size_t nb = out.bases.size(), nr = out.names.size();
+    for (size_t c = 0; c < nc; ++c) { b0[c] = nb; r0[c] = nr; nb += part[c].bases.size(); nr += part[c].names.size(); }
+    out.bases.resize(nb); out.off.resize(nr + 1); out.names.resize(nr); out.lengths.resize(nr);
+    inParallel([&](size_t c) {
+        ReadSet &q = part[c];
+        if (!q.bases.empty()) memcpy(out.bases.data() + b0[c], q.bases.data(), q.bases.size());
         for (size_t r = 0; r < q.names.size(); ++r) {
-            out.names.push_back(std::move(q.names[r]));
-            out.lengths.push_back(q.lengths[r]);
-            out.off.push_back(b0 + q.off[r + 1]);
+            out.names[r0[c] + r] = std::move(q.names[r]);
+            out.lengths[r0[c] + r] = q.lengths[r];
+            out.off[r0[c] + r + 1] = (int64_t)b0[c] + q.off[r + 1];
         }
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -788,7 +813,7 @@ struct Batch {
     uint64_t id = 0, firstRead = 0;
     ReadSet rs;                                   // the batch's reads (offsets start at 0)
     vector<uint32_t> segRead;                     // paired-end: read of every sequence
-    string text;                                  // per-read output of the batch
+    vector<string> texts;                         // per-read output of the batch, in slabs of reads (written one after the other)
     vector<uint64_t> flagged;                     // --filter: read numbers of contaminants
     uint64_t kmers = 0;
     uint32_t flaggedByDevice = 0;                 // reads kasa_batch_rank handed back to the host's std::sort
@@ -875,28 +900,44 @@ struct Batcher {
         if (useRef && !firstBatch && refBudget - (int64_t)(refBudget * 0.001) > 0) left -= (int64_t)(refBudget * 0.001);   // Compare.hpp:3129-3132
         uint64_t est = 0, n = 0;
         bool deviceFull = false;
-        for (;;) {
+        bool full = false;
+        while (!full) {
             if (pendingReads() == 0) { refill(); if (pendingReads() == 0) break; }
-            if (useRef && left <= 100ll * 1024 * 1024 && n > 0) break;                               // Read.hpp:1147
-            const size_t r = pendPos;
-            uint64_t len = 0;
-            int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), (uint32_t)ixf.content.taxids.size(), p.coherence ? 1 : 0) : 0;
-            for (size_t q = 0; q < spr; ++q) {
-                const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
-                len += (uint64_t)l;
-                if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
+            // how many of the pending reads the batch takes (the reference's arithmetic, read by read) ...
+            const size_t first = pendPos;
+            size_t r = first;
+            const uint32_t nTaxa = (uint32_t)ixf.content.taxids.size();
+            for (; r < pending.names.size(); ++r) {
+                if (useRef && left <= 100ll * 1024 * 1024 && n > 0) { full = true; break; }                        // Read.hpp:1147
+                uint64_t len = 0;
+                int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), nTaxa, p.coherence ? 1 : 0) : 0;
+                for (size_t q = 0; q < spr; ++q) {
+                    const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
+                    len += (uint64_t)l;
+                    if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
+                }
+                const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
+                if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; full = true; break; }
+                est += k; left -= cost; ++n;
             }
-            const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
-            if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; break; }
-            est += k; left -= cost; ++n;
-            // move the read into the batch
-            const int64_t s0 = pending.off[r * spr], s1 = pending.off[(r + 1) * spr];
-            const int64_t base = (int64_t)b.rs.bases.size();
+            // ... and those reads moved into it in one piece
+            const size_t m = r - first;
+            if (m == 0) break;
+            if (first == 0 && m == pending.names.size() && b.rs.names.empty() && !paired) {
+                b.rs = std::move(pending);                              // the whole chunk: nothing is copied
+                pending = ReadSet(); pendPos = 0;
+                continue;
+            }
+            const int64_t s0 = pending.off[first * spr], s1 = pending.off[r * spr];
+            const int64_t base = (int64_t)b.rs.bases.size() - s0;
             b.rs.bases.insert(b.rs.bases.end(), pending.bases.begin() + s0, pending.bases.begin() + s1);
-            for (size_t q = 0; q < spr; ++q) { b.rs.off.push_back(base + pending.off[r * spr + q + 1] - s0); if (paired) b.segRead.push_back((uint32_t)(n - 1)); }
-            b.rs.names.push_back(std::move(pending.names[r]));
-            b.rs.lengths.push_back(pending.lengths[r]);
-            ++pendPos;
+            const size_t o0 = b.rs.off.size();
+            b.rs.off.resize(o0 + m * spr);
+            for (size_t q = 0; q < m * spr; ++q) b.rs.off[o0 + q] = base + pending.off[first * spr + q + 1];
+            if (paired) { const uint32_t r0 = (uint32_t)b.rs.names.size(); for (size_t x = 0; x < m; ++x) { b.segRead.push_back(r0 + (uint32_t)x); b.segRead.push_back(r0 + (uint32_t)x); } }
+            b.rs.names.insert(b.rs.names.end(), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)first), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)r));
+            b.rs.lengths.insert(b.rs.lengths.end(), pending.lengths.begin() + (std::ptrdiff_t)first, pending.lengths.begin() + (std::ptrdiff_t)r);
+            pendPos = r;
         }
         if (useRef && deviceFull && !warned) {
             std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
@@ -991,7 +1032,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 if (sidx >= nSlabs) break;
                 const uint64_t a = sidx * slab, e = std::min<uint64_t>(nr, a + slab);
                 string &text = texts[sidx];
-                text.reserve((size_t)(e - a) * 320);
+                text.reserve((size_t)(e - a) * (p.fmt == Params::Json ? 900 : 600));
                 for (uint64_t r = a; r < e; ++r) {
                     if (p.coherence) w.coherence = coherence[r];
                     if (deviceRank && !(meta[4 * r + 1] >> 31)) {
@@ -1007,10 +1048,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     if (nt == 1) work(0);
     else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
     for (auto &e : err) if (e) std::rethrow_exception(e);
-    size_t total = 0;
-    for (auto &t : texts) total += t.size();
-    b.text.reserve(total);
-    for (auto &t : texts) b.text += t;
+    b.texts = std::move(texts);                                    // (no second copy of gigabytes of text: the writer takes the slabs)
     for (auto &f : flagged) b.flagged.insert(b.flagged.end(), f.begin(), f.end());
     tText += secondsSince(tTxt);
 }
@@ -1041,13 +1079,37 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     p.protein = batcher.protein;
     for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
-    std::ofstream out;
+    // the per-read file: written at explicit offsets, the slabs of a batch by several threads at once (one thread fills the
+    // page cache at 2-3 GB/s; 10 M reads are 5.5 GB of JSON lines)
+    struct OutFile {
+        int fd = -1; off_t pos = 0;
+        ~OutFile() { if (fd >= 0) ::close(fd); }
+        static void writeAt(int fd, const char *d, size_t n, off_t at)
+        {
+            while (n) { const ssize_t w = ::pwrite(fd, d, n, at); if (w <= 0) throw std::runtime_error("Readwise output file could not be written!"); d += w; n -= (size_t)w; at += w; }
+        }
+        void put(const string &t) { writeAt(fd, t.data(), t.size(), pos); pos += (off_t)t.size(); }
+        void putAll(const vector<string> &slabs, unsigned threads)
+        {
+            vector<off_t> at(slabs.size());
+            for (size_t i = 0; i < slabs.size(); ++i) { at[i] = pos; pos += (off_t)slabs[i].size(); }
+            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(threads, 16u), slabs.size()));
+            if (nt == 1) { for (size_t i = 0; i < slabs.size(); ++i) writeAt(fd, slabs[i].data(), slabs[i].size(), at[i]); return; }
+            std::atomic<size_t> next{0};
+            vector<std::exception_ptr> err(nt);
+            vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&, t] { try { for (size_t i; (i = next.fetch_add(1)) < slabs.size();) writeAt(fd, slabs[i].data(), slabs[i].size(), at[i]); } catch (...) { err[t] = std::current_exception(); } });
+            for (auto &th : pool) th.join();
+            for (auto &e : err) if (e) std::rethrow_exception(e);
+        }
+    } out;
     if (!p.rtt.empty()) {
-        out.open(p.rtt, std::ios::binary);
-        if (!out) throw std::runtime_error("Readwise output file could not be created!");
-        if (p.fmt == Params::Tsv) out << (p.coherence ? "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\tCoherence\n"
-                                                       : "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n");
-        else if (p.fmt == Params::Json) out << "[\n";
+        out.fd = ::open(p.rtt.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (out.fd < 0) throw std::runtime_error("Readwise output file could not be created!");
+        if (p.fmt == Params::Tsv) out.put(p.coherence ? "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\tCoherence\n"
+                                                      : "#Read number\tSpecifier from input file\tMatched taxa\tNames\tScores{relative,k-mer}\tError\n");
+        else if (p.fmt == Params::Json) out.put("[\n");
     }
     if (!p.profile.empty() && !std::ofstream(p.profile)) throw std::runtime_error("Profile file couldn't be opened for writing!");
 
@@ -1101,7 +1163,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
             std::unique_ptr<Batch> b = std::move(it->second);
             finished.erase(it);
             lk.unlock();
-            if (!p.rtt.empty()) out.write(b->text.data(), (std::streamsize)b->text.size());
+            if (!p.rtt.empty()) out.putAll(b->texts, p.threads);
             contaminants.insert(contaminants.end(), b->flagged.begin(), b->flagged.end());
             ++written;
             lk.lock();
@@ -1131,7 +1193,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     for (auto &t : pool) t.join();
     if (failure) std::rethrow_exception(failure);
     const uint64_t nReads = batcher.nextRead;
-    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out << "\n]"; out.flush(); }
+    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out.put("\n]"); ::close(out.fd); out.fd = -1; }
     if (p.filter) filterReads(p, contaminants);
     // profile: one RCCL all-reduce over the devices' tables, then device 0's copy
     if (nDev > 1 || getenv("KASA_FORCE_ALLREDUCE")) {        // (the variable: tests run the reduce with a single rank)
@@ -1274,7 +1336,7 @@ static int run(int argc, char **argv)
         ixf.onDevice.push_back(ix);
     }
     munmap(rec, ixf.nRec * ixf.recBytes); close(fd);
-    if (p.threads == 0) p.threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (p.threads == 0) p.threads = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
 
     vector<int> allSlots;
     for (size_t d = 0; d < p.devices.size(); ++d) allSlots.push_back((int)d);

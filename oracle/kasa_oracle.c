@@ -774,6 +774,7 @@ typedef struct {
     uint64_t *hist;               /* [nThreads][KO_NB] */
     uint64_t *bucketStart;        /* [KO_NB + 1] */
     int zeroM;                    /* the score matrix still has to be cleared */
+    int timing; double t0;
     volatile int *nextBucket;
     uint64_t *rs; uint32_t *rl;
     uint64_t s0, s1;              /* slice of the sorted queries */
@@ -788,6 +789,12 @@ typedef struct {
 #define KO_BBITS 16
 #define KO_NB (1 << KO_BBITS)
 static int key_bucket(ko_key k, int K) { return (int)((k >> (5 * K - KO_BBITS)) & (KO_NB - 1)); }
+
+#include <time.h>
+#include <stdio.h>
+static double ko_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+/* KO_TIMING=1: thread 0 reports when it passed each phase (seconds since the workers started) */
+#define KO_MARK(name) do { if (t == 0 && j->timing) fprintf(stderr, "ko_identify_threaded: %-22s %8.3f s\n", name, ko_now() - j->t0); } while (0)
 
 static void *ko_worker(void *arg)
 {
@@ -804,12 +811,16 @@ static void *ko_worker(void *arg)
         ko_encode_batch(j->bases, j->off + j->r0, n, j->p, j->lut, j->km + q0, j->rd + q0);
         for (uint64_t i = q0; i < q1; ++i) j->rd[i] += (uint32_t)j->r0;
     }
+    pthread_barrier_wait(j->bar);
+    KO_MARK("translated");
     /* the score matrix is touched first by the workers, a share each: its pages are spread over the memory nodes and the
      * page faults (3.4 GB at 600 000 reads x 1400 taxa) are not taken one after the other by the thread that merges first */
     if (j->zeroM) {
         const uint64_t cellsM = j->nReads * (uint64_t)j->ix->nTaxa, za = cellsM * (uint64_t)t / (uint64_t)T, ze = cellsM * (uint64_t)(t + 1) / (uint64_t)T;
         memset(j->M + za, 0, (size_t)(ze - za) * 4);
     }
+    pthread_barrier_wait(j->bar);
+    KO_MARK("matrix cleared");
     /* 2. parallel sort: stable bucket pass on the top bits, then the buckets */
     uint64_t *h = j->hist + (size_t)t * KO_NB;
     memset(h, 0, KO_NB * sizeof(uint64_t));
@@ -829,6 +840,7 @@ static void *ko_worker(void *arg)
     pthread_barrier_wait(j->bar);
     for (uint64_t i = q0; i < q1; ++i) { const uint64_t d = h[key_bucket(j->km[i], j->p->K)]++; j->km2[d] = j->km[i]; j->rd2[d] = j->rd[i]; }
     pthread_barrier_wait(j->bar);
+    KO_MARK("bucket pass");
     for (;;) {                                                     /* runs of 64 buckets at a time */
         const int b = __sync_fetch_and_add(j->nextBucket, 64);
         if (b >= KO_NB) break;
@@ -838,10 +850,12 @@ static void *ko_worker(void *arg)
         }
     }
     pthread_barrier_wait(j->bar);
+    KO_MARK("buckets sorted");
     /* 3. ranges of my share */
     const uint64_t nQ = j->nQ, a = nQ * (uint64_t)t / (uint64_t)T, e = nQ * (uint64_t)(t + 1) / (uint64_t)T;
     if (e > a) ko_ranges(j->ix, j->p, j->km2 + a, e - a, j->rs + a, j->rl + a);
     pthread_barrier_wait(j->bar);
+    KO_MARK("ranges");
     /* 4. slices on range boundaries (Compare.hpp:3263-3283), private tables, shared matrix */
     if (t == 0) {
         j->cuts[0] = 0;
@@ -857,6 +871,9 @@ static void *ko_worker(void *arg)
     const uint64_t s0 = j->cuts[t], s1 = j->cuts[t + 1];
     if (s1 > s0)
         ko_compare_sequential(j->p, j->ix, j->km2 + s0, j->rd2 + s0, j->rs + s0, j->rl + s0, s1 - s0, j->nReads, j->ca, j->cu, j->ct, j->M);
+    KO_MARK("my slice merged");
+    pthread_barrier_wait(j->bar);
+    KO_MARK("all slices merged");
     return NULL;
 }
 
@@ -885,6 +902,7 @@ int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *
     int rc = -1;
     if (km && km2 && rd && rd2 && rl && rs && kcount && koff && hist && cuts && ca && cu && ct && Mloc && jobs && th && bucketStart) {
         pthread_barrier_init(&bar, NULL, (unsigned)T);
+        const double tStart = ko_now();
         for (int t = 0; t < T; ++t) {
             ko_job *j = &jobs[t];
             j->p = p; j->ix = ix; j->bases = bases; j->off = off; j->lut = lut; j->nThreads = T; j->tid = t;
@@ -892,7 +910,7 @@ int ko_identify_threaded(const ko_params *p, const ko_index *ix, const uint8_t *
             j->kcount = kcount; j->km = km; j->km2 = km2; j->rd = rd; j->rd2 = rd2; j->nQ = nQ; j->koff = koff;
             j->hist = hist; j->bucketStart = bucketStart; j->nextBucket = &nextBucket; j->rs = rs; j->rl = rl;
             j->nReads = (uint64_t)nReads; j->ca = ca + cells * (size_t)t; j->cu = cu + cells * (size_t)t; j->ct = ct + cells * (size_t)t;
-            j->M = Mloc; j->bar = &bar; j->cuts = cuts; j->zeroM = M ? 0 : 1;
+            j->M = Mloc; j->bar = &bar; j->cuts = cuts; j->zeroM = M ? 0 : 1; j->timing = getenv("KO_TIMING") != NULL; j->t0 = tStart;
             pthread_create(&th[t], NULL, ko_worker, j);
         }
         for (int t = 0; t < T; ++t) pthread_join(th[t], NULL);

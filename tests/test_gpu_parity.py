@@ -372,7 +372,7 @@ def test_repeated_reads_fill_a_sort_bucket(K):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, 7, 3)
     outs = []
-    for flags in (0, 64, 128):
+    for flags in (0, 64, 128, 512):
         ctx.debug_flags(flags)
         ctx.upload(big.bases, big.offsets); ctx.encode(); ctx.sort_and_range()
         km, rd = ctx.queries()
@@ -404,13 +404,47 @@ def test_last_sort_bucket_straddles_the_last_tile(tail, members):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
     qs, rs_ = oracle.sort_queries(q, rd)
-    for flags in (0, 64):
+    for flags in (0, 64, 512):
         ctx.debug_flags(flags)
         ctx.set_queries(q, rd, 50)
         ctx.sort_and_range()
         km, r2 = ctx.queries()
         assert np.array_equal(km, qs) and np.array_equal(r2, rs_)
     ctx.close(); dix.close()
+
+
+@pytest.mark.parametrize("K", [12, 25])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 3 * 8192 + 5, 70001])
+def test_query_sort_of_any_size(n, K):
+    """The hand-written radix passes (kasa_radix.h: tiles of 8192 / 4096 pairs, look-back over the tiles before) followed
+    by the bucket pass, on batches that end anywhere in a tile: equal to a stable sort, payload included.  Half of the keys
+    share their top 40 bits with another key; a fifth are equal."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(1234 + n)
+    ix, _ = synthetic_world(71 + K, 4, 3000, 10, K=K)
+    bits = 5 * K
+    top = rng.integers(0, 1 << 40, size=max(1, n // 2), dtype=np.uint64)
+    pick = top[rng.integers(0, top.shape[0], size=n)]
+    if K == 12:
+        q = (pick << np.uint64(20)) | rng.integers(0, 1 << 20, size=n, dtype=np.uint64)
+        q[rng.random(n) < 0.2] = q[0]
+    else:
+        q = np.zeros(n, dtype=formats.KEY128_DTYPE)
+        q["hi"] = (pick << np.uint64(21)) | rng.integers(0, 1 << 21, size=n, dtype=np.uint64)     # key bits 64..124
+        q["lo"] = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        q[rng.random(n) < 0.2] = q[0]
+    rd = rng.integers(0, 30, size=n).astype(np.uint32)
+    qs, rs_ = oracle.sort_queries(q, rd)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, K, 7, 3)
+    for flags in (0, 512):
+        ctx.debug_flags(flags)
+        ctx.set_queries(q, rd, 30)
+        ctx.sort_and_range()
+        km, r2 = ctx.queries()
+        assert np.array_equal(km, qs) and np.array_equal(r2, rs_)
+    ctx.close(); dix.close()
+    assert bits in (60, 125)
 
 
 def test_one_frame_reads_of_several_encoder_chunks():

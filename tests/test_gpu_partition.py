@@ -186,22 +186,99 @@ def test_two_ranks_one_partition_each(tmp_path):
     dix.close()
 
 
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (fresh processes, before
-    anything touches a GPU) and rank 0 prints the one JSON line.  On a one-GPU box both ranks share device 0 and the
-    reduce runs over gloo (KASA_BENCH_SHARE_GPU=1: the multi-rank code path, not a measurement)."""
+def _bench(args, share=True, timeout=900):
     import json
     import subprocess
     import sys
     assert capi.device_count() > 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KASA_BENCH_SHARE_GPU="1")
+    env = dict(os.environ)
+    if share:
+        env["KASA_BENCH_SHARE_GPU"] = "1"
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "20000",
-                        "--taxa", "8", "--genome-len", "20000", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (fresh processes, before
+    anything touches a GPU) and rank 0 prints the one JSON line.  On a one-GPU box both ranks share device 0 and the
+    reduce runs over gloo (KASA_BENCH_SHARE_GPU=1: the multi-rank code path, not a measurement).  The workload is
+    BASELINE.json configs[3] in small: a fixed total of reads, every rank's share resident in HBM and taken in batches."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "10000", "--total-reads", "50000",
+                  "--taxa", "8", "--genome-len", "20000", "--no-cpu"])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["kernel"]
+    assert out["scaling"] == "strong" and out["config"]["batches_per_step"] == 3 and out["config"]["reads_per_gpu"] == 25000
+    assert out["config"]["total_reads"] == 50000 and 0.5 < out["identified_fraction"] <= 1.0
+
+
+def test_bench_default_line_carries_every_leg(tmp_path):
+    """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), the PCIe-inclusive and the
+    file-to-file rates, the CPU baseline with its one-thread rate -- all in the one JSON line."""
+    out = _bench(["--steps", "1", "--warmup", "1", "--reads", "30000", "--taxa", "8", "--genome-len", "20000",
+                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000"], share=False)
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["dtype"] == "u64"
+    assert out["secondary"]["dtype"] == "u128" and out["secondary"]["value"] > 0
+    e = out["e2e"]
+    assert e["pcie_inclusive_reads_per_s"] > 0 and e["file_to_file_reads_per_s"] > 0 and e["batches"] >= 1
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["single_thread_value"] > 0 and c["speedup_over_1"] > 0
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+
+
+def test_c_abi_reduce_with_a_communicator_of_its_own(tmp_path):
+    """kasa_amd/dist.py:rccl_communicator (ncclUniqueId over torch.distributed, ncclCommInitRank by ctypes) + kasa_profile_allreduce
+    -- what bench.py's multi-GPU step uses -- with the one rank this box has: the tables come back unchanged."""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from kasa_amd import capi, formats, reads, dist as kdist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+d = os.path.join(sys.argv[1], "tests", "golden", "pairs")
+ix = formats.load_index(os.path.join(d, "idx"), os.path.join(d, "content.txt"))
+batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+dix = capi.DeviceIndex(ix); ctx = capi.Context(dix, 12, 7, 3)
+ctx.run_batch(batch.bases, batch.offsets, True)
+before = ctx.profile_limbs().copy()
+comm, n = kdist.rccl_communicator(0, 1)
+assert n == 1 and comm
+ctx.profile_allreduce(comm)
+ctx.synchronize()
+ca0, cu0, _ = ctx.profile()
+assert np.array_equal(cu0, before.reshape(-1, 6)[:, 0].reshape(cu0.shape))
+ctx.profile_allreduce(comm)                                   # idempotent with one rank
+ca1, cu1, _ = ctx.profile()
+assert np.array_equal(cu0, cu1) and np.array_equal(ca0, ca1) and cu0.sum() > 0
+kdist.rccl_destroy(comm)
+dist.destroy_process_group()
+print("ok")
+""")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), root], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("gpus,share", [(2, True), (1, False)], ids=["two_ranks_share_the_gpu_gloo", "one_rank_rccl_device_resident"])
+def test_bench_partitioned(gpus, share):
+    """bench.py --partitioned (BASELINE.json configs[4] in small): every rank synthesises its slice of the index on the device
+    (the genomes' records of its prefix range + random filler), sizes its batch from the free HBM and runs the exchange."""
+    out = _bench(["--partitioned", "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--reads", "4000", "--part-records", "3e6",
+                  "--taxa", "8", "--genome-len", "20000"], share=share)
+    assert out["n_gpus"] == gpus and out["value"] > 0 and out["config"]["slice_records"] > 1_000_000
+    assert 0.3 < out["identified_fraction"] <= 1.0
+    x = out["exchange_bytes_per_step_this_rank"]
+    if gpus > 1:
+        assert x["queries_sent"] > 0 and x["records_received"] > 0
