@@ -158,6 +158,33 @@ template <class Key> __host__ __device__ constexpr Key field_repeat(unsigned v)
 
 __device__ __forceinline__ int group_letters(int k) { return k < RANGE_LETTERS ? RANGE_LETTERS : k; }
 
+// Running sums over the 64 lanes of a wavefront by DPP (data-parallel primitives: a lane reads its neighbour's register
+// inside the VALU instruction): four shifts inside the rows of 16 lanes, then the last lane of a row added to the rows
+// behind it.  Twelve instructions and no trip through the LDS crossbar, where the __shfl_up form (ds_bpermute) takes six
+// dependent LDS round trips.  ALL 64 lanes must be active.
+#define KASA_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    v += (uint32_t)KASA_DPP(v, 0x111, 0xf);                           // row_shr:1
+    v += (uint32_t)KASA_DPP(v, 0x112, 0xf);                           // row_shr:2
+    v += (uint32_t)KASA_DPP(v, 0x114, 0xf);                           // row_shr:4
+    v += (uint32_t)KASA_DPP(v, 0x118, 0xf);                           // row_shr:8
+    v += (uint32_t)KASA_DPP(v, 0x142, 0xa);                           // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)KASA_DPP(v, 0x143, 0xc);                           // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
+// the same, restarting at every lane whose flag is set: on return f = "a flag was set at or before this lane"
+__device__ __forceinline__ void wave_seg_incl_sum(uint32_t &v, bool &f)
+{
+    uint32_t fl = f ? 1u : 0u;
+#define KASA_SEG_STEP(ctrl, rows) do { const uint32_t ov = (uint32_t)KASA_DPP(v, ctrl, rows), of = (uint32_t)KASA_DPP(fl, ctrl, rows); v += fl ? 0u : ov; fl |= of; } while (0)
+    KASA_SEG_STEP(0x111, 0xf); KASA_SEG_STEP(0x112, 0xf); KASA_SEG_STEP(0x114, 0xf); KASA_SEG_STEP(0x118, 0xf);
+    KASA_SEG_STEP(0x142, 0xa); KASA_SEG_STEP(0x143, 0xc);
+#undef KASA_SEG_STEP
+    f = fl != 0u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // index
 // ------------------------------------------------------------------------------------------------
@@ -765,6 +792,7 @@ static constexpr int ENC_CHUNK = 512;                       // windows per chunk
 static constexpr int ENC_WAVES = 4;
 static constexpr int ENC_RANK_MAX = 512;                    // k-mers of a read the encoder ranks itself (payload = slot)
 
+#define LDS_WAVE_SYNC_ENC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 template <class Key>
 __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
@@ -852,59 +880,53 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
             }
         }
         if (rankSlots) {
-            // rank = k-mers of the read that are smaller; every lane holds up to ENC_RANK_MAX / 64 of them and compares them
-            // with each of the read's k-mers (one broadcast LDS read per k-mer).  The keys wait in LDS shifted to the top of
-            // their word, and the count runs over their TOP HALVES only (one 32-bit compare and one add with carry per pair
-            // for 64-bit keys; a 64-bit compare for 128-bit ones): two k-mers of one read that share their first six (twelve)
-            // letters are rare.  k-mers that end up with the same count -- equal top halves -- are counted again in full,
-            // equal k-mers told apart by their index (window order, as the stable sort would leave them).
-            typedef typename std::conditional<sizeof(Key) == 8, uint32_t, uint64_t>::type Half;
-            constexpr int HSH = 8 * (sizeof(Key) - sizeof(Half));
+            // rank = k-mers of the read that are smaller (equal ones: those with a lower index, as the stable sort leaves
+            // them).  Comparing every k-mer with every other took 130 steps per k-mer; instead the k-mers are dealt into 64
+            // buckets by their top six bits (lane b owns bucket b: counts by LDS atomics, starts by one running sum over the
+            // lanes) and a k-mer is compared with the members of its own bucket only -- two or three on average, a dozen for
+            // the most common first letter.
             const int n = strands * (int)cnt;
             constexpr int PER = ENC_RANK_MAX / 64;
-            Half mine[PER];
-            uint32_t rank[PER];
+            constexpr int TOPSH = 8 * (int)sizeof(Key) - 6;
+            uint32_t *sCount = &sTaken[wv][0], *sStart = &sTaken[wv][64];    // (sTaken: 512 words per wave, 128 used here)
+            uint16_t *sMember = reinterpret_cast<uint16_t *>(&sTaken[wv][128]);   // item indices grouped by bucket: n <= 512 halfwords
+            sCount[lane] = 0u;
+            LDS_WAVE_SYNC_ENC();
+            uint32_t place[PER];                                         // arrival number inside the bucket
 #pragma unroll
-            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; mine[q] = i < n ? (Half)(sKey[wv][i] >> HSH) : (Half)0; rank[q] = 0; if (i < n) sTaken[wv][i] = 0; }
-            const int groups = (n + 63) / 64;                        // items per lane that exist at all (uniform)
-            const Half *sHalf = reinterpret_cast<const Half *>(&sKey[wv][0]) + 1;   // little endian: the top half is the second one
-            auto count = [&](auto G) {                               // the loop for G items per lane
-                for (int j = 0; j < n; ++j) {
-                    const Half kj = sHalf[2 * j];
-#pragma unroll
-                    for (int q = 0; q < decltype(G)::value; ++q) rank[q] += (kj < mine[q]) ? 1u : 0u;
-                }
-            };
-            switch (groups) {
-            case 1: count(std::integral_constant<int, 1>()); break;
-            case 2: count(std::integral_constant<int, 2>()); break;
-            case 3: count(std::integral_constant<int, 3>()); break;
-            case 4: count(std::integral_constant<int, 4>()); break;
-            default: count(std::integral_constant<int, PER>()); break;
+            for (int q = 0; q < PER; ++q) {
+                const int i = lane + 64 * q;
+                place[q] = i < n ? atomicAdd(&sCount[(uint32_t)(sKey[wv][i] >> TOPSH)], 1u) : 0u;
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            LDS_WAVE_SYNC_ENC();
+            const uint32_t mineCount = sCount[lane];
+            sStart[lane] = wave_incl_sum(mineCount) - mineCount;
+            LDS_WAVE_SYNC_ENC();
 #pragma unroll
-            for (int q = 0; q < PER; ++q) { const int i = lane + 64 * q; if (i < n) atomicAdd(&sTaken[wv][rank[q]], 1u); }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < PER; ++q) {
+                const int i = lane + 64 * q;
+                if (i < n) sMember[sStart[(uint32_t)(sKey[wv][i] >> TOPSH)] + place[q]] = (uint16_t)i;
+            }
+            LDS_WAVE_SYNC_ENC();
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
                 const int i = lane + 64 * q;
                 if (i >= n) continue;
-                uint32_t rk = rank[q];
-                if (sTaken[wv][rk] > 1u) {                            // equal top halves: the whole keys, then the index
-                    const Key me = sKey[wv][i];
-                    rk = 0;
-                    for (int j = 0; j < n; ++j) { const Key kj = sKey[wv][j]; rk += (kj < me || (kj == me && j < i)) ? 1u : 0u; }
+                const Key me = sKey[wv][i];
+                const uint32_t b = (uint32_t)(me >> TOPSH), first = sStart[b], members = sCount[b];
+                uint32_t rk = first;
+                for (uint32_t m = 0; m < members; ++m) {
+                    const int other = (int)sMember[first + m];
+                    const Key ko = sKey[wv][other];
+                    rk += (ko < me || (ko == me && other < i)) ? 1u : 0u;
                 }
                 outRead[o0 + (uint64_t)i] = (uint32_t)(o0 + rk);
             }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            LDS_WAVE_SYNC_ENC();
         }
     }
 }
+#undef LDS_WAVE_SYNC_ENC
 
 extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
 {
@@ -1679,10 +1701,7 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t incl = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
+    incl = wave_incl_sum(incl);
     if (lane == 63) sh[wv] = incl;
     __syncthreads();
     uint32_t before = 0, all = 0;
@@ -2663,10 +2682,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                 const uint32_t nm = live ? Q.nMore : 0u;
                 if (__ballot(nm != 0u) != 0ull) {
                     uint32_t incl = nm;
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t o = __shfl_up(incl, off);
-                        if (lane >= off) incl += o;
-                    }
+                    incl = wave_incl_sum(incl);
                     const uint32_t S = __shfl(incl, 63);
                     const unsigned long long satMask = __ballot(sat);
                     sPB[lane] = incl - nm;
@@ -2736,10 +2752,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         if (active && !fb && nFinal + nprof + nOther > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge handles
         const uint32_t m = (active && !fb) ? nFinal + nprof + nOther : 0u;
         uint32_t incl = m;
-        for (int off = 1; off < 64; off <<= 1) {                               // converged: one allocation per wavefront
-            const uint32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        incl = wave_incl_sum(incl);
         const uint32_t total = __shfl(incl, 63);
         unsigned long long start = 0;
         if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
@@ -2748,10 +2761,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         // ... and its profile keys: one per counter record and per event of the other taxa
         const uint32_t mk = (active && !fb) ? nprof + nKeys : 0u;
         uint32_t inclK = mk;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(inclK, off);
-            if (lane >= off) inclK += o;
-        }
+        inclK = wave_incl_sum(inclK);
         const uint32_t totalK = __shfl(inclK, 63);
         unsigned long long startK = 0;
         if (lane == 0 && totalK) startK = atomicAdd(A.keyCursor, (unsigned long long)totalK);
@@ -2900,17 +2910,10 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         const bool head = inRange && (uint64_t)slot == readStart;
         uint32_t incl = mine;
         bool started = head;                                                   // a read starts at or before this lane, inside the wavefront
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off);
-            const bool s2 = __shfl_up((int)started, off) != 0;
-            if (lane >= off && !started) { incl += o; started = s2; }
-        }
+        wave_seg_incl_sum(incl, started);
         // place in the wavefront's staging area: a plain prefix sum
         uint32_t lincl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(lincl, off);
-            if (lane >= off) lincl += o;
-        }
+        lincl = wave_incl_sum(lincl);
         const uint32_t total = __shfl(lincl, 63);
         if (total == 0u) continue;                                           // uniform
         const bool staged = total <= STAGE;
@@ -3047,10 +3050,7 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
         const uint32_t nEmInl = (uint32_t)__popc(emInl);
         const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
         uint32_t incl = nFlat;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        incl = wave_incl_sum(incl);
         const uint32_t S = __shfl(incl, 63);
         if (S == 0u) continue;                                                 // uniform
         const bool head = inRange && (uint64_t)slot == readStart;
@@ -3101,11 +3101,7 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
             const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
             bool f = act && (H & toOwn & ~toPrev) != 0ull;
             uint32_t v = c;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(v, off);
-                const bool fo = __shfl_up((int)f, off) != 0;
-                if (lane >= off && !f) { v += o; f = fo; }
-            }
+            wave_seg_incl_sum(v, f);
             uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
             carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
             prevOwnCarry = __shfl((int)own, 63);
@@ -3218,10 +3214,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         // ---- sweep 1: |T_k| of every query
         for (int lv = 0; lv <= nK; ++lv) sLvN[wv][lv][lane] = 0u;
         uint32_t incl = Q.nseg;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        incl = wave_incl_sum(incl);
         const uint32_t S1 = __shfl(incl, 63);
         if (S1 == 0u) continue;                                                // uniform: no live query
         sBase[wv][lane] = incl - Q.nseg;
@@ -3267,10 +3260,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         const uint32_t nEmInl = (uint32_t)__popc(emInl);
         const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
         incl = nFlat;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        incl = wave_incl_sum(incl);
         const uint32_t S = __shfl(incl, 63);
         if (S == 0u) { LDS_WAVE_SYNC(); continue; }                            // uniform
         const bool head = inRange && (uint64_t)slot == readStart;
@@ -3317,11 +3307,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
             const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
             bool f = act && (H & toOwn & ~toPrev) != 0ull;
             uint32_t v = c;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(v, off);
-                const bool fo = __shfl_up((int)f, off) != 0;
-                if (lane >= off && !f) { v += o; f = fo; }
-            }
+            wave_seg_incl_sum(v, f);
             uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
             carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
             prevOwnCarry = __shfl((int)own, 63);
@@ -3399,10 +3385,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
             }
             const uint32_t nk = i < m ? record_keys(e) : 0u;          // every event leaves as a profile key
             uint32_t incl = nk;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
-            }
+            incl = wave_incl_sum(incl);
             uint32_t kw = keyAt + incl - nk;
             keyAt += __shfl(incl, 63);
             if (nk) {
@@ -3520,10 +3503,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             if (i < m && kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
             const uint32_t nk = i < m ? record_keys(e) : 0u;
             uint32_t incl = nk;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
-            }
+            incl = wave_incl_sum(incl);
             uint32_t kw = keyAt + incl - nk;
             keyAt += __shfl(incl, 63);
             if (nk) {
@@ -3546,10 +3526,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             const uint32_t w = w0 + lane;
             const uint32_t pc = (w < W) ? (uint32_t)__popc(bm[w]) : 0u;
             uint32_t incl = pc;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off);
-                if (lane >= off) incl += o;
-            }
+            incl = wave_incl_sum(incl);
             if (w < W) pre[w] = carry + incl - pc;
             carry += __shfl(incl, 63);
         }
@@ -4706,10 +4683,7 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
         }
     }
     uint32_t incl = nOut;                                                  // one allocation per wavefront
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
-    }
+    incl = wave_incl_sum(incl);
     const uint32_t total = __shfl(incl, RANK_EXACT_LANES - 1);
     unsigned long long at = 0;
     if (lane == 0 && total) at = atomicAdd(cursor, (unsigned long long)total);

@@ -210,6 +210,20 @@ static vector<uint64_t> loadFreq(const string &prefix, size_t nTaxa, int kHigh, 
     return out;
 }
 
+// KASA_HOST_TIMING=1: where the host spends the time of "Time fastq" (seconds, summed over the file)
+struct HostTimers { double read = 0, cut = 0, parse = 0, merge = 0, form = 0, write = 0; std::mutex mu; bool on = getenv("KASA_HOST_TIMING") != nullptr; };
+static HostTimers g_ht;
+struct ScopedTimerMt {                               // from several threads: summed under a lock (CPU seconds, not wall time)
+    double &acc; std::mutex &mu; std::chrono::steady_clock::time_point t0;
+    ScopedTimerMt(double &a, std::mutex &m) : acc(a), mu(m), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedTimerMt() { const double d = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(mu); acc += d; }
+};
+struct ScopedTimer {
+    double &acc; std::chrono::steady_clock::time_point t0;
+    explicit ScopedTimer(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct ReadSet { vector<uint8_t> bases; vector<int64_t> off{0}; vector<string> names; vector<uint32_t> lengths; bool protein = false; };
 
 // kASA::detectAlphabet (kASA.hpp:155-183) on the first four characters of the file's second line
@@ -408,14 +422,18 @@ struct ChunkReader {
             string data = std::move(carry);
             carry.clear();
             const size_t had = data.size();
-            data.resize(had + blockBytes);
             size_t got = 0;
-            while (got < blockBytes) {
-                const long n = readSome(&data[had + got], blockBytes - got);
-                if (n <= 0) { eof = true; break; }
-                got += (size_t)n;
+            {
+                ScopedTimer tm(g_ht.read);
+                data.resize(had + blockBytes);
+                while (got < blockBytes) {
+                    const long n = readSome(&data[had + got], blockBytes - got);
+                    if (n <= 0) { eof = true; break; }
+                    got += (size_t)n;
+                }
+                data.resize(had + got);
             }
-            data.resize(had + got);
+            ScopedTimer tmCut(g_ht.cut);
             if (first && !data.empty()) {
                 if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
                 fasta = data[0] == '>';
@@ -463,7 +481,8 @@ static void parseChunk(const string &data, bool fasta, unsigned threads, ReadSet
         for (auto &t : pool) t.join();
         for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
     };
-    inParallel([&](size_t c) { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); });
+    { ScopedTimer tm(g_ht.parse); inParallel([&](size_t c) { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); }); }
+    ScopedTimer tmMerge(g_ht.merge);
     // the runs' reads behind the pending ones: places from running sums, copies by the same threads
     vector<size_t> b0(nc), r0(nc);
     size_t nb = out.bases.size(), nr = out.names.size();
@@ -813,7 +832,6 @@ struct Batch {
     uint64_t id = 0, firstRead = 0;
     ReadSet rs;                                   // the batch's reads (offsets start at 0)
     vector<uint32_t> segRead;                     // paired-end: read of every sequence
-    vector<string> texts;                         // per-read output of the batch, in slabs of reads (written one after the other)
     vector<uint64_t> flagged;                     // --filter: read numbers of contaminants
     uint64_t kmers = 0;
     uint32_t flaggedByDevice = 0;                 // reads kasa_batch_rank handed back to the host's std::sort
@@ -886,6 +904,13 @@ struct Batcher {
             }
             pending = std::move(rest); pendPos = 0;
         }
+        if (pending.names.empty() && reader->fileSize > 0) {
+            // room for what is still to come (address space only: untouched pages cost nothing), so that a batch that
+            // takes many chunks never moves what it already holds
+            const size_t left = (size_t)(reader->fileSize - std::min(reader->fileSize, reader->filePos)) + chunk.size();
+            pending.bases.reserve(left / 2 + left / 8 + 1024);
+            pending.names.reserve(left / 160 + 16); pending.lengths.reserve(left / 160 + 16); pending.off.reserve(left / 160 + 17);
+        }
         parseChunk(chunk, reader->fasta, p.threads, pending);
     }
     // the next batch; false at the end of the input
@@ -901,12 +926,19 @@ struct Batcher {
         uint64_t est = 0, n = 0;
         bool deviceFull = false;
         bool full = false;
+        const uint32_t nTaxa = (uint32_t)ixf.content.taxids.size();
+        // The batch's reads are pending[pendPos, r): counted here read by read with the reference's arithmetic; chunks are
+        // parsed behind them as long as the batch has room, and only then the reads change hands -- in one piece.
+        size_t r = pendPos;
         while (!full) {
-            if (pendingReads() == 0) { refill(); if (pendingReads() == 0) break; }
-            // how many of the pending reads the batch takes (the reference's arithmetic, read by read) ...
-            const size_t first = pendPos;
-            size_t r = first;
-            const uint32_t nTaxa = (uint32_t)ixf.content.taxids.size();
+            if (r == pending.names.size()) {
+                const size_t before = pending.names.size() - pendPos;
+                const size_t keep = r - pendPos;
+                refill();                                                   // (may drop the reads before pendPos)
+                r = pendPos + keep;
+                if (pending.names.size() - pendPos == before) break;       // end of the input
+            }
+            ScopedTimer tmForm(g_ht.form);
             for (; r < pending.names.size(); ++r) {
                 if (useRef && left <= 100ll * 1024 * 1024 && n > 0) { full = true; break; }                        // Read.hpp:1147
                 uint64_t len = 0;
@@ -920,24 +952,23 @@ struct Batcher {
                 if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; full = true; break; }
                 est += k; left -= cost; ++n;
             }
-            // ... and those reads moved into it in one piece
-            const size_t m = r - first;
-            if (m == 0) break;
-            if (first == 0 && m == pending.names.size() && b.rs.names.empty() && !paired) {
-                b.rs = std::move(pending);                              // the whole chunk: nothing is copied
+        }
+        {
+            ScopedTimer tmForm(g_ht.form);
+            const size_t first = pendPos, m = r - first;
+            if (m > 0 && first == 0 && r == pending.names.size() && !paired) {
+                b.rs = std::move(pending);                              // everything that is pending: nothing is copied
                 pending = ReadSet(); pendPos = 0;
-                continue;
+            } else if (m > 0) {
+                const int64_t s0 = pending.off[first * spr], s1 = pending.off[r * spr];
+                b.rs.bases.assign(pending.bases.begin() + s0, pending.bases.begin() + s1);
+                b.rs.off.resize(m * spr + 1);
+                for (size_t q = 0; q <= m * spr; ++q) b.rs.off[q] = pending.off[first * spr + q] - s0;
+                if (paired) { b.segRead.resize(2 * m); for (size_t x = 0; x < m; ++x) b.segRead[2 * x] = b.segRead[2 * x + 1] = (uint32_t)x; }
+                b.rs.names.assign(std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)first), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)r));
+                b.rs.lengths.assign(pending.lengths.begin() + (std::ptrdiff_t)first, pending.lengths.begin() + (std::ptrdiff_t)r);
+                pendPos = r;
             }
-            const int64_t s0 = pending.off[first * spr], s1 = pending.off[r * spr];
-            const int64_t base = (int64_t)b.rs.bases.size() - s0;
-            b.rs.bases.insert(b.rs.bases.end(), pending.bases.begin() + s0, pending.bases.begin() + s1);
-            const size_t o0 = b.rs.off.size();
-            b.rs.off.resize(o0 + m * spr);
-            for (size_t q = 0; q < m * spr; ++q) b.rs.off[o0 + q] = base + pending.off[first * spr + q + 1];
-            if (paired) { const uint32_t r0 = (uint32_t)b.rs.names.size(); for (size_t x = 0; x < m; ++x) { b.segRead.push_back(r0 + (uint32_t)x); b.segRead.push_back(r0 + (uint32_t)x); } }
-            b.rs.names.insert(b.rs.names.end(), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)first), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)r));
-            b.rs.lengths.insert(b.rs.lengths.end(), pending.lengths.begin() + (std::ptrdiff_t)first, pending.lengths.begin() + (std::ptrdiff_t)r);
-            pendPos = r;
         }
         if (useRef && deviceFull && !warned) {
             std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
@@ -950,6 +981,51 @@ struct Batcher {
     }
 };
 
+// The per-read file.  A slab of text (the reads [32768 s, 32768 (s + 1)) of a batch) gets its place in the file as soon as
+// the sizes of all slabs before it are known, and is written there by the thread that formatted it: formatting and writing
+// overlap, several threads fill the page cache at once (one thread does 2-3 GB/s; 10 M reads are 5.5 GB of JSON lines), and
+// no slab is copied into a batch-sized string first.  Slabs that arrive early wait (text of a later batch on another device).
+struct OrderedOut {
+    int fd = -1; off_t pos = 0;
+    std::mutex mu;
+    uint64_t curBatch = 0; size_t curSlab = 0;                  // the next slab to be placed
+    std::map<std::pair<uint64_t, size_t>, string> parked;
+    std::map<uint64_t, size_t> slabsOf;
+    ~OrderedOut() { if (fd >= 0) ::close(fd); }
+    static void writeAt(int fd, const char *d, size_t n, off_t at)
+    {
+        while (n) { const ssize_t w = ::pwrite(fd, d, n, at); if (w <= 0) throw std::runtime_error("Readwise output file could not be written!"); d += w; n -= (size_t)w; at += w; }
+    }
+    void put(const string &t) { writeAt(fd, t.data(), t.size(), pos); pos += (off_t)t.size(); }   // header / footer (nothing else in flight)
+    void place(vector<std::pair<off_t, string>> &todo)             // mu held: everything that is next in line gets its offset
+    {
+        for (;;) {
+            auto sit = slabsOf.find(curBatch);
+            if (sit != slabsOf.end() && curSlab >= sit->second) { slabsOf.erase(sit); ++curBatch; curSlab = 0; continue; }
+            auto it = parked.find({curBatch, curSlab});
+            if (it == parked.end()) return;
+            todo.emplace_back(pos, std::move(it->second));
+            pos += (off_t)todo.back().second.size();
+            parked.erase(it);
+            ++curSlab;
+        }
+    }
+    void begin(uint64_t batch, size_t nSlabs)
+    {
+        if (fd < 0) return;
+        vector<std::pair<off_t, string>> todo;
+        { std::lock_guard<std::mutex> lk(mu); slabsOf[batch] = nSlabs; place(todo); }
+        for (auto &w : todo) writeAt(fd, w.second.data(), w.second.size(), w.first);
+    }
+    void submit(uint64_t batch, size_t slab, string &&t)
+    {
+        if (fd < 0) return;
+        vector<std::pair<off_t, string>> todo;
+        { std::lock_guard<std::mutex> lk(mu); parked.emplace(std::make_pair(batch, slab), std::move(t)); place(todo); }
+        for (auto &w : todo) { ScopedTimerMt tm(g_ht.write, g_ht.mu); writeAt(fd, w.second.data(), w.second.size(), w.first); }
+    }
+};
+
 // Everything one device does for one batch: upload -> encode -> sort -> lookup/score on the device (the calls
 // CompareWithLib_partialSort makes per batch, Compare.hpp:3107-3310), CSR back, ranking + text by all host threads (N2).
 // what crosses PCIe for one worker (device): kept over its batches
@@ -958,7 +1034,7 @@ struct WorkerBuffers {
     PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
 };
 
-static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb)
+static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb, OrderedOut &out)
 {
     const auto tDev = std::chrono::steady_clock::now();
     auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -970,7 +1046,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
     if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
     b.kmers = nk;
-    if (!wantRows) { tDevice += secondsSince(tDev); return; }
+    if (!wantRows) { tDevice += secondsSince(tDev); out.begin(b.id, 0); return; }
     vector<float> coherence;                                     // --coherence (Compare::postProcess, Compare.hpp:3317-3321)
     if (p.coherence) {
         coherence.assign(nr, 0.f);
@@ -1020,7 +1096,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     const uint64_t slab = 1u << 15;
     const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, (nr + slab - 1) / slab));
     const uint64_t nSlabs = (nr + slab - 1) / slab;
-    vector<string> texts(nSlabs);
+    out.begin(b.id, (size_t)nSlabs);
     vector<vector<uint64_t>> flagged(nSlabs);
     vector<std::exception_ptr> err(nt);
     std::atomic<uint64_t> nextSlab{0};
@@ -1031,7 +1107,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 const uint64_t sidx = nextSlab.fetch_add(1);
                 if (sidx >= nSlabs) break;
                 const uint64_t a = sidx * slab, e = std::min<uint64_t>(nr, a + slab);
-                string &text = texts[sidx];
+                string text;
                 text.reserve((size_t)(e - a) * (p.fmt == Params::Json ? 900 : 600));
                 for (uint64_t r = a; r < e; ++r) {
                     if (p.coherence) w.coherence = coherence[r];
@@ -1042,13 +1118,13 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                         w.read(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
                     if (p.filter && w.lastContaminated) flagged[sidx].push_back(b.firstRead + r);
                 }
+                out.submit(b.id, (size_t)sidx, std::move(text));
             }
         } catch (...) { err[t] = std::current_exception(); }
     };
     if (nt == 1) work(0);
     else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
     for (auto &e : err) if (e) std::rethrow_exception(e);
-    b.texts = std::move(texts);                                    // (no second copy of gigabytes of text: the writer takes the slabs)
     for (auto &f : flagged) b.flagged.insert(b.flagged.end(), f.begin(), f.end());
     tText += secondsSince(tTxt);
 }
@@ -1079,31 +1155,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     p.protein = batcher.protein;
     for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
-    // the per-read file: written at explicit offsets, the slabs of a batch by several threads at once (one thread fills the
-    // page cache at 2-3 GB/s; 10 M reads are 5.5 GB of JSON lines)
-    struct OutFile {
-        int fd = -1; off_t pos = 0;
-        ~OutFile() { if (fd >= 0) ::close(fd); }
-        static void writeAt(int fd, const char *d, size_t n, off_t at)
-        {
-            while (n) { const ssize_t w = ::pwrite(fd, d, n, at); if (w <= 0) throw std::runtime_error("Readwise output file could not be written!"); d += w; n -= (size_t)w; at += w; }
-        }
-        void put(const string &t) { writeAt(fd, t.data(), t.size(), pos); pos += (off_t)t.size(); }
-        void putAll(const vector<string> &slabs, unsigned threads)
-        {
-            vector<off_t> at(slabs.size());
-            for (size_t i = 0; i < slabs.size(); ++i) { at[i] = pos; pos += (off_t)slabs[i].size(); }
-            const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(threads, 16u), slabs.size()));
-            if (nt == 1) { for (size_t i = 0; i < slabs.size(); ++i) writeAt(fd, slabs[i].data(), slabs[i].size(), at[i]); return; }
-            std::atomic<size_t> next{0};
-            vector<std::exception_ptr> err(nt);
-            vector<std::thread> pool;
-            for (unsigned t = 0; t < nt; ++t)
-                pool.emplace_back([&, t] { try { for (size_t i; (i = next.fetch_add(1)) < slabs.size();) writeAt(fd, slabs[i].data(), slabs[i].size(), at[i]); } catch (...) { err[t] = std::current_exception(); } });
-            for (auto &th : pool) th.join();
-            for (auto &e : err) if (e) std::rethrow_exception(e);
-        }
-    } out;
+    OrderedOut out;
     if (!p.rtt.empty()) {
         out.fd = ::open(p.rtt.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (out.fd < 0) throw std::runtime_error("Readwise output file could not be created!");
@@ -1134,7 +1186,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
                     b = std::move(todo.front()); todo.pop_front();
                     cvSpace.notify_all();
                 }
-                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d], wb);
+                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d], wb, out);
                 totalKmers += b->kmers;
                 b->rs = ReadSet();                                   // the reads are done with
                 std::lock_guard<std::mutex> lk(mu);
@@ -1163,7 +1215,6 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
             std::unique_ptr<Batch> b = std::move(it->second);
             finished.erase(it);
             lk.unlock();
-            if (!p.rtt.empty()) out.putAll(b->texts, p.threads);
             contaminants.insert(contaminants.end(), b->flagged.begin(), b->flagged.end());
             ++written;
             lk.lock();
@@ -1211,6 +1262,9 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     vector<double> all((size_t)nK * ixf.content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
     if (kasa_profile_fetch(ctx[0], all.data(), uniq.data(), tot.data())) throwLast();
     if (!p.profile.empty()) writeProfile(p.profile, p, ixf.content, all, uniq, tot, ixf.freqAll, totalKmers.load(), nReads);
+    if (p.verbose && g_ht.on)
+        std::cout << "OUT: host timing: read " << g_ht.read << " s, cut " << g_ht.cut << " s, parse " << g_ht.parse << " s, merge " << g_ht.merge
+                  << " s, batch forming " << g_ht.form << " s, output write " << g_ht.write << " s" << std::endl;
     if (p.verbose) {
         double ident = 0; for (size_t t = 1; t < ixf.content.names.size(); ++t) ident += all[(size_t)(nK - 1) * ixf.content.names.size() + t];
         double dev = 0, txt = 0; for (size_t d = 0; d < nDev; ++d) { dev = std::max(dev, tDevice[d]); txt = std::max(txt, tText[d]); }
