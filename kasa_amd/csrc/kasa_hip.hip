@@ -174,6 +174,14 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
     return v;
 }
 __device__ __forceinline__ uint32_t wave_total(uint32_t inclusive) { return (uint32_t)__builtin_amdgcn_readlane((int)inclusive, 63); }
+// one lane's value for all (the lane number is a constant: v_readlane, no LDS round trip as with __shfl)
+template <int LANE> __device__ __forceinline__ uint32_t lane_value(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, LANE); }
+template <int LANE> __device__ __forceinline__ unsigned long long lane_value(unsigned long long v)
+{
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), LANE) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, LANE);
+}
+// the value of the lane before (lane 0: `first`)
+__device__ __forceinline__ int lane_before(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 // the same, restarting at every lane whose flag is set: on return f = "a flag was set at or before this lane"
 __device__ __forceinline__ void wave_seg_incl_sum(uint32_t &v, bool &f)
 {
@@ -2408,7 +2416,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                 A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? m : 0u;
                 if (!fits) start = ~0ull;
             }
-            start = __shfl(start, 0);
+            start = lane_value<0>(start);
             __threadfence_block();
             if (m && start != ~0ull) {
                 if (m <= 64) {
@@ -2532,12 +2540,17 @@ template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t level
 // FB: bits of a hit counter.  16 by default; 8 when no read of the batch has more than 255 k-mers (narrow records): the LDS
 // counters are what limits the resident wavefronts of this kernel, and it runs faster the more there are (26 ms at 16 per
 // CU, 40 at 8).
-template <int RW, bool PERREAD, int FB = 16>
+// NLV: rows of the per-level LDS tables (the levels the launch can meet: 8 for narrow records; 25, or 19 for the default
+// -k 25 7 of a 128-bit index -- the kernel's LDS footprint is what limits its resident wavefronts, and with 64-byte records
+// and 16-bit fields it was down to six per CU).
+template <int RW, bool PERREAD, int FB = 16, int NLV = RecTraits<RW>::LEVELS>
 __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
-    constexpr int NL = RT::LEVELS, OB = RT::OBITS;
-    typedef typename std::conditional<RW == 8 && FB == 16, unsigned long long, uint32_t>::type Counter;   // hit counters per |T|: 4 (wide records: 2) fields of FB bits
+    constexpr int NL = NLV, OB = RT::OBITS;
+    // hit counters per |T|: 4 (wide records: 2) fields of FB bits
+    typedef typename std::conditional<RW == 8, typename std::conditional<FB == 16, unsigned long long, uint32_t>::type,
+                                      typename std::conditional<FB == 16, uint32_t, uint16_t>::type>::type Counter;
     constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
     constexpr uint32_t FMASK = (1u << FB) - 1u;
     __shared__ Counter cnt[FTA * NL][64];
@@ -2559,7 +2572,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.workCursor, 64u);          // persistent wavefronts take 64 reads at a time
-        base = __shfl(base, 0);
+        base = lane_value<0>(base);
         if (base >= A.nReads) break;
         const uint32_t r = base + lane;
         const bool active = r < A.nReads;
@@ -2683,7 +2696,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                 if (__ballot(nm != 0u) != 0ull) {
                     uint32_t incl = nm;
                     incl = wave_incl_sum(incl);
-                    const uint32_t S = __shfl(incl, 63);
+                    const uint32_t S = lane_value<63>(incl);
                     const unsigned long long satMask = __ballot(sat);
                     sPB[lane] = incl - nm;
                     if (lane == 63) sPB[64] = S;
@@ -2753,19 +2766,19 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         const uint32_t m = (active && !fb) ? nFinal + nprof + nOther : 0u;
         uint32_t incl = m;
         incl = wave_incl_sum(incl);
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = lane_value<63>(incl);
         unsigned long long start = 0;
         if (lane == 0 && total) start = atomicAdd(A.stCursor, (unsigned long long)total);   // 64-bit: the host sees the true demand
-        start = __shfl(start, 0);
+        start = lane_value<0>(start);
         start += incl - m;
         // ... and its profile keys: one per counter record and per event of the other taxa
         const uint32_t mk = (active && !fb) ? nprof + nKeys : 0u;
         uint32_t inclK = mk;
         inclK = wave_incl_sum(inclK);
-        const uint32_t totalK = __shfl(inclK, 63);
+        const uint32_t totalK = lane_value<63>(inclK);
         unsigned long long startK = 0;
         if (lane == 0 && totalK) startK = atomicAdd(A.keyCursor, (unsigned long long)totalK);
-        startK = __shfl(startK, 0);
+        startK = lane_value<0>(startK);
         const bool fits = start - (incl - m) + total <= (unsigned long long)A.stCap && startK + totalK <= (unsigned long long)A.keyCap;
         startK += inclK - mk;
         if (active) {
@@ -2796,7 +2809,7 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
         if (fbMask) {
             uint32_t fbBase = 0;
             if (lane == 0) fbBase = atomicAdd(A.fbCount, (uint32_t)__popcll(fbMask));
-            fbBase = __shfl(fbBase, 0);
+            fbBase = lane_value<0>(fbBase);
             if (active && fb) A.fbList[fbBase + __popcll(fbMask & ((1ull << lane) - 1ull))] = r;
         }
     }
@@ -2914,7 +2927,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         // place in the wavefront's staging area: a plain prefix sum
         uint32_t lincl = mine;
         lincl = wave_incl_sum(lincl);
-        const uint32_t total = __shfl(lincl, 63);
+        const uint32_t total = lane_value<63>(lincl);
         if (total == 0u) continue;                                           // uniform
         const bool staged = total <= STAGE;
         uint32_t lp = lincl - mine;
@@ -3051,7 +3064,7 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
         const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
         uint32_t incl = nFlat;
         incl = wave_incl_sum(incl);
-        const uint32_t S = __shfl(incl, 63);
+        const uint32_t S = lane_value<63>(incl);
         if (S == 0u) continue;                                                 // uniform
         const bool head = inRange && (uint64_t)slot == readStart;
         const unsigned long long H = __ballot(head);
@@ -3095,16 +3108,15 @@ __global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
             uint32_t c = segRec ? (pc ? 1u : 0u) : pc;
             if (act && isSplit) c = sSplit[wv][own];
             // does a read begin between the previous item's query and this one's?  Then the count restarts here.
-            int prevOwn = __shfl_up((int)own, 1);
-            if (lane == 0) prevOwn = prevOwnCarry;
+            const int prevOwn = lane_before((int)own, prevOwnCarry);
             const unsigned long long toOwn = own == 63u ? ~0ull : ((2ull << own) - 1ull);
             const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
             bool f = act && (H & toOwn & ~toPrev) != 0ull;
             uint32_t v = c;
             wave_seg_incl_sum(v, f);
             uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
-            carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
-            prevOwnCarry = __shfl((int)own, 63);
+            carry = lane_value<63>(v) + ((int)lane_value<63>((uint32_t)f) ? 0u : carry);
+            prevOwnCarry = (int)lane_value<63>((uint32_t)own);
             const int nEv = (int)(w2 & 31u) - A.kLow + 1;
             const uint32_t order = (w2 >> 5) & 0xFFFFFFu;
             auto sizeOf = [&](int lv) -> uint32_t {
@@ -3215,7 +3227,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         for (int lv = 0; lv <= nK; ++lv) sLvN[wv][lv][lane] = 0u;
         uint32_t incl = Q.nseg;
         incl = wave_incl_sum(incl);
-        const uint32_t S1 = __shfl(incl, 63);
+        const uint32_t S1 = lane_value<63>(incl);
         if (S1 == 0u) continue;                                                // uniform: no live query
         sBase[wv][lane] = incl - Q.nseg;
         if (lane == 63) sBase[wv][64] = S1;
@@ -3261,7 +3273,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         const uint32_t nFlat = split ? (mineSplit ? 1u : 0u) : nEmInl + Q.nMore;
         incl = nFlat;
         incl = wave_incl_sum(incl);
-        const uint32_t S = __shfl(incl, 63);
+        const uint32_t S = lane_value<63>(incl);
         if (S == 0u) { LDS_WAVE_SYNC(); continue; }                            // uniform
         const bool head = inRange && (uint64_t)slot == readStart;
         const unsigned long long H = __ballot(head);
@@ -3301,16 +3313,15 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
             const uint32_t em = isMain ? (m & sBig[wv][own]) : m;
             uint32_t c = (uint32_t)__popc(em);
             if (act && isSplit) c = sSplit[wv][own];
-            int prevOwn = __shfl_up((int)own, 1);
-            if (lane == 0) prevOwn = prevOwnCarry;
+            const int prevOwn = lane_before((int)own, prevOwnCarry);
             const unsigned long long toOwn = own == 63u ? ~0ull : ((2ull << own) - 1ull);
             const unsigned long long toPrev = prevOwn < 0 ? 0ull : (prevOwn == 63 ? ~0ull : ((2ull << prevOwn) - 1ull));
             bool f = act && (H & toOwn & ~toPrev) != 0ull;
             uint32_t v = c;
             wave_seg_incl_sum(v, f);
             uint32_t w = sRow[wv][own] + v - c + (f ? 0u : carry);
-            carry = __shfl(v, 63) + (__shfl((int)f, 63) ? 0u : carry);
-            prevOwnCarry = __shfl((int)own, 63);
+            carry = lane_value<63>(v) + ((int)lane_value<63>((uint32_t)f) ? 0u : carry);
+            prevOwnCarry = (int)lane_value<63>((uint32_t)own);
             if (act && c) {
                 const uint32_t kind = isMain ? RK_PROFILE : kindOther;
                 if (isSplit) sSplit[wv][own] = w;
@@ -3387,7 +3398,7 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
             uint32_t incl = nk;
             incl = wave_incl_sum(incl);
             uint32_t kw = keyAt + incl - nk;
-            keyAt += __shfl(incl, 63);
+            keyAt += lane_value<63>(incl);
             if (nk) {
                 if ((e.x >> 30) == 3u) {
                     const uint32_t kF = (e.x >> 20) & 31u;
@@ -3505,7 +3516,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             uint32_t incl = nk;
             incl = wave_incl_sum(incl);
             uint32_t kw = keyAt + incl - nk;
-            keyAt += __shfl(incl, 63);
+            keyAt += lane_value<63>(incl);
             if (nk) {
                 if (kind == 3u) {
                     const uint32_t kF = (e.x >> 20) & 31u;
@@ -3528,7 +3539,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             uint32_t incl = pc;
             incl = wave_incl_sum(incl);
             if (w < W) pre[w] = carry + incl - pc;
-            carry += __shfl(incl, 63);
+            carry += lane_value<63>(incl);
         }
         const uint32_t nSlots = carry;
         LDS_WAVE_SYNC();
@@ -3693,8 +3704,8 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
     if (threadIdx.x == 0) sLeftN = 0;
     __syncthreads();
     const uint64_t mask = (1ull << PL.bits()) - 1ull;
-    auto flush = [&]() {                                               // all threads; the buffer goes to the list
-        const uint32_t n = sLeftN;
+    auto flush0 = [&]() {                                              // all threads; the buffer goes to the list
+        const uint32_t n = min(sLeftN, (uint32_t)PT_LEFT);
         if (threadIdx.x == 0) sLeftBase = atomicAdd(leftCursor, (unsigned long long)n);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += PT_THREADS) leftOut[sLeftBase + i] = sLeft[i];   // (the list holds nKeys entries)
@@ -3702,14 +3713,24 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
         if (threadIdx.x == 0) sLeftN = 0;
         __syncthreads();
     };
-    const uint64_t step = (uint64_t)gridDim.x * PT_THREADS;
-    // a workgroup sees at most `rounds * PT_THREADS` keys: with hits <= maxHits no 32-bit counter can wrap
-    const uint32_t maxHits = (uint32_t)std::min<uint64_t>(65535ull, 0xFFFFFFFFull / std::max<uint64_t>(1, (((uint64_t)nKeys + step - 1) / step) * PT_THREADS));
+    // A round = PT_KEYS keys per thread between two barriers (one key per round made the barrier the kernel's clock: 7 000
+    // rounds per workgroup at 10 M reads).  Keys without a cell wait in sLeft; should a round bring more of them than the
+    // buffer holds -- a few per cent of the keys have no cell, a round could in theory bring 8 192 -- the surplus goes to
+    // the list one by one.
+    constexpr int PT_KEYS = 8;
+    const uint64_t step = (uint64_t)gridDim.x * PT_THREADS * PT_KEYS;
+    // a workgroup sees at most `rounds * PT_THREADS * PT_KEYS` keys: with hits <= maxHits no 32-bit counter can wrap
     const uint64_t rounds = ((uint64_t)nKeys + step - 1) / step;       // the same for every workgroup: barriers inside
+    const uint32_t maxHits = (uint32_t)std::min<uint64_t>(65535ull, 0xFFFFFFFFull / std::max<uint64_t>(1, rounds * PT_THREADS * PT_KEYS));
+    auto &flush = flush0;
     for (uint64_t rd = 0; rd < rounds; ++rd) {
-        const uint64_t i = rd * step + (uint64_t)blockIdx.x * PT_THREADS + threadIdx.x;
-        if (i < nKeys) {
-            const uint64_t key = keys[i];
+        const uint64_t i0 = rd * step + (uint64_t)blockIdx.x * PT_THREADS * PT_KEYS + threadIdx.x;
+        uint64_t kk[PT_KEYS];
+#pragma unroll
+        for (int q = 0; q < PT_KEYS; ++q) { const uint64_t i = i0 + (uint64_t)q * PT_THREADS; kk[q] = i < nKeys ? keys[i] : 0ull; }   // (hits = 0: skipped)
+#pragma unroll
+        for (int q = 0; q < PT_KEYS; ++q) {
+            const uint64_t key = kk[q];
             const uint64_t f = (key >> 16) & mask;
             const uint32_t hits = (uint32_t)(key & 0xFFFFull);
             const uint32_t tax = (uint32_t)(f & ((1ull << PL.tb) - 1ull));
@@ -3718,11 +3739,15 @@ __global__ __launch_bounds__(PT_THREADS) void profile_table_kernel(const uint64_
                 const uint32_t lv = (uint32_t)(f >> (PL.tb + PL.nb));
                 if ((int)lv < TL.lvLo || (int)lv >= TL.lvHi) {}                // another pass counts this level
                 else if (n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
-                else sLeft[atomicAdd(&sLeftN, 1u)] = key;
+                else {
+                    const uint32_t at = atomicAdd(&sLeftN, 1u);
+                    if (at < (uint32_t)PT_LEFT) sLeft[at] = key;
+                    else leftOut[atomicAdd(leftCursor, 1ull)] = key;     // the buffer is full: straight to the list
+                }
             }
         }
         __syncthreads();
-        if (sLeftN > (uint32_t)(PT_LEFT - PT_THREADS)) flush();        // uniform: read after the barrier
+        if (sLeftN > (uint32_t)(PT_LEFT / 2)) flush();                 // uniform: read after the barrier
     }
     flush();
     for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) {
@@ -3946,11 +3971,16 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (fast) {
             // persistent wavefronts: as many as are resident at once, each takes 64 reads at a time from a work counter
             int perCu = 0, nCu = 0;
-            const bool fb8 = RW == 8 && c->maxCnt <= 255u;                   // 8-bit counter fields: twice the wavefronts per CU
-            const void *kern = RW == 8 ? (fb8 ? (wantPerRead ? (const void *)score_main_kernel<8, true, 8> : (const void *)score_main_kernel<8, false, 8>)
-                                              : (wantPerRead ? (const void *)score_main_kernel<8, true> : (const void *)score_main_kernel<8, false>))
-                                       : (wantPerRead ? (const void *)score_main_kernel<16, true> : (const void *)score_main_kernel<16, false>);
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kern, 64, 0));
+            const bool fb8 = c->maxCnt <= 255u;                              // 8-bit counter fields: twice the wavefronts per CU
+            const bool lv19 = RW == 16 && nK <= 19;                          // (the default -k 25 7 has 19 levels)
+            typedef void (*MainKernel)(ScoreArgs);
+            const MainKernel kern = RW == 8 ? (fb8 ? (wantPerRead ? score_main_kernel<8, true, 8> : score_main_kernel<8, false, 8>)
+                                                   : (wantPerRead ? score_main_kernel<8, true> : score_main_kernel<8, false>))
+                                  : lv19 ? (fb8 ? (wantPerRead ? score_main_kernel<16, true, 8, 19> : score_main_kernel<16, false, 8, 19>)
+                                                : (wantPerRead ? score_main_kernel<16, true, 16, 19> : score_main_kernel<16, false, 16, 19>))
+                                         : (fb8 ? (wantPerRead ? score_main_kernel<16, true, 8> : score_main_kernel<16, false, 8>)
+                                                : (wantPerRead ? score_main_kernel<16, true> : score_main_kernel<16, false>));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, (const void *)kern, 64, 0));
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
             const uint32_t fblocks = std::min<uint32_t>((nReads + 63) / 64, (uint32_t)std::max(1, perCu) * (uint32_t)std::max(1, nCu));
             if ((rc = c->fastScratch.reserve((size_t)nReads * 16 + 64))) return rc;
@@ -3962,9 +3992,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const unsigned oblocks = std::min<unsigned>(blocks_for(nQ, 256), 256u * 64u);
             hipEvent_t ka, kb;
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_MAIN], &ka, &kb))) return rc;
-            if (fb8) { if (wantPerRead) score_main_kernel<8, true, 8><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<8, false, 8><<<fblocks, 64, 0, c->stream>>>(A); }
-            else if (wantPerRead) { if (RW == 8) score_main_kernel<8, true><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, true><<<fblocks, 64, 0, c->stream>>>(A); }
-            else { if (RW == 8) score_main_kernel<8, false><<<fblocks, 64, 0, c->stream>>>(A); else score_main_kernel<16, false><<<fblocks, 64, 0, c->stream>>>(A); }
+            kern<<<fblocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_MAIN], ka, kb))) return rc;
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_OTHER], &ka, &kb))) return rc;
@@ -4582,7 +4610,7 @@ __global__ void rank_list_kernel(const uint4 *__restrict__ meta, uint32_t nReads
     const unsigned long long mk = __ballot(f);
     uint32_t base = 0;
     if ((threadIdx.x & 63) == 0 && mk) base = atomicAdd(nList, (uint32_t)__popcll(mk));
-    base = __shfl(base, 0);
+    base = lane_value<0>(base);
     if (f) {
         const uint32_t at = base + (uint32_t)__popcll(mk & ((1ull << (threadIdx.x & 63)) - 1ull));
         list[at] = r;

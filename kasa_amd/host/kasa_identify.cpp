@@ -1390,7 +1390,20 @@ static int run(int argc, char **argv)
         ixf.onDevice.push_back(ix);
     }
     munmap(rec, ixf.nRec * ixf.recBytes); close(fd);
-    if (p.threads == 0) p.threads = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+    if (p.threads == 0) {
+        // all CPUs this process may really use: the machine's, capped by a cgroup CPU quota (a container that sees 256 CPUs
+        // and is throttled to 16 runs slower with 128 threads than with 16)
+        unsigned cpus = std::max(1u, std::min(128u, std::thread::hardware_concurrency()));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[64] = {0}; double period = 0;
+            if (fscanf(f, "%63s %lf", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) {
+                const double q = atof(a) / period;
+                if (q >= 1.0) cpus = std::min(cpus, (unsigned)(q + 0.5));
+            }
+            fclose(f);
+        }
+        p.threads = cpus;
+    }
 
     vector<int> allSlots;
     for (size_t d = 0; d < p.devices.size(); ++d) allSlots.push_back((int)d);

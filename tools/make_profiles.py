@@ -9,11 +9,11 @@
 """
 import csv, glob, json, os, re, subprocess, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = "gpurun_out/profiles"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel"
+KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|row_copy_kernel"
 
 
 def run(cmd, **kw):
@@ -29,7 +29,7 @@ if PMC_ONLY:
 else:
   with open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w") as f:
       run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
-           "--no-cpu", "--no-e2e"], stdout=f, stderr=subprocess.DEVNULL)
+           "--no-cpu", "--no-e2e", "--no-secondary"], stdout=f, stderr=subprocess.DEVNULL)
   src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
   rows = list(csv.DictReader(open(src)))
   with open(os.path.join(out, tag + "_kernel_stats_bench_10M.csv"), "w") as f:
@@ -39,7 +39,7 @@ else:
           w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
   md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
   open(os.path.join(out, tag + "_kernel_stats_bench_10M.md"), "w").write(
-      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e` on one MI355X\n"
+      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-secondary` on one MI355X\n"
       "(10 M reads x 150 bp, 419,951,000-record index).  The run holds the index build (one call of encode / lookup of its own) plus 1 warm-up\n"
       "and 3 timed steps.  The warm-up step launches score_main / score_other twice (the first attempt sizes the staging rows, stops early\n"
       "and is repeated with the capacity it asked for): their 5th call is that short one, so their averages here are below the per-launch\n"
@@ -52,12 +52,12 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i, p in enumerate(passes):
     dd = os.path.join(out, "pmc%d" % i)
     run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", dd, "--", "python3", "bench.py",
-         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             name = re.sub(r"[<(].*", "", row["Kernel_Name"]).replace("void ", "")
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-res = {"command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e",
+res = {"command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-secondary",
        "workload": "10M x 150bp reads vs 419951000-record index (bench.py default); per kernel the LARGEST dispatch (the 1.3e9-query batch; the index build "
                    "launches encode/lookup once on its own input)",
        "correction": "hbm_bytes_per_launch = FETCH_SIZE[KB] x 1024 x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM; exact for "
@@ -78,7 +78,7 @@ if PMC_ONLY:
             ins = e["SQ_INSTS_VALU"] + e["SQ_INSTS_SALU"]
             print("%-24s insts %.2fe9 -> %.1f ms at 4 cycles; HBM %.1f GB" % (k, ins / 1e9, ins * 4 / (1024 * 2.4e9) * 1e3, e.get("hbm_bytes_per_launch", 0) / 1e9))
     sys.exit(0)
-args = ["python3", "bench.py", "--steps", "5", "--warmup", "2"] + (["--secondary"] if "--secondary" in sys.argv else [])
+args = ["python3", "bench.py", "--steps", "5", "--warmup", "2"]          # (secondary, file to file and CPU baseline are part of the default line)
 with open(os.path.join(out, tag + "_bench_1gpu.json"), "w") as f:
     run(args, stdout=f, stderr=subprocess.DEVNULL)
 print(open(os.path.join(out, tag + "_bench_1gpu.json")).read()[:600])
