@@ -486,7 +486,9 @@ struct kasa_ctx {
     bool protein = false;                      // amino-acid input (kasa_ctx_set_protein)
     int enc_mode() const { return protein ? 2 : (frames == 1 ? 1 : 0); }   // ENC_PROTEIN / ENC_ONE / ENC_DNA
     int strands() const { return (frames == 6 && !protein) ? 2 : 1; }      // kASA.hpp:181: protein input switches --six off
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;    // stream2: the profile side of the score stage, beside the CSR packing
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    DevBuf scanTmp;
     // batch state
     int64_t nReads = 0;
     uint64_t nBases = 0;
@@ -612,6 +614,8 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     c->ix = ix; c->device = ix->device; c->kHigh = kHigh; c->kLow = kLow; c->nK = kHigh - kLow + 1; c->frames = frames;
     auto bail = [&](int code) { kasa_ctx_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
     uint8_t lut[366];
     if (codonLut) memcpy(lut, codonLut, 366); else builtin_codon_table(lut);
     int rc = c->lut.reserve(512); if (rc) return bail(rc);
@@ -651,6 +655,10 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     };
     for (auto &t : c->timers) drop(t);
     for (auto &t : c->kernels) drop(t);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
+    c->scanTmp.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -4090,6 +4098,9 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         c->stCap = want + want / 8 + 1024;
     }
     // ---- resolve the fast kernels' records: per-read merge, then the profile contributions by sort + reduce
+    bool profPending = false, profTables = false;
+    unsigned long long profLeft = 0;
+    uint64_t *profSortIn = nullptr, *profSortOut = nullptr, profSort = 0;
     if (fast && staged > 0) {
         const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
@@ -4123,42 +4134,33 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         }
         bool tables = nKeys > 0 && !(c->debugFlags & 16);
         for (const auto &TL : passes) if (TL.lvHi <= TL.lvLo) tables = false;      // a window without cells: everything is sorted
-        uint64_t *sortIn = c->profKeys.as<uint64_t>(), *sortOut = c->profSorted.as<uint64_t>();
-        uint64_t nSort = nKeys;
+        // The profile side runs on the context's SECOND stream from here: it only reads the keys row_merge has written, while
+        // the first stream packs the rows into the CSR (below); both are small kernels that leave most of the chip idle.
+        HIPCHK(hipEventRecord(c->evFork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+        profSortIn = c->profKeys.as<uint64_t>(); profSortOut = c->profSorted.as<uint64_t>();
+        profSort = nKeys;
         if (tables) {
             int nCu = 0;
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
             unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
-            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream));
+            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream2));
             for (const auto &TL : passes) {
                 const size_t shBytes = (size_t)TL.first[MAX_LEVELS] * nTaxa * 4;
                 HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
-                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
+                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream2>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
                     c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
                     c->profSorted.as<uint64_t>(), leftCursor);
                 HIPCHK(hipGetLastError());
             }
-            unsigned long long nLeft = 0;
-            HIPCHK(hipMemcpyAsync(&nLeft, leftCursor, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            nSort = nLeft; sortIn = c->profSorted.as<uint64_t>(); sortOut = c->profKeys.as<uint64_t>();   // what is left, sorted back into the key buffer
+            HIPCHK(hipMemcpyAsync(&profLeft, leftCursor, 8, hipMemcpyDeviceToHost, c->stream2));
+            profTables = true;
         }
-        if (nSort > 0) {
-            // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
-            const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
-            if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(nSort)))) return rc;
-            uint64_t *kRes = nullptr;
-            HIPCHK(kasa_radix::sort_pairs<uint64_t>(sortIn, nullptr, sortOut, nullptr, (uint32_t)nSort, 16, sortBits, c->sortTmp.p, c->stream, &kRes, nullptr));
-            sortOut = kRes;                                            // (wherever the last pass left them)
-            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream>>>(
-                sortOut, (uint32_t)nSort, nTaxa,
-                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
-            HIPCHK(hipGetLastError());
-        }
-        if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
+        profPending = true;
     }
     if (wantPerRead) {
         // CSR offsets = exclusive scan of the row lengths, then rows copied in read order
+        if (!profPending && (rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         DevBuf &len64 = c->qReadA; // reuse
         if ((rc = len64.reserve(((size_t)nReads + 1) * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(len64.p, 0, ((size_t)nReads + 1) * 8, c->stream));
@@ -4166,8 +4168,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         size_t tmpBytes = 0;
         HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
-        if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-        HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
+        if ((rc = c->scanTmp.reserve(tmpBytes))) return rc;              // (not sortTmp: the profile's sort on the other stream uses that)
+        HIPCHK(rocprim::exclusive_scan(c->scanTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
         uint64_t nnz = 0;
         HIPCHK(hipMemcpyAsync(&nnz, c->rowOff.as<uint64_t>() + nReads, 8, hipMemcpyDeviceToHost, c->stream));
@@ -4177,9 +4179,29 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
             nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
-        c->haveScores = true;
     }
+    if (profPending) {
+        // back to the profile side: what the tables had no cell for is sorted and reduced, then the streams join
+        HIPCHK(hipStreamSynchronize(c->stream2));
+        if (profTables) { profSort = profLeft; profSortIn = c->profSorted.as<uint64_t>(); profSortOut = c->profKeys.as<uint64_t>(); }   // what is left, sorted back into the key buffer
+        if (profSort > 0) {
+            const ProfLayout PL = prof_layout(nTaxa, nK);
+            // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
+            const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
+            if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(profSort)))) return rc;
+            uint64_t *kRes = nullptr;
+            HIPCHK(kasa_radix::sort_pairs<uint64_t>(profSortIn, nullptr, profSortOut, nullptr, (uint32_t)profSort, 16, sortBits, c->sortTmp.p, c->stream2, &kRes, nullptr));
+            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(profSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream2>>>(
+                kRes, (uint32_t)profSort, nTaxa,
+                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(c->evJoin, c->stream2));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
+    }
+    if (profPending || wantPerRead) { if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (wantPerRead) c->haveScores = true;
     c->state = 4;
     return KASA_OK;
 }

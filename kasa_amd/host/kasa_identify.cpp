@@ -516,6 +516,7 @@ struct Params {
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
     bool verbose = false, coverage = false, unique = false, protein = false;
+    bool gzipOut = false;                        // --gzip: the --filter files are written through zlib (Compare.hpp:2455,3713-3731)
     bool coherence = false; float coherenceThreshold = 11.0f;   // --coherence, --coherenceThreshold (MetaHeader.h:159)
 };
 
@@ -758,41 +759,61 @@ static void filterReads(const Params &p, const vector<uint64_t> &flagged)
     vector<string> data{slurp(p.input)};
     if (paired) data.push_back(slurp(p.input2));
     const bool fasta = !data[0].empty() && data[0][0] == '>';
-    const string ext = fasta ? ".fasta" : ".fastq";
-    auto openSide = [&](const string &prefix, const char *what) {
-        vector<std::unique_ptr<std::ofstream>> f;
-        if (prefix == "_") return f;
-        for (size_t i = 0; i < data.size(); ++i) {
-            f.emplace_back(new std::ofstream(prefix + (paired ? (i ? "_2" : "_1") : "") + ext, std::ios::binary));
-            if (f.back()->fail()) throw std::runtime_error(string(what) + " output files could not be opened for writing, did you use the correct path?");
+    const string ext = string(fasta ? ".fasta" : ".fastq") + (p.gzipOut ? ".gz" : "");      // Compare.hpp:2454-2455
+    // one side (clean or contaminants): a text per input file, written -- plain or through zlib (--gzip, as the reference's
+    // ogzstream does) -- when the input has been walked
+    struct Side {
+        vector<string> names, text; bool on = false;
+        void flush(bool gz, const char *what)
+        {
+            for (size_t i = 0; i < names.size(); ++i) {
+                if (gz) {
+                    gzFile g = gzopen(names[i].c_str(), "wb");
+                    if (!g) throw std::runtime_error(string(what) + " output files could not be opened for writing, did you use the correct path?");
+                    for (size_t a = 0; a < text[i].size();) { const unsigned n = (unsigned)std::min<size_t>(text[i].size() - a, 1u << 30); if (gzwrite(g, text[i].data() + a, n) <= 0) break; a += n; }
+                    gzclose(g);
+                } else {
+                    std::ofstream f(names[i], std::ios::binary);
+                    if (f.fail()) throw std::runtime_error(string(what) + " output files could not be opened for writing, did you use the correct path?");
+                    f.write(text[i].data(), (std::streamsize)text[i].size());
+                }
+            }
         }
-        return f;
     };
-    auto clean = openSide(p.filterClean, "Filtered"), cont = openSide(p.filterCont, "Contaminants");
-    if (flagged.empty() && !clean.empty()) { for (size_t i = 0; i < data.size(); ++i) *clean[i] << data[i]; return; }
+    auto openSide = [&](const string &prefix) {
+        Side sd;
+        if (prefix == "_") return sd;
+        sd.on = true;
+        for (size_t i = 0; i < data.size(); ++i) { sd.names.push_back(prefix + (paired ? (i ? "_2" : "_1") : "") + ext); sd.text.emplace_back(); }
+        return sd;
+    };
+    Side clean = openSide(p.filterClean), cont = openSide(p.filterCont);
+    auto finish = [&]() { clean.flush(p.gzipOut, "Filtered"); cont.flush(p.gzipOut, "Contaminants"); };
+    if (flagged.empty() && clean.on) { for (size_t i = 0; i < data.size(); ++i) clean.text[i] = data[i]; finish(); return; }
     vector<vector<std::pair<size_t, size_t>>> lines(data.size());
     for (size_t f = 0; f < data.size(); ++f)
         for (size_t a = 0; a < data[f].size();) { size_t b = data[f].find('\n', a); if (b == string::npos) b = data[f].size(); lines[f].emplace_back(a, b); a = b + 1; }
     auto line = [&](size_t f, size_t i) { return i < lines[f].size() ? data[f].substr(lines[f][i].first, lines[f][i].second - lines[f][i].first) : string(); };
     uint64_t rid = 0; size_t fi = 0;
-    vector<std::unique_ptr<std::ofstream>> *target = &clean;
+    Side *target = &clean;
     const size_t n = lines[0].size();
     if (fasta) {
         for (size_t i = 0; i < n; ++i) {
             const string l1 = line(0, i);
             if (l1.empty()) continue;
             if (l1[0] == '>') { const bool hit = fi < flagged.size() && rid == flagged[fi]; target = hit ? &cont : &clean; if (hit) ++fi; ++rid; }
-            if (!target->empty()) { *(*target)[0] << l1 << "\n"; if (paired) *(*target)[1] << line(1, i) << "\n"; }
+            if (target->on) { target->text[0] += l1; target->text[0] += "\n"; if (paired) { target->text[1] += line(1, i); target->text[1] += "\n"; } }
         }
     } else {
         for (size_t i = 0; i < n; i += 4) {
             if (line(0, i).empty()) continue;
             const bool hit = fi < flagged.size() && rid == flagged[fi];
             target = hit ? &cont : &clean; if (hit) ++fi; ++rid;
-            if (target->empty()) continue;
-            for (size_t f = 0; f < data.size(); ++f) for (size_t k = 0; k < 4; ++k) *(*target)[f] << line(f, i + k) << "\n";
+            if (!target->on) continue;
+            for (size_t f = 0; f < data.size(); ++f) for (size_t k = 0; k < 4; ++k) { target->text[f] += line(f, i + k); target->text[f] += "\n"; }
         }
     }
+    finish();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1344,6 +1365,7 @@ static int run(int argc, char **argv)
         else if (s == "--host-rank") p.hostRank = true;
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
+        else if (s == "--gzip") p.gzipOut = true;                                                  // main.cpp:570-572
         else if (s == "-a" || s == "--alphabet") { p.codonFile = next(); p.codonId = next(); }
         else if (s == "--coherence") p.coherence = true;                                        // main.cpp:576-581
         else if (s == "--coherenceThreshold") p.coherenceThreshold = std::stof(next());

@@ -407,7 +407,7 @@ def is_contaminant(best: np.float32, max_score: np.float32, error_threshold: flo
     return (b - float(np.float32(max_score))) / b < float(np.float32(error_threshold))
 
 
-def filter_reads(in_paths, flagged, clean_prefix: str, cont_prefix: str) -> None:
+def filter_reads(in_paths, flagged, clean_prefix: str, cont_prefix: str, gzip_out: bool = False) -> None:
     """Compare::filter (Compare.hpp:2448-2596): re-read the input file(s) and write every record to `<clean>.fast[aq]`
     or `<contaminants>.fast[aq]` (`_1`/`_2` before the extension for paired input; "_" = do not write that side).
     `flagged`: ascending read numbers of the contaminated reads."""
@@ -427,6 +427,8 @@ def filter_reads(in_paths, flagged, clean_prefix: str, cont_prefix: str) -> None
         if prefix == "_":
             return None
         names = [prefix + "_1" + ext, prefix + "_2" + ext] if paired else [prefix + ext]
+        if gzip_out:                                               # --gzip (Compare.hpp:2455): the same files through zlib, ".gz" appended
+            return [gzip.open(n + ".gz", "wb") for n in names]
         return [open(n, "wb") for n in names]
     clean, cont = outs(clean_prefix), outs(cont_prefix)
     try:

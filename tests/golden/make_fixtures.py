@@ -209,6 +209,10 @@ def case_pairs(out):
                 "-q", "out_flta.jsonl", "-p", "prof_flta.csv"], out)
     for junk in ("out_flt.jsonl", "prof_flt.csv", "out_flta.jsonl", "prof_flta.csv"):   # same as b100 / fasta
         os.remove(os.path.join(out, junk))
+    # --gzip: the filter's files written through the reference's zlib (same split as flt_*)
+    run(base + ["-i", "reads.fastq", "--jsonl", "-b", "100", "--filter", "gflt_clean", "gflt_cont", "--gzip", "-q", "out_gflt.jsonl", "-p", "prof_gflt.csv"], out)
+    for junk in ("out_gflt.jsonl", "prof_gflt.csv"):
+        os.remove(os.path.join(out, junk))
     # --coherence (Compare::postProcess): one more column / field per read in every text format but the Kraken one; with
     # --six on an input whose last read matches on both strands (reads_dup.fastq ends in a palindrome) ...
     coh = {

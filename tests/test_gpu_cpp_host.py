@@ -211,3 +211,19 @@ def test_cpp_host_rccl_reduce_with_one_rank(tmp_path):
                "--jsonl", "-b", "100", "-n", "2", "--devices", "0", "--coverage"], env={"KASA_FORCE_ALLREDUCE": "1"})
     assert _read(out) == _read(os.path.join(d, "out_cov.jsonl"))
     assert _read(prof) == _read(os.path.join(d, "prof_cov.csv"))
+
+
+def test_cpp_host_filter_gzip(tmp_path):
+    """--filter --gzip: the driver's files unpack to what the reference's unpack to."""
+    import gzip
+    assert capi.device_count() > 0
+    exe = hipbuild.build_host()
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    c, x = str(tmp_path / "c"), str(tmp_path / "x")
+    r = subprocess.run([exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
+                        "-p", str(tmp_path / "prof.csv"), "--jsonl", "-b", "100", "--filter", c, x, "--gzip"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for mine, ref in ((c + ".fastq.gz", "gflt_clean.fastq.gz"), (x + ".fastq.gz", "gflt_cont.fastq.gz")):
+        assert open(mine, "rb").read(2) == b"\x1f\x8b"
+        assert gzip.open(mine).read() == gzip.open(os.path.join(d, ref)).read()

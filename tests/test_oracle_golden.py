@@ -147,6 +147,27 @@ def test_filter_outputs_byte_identical(infile, thr, clean, cont, tmp_path):
     assert _read(str(tmp_path / ("x" + ext)), True) == _read(os.path.join(d, cont), True)
 
 
+def test_filter_outputs_gzip(tmp_path):
+    """--filter --gzip (Compare.hpp:2455,3713-3731): the same two files through zlib, ".gz" appended to their names.  The
+    reference's files unpack to the plain ones of the same run; so do the host's."""
+    import gzip
+    from kasa_amd import report
+    d, ix = helpers.load_case("pairs")
+    ref_clean, ref_cont = (gzip.open(os.path.join(d, n)).read() for n in ("gflt_clean.fastq.gz", "gflt_cont.fastq.gz"))
+    assert ref_clean == _read(os.path.join(d, "flt_clean.fastq"), True) and ref_cont == _read(os.path.join(d, "flt_cont.fastq"), True)
+    batch = reads.parse_reads(os.path.join(d, "reads.fastq"))
+    res, _ = helpers.oracle_identify(ix, batch, 12, 7, 3)
+    rows = helpers.csr_from_dense(res.M)
+    flagged = []
+    for r in range(batch.n):
+        rk = report.rank_read(rows[r][0], rows[r][1], int(batch.lengths[r]), ix.freq_at(12), 12, 7, 3, 0.0, 100)
+        if rk.hits and report.is_contaminant(rk.best, max(h.score for h in rk.hits), 0.5):
+            flagged.append(r)
+    report.filter_reads([os.path.join(d, "reads.fastq")], flagged, str(tmp_path / "c"), str(tmp_path / "x"), gzip_out=True)
+    assert gzip.open(str(tmp_path / "c.fastq.gz")).read() == ref_clean
+    assert gzip.open(str(tmp_path / "x.fastq.gz")).read() == ref_cont
+
+
 @pytest.mark.parametrize("closed_form", [False, True], ids=["sequential", "closed_form"])
 def test_custom_codon_table(closed_form):
     """-a gc.prt 2 (kASA::setCodonTable, kASA.hpp:579-615) for `build` and `identify`."""
