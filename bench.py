@@ -525,6 +525,7 @@ def main():
     ap.add_argument("--secondary", action="store_true", help="(the default at N = 1; kept for older command lines)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="do not run configs[2] (128-bit index, -k 25 7, same reads) after the headline measurement")
+    ap.add_argument("--debug-flags", type=int, default=0, help="kasa_ctx_debug bits for A/B runs of one kernel choice against another (0 = the product path)")
     ap.add_argument("--partitioned", action="store_true", help="BASELINE.json configs[4]: range-partitioned index (see bench_partitioned)")
     ap.add_argument("--part-records", type=float, default=3.0e9, help="--partitioned: index records per rank (36 GB at 3e9)")
     args = ap.parse_args()
@@ -598,6 +599,8 @@ def main():
         t0 = time.perf_counter()
         dix = capi.DeviceIndex(ix, local_rank, check_trie=True)
         ctx = capi.Context(dix, k_high, k_low, 3)
+        if args.debug_flags:
+            ctx.debug_flags(args.debug_flags)
         batches, dev_reads, extra_cfg = None, None, None
         if world == 1:
             reads = synth.reads_from_genomes(g, args.reads, args.read_len, seed=1000 + rank)

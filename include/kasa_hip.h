@@ -215,6 +215,39 @@ int kasa_batch_rank(kasa_ctx *ctx, const double *den, uint32_t nClasses, const u
                     uint64_t *nEntries, uint32_t *nFlagged);
 int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);
 
+/* The per-read file's text written on the device (the printing loops of Compare::scoringFunc,
+ * Compare.hpp:1526-1872, with the reference's number formats utils/iToStr.hpp:35-114 and utils/dToStr.h:427-456): after
+ * kasa_batch_rank the hits never leave the device -- a kernel writes every read's TSV / JSON / JSON-lines / Kraken bytes
+ * into one buffer (read order, offsets by a prefix sum of the sizes), and what crosses PCIe is the next piece of the file.
+ *   kasa_ctx_set_taxa_text  once per context: taxIds[nTaxa] and the names of the content file (entry 0 = "non_unique"),
+ *                           back to back, names[nameOff[t] .. nameOff[t+1])
+ *   kasa_batch_text         the text of the batch last ranked.  KASA_E_STATE when kasa_batch_rank left reads to the host
+ *                           (nFlagged > 0: the host then writes the whole batch from kasa_batch_rank_fetch +
+ *                           kasa_batch_scores_fetch as before)
+ *   kasa_batch_text_fetch   text[nBytes]; readOffsets[nReads + 1] (may be NULL): where each read's text starts;
+ *                           contaminated[nReads] (may be NULL): 1 = --filter's rule holds for the read (Compare.hpp:1597-1606:
+ *                           within errorThreshold of the perfect score, or coherence >= coherenceThreshold) */
+enum { KASA_TEXT_TSV = 0, KASA_TEXT_JSON = 1, KASA_TEXT_JSONL = 2, KASA_TEXT_KRAKEN = 3 };
+typedef struct kasa_text_params {
+    int format;                    /* KASA_TEXT_* */
+    uint32_t beasts;               /* -b */
+    uint64_t firstRead;            /* number of the batch's first read in its file ("Read number") */
+    const char *readNames;         /* host: the specifiers as printed, back to back */
+    const uint64_t *readNameOff;   /* host: [nReads + 1] */
+    const uint32_t *readLen;       /* host: "Length" of every read */
+    const float *bestScore;        /* host: [nClasses] the perfect score of a read of class c (Compare.hpp:1452-1481); classes =
+                                      the readClass given to kasa_batch_rank */
+    uint32_t nClasses;
+    int coherence;                 /* print the coherence of the read (the scores of kasa_batch_coherence on this batch) */
+    double errorThreshold;         /* --errorThreshold, as a double */
+    float coherenceThreshold;      /* --coherenceThreshold */
+} kasa_text_params;
+int kasa_ctx_set_taxa_text(kasa_ctx *ctx, const uint32_t *taxIds, const char *names, const uint64_t *nameOff);
+int kasa_batch_text(kasa_ctx *ctx, const kasa_text_params *params, uint64_t *nBytes);
+int kasa_batch_text_fetch(kasa_ctx *ctx, char *text, uint64_t *readOffsets, uint8_t *contaminated);
+/* Test tap: the reference's double -> text (dToStr.h) as the device writes it; out = 32 bytes per value, zero-terminated. */
+int kasa_text_dtoa(int device, const double *values, uint32_t n, char *out);
+
 /* Page-locked host memory for buffers that cross PCIe (reads in, ranked hits or CSR out).  NULL when it cannot be had. */
 void *kasa_host_alloc(size_t bytes);
 void kasa_host_free(void *p);

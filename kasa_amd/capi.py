@@ -29,6 +29,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_text_dtoa",
 ]
 
 
@@ -162,6 +163,21 @@ class RefBatcher:
 
 
 RANK_ENTRY = np.dtype([("tax", np.uint32), ("score", np.float32), ("rel", np.float64)])
+
+
+class TextParams(C.Structure):
+    """kasa_text_params (include/kasa_hip.h)"""
+    _fields_ = [("format", C.c_int), ("beasts", C.c_uint32), ("firstRead", C.c_uint64), ("readNames", C.c_char_p),
+                ("readNameOff", C.POINTER(C.c_uint64)), ("readLen", C.POINTER(C.c_uint32)), ("bestScore", C.POINTER(C.c_float)),
+                ("nClasses", C.c_uint32), ("coherence", C.c_int), ("errorThreshold", C.c_double), ("coherenceThreshold", C.c_float)]
+
+
+def device_dtoa(values, device: int = 0):
+    """The reference's double -> text as the DEVICE writes it (kasa_text_dtoa): list of str."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    out = np.zeros(v.shape[0] * 32, dtype=np.uint8)
+    _check(lib().kasa_text_dtoa(C.c_int(device), _p(v), C.c_uint32(v.shape[0]), _p(out)))
+    return [bytes(out[i * 32:(i + 1) * 32]).split(b"\0", 1)[0].decode("ascii") for i in range(v.shape[0])]
 
 
 def pinned_empty(n: int, dtype) -> np.ndarray:
@@ -412,6 +428,44 @@ class Context:
             ent = alloc(n_ent.value, RANK_ENTRY)
         _check(lib().kasa_batch_rank_fetch(self.h, _p(meta), _p(ent)))
         return meta.reshape(-1, 4), ent, n_flag.value
+
+    def set_taxa_text(self, taxids, names):
+        """kasa_ctx_set_taxa_text: what the device prints for a taxon (content file: entry 0 = non_unique)."""
+        ids = np.ascontiguousarray(taxids, dtype=np.uint32)
+        enc = [n.encode("latin-1") if isinstance(n, str) else bytes(n) for n in names]
+        if len(enc) != self.dix.n_taxa or ids.shape[0] != self.dix.n_taxa:
+            raise ValueError("set_taxa_text: one id and one name per taxon of the index")
+        off = np.zeros(len(enc) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+        blob = b"".join(enc)
+        _check(lib().kasa_ctx_set_taxa_text(self.h, _p(ids), C.c_char_p(blob), _p(off)))
+
+    TEXT_FORMATS = {"tsv": 0, "json": 1, "jsonl": 2, "kraken": 3}
+
+    def text(self, fmt: str, beasts: int, first_read: int, names, lengths, best, coherence: bool = False,
+             error_threshold: float = 0.5, coherence_threshold: float = 11.0, pinned: bool = False):
+        """kasa_batch_text + fetch: the per-read file's bytes of the batch last ranked, written on the device.
+        names: the specifiers as printed; lengths: uint32[nReads]; best: float32[nClasses] (the classes given to rank()).
+        -> (text bytes, uint64 offsets[nReads + 1], uint8 contaminated[nReads])"""
+        enc = [n.encode("latin-1") if isinstance(n, str) else bytes(n) for n in names]
+        if len(enc) != self.n_reads:
+            raise ValueError("text: one name per read")
+        off = np.zeros(len(enc) + 1, dtype=np.uint64)
+        if enc:
+            off[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+        blob = b"".join(enc)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        best = np.ascontiguousarray(best, dtype=np.float32)
+        tp = TextParams(self.TEXT_FORMATS[fmt], int(beasts), int(first_read), C.c_char_p(blob), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                        lengths.ctypes.data_as(C.POINTER(C.c_uint32)), best.ctypes.data_as(C.POINTER(C.c_float)), int(best.shape[0]),
+                        1 if coherence else 0, float(np.float32(error_threshold)), float(np.float32(coherence_threshold)))
+        n = C.c_uint64(0)
+        _check(lib().kasa_batch_text(self.h, C.byref(tp), C.byref(n)))
+        buf = (pinned_empty if pinned else (lambda k, dt: np.empty(k, dtype=dt)))(max(1, n.value), np.uint8)
+        offs = np.zeros(self.n_reads + 1, dtype=np.uint64)
+        flags = np.zeros(max(1, self.n_reads), dtype=np.uint8)
+        _check(lib().kasa_batch_text_fetch(self.h, _p(buf), _p(offs), _p(flags)))
+        return buf[:n.value].tobytes(), offs, flags[:self.n_reads]
 
     def coherence(self) -> np.ndarray:
         """--coherence scores of the batch (Compare::postProcess): float32[n_reads].  Raises where the reference throws."""

@@ -39,6 +39,7 @@
 #include "../../include/kasa_hip.h"
 #include "stdsort_order.h"
 #include "kasa_radix.h"
+#include "kasa_text.h"
 
 // ------------------------------------------------------------------------------------------------
 // constants
@@ -486,8 +487,7 @@ struct kasa_ctx {
     bool protein = false;                      // amino-acid input (kasa_ctx_set_protein)
     int enc_mode() const { return protein ? 2 : (frames == 1 ? 1 : 0); }   // ENC_PROTEIN / ENC_ONE / ENC_DNA
     int strands() const { return (frames == 6 && !protein) ? 2 : 1; }      // kASA.hpp:181: protein input switches --six off
-    hipStream_t stream = nullptr, stream2 = nullptr;    // stream2: the profile side of the score stage, beside the CSR packing
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t stream = nullptr;
     DevBuf scanTmp;
     // batch state
     int64_t nReads = 0;
@@ -497,6 +497,12 @@ struct kasa_ctx {
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
     DevBuf rankDen, rankClass, rankMeta, rankOut, rankList, rankScratch; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
+    bool rankValid = false; uint32_t rankFlagged = 0;          // ... of THIS batch; reads it left to the host
+    DevBuf taxText, taxTextOff, taxTextIds;                    // kasa_ctx_set_taxa_text: names back to back, u64[nTaxa + 1], u32[nTaxa]
+    bool haveTaxText = false;
+    DevBuf txtNames, txtNameOff, txtLen, txtBest, txtBytes, txtOff, txtOut, txtFlags;   // kasa_batch_text
+    uint64_t txtTotal = 0; bool txtValid = false;
+    const float *cohScores = nullptr;                          // device: the scores of the last kasa_batch_coherence of this batch
     bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
     bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
@@ -614,8 +620,6 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     c->ix = ix; c->device = ix->device; c->kHigh = kHigh; c->kLow = kLow; c->nK = kHigh - kLow + 1; c->frames = frames;
     auto bail = [&](int code) { kasa_ctx_destroy(c); return code; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess) return bail(fail(KASA_E_HIP, "hipStreamCreate failed"));
     uint8_t lut[366];
     if (codonLut) memcpy(lut, codonLut, 366); else builtin_codon_table(lut);
     int rc = c->lut.reserve(512); if (rc) return bail(rc);
@@ -647,7 +651,8 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                      &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                     &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
+                     &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
+                     &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
         for (auto &pr : t.open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -655,10 +660,6 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     };
     for (auto &t : c->timers) drop(t);
     for (auto &t : c->kernels) drop(t);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->evFork) (void)hipEventDestroy(c->evFork);
-    if (c->evJoin) (void)hipEventDestroy(c->evJoin);
-    c->scanTmp.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -739,7 +740,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     if (nSeq < 0 || nReads < 0 || (nSeq > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
     if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
     const int64_t zero = 0;
     if (nSeq == 0) offsets = &zero;
     if (offsets[nSeq] < offsets[0]) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
@@ -1357,114 +1358,135 @@ __global__ __launch_bounds__(256) void bucket_rank_kernel(const Key *__restrict_
                                                           uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big,
                                                           uint32_t *__restrict__ bigHead)
 {
-    // A tile of keys plus a short halo in LDS: a query looks at its neighbours four at a time (independent LDS reads; one
-    // at a time the scan is a chain of round trips, and from global memory it is bound by the load-issue rate).  Members
-    // of a bucket that reaches beyond the staged window are read from global memory.
-    __shared__ Key sK[RANK_TILE + 2 * RANK_HALO];
+    // A tile of keys plus a short halo in LDS, and one bit per staged query "first of its bucket" (a ballot per 64 queries).
+    // A query finds its bucket's ends in that bit mask (count-leading/trailing-zeros; longer buckets walk the mask 64 queries
+    // a step), then counts: one LDS read and one compare per member.  Members of a bucket that reaches beyond the staged
+    // window are read from global memory.
+    constexpr uint32_t WIN = RANK_TILE + 2 * RANK_HALO;
+    static_assert(WIN % 256 == 0, "whole wavefronts stage the window");
+    __shared__ Key sK[WIN];
+    __shared__ uint64_t sHead[WIN / 64];
     const uint32_t base = blockIdx.x * RANK_TILE;
     const uint32_t lo = base >= RANK_HALO ? base - RANK_HALO : 0u;
     const uint32_t hi = (uint64_t)base + RANK_TILE + RANK_HALO < (uint64_t)n ? base + RANK_TILE + RANK_HALO : n;
     const uint32_t win = hi - lo;
-    for (uint32_t x = threadIdx.x; x < win; x += 256u) sK[x] = kin[lo + x];
+    for (uint32_t x = threadIdx.x; x < WIN; x += 256u) {
+        bool head = false;
+        if (x < win) {
+            const uint32_t q = lo + x;
+            const Key k = kin[q];
+            head = q == 0u || (uint64_t)(kin[q - 1u] >> shift) != (uint64_t)(k >> shift);
+            sK[x] = k;
+        }
+        const uint64_t m = __ballot(head);
+        if ((threadIdx.x & 63u) == 0u) sHead[x >> 6] = m;
+    }
     __syncthreads();
-    auto keyAt = [&](uint32_t q) -> Key { const uint32_t x = q - lo; return x < win ? sK[x] : kin[q]; };
+    const uint32_t lastWord = (win - 1u) >> 6;
     for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
         const uint32_t p = base + e;
         if (p >= n) break;
-        const Key k = sK[p - lo];
-        const uint64_t top = (uint64_t)(k >> shift);
-        uint32_t rank = 0, L = 0, R = 0;
-        bool open = true;
-        for (uint32_t b0 = 0; open && L < SORT_BUCKET_LIMIT; b0 += 4) {
-            Key o[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) o[j] = (p >= 1u + b0 + j) ? keyAt(p - 1u - b0 - j) : k;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (open && (p < 1u + b0 + j || (uint64_t)(o[j] >> shift) != top)) open = false;
-                if (open) { ++L; rank += (o[j] <= k) ? 1u : 0u; }
-            }
+        const uint32_t i0 = p - lo, bit = i0 & 63u;
+        const Key k = sK[i0];
+        bool edge = false;
+        uint32_t m = i0 >> 6;
+        uint64_t w = sHead[m] & (~0ull >> (63u - bit));                   // the bucket's first member: the last flag at or before me
+        while (w == 0ull && m > 0u) w = sHead[--m];
+        uint32_t hs = 0;
+        if (w == 0ull) edge = true; else hs = m * 64u + 63u - (uint32_t)__clzll((long long)w);
+        m = i0 >> 6;
+        w = sHead[m] & ((~0ull << bit) << 1);                             // its end: the first flag after me
+        while (w == 0ull && m < lastWord) w = sHead[++m];
+        uint32_t he = win;
+        if (w == 0ull) edge = edge || (hi < n); else he = m * 64u + (uint32_t)__ffsll((unsigned long long)w) - 1u;
+        uint32_t L = i0 - hs, members = he - hs, rank = 0;
+        if (!edge && members <= SORT_BUCKET_LIMIT) {                      // before me: not larger; after me: smaller (= the stable order)
+            for (uint32_t j = hs; j < i0; ++j) rank += (sK[j] <= k) ? 1u : 0u;
+            for (uint32_t j = i0 + 1u; j < he; ++j) rank += (sK[j] < k) ? 1u : 0u;
         }
-        open = true;
-        for (uint32_t b0 = 0; open && R < SORT_BUCKET_LIMIT; b0 += 4) {
-            Key o[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) o[j] = ((uint64_t)p + 1u + b0 + j < (uint64_t)n) ? keyAt(p + 1u + b0 + j) : k;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (open && ((uint64_t)p + 1u + b0 + j >= (uint64_t)n || (uint64_t)(o[j] >> shift) != top)) open = false;
-                if (open) { ++R; rank += (o[j] < k) ? 1u : 0u; }
-            }
+        if (edge) {                                                       // the bucket leaves the window: the whole scan again, from global memory
+            const uint64_t top = (uint64_t)(k >> shift);
+            uint32_t R = 0;
+            rank = 0; L = 0;
+            for (uint32_t q = p; q > 0 && L < SORT_BUCKET_LIMIT;) { --q; const Key o = kin[q]; if ((uint64_t)(o >> shift) != top) break; ++L; rank += (o <= k) ? 1u : 0u; }
+            for (uint32_t q = p + 1; q < n && R < SORT_BUCKET_LIMIT; ++q) { const Key o = kin[q]; if ((uint64_t)(o >> shift) != top) break; ++R; rank += (o < k) ? 1u : 0u; }
+            members = L + R + 1u;
         }
         // a bucket of more than SORT_BUCKET_LIMIT members stays as it is (every member decides the same way: it sees both
         // ends of the bucket or knows it is longer); its first member files it for the segmented sort that follows
-        if (L + R + 1u > SORT_BUCKET_LIMIT) {
+        if (members > SORT_BUCKET_LIMIT) {
             kout[p] = k; vout[p] = vin[p];
             if (L == 0u) { const uint32_t at = atomicAdd(big, 1u); if (at < SORT_BIG_CAP) bigHead[at] = p; }
         } else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
     }
 }
 
-// The same for 64-bit keys, where the bits below the bucket's fit 32: LDS holds one word per query -- those bits and a flag
-// "first of its bucket" -- so a member is one 4-byte read and one 32-bit compare (half the LDS traffic, no 64-bit
-// arithmetic in the scans).  A bucket that reaches beyond the staged window is scanned in global memory (rare).
+// The same for 64-bit keys, where the bits below the bucket's fit 20: LDS holds one word per query -- those bits above its
+// position in the window, so members compare like (key, position) with ONE 32-bit compare -- and one bit per query "first of
+// its bucket" (a ballot per 64 staged queries).  A query finds its bucket's ends in that bit mask (count-leading/trailing-zeros;
+// longer buckets walk the mask 64 queries a step) and then counts the members that order before it: one LDS read, one compare
+// and one add per member, no open/closed bookkeeping.  A bucket that reaches beyond the staged window is scanned in global
+// memory (rare).
 __global__ __launch_bounds__(256) void bucket_rank32_kernel(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
                                                             uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big,
                                                             uint32_t *__restrict__ bigHead)
 {
-    __shared__ uint32_t sW[RANK_TILE + 2 * RANK_HALO];
+    constexpr uint32_t WIN = RANK_TILE + 2 * RANK_HALO, POS_BITS = 12;
+    static_assert(WIN % 256 == 0 && WIN <= (1u << POS_BITS), "window positions fit the low bits of the LDS word; whole wavefronts stage it");
+    __shared__ uint32_t sW[WIN + 1];
+    __shared__ uint64_t sHead[WIN / 64];
     const uint32_t base = blockIdx.x * RANK_TILE;
     const uint32_t lo = base >= RANK_HALO ? base - RANK_HALO : 0u;
     const uint32_t hi = (uint64_t)base + RANK_TILE + RANK_HALO < (uint64_t)n ? base + RANK_TILE + RANK_HALO : n;
     const uint32_t win = hi - lo;
-    const uint32_t lowMask = (1u << shift) - 1u;
-    for (uint32_t x = threadIdx.x; x < win; x += 256u) {
-        const uint32_t q = lo + x;
-        const uint64_t k = kin[q];
-        const bool head = q == 0u || (kin[q - 1u] >> shift) != (k >> shift);
-        sW[x] = ((uint32_t)k & lowMask) | (head ? 0x80000000u : 0u);
+    const uint32_t lowMask = (1u << shift) - 1u;                         // (shift + POS_BITS <= 32: checked by the caller)
+    for (uint32_t x = threadIdx.x; x < WIN; x += 256u) {
+        bool head = false;
+        if (x < win) {
+            const uint32_t q = lo + x;
+            const uint64_t k = kin[q];
+            head = q == 0u || (kin[q - 1u] >> shift) != (k >> shift);
+            sW[x] = (((uint32_t)k & lowMask) << POS_BITS) | x;
+        }
+        const uint64_t m = __ballot(head);
+        if ((threadIdx.x & 63u) == 0u) sHead[x >> 6] = m;
     }
     __syncthreads();
+    const uint32_t lastWord = (win - 1u) >> 6;
     for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
         const uint32_t p = base + e;
         if (p >= n) break;
-        const uint32_t i0 = p - lo, my = sW[i0], myLow = my & lowMask;
-        uint32_t rank = 0, L = 0, R = 0;
+        const uint32_t i0 = p - lo, my = sW[i0], bit = i0 & 63u;
         bool edge = false;
-        bool open = (my >> 31) == 0u;                                     // members before me, down to the first of the bucket
-        for (uint32_t b0 = 0; open && L < SORT_BUCKET_LIMIT; b0 += 4) {
-            uint32_t w[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) w[j] = (i0 >= 1u + b0 + j) ? sW[i0 - 1u - b0 - j] : 0u;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (!open) continue;
-                if (i0 < 1u + b0 + j) { edge = true; open = false; continue; }
-                ++L; rank += ((w[j] & lowMask) <= myLow) ? 1u : 0u;
-                if (w[j] >> 31) open = false;
-            }
-        }
-        open = true;                                                      // members after me, up to the first of the next bucket
-        for (uint32_t b0 = 0; open && R < SORT_BUCKET_LIMIT; b0 += 4) {
-            uint32_t w[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) w[j] = (i0 + 1u + b0 + j < win) ? sW[i0 + 1u + b0 + j] : 0x80000000u;
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (!open) continue;
-                if (i0 + 1u + b0 + j >= win) { edge = edge || (hi < n); open = false; continue; }   // (never clears what the left scan found)
-                if (w[j] >> 31) { open = false; continue; }
-                ++R; rank += ((w[j] & lowMask) < myLow) ? 1u : 0u;
+        uint32_t m = i0 >> 6;
+        uint64_t w = sHead[m] & (~0ull >> (63u - bit));                   // the bucket's first member: the last flag at or before me
+        while (w == 0ull && m > 0u) w = sHead[--m];
+        uint32_t hs = 0;
+        if (w == 0ull) edge = true; else hs = m * 64u + 63u - (uint32_t)__clzll((long long)w);
+        m = i0 >> 6;
+        w = sHead[m] & ((~0ull << bit) << 1);                             // its end: the first flag after me
+        while (w == 0ull && m < lastWord) w = sHead[++m];
+        uint32_t he = win;
+        if (w == 0ull) edge = edge || (hi < n); else he = m * 64u + (uint32_t)__ffsll((unsigned long long)w) - 1u;
+        uint32_t L = i0 - hs, members = he - hs, rank = 0;
+        if (!edge && members <= SORT_BUCKET_LIMIT) {
+            for (uint32_t j = hs; j < he; j += 2u) {
+                const uint32_t a = sW[j], b = sW[j + 1u];
+                rank += (a < my ? 1u : 0u) + ((j + 1u < he && b < my) ? 1u : 0u);
             }
         }
         const uint64_t k = kin[p];
         if (edge) {                                                       // the bucket leaves the window: the whole scan again, from global memory
             const uint64_t top = k >> shift;
-            rank = 0; L = 0; R = 0;
+            uint32_t R = 0;
+            rank = 0; L = 0;
             for (uint32_t q = p; q > 0 && L < SORT_BUCKET_LIMIT;) { --q; const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++L; rank += (o <= k) ? 1u : 0u; }
             for (uint32_t q = p + 1; q < n && R < SORT_BUCKET_LIMIT; ++q) { const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++R; rank += (o < k) ? 1u : 0u; }
+            members = L + R + 1u;
         }
-        if (L + R + 1u > SORT_BUCKET_LIMIT) {
+        // a bucket of more than SORT_BUCKET_LIMIT members stays as it is (every member decides the same way); its first member
+        // files it for the segmented sort that follows
+        if (members > SORT_BUCKET_LIMIT) {
             kout[p] = k; vout[p] = vin[p];
             if (L == 0u) { const uint32_t at = atomicAdd(big, 1u); if (at < SORT_BIG_CAP) bigHead[at] = p; }
         } else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
@@ -1526,6 +1548,7 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
                 if (kRes != c->qKmerB.as<Key>()) return fail(KASA_E_HIP, "query sort: unexpected result buffer");
             }
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
+            static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP + 12 <= 32, "bucket_rank32_kernel: low key bits and window position share a word");
             if constexpr (sizeof(Key) == 8)
                 bucket_rank32_kernel<<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<uint64_t>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<uint64_t>(),
                                                                                       c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
@@ -4099,6 +4122,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
     }
     // ---- resolve the fast kernels' records: per-read merge, then the profile contributions by sort + reduce
     bool profPending = false, profTables = false;
+    hipStream_t ps = c->stream;                                // (a second stream for the profile side, beside the CSR packing, was measured: no gain)
     unsigned long long profLeft = 0;
     uint64_t *profSortIn = nullptr, *profSortOut = nullptr, profSort = 0;
     if (fast && staged > 0) {
@@ -4134,26 +4158,22 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         }
         bool tables = nKeys > 0 && !(c->debugFlags & 16);
         for (const auto &TL : passes) if (TL.lvHi <= TL.lvLo) tables = false;      // a window without cells: everything is sorted
-        // The profile side runs on the context's SECOND stream from here: it only reads the keys row_merge has written, while
-        // the first stream packs the rows into the CSR (below); both are small kernels that leave most of the chip idle.
-        HIPCHK(hipEventRecord(c->evFork, c->stream));
-        HIPCHK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
         profSortIn = c->profKeys.as<uint64_t>(); profSortOut = c->profSorted.as<uint64_t>();
         profSort = nKeys;
         if (tables) {
             int nCu = 0;
             HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
             unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
-            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, c->stream2));
+            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, ps));
             for (const auto &TL : passes) {
                 const size_t shBytes = (size_t)TL.first[MAX_LEVELS] * nTaxa * 4;
                 HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
-                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, c->stream2>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
+                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, ps>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
                     c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
                     c->profSorted.as<uint64_t>(), leftCursor);
                 HIPCHK(hipGetLastError());
             }
-            HIPCHK(hipMemcpyAsync(&profLeft, leftCursor, 8, hipMemcpyDeviceToHost, c->stream2));
+            HIPCHK(hipMemcpyAsync(&profLeft, leftCursor, 8, hipMemcpyDeviceToHost, ps));
             profTables = true;
         }
         profPending = true;
@@ -4168,7 +4188,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         size_t tmpBytes = 0;
         HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
-        if ((rc = c->scanTmp.reserve(tmpBytes))) return rc;              // (not sortTmp: the profile's sort on the other stream uses that)
+        if ((rc = c->scanTmp.reserve(tmpBytes))) return rc;              // (not sortTmp: the profile's leftover sort is queued with that)
         HIPCHK(rocprim::exclusive_scan(c->scanTmp.p, tmpBytes, len64.as<uint64_t>(), c->rowOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1,
                                        rocprim::plus<uint64_t>(), c->stream));
         uint64_t nnz = 0;
@@ -4181,8 +4201,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipGetLastError());
     }
     if (profPending) {
-        // back to the profile side: what the tables had no cell for is sorted and reduced, then the streams join
-        HIPCHK(hipStreamSynchronize(c->stream2));
+        // back to the profile side: what the tables had no cell for is sorted and reduced
+        HIPCHK(hipStreamSynchronize(ps));
         if (profTables) { profSort = profLeft; profSortIn = c->profSorted.as<uint64_t>(); profSortOut = c->profKeys.as<uint64_t>(); }   // what is left, sorted back into the key buffer
         if (profSort > 0) {
             const ProfLayout PL = prof_layout(nTaxa, nK);
@@ -4190,14 +4210,12 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
             if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(profSort)))) return rc;
             uint64_t *kRes = nullptr;
-            HIPCHK(kasa_radix::sort_pairs<uint64_t>(profSortIn, nullptr, profSortOut, nullptr, (uint32_t)profSort, 16, sortBits, c->sortTmp.p, c->stream2, &kRes, nullptr));
-            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(profSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, c->stream2>>>(
+            HIPCHK(kasa_radix::sort_pairs<uint64_t>(profSortIn, nullptr, profSortOut, nullptr, (uint32_t)profSort, 16, sortBits, c->sortTmp.p, ps, &kRes, nullptr));
+            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(profSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, ps>>>(
                 kRes, (uint32_t)profSort, nTaxa,
                 c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipEventRecord(c->evJoin, c->stream2));
-        HIPCHK(hipStreamWaitEvent(c->stream, c->evJoin, 0));
     }
     if (profPending || wantPerRead) { if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -4376,7 +4394,7 @@ extern "C" int kasa_batch_set_sorted_device(kasa_ctx *c, const void *kmersDev, u
     if (!c || (n && !kmersDev)) return fail(KASA_E_ARG, "kasa_batch_set_sorted_device: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_sorted_device: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr;
     int rc;
     if ((rc = c->qKmerB.reserve(n * c->keyBytes() + 64))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c->qKmerB.p, kmersDev, n * c->keyBytes(), hipMemcpyDefault, c->stream));   // same device or a peer's memory
@@ -4764,8 +4782,8 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 20;
     uint32_t *flagged = c->misc.as<uint32_t>() + 42;
     if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1 << 20, (uint64_t)nReads * 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u);
-    c->rankEntries = 0; *nEntries = 0; *nFlagged = 0;
-    if (nReads == 0) return KASA_OK;
+    c->rankEntries = 0; *nEntries = 0; *nFlagged = 0; c->rankValid = false; c->txtValid = false;
+    if (nReads == 0) { c->rankValid = true; c->rankFlagged = 0; return KASA_OK; }
     for (int attempt = 0; attempt < 6; ++attempt) {
         if ((rc = c->rankOut.reserve(c->rankCap * sizeof(RankEntry)))) return rc;
         HIPCHK(hipMemsetAsync(cursor, 0, 8, c->stream));
@@ -4811,7 +4829,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
             HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
         }
-        if (used <= c->rankCap) { c->rankEntries = used; *nEntries = used; *nFlagged = nf; return KASA_OK; }
+        if (used <= c->rankCap) { c->rankEntries = used; *nEntries = used; *nFlagged = nf; c->rankValid = true; c->rankFlagged = nf; c->txtValid = false; return KASA_OK; }
         // the kernel has no side effects: grow and rerun.  Output space is handed out in slabs per wavefront, so `used` depends a
         // little on the scheduling: leave a slab for every wavefront that can be in flight on top of the usual slack
         c->rankCap = used + used / 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u + 1024;
@@ -4827,6 +4845,109 @@ extern "C" int kasa_batch_rank_fetch(kasa_ctx *c, uint32_t *meta, void *entries)
     if (c->nReads) HIPCHK(hipMemcpyAsync(meta, c->rankMeta.p, (size_t)c->nReads * 16, hipMemcpyDeviceToHost, c->stream));
     if (c->rankEntries && entries) HIPCHK(hipMemcpyAsync(entries, c->rankOut.p, c->rankEntries * sizeof(RankEntry), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The per-read file's text, written on the device (kasa_text.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" int kasa_ctx_set_taxa_text(kasa_ctx *c, const uint32_t *taxIds, const char *names, const uint64_t *nameOff)
+{
+    if (!c || !taxIds || !nameOff) return fail(KASA_E_ARG, "kasa_ctx_set_taxa_text: NULL argument");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t nTaxa = c->ix->nTaxa;
+    for (uint32_t t = 0; t < nTaxa; ++t) if (nameOff[t + 1] < nameOff[t]) return fail(KASA_E_ARG, "kasa_ctx_set_taxa_text: name offsets descend");
+    if (nameOff[0] != 0) return fail(KASA_E_ARG, "kasa_ctx_set_taxa_text: name offsets do not start at 0");
+    if (nameOff[nTaxa] && !names) return fail(KASA_E_ARG, "kasa_ctx_set_taxa_text: NULL names");
+    int rc;
+    if ((rc = c->taxText.reserve(nameOff[nTaxa] + 64)) || (rc = c->taxTextOff.reserve(((size_t)nTaxa + 1) * 8)) || (rc = c->taxTextIds.reserve((size_t)nTaxa * 4 + 64))) return rc;
+    if (nameOff[nTaxa]) HIPCHK(hipMemcpyAsync(c->taxText.p, names, nameOff[nTaxa], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->taxTextOff.p, nameOff, ((size_t)nTaxa + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->taxTextIds.p, taxIds, (size_t)nTaxa * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->haveTaxText = true;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_text(kasa_ctx *c, const kasa_text_params *tp, uint64_t *nBytes)
+{
+    if (!c || !tp || !nBytes) return fail(KASA_E_ARG, "kasa_batch_text: NULL argument");
+    if (!c->haveScores || !c->rankValid) return fail(KASA_E_STATE, "kasa_batch_text: the batch is not ranked (kasa_batch_rank)");
+    if (c->rankFlagged) return fail(KASA_E_STATE, "kasa_batch_text: kasa_batch_rank left reads to the host; their text is the host's, too");
+    if (!c->haveTaxText) return fail(KASA_E_STATE, "kasa_batch_text: no taxon names (kasa_ctx_set_taxa_text)");
+    if (tp->format < 0 || tp->format > 3) return fail(KASA_E_ARG, "kasa_batch_text: unknown format");
+    if (!tp->readNameOff || !tp->readLen || !tp->bestScore || tp->nClasses == 0) return fail(KASA_E_ARG, "kasa_batch_text: NULL argument");
+    if (tp->coherence && !c->cohScores) return fail(KASA_E_STATE, "kasa_batch_text: no coherence scores of this batch (kasa_batch_coherence)");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint32_t nReads = (uint32_t)c->nReads;
+    *nBytes = 0; c->txtTotal = 0; c->txtValid = false;
+    if (nReads == 0) { c->txtValid = true; return KASA_OK; }
+    const uint64_t nameBytes = tp->readNameOff[nReads];
+    if (nameBytes && !tp->readNames) return fail(KASA_E_ARG, "kasa_batch_text: NULL readNames");
+    int rc;
+    if ((rc = c->txtNames.reserve(nameBytes + 64)) || (rc = c->txtNameOff.reserve(((size_t)nReads + 1) * 8)) || (rc = c->txtLen.reserve((size_t)nReads * 4 + 64)) ||
+        (rc = c->txtBest.reserve((size_t)tp->nClasses * 4 + 64)) || (rc = c->txtBytes.reserve(((size_t)nReads + 1) * 8)) || (rc = c->txtOff.reserve(((size_t)nReads + 1) * 8)) ||
+        (rc = c->txtFlags.reserve((size_t)nReads + 64)))
+        return rc;
+    if (nameBytes) HIPCHK(hipMemcpyAsync(c->txtNames.p, tp->readNames, nameBytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->txtNameOff.p, tp->readNameOff, ((size_t)nReads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->txtLen.p, tp->readLen, (size_t)nReads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->txtBest.p, tp->bestScore, (size_t)tp->nClasses * 4, hipMemcpyHostToDevice, c->stream));
+    kasa_text::Args A;
+    A.fmt = tp->format; A.beasts = tp->beasts; A.firstRead = tp->firstRead; A.nReads = nReads;
+    A.readNames = c->txtNames.as<char>(); A.readNameOff = c->txtNameOff.as<uint64_t>(); A.readLen = c->txtLen.as<uint32_t>();
+    A.readClass = c->rankClass.as<uint32_t>(); A.best = c->txtBest.as<float>();
+    A.meta = c->rankMeta.as<uint4>(); A.entries = reinterpret_cast<const kasa_text::Entry *>(c->rankOut.p);
+    A.taxIds = c->taxTextIds.as<uint32_t>(); A.taxNames = c->taxText.as<char>(); A.taxNameOff = c->taxTextOff.as<uint64_t>();
+    A.coherence = tp->coherence ? 1 : 0; A.cohScores = c->cohScores;
+    A.errorThreshold = tp->errorThreshold; A.coherenceThreshold = tp->coherenceThreshold;
+    static_assert(sizeof(kasa_text::Entry) == sizeof(RankEntry), "kasa_text reads kasa_batch_rank's entries");
+    HIPCHK(hipMemsetAsync(c->txtBytes.p, 0, ((size_t)nReads + 1) * 8, c->stream));
+    kasa_text::text_size_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(A, c->txtBytes.as<uint64_t>(), c->txtFlags.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    size_t tmpBytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->txtBytes.as<uint64_t>(), c->txtOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+    if ((rc = c->scanTmp.reserve(tmpBytes))) return rc;
+    HIPCHK(rocprim::exclusive_scan(c->scanTmp.p, tmpBytes, c->txtBytes.as<uint64_t>(), c->txtOff.as<uint64_t>(), (uint64_t)0, (size_t)nReads + 1, rocprim::plus<uint64_t>(), c->stream));
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->txtOff.as<uint64_t>() + nReads, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = c->txtOut.reserve(total + 64))) return rc;
+    kasa_text::text_write_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(A, c->txtOff.as<uint64_t>(), c->txtOut.as<char>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->txtTotal = total; c->txtValid = true; *nBytes = total;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_text_fetch(kasa_ctx *c, char *text, uint64_t *readOffsets, uint8_t *contaminated)
+{
+    if (!c) return fail(KASA_E_ARG, "kasa_batch_text_fetch: NULL argument");
+    if (!c->txtValid) return fail(KASA_E_STATE, "kasa_batch_text_fetch: no text of this batch (kasa_batch_text)");
+    if (c->txtTotal && !text) return fail(KASA_E_ARG, "kasa_batch_text_fetch: NULL text");
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (c->txtTotal) HIPCHK(hipMemcpyAsync(text, c->txtOut.p, c->txtTotal, hipMemcpyDeviceToHost, c->stream));
+    if (readOffsets && c->nReads) HIPCHK(hipMemcpyAsync(readOffsets, c->txtOff.p, ((size_t)c->nReads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    else if (readOffsets) readOffsets[0] = 0;
+    if (contaminated && c->nReads) HIPCHK(hipMemcpyAsync(contaminated, c->txtFlags.p, (size_t)c->nReads, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+// test tap: the number format on its own (32 bytes per value, zero-terminated)
+extern "C" int kasa_text_dtoa(int device, const double *values, uint32_t n, char *out)
+{
+    if (!values || !out) return fail(KASA_E_ARG, "kasa_text_dtoa: NULL argument");
+    HIPCHK(hipSetDevice(device));
+    double *dv = nullptr; char *dout = nullptr;
+    if (n == 0) return KASA_OK;
+    HIPCHK(hipMalloc(&dv, (size_t)n * 8));
+    if (hipMalloc(&dout, (size_t)n * 32) != hipSuccess) { (void)hipFree(dv); return fail(KASA_E_NOMEM, "kasa_text_dtoa: out of device memory"); }
+    hipError_t e = hipMemcpy(dv, values, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) { kasa_text::dtoa_probe_kernel<<<blocks_for(n, 256), 256>>>(dv, n, dout); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(dv); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(KASA_E_HIP, hipGetErrorString(e));
     return KASA_OK;
 }
 
@@ -5035,6 +5156,7 @@ extern "C" int kasa_batch_coherence(kasa_ctx *c, float *scores, uint64_t *throws
     HIPCHK(hipMemcpyAsync(scores, dScores, (size_t)nReads * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (anyFail) *throwsAt = nE;
+    c->cohScores = dScores;
     return KASA_OK;
 }
 
@@ -5336,7 +5458,7 @@ static int batch_set_queries_impl(kasa_ctx *c, const void *kmers, const uint32_t
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->readsUploaded = false;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->readsUploaded = false;
     std::vector<uint64_t> koff((size_t)nReads + 1, 0);
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -5384,7 +5506,8 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
                            &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                           &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch};
+                           &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
+                     &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;

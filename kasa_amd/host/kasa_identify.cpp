@@ -512,6 +512,7 @@ struct Params {
     bool filter = false; string filterClean, filterCont; float errorThreshold = 0.5f;   // --filter <clean> <contaminants>, --errorThreshold
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
     bool hostRank = false;                         // --host-rank: the whole CSR comes back and the host ranks every read
+    bool hostText = false;                         // --host-text: the hits come back and the host writes the per-read text
     int memoryGiB = 0, refThreads = 1; bool ram = false;   // -m / -n / -r as the reference's batch budget sees them (kasa_refbatch_*)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
@@ -1012,6 +1013,7 @@ struct OrderedOut {
     uint64_t curBatch = 0; size_t curSlab = 0;                  // the next slab to be placed
     std::map<std::pair<uint64_t, size_t>, string> parked;
     std::map<uint64_t, size_t> slabsOf;
+    std::condition_variable turn;                               // direct(): a batch waits until everything before it has its place
     ~OrderedOut() { if (fd >= 0) ::close(fd); }
     static void writeAt(int fd, const char *d, size_t n, off_t at)
     {
@@ -1036,13 +1038,46 @@ struct OrderedOut {
         if (fd < 0) return;
         vector<std::pair<off_t, string>> todo;
         { std::lock_guard<std::mutex> lk(mu); slabsOf[batch] = nSlabs; place(todo); }
+        turn.notify_all();
         for (auto &w : todo) writeAt(fd, w.second.data(), w.second.size(), w.first);
+    }
+    // The whole text of a batch in one piece that the caller keeps (the buffer the device's text arrived in): waits for its
+    // turn, then `threads` threads write it at its place.
+    void direct(uint64_t batch, const char *d, size_t n, unsigned threads)
+    {
+        if (fd < 0) return;
+        vector<std::pair<off_t, string>> todo;
+        off_t at;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            slabsOf[batch] = 1;
+            place(todo);
+            turn.wait(lk, [&] { return curBatch == batch && curSlab == 0; });
+            at = pos; pos += (off_t)n; curSlab = 1;
+            place(todo);
+        }
+        turn.notify_all();
+        for (auto &w : todo) writeAt(fd, w.second.data(), w.second.size(), w.first);
+        ScopedTimerMt tm(g_ht.write, g_ht.mu);
+        const size_t piece = (size_t)8 << 20;
+        const size_t nPieces = (n + piece - 1) / piece;
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nPieces));
+        std::atomic<size_t> next{0};
+        vector<std::exception_ptr> err(nt);
+        auto work = [&](unsigned t) {
+            try { for (;;) { const size_t i = next.fetch_add(1); if (i >= nPieces) break; const size_t a = i * piece; writeAt(fd, d + a, std::min(piece, n - a), at + (off_t)a); } }
+            catch (...) { err[t] = std::current_exception(); }
+        };
+        if (nt == 1) work(0);
+        else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
+        for (auto &e : err) if (e) std::rethrow_exception(e);
     }
     void submit(uint64_t batch, size_t slab, string &&t)
     {
         if (fd < 0) return;
         vector<std::pair<off_t, string>> todo;
         { std::lock_guard<std::mutex> lk(mu); parked.emplace(std::make_pair(batch, slab), std::move(t)); place(todo); }
+        turn.notify_all();
         for (auto &w : todo) { ScopedTimerMt tm(g_ht.write, g_ht.mu); writeAt(fd, w.second.data(), w.second.size(), w.first); }
     }
 };
@@ -1053,6 +1088,7 @@ struct OrderedOut {
 struct WorkerBuffers {
     PcieBuf<uint32_t> meta; PcieBuf<Writer::DeviceHit> hits;
     PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
+    PcieBuf<char> text; PcieBuf<uint8_t> flags; PcieBuf<char> names; PcieBuf<uint64_t> nameOff;   // the device's text (kasa_batch_text)
 };
 
 static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb, OrderedOut &out)
@@ -1100,6 +1136,41 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
             for (uint64_t r = 0; r < nr; ++r) rclass[r] = classOf[b.rs.lengths[r]];
             uint64_t nEntries = 0;
             if (kasa_batch_rank(ctx, den.data(), (uint32_t)classOf.size(), rclass.data(), p.threshold, (uint32_t)std::max(0, p.beasts), &nEntries, &nFlagged)) throwLast();
+            if (nFlagged == 0 && !p.hostText) {
+                // The text is written on the device (kasa_batch_text): neither the hits nor the rows cross PCIe, the buffer
+                // that comes back is the file's next piece.  The host adds what only it knows: the specifiers and, per read
+                // length, the perfect score.
+                vector<float> best(classOf.size());
+                for (auto &kv : classOf) best[kv.second] = bestScore(kv.first, p);
+                wb.nameOff.resize(nr + 1);
+                uint64_t *no = wb.nameOff.data();
+                no[0] = 0;
+                for (uint64_t r = 0; r < nr; ++r) no[r + 1] = no[r] + b.rs.names[r].size();
+                wb.names.resize(std::max<uint64_t>(1, no[nr]));
+                {
+                    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, nr / 65536 + 1));
+                    auto copy = [&](unsigned t) { for (uint64_t r = nr * t / nt, e = nr * (t + 1) / nt; r < e; ++r) std::memcpy(wb.names.data() + no[r], b.rs.names[r].data(), b.rs.names[r].size()); };
+                    if (nt == 1) copy(0);
+                    else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(copy, t); for (auto &th : pool) th.join(); }
+                }
+                kasa_text_params tp{};
+                tp.format = p.fmt == Params::Tsv ? KASA_TEXT_TSV : p.fmt == Params::Json ? KASA_TEXT_JSON : p.fmt == Params::JsonL ? KASA_TEXT_JSONL : KASA_TEXT_KRAKEN;
+                tp.beasts = (uint32_t)std::max(0, p.beasts); tp.firstRead = b.firstRead;
+                tp.readNames = wb.names.data(); tp.readNameOff = no; tp.readLen = b.rs.lengths.data();
+                tp.bestScore = best.data(); tp.nClasses = (uint32_t)best.size();
+                tp.coherence = p.coherence ? 1 : 0; tp.errorThreshold = (double)p.errorThreshold; tp.coherenceThreshold = p.coherenceThreshold;
+                uint64_t nBytes = 0;
+                if (kasa_batch_text(ctx, &tp, &nBytes)) throwLast();
+                wb.text.resize(std::max<uint64_t>(1, nBytes)); wb.flags.resize(nr);
+                if (kasa_batch_text_fetch(ctx, wb.text.data(), nullptr, p.filter ? wb.flags.data() : nullptr)) throwLast();
+                b.flaggedByDevice = 0;
+                tDevice += secondsSince(tDev);
+                const auto tTxt = std::chrono::steady_clock::now();
+                out.direct(b.id, wb.text.data(), (size_t)nBytes, std::max(1u, std::min(p.threads, 16u)));
+                if (p.filter) for (uint64_t r = 0; r < nr; ++r) if (wb.flags.data()[r]) b.flagged.push_back(b.firstRead + r);
+                tText += secondsSince(tTxt);
+                return;
+            }
             meta.resize(nr * 4); hits.resize(nEntries);
             if (kasa_batch_rank_fetch(ctx, meta.data(), hits.data())) throwLast();
         }
@@ -1176,6 +1247,12 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     p.protein = batcher.protein;
     for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
+    if (wantRows && !p.hostRank && !p.hostText) {                     // what the device prints for a taxon (kasa_batch_text)
+        vector<uint64_t> off(ixf.content.names.size() + 1, 0);
+        string blob;
+        for (size_t t = 0; t < ixf.content.names.size(); ++t) { blob += ixf.content.names[t]; off[t + 1] = blob.size(); }
+        for (auto *c : ctx) if (kasa_ctx_set_taxa_text(c, ixf.content.taxids.data(), blob.data(), off.data())) throwLast();
+    }
     OrderedOut out;
     if (!p.rtt.empty()) {
         out.fd = ::open(p.rtt.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -1363,6 +1440,7 @@ static int run(int argc, char **argv)
         else if (s == "-m" || s == "--memory") { const string v = next(); p.memoryGiB = v == "inf" ? (1 << 30) : std::stoi(v); }   // main.cpp:438-447
         else if (s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
         else if (s == "--host-rank") p.hostRank = true;
+        else if (s == "--host-text") p.hostText = true;
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "--gzip") p.gzipOut = true;                                                  // main.cpp:570-572

@@ -37,6 +37,8 @@ class Identify:
         self.n_kmers = 0
         self.n_reads = 0
         self.device_rank = True         # kasa_batch_rank; False: the whole CSR comes back and the host ranks every read
+        self.device_text = True         # kasa_batch_text: the device writes the per-read file's bytes (needs device_rank, no flagged reads)
+        self.device_text_batches = 0    # batches whose text came from the device
         self.flagged_reads = 0          # reads the device handed back to the host's std::sort emulation
 
     def close(self):
@@ -57,6 +59,9 @@ class Identify:
         self.n_reads = 0
         self.flagged_reads = 0
         self.contaminants = []
+        self.device_text_batches = 0
+        if want_per_read and self.device_text and self.device_rank:
+            self.ctx.set_taxa_text(ix.content.taxids, ix.content.names)
         step = reads.n if not batch_reads else batch_reads
         if not batch_reads and reads.n:
             # the whole input is one batch unless it does not fit the free HBM (the reference cuts batches by its -m budget)
@@ -92,6 +97,20 @@ class Identify:
                     off, tax, sc = self.ctx.scores(pinned=not keep_csr)
                     if keep_csr:
                         csr.append((off, tax, sc))
+                if device_rank and self.device_text and not flagged and not keep_csr:
+                    # the text is written on the device (kasa_batch_text): the hits do not cross PCIe at all
+                    distinct = np.unique(np.asarray(part.lengths))
+                    best = np.array([report.best_score(int(L), self.k_high, self.k_low, self.frames, protein) for L in distinct], dtype=np.float32)
+                    text, _, cont = self.ctx.text(self.fmt, self.beasts, self.n_reads, part.names, part.lengths, best, coherence=coh is not None,
+                                                  error_threshold=self.error_threshold, coherence_threshold=self.coherence_threshold)
+                    out.append(text.decode("latin-1"))
+                    self.contaminants.extend(int(self.n_reads + r) for r in np.flatnonzero(cont))
+                    self.device_text_batches += 1
+                    self.n_reads += part.n
+                    a = b
+                    if reads.n == 0:
+                        break
+                    continue
                 for r in range(part.n):
                     length = int(part.lengths[r])
                     if device_rank and not (int(meta[r, 1]) >> 31):

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 FLAGS = {"json": "--json", "jsonl": "--jsonl", "tsv": "--tsv", "kraken": "--kraken"}
 
 
+@pytest.mark.parametrize("text", ["device-text", "host-text"])          # kasa_batch_text / the host's Writer over the ranked hits
 @pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
-def test_cpp_host_byte_identical(case, tmp_path):
+def test_cpp_host_byte_identical(case, text, tmp_path):
     assert capi.device_count() > 0
     exe = hipbuild.build_host()
     stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
@@ -33,6 +34,8 @@ def test_cpp_host_byte_identical(case, tmp_path):
         cmd.append("--coverage")
     if thr:
         cmd += ["--threshold", str(thr)]
+    if text == "host-text":
+        cmd.append("--host-text")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert _read(out) == _read(os.path.join(d, "out_" + stem))

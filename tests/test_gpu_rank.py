@@ -74,18 +74,22 @@ def test_device_rank_writes_the_hosts_text(kind):
     for fmt in ("json", "jsonl", "tsv", "kraken"):
         for beasts, thr in ((1, 0.0), (3, 0.0), (7, 0.03), (100, 0.0)):
             texts = []
-            for mode in ("device", "device, ties to the host", "host"):
+            for mode in ("device", "device rank, host text", "device, ties to the host", "host"):
                 run = identify.Identify(ix, 0, 12, 7, 3, thr, beasts, fmt, dix=dix)
                 run.device_rank = mode != "host"
+                run.device_text = mode == "device"
                 run.ctx.debug_flags(256 if mode == "device, ties to the host" else 0)
                 text, prof, _ = run.run(batch, True)
                 texts.append((text, prof))
                 if mode == "device":
                     flagged += run.flagged_reads
+                    assert run.device_text_batches == 1            # the bytes came from kasa_batch_text
+                else:
+                    assert run.device_text_batches == 0
                 if mode == "device, ties to the host":
                     handed_back += run.flagged_reads
                 run.close()
-            assert texts[0] == texts[1] == texts[2], (fmt, beasts, thr)
+            assert texts[0] == texts[1] == texts[2] == texts[3], (fmt, beasts, thr)
     assert flagged == 0                       # ties among more than 16 hits take std::sort's own order on the device
     if kind == "clones":
         assert handed_back > 0                # 40 tied hits per read: with the test tap those reads go back to the host
@@ -155,3 +159,21 @@ def test_cpp_host_ties_follow_std_sort(kind, tmp_path):
             assert r.returncode == 0, r.stderr
             outs.append(open(out, "rb").read())
         assert outs[0] == outs[1] and len(outs[0]) > 1000, fmt
+
+
+def test_device_number_format():
+    """kasa_text.h's Grisu2 against the host's (kasa_amd/textnum.py, pinned on the reference's files): doubles of every
+    magnitude, float32 values widened (what k-mer scores and errors are), exact powers, subnormals, the specials."""
+    from kasa_amd import textnum
+    rs = np.random.default_rng(5)
+    vals = [0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 1e21, 1e22, 1e-5, 1e-6, 1e-7, 123456789012345678.0, 5e-324, 2.2250738585072014e-308,
+            1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 0.3, 2.0 / 3.0, 100.0, 1e20, 9.999999999999999e20]
+    vals += [10.0 ** k for k in range(-30, 31)]
+    vals += list(rs.random(3000))
+    vals += list((rs.random(3000) * 2 - 1) * 10.0 ** rs.integers(-12, 25, size=3000))
+    vals += [float(x) for x in rs.random(3000).astype(np.float32)]                                # float -> double as the writer passes them
+    vals += [float(np.float32(a) / np.float32(b)) for a, b in zip(rs.integers(1, 5000, 2000), rs.integers(1, 5000, 2000))]
+    vals += list(np.frombuffer(rs.bytes(8 * 3000), dtype=np.float64))                           # any bit pattern
+    got = capi.device_dtoa(vals)
+    for v, g in zip(vals, got):
+        assert g == textnum.dtoa(float(v)), (v, g, textnum.dtoa(float(v)))

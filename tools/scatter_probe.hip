@@ -37,6 +37,17 @@ __global__ void scatter_pair_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_
     dst[(size_t)s * 2 + (t & 1u)] = make_uint4(i, s, t & 1u, 0);
 }
 
+// 32-byte records whose slots stay inside a WINDOW of 2^wbits records that moves with the index: what the scatter costs when the
+// batch is taken in pieces (the footprint the stores of one moment touch is the window, not the whole buffer)
+__global__ void scatter_window_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_t wmask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = (i & ~wmask) | perm(i & wmask, wmask);
+    dst[(size_t)s * 2] = make_uint4(i, s, 0, 0);
+    dst[(size_t)s * 2 + 1] = make_uint4(i, s, 1, 0);
+}
+
 template <int WORDS>
 __global__ void gather_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ out, uint32_t n, uint32_t mask)
 {
@@ -84,6 +95,15 @@ int main(int argc, char **argv)
             hipEventElapsedTime(&ms, a, b);
         }
         printf("record 32 B by lane pairs: scatter %7.2f ms (%5.2f G rec/s)\n", ms, n / ms / 1e6);
+    }
+    for (int wb = 16; wb <= bits; wb += 2) {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a); scatter_window_kernel<<<(n + 255) / 256, 256>>>(buf, n, (1u << wb) - 1u); hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+        }
+        printf("record 32 B, slots within windows of 2^%d records (%7.1f MB): scatter %7.2f ms (%5.2f G rec/s)\n", wb, (double)(1u << wb) * 32 / 1e6, ms, n / ms / 1e6);
     }
     return 0;
 }
