@@ -224,7 +224,8 @@ int kasa_batch_rank_fetch(kasa_ctx *ctx, uint32_t *meta, void *entries);
  *   kasa_batch_text         the text of the batch last ranked.  KASA_E_STATE when kasa_batch_rank left reads to the host
  *                           (nFlagged > 0: the host then writes the whole batch from kasa_batch_rank_fetch +
  *                           kasa_batch_scores_fetch as before)
- *   kasa_batch_text_fetch   text[nBytes]; readOffsets[nReads + 1] (may be NULL): where each read's text starts;
+ *   kasa_batch_text_fetch   text[nBytes] (NULL: the text stays where it is, see kasa_batch_text_fetch_range); readOffsets[nReads + 1]
+ *                           (may be NULL): where each read's text starts;
  *                           contaminated[nReads] (may be NULL): 1 = --filter's rule holds for the read (Compare.hpp:1597-1606:
  *                           within errorThreshold of the perfect score, or coherence >= coherenceThreshold) */
 enum { KASA_TEXT_TSV = 0, KASA_TEXT_JSON = 1, KASA_TEXT_JSONL = 2, KASA_TEXT_KRAKEN = 3 };
@@ -245,6 +246,9 @@ typedef struct kasa_text_params {
 int kasa_ctx_set_taxa_text(kasa_ctx *ctx, const uint32_t *taxIds, const char *names, const uint64_t *nameOff);
 int kasa_batch_text(kasa_ctx *ctx, const kasa_text_params *params, uint64_t *nBytes);
 int kasa_batch_text_fetch(kasa_ctx *ctx, char *text, uint64_t *readOffsets, uint8_t *contaminated);
+/* text[offset .. offset + nBytes) of the same text: a host that moves it through a few small page-locked buffers (making one
+ * of 5.5 GB for the text of 10 M reads takes seconds) writes one piece to the file while the next one arrives. */
+int kasa_batch_text_fetch_range(kasa_ctx *ctx, char *text, uint64_t offset, uint64_t nBytes);
 /* Test tap: the reference's double -> text (dToStr.h) as the device writes it; out = 32 bytes per value, zero-terminated. */
 int kasa_text_dtoa(int device, const double *values, uint32_t n, char *out);
 
@@ -333,6 +337,11 @@ int64_t kasa_refbatch_sequence_cost(int K, int kLow, int mode, int strands, int6
 int64_t kasa_refbatch_read_overhead(int64_t nameLen, uint32_t nTaxa, int coherence);
 /* Reads of the next batch given the costs of the reads still to come. */
 uint64_t kasa_refbatch_cut(int64_t budget, int firstBatch, const int64_t *cost, uint64_t nReads);
+
+/* Device buffers for a batch of about nQueries k-mers out of nBases bases, before the batch is there: allocation takes
+ * 25-90 ms per GB on this platform (seconds for a 10 M-read batch), time a host has while it parses its input.  Sizes only --
+ * a batch that needs more gets more when it arrives.  Not while a batch of this context is in flight. */
+int kasa_ctx_reserve(kasa_ctx *ctx, uint64_t nQueries, uint64_t nBases, int wantPerRead);
 
 /* Of the last batch: reads scored by the general kernel (score_kernel) instead of the lane-per-read one, and how many of
  * those needed its second pass (full pending window / direct profile adds).  Diagnostics for tests and bench.py. */

@@ -29,7 +29,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_text_dtoa",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve",
 ]
 
 
@@ -443,7 +443,7 @@ class Context:
     TEXT_FORMATS = {"tsv": 0, "json": 1, "jsonl": 2, "kraken": 3}
 
     def text(self, fmt: str, beasts: int, first_read: int, names, lengths, best, coherence: bool = False,
-             error_threshold: float = 0.5, coherence_threshold: float = 11.0, pinned: bool = False):
+             error_threshold: float = 0.5, coherence_threshold: float = 11.0, pinned: bool = False, pieces: int = 1):
         """kasa_batch_text + fetch: the per-read file's bytes of the batch last ranked, written on the device.
         names: the specifiers as printed; lengths: uint32[nReads]; best: float32[nClasses] (the classes given to rank()).
         -> (text bytes, uint64 offsets[nReads + 1], uint8 contaminated[nReads])"""
@@ -464,7 +464,14 @@ class Context:
         buf = (pinned_empty if pinned else (lambda k, dt: np.empty(k, dtype=dt)))(max(1, n.value), np.uint8)
         offs = np.zeros(self.n_reads + 1, dtype=np.uint64)
         flags = np.zeros(max(1, self.n_reads), dtype=np.uint8)
-        _check(lib().kasa_batch_text_fetch(self.h, _p(buf), _p(offs), _p(flags)))
+        if pieces <= 1:
+            _check(lib().kasa_batch_text_fetch(self.h, _p(buf), _p(offs), _p(flags)))
+        else:                                                        # the text in pieces (kasa_batch_text_fetch_range), the rest as before
+            _check(lib().kasa_batch_text_fetch(self.h, None, _p(offs), _p(flags)))
+            step = max(1, (n.value + pieces - 1) // pieces)
+            for a in range(0, n.value, step):
+                k = min(step, n.value - a)
+                _check(lib().kasa_batch_text_fetch_range(self.h, C.c_void_p(buf.ctypes.data + a), C.c_uint64(a), C.c_uint64(k)))
         return buf[:n.value].tobytes(), offs, flags[:self.n_reads]
 
     def coherence(self) -> np.ndarray:

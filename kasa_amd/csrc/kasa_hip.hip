@@ -14,6 +14,7 @@
 // The semantics implemented are the closed form of SURVEY.md section 0.1; tests compare every stage with
 // the CPU oracle (oracle/), which is itself pinned to the reference binary's outputs.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -103,7 +104,13 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 16 + 256;
+        static const bool timing = getenv("KASA_ALLOC_TIMING") != nullptr;     // diagnostics: allocations that take long
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        if (timing) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt > 0.02) fprintf(stderr, "kasa: hipMalloc(%.2f GB) took %.3f s\n", want / 1e9, dt);
+        }
         if (e != hipSuccess) {
             p = nullptr;
             (void)hipGetLastError();
@@ -4913,7 +4920,7 @@ extern "C" int kasa_batch_text(kasa_ctx *c, const kasa_text_params *tp, uint64_t
     HIPCHK(hipMemcpyAsync(&total, c->txtOff.as<uint64_t>() + nReads, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = c->txtOut.reserve(total + 64))) return rc;
-    kasa_text::text_write_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(A, c->txtOff.as<uint64_t>(), c->txtOut.as<char>());
+    kasa_text::text_write_kernel<<<blocks_for(nReads, 64), 64, 0, c->stream>>>(A, c->txtOff.as<uint64_t>(), c->txtOut.as<char>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->txtTotal = total; c->txtValid = true; *nBytes = total;
@@ -4924,12 +4931,25 @@ extern "C" int kasa_batch_text_fetch(kasa_ctx *c, char *text, uint64_t *readOffs
 {
     if (!c) return fail(KASA_E_ARG, "kasa_batch_text_fetch: NULL argument");
     if (!c->txtValid) return fail(KASA_E_STATE, "kasa_batch_text_fetch: no text of this batch (kasa_batch_text)");
-    if (c->txtTotal && !text) return fail(KASA_E_ARG, "kasa_batch_text_fetch: NULL text");
     HIPCHK(hipSetDevice(c->ix->device));
-    if (c->txtTotal) HIPCHK(hipMemcpyAsync(text, c->txtOut.p, c->txtTotal, hipMemcpyDeviceToHost, c->stream));
+    if (c->txtTotal && text) HIPCHK(hipMemcpyAsync(text, c->txtOut.p, c->txtTotal, hipMemcpyDeviceToHost, c->stream));
     if (readOffsets && c->nReads) HIPCHK(hipMemcpyAsync(readOffsets, c->txtOff.p, ((size_t)c->nReads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     else if (readOffsets) readOffsets[0] = 0;
     if (contaminated && c->nReads) HIPCHK(hipMemcpyAsync(contaminated, c->txtFlags.p, (size_t)c->nReads, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+// a piece of the text: page-locked buffers are expensive to make (seconds for the 5.5 GB of a 10 M-read batch), so a host
+// moves the text through a few small ones, writing one to the file while the next arrives
+extern "C" int kasa_batch_text_fetch_range(kasa_ctx *c, char *text, uint64_t offset, uint64_t nBytes)
+{
+    if (!c) return fail(KASA_E_ARG, "kasa_batch_text_fetch_range: NULL argument");
+    if (!c->txtValid) return fail(KASA_E_STATE, "kasa_batch_text_fetch_range: no text of this batch (kasa_batch_text)");
+    if (offset > c->txtTotal || nBytes > c->txtTotal - offset) return fail(KASA_E_ARG, "kasa_batch_text_fetch_range: beyond the text (%llu bytes)", (unsigned long long)c->txtTotal);
+    if (nBytes && !text) return fail(KASA_E_ARG, "kasa_batch_text_fetch_range: NULL text");
+    HIPCHK(hipSetDevice(c->ix->device));
+    if (nBytes) HIPCHK(hipMemcpyAsync(text, c->txtOut.as<char>() + offset, nBytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return KASA_OK;
 }
@@ -5547,6 +5567,23 @@ extern "C" uint64_t kasa_batch_bytes_per_query(const kasa_ctx *c)
 {
     if (!c) return 0;
     return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)c->recWords() + 8 + 40;
+}
+
+// Room for a batch of about nQueries k-mers out of nBases bases before it arrives: hipMalloc takes 25-90 ms per GB on this
+// platform (the 44 GB of a 10 M-read batch's event records: 1.2-4 s), which a host can spend while it still parses the input.
+// Only sizes: what a batch needs beyond this is allocated when it comes, as always.  Not while a batch is in flight on ctx.
+extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases, int wantPerRead)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->ix->device));
+    const size_t nQ = (size_t)nQueries;
+    int rc;
+    if ((rc = c->bases.reserve((size_t)nBases + 64)) || (rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64)) ||
+        (rc = c->qKmerB.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) || (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)) ||
+        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))
+        return rc;
+    (void)wantPerRead;
+    return KASA_OK;
 }
 
 extern "C" int kasa_ctx_counters(kasa_ctx *c, uint32_t *generalReads, uint32_t *secondPassReads)

@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <chrono>
@@ -30,6 +31,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -211,8 +213,16 @@ static vector<uint64_t> loadFreq(const string &prefix, size_t nTaxa, int kHigh, 
 }
 
 // KASA_HOST_TIMING=1: where the host spends the time of "Time fastq" (seconds, summed over the file)
-struct HostTimers { double read = 0, cut = 0, parse = 0, merge = 0, form = 0, write = 0; std::mutex mu; bool on = getenv("KASA_HOST_TIMING") != nullptr; };
+struct HostTimers { double read = 0, cut = 0, parse = 0, merge = 0, form = 0, write = 0, upload = 0, compute = 0, rank = 0, text = 0, fetch = 0, encode = 0, sort = 0, score = 0; std::mutex mu; bool on = getenv("KASA_HOST_TIMING") != nullptr; };
 static HostTimers g_ht;
+static std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+static void mark(const char *what, uint64_t id = ~0ull)          // KASA_HOST_TIMING: a time line of the file's pipeline
+{
+    if (!g_ht.on) return;
+    const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count();
+    std::lock_guard<std::mutex> lk(g_ht.mu);
+    if (id == ~0ull) fprintf(stderr, "kasa: t=%.3f %s\n", t, what); else fprintf(stderr, "kasa: t=%.3f %s %llu\n", t, what, (unsigned long long)id);
+}
 struct ScopedTimerMt {                               // from several threads: summed under a lock (CPU seconds, not wall time)
     double &acc; std::mutex &mu; std::chrono::steady_clock::time_point t0;
     ScopedTimerMt(double &a, std::mutex &m) : acc(a), mu(m), t0(std::chrono::steady_clock::now()) {}
@@ -224,15 +234,108 @@ struct ScopedTimer {
     ~ScopedTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-struct ReadSet { vector<uint8_t> bases; vector<int64_t> off{0}; vector<string> names; vector<uint32_t> lengths; bool protein = false; };
+// Large host arrays.  Fresh 4 KB pages are touched at 6 GB/s by one core and 17 GB/s by sixteen on the GPU box, huge pages at
+// 17 and 195 GB/s (tools/hostio_probe.cpp), and a std::vector zeroes what it resizes on ONE core: arrays that hold a batch
+// are anonymous mappings with huge pages asked for, never value-initialised, grown in place (mremap), and filled by the
+// threads that parse.
+template <class T> struct HugeVec {
+    T *p = nullptr; size_t n = 0, cap = 0;
+    HugeVec() {}
+    ~HugeVec() { release(); }
+    HugeVec(const HugeVec &) = delete;
+    HugeVec &operator=(const HugeVec &) = delete;
+    HugeVec(HugeVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    HugeVec &operator=(HugeVec &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; } return *this; }
+    static size_t mapBytes(size_t elems) { const size_t g = (size_t)2 << 20; return (elems * sizeof(T) + g - 1) / g * g; }
+    void release() { if (p) ::munmap((void *)p, mapBytes(cap)); p = nullptr; n = cap = 0; }
+    void reserve(size_t want)
+    {
+        if (want <= cap) return;
+        const size_t nb = mapBytes(std::max(want, cap + cap / 2));
+        void *q = p ? ::mremap((void *)p, mapBytes(cap), nb, MREMAP_MAYMOVE) : ::mmap(nullptr, nb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) throw std::bad_alloc();
+        (void)::madvise(q, nb, MADV_HUGEPAGE);
+        p = (T *)q; cap = nb / sizeof(T);
+    }
+    void resize(size_t k) { reserve(k); n = k; }                // (new elements are NOT initialised)
+    void clear() { n = 0; }
+    void push_back(const T &v) { if (n == cap) reserve(n + 1); p[n++] = v; }
+    void append(const T *src, size_t k) { if (n + k > cap) reserve(n + k); std::memcpy((void *)(p + n), (const void *)src, k * sizeof(T)); n += k; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T &back() { return p[n - 1]; }
+};
+
+// memcpy by several threads (a batch's bases are gigabytes)
+static void parCopy(void *dst, const void *src, size_t bytes, unsigned threads)
+{
+    const size_t piece = (size_t)32 << 20;
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, bytes / piece));
+    if (nt <= 1) { if (bytes) std::memcpy(dst, src, bytes); return; }
+    vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([=] { const size_t a = bytes / nt * t, e = t + 1 == nt ? bytes : bytes / nt * (t + 1); std::memcpy((char *)dst + a, (const char *)src + a, e - a); });
+    for (auto &th : pool) th.join();
+}
+
+// The reads of a chunk / batch: bases and specifiers back to back with running offsets (no object per read)
+struct ReadSet {
+    HugeVec<uint8_t> bases; HugeVec<int64_t> off;              // off[nSequences + 1], off[0] = 0
+    HugeVec<char> nameBlob; HugeVec<uint64_t> nameOff;         // specifier of read r = nameBlob[nameOff[r] .. nameOff[r + 1])
+    HugeVec<uint32_t> lengths;                                 // "Length" of read r
+    bool protein = false;
+    ReadSet() { off.push_back(0); nameOff.push_back(0); }
+    ReadSet(ReadSet &&) = default;
+    ReadSet &operator=(ReadSet &&) = default;
+    size_t size() const { return lengths.size(); }
+    size_t nameLen(size_t r) const { return (size_t)(nameOff[r + 1] - nameOff[r]); }
+    std::string_view name(size_t r) const { return std::string_view(nameBlob.data() + nameOff[r], nameLen(r)); }
+    void clear() { bases.clear(); off.clear(); off.push_back(0); nameBlob.clear(); nameOff.clear(); nameOff.push_back(0); lengths.clear(); }
+    // reads [first, last) as a set of their own (spr sequences per read; offsets rebased); `threads` copy the bases
+    ReadSet slice(size_t first, size_t last, size_t spr, unsigned threads) const
+    {
+        ReadSet o;
+        o.protein = protein;
+        const size_t m = last - first;
+        const int64_t s0 = off[first * spr], s1 = off[last * spr];
+        o.bases.resize((size_t)(s1 - s0)); parCopy(o.bases.data(), bases.data() + s0, (size_t)(s1 - s0), threads);
+        o.off.resize(m * spr + 1);
+        for (size_t q = 0; q <= m * spr; ++q) o.off[q] = off[first * spr + q] - s0;
+        const uint64_t n0 = nameOff[first], n1 = nameOff[last];
+        o.nameBlob.resize((size_t)(n1 - n0)); if (n1 > n0) std::memcpy(o.nameBlob.data(), nameBlob.data() + n0, (size_t)(n1 - n0));
+        o.nameOff.resize(m + 1);
+        for (size_t r = 0; r <= m; ++r) o.nameOff[r] = nameOff[first + r] - n0;
+        o.lengths.resize(m); if (m) std::memcpy(o.lengths.data(), lengths.data() + first, m * 4);
+        return o;
+    }
+    // the reads of `q` behind mine (offsets rebased); `threads` copy the bases
+    void appendSet(const ReadSet &q, unsigned threads)
+    {
+        const size_t b0 = bases.size(), n0 = nameBlob.size(), r0 = size(), s0 = off.size() - 1, ns = q.off.size() - 1;
+        bases.resize(b0 + q.bases.size()); parCopy(bases.data() + b0, q.bases.data(), q.bases.size(), threads);
+        nameBlob.append(q.nameBlob.data(), q.nameBlob.size());
+        off.resize(s0 + ns + 1); nameOff.resize(r0 + q.size() + 1); lengths.resize(r0 + q.size());
+        for (size_t i = 0; i < ns; ++i) off[s0 + 1 + i] = (int64_t)b0 + q.off[i + 1];
+        for (size_t r = 0; r < q.size(); ++r) { nameOff[r0 + 1 + r] = n0 + q.nameOff[r + 1]; lengths[r0 + r] = q.lengths[r]; }
+    }
+};
 
 // kASA::detectAlphabet (kASA.hpp:155-183) on the first four characters of the file's second line
 // (Utilities::getFirstSequenceOfFile, Utilities.hpp:137-143)
-static bool detectProtein(const string &data, bool verbose)
+static bool detectProtein(const char *data, size_t size, bool verbose)
 {
-    size_t a = data.find('\n');
+    const char *nl = (const char *)memchr(data, '\n', size);
     string four;
-    if (a != string::npos) { size_t b = data.find('\n', a + 1); if (b == string::npos) b = data.size(); four = data.substr(a + 1, std::min<size_t>(4, b - a - 1)); }
+    if (nl) {
+        const size_t a = (size_t)(nl - data);
+        const char *nl2 = (const char *)memchr(data + a + 1, '\n', size - a - 1);
+        const size_t b = nl2 ? (size_t)(nl2 - data) : size;
+        four.assign(data + a + 1, std::min<size_t>(4, b - a - 1));
+    }
     auto in = [](const string &s, const char *set) { if (s.empty()) return false; for (char c : s) if (!strchr(set, toupper((unsigned char)c)) || c == 0) return false; return true; };
     if (in(four, "ACGTURYKMSWBDHVN-")) { if (verbose) std::cout << "OUT: DNA sequences detected." << std::endl; return false; }
     if (!in(four, "ABCDEFGHIJKLMNOPQRSTUVWXYZ*-"))
@@ -243,28 +346,31 @@ static bool detectProtein(const string &data, bool verbose)
 
 // One run of whole records, data[begin, end) with begin at a header line: what Read.hpp:699-760 hands on, for reads that
 // fit one chunk.  A '\r' stays part of its line, as with the reference's getline.
-static void parseRecords(const string &data, size_t begin, size_t end, bool fasta, ReadSet &rs)
+static void parseRecords(const char *data, size_t begin, size_t end, bool fasta, ReadSet &rs)
 {
     size_t a = begin;
     auto nextLine = [&](size_t &lb, size_t &le) -> bool {          // [lb, le) without the line feed
         if (a >= end) return false;
         lb = a;
-        const void *nl = memchr(data.data() + a, '\n', end - a);
-        le = nl ? (size_t)((const char *)nl - data.data()) : end;
+        const void *nl = memchr(data + a, '\n', end - a);
+        le = nl ? (size_t)((const char *)nl - data) : end;
         a = le + 1;
         return true;
     };
+    // room for what the run can hold at most (address space: untouched pages cost nothing)
+    rs.bases.reserve(rs.bases.size() + (end - begin)); rs.nameBlob.reserve(rs.nameBlob.size() + (end - begin) + 16);
     size_t lb, le;
     bool have = nextLine(lb, le);
     while (have) {
         if (lb == le) { have = nextLine(lb, le); continue; }
-        rs.names.emplace_back(data, lb + 1, le - lb - 1);           // Read.hpp:711-714: header without its first character
-        rs.names.back().push_back(' ');                             // ... plus a trailing space
+        rs.nameBlob.append(data + lb + 1, le - lb - 1);             // Read.hpp:711-714: header without its first character
+        rs.nameBlob.push_back(' ');                                 // ... plus a trailing space
+        rs.nameOff.push_back(rs.nameBlob.size());
         uint32_t nLines = 0; const size_t b0 = rs.bases.size();
         while ((have = nextLine(lb, le))) {
             const bool empty = lb == le;
             if (!empty && data[lb] == (fasta ? '>' : '+')) break;
-            if (!empty) rs.bases.insert(rs.bases.end(), data.begin() + (std::ptrdiff_t)lb, data.begin() + (std::ptrdiff_t)le);
+            if (!empty) rs.bases.append((const uint8_t *)data + lb, le - lb);
             if (!empty || !fasta) ++nLines;
         }
         const size_t len = rs.bases.size() - b0;
@@ -283,29 +389,73 @@ static void parseRecords(const string &data, size_t begin, size_t end, bool fast
 // First record start at or after `from` that is safe to cut at (N1: the input is parsed by several threads).  FASTA: a
 // line starting with '>'.  FASTQ: a line starting with '@' whose third line starts with '+' and whose fourth line is as
 // long as its second -- a quality line that happens to start with '@' fails that test.  npos: none found nearby.
-static size_t findRecordStart(const string &data, size_t from, bool fasta)
+static size_t findRecordStart(const char *data, size_t size, size_t from, bool fasta)
 {
-    const size_t limit = std::min(data.size(), from + (1u << 20));
+    const size_t npos = string::npos;
+    const size_t limit = std::min(size, from + (1u << 20));
     size_t p = from;
     while (p < limit) {
-        const void *nl = memchr(data.data() + p, '\n', limit - p);
-        if (!nl) return string::npos;
-        p = (size_t)((const char *)nl - data.data()) + 1;
-        if (p >= data.size()) return string::npos;
+        const void *nl = memchr(data + p, '\n', limit - p);
+        if (!nl) return npos;
+        p = (size_t)((const char *)nl - data) + 1;
+        if (p >= size) return npos;
         if (fasta) { if (data[p] == '>') return p; continue; }
         if (data[p] != '@') continue;
         size_t l[5]; l[0] = p; bool ok = true;
         for (int i = 1; i < 5 && ok; ++i) {
-            const void *e = memchr(data.data() + l[i - 1], '\n', data.size() - l[i - 1]);
-            if (!e) { ok = (i == 4); l[i] = data.size() + 1; break; }
-            l[i] = (size_t)((const char *)e - data.data()) + 1;
+            const void *e = memchr(data + l[i - 1], '\n', size - l[i - 1]);
+            if (!e) { ok = (i == 4); l[i] = size + 1; break; }
+            l[i] = (size_t)((const char *)e - data) + 1;
         }
-        if (!ok || l[2] >= data.size() || data[l[2]] != '+') continue;
+        if (!ok || l[2] >= size || data[l[2]] != '+') continue;
         if (l[4] - l[3] != l[2] - l[1]) continue;                  // quality as long as the sequence (both with their '\n')
-        if (l[4] < data.size() && data[l[4]] != '@') continue;
+        if (l[4] < size && data[l[4]] != '@') continue;
         return p;
     }
-    return string::npos;
+    return npos;
+}
+
+// A piece of whole records parsed by several threads and put behind the reads `out` holds: the piece is cut into one run per
+// thread at safe record starts, every run is parsed into a set of its own (`parts`: kept by the caller over its pieces, so
+// that their pages are touched once), and the same threads copy the runs to their places in `out`.
+static void parsePiece(const char *data, size_t size, bool fasta, unsigned threads, size_t minRun, ReadSet &out, vector<ReadSet> &parts)
+{
+    if (const char *e = getenv("KASA_PARSE_CHUNK")) minRun = std::max<size_t>(1, (size_t)atoll(e));   // tests force small runs
+    const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, size / minRun));
+    vector<size_t> cut{0};
+    for (size_t c = 1; c < want; ++c) {
+        const size_t p = findRecordStart(data, size, std::max(cut.back(), size / want * c), fasta);
+        if (p != string::npos && p > cut.back()) cut.push_back(p);
+    }
+    cut.push_back(size);
+    const size_t nc = cut.size() - 1;
+    auto inParallel = [&](const std::function<void(size_t)> &fn) {
+        if (nc == 1) { fn(0); return; }
+        vector<std::exception_ptr> err(nc);
+        vector<std::thread> pool;
+        for (size_t c = 0; c < nc; ++c) pool.emplace_back([&, c] { try { fn(c); } catch (...) { err[c] = std::current_exception(); } });
+        for (auto &t : pool) t.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
+    };
+    if (nc == 1 && out.size() == 0 && out.bases.empty()) { ScopedTimer tm(g_ht.parse); parseRecords(data, 0, size, fasta, out); return; }
+    if (parts.size() < nc) parts.resize(nc);
+    { ScopedTimer tm(g_ht.parse); inParallel([&](size_t c) { parts[c].clear(); parseRecords(data, cut[c], cut[c + 1], fasta, parts[c]); }); }
+    ScopedTimer tmMerge(g_ht.merge);
+    // the runs' reads behind the pending ones: places from running sums, copies by the same threads
+    vector<size_t> b0(nc), r0(nc), m0(nc);
+    size_t nb = out.bases.size(), nr = out.size(), nm = out.nameBlob.size();
+    for (size_t c = 0; c < nc; ++c) { b0[c] = nb; r0[c] = nr; m0[c] = nm; nb += parts[c].bases.size(); nr += parts[c].size(); nm += parts[c].nameBlob.size(); }
+    out.bases.resize(nb); out.off.resize(nr + 1); out.nameBlob.resize(nm); out.nameOff.resize(nr + 1); out.lengths.resize(nr);
+    inParallel([&](size_t c) {
+        const ReadSet &q = parts[c];
+        if (!q.bases.empty()) memcpy(out.bases.data() + b0[c], q.bases.data(), q.bases.size());
+        if (!q.nameBlob.empty()) memcpy(out.nameBlob.data() + m0[c], q.nameBlob.data(), q.nameBlob.size());
+        for (size_t r = 0; r < q.size(); ++r) {
+            out.lengths[r0[c] + r] = q.lengths[r];
+            out.off[r0[c] + r + 1] = (int64_t)b0[c] + q.off[r + 1];
+            out.nameOff[r0[c] + r + 1] = m0[c] + q.nameOff[r + 1];
+        }
+    });
 }
 
 static ReadSet readInput(const string &path, bool verbose, unsigned threads)
@@ -321,43 +471,9 @@ static ReadSet readInput(const string &path, bool verbose, unsigned threads)
     if (data.empty()) return rs;
     if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
     const bool fasta = data[0] == '>';
-    rs.protein = detectProtein(data, verbose);
-    // cut the file into one run of records per thread
-    size_t minChunk = 8u << 20;
-    if (const char *e = getenv("KASA_PARSE_CHUNK")) minChunk = std::max<size_t>(1, (size_t)atoll(e));   // tests force small chunks
-    const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, data.size() / minChunk));
-    vector<size_t> cut{0};
-    for (size_t c = 1; c < want; ++c) {
-        const size_t p = findRecordStart(data, std::max(cut.back(), data.size() / want * c), fasta);
-        if (p != string::npos && p > cut.back()) cut.push_back(p);
-    }
-    cut.push_back(data.size());
-    const size_t nc = cut.size() - 1;
-    if (nc == 1) { parseRecords(data, 0, data.size(), fasta, rs); return rs; }
-    vector<ReadSet> part(nc);
-    vector<std::exception_ptr> err(nc);
-    vector<std::thread> pool;
-    for (size_t c = 0; c < nc; ++c)
-        pool.emplace_back([&, c] { try { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); } catch (...) { err[c] = std::current_exception(); } });
-    for (auto &t : pool) t.join();
-    for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
-    size_t nb = 0, nr = 0;
-    for (auto &q : part) { nb += q.bases.size(); nr += q.names.size(); }
-    rs.bases.resize(nb); rs.off.resize(nr + 1); rs.names.resize(nr); rs.lengths.resize(nr);
-    vector<size_t> b0(nc), r0(nc);
-    for (size_t c = 0, b = 0, r = 0; c < nc; ++c) { b0[c] = b; r0[c] = r; b += part[c].bases.size(); r += part[c].names.size(); }
-    pool.clear();
-    for (size_t c = 0; c < nc; ++c)
-        pool.emplace_back([&, c] {
-            ReadSet &q = part[c];
-            if (!q.bases.empty()) memcpy(rs.bases.data() + b0[c], q.bases.data(), q.bases.size());
-            for (size_t r = 0; r < q.names.size(); ++r) {
-                rs.names[r0[c] + r] = std::move(q.names[r]);
-                rs.lengths[r0[c] + r] = q.lengths[r];
-                rs.off[r0[c] + r + 1] = (int64_t)b0[c] + q.off[r + 1];
-            }
-        });
-    for (auto &t : pool) t.join();
+    rs.protein = detectProtein(data.data(), data.size(), verbose);
+    vector<ReadSet> parts;
+    parsePiece(data.data(), data.size(), fasta, threads, 8u << 20, rs, parts);
     return rs;
 }
 
@@ -371,8 +487,11 @@ static ReadSet readInput(const string &path, bool verbose, unsigned threads)
 // boundary; a chunk is parsed by all host threads (parseRecords over runs cut at safe record starts).
 struct ChunkReader {
     gzFile g = nullptr;
-    int fd = -1;                                  // plain (not gzip'ed) input is read with read(2): zlib's pass-through copies at 1 GB/s
-    string carry;
+    int fd = -1;                                  // plain (not gzip'ed) input is read with pread(2): zlib's pass-through copies at 1 GB/s
+    // Two buffers that take turns: the block read behind what the last chunk left over; the chunk handed out stays where it is
+    // while its tail moves to the other buffer.  Their pages are touched once (8 threads pread into a warm buffer at 70 GB/s;
+    // into fresh memory the same call is bound by the page faults).
+    HugeVec<char> buf[2]; int cur = 0; size_t have = 0;
     bool fasta = false, protein = false, eof = false, first = true;
     size_t blockBytes = 256u << 20;
     explicit ChunkReader(const string &path)
@@ -394,8 +513,7 @@ struct ChunkReader {
     long readSome(char *dst, size_t want)
     {
         if (g) return gzread(g, dst, (unsigned)std::min<size_t>(want, 1u << 30));
-        // a plain file: its bytes are copied out of the page cache by several threads at known offsets (one read(2) copies
-        // at memory speed of ONE core; 6 GB took seconds)
+        // a plain file: its bytes are copied out of the page cache by several threads at known offsets
         if (fileSize < 0) { struct stat st; fileSize = (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) ? st.st_size : 0; }
         if (fileSize == 0) return (long)::read(fd, dst, std::min<size_t>(want, 1u << 30));          // a pipe or the like
         want = (size_t)std::min<off_t>((off_t)std::min<size_t>(want, 1u << 30), fileSize - filePos);
@@ -414,90 +532,51 @@ struct ChunkReader {
         filePos += total;
         return total;
     }
-    // next chunk of whole records ("" at the end of the file)
-    bool next(string &chunk, bool verbose)
+    // next chunk of whole records (false at the end of the file); it stays valid until the call after the next one
+    bool next(const char *&chunk, size_t &size, bool verbose)
     {
-        chunk.clear();
+        chunk = nullptr; size = 0;
         while (!eof) {
-            string data = std::move(carry);
-            carry.clear();
-            const size_t had = data.size();
+            HugeVec<char> &D = buf[cur];
             size_t got = 0;
             {
                 ScopedTimer tm(g_ht.read);
-                data.resize(had + blockBytes);
+                D.reserve(have + blockBytes);
                 while (got < blockBytes) {
-                    const long n = readSome(&data[had + got], blockBytes - got);
+                    const long n = readSome(D.data() + have + got, blockBytes - got);
                     if (n <= 0) { eof = true; break; }
                     got += (size_t)n;
                 }
-                data.resize(had + got);
+                have += got;
             }
             ScopedTimer tmCut(g_ht.cut);
-            if (first && !data.empty()) {
-                if (data[0] != '>' && data[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
-                fasta = data[0] == '>';
-                protein = detectProtein(data, verbose);
+            if (first && have > 0) {
+                if (D[0] != '>' && D[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
+                fasta = D[0] == '>';
+                protein = detectProtein(D.data(), have, verbose);
                 first = false;
             }
-            if (eof) { chunk = std::move(data); return !chunk.empty(); }
+            if (eof) break;
             // cut at the last safe record start; what follows waits for the next block
-            size_t cut = string::npos, from = data.size() > (4u << 20) ? data.size() - (4u << 20) : 0;
+            size_t cut = string::npos, from = have > (4u << 20) ? have - (4u << 20) : 0;
             for (;;) {
-                const size_t p = findRecordStart(data, from, fasta);
+                const size_t p = findRecordStart(D.data(), have, from, fasta);
                 if (p == string::npos) break;
                 cut = p; from = p;
             }
-            if (cut == string::npos || cut == 0) { carry = std::move(data); continue; }   // no boundary in sight: keep reading
-            carry.assign(data, cut, string::npos);
-            data.resize(cut);
-            chunk = std::move(data);
+            if (cut == string::npos || cut == 0) continue;          // no boundary in sight: keep reading behind what is there
+            HugeVec<char> &T = buf[cur ^ 1];
+            T.reserve(have - cut + blockBytes);
+            std::memcpy(T.data(), D.data() + cut, have - cut);
+            chunk = D.data(); size = cut;
+            have -= cut; cur ^= 1;
             return true;
         }
-        if (!carry.empty()) { chunk = std::move(carry); carry.clear(); return true; }
+        if (have > 0) { chunk = buf[cur].data(); size = have; have = 0; return true; }
         return false;
     }
 };
 
-// a chunk of whole records parsed by several threads, appended to `out`
-static void parseChunk(const string &data, bool fasta, unsigned threads, ReadSet &out)
-{
-    size_t minRun = 1u << 20;
-    if (const char *e = getenv("KASA_PARSE_CHUNK")) minRun = std::max<size_t>(1, (size_t)atoll(e));   // tests force small runs
-    const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, data.size() / minRun));
-    vector<size_t> cut{0};
-    for (size_t c = 1; c < want; ++c) {
-        const size_t p = findRecordStart(data, std::max(cut.back(), data.size() / want * c), fasta);
-        if (p != string::npos && p > cut.back()) cut.push_back(p);
-    }
-    cut.push_back(data.size());
-    const size_t nc = cut.size() - 1;
-    vector<ReadSet> part(nc);
-    auto inParallel = [&](const std::function<void(size_t)> &fn) {
-        if (nc == 1) { fn(0); return; }
-        vector<std::exception_ptr> err(nc);
-        vector<std::thread> pool;
-        for (size_t c = 0; c < nc; ++c) pool.emplace_back([&, c] { try { fn(c); } catch (...) { err[c] = std::current_exception(); } });
-        for (auto &t : pool) t.join();
-        for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
-    };
-    { ScopedTimer tm(g_ht.parse); inParallel([&](size_t c) { parseRecords(data, cut[c], cut[c + 1], fasta, part[c]); }); }
-    ScopedTimer tmMerge(g_ht.merge);
-    // the runs' reads behind the pending ones: places from running sums, copies by the same threads
-    vector<size_t> b0(nc), r0(nc);
-    size_t nb = out.bases.size(), nr = out.names.size();
-    for (size_t c = 0; c < nc; ++c) { b0[c] = nb; r0[c] = nr; nb += part[c].bases.size(); nr += part[c].names.size(); }
-    out.bases.resize(nb); out.off.resize(nr + 1); out.names.resize(nr); out.lengths.resize(nr);
-    inParallel([&](size_t c) {
-        ReadSet &q = part[c];
-        if (!q.bases.empty()) memcpy(out.bases.data() + b0[c], q.bases.data(), q.bases.size());
-        for (size_t r = 0; r < q.names.size(); ++r) {
-            out.names[r0[c] + r] = std::move(q.names[r]);
-            out.lengths[r0[c] + r] = q.lengths[r];
-            out.off[r0[c] + r + 1] = (int64_t)b0[c] + q.off[r + 1];
-        }
-    });
-}
 
 // ---------------------------------------------------------------------------------------------------
 // one input file (CompareWithLib_partialSort, Compare.hpp:2733-3766) over one or several devices
@@ -571,7 +650,7 @@ struct Writer {
 
     bool lastContaminated = false;   // --filter: the read just written comes within --errorThreshold of the perfect score
     // host ranking of one read from its full row (Compare.hpp:1501-1524)
-    void read(string &o, uint64_t number, const string &name, uint32_t len, const uint32_t *tax, const float *score, uint64_t n)
+    void read(string &o, uint64_t number, std::string_view name, uint32_t len, const uint32_t *tax, const float *score, uint64_t n)
     {
         int64_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
@@ -587,14 +666,14 @@ struct Writer {
     }
     // a read ranked on the device (kasa_batch_rank): its printable hits in order, and the largest k-mer score of all its hits
     struct DeviceHit { uint32_t tax; float score; double rel; };
-    void readRanked(string &o, uint64_t number, const string &name, uint32_t len, const DeviceHit *hits, uint32_t n, float maxV)
+    void readRanked(string &o, uint64_t number, std::string_view name, uint32_t len, const DeviceHit *hits, uint32_t n, float maxV)
     {
         if (res.size() < n) res.resize(n);
         for (uint32_t i = 0; i < n; ++i) res[i] = std::make_tuple((size_t)hits[i].tax, hits[i].score, hits[i].rel);
         print(o, number, name, len, (int64_t)n, maxV);
     }
     // res[0 .. cnt) = the hits in printing order (Compare.hpp:1526-1872)
-    void print(string &o, uint64_t number, const string &name, uint32_t len, int64_t cnt, float maxV)
+    void print(string &o, uint64_t number, std::string_view name, uint32_t len, int64_t cnt, float maxV)
     {
         lastContaminated = false;
         using numtext::dtoa; using numtext::itoa;
@@ -620,7 +699,7 @@ struct Writer {
         float before = 0;
         switch (p.fmt) {
         case Params::Tsv: {
-            string s1, s2, s3, s4; itoa(number, s1); s1 += "\t"; s1 += name + "\t";
+            string s1, s2, s3, s4; itoa(number, s1); s1 += "\t"; s1 += name; s1 += "\t";
             for (int64_t j = 0, i = 0; i < cnt && j < p.beasts; ++i) {
                 const auto &h = res[i];
                 itoa(c.taxids[std::get<0>(h)], s1); s1 += ";"; s2 += c.names[std::get<0>(h)]; s2 += ";";
@@ -883,15 +962,16 @@ struct Batcher {
             // paired-end (Read.hpp:834-1049): mate r of both files forms read r; the two sequences stay separate (no k-mer
             // spans the junction) but score into one row; specifier = both names, length = the sum
             ReadSet r1 = readInput(p.input, p.verbose, p.threads), r2 = readInput(p.input2, false, p.threads);
-            if (r2.names.size() != r1.names.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
+            if (r2.size() != r1.size()) throw std::runtime_error("The paired-end files hold different numbers of reads");
             pending.protein = r1.protein;
-            for (size_t r = 0; r < r1.names.size(); ++r) {
+            for (size_t r = 0; r < r1.size(); ++r) {
                 for (const ReadSet *x : {&r1, &r2}) {
-                    pending.bases.insert(pending.bases.end(), x->bases.begin() + x->off[r], x->bases.begin() + x->off[r + 1]);
+                    pending.bases.append(x->bases.data() + x->off[r], (size_t)(x->off[r + 1] - x->off[r]));
                     pending.off.push_back((int64_t)pending.bases.size());
                     pendSeg.push_back((uint32_t)r);
+                    pending.nameBlob.append(x->nameBlob.data() + x->nameOff[r], x->nameLen(r));
                 }
-                pending.names.push_back(r1.names[r] + r2.names[r]);
+                pending.nameOff.push_back(pending.nameBlob.size());
                 pending.lengths.push_back(r1.lengths[r] + r2.lengths[r]);
             }
             protein = pending.protein;
@@ -909,31 +989,53 @@ struct Batcher {
         }
     }
     size_t seqPerRead() const { return paired ? 2 : 1; }
-    size_t pendingReads() const { return pending.names.size() - pendPos; }
+    size_t pendingReads() const { return pending.size() - pendPos; }
+    vector<ReadSet> parts;                         // the parse threads' runs (kept: their pages are touched once)
     void refill()                                  // parse the next chunk of the file behind the pending reads
     {
         if (!reader) return;
-        if (pendPos > 0 && pendPos == pending.names.size()) { pending = ReadSet(); pendPos = 0; }
-        string chunk;
-        if (!reader->next(chunk, p.verbose)) return;
+        if (pendPos > 0 && pendPos == pending.size()) { pending.clear(); pendPos = 0; }
+        const char *chunk = nullptr; size_t chunkBytes = 0;
+        if (!reader->next(chunk, chunkBytes, p.verbose)) return;
         if (pendPos > 0) {                          // drop what was handed out, keep the rest
-            ReadSet rest;
-            const int64_t b0 = pending.off[pendPos];
-            rest.bases.assign(pending.bases.begin() + b0, pending.bases.end());
-            for (size_t r = pendPos; r < pending.names.size(); ++r) {
-                rest.names.push_back(std::move(pending.names[r])); rest.lengths.push_back(pending.lengths[r]);
-                rest.off.push_back(pending.off[r + 1] - b0);
-            }
+            ReadSet rest = pending.slice(pendPos, pending.size(), 1, p.threads);
             pending = std::move(rest); pendPos = 0;
         }
-        if (pending.names.empty() && reader->fileSize > 0) {
+        if (pending.size() == 0 && reader->fileSize > 0) {
             // room for what is still to come (address space only: untouched pages cost nothing), so that a batch that
             // takes many chunks never moves what it already holds
-            const size_t left = (size_t)(reader->fileSize - std::min(reader->fileSize, reader->filePos)) + chunk.size();
-            pending.bases.reserve(left / 2 + left / 8 + 1024);
-            pending.names.reserve(left / 160 + 16); pending.lengths.reserve(left / 160 + 16); pending.off.reserve(left / 160 + 17);
+            const size_t left = (size_t)(reader->fileSize - std::min(reader->fileSize, reader->filePos)) + chunkBytes;
+            pending.bases.reserve(left / 2 + left / 8 + 1024); pending.nameBlob.reserve(left / 8 + 1024);
+            pending.nameOff.reserve(left / 160 + 17); pending.lengths.reserve(left / 160 + 16); pending.off.reserve(left / 160 + 17);
         }
-        parseChunk(chunk, reader->fasta, p.threads, pending);
+        parsePiece(chunk, chunkBytes, reader->fasta, p.threads, 1u << 20, pending, parts);
+    }
+    // What the first batch will need on the device, from the reads parsed so far and the size of the file: the device buffers
+    // are allocated while the rest of the input is parsed (kasa_ctx_reserve).
+    void estimateFirstBatch(uint64_t &nQueries, uint64_t &nBases) const
+    {
+        nQueries = nBases = 0;
+        const size_t have = pending.size() - pendPos;
+        if (have == 0) return;
+        const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
+        const size_t spr = seqPerRead(), sample = std::min<size_t>(have, 65536);
+        const uint32_t nTaxa = (uint32_t)ixf.content.taxids.size();
+        double bases = 0, cost = 0;
+        for (size_t r = pendPos; r < pendPos + sample; ++r) {
+            if (useRef) cost += (double)kasa_refbatch_read_overhead((int64_t)pending.nameLen(r), nTaxa, p.coherence ? 1 : 0);
+            for (size_t q = 0; q < spr; ++q) {
+                const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
+                bases += (double)l;
+                if (useRef) cost += (double)kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
+            }
+        }
+        bases /= (double)sample; cost /= (double)sample;
+        double reads = (double)have;                                         // reads of the whole input, by the share of the file parsed
+        if (reader && reader->fileSize > 0 && reader->filePos > 0 && !reader->g) reads *= std::max(1.0, (double)reader->fileSize / (double)reader->filePos);
+        if (useRef && cost > 0) reads = std::min(reads, std::max(1.0, ((double)refBudget - 100.0 * 1024 * 1024) / cost));
+        double q = reads * (bases + 8.0 * spr) * strands;
+        if (q > (double)maxKmersPerBatch) { reads *= (double)maxKmersPerBatch / q; q = (double)maxKmersPerBatch; }
+        nQueries = (uint64_t)(q * 1.01); nBases = (uint64_t)(reads * bases * 1.01);
     }
     // the next batch; false at the end of the input
     bool next(Batch &b)
@@ -953,18 +1055,18 @@ struct Batcher {
         // parsed behind them as long as the batch has room, and only then the reads change hands -- in one piece.
         size_t r = pendPos;
         while (!full) {
-            if (r == pending.names.size()) {
-                const size_t before = pending.names.size() - pendPos;
+            if (r == pending.size()) {
+                const size_t before = pending.size() - pendPos;
                 const size_t keep = r - pendPos;
                 refill();                                                   // (may drop the reads before pendPos)
                 r = pendPos + keep;
-                if (pending.names.size() - pendPos == before) break;       // end of the input
+                if (pending.size() - pendPos == before) break;             // end of the input
             }
             ScopedTimer tmForm(g_ht.form);
-            for (; r < pending.names.size(); ++r) {
+            for (; r < pending.size(); ++r) {
                 if (useRef && left <= 100ll * 1024 * 1024 && n > 0) { full = true; break; }                        // Read.hpp:1147
                 uint64_t len = 0;
-                int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.names[r].size(), nTaxa, p.coherence ? 1 : 0) : 0;
+                int64_t cost = useRef ? kasa_refbatch_read_overhead((int64_t)pending.nameLen(r), nTaxa, p.coherence ? 1 : 0) : 0;
                 for (size_t q = 0; q < spr; ++q) {
                     const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
                     len += (uint64_t)l;
@@ -978,17 +1080,12 @@ struct Batcher {
         {
             ScopedTimer tmForm(g_ht.form);
             const size_t first = pendPos, m = r - first;
-            if (m > 0 && first == 0 && r == pending.names.size() && !paired) {
+            if (m > 0 && first == 0 && r == pending.size() && !paired) {
                 b.rs = std::move(pending);                              // everything that is pending: nothing is copied
                 pending = ReadSet(); pendPos = 0;
             } else if (m > 0) {
-                const int64_t s0 = pending.off[first * spr], s1 = pending.off[r * spr];
-                b.rs.bases.assign(pending.bases.begin() + s0, pending.bases.begin() + s1);
-                b.rs.off.resize(m * spr + 1);
-                for (size_t q = 0; q <= m * spr; ++q) b.rs.off[q] = pending.off[first * spr + q] - s0;
+                b.rs = pending.slice(first, r, spr, p.threads);
                 if (paired) { b.segRead.resize(2 * m); for (size_t x = 0; x < m; ++x) b.segRead[2 * x] = b.segRead[2 * x + 1] = (uint32_t)x; }
-                b.rs.names.assign(std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)first), std::make_move_iterator(pending.names.begin() + (std::ptrdiff_t)r));
-                b.rs.lengths.assign(pending.lengths.begin() + (std::ptrdiff_t)first, pending.lengths.begin() + (std::ptrdiff_t)r);
                 pendPos = r;
             }
         }
@@ -1011,16 +1108,23 @@ struct OrderedOut {
     int fd = -1; off_t pos = 0;
     std::mutex mu;
     uint64_t curBatch = 0; size_t curSlab = 0;                  // the next slab to be placed
-    std::map<std::pair<uint64_t, size_t>, string> parked;
+    // a slab: text the formatting thread made (owned), or the piece a device wrote (a view into the buffer it arrived in; `done`
+    // tells the buffer's owner when it may be used again)
+    struct Item { string text; const char *view = nullptr; size_t n = 0; std::shared_ptr<std::promise<void>> done; size_t size() const { return view ? n : text.size(); } };
+    std::map<std::pair<uint64_t, size_t>, Item> parked;
     std::map<uint64_t, size_t> slabsOf;
-    std::condition_variable turn;                               // direct(): a batch waits until everything before it has its place
-    ~OrderedOut() { if (fd >= 0) ::close(fd); }
+    // views are written by ONE thread of their own: new tmpfs pages take 7 GB/s from one writer and 3.5 GB/s from two or
+    // sixteen (tools/hostio_probe.cpp), and the device worker goes on with its next batch meanwhile
+    std::thread writer; std::mutex wmu; std::condition_variable wcv; std::deque<std::pair<off_t, Item>> wq; bool wStop = false; size_t wBusy = 0;
+    std::exception_ptr wErr;
+    bool abandoned = false;                                     // a batch failed: nothing more is placed, nobody waits for a place
+    ~OrderedOut() { stopWriter(); if (fd >= 0) ::close(fd); }
     static void writeAt(int fd, const char *d, size_t n, off_t at)
     {
-        while (n) { const ssize_t w = ::pwrite(fd, d, n, at); if (w <= 0) throw std::runtime_error("Readwise output file could not be written!"); d += w; n -= (size_t)w; at += w; }
+        while (n) { const ssize_t w = ::pwrite(fd, d, std::min<size_t>(n, (size_t)1 << 30), at); if (w <= 0) throw std::runtime_error("Readwise output file could not be written!"); d += w; n -= (size_t)w; at += w; }
     }
     void put(const string &t) { writeAt(fd, t.data(), t.size(), pos); pos += (off_t)t.size(); }   // header / footer (nothing else in flight)
-    void place(vector<std::pair<off_t, string>> &todo)             // mu held: everything that is next in line gets its offset
+    void place(vector<std::pair<off_t, Item>> &todo)               // mu held: everything that is next in line gets its offset
     {
         for (;;) {
             auto sit = slabsOf.find(curBatch);
@@ -1033,52 +1137,85 @@ struct OrderedOut {
             ++curSlab;
         }
     }
+    void writerLoop()
+    {
+        for (;;) {
+            std::pair<off_t, Item> job;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return wStop || !wq.empty(); });
+                if (wq.empty()) return;
+                job = std::move(wq.front()); wq.pop_front(); ++wBusy;
+            }
+            try {
+                ScopedTimerMt tm(g_ht.write, g_ht.mu);
+                writeAt(fd, job.second.view, job.second.n, job.first);
+                job.second.done->set_value();
+            } catch (...) { job.second.done->set_exception(std::current_exception()); std::lock_guard<std::mutex> lk(wmu); if (!wErr) wErr = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(wmu); --wBusy; }
+            wcv.notify_all();
+        }
+    }
+    void dispatch(vector<std::pair<off_t, Item>> &todo)            // (no lock held) owned text: written here; views: handed to the writer
+    {
+        for (auto &w : todo) {
+            if (w.second.view) {
+                std::lock_guard<std::mutex> lk(wmu);
+                if (!writer.joinable()) writer = std::thread([this] { writerLoop(); });
+                wq.push_back(std::move(w));
+                wcv.notify_all();
+            } else { ScopedTimerMt tm(g_ht.write, g_ht.mu); writeAt(fd, w.second.text.data(), w.second.text.size(), w.first); }
+        }
+    }
+    void abandon()                                                 // after a failure: what waits for its place is dropped, its owners are released
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        abandoned = true;
+        for (auto &kv : parked) if (kv.second.done) kv.second.done->set_value();
+        parked.clear();
+    }
+    void drainWriter()                                             // everything handed to the writer is in the file
+    {
+        std::unique_lock<std::mutex> lk(wmu);
+        wcv.wait(lk, [&] { return wq.empty() && wBusy == 0; });
+        if (wErr) { auto e = wErr; wErr = nullptr; std::rethrow_exception(e); }
+    }
+    void stopWriter()
+    {
+        { std::lock_guard<std::mutex> lk(wmu); wStop = true; }
+        wcv.notify_all();
+        if (writer.joinable()) writer.join();
+    }
     void begin(uint64_t batch, size_t nSlabs)
     {
         if (fd < 0) return;
-        vector<std::pair<off_t, string>> todo;
+        vector<std::pair<off_t, Item>> todo;
         { std::lock_guard<std::mutex> lk(mu); slabsOf[batch] = nSlabs; place(todo); }
-        turn.notify_all();
-        for (auto &w : todo) writeAt(fd, w.second.data(), w.second.size(), w.first);
-    }
-    // The whole text of a batch in one piece that the caller keeps (the buffer the device's text arrived in): waits for its
-    // turn, then `threads` threads write it at its place.
-    void direct(uint64_t batch, const char *d, size_t n, unsigned threads)
-    {
-        if (fd < 0) return;
-        vector<std::pair<off_t, string>> todo;
-        off_t at;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            slabsOf[batch] = 1;
-            place(todo);
-            turn.wait(lk, [&] { return curBatch == batch && curSlab == 0; });
-            at = pos; pos += (off_t)n; curSlab = 1;
-            place(todo);
-        }
-        turn.notify_all();
-        for (auto &w : todo) writeAt(fd, w.second.data(), w.second.size(), w.first);
-        ScopedTimerMt tm(g_ht.write, g_ht.mu);
-        const size_t piece = (size_t)8 << 20;
-        const size_t nPieces = (n + piece - 1) / piece;
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nPieces));
-        std::atomic<size_t> next{0};
-        vector<std::exception_ptr> err(nt);
-        auto work = [&](unsigned t) {
-            try { for (;;) { const size_t i = next.fetch_add(1); if (i >= nPieces) break; const size_t a = i * piece; writeAt(fd, d + a, std::min(piece, n - a), at + (off_t)a); } }
-            catch (...) { err[t] = std::current_exception(); }
-        };
-        if (nt == 1) work(0);
-        else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(work, t); for (auto &th : pool) th.join(); }
-        for (auto &e : err) if (e) std::rethrow_exception(e);
+        dispatch(todo);
     }
     void submit(uint64_t batch, size_t slab, string &&t)
     {
         if (fd < 0) return;
-        vector<std::pair<off_t, string>> todo;
-        { std::lock_guard<std::mutex> lk(mu); parked.emplace(std::make_pair(batch, slab), std::move(t)); place(todo); }
-        turn.notify_all();
-        for (auto &w : todo) { ScopedTimerMt tm(g_ht.write, g_ht.mu); writeAt(fd, w.second.data(), w.second.size(), w.first); }
+        vector<std::pair<off_t, Item>> todo;
+        { std::lock_guard<std::mutex> lk(mu); Item it; it.text = std::move(t); parked.emplace(std::make_pair(batch, slab), std::move(it)); place(todo); }
+        dispatch(todo);
+    }
+    // A slab that the caller keeps (the buffer a piece of the device's text arrived in) until the returned future is ready.
+    std::future<void> view(uint64_t batch, size_t slab, const char *d, size_t n)
+    {
+        auto done = std::make_shared<std::promise<void>>();
+        std::future<void> f = done->get_future();
+        if (fd < 0) { done->set_value(); return f; }
+        vector<std::pair<off_t, Item>> todo;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (abandoned) { done->set_value(); return f; }
+            Item it; it.view = d; it.n = n; it.done = done;
+            parked.emplace(std::make_pair(batch, slab), std::move(it));
+            place(todo);
+        }
+        dispatch(todo);
+        return f;
     }
 };
 
@@ -1088,20 +1225,32 @@ struct OrderedOut {
 struct WorkerBuffers {
     PcieBuf<uint32_t> meta; PcieBuf<Writer::DeviceHit> hits;
     PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
-    PcieBuf<char> text; PcieBuf<uint8_t> flags; PcieBuf<char> names; PcieBuf<uint64_t> nameOff;   // the device's text (kasa_batch_text)
+    // the device's text (kasa_batch_text) comes through a few small page-locked buffers (making one of 5.5 GB takes seconds):
+    // the writer thread empties one while the next pieces arrive
+    static constexpr unsigned TEXT_SLOTS = 4;
+    PcieBuf<char> text[TEXT_SLOTS]; std::future<void> written[TEXT_SLOTS]; unsigned turn = 0;
+    size_t pieceBytes = (size_t)64 << 20;
+    PcieBuf<uint8_t> flags;
+    ~WorkerBuffers() { for (auto &f : written) if (f.valid()) f.wait(); }      // the writer still reads the buffers
 };
 
 static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb, OrderedOut &out)
 {
     const auto tDev = std::chrono::steady_clock::now();
     auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    const uint64_t nr = b.rs.names.size();
-    if (b.segRead.empty()) { if (kasa_batch_upload(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)nr)) throwLast(); }
-    else if (kasa_batch_upload_segments(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)b.segRead.size(), b.segRead.data(), (int64_t)nr)) throwLast();
+    const uint64_t nr = b.rs.size();
+    {
+        ScopedTimerMt tm(g_ht.upload, g_ht.mu);
+        if (b.segRead.empty()) { if (kasa_batch_upload(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)nr)) throwLast(); }
+        else if (kasa_batch_upload_segments(ctx, b.rs.bases.data(), b.rs.off.data(), (int64_t)b.segRead.size(), b.segRead.data(), (int64_t)nr)) throwLast();
+    }
     uint64_t nk = 0;
-    if (kasa_batch_encode(ctx, &nk)) throwLast();
-    if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast();
-    if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast();
+    {
+        ScopedTimerMt tm(g_ht.compute, g_ht.mu);
+        { ScopedTimerMt t2(g_ht.encode, g_ht.mu); if (kasa_batch_encode(ctx, &nk)) throwLast(); }
+        { ScopedTimerMt t2(g_ht.sort, g_ht.mu); if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast(); }
+        { ScopedTimerMt t2(g_ht.score, g_ht.mu); if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast(); }
+    }
     b.kmers = nk;
     if (!wantRows) { tDevice += secondsSince(tDev); out.begin(b.id, 0); return; }
     vector<float> coherence;                                     // --coherence (Compare::postProcess, Compare.hpp:3317-3321)
@@ -1120,7 +1269,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     bool deviceRank = nr > 0 && !p.hostRank;
     if (deviceRank) {
         std::map<uint32_t, uint32_t> classOf;
-        for (uint64_t r = 0; r < nr; ++r) classOf.emplace(b.rs.lengths[r], 0u);
+        { uint32_t last = ~0u; for (uint64_t r = 0; r < nr; ++r) if (b.rs.lengths[r] != last) { last = b.rs.lengths[r]; classOf.emplace(last, 0u); } }   // (runs of equal lengths: one lookup)
         const size_t nT = ixf.content.names.size();
         if (classOf.size() * nT > (size_t)4000000) deviceRank = false;
         else {
@@ -1133,42 +1282,41 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 ++ci;
             }
             vector<uint32_t> rclass(nr);
-            for (uint64_t r = 0; r < nr; ++r) rclass[r] = classOf[b.rs.lengths[r]];
+            { uint32_t last = ~0u, cls = 0; for (uint64_t r = 0; r < nr; ++r) { if (b.rs.lengths[r] != last) { last = b.rs.lengths[r]; cls = classOf[last]; } rclass[r] = cls; } }
             uint64_t nEntries = 0;
-            if (kasa_batch_rank(ctx, den.data(), (uint32_t)classOf.size(), rclass.data(), p.threshold, (uint32_t)std::max(0, p.beasts), &nEntries, &nFlagged)) throwLast();
+            { ScopedTimerMt tm(g_ht.rank, g_ht.mu); if (kasa_batch_rank(ctx, den.data(), (uint32_t)classOf.size(), rclass.data(), p.threshold, (uint32_t)std::max(0, p.beasts), &nEntries, &nFlagged)) throwLast(); }
             if (nFlagged == 0 && !p.hostText) {
                 // The text is written on the device (kasa_batch_text): neither the hits nor the rows cross PCIe, the buffer
                 // that comes back is the file's next piece.  The host adds what only it knows: the specifiers and, per read
                 // length, the perfect score.
                 vector<float> best(classOf.size());
                 for (auto &kv : classOf) best[kv.second] = bestScore(kv.first, p);
-                wb.nameOff.resize(nr + 1);
-                uint64_t *no = wb.nameOff.data();
-                no[0] = 0;
-                for (uint64_t r = 0; r < nr; ++r) no[r + 1] = no[r] + b.rs.names[r].size();
-                wb.names.resize(std::max<uint64_t>(1, no[nr]));
-                {
-                    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, nr / 65536 + 1));
-                    auto copy = [&](unsigned t) { for (uint64_t r = nr * t / nt, e = nr * (t + 1) / nt; r < e; ++r) std::memcpy(wb.names.data() + no[r], b.rs.names[r].data(), b.rs.names[r].size()); };
-                    if (nt == 1) copy(0);
-                    else { vector<std::thread> pool; for (unsigned t = 0; t < nt; ++t) pool.emplace_back(copy, t); for (auto &th : pool) th.join(); }
-                }
                 kasa_text_params tp{};
                 tp.format = p.fmt == Params::Tsv ? KASA_TEXT_TSV : p.fmt == Params::Json ? KASA_TEXT_JSON : p.fmt == Params::JsonL ? KASA_TEXT_JSONL : KASA_TEXT_KRAKEN;
                 tp.beasts = (uint32_t)std::max(0, p.beasts); tp.firstRead = b.firstRead;
-                tp.readNames = wb.names.data(); tp.readNameOff = no; tp.readLen = b.rs.lengths.data();
+                tp.readNames = b.rs.nameBlob.data(); tp.readNameOff = b.rs.nameOff.data(); tp.readLen = b.rs.lengths.data();
                 tp.bestScore = best.data(); tp.nClasses = (uint32_t)best.size();
                 tp.coherence = p.coherence ? 1 : 0; tp.errorThreshold = (double)p.errorThreshold; tp.coherenceThreshold = p.coherenceThreshold;
                 uint64_t nBytes = 0;
-                if (kasa_batch_text(ctx, &tp, &nBytes)) throwLast();
-                wb.text.resize(std::max<uint64_t>(1, nBytes)); wb.flags.resize(nr);
-                if (kasa_batch_text_fetch(ctx, wb.text.data(), nullptr, p.filter ? wb.flags.data() : nullptr)) throwLast();
+                { ScopedTimerMt tm(g_ht.text, g_ht.mu); if (kasa_batch_text(ctx, &tp, &nBytes)) throwLast(); }
+                if (const char *e = getenv("KASA_TEXT_PIECE")) wb.pieceBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small pieces
+                wb.flags.resize(nr);
+                if (p.filter && kasa_batch_text_fetch(ctx, nullptr, nullptr, wb.flags.data())) throwLast();
+                const size_t nPieces = (size_t)((nBytes + wb.pieceBytes - 1) / wb.pieceBytes);
+                out.begin(b.id, nPieces);
                 b.flaggedByDevice = 0;
-                tDevice += secondsSince(tDev);
-                const auto tTxt = std::chrono::steady_clock::now();
-                out.direct(b.id, wb.text.data(), (size_t)nBytes, std::max(1u, std::min(p.threads, 16u)));
+                for (size_t i = 0; i < nPieces; ++i) {
+                    const unsigned slot = wb.turn++ % WorkerBuffers::TEXT_SLOTS;
+                    const auto tTxt = std::chrono::steady_clock::now();
+                    if (wb.written[slot].valid()) wb.written[slot].get();     // (the piece that was here is in the file)
+                    tText += secondsSince(tTxt);
+                    const uint64_t at = (uint64_t)i * wb.pieceBytes, len = std::min<uint64_t>(wb.pieceBytes, nBytes - at);
+                    if (wb.text[slot].capacity < wb.pieceBytes) wb.text[slot].resize(wb.pieceBytes);
+                    { ScopedTimerMt tm(g_ht.fetch, g_ht.mu); if (kasa_batch_text_fetch_range(ctx, wb.text[slot].data(), at, len)) throwLast(); }
+                    wb.written[slot] = out.view(b.id, i, wb.text[slot].data(), (size_t)len);
+                }
                 if (p.filter) for (uint64_t r = 0; r < nr; ++r) if (wb.flags.data()[r]) b.flagged.push_back(b.firstRead + r);
-                tText += secondsSince(tTxt);
+                tDevice += secondsSince(tDev);
                 return;
             }
             meta.resize(nr * 4); hits.resize(nEntries);
@@ -1205,9 +1353,9 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                     if (p.coherence) w.coherence = coherence[r];
                     if (deviceRank && !(meta[4 * r + 1] >> 31)) {
                         float maxV; std::memcpy(&maxV, &meta[4 * r + 2], 4);
-                        w.readRanked(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], hits.data() + meta[4 * r], meta[4 * r + 1], maxV);
+                        w.readRanked(text, b.firstRead + r, b.rs.name(r), b.rs.lengths[r], hits.data() + meta[4 * r], meta[4 * r + 1], maxV);
                     } else
-                        w.read(text, b.firstRead + r, b.rs.names[r], b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
+                        w.read(text, b.firstRead + r, b.rs.name(r), b.rs.lengths[r], tx.data() + ro[r], sc.data() + ro[r], ro[r + 1] - ro[r]);
                     if (p.filter && w.lastContaminated) flagged[sidx].push_back(b.firstRead + r);
                 }
                 out.submit(b.id, (size_t)sidx, std::move(text));
@@ -1229,6 +1377,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
 {
     p.input = input; p.input2 = input2; p.rtt = rtt; p.profile = profile;
     const auto tStart = std::chrono::steady_clock::now();
+    g_t0 = tStart; mark("file begins");
     const bool wantRows = !p.rtt.empty() || p.filter;
     const size_t nDev = devSlots.size();
     vector<kasa_ctx *> ctx(nDev, nullptr);
@@ -1244,7 +1393,9 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         if (per) maxKmersPerBatch = std::max<uint64_t>(1u << 20, std::min<uint64_t>(maxKmersPerBatch, (uint64_t)(0.8 * (double)freeB) / per));
         if (const char *e = getenv("KASA_MAX_BATCH_KMERS")) maxKmersPerBatch = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: force several batches
     }
+    mark("contexts made");
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
+    mark("first chunk parsed");
     p.protein = batcher.protein;
     for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
     if (wantRows && !p.hostRank && !p.hostText) {                     // what the device prints for a taxon (kasa_batch_text)
@@ -1252,6 +1403,15 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         string blob;
         for (size_t t = 0; t < ixf.content.names.size(); ++t) { blob += ixf.content.names[t]; off[t + 1] = blob.size(); }
         for (auto *c : ctx) if (kasa_ctx_set_taxa_text(c, ixf.content.taxids.data(), blob.data(), off.data())) throwLast();
+    }
+    // the device buffers of the first batch are allocated while the input is parsed (hipMalloc: 25-90 ms per GB here)
+    std::thread reserver;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joinReserver{reserver};
+    {
+        uint64_t estQ = 0, estB = 0;
+        batcher.estimateFirstBatch(estQ, estB);
+        if (estQ > 0 && !getenv("KASA_NO_RESERVE"))
+            reserver = std::thread([&ctx, estQ, estB, wantRows] { for (auto *c : ctx) (void)kasa_ctx_reserve(c, estQ, estB, wantRows ? 1 : 0); });   // (a failure shows when the batch allocates)
     }
     OrderedOut out;
     if (!p.rtt.empty()) {
@@ -1273,8 +1433,8 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     vector<double> tDevice(nDev, 0.0), tText(nDev, 0.0);
     std::atomic<uint64_t> totalKmers{0};
     auto worker = [&](size_t d) {
+        WorkerBuffers wb;
         try {
-            WorkerBuffers wb;
             for (;;) {
                 std::unique_ptr<Batch> b;
                 {
@@ -1284,7 +1444,9 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
                     b = std::move(todo.front()); todo.pop_front();
                     cvSpace.notify_all();
                 }
+                mark("device takes batch", b->id);
                 runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d], wb, out);
+                mark("device done with batch", b->id);
                 totalKmers += b->kmers;
                 b->rs = ReadSet();                                   // the reads are done with
                 std::lock_guard<std::mutex> lk(mu);
@@ -1294,6 +1456,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         } catch (...) {
             std::lock_guard<std::mutex> lk(mu);
             if (!failure) failure = std::current_exception();       // like Compare.hpp:1060-1067: parked, rethrown by the driver thread
+            out.abandon();
             cvDone.notify_all(); cvSpace.notify_all(); cvWork.notify_all();
         }
     };
@@ -1322,8 +1485,10 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         for (;;) {
             std::unique_ptr<Batch> b(new Batch());
             if (!batcher.next(*b)) break;
-            if (p.verbose) std::cout << "OUT: Batch of " << b->rs.names.size() << " reads" << std::endl;
+            if (p.verbose) std::cout << "OUT: Batch of " << b->rs.size() << " reads" << std::endl;
             ++nBatches;
+            mark("batch formed", b->id);
+            if (reserver.joinable()) { reserver.join(); mark("device buffers reserved"); }
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cvSpace.wait(lk, [&] { return todo.size() < nDev || failure; });
@@ -1342,7 +1507,8 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     for (auto &t : pool) t.join();
     if (failure) std::rethrow_exception(failure);
     const uint64_t nReads = batcher.nextRead;
-    if (!p.rtt.empty()) { if (p.fmt == Params::Json) out.put("\n]"); ::close(out.fd); out.fd = -1; }
+    mark("workers joined");
+    if (!p.rtt.empty()) { out.drainWriter(); out.stopWriter(); mark("writer drained"); if (p.fmt == Params::Json) out.put("\n]"); ::close(out.fd); out.fd = -1; }
     if (p.filter) filterReads(p, contaminants);
     // profile: one RCCL all-reduce over the devices' tables, then device 0's copy
     if (nDev > 1 || getenv("KASA_FORCE_ALLREDUCE")) {        // (the variable: tests run the reduce with a single rank)
@@ -1360,9 +1526,17 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     vector<double> all((size_t)nK * ixf.content.names.size()); vector<uint64_t> uniq(all.size()), tot(all.size());
     if (kasa_profile_fetch(ctx[0], all.data(), uniq.data(), tot.data())) throwLast();
     if (!p.profile.empty()) writeProfile(p.profile, p, ixf.content, all, uniq, tot, ixf.freqAll, totalKmers.load(), nReads);
+    mark("profile written");
     if (p.verbose && g_ht.on)
         std::cout << "OUT: host timing: read " << g_ht.read << " s, cut " << g_ht.cut << " s, parse " << g_ht.parse << " s, merge " << g_ht.merge
-                  << " s, batch forming " << g_ht.form << " s, output write " << g_ht.write << " s" << std::endl;
+                  << " s, batch forming " << g_ht.form << " s, output write " << g_ht.write << " s; upload " << g_ht.upload << " s, device " << g_ht.compute
+                  << " s (encode " << g_ht.encode << ", sort " << g_ht.sort << ", lookup + score " << g_ht.score << "), ranking " << g_ht.rank << " s, text " << g_ht.text << " s, text fetch " << g_ht.fetch << " s" << std::endl;
+    if (p.verbose && g_ht.on) {
+        std::cout << "OUT: device stages (HIP events, ms):";
+        const char *nm[] = {"encode", "sort", "lookup", "group", "regroup", "score"};
+        for (int st = 0; st < 6; ++st) { double ms = 0; uint64_t n = 0; if (!kasa_ctx_stage_ms(ctx[0], st, &ms, &n)) std::cout << " " << nm[st] << " " << ms; }
+        std::cout << std::endl;
+    }
     if (p.verbose) {
         double ident = 0; for (size_t t = 1; t < ixf.content.names.size(); ++t) ident += all[(size_t)(nK - 1) * ixf.content.names.size() + t];
         double dev = 0, txt = 0; for (size_t d = 0; d < nDev; ++d) { dev = std::max(dev, tDevice[d]); txt = std::max(txt, tText[d]); }
@@ -1400,6 +1574,31 @@ static int run(int argc, char **argv)
     std::cout << "OUT: kasa_identify (MI355X path of kASA identify)\nOUT: ";
     for (auto &s : a) std::cout << s << " ";
     std::cout << std::endl;
+    if (argc >= 4 && a[1] == "parse-dump") {                     // test tap: what the parsers make of a file (no device involved)
+        const unsigned nt = (unsigned)std::stoul(a[3]);
+        auto dump = [](const ReadSet &rs, size_t from) {
+            for (size_t r = from; r < rs.size(); ++r) {
+                std::cout << rs.name(r) << "\t" << rs.lengths[r] << "\t";
+                std::cout.write((const char *)rs.bases.data() + rs.off[r], rs.off[r + 1] - rs.off[r]);
+                std::cout << "\n";
+            }
+        };
+        const bool quiet = argc >= 5 && a[4] == "quiet";         // timing only
+        if (!quiet) {
+            std::cout << "== whole file\n";
+            ReadSet rs = readInput(a[2], false, nt); std::cout << "protein=" << rs.protein << "\n"; dump(rs, 0);
+            std::cout << "== streamed\n";
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        ChunkReader cr(a[2]);
+        const char *chunk; size_t chunkBytes; ReadSet all; vector<ReadSet> parts;
+        while (cr.next(chunk, chunkBytes, false)) parsePiece(chunk, chunkBytes, cr.fasta, nt, 1u << 20, all, parts);
+        std::cout << "protein=" << cr.protein << " fasta=" << cr.fasta << "\n";
+        if (!quiet) dump(all, 0);
+        else std::cout << all.size() << " reads, " << all.bases.size() << " bases in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s; read " << g_ht.read
+                       << " cut " << g_ht.cut << " parse " << g_ht.parse << " merge " << g_ht.merge << "\n";
+        return 0;
+    }
     if (argc < 2 || (a[1] != "identify" && a[1] != "identify_multiple")) throw std::runtime_error("only the modes `identify` and `identify_multiple` are available on this path");
     Params p;
     p.mode = a[1];

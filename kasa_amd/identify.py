@@ -102,7 +102,8 @@ class Identify:
                     distinct = np.unique(np.asarray(part.lengths))
                     best = np.array([report.best_score(int(L), self.k_high, self.k_low, self.frames, protein) for L in distinct], dtype=np.float32)
                     text, _, cont = self.ctx.text(self.fmt, self.beasts, self.n_reads, part.names, part.lengths, best, coherence=coh is not None,
-                                                  error_threshold=self.error_threshold, coherence_threshold=self.coherence_threshold)
+                                                  error_threshold=self.error_threshold, coherence_threshold=self.coherence_threshold,
+                                                  pieces=1 + self.device_text_batches % 3)
                     out.append(text.decode("latin-1"))
                     self.contaminants.extend(int(self.n_reads + r) for r in np.flatnonzero(cont))
                     self.device_text_batches += 1

@@ -103,8 +103,12 @@ def test_cpp_host_parallel_parser_and_writer(infile, stem, tmp_path):
     out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
     cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile),
            "-q", out, "-p", prof, "--jsonl", "-b", "100", "-n", "4"]
-    env = dict(os.environ, KASA_PARSE_CHUNK="700")
+    # (and the device's text fetched through page-locked buffers of 1000 bytes that take turns)
+    env = dict(os.environ, KASA_PARSE_CHUNK="700", KASA_TEXT_PIECE="1000")
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == _read(os.path.join(d, "out_" + stem))
+    r = subprocess.run(cmd + ["--host-text"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert _read(out) == _read(os.path.join(d, "out_" + stem))
     assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
@@ -154,7 +158,7 @@ def test_cpp_host_several_batches(tmp_path):
     cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
            "-q", out, "-p", prof, "--jsonl", "-b", "100"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
-                       env=dict(os.environ, KASA_MAX_BATCH_KMERS="1500"))
+                       env=dict(os.environ, KASA_MAX_BATCH_KMERS="1500", KASA_TEXT_PIECE="3000"))
     assert r.returncode == 0, r.stderr
     assert _read(prof) == _read(os.path.join(d, "prof_b100.csv"))
     strip = lambda t: re.sub(r'"(k-mer Score|Relative Score|Error)": [-0-9.e+infa]+', r'"\1": x', t)

@@ -14,6 +14,7 @@ g = synth.genomes(1400, 300_000, seed=11)
 ix = synth.index_from_genomes(g)
 reads = synth.reads_from_genomes(g, n, 150, seed=1000)
 os.environ["KASA_HOST_TIMING"] = "1"
+os.environ["KASA_ALLOC_TIMING"] = "1"
 for m in mems:
     a = A(); a.read_len = 150; a.f2f_memory = m
     # bench.file_to_file prints nothing of the child's output: run the same command here to see the host timing line
@@ -33,12 +34,13 @@ for m in mems:
         rec[:, 14 + 2 * L] = 10
         open(os.path.join(d, "reads.fastq"), "wb").write(rec.tobytes())
         del rec
-        for threads in ([] if m != mems[0] else [["-n", "16"]]) + [[]]:
+        nlist = os.environ.get("F2F_THREADS", "")
+        for threads in ([["-n", x] for x in nlist.split(",")] if nlist else ([] if m != mems[0] else [["-n", "16"]]) + [[]]):
             cmd = [build.build_host(), "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
                    "-q", os.path.join(d, "out.jsonl"), "-p", os.path.join(d, "prof.csv"), "--jsonl", "-v", "-m", str(m)] + threads
             t0 = time.perf_counter()
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             print("== -m", m, " ".join(threads), "wall %.2f s" % (time.perf_counter() - t0))
-            print("\n".join(l for l in r.stdout.splitlines() if l.startswith("OUT: Time") or "host timing" in l or l.startswith("ERROR")), flush=True)
+            print("\n".join(l for l in r.stdout.splitlines() if l.startswith("OUT: Time") or "host timing" in l or "device stages" in l or l.startswith("ERROR") or (l.startswith("kasa:") and not os.environ.get("F2F_QUIET"))), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
