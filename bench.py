@@ -370,25 +370,34 @@ def file_to_file(args, ix, reads, device, memories=None):
                    "-q", os.path.join(d, "out.jsonl"), "-p", os.path.join(d, "prof.csv"), "--jsonl", "-v", "-m", str(mem),
                    "--device", str(device)]
             t0 = time.perf_counter()
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1200,
+                               env=dict(os.environ, KASA_ALLOC_TIMING="1"))
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stdout[-400:]}
             t = {}
+            slow_alloc = 0.0                                       # hipMalloc calls of more than 20 ms (the library reports them)
             for line in r.stdout.splitlines():
                 for key in ("Time fastq", "Time compare", "Time output", "Time file"):
                     if line.startswith("OUT: " + key + ":"):
                         t[key] = float(line.split(":")[2].split()[0])
+                if line.startswith("kasa: hipMalloc("):
+                    slow_alloc += float(line.split(" took ")[1].split()[0])
             n_batches = sum(1 for line in r.stdout.splitlines() if line.startswith("OUT: Batch of "))
             return {"file_to_file_reads_per_s": reads.n / t["Time file"] if t.get("Time file") else None,
                     "file_to_file_s": t.get("Time file"), "parse_s": t.get("Time fastq"), "device_s": t.get("Time compare"),
-                    "text_s": t.get("Time output"), "child_wall_s_incl_index_load": wall, "batches": n_batches, "memory_gib": mem,
+                    "text_s": t.get("Time output"), "slow_hipmalloc_s": round(slow_alloc, 3), "child_wall_s_incl_index_load": wall, "batches": n_batches, "memory_gib": mem,
                     "input_bytes": os.path.getsize(fq), "output_bytes": os.path.getsize(os.path.join(d, "out.jsonl"))}
         # the pipelined run (-m small enough for several batches: parse, device and text overlap) is the headline of this leg;
         # the one-batch run (-m large: what the reference does when everything fits its budget) is reported beside it
         mems = memories or [args.f2f_memory, args.f2f_memory_one_batch]
+        # (hipMalloc on this platform takes 0-90 ms per GB depending on what other processes have just freed -- the driver
+        # clears released VRAM in the background -- so each child starts after the device has been left alone for a while,
+        # and what the library saw of it is reported as slow_hipmalloc_s: part of device_s and of the file time)
+        time.sleep(args.f2f_settle)
         out = one(mems[0])
         if len(mems) > 1 and "error" not in out:
+            time.sleep(args.f2f_settle)
             out["one_batch"] = one(mems[1])
         out["command"] = ("kasa_identify identify --jsonl -m <GiB> -v (FASTQ and index in %s; inputs written in %.1f s; rate = reads / the "
                           "driver's own 'Time file', index load excluded)" % (base or "tmp", t_files))
@@ -523,6 +532,7 @@ def main():
     ap.add_argument("--wide", action="store_true",
                     help="BASELINE.json configs[2] as the only measurement: 128-bit index, -k 25 7")
     ap.add_argument("--secondary", action="store_true", help="(the default at N = 1; kept for older command lines)")
+    ap.add_argument("--f2f-settle", type=float, default=8.0, help="seconds the device is left alone before each file-to-file child (VRAM released by the previous process is cleared in the background)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="do not run configs[2] (128-bit index, -k 25 7, same reads) after the headline measurement")
     ap.add_argument("--debug-flags", type=int, default=0, help="kasa_ctx_debug bits for A/B runs of one kernel choice against another (0 = the product path)")
