@@ -4889,6 +4889,9 @@ extern "C" int kasa_batch_text(kasa_ctx *c, const kasa_text_params *tp, uint64_t
     const uint32_t nReads = (uint32_t)c->nReads;
     *nBytes = 0; c->txtTotal = 0; c->txtValid = false;
     if (nReads == 0) { c->txtValid = true; return KASA_OK; }
+    if (tp->readNameOff[0] != 0) return fail(KASA_E_ARG, "kasa_batch_text: readNameOff does not start at 0");
+    for (uint32_t r = 0; r < nReads; ++r)
+        if (tp->readNameOff[r + 1] < tp->readNameOff[r]) return fail(KASA_E_ARG, "kasa_batch_text: readNameOff descends at read %u", r);
     const uint64_t nameBytes = tp->readNameOff[nReads];
     if (nameBytes && !tp->readNames) return fail(KASA_E_ARG, "kasa_batch_text: NULL readNames");
     int rc;

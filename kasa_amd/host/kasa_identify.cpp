@@ -1302,7 +1302,7 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 if (const char *e = getenv("KASA_TEXT_PIECE")) wb.pieceBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small pieces
                 wb.flags.resize(nr);
                 if (p.filter && kasa_batch_text_fetch(ctx, nullptr, nullptr, wb.flags.data())) throwLast();
-                const size_t nPieces = (size_t)((nBytes + wb.pieceBytes - 1) / wb.pieceBytes);
+                const size_t nPieces = out.fd < 0 ? 0 : (size_t)((nBytes + wb.pieceBytes - 1) / wb.pieceBytes);   // (--filter without -q: only the flags)
                 out.begin(b.id, nPieces);
                 b.flaggedByDevice = 0;
                 for (size_t i = 0; i < nPieces; ++i) {

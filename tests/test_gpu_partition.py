@@ -219,7 +219,7 @@ def test_bench_default_line_carries_every_leg(tmp_path):
     """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), the PCIe-inclusive and the
     file-to-file rates, the CPU baseline with its one-thread rate -- all in the one JSON line."""
     out = _bench(["--steps", "1", "--warmup", "1", "--reads", "30000", "--taxa", "8", "--genome-len", "20000",
-                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000"], share=False)
+                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000", "--f2f-settle", "0"], share=False)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["dtype"] == "u64"
     assert out["secondary"]["dtype"] == "u128" and out["secondary"]["value"] > 0
     e = out["e2e"]
