@@ -51,9 +51,11 @@ measured = (
     "same k-mer frequency, so a third of the reads have tied third-best hits and take the `std::sort`-order kernel). The whole CSR into pageable memory: "
     f"{e['csr_download_s_per_batch']:.2f} s.\n\n"
     f"File to file (`kasa_identify identify --jsonl`, 10 M reads = {e['input_bytes'] / 1e9:.2f} GB of FASTQ in, {e['output_bytes'] / 1e9:.2f} GB of JSON lines out, both in `/dev/shm`, "
-    f"host threads = the box's cgroup quota): **{e['file_to_file_reads_per_s'] / 1e6:.2f} M reads/s** with `-m {e['memory_gib']}` ({e['batches']} batches: parse {e['parse_s']:.2f} s, "
-    f"device {e['device_s']:.2f} s, text {e['text_s']:.2f} s overlap; file {e['file_to_file_s']:.2f} s), {ob.get('file_to_file_reads_per_s', 0) / 1e6:.2f} M reads/s as one batch "
-    f"(`-m {ob.get('memory_gib', 0)}`: {ob.get('parse_s', 0):.2f} + {ob.get('device_s', 0):.2f} + {ob.get('text_s', 0):.2f} s one after the other; round 2: 1.4 M on 20 M reads). "
+    f"host threads = the box's cgroup quota; the text is written on the device and leaves through one writer thread): **{e['file_to_file_reads_per_s'] / 1e6:.2f} M reads/s** with `-m {e['memory_gib']}` "
+    f"({e['batches']} batches in a pipeline: parse {e['parse_s']:.2f} s, device incl. ranking, text and its download {e['device_s']:.2f} s of which {e['text_s']:.2f} s waiting for the writer; "
+    f"file {e['file_to_file_s']:.2f} s; hipMalloc calls over 20 ms: {e.get('slow_hipmalloc_s', 0):.2f} s), {ob.get('file_to_file_reads_per_s', 0) / 1e6:.2f} M reads/s as one batch "
+    f"(`-m {ob.get('memory_gib', 0)}`: parse {ob.get('parse_s', 0):.2f} s, device {ob.get('device_s', 0):.2f} s, file {ob.get('file_to_file_s', 0):.2f} s, slow hipMalloc {ob.get('slow_hipmalloc_s', 0):.2f} s; "
+    "start of round 3: 3.3 M / 2.5 M with the text formatted by 16 host threads; round 2: 1.4 M on 20 M reads). "
     "The reference binary itself ran at 35 k reads/s with `-n 8` on the calibration box (`profiles/cpu_calibration.json`).\n\n"
     f"CPU baseline (`cpu_baseline`, kind `port`): {cb['value'] / 1e3:.0f} k reads/s with {cb['threads']} threads, {cb['single_thread_value'] / 1e3:.1f} k with one "
     f"({cb['speedup_over_1']:.1f} ×) on {cb['cpu']}: the box shows {cb['host_cpus']['logical']} CPUs but grants the job a cgroup quota of "
