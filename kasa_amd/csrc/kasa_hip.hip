@@ -104,12 +104,13 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = bytes + bytes / 16 + 256;
-        static const bool timing = getenv("KASA_ALLOC_TIMING") != nullptr;     // diagnostics: allocations that take long
+        static const char *timing = getenv("KASA_ALLOC_TIMING");               // diagnostics: allocations that take long (value: ms, default 20)
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
         if (timing) {
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (dt > 0.02) fprintf(stderr, "kasa: hipMalloc(%.2f GB) took %.3f s\n", want / 1e9, dt);
+            const double limit = atof(timing) > 0 ? atof(timing) * 1e-3 : 0.02;
+            if (dt > limit) fprintf(stderr, "kasa: hipMalloc(%.2f GB) took %.3f s\n", want / 1e9, dt);
         }
         if (e != hipSuccess) {
             p = nullptr;

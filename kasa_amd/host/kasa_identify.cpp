@@ -1227,9 +1227,16 @@ struct WorkerBuffers {
     PcieBuf<uint64_t> ro; PcieBuf<uint32_t> tx; PcieBuf<float> sc;
     // the device's text (kasa_batch_text) comes through a few small page-locked buffers (making one of 5.5 GB takes seconds):
     // the writer thread empties one while the next pieces arrive
-    static constexpr unsigned TEXT_SLOTS = 4;
+    // ten of them hold the text of a reference-sized batch (-m 12: 550 MB), so the device can be a whole batch ahead of the
+    // writer; they are made when the worker starts, while the input is still being parsed (page-locking takes 0.2 s per GB)
+    static constexpr unsigned TEXT_SLOTS = 10;
     PcieBuf<char> text[TEXT_SLOTS]; std::future<void> written[TEXT_SLOTS]; unsigned turn = 0;
     size_t pieceBytes = (size_t)64 << 20;
+    void prepareText()
+    {
+        if (const char *e = getenv("KASA_TEXT_PIECE")) pieceBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small pieces
+        for (auto &t : text) if (t.capacity < pieceBytes) t.resize(pieceBytes);
+    }
     PcieBuf<uint8_t> flags;
     ~WorkerBuffers() { for (auto &f : written) if (f.valid()) f.wait(); }      // the writer still reads the buffers
 };
@@ -1299,7 +1306,6 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
                 tp.coherence = p.coherence ? 1 : 0; tp.errorThreshold = (double)p.errorThreshold; tp.coherenceThreshold = p.coherenceThreshold;
                 uint64_t nBytes = 0;
                 { ScopedTimerMt tm(g_ht.text, g_ht.mu); if (kasa_batch_text(ctx, &tp, &nBytes)) throwLast(); }
-                if (const char *e = getenv("KASA_TEXT_PIECE")) wb.pieceBytes = std::max<size_t>(1, (size_t)atoll(e));   // tests force small pieces
                 wb.flags.resize(nr);
                 if (p.filter && kasa_batch_text_fetch(ctx, nullptr, nullptr, wb.flags.data())) throwLast();
                 const size_t nPieces = out.fd < 0 ? 0 : (size_t)((nBytes + wb.pieceBytes - 1) / wb.pieceBytes);   // (--filter without -q: only the flags)
@@ -1394,6 +1400,12 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         if (const char *e = getenv("KASA_MAX_BATCH_KMERS")) maxKmersPerBatch = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: force several batches
     }
     mark("contexts made");
+    OrderedOut out;
+    vector<WorkerBuffers> wbs(nDev);                                   // (after `out`: their destructors wait for its writer)
+    // the page-locked text buffers are made while the first chunk is parsed
+    std::thread textPrep;
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joinTextPrep{textPrep};
+    if (!p.rtt.empty() && !p.hostRank && !p.hostText) textPrep = std::thread([&wbs] { for (auto &w : wbs) w.prepareText(); });
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     mark("first chunk parsed");
     p.protein = batcher.protein;
@@ -1406,14 +1418,13 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     }
     // the device buffers of the first batch are allocated while the input is parsed (hipMalloc: 25-90 ms per GB here)
     std::thread reserver;
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joinReserver{reserver};
+    Joiner joinReserver{reserver};
     {
         uint64_t estQ = 0, estB = 0;
         batcher.estimateFirstBatch(estQ, estB);
         if (estQ > 0 && !getenv("KASA_NO_RESERVE"))
             reserver = std::thread([&ctx, estQ, estB, wantRows] { for (auto *c : ctx) (void)kasa_ctx_reserve(c, estQ, estB, wantRows ? 1 : 0); });   // (a failure shows when the batch allocates)
     }
-    OrderedOut out;
     if (!p.rtt.empty()) {
         out.fd = ::open(p.rtt.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (out.fd < 0) throw std::runtime_error("Readwise output file could not be created!");
@@ -1433,7 +1444,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     vector<double> tDevice(nDev, 0.0), tText(nDev, 0.0);
     std::atomic<uint64_t> totalKmers{0};
     auto worker = [&](size_t d) {
-        WorkerBuffers wb;
+        WorkerBuffers &wb = wbs[d];
         try {
             for (;;) {
                 std::unique_ptr<Batch> b;
@@ -1489,6 +1500,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
             ++nBatches;
             mark("batch formed", b->id);
             if (reserver.joinable()) { reserver.join(); mark("device buffers reserved"); }
+            if (textPrep.joinable()) { textPrep.join(); mark("text buffers page-locked"); }
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cvSpace.wait(lk, [&] { return todo.size() < nDev || failure; });

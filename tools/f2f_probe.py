@@ -14,7 +14,7 @@ g = synth.genomes(1400, 300_000, seed=11)
 ix = synth.index_from_genomes(g)
 reads = synth.reads_from_genomes(g, n, 150, seed=1000)
 os.environ["KASA_HOST_TIMING"] = "1"
-os.environ["KASA_ALLOC_TIMING"] = "1"
+os.environ["KASA_ALLOC_TIMING"] = os.environ.get("F2F_ALLOC_MS", "20")
 for m in mems:
     a = A(); a.read_len = 150; a.f2f_memory = m
     # bench.file_to_file prints nothing of the child's output: run the same command here to see the host timing line
