@@ -186,6 +186,25 @@ def test_cpp_host_streams_the_input_in_chunks(infile, stem, tmp_path):
     assert _read(prof) == _read(os.path.join(d, "prof_" + stem + ".csv"))
 
 
+@pytest.mark.parametrize("block", ["1500", None])
+def test_cpp_host_gzipped_input(block, tmp_path):
+    """The same reads gzip'ed (two members, as `cat a.gz b.gz` leaves them): inflated as they come, block by block."""
+    import gzip
+    assert capi.device_count() > 0
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    raw = open(os.path.join(d, "reads.fastq"), "rb").read()
+    cut = raw.index(b"\n@", len(raw) // 2) + 1
+    gz = str(tmp_path / "reads.fastq.gz")
+    with open(gz, "wb") as f:
+        f.write(gzip.compress(raw[:cut]) + gzip.compress(raw[cut:]))
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    env = {"KASA_READ_BLOCK": block, "KASA_PARSE_CHUNK": "400"} if block else {}
+    _run_host(["identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", gz, "-q", out, "-p", prof,
+               "--jsonl", "-b", "100", "-n", "3"], env=env)
+    assert _read(out) == _read(os.path.join(d, "out_b100.jsonl"))
+    assert _read(prof) == _read(os.path.join(d, "prof_b100.csv"))
+
+
 def test_cpp_host_identify_multiple(tmp_path):
     """identify_multiple (main.cpp:1118-1334): several input files as a job queue over ONE shared index object, one
     context per worker; outputs named <prefix><file name><format ending> / <prefix><file name>.csv."""
