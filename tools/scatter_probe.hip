@@ -48,6 +48,18 @@ __global__ void scatter_window_kernel(uint4 *__restrict__ dst, uint32_t n, uint3
     dst[(size_t)s * 2 + 1] = make_uint4(i, s, 1, 0);
 }
 
+// 32-byte records with non-temporal stores (the records are read once, by another kernel, much later)
+__global__ void scatter_nt_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_t mask)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm(i, mask);
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    v4 a = {i, s, 0u, 0u}, b = {i, s, 1u, 0u};
+    __builtin_nontemporal_store(a, reinterpret_cast<v4 *>(dst + (size_t)s * 2));
+    __builtin_nontemporal_store(b, reinterpret_cast<v4 *>(dst + (size_t)s * 2 + 1));
+}
+
 template <int WORDS>
 __global__ void gather_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ out, uint32_t n, uint32_t mask)
 {
@@ -96,7 +108,23 @@ int main(int argc, char **argv)
         }
         printf("record 32 B by lane pairs: scatter %7.2f ms (%5.2f G rec/s)\n", ms, n / ms / 1e6);
     }
-    for (int wb = 16; wb <= bits; wb += 2) {
+    {
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(a); scatter_nt_kernel<<<(n + 255) / 256, 256>>>(buf, n, mask); hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&ms, a, b);
+        }
+        printf("record 32 B, non-temporal stores: scatter %7.2f ms (%5.2f G rec/s)\n", ms, n / ms / 1e6);
+        for (int threads : {64, 128, 512, 1024}) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(a); scatter_kernel<2><<<(n + threads - 1) / threads, threads>>>(buf, n, mask); hipEventRecord(b); hipEventSynchronize(b);
+                hipEventElapsedTime(&ms, a, b);
+            }
+            printf("record 32 B, workgroups of %4d: scatter %7.2f ms (%5.2f G rec/s)\n", threads, ms, n / ms / 1e6);
+        }
+    }
+    for (int wb = 16; wb <= bits; wb += 6) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
