@@ -356,7 +356,8 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * key bits instead of 5 passes + bucket_rank_kernel, bit 7 = long sort buckets are not sorted one by one but by the
  * library over all bits (the path for inputs with too many or too long ones), bit 8 = kasa_batch_rank leaves reads with
  * tied hits to the host instead of ranking them with std::sort's order on the device, bit 9 = the library's radix passes
- * over the top 40 key bits instead of the hand-written ones (kasa_amd/csrc/kasa_radix.h); lastSlowReads (may be
+ * over the top 40 key bits instead of the hand-written ones (kasa_amd/csrc/kasa_radix.h), bit 10 = score_main_kernel with the
+ * next line of records prefetched into registers (fewer resident wavefronts); lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

@@ -2582,7 +2582,10 @@ template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t level
 // NLV: rows of the per-level LDS tables (the levels the launch can meet: 8 for narrow records; 25, or 19 for the default
 // -k 25 7 of a 128-bit index -- the kernel's LDS footprint is what limits its resident wavefronts, and with 64-byte records
 // and 16-bit fields it was down to six per CU).
-template <int RW, bool PERREAD, int FB = 16, int NLV = RecTraits<RW>::LEVELS>
+// PF: the next line is loaded while this one is replayed.  Off for narrow records: the 32 registers that holds cost two of six
+// resident wavefronts per SIMD, and those hide the latency better (22.0 -> 21.0 ms; debug flag 1024 runs the prefetching
+// variant).  Wide records: the LDS tables limit the wavefronts anyway, prefetching wins (60 against 64 ms).
+template <int RW, bool PERREAD, int FB = 16, int NLV = RecTraits<RW>::LEVELS, bool PF = (RW != 8)>
 __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
@@ -2682,11 +2685,12 @@ __global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
                         nxt[r2 * (RW / 4) + i] = mineRec ? lp0[(size_t)k * (RW / 4) + i] : make_uint4(0, 0, 0, 0);
                 }
             };
-            loadLine(0);
+            if (PF) loadLine(0);
             for (uint32_t g = 0; g * LN < maxCnt; ++g) {
+            if (!PF) loadLine(g);
 #pragma unroll
             for (uint32_t i = 0; i < LW; ++i) cur[i] = nxt[i];
-            if ((g + 1u) * LN < maxCnt) loadLine(g + 1u);
+            if (PF && (g + 1u) * LN < maxCnt) loadLine(g + 1u);
             for (uint32_t kk = 0; kk < LN; ++kk) {
                 const uint32_t k = g * LN + kk, j = k - ph;
                 const bool has = active && !fb && k >= ph && k < kEnd;
@@ -4013,7 +4017,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const bool fb8 = c->maxCnt <= 255u;                              // 8-bit counter fields: twice the wavefronts per CU
             const bool lv19 = RW == 16 && nK <= 19;                          // (the default -k 25 7 has 19 levels)
             typedef void (*MainKernel)(ScoreArgs);
-            const MainKernel kern = RW == 8 ? (fb8 ? (wantPerRead ? score_main_kernel<8, true, 8> : score_main_kernel<8, false, 8>)
+            const MainKernel kern = (RW == 8 && fb8 && wantPerRead && (c->debugFlags & 1024)) ? score_main_kernel<8, true, 8, 8, true> :
+                                    RW == 8 ? (fb8 ? (wantPerRead ? score_main_kernel<8, true, 8> : score_main_kernel<8, false, 8>)
                                                    : (wantPerRead ? score_main_kernel<8, true> : score_main_kernel<8, false>))
                                   : lv19 ? (fb8 ? (wantPerRead ? score_main_kernel<16, true, 8, 19> : score_main_kernel<16, false, 8, 19>)
                                                 : (wantPerRead ? score_main_kernel<16, true, 16, 19> : score_main_kernel<16, false, 16, 19>))
