@@ -818,8 +818,10 @@ static constexpr int ENC_WAVES = 4;
 static constexpr int ENC_RANK_MAX = 512;                    // k-mers of a read the encoder ranks itself (payload = slot)
 
 #define LDS_WAVE_SYNC_ENC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
-template <class Key>
-__global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
+// RM: capacity of the per-read ranking (k-mers of a read): 512, or 192 when no read of the batch has more (150-bp reads in
+// three frames have 130) -- a third of the LDS and three ranking rounds instead of eight, so more wavefronts are resident.
+template <class Key, int RM = ENC_RANK_MAX>
+__global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
     const uint32_t *__restrict__ seqRead, int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG,
     Key *__restrict__ outKmer, uint32_t *__restrict__ outRead, int rankSlots)
@@ -833,8 +835,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
     // k-mer among the read's k-mers (ties in window order, as the stable sort would leave them) -- so that after the sort
     // every query knows its place in the read-major, sorted-within-read record array (group_kernel writes there).  All
     // k-mers of a read (both strands) wait in LDS for that; the host enables it when every read has at most ENC_RANK_MAX.
-    __shared__ Key sKey[ENC_WAVES][ENC_RANK_MAX];
-    __shared__ uint32_t sTaken[ENC_WAVES][ENC_RANK_MAX];
+    __shared__ Key sKey[ENC_WAVES][RM];
+    __shared__ uint32_t sTaken[ENC_WAVES][128 + RM / 2];              // bucket counts, bucket starts, members (halfwords)
     for (int i = threadIdx.x; i < 366; i += blockDim.x) sLut[i] = lutG[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -911,10 +913,10 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void encode_kernel(
             // lanes) and a k-mer is compared with the members of its own bucket only -- two or three on average, a dozen for
             // the most common first letter.
             const int n = strands * (int)cnt;
-            constexpr int PER = ENC_RANK_MAX / 64;
+            constexpr int PER = RM / 64;
             constexpr int TOPSH = 8 * (int)sizeof(Key) - 6;
-            uint32_t *sCount = &sTaken[wv][0], *sStart = &sTaken[wv][64];    // (sTaken: 512 words per wave, 128 used here)
-            uint16_t *sMember = reinterpret_cast<uint16_t *>(&sTaken[wv][128]);   // item indices grouped by bucket: n <= 512 halfwords
+            uint32_t *sCount = &sTaken[wv][0], *sStart = &sTaken[wv][64];
+            uint16_t *sMember = reinterpret_cast<uint16_t *>(&sTaken[wv][128]);   // item indices grouped by bucket: n <= RM halfwords
             sCount[lane] = 0u;
             LDS_WAVE_SYNC_ENC();
             uint32_t place[PER];                                         // arrival number inside the bucket
@@ -969,10 +971,18 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     c->payloadIsSlot = rankSlots != 0;
     if (c->nSeq > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
-        if (c->ix->wide)
+        if (c->ix->wide && rankSlots && c->maxCnt <= 192u)
+            encode_kernel<key128, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+                c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
+        else if (c->ix->wide)
             encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                 c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
+        else if (rankSlots && c->maxCnt <= 192u)
+            encode_kernel<uint64_t, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+                c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
         else
             encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
@@ -2586,7 +2596,7 @@ template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t level
 // resident wavefronts per SIMD, and those hide the latency better (22.0 -> 21.0 ms; debug flag 1024 runs the prefetching
 // variant).  Wide records: the LDS tables limit the wavefronts anyway, prefetching wins (60 against 64 ms).
 template <int RW, bool PERREAD, int FB = 16, int NLV = RecTraits<RW>::LEVELS, bool PF = (RW != 8)>
-__global__ __launch_bounds__(64) void score_main_kernel(ScoreArgs A)
+__global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void score_main_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
     constexpr int NL = NLV, OB = RT::OBITS;
@@ -3047,7 +3057,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
 // new read begins -- gives each record its place in the read's row, and neighbouring lanes write neighbouring records.
 // Queries marked REC_SPLIT (rare) are one item: their owner lane writes their records event by event afterwards.
 template <bool PERREAD>
-__global__ __launch_bounds__(256) void score_other_flat_kernel(ScoreArgs A)
+__global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
 {
     constexpr int WV = 4;
     __shared__ uint32_t sBase[WV][65];                                    // exclusive prefix sums of the queries' item counts
@@ -4017,7 +4027,9 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const bool fb8 = c->maxCnt <= 255u;                              // 8-bit counter fields: twice the wavefronts per CU
             const bool lv19 = RW == 16 && nK <= 19;                          // (the default -k 25 7 has 19 levels)
             typedef void (*MainKernel)(ScoreArgs);
+            const bool lv6 = RW == 8 && nK <= 6;                             // (the default -k 12 7 has 6 levels: smaller LDS tables, one more wavefront per SIMD)
             const MainKernel kern = (RW == 8 && fb8 && wantPerRead && (c->debugFlags & 1024)) ? score_main_kernel<8, true, 8, 8, true> :
+                                    (lv6 && fb8) ? (wantPerRead ? score_main_kernel<8, true, 8, 6> : score_main_kernel<8, false, 8, 6>) :
                                     RW == 8 ? (fb8 ? (wantPerRead ? score_main_kernel<8, true, 8> : score_main_kernel<8, false, 8>)
                                                    : (wantPerRead ? score_main_kernel<8, true> : score_main_kernel<8, false>))
                                   : lv19 ? (fb8 ? (wantPerRead ? score_main_kernel<16, true, 8, 19> : score_main_kernel<16, false, 8, 19>)
@@ -4147,8 +4159,11 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
-                row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                // (three sizes: the LDS a row needs is what limits the resident wavefronts of this latency-bound kernel)
+                row_merge_bitmap_kernel<256, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                     c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
+                row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 256u, PL);
                 mLo = 512;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
