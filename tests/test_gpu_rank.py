@@ -177,3 +177,25 @@ def test_device_number_format():
     got = capi.device_dtoa(vals)
     for v, g in zip(vals, got):
         assert g == textnum.dtoa(float(v)), (v, g, textnum.dtoa(float(v)))
+
+
+def test_device_text_with_awkward_names():
+    """Specifiers and taxon names are printed as they are (no escaping in the reference): empty names, quotes, backslashes,
+    bytes beyond ASCII, a name of a kilobyte (beyond any short-string buffer); beasts 1..5; with and without a threshold."""
+    ix, batch = _world("pairs")
+    odd = ['', '"quoted"', 'back\\slash', 'caf\xe9 \xfc\xf1', 'x' * 1000, 'a;b,c', "tab\there", ' ', '{', '}']
+    ix.content.names = [ix.content.names[0]] + [odd[i % len(odd)] + (str(i) if i % 3 else "") for i in range(len(ix.content.names) - 1)]
+    batch.names = [odd[(7 * i) % len(odd)] + ("" if i % 5 == 0 else f"r{i} ") for i in range(batch.n)]
+    dix = capi.DeviceIndex(ix)
+    for fmt in ("json", "jsonl", "tsv", "kraken"):
+        for beasts, thr in ((1, 0.0), (2, 0.02), (5, 0.0)):
+            texts = []
+            for device_text in (True, False):
+                run = identify.Identify(ix, 0, 12, 7, 3, thr, beasts, fmt, dix=dix)
+                run.device_text = device_text
+                text, prof, _ = run.run(batch, True)
+                assert run.device_text_batches == (1 if device_text else 0)
+                texts.append(text)
+                run.close()
+            assert texts[0] == texts[1], (fmt, beasts, thr)
+    dix.close()
