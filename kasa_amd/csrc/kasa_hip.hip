@@ -4165,6 +4165,10 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
                 row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                     c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 256u, PL);
                 mLo = 512;
+            } else {                                                 // up to 16384 taxa: the same two sizes over the wide bitmap
+                row_merge_bitmap_kernel<256, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
+                mLo = 256;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                 c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo, PL);
