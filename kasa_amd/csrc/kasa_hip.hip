@@ -893,10 +893,17 @@ __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kern
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < nw; i += 64) {
+                    // (six letters at a time in 32 bits -- one shift-or each -- then one wide shift per group)
                     Key v = 0;
                     const uint8_t *lt = &sLetter[wv][i * ws];
 #pragma unroll
-                    for (int j = 0; j < KLETTERS; ++j) v = (v << 5) | lt[j * ls];
+                    for (int j0 = 0; j0 < KLETTERS; j0 += 6) {
+                        uint32_t part = 0;
+#pragma unroll
+                        for (int j = j0; j < j0 + 6 && j < KLETTERS; ++j) part = (part << 5) | lt[j * ls];
+                        const int got = KLETTERS - j0 < 6 ? KLETTERS - j0 : 6;
+                        v = (v << (5 * got)) | (Key)part;
+                    }
                     const uint64_t o = o0 + (uint64_t)s * cnt + w0 + i;
                     outKmer[o] = v;
                     if (rankSlots) sKey[wv][s * (int)cnt + (int)w0 + i] = v << KeyTraits<Key>::SHIFT;   // (--one: several chunks per strand; strands * cnt <= ENC_RANK_MAX)
