@@ -541,15 +541,22 @@ struct ChunkReader {
             size_t got = 0;
             {
                 ScopedTimer tm(g_ht.read);
+                // (the first block is a quarter: the reads in it size the device buffers, which are then allocated while the
+                // rest of the first batch is parsed)
+                const size_t want = first ? std::max<size_t>(1, blockBytes / 4) : blockBytes;
                 D.reserve(have + blockBytes);
-                while (got < blockBytes) {
-                    const long n = readSome(D.data() + have + got, blockBytes - got);
+                while (got < want) {
+                    const long n = readSome(D.data() + have + got, want - got);
                     if (n <= 0) { eof = true; break; }
                     got += (size_t)n;
                 }
                 have += got;
             }
             ScopedTimer tmCut(g_ht.cut);
+            if (first && have > 0 && !eof) {                          // the alphabet is read off the second line's first four characters: wait for them
+                const char *nl = (const char *)memchr(D.data(), '\n', have);
+                if (!nl || have - (size_t)(nl - D.data()) - 1 < 4) continue;
+            }
             if (first && have > 0) {
                 if (D[0] != '>' && D[0] != '@') throw std::runtime_error("Input does not start with @ or >.");
                 fasta = D[0] == '>';

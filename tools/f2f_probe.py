@@ -38,6 +38,9 @@ for m in mems:
         for threads in ([["-n", x] for x in nlist.split(",")] if nlist else ([] if m != mems[0] else [["-n", "16"]]) + [[]]):
             cmd = [build.build_host(), "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "reads.fastq"),
                    "-q", os.path.join(d, "out.jsonl"), "-p", os.path.join(d, "prof.csv"), "--jsonl", "-v", "-m", str(m)] + threads
+            for name in ("out.jsonl", "prof.csv"):
+                try: os.unlink(os.path.join(d, name))
+                except OSError: pass
             t0 = time.perf_counter()
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             print("== -m", m, " ".join(threads), "wall %.2f s" % (time.perf_counter() - t0))
