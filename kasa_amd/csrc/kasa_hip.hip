@@ -3236,11 +3236,11 @@ __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
 // owner's column of an LDS table (a running sum over the levels then gives |T_k|, and the crowded levels of the register
 // taxa), the second emits: every record of a wide query is an event record, a segment's levels leave in the query's flush
 // order (5 bits per event in the record's 128-bit order field).
-template <bool PERREAD>
+template <bool PERREAD, int NLW = RecTraits<16>::LEVELS>             // NLW: rows of the |T_k| table (19 for the default -k 25 7: less LDS, more wavefronts)
 __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
 {
     typedef RecTraits<16> RT;
-    constexpr int WV = 2, INL = RT::INL, NLW = RT::LEVELS;
+    constexpr int WV = 2, INL = RT::INL;
     constexpr uint32_t CNT_FIELDS = 2u;
     __shared__ uint32_t sBase[WV][65];
     __shared__ uint32_t sSg[WV][INL][64];                                  // inline segments (sweep 1: all; sweep 2: those that leave records)
@@ -4062,7 +4062,10 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const bool flat = RW == 8 && !(c->debugFlags & 32);              // debug flag 32: the per-lane kernels
             if (RW == 16 && !(c->debugFlags & 32)) {
                 const unsigned fblocks16 = std::min<unsigned>(blocks_for(nQ, 128), 256u * 128u);
-                if (wantPerRead) score_other_flat16_kernel<true><<<fblocks16, 128, 0, c->stream>>>(A);
+                if (nK <= 19) {
+                    if (wantPerRead) score_other_flat16_kernel<true, 19><<<fblocks16, 128, 0, c->stream>>>(A);
+                    else score_other_flat16_kernel<false, 19><<<fblocks16, 128, 0, c->stream>>>(A);
+                } else if (wantPerRead) score_other_flat16_kernel<true><<<fblocks16, 128, 0, c->stream>>>(A);
                 else score_other_flat16_kernel<false><<<fblocks16, 128, 0, c->stream>>>(A);
             } else
             if (wantPerRead) { if (flat) score_other_flat_kernel<true><<<oblocks, 256, 0, c->stream>>>(A); else if (RW == 8) score_other_kernel<8, true><<<oblocks, 256, 0, c->stream>>>(A); else score_other_kernel<16, true><<<oblocks, 256, 0, c->stream>>>(A); }
