@@ -253,3 +253,42 @@ def test_cpp_host_filter_gzip(tmp_path):
     for mine, ref in ((c + ".fastq.gz", "gflt_clean.fastq.gz"), (x + ".fastq.gz", "gflt_cont.fastq.gz")):
         assert open(mine, "rb").read(2) == b"\x1f\x8b"
         assert gzip.open(mine).read() == gzip.open(os.path.join(d, ref)).read()
+
+
+@pytest.mark.parametrize("fmt,extra", [("--jsonl", []), ("--tsv", ["--six"]), ("--json", ["-b", "7", "--threshold", "0.02"])])
+def test_cpp_host_paths_agree_at_scale(fmt, extra, tmp_path):
+    """150 000 reads of 1..400 bases (reads too short for a k-mer, runs of N, lower case), several device batches: the text
+    written on the device, the host's writer over the device's ranking (--host-text) and the host's own ranking over the
+    full rows (--host-rank) must give the same file and the same profile."""
+    import numpy as np
+    from kasa_amd import formats, synth
+    assert capi.device_count() > 0
+    g = synth.genomes(40, 20_000, seed=3)
+    ix = synth.index_from_genomes(g)
+    formats.write_index(ix, str(tmp_path / "idx"), str(tmp_path / "content.txt"))
+    rng = np.random.default_rng(17)
+    n = 150_000
+    flat = g.reshape(-1)
+    lens = rng.integers(1, 401, size=n)
+    lens[rng.random(n) < 0.6] = 150
+    starts = rng.integers(0, flat.shape[0] - 400, size=n)
+    lines = []
+    for r in range(n):
+        s = flat[starts[r]:starts[r] + lens[r]].copy()
+        if r % 11 == 0 and lens[r] > 20:
+            a = int(rng.integers(0, lens[r] - 5)); s[a:a + int(rng.integers(1, 6))] = ord("N")
+        if r % 13 == 0:
+            s = np.frombuffer(bytes(s).lower(), dtype=np.uint8)
+        lines.append(b"@r%d some text\n" % r + bytes(s) + b"\n+\n" + b"I" * int(lens[r]) + b"\n")
+    fq = str(tmp_path / "reads.fastq")
+    open(fq, "wb").write(b"".join(lines))
+    outs = []
+    for mode in ([], ["--host-text"], ["--host-rank"]):
+        out, prof = str(tmp_path / ("out" + "".join(mode))), str(tmp_path / ("prof" + "".join(mode)))
+        _run_host(["identify", "-c", str(tmp_path / "content.txt"), "-d", str(tmp_path / "idx"), "-i", fq, "-q", out, "-p", prof, fmt, "-m", "4"] + extra + mode,
+                  env={"KASA_MAX_BATCH_KMERS": "6000000", "KASA_TEXT_PIECE": "3000000"})
+        outs.append((open(out, "rb").read(), open(prof, "rb").read()))
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+    assert outs[0][0] == outs[1][0], "device text != host text over the device's ranking"
+    assert outs[0][0] == outs[2][0], "device ranking + text != host ranking + text"
+    assert outs[0][0].count(b"\n") > n // 2
