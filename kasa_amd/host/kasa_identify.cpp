@@ -1412,7 +1412,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     // the page-locked text buffers are made while the first chunk is parsed
     std::thread textPrep;
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joinTextPrep{textPrep};
-    if (!p.rtt.empty() && !p.hostRank && !p.hostText) textPrep = std::thread([&wbs] { for (auto &w : wbs) w.prepareText(); });
+    if (!p.rtt.empty() && !p.hostRank && !p.hostText) textPrep = std::thread([&wbs] { try { for (auto &w : wbs) w.prepareText(); } catch (...) {} });   // (what is missing is made, or fails, when a worker needs it)
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     mark("first chunk parsed");
     p.protein = batcher.protein;
