@@ -124,6 +124,18 @@ int main(int argc, char **argv)
             printf("record 32 B, workgroups of %4d: scatter %7.2f ms (%5.2f G rec/s)\n", threads, ms, n / ms / 1e6);
         }
     }
+    {   // fewer resident wavefronts (dynamic LDS as ballast): does the scatter rate depend on how many stores are in flight?
+        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+        float ms = 0;
+        hipFuncSetAttribute((const void *)scatter_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int lds : {0, 16 * 1024, 32 * 1024, 64 * 1024, 128 * 1024}) {
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(a); scatter_kernel<2><<<(n + 255) / 256, 256, lds>>>(buf, n, mask); hipEventRecord(b); hipEventSynchronize(b);
+                hipEventElapsedTime(&ms, a, b);
+            }
+            printf("record 32 B, %3d KB of LDS per 256-thread workgroup: scatter %7.2f ms (%5.2f G rec/s)\n", lds / 1024, ms, n / ms / 1e6);
+        }
+    }
     for (int wb = 16; wb <= bits; wb += 6) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         float ms = 0;
