@@ -199,3 +199,39 @@ def test_device_text_with_awkward_names():
                 run.close()
             assert texts[0] == texts[1], (fmt, beasts, thr)
     dix.close()
+
+
+def test_text_abi_edges():
+    """kasa_batch_text refuses what it cannot do; kasa_batch_text_fetch_range hands out any piece and nothing beyond the text;
+    kasa_ctx_reserve before a batch changes nothing but where the buffers come from."""
+    import ctypes as C
+    ix, batch = _world("pairs")
+    dix = capi.DeviceIndex(ix)
+    lib = capi.lib()
+    texts = []
+    for reserve in (False, True):
+        ctx = capi.Context(dix, 12, 7, 3)
+        if reserve:
+            assert lib.kasa_ctx_reserve(ctx.h, C.c_uint64(5_000_000), C.c_uint64(1_000_000), C.c_int(1)) == 0
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        freq = ix.freq_at(12)
+        den, rclass = report.rank_denominators(freq, batch.lengths, ix.K, False)
+        best = np.array([report.best_score(int(L), 12, 7, 3, False) for L in np.unique(batch.lengths)], dtype=np.float32)
+        with pytest.raises(RuntimeError):                           # not ranked yet
+            ctx.text("jsonl", 3, 0, batch.names, batch.lengths, best)
+        ctx.rank(den, rclass, 0.0, 3)
+        with pytest.raises(RuntimeError):                           # no taxon names yet
+            ctx.text("jsonl", 3, 0, batch.names, batch.lengths, best)
+        ctx.set_taxa_text(ix.content.taxids, ix.content.names)
+        whole, offs, _ = ctx.text("jsonl", 3, 7, batch.names, batch.lengths, best)
+        pieces, _, _ = ctx.text("jsonl", 3, 7, batch.names, batch.lengths, best, pieces=5)
+        assert whole == pieces and int(offs[-1]) == len(whole) and whole.count(b"\n") == batch.n
+        assert whole.startswith(b'{ "Read number": 7, ')
+        buf = np.zeros(16, dtype=np.uint8)
+        assert lib.kasa_batch_text_fetch_range(ctx.h, C.c_void_p(buf.ctypes.data), C.c_uint64(len(whole) - 8), C.c_uint64(16)) != 0   # beyond the end
+        assert lib.kasa_batch_text_fetch_range(ctx.h, C.c_void_p(buf.ctypes.data), C.c_uint64(len(whole) - 8), C.c_uint64(8)) == 0
+        assert bytes(buf[:8]) == whole[-8:]
+        texts.append(whole)
+        ctx.close()
+    assert texts[0] == texts[1]
+    dix.close()
