@@ -2522,6 +2522,29 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // Neither kernel touches the profile tables: everything leaves as records, so both can be rerun.
 // ------------------------------------------------------------------------------------------------
 // |T_k| of a level and the decoded record of one query, for both record widths
+// |T_k| tables of wide records in LDS: TWO levels per 32-bit word, 16 bits each (a query has fewer than 2^13 segments), so
+// that the tables -- which limit the resident wavefronts of the wide score kernels -- take half the room.  The +1 / -1 marks
+// at the ends of a segment's level range go into a word as +-1 or +-65536 (plain or atomic adds); a borrow out of the low
+// half is undone when the running sum reads the marks back as two SIGNED halves.
+__device__ __forceinline__ uint32_t lvp_rows(int levels) { return (uint32_t)(levels + 3) / 2u; }   // levels + 1 marks (one past the last level)
+__device__ __forceinline__ uint32_t lvp_unit(int lv) { return (lv & 1) ? 0x10000u : 1u; }
+__device__ __forceinline__ uint32_t lvp_get(const uint32_t *col, int stride, int lv) { return (col[(lv >> 1) * stride] >> (16 * (lv & 1))) & 0xFFFFu; }
+// marks -> sizes, in place; calls f(lv, size) for every level
+template <class F> __device__ __forceinline__ void lvp_running(uint32_t *col, int stride, int nK, F f)
+{
+    uint32_t running = 0;
+    for (int w = 0; 2 * w < nK; ++w) {
+        const uint32_t x = col[w * stride];
+        const int lo = (int)(int16_t)(x & 0xFFFFu);
+        const int hi = (int)(int16_t)((x - (uint32_t)lo) >> 16);
+        const uint32_t a = running + (uint32_t)lo, b = a + (uint32_t)hi;
+        running = b;
+        col[w * stride] = (a & 0xFFFFu) | (b << 16);
+        f(2 * w, a);
+        if (2 * w + 1 < nK) f(2 * w + 1, b);
+    }
+}
+
 template <int RW> struct QueryRec {
     typedef RecTraits<RW> RT;
     uint32_t p, fmax, nseg, nlev, split;
@@ -2570,7 +2593,7 @@ template <int RW> struct QueryRec {
     {
         uint32_t n = RW == 8 ? ((nlev >> (3 * lv)) & 7u) : 7u;
         if (RW == 8) return n < 7u ? n : ((sizes[lv >> 1] >> (16 * (lv & 1))) & 0xFFFFu);   // "7 or more": the exact size is in the pool
-        if (tab) return tab[lv * tabStride];
+        if (tab) return lvp_get(tab, tabStride, lv);
         if (n == 7u) {                                               // not recorded: count
             const uint32_t k = (uint32_t)(kHigh - lv);
             n = 0;
@@ -2618,7 +2641,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
     __shared__ uint32_t sPB[65], sPPtr[64], sPT0[64], sPT1[64], sPM0[64], sPM1[64], sPRec[64], sPKey[64];   // pool segments of the current queries
     // wide records: |T_k| of the current query of every lane -- +1 / -1 at the ends of each segment's level range, then a
     // running sum over the levels (counting the segments again for every event cost seven times as much)
-    __shared__ uint32_t sLvN[RW == 16 ? NL + 2 : 1][64];
+    __shared__ uint32_t sLvN[RW == 16 ? (NL + 3) / 2 : 1][64];
     event_tables_init(evT);
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
@@ -2744,12 +2767,13 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
                 }
                 if constexpr (RW == 16) {
-                    for (int lv = 0; lv <= nK; ++lv) sLvN[lv][lane] = 0u;
+                    for (uint32_t w = 0; w < lvp_rows(nK); ++w) sLvN[w][lane] = 0u;
 #pragma unroll
                     for (int q = 0; q < RT::INL; ++q) {
                         if (!live || (uint32_t)q >= Q.nInl) continue;
-                        sLvN[A.kHigh - (int)(Q.sg[q] >> 27)][lane] += 1u;
-                        sLvN[A.kHigh - (int)((Q.sg[q] >> 22) & 31u) + 1][lane] -= 1u;
+                        const int la = A.kHigh - (int)(Q.sg[q] >> 27), lb = A.kHigh - (int)((Q.sg[q] >> 22) & 31u) + 1;
+                        sLvN[la >> 1][lane] += lvp_unit(la);
+                        sLvN[lb >> 1][lane] -= lvp_unit(lb);
                     }
                 }
                 const uint32_t nm = live ? Q.nMore : 0u;
@@ -2772,8 +2796,9 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                             const uint32_t sq = A.pool[sPPtr[own] + (i - sPB[own])];
                             const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
                             if constexpr (RW == 16) {
-                                atomicAdd(&sLvN[A.kHigh - (int)(sq >> 27)][own], 1u);
-                                atomicSub(&sLvN[A.kHigh - (int)((sq >> 22) & 31u) + 1][own], 1u);
+                                const int la = A.kHigh - (int)(sq >> 27), lb = A.kHigh - (int)((sq >> 22) & 31u) + 1;
+                                atomicAdd(&sLvN[la >> 1][own], lvp_unit(la));
+                                atomicSub(&sLvN[lb >> 1][own], lvp_unit(lb));
                             }
                             if (t == sPT0[own]) atomicOr(&sPM0[own], m);
                             else if (t == sPT1[own]) atomicOr(&sPM1[own], m);
@@ -2787,8 +2812,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                 if ((mask0 | mask1) == 0u) continue;
                 if constexpr (RW == 16) {
                     LDS_WAVE_SYNC();
-                    uint32_t running = 0;
-                    for (int lv = 0; lv < nK; ++lv) { running += sLvN[lv][lane]; sLvN[lv][lane] = running; }
+                    lvp_running(&sLvN[0][lane], 64, nK, [](int, uint32_t) {});
                     Q.tab = &sLvN[0][lane]; Q.tabStride = 64;
                 }
                 const int nEv = Q.d - A.kLow + 1;
@@ -2899,7 +2923,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
     constexpr uint32_t STAGE = 512;                                        // records a wavefront stages; larger (rare) batches are written directly
     __shared__ uint2 sRec[4][STAGE];
     __shared__ uint32_t sAt[4][STAGE];
-    __shared__ uint32_t sLvN[RW == 16 ? RT::LEVELS + 2 : 1][256];        // wide records: |T_k| of this thread's query (QueryRec::tab)
+    __shared__ uint32_t sLvN[RW == 16 ? (RT::LEVELS + 3) / 2 : 1][256];  // wide records: |T_k| of this thread's query (QueryRec::tab), two levels per word
     const int wv = threadIdx.x >> 6;
     for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < nQup; slot += stride) {
         const bool inRange = slot < A.nQ;
@@ -2939,20 +2963,19 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         if constexpr (RW == 16) {
             if (live) {                                                        // + 1 / - 1 at the ends of every segment's level range, running sum
                 const int nKl = A.kHigh - A.kLow + 1, me = (int)threadIdx.x;
-                for (int lv = 0; lv <= nKl; ++lv) sLvN[lv][me] = 0u;
+                for (uint32_t w = 0; w < lvp_rows(nKl); ++w) sLvN[w][me] = 0u;
+                auto mark = [&](uint32_t sq) {
+                    const int la = A.kHigh - (int)(sq >> 27), lb = A.kHigh - (int)((sq >> 22) & 31u) + 1;
+                    sLvN[la >> 1][me] += lvp_unit(la);
+                    sLvN[lb >> 1][me] -= lvp_unit(lb);
+                };
 #pragma unroll
                 for (int q = 0; q < RT::INL; ++q) {
                     if ((uint32_t)q >= Q.nInl) continue;
-                    sLvN[A.kHigh - (int)(Q.sg[q] >> 27)][me] += 1u;
-                    sLvN[A.kHigh - (int)((Q.sg[q] >> 22) & 31u) + 1][me] -= 1u;
+                    mark(Q.sg[q]);
                 }
-                for (uint32_t q = 0; q < Q.nMore; ++q) {
-                    const uint32_t sq = extra(q);
-                    sLvN[A.kHigh - (int)(sq >> 27)][me] += 1u;
-                    sLvN[A.kHigh - (int)((sq >> 22) & 31u) + 1][me] -= 1u;
-                }
-                uint32_t running = 0;
-                for (int lv = 0; lv < nKl; ++lv) { running += sLvN[lv][me]; sLvN[lv][me] = running; }
+                for (uint32_t q = 0; q < Q.nMore; ++q) mark(extra(q));
+                lvp_running(&sLvN[0][me], 256, nKl, [](int, uint32_t) {});
                 Q.tab = &sLvN[0][me]; Q.tabStride = 256;
             }
         }
@@ -3246,7 +3269,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
     __shared__ uint32_t sSg[WV][INL][64];                                  // inline segments (sweep 1: all; sweep 2: those that leave records)
     __shared__ uint32_t sOrd[WV][4][64];                                   // flush order, 5 bits per event
     __shared__ uint32_t sW2[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64], sPool[WV][64], sNInl[WV][64];
-    __shared__ uint32_t sLvN[WV][NLW + 2][64];                             // |T_k| of every lane's query (QueryRec::tab)
+    __shared__ uint32_t sLvN[WV][(NLW + 3) / 2][64];                       // |T_k| of every lane's query (QueryRec::tab), two levels per word
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t kindOther = PERREAD ? 0u : RK_PROFILE;
     const uint32_t stride = gridDim.x * 128u;
@@ -3284,7 +3307,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         const bool split = Q.split != 0u;
         const int nEvMine = Q.d ? Q.d - A.kLow + 1 : 0;
         // ---- sweep 1: |T_k| of every query
-        for (int lv = 0; lv <= nK; ++lv) sLvN[wv][lv][lane] = 0u;
+        for (uint32_t w = 0; w < lvp_rows(nK); ++w) sLvN[wv][w][lane] = 0u;
         uint32_t incl = Q.nseg;
         incl = wave_incl_sum(incl);
         const uint32_t S1 = lane_value<63>(incl);
@@ -3304,16 +3327,14 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
                 for (int step = 32; step; step >>= 1) if (sBase[wv][own + step] <= i) own += step;
                 const uint32_t idx = i - sBase[wv][own], nInl = sNInl[wv][own];
                 const uint32_t sq = idx < nInl ? sSg[wv][idx][own] : A.pool[sPool[wv][own] + 1u + idx - nInl];
-                atomicAdd(&sLvN[wv][A.kHigh - (int)(sq >> 27)][own], 1u);
-                atomicSub(&sLvN[wv][A.kHigh - (int)((sq >> 22) & 31u) + 1][own], 1u);
+                const int la = A.kHigh - (int)(sq >> 27), lb = A.kHigh - (int)((sq >> 22) & 31u) + 1;
+                atomicAdd(&sLvN[wv][la >> 1][own], lvp_unit(la));
+                atomicSub(&sLvN[wv][lb >> 1][own], lvp_unit(lb));
             }
         }
         LDS_WAVE_SYNC();
         uint32_t bigLv = 0;                                                    // levels where the register taxa leave profile records
-        {
-            uint32_t running = 0;
-            for (int lv = 0; lv < nK; ++lv) { running += sLvN[wv][lv][lane]; sLvN[wv][lv][lane] = running; if (running > CNT_FIELDS) bigLv |= 1u << lv; }
-        }
+        lvp_running(&sLvN[wv][0][lane], 64, nK, [&](int lv, uint32_t n) { if (n > CNT_FIELDS) bigLv |= 1u << lv; });
         Q.tab = &sLvN[wv][0][lane]; Q.tabStride = 64;
         auto emitMask = [&](uint32_t sq) -> uint32_t {
             const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
@@ -3387,14 +3408,14 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
                 if (isSplit) sSplit[wv][own] = w;
                 else if (c == 1u) {
                     const int lv = __ffs((int)em) - 1;
-                    A.st[w] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (sLvN[wv][lv][own] << 16) | 1u);
+                    A.st[w] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (lvp_get(&sLvN[wv][0][own], 64, lv) << 16) | 1u);
                 } else {                                                       // its levels in the query's flush order
                     const int nEv = (int)(w2 & 31u) - A.kLow + 1;
                     unsigned __int128 o = ((unsigned __int128)sOrd[wv][3][own] << 96) | ((unsigned __int128)sOrd[wv][2][own] << 64) |
                                           ((unsigned __int128)sOrd[wv][1][own] << 32) | sOrd[wv][0][own];
                     for (int ev = 0; ev < nEv; ++ev, o >>= 5) {
                         const int lv = (int)((uint32_t)o & 31u);
-                        if ((em >> lv) & 1u) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (sLvN[wv][lv][own] << 16) | 1u);
+                        if ((em >> lv) & 1u) A.st[w++] = make_uint2(t | ((uint32_t)lv << RK_LV_SHIFT) | kind, (lvp_get(&sLvN[wv][0][own], 64, lv) << 16) | 1u);
                     }
                 }
             }
