@@ -6,7 +6,7 @@ out = "gpurun_out/gaps"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 subprocess.run(["rocprofv3", "--kernel-trace", "--memory-copy-trace", "--output-format", "csv", "-d", out, "--", "python3", "bench.py", "--steps", "2", "--warmup", "1",
-                "--no-cpu", "--no-e2e", "--no-secondary"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                "--no-cpu", "--no-e2e", "--no-secondary"] + os.environ.get("GAP_ARGS", "").split(), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 rows = []
 for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -26,5 +26,12 @@ for i in range(a, b):
     g = rows[i + 1][0] - rows[i][1]
     gaps.append((g, rows[i][2], rows[i + 1][2], (rows[i][1] - rows[a][0]) / 1e6))
 gaps.sort(reverse=True)
-for g, x, y, t in gaps[:25]:
+import collections
+acc = collections.OrderedDict()
+for s_, e_, n_ in step:
+    n_ = n_.replace("void ", "")[:64]
+    acc.setdefault(n_, [0, 0]); acc[n_][0] += e_ - s_; acc[n_][1] += 1
+for n_, (t_, c_) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:22]:
+    print("%8.3f ms x%-3d %s" % (t_ / 1e6, c_, n_))
+for g, x, y, t in gaps[:6]:
     print("%8.3f ms idle at t=%7.2f ms after %-50s before %s" % (g / 1e6, t, x, y))

@@ -44,7 +44,7 @@ measured = (
     + krow("score_other_flat_kernel", "score_other_kernel", "")
     + krow("row_merge_bitmap_kernel", "row_merge_kernel", "")
     + f"\n64-byte records (C3): `group_kernel<16>` {SK['group_kernel']['avg_launch_ms']:.0f}, `score_main_kernel<16>` {SK['score_main_kernel']['avg_launch_ms']:.0f} "
-    f"(round 2: 91; level-sized LDS tables and 8-bit fields), `score_other_flat16_kernel` {SK['score_other_kernel']['avg_launch_ms']:.0f} ms.\n\n"
+    f"(round 2: 91; level-sized LDS tables, 8-bit fields, two levels per LDS word), `score_other_flat16_kernel` {SK['score_other_kernel']['avg_launch_ms']:.0f} ms (round 2: 88).\n\n"
     f"PCIe-inclusive (`e2e`, never `value`): page-locked reads up, device, ranking on the device (`-b 3`), ranked hits + profile down = "
     f"{e['pcie_inclusive_s_per_batch']:.2f} s per batch = **{e['pcie_inclusive_reads_per_s'] / 1e6:.1f} M reads/s** ({e['upload_and_device_s']:.2f} s upload + device, "
     f"{e['rank_and_fetch_s']:.2f} s ranking + {e['downloaded_bytes'] / 1e9:.2f} GB of hits; {e['reads_ranked_by_host']} reads go back to the host; all 1400 synthetic taxa have the "
