@@ -283,7 +283,7 @@ def report(args, ctx, reads, ix, world, dt, wide, pcie, reads_per_rank=None, n_b
 def pcie_inclusive(ctx, reads, want, ix, k_high):
     """Two more passes with the PCIe legs inside the clock (never `value`): host reads in, and out either what the per-read
     file can print (ranked on the device, kasa_batch_rank; page-locked buffers) or the whole CSR (pageable memory, the
-    round-1 path).  The file-to-file rate of the C++ driver is measured by tools/e2e_host.py."""
+    round-1 path).  The file-to-file rate of the C++ driver is measured by file_to_file() below."""
     from kasa_amd import capi, report
     import numpy as np
     out = {}
@@ -327,7 +327,7 @@ def pcie_inclusive(ctx, reads, want, ix, k_high):
     out.update({"csr_download_reads_per_s": reads.n / dt, "csr_download_s_per_batch": dt,
                 "note": "pcie_inclusive: page-locked reads up, device, ranking on the device (-b 3), ranked hits + profile down "
                         "(+ the CSR into page-locked memory when the device hands reads back); "
-                        "csr_download: the same with the whole CSR down into pageable memory; file to file: tools/e2e_host.py"})
+                        "csr_download: the same with the whole CSR down into pageable memory; file_to_file_*: the C++ driver as a child process (text written on the device)"})
     if not want:
         out["pcie_inclusive_reads_per_s"] = out["csr_download_reads_per_s"]
         out["pcie_inclusive_s_per_batch"] = out["csr_download_s_per_batch"]
