@@ -142,3 +142,30 @@ def test_python_stdsort_order_equals_libstdcxx(tmp_path):
         want = [int(x) for x in ids.split()]
         got = report._stdsort_order(len(rel), lambda x, y: rel[x] > rel[y])
         assert got == want
+
+
+@pytest.mark.parametrize("name", ["reads.fastq", "reads.fasta", "edge_crlf.fasta", "edge_multi.fastq", "edge_noeol.fasta", "exampleInput.fasta",
+                                  "reads_prot.fasta", "reads_dup.fastq"])
+@pytest.mark.parametrize("block,run", [(None, None), ("1500", "400"), ("97", "33")])
+def test_cpp_parser_equals_python_parser(name, block, run, golden_dir):
+    """The C++ driver's streaming parser (blocks that take turns, runs parsed by several threads, huge-page arrays) against
+    kasa_amd/reads.py on the reference's own kinds of input -- without a device: `kasa_identify parse-dump` is a test tap."""
+    import subprocess
+    from kasa_amd import build as hipbuild, reads
+    exe = hipbuild.HOST_BIN
+    if not os.path.exists(exe):
+        pytest.skip("host driver not built (python -m kasa_amd.build)")
+    path = os.path.join(golden_dir, "pairs", name)
+    env = dict(os.environ)
+    if block:
+        env.update(KASA_READ_BLOCK=block, KASA_PARSE_CHUNK=run)
+    r = subprocess.run([exe, "parse-dump", path, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-400:]
+    out = r.stdout.decode("latin-1")
+    whole, streamed = out.split("== streamed\n")
+    ref = reads.parse_reads(path)
+    want = "".join(f"{ref.names[i]}\t{int(ref.lengths[i])}\t{bytes(ref.bases[int(ref.offsets[i]):int(ref.offsets[i + 1])]).decode('latin-1')}\n" for i in range(ref.n))
+    for part in (whole.split("== whole file\n")[1], streamed):
+        head, body = part.split("\n", 1)
+        assert head.startswith("protein=%d" % (1 if ref.protein else 0)), head
+        assert body == want
