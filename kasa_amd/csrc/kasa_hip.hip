@@ -3941,7 +3941,7 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
     if ((rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging
     hipEvent_t a, b;
-    if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ / 4);
+    if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ);   // (a word per query: a first batch with crowded taxon lists -- 0.75 words per query on the bench data -- need not run group_kernel twice)
     for (int attempt = 0;; ++attempt) {
         if ((rc = c->pool.reserve(c->poolCap * 4))) return rc;
         const unsigned long long one = 1;
