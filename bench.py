@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the `identify` hot path on MI355X (BASELINE.json metric).
 
-One step = one pass of the whole hot path (encode -> sort -> lookup -> group -> score, per-read CSR included) over
-synthetic reads that are already resident in HBM.
+One step, AT EVERY N, is the same loop: for each of the rank's batches (bases and offsets already resident in HBM)
+kasa_batch_upload_device (the read geometry, no PCIe) -> encode -> sort -> lookup -> group -> score (per-read CSR
+included); with N > 1 the step ends with ONE RCCL all-reduce of the profile tables through the C ABI
+(kasa_profile_allreduce on the context's stream; its own communicator, created from an ncclUniqueId that travels over
+torch.distributed).  `value` = all reads of all ranks / max-over-ranks time.
 
   N = 1   BASELINE.json configs[1] (C2): ONE batch of 10 M synthetic 150 bp reads against a ~5 GB k<=12 64-bit index
           (1400 taxa x 300 kb, sibling genomes 3 % apart; 1 % read errors; -k 12 7, three frames).  The same line also
-          carries `secondary` = configs[2] (C3: the same reads against the 128-bit index, -k 25 7), `e2e` (PCIe-inclusive
-          rates and the file-to-file rate of the C++ driver: FASTQ in, JSONL + profile out, index load excluded) and
-          `cpu_baseline` (the oracle with the reference's threading model on the host cores).
-  N > 1   BASELINE.json configs[3] (C4): 100 M reads in all, index replicated, every rank takes 100 M / N reads (kept in
-          its HBM) in batches of at most 10 M; a step = all batches of the rank + ONE RCCL all-reduce of the profile
-          tables through the C ABI (kasa_profile_allreduce on the context's stream; its own communicator, created from
-          an ncclUniqueId that travels over torch.distributed).  `value` = all reads of all ranks / max-over-ranks time.
+          carries `secondary` = configs[2] (C3: the same reads against the 128-bit index, -k 25 7), `tertiary` (a crowded
+          index: clades of taxa sharing conserved genes), `e2e` (PCIe-inclusive rates and the file-to-file rate of the
+          C++ driver: FASTQ in, JSONL + profile out, index load excluded) and `cpu_baseline` (the oracle with the
+          reference's threading model on the host cores).
+  N > 1   the same 10 M-read batch on EVERY rank, index replicated ("weak": N x 10 M reads per step; N = 1 and N = 8 differ
+          by the reduce only).  The same line carries `c4` = BASELINE.json configs[3]: 100 M reads in all, 100 M / N per
+          rank in batches of at most 10 M ("strong").  `--total-reads T` makes that the headline instead.
   --partitioned   BASELINE.json configs[4] (C5): the index range-partitioned over the ranks (kasa_amd/dist.py), one
           slice per rank made of the genomes' k-mers of its prefix range plus random filler records.
 
@@ -163,32 +166,57 @@ def launch_ranks(n):
     return failed
 
 
-def measure(args, ctx, world, dist, share, torch, kdist, batches=None, comm=0):
-    """Warm up, time exactly --steps steps between barriers -> seconds (max over ranks).
-    batches = None: the one batch already uploaded (N = 1).  Else [(device pointer of the bases, host offsets)]: the rank's
-    reads, resident in HBM, taken batch by batch; the step ends with the profile reduce over the ranks."""
+def resident_batches(torch, synth, g, per_rank, max_batch, L, seed0):
+    """The rank's reads in HBM: one uint8 tensor + per batch a device tensor of offsets.  -> (tensors to keep alive,
+    [(bases pointer, offsets pointer, reads)], the first part as a host ReadBatch for the report and the e2e legs)."""
+    n_batches = max(1, -(-per_rank // max_batch))
+    per_batch = -(-per_rank // n_batches)
+    dev_reads = torch.empty(per_rank * L, dtype=torch.uint8, device="cuda")
+    first = None
+    done = 0
+    while done < per_rank:
+        m = min(max_batch, per_rank - done)
+        part = synth.reads_from_genomes(g, m, L, seed=seed0 + done // max(1, max_batch))
+        dev_reads[done * L:(done + m) * L].copy_(torch.from_numpy(part.bases))
+        if first is None:
+            first = part
+        done += m
+    keep, batches = [dev_reads], []
+    for b in range(n_batches):
+        a0, a1 = b * per_batch, min(per_rank, (b + 1) * per_batch)
+        off = torch.arange(a1 - a0 + 1, dtype=torch.int64, device="cuda") * L
+        keep.append(off)
+        batches.append((dev_reads.data_ptr() + a0 * L, off.data_ptr(), a1 - a0))
+    torch.cuda.synchronize()
+    return keep, batches, first
+
+
+def measure(args, ctx, world, dist, share, torch, kdist, batches, comm=0):
+    """Warm up, time exactly --steps steps between barriers.  batches = [(device pointer of the bases, device pointer of the
+    offsets, reads)]: the rank's reads, resident in HBM, taken batch by batch -- the same loop at every N; with N > 1 the step
+    ends with the profile reduce over the ranks.  -> {"dt": seconds (max over ranks), per-rank times, reduce / upload time}."""
     want = not args.profile_only
+    acc = {"reduce_s": 0.0}
 
     def reduce_profile():
-        if dist is None:
+        if dist is None or world == 1:
             return
+        ctx.synchronize()                                                  # (the step's device work is done: what follows is the reduce alone,
+        t0 = time.perf_counter()                                           #  waiting for the slowest rank included)
         if comm:
             ctx.profile_allreduce(comm)                                    # C ABI: pack on the device, ncclAllReduce on the context's stream, unpack
         else:
             ctx.profile_set_limbs(kdist.allreduce_limbs(ctx.profile_limbs(), device=None if share else "cuda"))   # (shared-GPU test hook / fallback: through torch.distributed)
+        ctx.synchronize()
+        acc["reduce_s"] += time.perf_counter() - t0
 
     def step():
-        if batches is None:
+        ctx.profile_reset()                                                # a step is a whole "file": its own profile, summed over the ranks at its end
+        for bases_ptr, off_ptr, n in batches:
+            ctx.upload_resident(bases_ptr, off_ptr, n)
             ctx.encode()
             ctx.sort_and_range()
             ctx.lookup_score(want, False)
-        else:
-            ctx.profile_reset()                                            # a step is a whole "file": its own profile, summed over the ranks at its end
-            for ptr, off in batches:
-                ctx.upload_device(ptr, off)
-                ctx.encode()
-                ctx.sort_and_range()
-                ctx.lookup_score(want, False)
         reduce_profile()
 
     def fence():
@@ -199,36 +227,77 @@ def measure(args, ctx, world, dist, share, torch, kdist, batches=None, comm=0):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        if batches is None:
-            ctx.profile_reset()
         step()
     fence()
+    # what the per-batch upload costs (geometry kernels, two scans, one 8-byte read-back), timed alone before the run
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.upload_resident(*batches[0])
+    ctx.synchronize()
+    upload_ms = (time.perf_counter() - t0) / 3 * 1e3
+    fence()
     ctx.stage_reset()
-    if batches is None:
-        ctx.profile_reset()
+    acc["reduce_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ctx.synchronize()
+    mine = time.perf_counter() - t0                                        # this rank's own time, before it waits for the others
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else "cuda")
+    res = {"dt": dt, "rank_s": [mine], "reduce_ms_per_step": acc["reduce_s"] / max(1, args.steps) * 1e3}
+    if dist is not None and world > 1:
+        dev = "cpu" if share else "cuda"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    return dt
+        res["dt"] = float(tmax.item())
+        every = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, torch.tensor([mine, acc["reduce_s"]], dtype=torch.float64, device=dev))
+        res["rank_s"] = [float(t[0].item()) for t in every]
+        res["reduce_ms_per_step"] = max(float(t[1].item()) for t in every) / max(1, args.steps) * 1e3
+    res["upload_ms_per_batch"] = upload_ms
+    return res
 
 
-def report(args, ctx, reads, ix, world, dt, wide, pcie, reads_per_rank=None, n_batches=1, total_kmers=None, extra_cfg=None):
+def source_sha16():
+    """What the committed PMC / profile files are stamped with: a hash of the kernel sources (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("kasa_hip.hip", "kasa_radix.h", "kasa_text.h", "stdsort_order.h"):
+        with open(os.path.join(ROOT, "kasa_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def scatter_bound(n_q, avg_ms, rec_words):
+    """group_kernel ends in one random record store per query; tools/scatter_probe.hip measured what this chip takes
+    (profiles/r04_scatter_probe.json): the second bound of the roofline object."""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "r04_scatter_probe.json")))["rows"]
+    except Exception:
+        return None
+    want = ("scatter, whole buffer, 256-thread workgroups", 32) if rec_words == 8 else \
+           ("scatter of 64-byte records, lane per record, stored by quads through LDS (4 instructions of 16 records)", 64)
+    peak = [r["g_records_per_s"] for r in rows if r["what"] == want[0] and r["record_bytes"] == want[1]]
+    if not peak or not avg_ms:
+        return None
+    achieved = n_q / (avg_ms * 1e-3) / 1e9
+    return {"bound": "scatter", "kernel": "group_kernel", "peak": peak[0], "unit": "G records/s", "achieved": achieved, "frac": achieved / peak[0],
+            "source": "profiles/r04_scatter_probe.json: \"%s\", %d-byte records into a 34 GB buffer" % want}
+
+
+def report(args, ctx, reads, ix, world, res, wide, n_reads, n_batches, scaling, extra_cfg=None, traffic=None):
+    """n_reads: reads of one rank per step (in n_batches batches); res: measure()'s times."""
     k_high, k_low = (25, 7) if wide else (12, 7)
     rec_bytes = 20 if wide else 12
+    dt = res["dt"]
     n_kmers = ctx.n_kmers                                                 # of the last batch: what the per-kernel byte counts refer to
     stages = ctx.stage_ms()
     kern = ctx.kernel_ms()
     stats = ctx.batch_stats()
     ca, cu, _ = ctx.profile()
-    n_reads = reads.n if reads_per_rank is None else reads_per_rank       # reads of one rank per step
-    kmers_step = n_kmers if total_kmers is None else total_kmers          # k-mers of one rank per step
-    identified = float(ca[-1].sum()) / max(1, args.steps if n_batches == 1 and world == 1 else world) / max(1, kmers_step)
+    kmers_step = n_reads * max(0, args.read_len - 3 * k_low + 1)          # windows of a read: len - 3 kLow + 1 (Read.hpp:36-57,1074-1077)
+    identified = float(ca[-1].sum()) / max(1, world) / max(1, kmers_step)
     value = n_reads * world * args.steps / dt
     kb = kernel_bytes(n_kmers, ix.n, rec_bytes, ctx.rec_words, stats)
     kernels = {}
@@ -239,45 +308,96 @@ def report(args, ctx, reads, ix, world, dt, wide, pcie, reads_per_rank=None, n_b
                              "achieved": kb[name] / (avg * 1e-3) / 1e9, "frac": kb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # the roofline line is the kernel with the largest share of the step
     dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"]) if kernels else None
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r03_kernel_pmc.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r02_kernel_pmc.json")
-    if dom and os.path.exists(pmc) and not wide and n_reads == 10_000_000 and n_batches == 1:   # measured for that workload only (rocprofv3 --pmc passes, tools/make_profiles.py)
-        try:
-            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
     per_batch_reads = n_reads // max(1, n_batches)
     sb = stage_bytes(n_kmers, per_batch_reads * args.read_len, ix.n, rec_bytes, ctx.rec_words, stats)
     sb = {k: v * n_batches for k, v in sb.items()}
+    roof = dict({"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}, **(kernels.get(dom, {})))
+    if "group_kernel" in kernels:
+        sc = scatter_bound(n_kmers, kernels["group_kernel"]["avg_launch_ms"], ctx.rec_words)
+        if sc:
+            roof["second_bound"] = sc
+    rank_ms = [t / args.steps * 1e3 for t in res["rank_s"]]
     out = {
         "metric": "reads/s in identify (10M x 150bp vs k=12 index)" if not wide else
                   "reads/s in identify (150bp reads vs k<=25 128-bit index)", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u128" if wide else "u64",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u128" if wide else "u64",
         "data": "synthetic",
         "config": dict({"workload": (f"{n_reads} synthetic {args.read_len} bp reads per GPU" if world == 1 else
-                                     f"{n_reads * world} synthetic {args.read_len} bp reads in all, {n_reads} per GPU in {n_batches} "
-                                     f"batch{'es' if n_batches > 1 else ''}") +
+                                     f"{n_reads * world} synthetic {args.read_len} bp reads in all, {n_reads} per GPU") +
+                                    f" in {n_batches} batch{'es' if n_batches > 1 else ''} resident in HBM" +
                                     f" vs {ix.n}-record ({ix.n * rec_bytes / 1e9:.1f} GB) "
                                     + ("k<=25 128-bit index, -k 25 7, 3 frames, " if wide else "k<=12 64-bit index, -k 12 7, 3 frames, ") +
                                     f"{'profile only' if args.profile_only else 'profile + per-read scores'}",
+                        "step": "per batch: kasa_batch_upload_device (read geometry on the device, no PCIe) + encode + sort + lookup + group + score"
+                                + ("; then one all-reduce of the profile tables" if world > 1 else ""),
                         "reads_per_gpu": n_reads, "batches_per_step": n_batches, "kmers_per_gpu": kmers_step, "index_records": int(ix.n),
                         "taxa": args.taxa, "parallelism": f"read-sharded x{world}, index replicated"}, **(extra_cfg or {})),
         "kmers_per_s": kmers_step * world * args.steps / dt,
         "identified_fraction": identified,
+        "rank_step_ms": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+        "reduce_ms_per_step": res["reduce_ms_per_step"], "upload_ms_per_batch": res["upload_ms_per_batch"],
         "batch": stats,
         "stage_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stages.items()},
         "stage_algorithmic_gbps": {k: (b / (stages[k][0] / max(1, args.steps) * 1e-3) / 1e9 if stages.get(k, (0,))[0] > 0 else None)
                                    for k, b in sb.items()},
-        "roofline": dict({"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic},
-                         **(kernels.get(dom, {}))),
+        "roofline": roof,
         "kernels": kernels,
     }
-    if pcie is not None:
-        out["e2e"] = pcie
     return out
+
+
+def pmc_traffic(args, wide, kernel, live=True):
+    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this file under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950), one step of the
+    same workload each.  The caller has released its device memory.  Falls back to the committed passes of the same kernel
+    sources (profiles/r04_kernel_pmc.json, stamped with source_sha16) and says which."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    want = {"score_other_kernel": "score_other_flat", "row_merge_kernel": "row_merge_bitmap_kernel"}.get(kernel, kernel)
+    got = {}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if live and os.path.exists(exe):
+        d = tempfile.mkdtemp(prefix="kasa_pmc_")
+        try:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                dd = os.path.join(d, counter)
+                cmd = [exe, "--pmc", counter, "--kernel-include-regex", want, "--output-format", "csv", "-d", dd, "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc",
+                       "--reads", str(args.reads), "--taxa", str(args.taxa), "--genome-len", str(args.genome_len), "--read-len", str(args.read_len)]
+                if wide:
+                    cmd.append("--wide")
+                env = dict(os.environ, TMPDIR="/tmp")
+                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                    env.pop(k, None)
+                subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, cwd="/tmp")
+                vals = []
+                for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row["Counter_Name"] == counter and want in row["Kernel_Name"]:
+                            vals.append(float(row["Counter_Value"]))
+                if vals:
+                    got[counter] = max(vals)                               # the largest dispatch: the batch (the index build launches some kernels too)
+        except Exception as ex:
+            got["error"] = str(ex)[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
+        return {"traffic": got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024,
+                "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child passes of one step each; FETCH_SIZE x 2, gfx950)"}
+    if (args.reads, args.taxa, args.genome_len, args.read_len) != (10_000_000, 1400, 300_000, 150):
+        return {"traffic": None, "traffic_source": "none: the committed counter passes are of the default workload"}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_kernel_pmc.json" if not wide else "r04_kernel_pmc_wide.json")))
+        if pmc.get("source_sha16") != source_sha16():
+            return {"traffic": None, "traffic_source": "none: rocprofv3 pass failed here (%s) and profiles/r04_kernel_pmc*.json was taken from other kernel sources" % got.get("error", "no counters")}
+        return {"traffic": pmc.get(kernel, {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/r04_kernel_pmc%s.json (same kernel sources, source_sha16 %s)" % ("_wide" if wide else "", pmc["source_sha16"])}
+    except Exception:
+        return {"traffic": None, "traffic_source": "none"}
 
 
 def pcie_inclusive(ctx, reads, want, ix, k_high):
@@ -522,7 +642,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads of the one batch at N = 1; the largest batch at N > 1")
-    ap.add_argument("--total-reads", type=int, default=100_000_000, help="N > 1 (BASELINE.json configs[3]): reads of all ranks together")
+    ap.add_argument("--total-reads", type=int, default=None, help="reads of all ranks together, taken in batches of at most --reads (\"strong\"); default: --reads on every rank (\"weak\")")
+    ap.add_argument("--c4-reads", type=int, default=100_000_000, help="N > 1: total reads of the `c4` leg (BASELINE.json configs[3])")
+    ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the `c4` leg")
+    ap.add_argument("--no-tertiary", action="store_true", help="skip the crowded-index workload")
+    ap.add_argument("--crowded-reads", type=int, default=2_000_000, help="reads of the crowded-index batch (its (event, taxon) contributions per read are ten times the headline's)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes for roofline.traffic")
+    ap.add_argument("--pmc-secondary", action="store_true", help="also measure the 128-bit leg's traffic live (two more child passes)")
     ap.add_argument("--taxa", type=int, default=1400)
     ap.add_argument("--genome-len", type=int, default=300_000)
     ap.add_argument("--read-len", type=int, default=150)
@@ -603,67 +729,57 @@ def main():
 
     holder = {}
 
-    def one(wide):
+    def one(wide, workload="pairs", total_reads=None, legs=True):
+        """One measurement: index (wide: 128-bit, -k 25 7) + the rank's reads resident in HBM + measure().
+        workload: "pairs" (sibling genomes, BASELINE's synthetic database) or "crowded" (clades sharing conserved genes);
+        total_reads: None = --reads on every rank (weak), else that many over all ranks in batches of at most --reads (strong)."""
         k_high, k_low = (25, 7) if wide else (12, 7)
         rec_bytes = 20 if wide else 12
         t0 = time.perf_counter()
-        g = synth.genomes(args.taxa, args.genome_len, seed=11)
+        if workload == "crowded":
+            g = synth.genomes_crowded(args.taxa, args.genome_len, seed=11)
+        else:
+            g = synth.genomes(args.taxa, args.genome_len, seed=11)
         ix = synth.index_from_genomes(g, device=local_rank, K=25 if wide else 12)
-        log(f"[rank {rank}] index: {ix.n} records ({ix.n * rec_bytes / 1e9:.2f} GB on disk layout), "
+        log(f"[rank {rank}] {workload} index: {ix.n} records ({ix.n * rec_bytes / 1e9:.2f} GB on disk layout), "
             f"{ix.trie_prefix.shape[0]} prefixes, {time.perf_counter() - t0:.1f} s")
         t0 = time.perf_counter()
         dix = capi.DeviceIndex(ix, local_rank, check_trie=True)
         ctx = capi.Context(dix, k_high, k_low, 3)
         if args.debug_flags:
             ctx.debug_flags(args.debug_flags)
-        batches, dev_reads, extra_cfg = None, None, None
-        if world == 1:
-            reads = synth.reads_from_genomes(g, args.reads, args.read_len, seed=1000 + rank)
-            per_rank, n_batches, total_kmers = reads.n, 1, None
-            ctx.upload(reads.bases, reads.offsets)         # inputs resident in HBM before the timed region
-        else:
-            # C4: the rank's share of the 100 M reads lies in HBM as one tensor; a step takes it in batches of at most --reads
-            per_rank = args.total_reads // world
-            n_batches = max(1, -(-per_rank // args.reads))
-            per_batch = -(-per_rank // n_batches)
-            L = args.read_len
-            dev_reads = torch.empty(per_rank * L, dtype=torch.uint8, device="cuda")
-            reads = None
-            done = 0
-            while done < per_rank:
-                m = min(args.reads, per_rank - done)
-                part = synth.reads_from_genomes(g, m, L, seed=1000 + rank * 97 + done // max(1, args.reads))
-                dev_reads[done * L:(done + m) * L].copy_(torch.from_numpy(part.bases))
-                if reads is None:
-                    reads = part                             # (kept for the report's shapes)
-                done += m
-            torch.cuda.synchronize()
-            batches = []
-            for b in range(n_batches):
-                a0, a1 = b * per_batch, min(per_rank, (b + 1) * per_batch)
-                batches.append((dev_reads.data_ptr() + a0 * L, np.arange(a1 - a0 + 1, dtype=np.int64) * L))
-            total_kmers = per_rank * max(0, L - 3 * k_low + 1)          # windows of a read: len - 3 kLow + 1 (Read.hpp:36-57,1074-1077)
-            extra_cfg = {"total_reads": per_rank * world, "reduce": reduce_how, "rccl_ranks": rccl_ranks}
+        n_reads = args.reads if workload != "crowded" else min(args.reads, args.crowded_reads)
+        per_rank = n_reads if total_reads is None else max(1, total_reads // world)
+        keep, batches, reads = resident_batches(torch, synth, g, per_rank, n_reads, args.read_len, 1000 + rank * 97)
+        n_batches = len(batches)
+        extra_cfg = {"database": workload}
+        if world > 1:
+            extra_cfg.update({"total_reads": per_rank * world, "reduce": reduce_how, "rccl_ranks": rccl_ranks})
         log(f"[rank {rank}] reads: {per_rank} x {args.read_len} bp in {n_batches} batch(es), {time.perf_counter() - t0:.1f} s")
-        dt = measure(args, ctx, world, dist, share, torch, kdist, batches, comm)
-        pcie = None
+        res = measure(args, ctx, world, dist, share, torch, kdist, batches, comm)
         out = None
         if rank == 0:
-            out = report(args, ctx, reads, ix, world, dt, wide, None, per_rank, n_batches, total_kmers, extra_cfg)
-            if world == 1 and not args.no_e2e:
+            out = report(args, ctx, reads, ix, world, res, wide, per_rank, n_batches, "weak" if total_reads is None else "strong", extra_cfg)
+            if legs and world == 1 and not args.no_e2e and workload == "pairs":
                 try:                                               # an extra pass: it must never cost the headline line
-                    pcie = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
+                    out["e2e"] = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
                 except Exception as ex:                            # e.g. no memory left for the page-locked buffers
-                    pcie = {"error": str(ex)[:300]}
-                out["e2e"] = pcie
+                    out["e2e"] = {"error": str(ex)[:300]}
         ctx.close()
         dix.close()
-        del dev_reads
-        if rank == 0 and world == 1 and not wide:
+        del keep, batches
+        torch.cuda.empty_cache()
+        if rank == 0 and world == 1 and not wide and legs and workload == "pairs":
             holder["ix"], holder["reads"], holder["k"] = ix, reads, (k_high, k_low)
+        if rank == 0 and world == 1 and out["roofline"].get("kernel") and workload == "pairs":
+            # HBM bytes of the dominant kernel from the counters (the device is free now)
+            live = not args.no_pmc and (args.pmc_secondary if (wide and not args.wide) else True)
+            out["roofline"].update(pmc_traffic(args, wide, out["roofline"]["kernel"], live))
         return out
 
-    out = one(args.wide)
+    KEEP = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "kmers_per_s", "identified_fraction", "rank_step_ms",
+            "reduce_ms_per_step", "upload_ms_per_batch", "batch", "stage_ms_per_step", "roofline", "kernels")
+    out = one(args.wide, total_reads=args.total_reads)
     if rank == 0 and world == 1 and not args.wide:
         ix, reads, (k_high, k_low) = holder["ix"], holder["reads"], holder["k"]
         if not args.no_e2e and not args.no_f2f:
@@ -677,10 +793,20 @@ def main():
         holder.clear()
         del ix, reads
     if world == 1 and not args.wide and not args.no_secondary:
-        sec = one(True)
+        sec = one(True, legs=False)
         if rank == 0 and out is not None and sec is not None:
-            out["secondary"] = {k: sec[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "kmers_per_s",
-                                                    "identified_fraction", "batch", "stage_ms_per_step", "roofline", "kernels")}
+            out["secondary"] = {k: sec[k] for k in KEEP}
+    if world == 1 and not args.wide and not args.no_tertiary:
+        try:
+            ter = one(False, workload="crowded", legs=False)
+        except Exception as ex:                                     # never lose the headline to the extra workload
+            ter = {"error": str(ex)[:400]}
+        if rank == 0 and out is not None and ter is not None:
+            out["tertiary"] = {k: ter[k] for k in KEEP} if "error" not in ter else ter
+    if world > 1 and args.total_reads is None and not args.no_c4:
+        c4 = one(args.wide, total_reads=args.c4_reads, legs=False)   # BASELINE.json configs[3]: 100 M reads in all ("strong")
+        if rank == 0 and out is not None and c4 is not None:
+            out["c4"] = {k: c4[k] for k in KEEP}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if comm:

@@ -106,6 +106,13 @@ int kasa_ctx_set_protein(kasa_ctx *ctx, int protein);
  * `offsets` is host memory. */
 int kasa_batch_upload(kasa_ctx *ctx, const uint8_t *bases, const int64_t *offsets, int64_t nReads);
 
+/* The same for a host that keeps the reads of a whole file resident in HBM (bench.py's steps at every N, a pipeline that
+ * parses on the device): `basesDev` AND `offsetsDev` (int64[nReads+1], relative to basesDev) lie in device memory.  Nothing
+ * crosses PCIe and the bases are NOT copied: the context reads them in place, so they must stay valid and unchanged until
+ * the batch's last call (kasa_batch_coherence re-reads them).  What is left of the upload is the geometry of Read.hpp:36-57,
+ * 633-675 on the device (k-mers per read, running sums) and one 8-byte read-back of the batch's k-mer count. */
+int kasa_batch_upload_device(kasa_ctx *ctx, const uint8_t *basesDev, const int64_t *offsetsDev, int64_t nReads);
+
 /* The same for reads made of several sequences: paired-end input (-1/-2; Read::readFastqa_pairedEnd,
  * Read.hpp:834-1049) hands both mates of a pair on as two entries of vLines with ONE read id, so their
  * k-mers score into the same row and none spans the junction.  offsets[nSegments+1] delimit the
@@ -255,6 +262,10 @@ int kasa_text_dtoa(int device, const double *values, uint32_t n, char *out);
 /* Page-locked host memory for buffers that cross PCIe (reads in, ranked hits or CSR out).  NULL when it cannot be had. */
 void *kasa_host_alloc(size_t bytes);
 void kasa_host_free(void *p);
+/* Binds the CALLING host thread to a device.  A fresh thread stands on device 0, and kasa_host_alloc page-locks for the
+ * thread's current device: a helper thread that prepares a worker's buffers calls this first (the kasa_ctx_* / kasa_batch_*
+ * calls select their context's device themselves). */
+int kasa_thread_device(int device);
 
 /* ---- profile tables: vCount_all / vCount_unique / vCount_total (Compare.hpp:2830-2839) ---------- */
 int kasa_profile_reset(kasa_ctx *ctx);

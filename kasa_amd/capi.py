@@ -19,14 +19,14 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
-    "kasa_index_device_bytes", "kasa_builtin_codon_table", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_segments", "kasa_batch_encode",
+    "kasa_index_device_bytes", "kasa_builtin_codon_table", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_device", "kasa_batch_upload_segments", "kasa_batch_encode",
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs", "kasa_profile_allreduce",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
-    "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free",
+    "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
     "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve",
@@ -309,6 +309,12 @@ class Context:
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self.n_reads = int(offsets.shape[0] - 1)
         _check(lib().kasa_batch_upload(self.h, C.c_void_p(bases_ptr), _p(offsets), C.c_int64(self.n_reads)))
+
+    def upload_resident(self, bases_ptr: int, offsets_ptr: int, n_reads: int):
+        """kasa_batch_upload_device: bases AND offsets (int64[n_reads + 1]) lie in device memory and are read in place --
+        nothing crosses PCIe; the caller keeps both alive until the batch is done."""
+        self.n_reads = int(n_reads)
+        _check(lib().kasa_batch_upload_device(self.h, C.c_void_p(bases_ptr), C.c_void_p(offsets_ptr), C.c_int64(self.n_reads)))
 
     def profile_allreduce(self, comm: int):
         """kasa_profile_allreduce: the profile tables summed over the ranks of an RCCL communicator (ncclComm_t as an

@@ -4,12 +4,14 @@
 // LDS for the per-tile scans, everything resident in HBM between stages.
 //
 // Pipeline of one batch (reference lines in include/kasa_hip.h and DESIGN.md):
-//   encode  : reads -> packed 5-bit-letter k-mers (+ read id)                       [encode_kernel]
-//   sort    : LSD radix sort of (k-mer, read) on the 5*K key bits                    [rocPRIM onesweep]
-//   lookup  : two-level prefix table + binary search in the HBM-resident index      [lookup_kernel]
-//   group   : per k level: query groups, taxon sets of the index groups, flush order [group_kernel]
-//   regroup : stable sort of sorted positions by read id                            [rocPRIM]
-//   score   : per read, events replayed in the reference's flush order (float32)    [score_kernel]
+//   encode  : reads -> packed 5-bit-letter k-mers; payload = the query's slot in the read-major record array  [encode_kernel]
+//   sort    : stable LSD radix sort of (k-mer, slot): five hand-written 8-bit passes over the top 40 key bits
+//             (kasa_radix.h) + a rank inside the remaining buckets                                           [pass_kernel, bucket_rank32_kernel]
+//   lookup  : two-level prefix table + the tile's index span in LDS: deepest matched level, an index position   [lookup_tile_kernel]
+//   group   : per query: flush positions of its levels, their order, taxon segments -> one record, to its slot  [group_kernel]
+//   score   : per read, records replayed in the reference's flush order (float32); profile tables in integers   [score_main_kernel,
+//             score_other_flat_kernel, row_merge_*, profile_table_kernel; score_kernel for the general case]
+//   then, outside the scored path: ranking, per-read text, --coherence                                         [rank_*, text_*, coh_*]
 //
 // The semantics implemented are the closed form of SURVEY.md section 0.1; tests compare every stage with
 // the CPU oracle (oracle/), which is itself pinned to the reference binary's outputs.
@@ -506,6 +508,7 @@ struct kasa_ctx {
     bool haveScores = false;
     DevBuf rankDen, rankClass, rankMeta, rankOut, rankList, rankScratch; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
     bool rankValid = false; uint32_t rankFlagged = 0;          // ... of THIS batch; reads it left to the host
+    uint32_t rankClasses = 0;                                  // denominator rows kasa_batch_rank was given (kasa_batch_text's bestScore has as many)
     DevBuf taxText, taxTextOff, taxTextIds;                    // kasa_ctx_set_taxa_text: names back to back, u64[nTaxa + 1], u32[nTaxa]
     bool haveTaxText = false;
     DevBuf txtNames, txtNameOff, txtLen, txtBest, txtBytes, txtOff, txtOut, txtFlags;   // kasa_batch_text
@@ -516,6 +519,7 @@ struct kasa_ctx {
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
     // buffers
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
+    const uint8_t *basesPtr = nullptr;         // the batch's bases: bases.p, or the caller's own device memory (kasa_batch_upload_device)
     DevBuf seqOff, seqRead;                    // u64[nSeq+1] k-mer offset of every uploaded sequence, u32[nSeq] its read
     int64_t nSeq = 0; bool haveSeqRead = false;
     DevBuf qKmerA, qKmerB, qReadA, qReadB;     // double buffers of the query arrays
@@ -742,7 +746,8 @@ __global__ void upload_max_kernel(const uint64_t *__restrict__ readCnt, int64_t 
 // Paired-end input hands both mates of a pair over as two sequences of one read (Read.hpp:834-1049): their k-mers
 // carry the same read id, none spans the junction.  The host only copies: the tables (offsets relative to the batch,
 // k-mers before every sequence and read) are made on the device -- the host loop over ten million reads took 0.1 s.
-static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSeq, const uint32_t *seqRead, int64_t nReads)
+// resident: `bases` and `offsets` both lie in device memory and stay the caller's; the bases are read in place.
+static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSeq, const uint32_t *seqRead, int64_t nReads, bool resident = false)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (nSeq < 0 || nReads < 0 || (nSeq > 0 && (!offsets || !bases))) return fail(KASA_E_ARG, "kasa_batch_upload: bad arguments");
@@ -750,16 +755,26 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     HIPCHK(hipSetDevice(c->ix->device));
     c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
     const int64_t zero = 0;
-    if (nSeq == 0) offsets = &zero;
-    if (offsets[nSeq] < offsets[0]) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
-    const uint64_t nBases = (uint64_t)(offsets[nSeq] - offsets[0]);
+    if (nSeq == 0) { offsets = &zero; resident = false; }
+    int64_t ends[2] = {0, 0};                                               // offsets[0], offsets[nSeq]
+    if (resident) {
+        HIPCHK(hipMemcpyAsync(&ends[0], offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&ends[1], offsets + nSeq, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else { ends[0] = offsets[0]; ends[1] = offsets[nSeq]; }
+    if (ends[1] < ends[0]) return fail(KASA_E_ARG, "kasa_batch_upload: offsets are not ascending");
+    const uint64_t nBases = (uint64_t)(ends[1] - ends[0]);
     int rc;
-    if ((rc = c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nSeq + 1) * 8)) ||
+    if ((rc = resident ? KASA_OK : c->bases.reserve(nBases + 64)) || (rc = c->baseOff.reserve(((size_t)nSeq + 1) * 8)) ||
         (rc = c->kmerOff.reserve(((size_t)nReads + 1) * 8)) || (rc = c->seqOff.reserve(((size_t)nSeq + 1) * 8)) ||
         (rc = c->seqRead.reserve((size_t)nSeq * 4 + 64)) || (rc = c->rawOff.reserve(((size_t)nSeq + 1) * 8)))
         return rc;
-    if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + offsets[0], nBases, hipMemcpyDefault, c->stream));   // `bases` may live in device memory (a host that keeps its reads in HBM)
-    HIPCHK(hipMemcpyAsync(c->rawOff.p, offsets, ((size_t)nSeq + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (resident) c->basesPtr = bases + ends[0];
+    else {
+        if (nBases) HIPCHK(hipMemcpyAsync(c->bases.p, bases + ends[0], nBases, hipMemcpyDefault, c->stream));   // `bases` may live in device memory (a host that keeps its reads in HBM)
+        c->basesPtr = c->bases.as<uint8_t>();
+    }
+    HIPCHK(hipMemcpyAsync(c->rawOff.p, offsets, ((size_t)nSeq + 1) * 8, resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     c->haveSeqRead = seqRead != nullptr;
     if (seqRead && nSeq) HIPCHK(hipMemcpyAsync(c->seqRead.p, seqRead, (size_t)nSeq * 4, hipMemcpyHostToDevice, c->stream));
     // device: counts, checks, running sums
@@ -800,6 +815,11 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
 extern "C" int kasa_batch_upload(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nReads)
 {
     KASA_GUARDED(upload_impl(c, bases, offsets, nReads, nullptr, nReads))
+}
+
+extern "C" int kasa_batch_upload_device(kasa_ctx *c, const uint8_t *basesDev, const int64_t *offsetsDev, int64_t nReads)
+{
+    KASA_GUARDED(upload_impl(c, basesDev, offsetsDev, nReads, nullptr, nReads, true))
 }
 
 extern "C" int kasa_batch_upload_segments(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets, int64_t nSegments,
@@ -979,19 +999,19 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     if (c->nSeq > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide && rankSlots && c->maxCnt <= 192u)
-            encode_kernel<key128, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+            encode_kernel<key128, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                 c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
         else if (c->ix->wide)
-            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                 c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
         else if (rankSlots && c->maxCnt <= 192u)
-            encode_kernel<uint64_t, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+            encode_kernel<uint64_t, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                 c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
         else
-            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(),
+            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                 c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
         HIPCHK(hipGetLastError());
@@ -1837,8 +1857,12 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     // the index entries the tile's walks visit (their taxa and neighbour counts), staged once: the walks are chains of
     // dependent reads, from LDS they cost tens of cycles instead of a trip to L2/HBM each
     typedef typename KeyTraits<Key>::Meta Meta;
-    __shared__ uint32_t sTax[GSPAN];
-    __shared__ Meta sMeta[GSPAN];
+    __shared__ uint32_t sTax[RW == 16 ? 1 : GSPAN];                  // (64-byte records read the index from global memory: spanN = 0 below)
+    __shared__ Meta sMeta[RW == 16 ? 1 : GSPAN];
+    // 64-byte records leave through LDS: a lane owns a record, FOUR lanes store it -- one store instruction then touches 16
+    // whole 64-byte cells instead of a quarter of 64 (tools/scatter_probe.hip: 19 G records/s lane by lane, 4 instructions
+    // of 64 partial cells each; by quads the chip takes them at the rate of its address path)
+    __shared__ uint4 sOut[RW == 16 ? GTHREADS * 4 : 1];
     __shared__ uint32_t sRepLo[GTHREADS / 64], sRepHi[GTHREADS / 64];
     // narrow records: the segments beyond the inline ones wait here until the workgroup's pool block is allocated (one walk
     // per query instead of two); {segment, owner query | index in its pool list << 10}
@@ -2089,16 +2113,30 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     for (int i = 0; i < GITEMS; ++i) {
         const uint32_t p = base + i;
         if (p >= nQ) continue;
-        const uint32_t slot = slotOf ? slotOf[p] : p;
-        uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * RW);
         if constexpr (RW == 8) {
+            const uint32_t slot = slotOf ? slotOf[p] : p;
+            uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * RW);
             o[0] = make_uint4(p, fmax[i], w2[i], w3[i]);
             o[1] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
-        } else {
-            o[0] = make_uint4(p, fmax[i], w2[i], w3[i]);
-            o[1] = make_uint4((uint32_t)ord[i], (uint32_t)(ord[i] >> 32), (uint32_t)(ord[i] >> 64), (uint32_t)(ord[i] >> 96));
-            o[2] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
-            o[3] = make_uint4(seg[i][4], seg[i][5], seg[i][6], seg[i][7]);
+        }
+    }
+    if constexpr (RW == 16) {
+        uint4 *mine = sOut + wv * 256;
+#pragma unroll
+        for (int i = 0; i < GITEMS; ++i) {
+            const uint32_t p = base + i;
+            const uint32_t slot = p < nQ ? (slotOf ? slotOf[p] : p) : NOPOS;
+            mine[lane * 4 + 0] = make_uint4(p, fmax[i], w2[i], w3[i]);
+            mine[lane * 4 + 1] = make_uint4((uint32_t)ord[i], (uint32_t)(ord[i] >> 32), (uint32_t)(ord[i] >> 64), (uint32_t)(ord[i] >> 96));
+            mine[lane * 4 + 2] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
+            mine[lane * 4 + 3] = make_uint4(seg[i][4], seg[i][5], seg[i][6], seg[i][7]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                            // instruction k: the records of lanes 16k .. 16k+15, a quad each
+                const uint32_t sk = (uint32_t)__shfl((int)slot, 16 * k + (lane >> 2));
+                if (sk != NOPOS) reinterpret_cast<uint4 *>(rec + (size_t)sk * RW)[lane & 3] = mine[k * 64 + lane];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -4836,6 +4874,12 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
     if (nClasses == 0) return fail(KASA_E_ARG, "kasa_batch_rank: no denominator rows");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint32_t nTaxa = c->ix->nTaxa, nReads = (uint32_t)c->nReads;
+    {   // the class ids index den[] here and bestScore[] in kasa_batch_text: an id out of range would read device memory out of bounds
+        uint32_t top = 0;
+        for (uint32_t r = 0; r < nReads; ++r) top = readClass[r] > top ? readClass[r] : top;
+        if (nReads && top >= nClasses) return fail(KASA_E_ARG, "kasa_batch_rank: readClass names class %u of %u", top, nClasses);
+    }
+    c->rankClasses = nClasses;
     int rc;
     if ((rc = c->rankDen.reserve((size_t)nClasses * nTaxa * 8)) || (rc = c->rankClass.reserve((size_t)nReads * 4 + 64)) ||
         (rc = c->rankMeta.reserve((size_t)nReads * 16 + 64)))
@@ -4940,6 +4984,7 @@ extern "C" int kasa_batch_text(kasa_ctx *c, const kasa_text_params *tp, uint64_t
     if (!c->haveTaxText) return fail(KASA_E_STATE, "kasa_batch_text: no taxon names (kasa_ctx_set_taxa_text)");
     if (tp->format < 0 || tp->format > 3) return fail(KASA_E_ARG, "kasa_batch_text: unknown format");
     if (!tp->readNameOff || !tp->readLen || !tp->bestScore || tp->nClasses == 0) return fail(KASA_E_ARG, "kasa_batch_text: NULL argument");
+    if (tp->nClasses != c->rankClasses) return fail(KASA_E_ARG, "kasa_batch_text: %u classes, but kasa_batch_rank was given %u (the class ids of the reads are its)", tp->nClasses, c->rankClasses);
     if (tp->coherence && !c->cohScores) return fail(KASA_E_STATE, "kasa_batch_text: no coherence scores of this batch (kasa_batch_coherence)");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint32_t nReads = (uint32_t)c->nReads;
@@ -5104,7 +5149,10 @@ __device__ unsigned long long coh_walk(CohCursor &C, const uint8_t *__restrict__
 {
     fail = false;
     for (uint32_t r = r0; r < r1; ++r) scores[r] = 0.0f;
-    if (firstIdx == COH_NONE || r1 <= firstRead) return entry;         // no match at all, or none before this chunk ends: no turn
+    // no match at all, or none before this chunk ends: no turn.  Nothing of it reaches the reads behind (the first-match turn
+    // sets its own entry), so the exit is what the next chunk assumed -- returning `entry` made every such chunk's successor
+    // walk again, one per round: as many rounds as there are chunks before the first match
+    if (firstIdx == COH_NONE || r1 <= firstRead) return C.off[r1];
     uint32_t rid = r0, last = 0xFFFFFFFFu, cur = 0, cnt = 0;
     if (r0 <= firstRead) { rid = firstRead; last = firstLast; entry = firstIdx + 1ull; }
     C.seek(entry);
@@ -5203,12 +5251,12 @@ extern "C" int kasa_batch_coherence(kasa_ctx *c, float *scores, uint64_t *throws
     if (nE > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide) {
-            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
+            encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
                 c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0);
             coh_depth_kernel<key128><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<key128>(), nE, c->ix->kmer.as<key128>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
         } else {
-            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->bases.as<uint8_t>(), c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
+            encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
                 c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0);
             coh_depth_kernel<uint64_t><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<uint64_t>(), nE, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
@@ -5248,6 +5296,11 @@ extern "C" void *kasa_host_alloc(size_t bytes)
     return p;
 }
 extern "C" void kasa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+extern "C" int kasa_thread_device(int device)
+{
+    HIPCHK(hipSetDevice(device));
+    return KASA_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // profile tables

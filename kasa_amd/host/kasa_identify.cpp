@@ -389,10 +389,10 @@ static void parseRecords(const char *data, size_t begin, size_t end, bool fasta,
 // First record start at or after `from` that is safe to cut at (N1: the input is parsed by several threads).  FASTA: a
 // line starting with '>'.  FASTQ: a line starting with '@' whose third line starts with '+' and whose fourth line is as
 // long as its second -- a quality line that happens to start with '@' fails that test.  npos: none found nearby.
-static size_t findRecordStart(const char *data, size_t size, size_t from, bool fasta)
+static size_t findRecordStart(const char *data, size_t size, size_t from, bool fasta, size_t span = 1u << 20)
 {
     const size_t npos = string::npos;
-    const size_t limit = std::min(size, from + (1u << 20));
+    const size_t limit = span >= size - std::min(size, from) ? size : from + span;
     size_t p = from;
     while (p < limit) {
         const void *nl = memchr(data + p, '\n', limit - p);
@@ -565,13 +565,19 @@ struct ChunkReader {
             }
             if (eof) break;
             // cut at the last safe record start; what follows waits for the next block
+            // (looked for in the last 4 MiB first; a record longer than that -- a contig, a long read -- sends the search over
+            // the whole buffer instead of letting block after block pile up behind it)
             size_t cut = string::npos, from = have > (4u << 20) ? have - (4u << 20) : 0;
-            for (;;) {
-                const size_t p = findRecordStart(D.data(), have, from, fasta);
-                if (p == string::npos) break;
-                cut = p; from = p;
+            for (int pass = 0; pass < 2 && cut == string::npos; ++pass) {
+                for (;;) {
+                    const size_t p = findRecordStart(D.data(), have, from, fasta, have - from);
+                    if (p == string::npos) break;
+                    cut = p; from = p;
+                }
+                if (from == 0) break;
+                if (cut == string::npos) from = 0;
             }
-            if (cut == string::npos || cut == 0) continue;          // no boundary in sight: keep reading behind what is there
+            if (cut == string::npos || cut == 0) continue;          // ONE record so far: keep reading behind what is there
             HugeVec<char> &T = buf[cur ^ 1];
             T.reserve(have - cut + blockBytes);
             std::memcpy(T.data(), D.data() + cut, have - cut);
@@ -1412,7 +1418,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     // the page-locked text buffers are made while the first chunk is parsed
     std::thread textPrep;
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joinTextPrep{textPrep};
-    if (!p.rtt.empty() && !p.hostRank && !p.hostText) textPrep = std::thread([&wbs] { try { for (auto &w : wbs) w.prepareText(); } catch (...) {} });   // (what is missing is made, or fails, when a worker needs it)
+    if (!p.rtt.empty() && !p.hostRank && !p.hostText) textPrep = std::thread([&wbs, &p] { try { for (size_t i = 0; i < wbs.size(); ++i) { (void)kasa_thread_device(p.devices[i]); wbs[i].prepareText(); } } catch (...) {} });   // (a fresh thread stands on device 0: the buffers are page-locked for the worker's device)   // (what is missing is made, or fails, when a worker needs it)
     Batcher batcher(p, ixf, wantRows, maxKmersPerBatch);
     mark("first chunk parsed");
     p.protein = batcher.protein;

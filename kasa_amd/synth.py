@@ -28,6 +28,48 @@ def genomes(n_taxa: int, length: int, seed: int, divergence: float = 0.03) -> np
     return g
 
 
+def genomes_crowded(n_taxa: int, length: int, seed: int, clade_share: float = 0.30, universal_share: float = 0.05,
+                    clade_sizes=(50, 200), divergence=(0.01, 0.05), gene_len=(1000, 3000)) -> np.ndarray:
+    """u8[n_taxa, length]: taxa in clades of 50-200 that share conserved "genes" -- what real bacterial indices look like at
+    k = 7...9 (hard part 5; Compare.hpp:396-441,917-955 is where the reference pays for it).  A clade
+    has an ancestor and a set of gene intervals covering `clade_share` of the genome: every member copies those intervals
+    from the ancestor with its own 1-5 % of substitutions; `universal_share` of every genome comes the same way from ONE
+    universal ancestor; the rest is the taxon's own random sequence.  So a conserved k-mer at k = 7 sits in tens to
+    hundreds of taxa and at k = 12 in a handful."""
+    rng = np.random.default_rng(seed)
+
+    def intervals(share):
+        mask = np.zeros(length, dtype=bool)
+        want, guard = int(share * length), 0
+        while mask.sum() < want and guard < 100000:
+            n = int(rng.integers(gene_len[0], gene_len[1] + 1))
+            a = int(rng.integers(0, max(1, length - n)))
+            mask[a:a + n] = True
+            guard += 1
+        return mask
+
+    def mutated(src, mask, d):
+        out = src[mask].copy()
+        m = rng.random(out.shape[0]) < d
+        out[m] = _ACGT[rng.integers(0, 4, size=int(m.sum()))]
+        return out
+
+    g = np.empty((n_taxa, length), dtype=np.uint8)
+    universal = _ACGT[rng.integers(0, 4, size=length)]
+    umask = intervals(universal_share)
+    t = 0
+    while t < n_taxa:
+        size = min(n_taxa - t, int(rng.integers(clade_sizes[0], clade_sizes[1] + 1)))
+        ancestor = _ACGT[rng.integers(0, 4, size=length)]
+        cmask = intervals(clade_share) & ~umask
+        for x in range(t, t + size):
+            g[x] = _ACGT[rng.integers(0, 4, size=length)]
+            g[x, cmask] = mutated(ancestor, cmask, rng.uniform(*divergence))
+            g[x, umask] = mutated(universal, umask, rng.uniform(*divergence))
+        t += size
+    return g
+
+
 def content_for(n_taxa: int) -> formats.Content:
     return formats.Content(["non_unique"] + [f"Taxon {t}" for t in range(n_taxa)],
                            np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))

@@ -283,6 +283,37 @@ def test_device_coherence_many_chunks_and_quirks(frames, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("matches", [True, False], ids=["first_match_late", "no_match_at_all"])
+def test_device_coherence_first_match_late_in_a_large_batch(matches):
+    """Hundreds of thousands of reads that match nothing (thousands of chunks that take no turn) before the first matching read: the
+    chunks without a turn leave where their successor starts, so the fix-up settles in a round or two (advisor finding of
+    round 3: one round per chunk -- a launch, a copy and a synchronisation each)."""
+    import time
+    from tests.test_gpu_parity import synthetic_world
+    rng = np.random.default_rng(77)
+    ix, base = synthetic_world(411, 6, 6000, 400)
+    n_foreign = 300_000
+    foreign = np.full((n_foreign, 100), ord("N"), dtype=np.uint8)          # (random reads find chance matches at k = 7; these cannot)
+    tail = base.bases[:base.offsets[base.n]] if matches else np.zeros(0, dtype=np.uint8)
+    off = np.concatenate((np.arange(n_foreign + 1, dtype=np.int64) * 100,
+                          (n_foreign * 100 + base.offsets[1:base.n + 1]) if matches else np.zeros(0, dtype=np.int64))).astype(np.int64)
+    bases = np.concatenate((foreign.reshape(-1), tail))
+    p = oracle.params(12, 7, 3)
+    _, _, coh, _ = oracle.identify_batch_coherence(ix, bases, off, p, False)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(bases, off, True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    got = ctx.coherence()
+    dt = time.perf_counter() - t0
+    ctx.close(); dix.close()
+    assert np.array_equal(got.view(np.uint32), coh.view(np.uint32))
+    assert (coh > 0).any() == matches
+    assert dt < 2.0, f"{dt:.2f} s: the walk's fix-up rounds did not settle quickly"
+
+
+@pytest.mark.gpu
 def test_device_reports_where_the_reference_throws():
     d, ix = helpers.load_case("pairs")
     batch = reads.parse_reads(os.path.join(d, "reads.fastq"))

@@ -215,13 +215,34 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out["config"]["total_reads"] == 50000 and 0.5 < out["identified_fraction"] <= 1.0
 
 
+def test_bench_same_step_at_every_n(tmp_path):
+    """The default multi-GPU line: every rank runs the SAME resident batch loop as N = 1 (weak: --reads per rank, the reduce
+    is the only difference) and the line carries `c4` (BASELINE.json configs[3] in small: a fixed total, in batches), the
+    per-rank step times and the reduce time.  N = 1 with --total-reads goes through the same loop in several batches."""
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "8000", "--c4-reads", "30000",
+                  "--taxa", "8", "--genome-len", "20000", "--no-cpu"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["batches_per_step"] == 1 and out["config"]["reads_per_gpu"] == 8000
+    assert out["config"]["total_reads"] == 16000 and len(out["rank_step_ms"]["per_rank"]) == 2 and out["reduce_ms_per_step"] > 0
+    assert out["upload_ms_per_batch"] > 0 and 0.5 < out["identified_fraction"] <= 1.0
+    c4 = out["c4"]
+    assert c4["scaling"] == "strong" and c4["config"]["total_reads"] == 30000 and c4["config"]["batches_per_step"] == 2 and c4["value"] > 0
+    one = _bench(["--steps", "2", "--warmup", "1", "--reads", "8000", "--total-reads", "20000", "--taxa", "8", "--genome-len", "20000",
+                  "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"], share=False)
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["config"]["batches_per_step"] == 3 and one["reduce_ms_per_step"] == 0
+    assert 0.5 < one["identified_fraction"] <= 1.0
+
+
 def test_bench_default_line_carries_every_leg(tmp_path):
-    """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), the PCIe-inclusive and the
-    file-to-file rates, the CPU baseline with its one-thread rate -- all in the one JSON line."""
+    """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), `tertiary` (the crowded index), the
+    PCIe-inclusive and the file-to-file rates, the CPU baseline with its one-thread rate, the dominant kernel's HBM traffic from
+    counter passes run as children -- all in the one JSON line."""
     out = _bench(["--steps", "1", "--warmup", "1", "--reads", "30000", "--taxa", "8", "--genome-len", "20000",
-                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000", "--f2f-settle", "0"], share=False)
+                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000", "--f2f-settle", "0", "--crowded-reads", "10000"], share=False)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["dtype"] == "u64"
     assert out["secondary"]["dtype"] == "u128" and out["secondary"]["value"] > 0
+    assert out["tertiary"]["value"] > 0 and out["tertiary"]["config"]["database"] == "crowded" and out["tertiary"]["config"]["reads_per_gpu"] == 10000
+    assert out["roofline"]["traffic_source"] and out["roofline"]["second_bound"]["bound"] == "scatter"
+    assert out["roofline"]["traffic"] is None or out["roofline"]["traffic"] > 0
     e = out["e2e"]
     assert e["pcie_inclusive_reads_per_s"] > 0 and e["file_to_file_reads_per_s"] > 0 and e["batches"] >= 1
     c = out["cpu_baseline"]
