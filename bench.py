@@ -100,27 +100,27 @@ def kernel_bytes(n_q, n_idx, rec_bytes, rec_words, stats):
     return {
         # every sorted query record once + every index record once (the merge-join lower bound)
         "lookup_tile_kernel": n_q * rec_bytes + n_idx * rec_bytes,
-        # key + depth + index position + slot in, one event record out per query; meta + taxon of every index record
-        "group_kernel": n_q * (key + 1 + 4 + 4 + rec) + n_idx * 5,
+        # key + depth + index position + slot in, one event record out per query; meta + taxon of every index record; the profile keys out
+        "group_kernel": n_q * (key + 1 + 4 + 4 + rec) + n_idx * 5 + 8 * stats["profile_keys"],
         # every event record once; per read two offsets in, 16 bytes out
         "score_main_kernel": n_q * rec,
         # every event record once, 8 bytes per staging record out
         "score_other_kernel": n_q * rec + 8 * stats["staging_records"],
-        # staging records twice (bitmap pass, replay pass), final rows and profile keys out
-        "row_merge_kernel": 16 * stats["staging_records"] + 8 * stats["nnz"] + 8 * stats["profile_keys"],
+        # staging records twice (bitmap pass, replay pass), final rows out
+        "row_merge_kernel": 16 * stats["staging_records"] + 8 * stats["nnz"],
     }
 
 
 def stage_bytes(n_q, n_bases, n_idx, rec_bytes, rec_words, stats):
     """minimum HBM traffic of a stage.  encode: bases in + (key, payload) out; sort: one read + one
     write of the records (the radix passes it really takes are the implementation's); lookup: every query record and
-    every index record once; group: as the kernel; score: every event record twice (main chains, other taxa) + the
-    staging records written and read twice + profile keys written, sorted once (read + write) and reduced + the CSR out --
-    the per-(event, taxon) contributions section 8(d) counts travel inside those records."""
+    every index record once; group: as the kernel + the profile keys (one per leader, segment and level) read once by the
+    table kernel; score: every event record twice (main chains, other taxa) + the staging records written and read twice +
+    the CSR out -- the per-(event, taxon) contributions section 8(d) counts travel inside those records."""
     kb = kernel_bytes(n_q, n_idx, rec_bytes, rec_words, stats)
     return {"encode": n_bases + n_q * rec_bytes, "sort": 2 * n_q * rec_bytes, "lookup": kb["lookup_tile_kernel"],
-            "group": kb["group_kernel"],
-            "score": kb["score_main_kernel"] + kb["score_other_kernel"] + kb["row_merge_kernel"] + 32 * stats["profile_keys"] + 16 * stats["nnz"]}
+            "group": kb["group_kernel"] + 8 * stats["profile_keys"],
+            "score": kb["score_main_kernel"] + kb["score_other_kernel"] + kb["row_merge_kernel"] + 16 * stats["nnz"]}
 
 
 def launch_ranks(n):

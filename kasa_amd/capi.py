@@ -22,7 +22,7 @@ EXPORTS = [
     "kasa_index_device_bytes", "kasa_builtin_codon_table", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_device", "kasa_batch_upload_segments", "kasa_batch_encode",
     "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
-    "kasa_profile_reset", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs", "kasa_profile_allreduce",
+    "kasa_profile_reset", "kasa_profile_absorb", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs", "kasa_profile_allreduce",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
     "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
@@ -498,6 +498,10 @@ class Context:
     # ---- profile ----
     def profile_reset(self):
         _check(lib().kasa_profile_reset(self.h))
+
+    def profile_absorb(self, other: "Context"):
+        """self += other, other = 0 (kasa_profile_absorb): the tables of a context that grouped slices for this one."""
+        _check(lib().kasa_profile_absorb(self.h, other.h))
 
     def profile(self):
         shape = (self.nK, self.dix.n_taxa)

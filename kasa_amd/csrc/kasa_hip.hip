@@ -541,7 +541,7 @@ struct kasa_ctx {
     bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
     DevBuf rowPos, rowLen, rowKey, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
-    uint64_t poolCap = 0, stCap = 0, keyCap = 0, nnz = 0;
+    uint64_t poolCap = 0, stCap = 0, keyCap = 0, keyCapScore = 0, nnz = 0;   // keyCap: group keys (narrow records); keyCapScore: the per-read side's keys (wide records)
     void *qKmer = nullptr; uint32_t *qRead = nullptr; // current (valid) query arrays; keys are u64 or key128 as the index
     size_t keyBytes() const { return ix->wide ? 16 : 8; }
     int K() const { return ix->letters(); }
@@ -1718,7 +1718,7 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 
 static constexpr int GITEMS = 2;                  // the group kernel gives a thread two queries of the tile
 static constexpr int GTHREADS = TILE / GITEMS;    // 512
-static constexpr int GOVF = 2048;                 // segments beyond the inline ones a tile can park in LDS (narrow records)
+static constexpr int GOVF = 1536;                 // segments beyond the inline ones a tile can park in LDS (narrow records)
 static constexpr int GSPAN = 3072;                // index entries around the tile's matches staged in LDS (taxon + neighbour counts)
 static constexpr uint32_t GMARGIN = 96;           // ... this many beyond the first and last representative
 
@@ -1834,6 +1834,78 @@ __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, GetMe
     }
 }
 
+// Profile key of a record: {level | |T| | taxon | hits:16}.  The three upper fields are as wide as the batch needs
+// (taxon: enough bits that the all-ones value is no taxon -- it marks unused slots; |T| <= 8191 and < nTaxa), so the
+// radix sort of the keys runs over as few bits as possible: 27 instead of 38 for 1400 taxa and 6 levels.
+struct ProfLayout {
+    uint32_t tb, nb, lb;
+    __host__ __device__ uint32_t bits() const { return tb + nb + lb; }
+};
+static inline ProfLayout prof_layout(uint32_t nTaxa, int nK)
+{
+    ProfLayout L;
+    L.tb = 1; while ((1u << L.tb) <= nTaxa) ++L.tb;              // 2^tb > nTaxa: the all-ones taxon is free
+    L.nb = L.tb < 13 ? L.tb : 13;
+    L.lb = 1; while ((1u << L.lb) < (uint32_t)nK) ++L.lb;
+    return L;
+}
+__device__ __forceinline__ uint64_t profile_key_of(uint32_t lv, uint32_t n, uint32_t tax, uint32_t hits, ProfLayout L)
+{
+    const uint64_t f = ((uint64_t)lv << (L.tb + L.nb)) | ((uint64_t)n << L.tb) | tax;
+    return (f << 16) | hits;
+}
+// c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
+// x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
+// with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
+// terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
+__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint64_t c, uint32_t n)
+{
+    if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
+    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
+    if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
+    const uint64_t lo64 = c * R;
+    const uint64_t hi = __umul64hi(c, R);
+    const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
+    if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
+    if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
+    if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
+}
+
+// |T_k| of a level and the decoded record of one query, for both record widths
+// |T_k| tables of wide records in LDS: TWO levels per 32-bit word, 16 bits each (a query has fewer than 2^13 segments), so
+// that the tables -- which limit the resident wavefronts of the wide score kernels -- take half the room.  The +1 / -1 marks
+// at the ends of a segment's level range go into a word as +-1 or +-65536 (plain or atomic adds); a borrow out of the low
+// half is undone when the running sum reads the marks back as two SIGNED halves.
+__device__ __forceinline__ uint32_t lvp_rows(int levels) { return (uint32_t)(levels + 3) / 2u; }   // levels + 1 marks (one past the last level)
+__device__ __forceinline__ uint32_t lvp_unit(int lv) { return (lv & 1) ? 0x10000u : 1u; }
+__device__ __forceinline__ uint32_t lvp_get(const uint32_t *col, int stride, int lv) { return (col[(lv >> 1) * stride] >> (16 * (lv & 1))) & 0xFFFFu; }
+// marks -> sizes, in place; calls f(lv, size) for every level
+template <class F> __device__ __forceinline__ void lvp_running(uint32_t *col, int stride, int nK, F f)
+{
+    uint32_t running = 0;
+    for (int w = 0; 2 * w < nK; ++w) {
+        const uint32_t x = col[w * stride];
+        const int lo = (int)(int16_t)(x & 0xFFFFu);
+        const int hi = (int)(int16_t)((x - (uint32_t)lo) >> 16);
+        const uint32_t a = running + (uint32_t)lo, b = a + (uint32_t)hi;
+        running = b;
+        col[w * stride] = (a & 0xFFFFu) | (b << 16);
+        f(2 * w, a);
+        if (2 * w + 1 < nK) f(2 * w + 1, b);
+    }
+}
+
+// Narrow records (up to 8 levels): the profile is made by group_kernel (keys of the groups' first queries) and the per-read
+// kernels carry no profile records, counters or keys.  Wide records still take theirs from the per-read side.
+template <int RW> struct GpOf { static constexpr bool v = RW == 8; };
+// Profile keys of group_kernel ("group keys"): ONE key for a run of levels of a taxon segment that share |T| and the hits
+// -- the rule: a k-mer run matched down to k = 12 against one taxon is one key, not six.
+//   hits:16 | taxon:22 | |T|:13 | first level (lv = kHigh - k):5 | levels - 1:5
+__device__ __forceinline__ uint64_t group_key(uint32_t lvLo, uint32_t lvHi, uint32_t n, uint32_t tax, uint32_t hits)
+{
+    return (uint64_t)hits | ((uint64_t)tax << 16) | ((uint64_t)n << 38) | ((uint64_t)lvLo << 51) | ((uint64_t)(lvHi - lvLo) << 56);
+}
+
 // group: one workgroup per tile of TILE sorted queries, a thread owns GITEMS consecutive ones.
 //   1. flush positions F_k(p) = next position after p that closes level k: inside the wavefront from two ballots per
 //      level, across wavefronts through one LDS table (one barrier), across tiles from tileNext;
@@ -1846,29 +1918,38 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
     const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
-    uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int coverage,
-    uint64_t *__restrict__ cntTotal, uint32_t nTaxa)
+    uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
+    uint64_t *__restrict__ cntTotal, uint32_t nTaxa,
+    uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
+    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo)
 {
+    const int coverage = flags & 1;                                // bit 1: every query walks the index itself (test tap); bit 2: no LDS span for 64-byte records
     typedef RecTraits<RW> RT;
     constexpr int NL = NKT ? NKT : RT::LEVELS, INL = RT::INL;       // levels the unrolled loops run over
     __shared__ uint32_t shU[GTHREADS / 64];
     __shared__ uint32_t sFirst[GTHREADS / 64][NL];                 // first closing position of a wavefront, per level
-    __shared__ uint32_t sBase;
+    __shared__ uint32_t sBase, sBaseK;
     // the index entries the tile's walks visit (their taxa and neighbour counts), staged once: the walks are chains of
     // dependent reads, from LDS they cost tens of cycles instead of a trip to L2/HBM each
     typedef typename KeyTraits<Key>::Meta Meta;
-    __shared__ uint32_t sTax[RW == 16 ? 1 : GSPAN];                  // (64-byte records read the index from global memory: spanN = 0 below)
-    __shared__ Meta sMeta[RW == 16 ? 1 : GSPAN];
     // 64-byte records leave through LDS: a lane owns a record, FOUR lanes store it -- one store instruction then touches 16
     // whole 64-byte cells instead of a quarter of 64 (tools/scatter_probe.hip: 19 G records/s lane by lane, 4 instructions
-    // of 64 partial cells each; by quads the chip takes them at the rate of its address path)
-    __shared__ uint4 sOut[RW == 16 ? GTHREADS * 4 : 1];
+    // of 64 partial cells each; 49 G records/s by quads).  The output stage lies over the index span, which is dead by then.
+    constexpr int SPAN_BYTES = GSPAN * 4 + GSPAN * (int)sizeof(Meta), OUT_BYTES = RW == 16 ? GTHREADS * 4 * 16 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char sRaw[SPAN_BYTES > OUT_BYTES ? SPAN_BYTES : OUT_BYTES];
+    uint32_t *sTax = reinterpret_cast<uint32_t *>(sRaw);
+    Meta *sMeta = reinterpret_cast<Meta *>(sRaw + GSPAN * 4);
+    uint4 *sOut = reinterpret_cast<uint4 *>(sRaw);
     __shared__ uint32_t sRepLo[GTHREADS / 64], sRepHi[GTHREADS / 64];
     // narrow records: the segments beyond the inline ones wait here until the workgroup's pool block is allocated (one walk
     // per query instead of two); {segment, owner query | index in its pool list << 10}
     __shared__ uint2 sOvf[RW == 8 ? GOVF : 1];
     __shared__ uint32_t sOvfDst[RW == 8 ? TILE : 1];                 // per query of the tile: pool word of its first overflow segment
     __shared__ uint32_t sOvfN;
+    // per query of the tile, for the profile keys of parked segments: hits and |T| per level (8 bits each), the levels with hits
+    // and where a run of equal (|T|, hits) begins
+    __shared__ unsigned long long sHitsQ[RW == 8 ? TILE : 1], sSizeQ[RW == 8 ? TILE : 1];
+    __shared__ uint16_t sRunQ[RW == 8 ? TILE : 1];
     if (threadIdx.x == 0) sOvfN = 0u;
     const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
@@ -1888,6 +1969,19 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             sp[i] = special_mask(ql, d[i], kHigh, allLv);
         }
     }
+    // A query whose (representative, depth) are its predecessor's sees the same index entries the same way: the same
+    // segments, sizes and flags.  Such FOLLOWERS (the copies of a k-mer that the reads' coverage brings, and every read of a
+    // conserved region) do not walk the index and own no pool block: they take their leader's words once those are final.
+    // The first query of a wavefront is a leader by construction.
+    bool fol[GITEMS];
+    {
+        const uint32_t prevRp = (uint32_t)__shfl_up((int)rp[1], 1);
+        const int prevD = __shfl_up(d[1], 1);
+        const bool on = !(flags & 2);
+        fol[0] = on && lane > 0 && d[0] != 0 && d[0] == prevD && rp[0] == prevRp;
+        fol[1] = on && d[1] != 0 && d[1] == d[0] && rp[1] == rp[0];
+    }
+    const unsigned long long lead0 = __ballot(!fol[0]), lead1 = __ballot(!fol[1]);
     {   // span of the representatives (nearly monotone in p): first and last matched query of the wavefront
         const unsigned long long m0 = __ballot(d[0] != 0), m1 = __ballot(d[1] != 0);
         const unsigned long long any = m0 | m1;
@@ -1943,8 +2037,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     if (spanLo != NOPOS) {
         spanLo = spanLo > GMARGIN ? spanLo - GMARGIN : 0u;
         spanHi = min(spanHi + GMARGIN + 1u, nIdx);
-        // (not for 64-byte records: there the staging costs more than it saves, 137 against 124 ms at C3)
-        spanN = RW == 16 ? 0u : min(spanHi - spanLo, (uint32_t)GSPAN);   // what lies beyond is read from global memory
+        spanN = (RW == 16 && (flags & 4)) ? 0u : min(spanHi - spanLo, (uint32_t)GSPAN);   // what lies beyond is read from global memory
         for (uint32_t x = t; x < spanN; x += GTHREADS) { sTax[x] = tax[spanLo + x]; sMeta[x] = meta[spanLo + x]; }
     }
     __syncthreads();
@@ -2003,7 +2096,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         uint32_t n = 0, nlev = 0;                                 // nlev: |T_k| per level, 3 bits each, saturating at 7 (RW = 8)
         unsigned long long cnt8 = 0;                              // |T_k| per level, 8 bits each (exact below 255 segments)
         bool split = false;                                       // a taxon may own several segments (an entry continues an earlier one of its taxon)
-        walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
+        if (!fol[i]) walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
 #pragma unroll
             for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
             if constexpr (RW == 8) {
@@ -2037,6 +2130,8 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             });
         }
     }
+    bool poolOk = true;                                              // the workgroup's pool block was allocated (else the host grows the pool and reruns)
+    bool parked = false;                                             // the lists' further segments all wait in sOvf (no query with 255 or more, no overflow of the buffer)
     if (__syncthreads_or(need != 0u)) {                              // uniform across the workgroup
         uint32_t total = 0;
         uint32_t off = block_excl_prefix_sum(need, shU, total);
@@ -2046,6 +2141,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         }
         __syncthreads();
         const bool fits = sBase != NOPOS;
+        poolOk = fits;
         off += fits ? sBase : 0u;
         // fast way (narrow records): headers by the owners, the waiting segments by everybody.  Not when the buffer
         // overflowed or a query has 255 or more segments (8-bit counts): then the lists are walked again, below.
@@ -2055,6 +2151,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
 #pragma unroll
             for (int i = 0; i < GITEMS; ++i) if (nseg[i] >= 255u) mineOk = false;
             again = __syncthreads_or((!mineOk || sOvfN > (uint32_t)GOVF) ? 1 : 0) != 0;
+            parked = !again;
             if (!again) {
 #pragma unroll
                 for (int i = 0; i < GITEMS; ++i) {
@@ -2108,6 +2205,33 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                 off += nseg[i] - (uint32_t)(INL - 1) + 1u + (sat ? POOL_SIZES : 0u);
             }
     }
+    // ---- followers take their leader's words (all lanes run the shuffles)
+    {
+        const unsigned long long l0 = lead0, l1 = lead1;
+        const unsigned long long before = (l0 | l1) & ((1ull << lane) - 1ull);       // leaders in the lanes before (lane 0: none, and it never follows)
+        const int src = fol[0] ? 63 - __clzll((long long)before) : lane;             // the nearest one: item 1 of that lane if it leads, else item 0
+        const bool srcItem1 = ((l1 >> src) & 1ull) != 0ull;
+        auto take = [&](uint32_t a, uint32_t b) -> uint32_t {
+            const uint32_t va = (uint32_t)__shfl((int)a, src), vb = (uint32_t)__shfl((int)b, src);
+            return srcItem1 ? vb : va;
+        };
+        const uint32_t FL = REC_SPLIT | (RW == 8 ? REC_SAT : 0u);
+        const uint32_t g3 = take(w3[0], w3[1]), g2 = take(w2[0] & FL, w2[1] & FL);
+        uint32_t gs[INL];
+#pragma unroll
+        for (int q = 0; q < INL; ++q) gs[q] = take(seg[0][q], seg[1][q]);
+        if (fol[0]) {
+            w3[0] = g3; w2[0] |= g2;
+#pragma unroll
+            for (int q = 0; q < INL; ++q) seg[0][q] = gs[q];
+        }
+        if (fol[1]) {
+            w3[1] = w3[0]; w2[1] |= w2[0] & FL;
+#pragma unroll
+            for (int q = 0; q < INL; ++q) seg[1][q] = seg[0][q];
+        }
+    }
+    if constexpr (RW == 16) __syncthreads();                         // the index span is dead: the output stage takes its place
     // ---- 4. the record
 #pragma unroll
     for (int i = 0; i < GITEMS; ++i) {
@@ -2139,9 +2263,166 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
+    // ---- the profile (after the records have left: their stores drain meanwhile, and their registers are free): countAll[k][t] += |H| / |T|, countUnique[k][t] += |H| iff |T| = 1 (Compare.hpp:922-925) is a sum over
+    // (group, taxon) -- it is made HERE, from the sorted queries, not per read: the first query a wavefront holds of a level-k
+    // group adds the group's hits inside the wavefront (sums are associative: a group that spans wavefronts adds in pieces)
+    // to every taxon of T_k.  Such a query is a leader (a follower shares all its levels' groups with its predecessor).  The
+    // contributions leave as keys {levels, |T|, taxon, hits} -- one key for a run of levels with the same |T| and hits -- for
+    // profile_group_table_kernel (one allocation per workgroup); the per-read side (score_*) carries no profile bookkeeping,
+    // and a batch without per-read scores needs no score stage at all.
+    if (GpOf<RW>::v && !(flags & 8)) {                               // (flags 8, 16: timing taps -- no key phase; no key stores)
+        // hits per level: members of the level's group from this query on, if it is the group's first in the wavefront (else 0)
+        unsigned long long gq[GITEMS] = {0ull, 0ull};               // 8 bits per level
+        {
+            const unsigned long long beyond = lane == 63 ? 0ull : (~0ull << (lane + 1)), fromMe = ~0ull << lane;
+#pragma unroll
+            for (int lv = 0; lv < NL; ++lv) {
+                if (lv >= nK) continue;
+                const int k = kHigh - lv;
+                const bool mem0 = d[0] >= k, mem1 = d[1] >= k;
+                const bool head0 = mem0 && (((sp[0] >> lv) & 1u) || lane == 0), head1 = mem1 && ((sp[1] >> lv) & 1u);
+                // where a group that begins here ends: at the next head or the next query that is not matched this deep
+                const unsigned long long stop0 = __ballot(head0 || !mem0), stop1 = __ballot(head1 || !mem1);
+                const unsigned long long s0 = stop0 & beyond, s1f = stop1 & fromMe, s1b = stop1 & beyond;
+                const uint32_t e0 = s0 ? 2u * (uint32_t)(__ffsll((long long)s0) - 1) : 128u;
+                const uint32_t e1f = s1f ? 2u * (uint32_t)(__ffsll((long long)s1f) - 1) + 1u : 128u;
+                const uint32_t e1b = s1b ? 2u * (uint32_t)(__ffsll((long long)s1b) - 1) + 1u : 128u;
+                if (head0) gq[0] |= (unsigned long long)(min(e0, e1f) - 2u * (uint32_t)lane) << (8 * lv);
+                if (head1) gq[1] |= (unsigned long long)(min(e0, e1b) - (2u * (uint32_t)lane + 1u)) << (8 * lv);
+            }
+        }
+        // Per item: the levels with hits (V), where a run of levels with the same (|T|, hits) begins (B), and |T| per level in
+        // 16-bit fields (the 8-bit fields of cnt8 have wrapped at 255 or more segments: then the exact sizes group_kernel put
+        // into the pool block).  A segment's keys: one per run that begins inside its level range -- counted and cut out
+        // with a few bit operations; the segments come from the registers and, beyond the inline ones, from the pool block the
+        // workgroup has just written (no second walk).
+        // Per item: the levels with hits (V), where a run of levels with the same (|T|, hits) begins (B).  A segment's keys: one
+        // per run that begins inside its level range -- counted and cut out with a few bit operations.  The segments: the
+        // inline ones from their owner's registers; the further ones of a list from where walk 1 parked them (sOvf) -- every
+        // thread takes a share of those, with the owner's level data from LDS (keys need no order); only when the tile could
+        // not park them (a query with 255 or more, a full buffer) from the pool block, or by walks of their own.
+        uint32_t Vm[GITEMS], Bm[GITEMS];
+        uint32_t needK = 0;
+        auto segAt = [&](int i, uint32_t idx) -> uint32_t {          // idx >= INL - 1 of a list that continues in the pool
+            const uint32_t skip = (w2[i] & REC_SAT) ? POOL_SIZES : 0u;
+            return pool[seg[i][INL - 1] + 1u + skip + idx - (uint32_t)(INL - 1)];
+        };
+        auto forSegs = [&](int i, auto f) {                          // the owner's share of item i's segments
+            const uint32_t ns = nseg[i];
+            const uint32_t inl = ns <= (uint32_t)INL ? ns : (uint32_t)(INL - 1);
+#pragma unroll
+            for (int q = 0; q < INL; ++q) if ((uint32_t)q < inl) f(seg[i][q]);
+            if (!parked) for (uint32_t q = inl; q < ns; ++q) f(segAt(i, q));
+        };
+        auto coveringWalk = [&](int i, int lv, auto f) {             // 255 or more segments (the 8-bit fields of cnt8 have wrapped): level by level
+            walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t sg) { if (seg_covers(sg, (uint32_t)(kHigh - lv))) f(sg); });
+        };
+        auto startsOf = [](uint32_t M, uint32_t V, uint32_t B) -> uint32_t { return (B & M) | (V & M & (0u - M)); };
+        // one key per run: levels lo .. hi, |T| and hits of level lo
+        auto cutRuns = [](uint32_t M, uint32_t V, uint32_t B, auto emit) {
+            uint32_t starts = (B & M) | (V & M & (0u - M));
+            const uint32_t stops = (B | ~V) & M;                     // a run ends before the next run's start, a level without hits, or with the segment
+            while (starts) {
+                const int lo = __ffs((int)starts) - 1;
+                starts &= starts - 1u;
+                const uint32_t above = stops & ~((2u << lo) - 1u);
+                emit(lo, above ? __ffs((int)above) - 2 : 31 - __clz((int)M));
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < GITEMS; ++i) {
+            Vm[i] = 0; Bm[i] = 0;
+            if (nseg[i] == 0u || gq[i] == 0ull || (nseg[i] > (uint32_t)INL && !poolOk)) gq[i] = 0ull;
+            if (gq[i] != 0ull && nseg[i] < 255u) {
+                uint32_t pn = 0, pg = 0;
+#pragma unroll
+                for (int lv = 0; lv < NL; ++lv) {
+                    const uint32_t n = (uint32_t)(cnt8x[i] >> (8 * lv)) & 255u;
+                    const uint32_t h = (uint32_t)(gq[i] >> (8 * lv)) & 255u;
+                    if (h) { Vm[i] |= 1u << lv; if (!(pg == h && pn == n)) Bm[i] |= 1u << lv; }
+                    pn = n; pg = h;                                   // (pg = 0 after a level without hits: the next one begins a run)
+                }
+            }
+            sHitsQ[t * GITEMS + i] = gq[i]; sSizeQ[t * GITEMS + i] = cnt8x[i]; sRunQ[t * GITEMS + i] = (uint16_t)(Vm[i] | (Bm[i] << 8));
+            if (gq[i] == 0ull) continue;
+            if (nseg[i] >= 255u) {
+                for (int lv = 0; lv < nK; ++lv) if ((gq[i] >> (8 * lv)) & 255ull) coveringWalk(i, lv, [&](uint32_t) { ++needK; });
+                continue;
+            }
+            forSegs(i, [&](uint32_t sg) { needK += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), Vm[i], Bm[i])); });
+        }
+        __syncthreads();                                             // the owners' level data, the pool blocks (other threads have filled them)
+        const uint32_t nPark = (parked && poolOk) ? sOvfN : 0u;
+        for (uint32_t x = t; x < nPark; x += GTHREADS) {
+            const uint2 e = sOvf[x];
+            const uint32_t o = e.y & 1023u;
+            if (sOvfDst[o] == NOPOS) continue;                       // (its query has no list after all: the segment is inline)
+            const uint32_t vb = sRunQ[o];
+            needK += (uint32_t)__popc(startsOf(seg_level_mask(e.x, kHigh), vb & 255u, vb >> 8));
+        }
+        if (__syncthreads_or(needK != 0u)) {
+            uint32_t totalK = 0;
+            uint32_t kw = block_excl_prefix_sum(needK, shU, totalK);
+            if (t == 64) {
+                const unsigned long long at = atomicAdd(keyCursor, (unsigned long long)totalK);
+                sBaseK = at + totalK <= (unsigned long long)keyCap ? (uint32_t)at : NOPOS;
+            }
+            __syncthreads();
+            // The workgroup's keys are one piece of the key buffer.  A thread's keys leave from inside its loops, a few lanes at a
+            // time and with gaps between the lanes' places (partial-cell writes); so, when the index span in LDS is dead (no walks
+            // in this phase) and the keys fit there, they are collected in LDS and copied out in whole lines.
+            constexpr uint32_t KSTAGE = (uint32_t)(SPAN_BYTES / 8);
+            const bool staged = parked && totalK <= KSTAGE && sBaseK != NOPOS;
+            unsigned long long *sKeys = reinterpret_cast<unsigned long long *>(sRaw);
+            if (sBaseK != NOPOS && needK) {
+                if (!staged) kw += sBaseK;
+                auto put = [&](int lo, int hi, uint32_t n, uint32_t hits, uint32_t tx) {
+                    if (flags & 16) { ++kw; return; }
+                    unsigned long long key = 0ull;                      // (hits = 0: skipped by the table kernel)
+                    if (n < (1u << PL.nb)) key = group_key((uint32_t)lo, (uint32_t)hi, n, tx, hits);
+                    else                                                // a set too large for the key's field: straight to the tables
+                        for (int lv = lo; lv <= hi; ++lv) fixed_add(cntAllHi, cntAllMid, cntAllLo, (size_t)lv * nTaxa + tx, hits, n);
+                    if (staged) sKeys[kw++] = key; else profKeys[kw++] = key;
+                };
+#pragma unroll
+                for (int i = 0; i < GITEMS; ++i) {
+                    if (gq[i] == 0ull) continue;
+                    if (nseg[i] >= 255u) {
+                        for (int lv = 0; lv < nK; ++lv) {
+                            const uint32_t hits = (uint32_t)(gq[i] >> (8 * lv)) & 255u;
+                            if (!hits) continue;
+                            uint32_t n = 0;
+                            coveringWalk(i, lv, [&](uint32_t) { ++n; });
+                            coveringWalk(i, lv, [&](uint32_t sg) { put(lv, lv, n, hits, sg & SEG_TAX_MASK); });
+                        }
+                        continue;
+                    }
+                    forSegs(i, [&](uint32_t sg) {
+                        cutRuns(seg_level_mask(sg, kHigh), Vm[i], Bm[i], [&](int lo, int hi) {
+                            put(lo, hi, (uint32_t)(cnt8x[i] >> (8 * lo)) & 255u, (uint32_t)(gq[i] >> (8 * lo)) & 255u, sg & SEG_TAX_MASK);
+                        });
+                    });
+                }
+                for (uint32_t x = t; x < nPark; x += GTHREADS) {
+                    const uint2 e = sOvf[x];
+                    const uint32_t o = e.y & 1023u;
+                    if (sOvfDst[o] == NOPOS) continue;
+                    const uint32_t vb = sRunQ[o];
+                    const unsigned long long hq = sHitsQ[o], sq = sSizeQ[o];
+                    cutRuns(seg_level_mask(e.x, kHigh), vb & 255u, vb >> 8, [&](int lo, int hi) {
+                        put(lo, hi, (uint32_t)(sq >> (8 * lo)) & 255u, (uint32_t)(hq >> (8 * lo)) & 255u, e.x & SEG_TAX_MASK);
+                    });
+                }
+            }
+            if (staged && !(flags & 16)) {                              // (uniform)
+                __syncthreads();
+                for (uint32_t x = t; x < totalK; x += GTHREADS) profKeys[(size_t)sBaseK + x] = sKeys[x];
+            }
+        }
+    }
 }
 
-static constexpr int FTA = 2;       // taxa kept in registers with per-level counters in LDS
+static constexpr int FTA = 2;       // taxa kept in registers
 static constexpr int RMAX = 1024;   // longest staging row row_merge_kernel handles; the fast kernels hand reads with longer rows to score_kernel
 static constexpr uint32_t ROW_MERGE = 0x80000000u;   // rowLen flag: the row holds records, not final {taxon, score} pairs
 
@@ -2161,26 +2442,6 @@ __device__ __forceinline__ uint32_t seg_size(uint32_t y, bool first) { return (f
 static constexpr int RK_LV_SHIFT = 23;
 static constexpr uint32_t RK_LV_MASK = 31u;
 __device__ __forceinline__ uint32_t rk_level(uint32_t x) { return (x >> RK_LV_SHIFT) & RK_LV_MASK; }
-// Profile key of a record: {level | |T| | taxon | hits:16}.  The three upper fields are as wide as the batch needs
-// (taxon: enough bits that the all-ones value is no taxon -- it marks unused slots; |T| <= 8191 and < nTaxa), so the
-// radix sort of the keys runs over as few bits as possible: 27 instead of 38 for 1400 taxa and 6 levels.
-struct ProfLayout {
-    uint32_t tb, nb, lb;
-    __host__ __device__ uint32_t bits() const { return tb + nb + lb; }
-};
-static inline ProfLayout prof_layout(uint32_t nTaxa, int nK)
-{
-    ProfLayout L;
-    L.tb = 1; while ((1u << L.tb) <= nTaxa) ++L.tb;              // 2^tb > nTaxa: the all-ones taxon is free
-    L.nb = L.tb < 13 ? L.tb : 13;
-    L.lb = 1; while ((1u << L.lb) < (uint32_t)nK) ++L.lb;
-    return L;
-}
-__device__ __forceinline__ uint64_t profile_key_of(uint32_t lv, uint32_t n, uint32_t tax, uint32_t hits, ProfLayout L)
-{
-    const uint64_t f = ((uint64_t)lv << (L.tb + L.nb)) | ((uint64_t)n << L.tb) | tax;
-    return (f << 16) | hits;
-}
 __device__ __forceinline__ uint64_t profile_key(uint2 e, ProfLayout L)
 {
     const uint64_t f = ((uint64_t)rk_level(e.x) << (L.tb + L.nb)) | ((uint64_t)(e.y >> 16) << L.tb) | (e.x & 0xFFFFFu);
@@ -2236,24 +2497,8 @@ struct ScoreArgs {
     uint32_t nQ;
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
     uint32_t *workCursor;                        // fast kernel: next read a wavefront takes
+    int forceHandOn;                             // general kernel, first pass: every read goes to the second pass (test tap 16384)
 };
-
-// c / n added to a 64.64 fixed-point cell kept as three u64 accumulators {hi, mid, lo}: the 128-bit term
-// x = c * floor(2^64 / n) is split into hi = x >> 64 and the two 32-bit halves of its low word, each added
-// with a fire-and-forget integer atomic (value = hi + (mid * 2^32 + lo) / 2^64; mid and lo absorb up to 2^32
-// terms before they could wrap).  Exact, associative, independent of the order in which waves arrive.
-__device__ __forceinline__ void fixed_add(uint64_t *hiTab, uint64_t *midTab, uint64_t *loTab, size_t cell, uint64_t c, uint32_t n)
-{
-    if (n == 1) { atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)c); return; }
-    uint64_t R = 0xFFFFFFFFFFFFFFFFull / n;
-    if ((n & (n - 1)) == 0) R += 1;                                      // n divides 2^64
-    const uint64_t lo64 = c * R;
-    const uint64_t hi = __umul64hi(c, R);
-    const uint64_t lo = lo64 & 0xFFFFFFFFull, mid = lo64 >> 32;
-    if (lo) atomicAdd((unsigned long long *)&loTab[cell], (unsigned long long)lo);
-    if (mid) atomicAdd((unsigned long long *)&midTab[cell], (unsigned long long)mid);
-    if (hi) atomicAdd((unsigned long long *)&hiTab[cell], (unsigned long long)hi);
-}
 
 static constexpr int AGG = 256;                                   // per-read profile aggregation table (LDS)
 static constexpr int PCAP_SMALL = 96;                              // pending window of the first pass (small LDS footprint: many wavefronts per CU)
@@ -2319,10 +2564,20 @@ __global__ __launch_bounds__(256) void flush_positions_kernel(
 // per taxon list), so the first pass runs with a small window -- little LDS, many resident wavefronts -- and hands the
 // rare read that overflows it (or the aggregation table) to a second pass with the full window.  A read that is handed
 // on leaves nothing behind: its score cells are cleared again and its profile counts never left LDS.
-template <int PC, int RW>
+// DENSE: the read's score row lies in LDS (dynamic: nTaxa floats) and an event's taxa are dealt out to the LANES -- a query of
+// a conserved region brings hundreds of taxa per level, and the lane-owns-its-cells form below walks all of them on every
+// lane for every event.  The segments of the query being replayed wait in LDS with the sizes of its levels (a query's
+// events mostly follow each other).  Within an event every taxon occurs once (a taxon's segments cover disjoint levels), so
+// the lanes' read-modify-writes never meet; LDS operations of a wavefront execute in order, so events do not overtake.
+static constexpr int DENSE_TAXA = 16384;      // 64 KB of LDS for the row at most
+static constexpr int DQ_SEGS = 1024;          // segments of one query kept in LDS
+template <int PC, int RW, bool DENSE = false>
 __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
+    extern __shared__ float sRowDyn[];
+    __shared__ uint32_t sSegQ[DENSE ? DQ_SEGS : 1];
+    __shared__ uint32_t sCntQ[DENSE ? 32 : 1];
     __shared__ unsigned long long aKey[AGG];
     __shared__ uint32_t aCnt[AGG];
     __shared__ uint32_t pF[PC], pRef[PC];
@@ -2332,7 +2587,9 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     __shared__ uint32_t sList[TLIST];
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
-    float *score = A.scratch + (size_t)blockIdx.x * A.nTaxa;
+    float *score = DENSE ? sRowDyn : A.scratch + (size_t)blockIdx.x * A.nTaxa;
+    if constexpr (DENSE) for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f;
+    uint32_t cachedSlot = NOPOS, cachedN = 0;     // DENSE: the query whose segments and level sizes lie in LDS (uniform)
 
     for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
     const uint32_t nWork = A.list ? A.nList : A.nReads;
@@ -2345,7 +2602,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         uint32_t cTax = 0xFFFFFFFFu;       // this lane's cached score cell (taxa with tx % 64 == lane live here)
         float cVal = 0.0f;
         const bool mayHandOn = A.ovList != nullptr;
-        bool ovf = false;                  // this read does not fit this pass (per lane; combined with a ballot)
+        bool ovf = mayHandOn && A.forceHandOn != 0;   // this read does not fit this pass (per lane; combined with a ballot)
         if (lane == 0) sTouched = 0;
         __syncthreads();
 
@@ -2376,6 +2633,44 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         // |T| = the segments covering k; every taxon is handled by the lane that owns its cell.
         auto applyVals = [&](const int k, const uint32_t slot, const uint32_t c) {
             const uint32_t *w = A.rec + (size_t)slot * RW;
+            if constexpr (DENSE) {
+                if (slot != cachedSlot) {                                    // stage the query: segments, +1 / -1 at the ends of their level ranges, running sum
+                    const uint32_t ns = rec_nseg<RW>(w, A.pool);
+                    cachedN = ns;
+                    cachedSlot = slot;
+                    if (lane < 32) sCntQ[lane] = 0u;
+                    LDS_WAVE_SYNC();
+                    for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
+                        const uint32_t i = b0 + lane;
+                        if (i < ns) {
+                            const uint32_t sg = rec_seg<RW>(w, A.pool, ns, i);
+                            if (i < (uint32_t)DQ_SEGS) sSegQ[i] = sg;
+                            atomicAdd(&sCntQ[A.kHigh - (int)(sg >> 27)], 1u);
+                            atomicSub(&sCntQ[A.kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+                        }
+                    }
+                    LDS_WAVE_SYNC();
+                    uint32_t v = lane < 32 ? sCntQ[lane] : 0u;
+                    v = wave_incl_sum(v);
+                    LDS_WAVE_SYNC();
+                    if (lane < 32) sCntQ[lane] = v;
+                    LDS_WAVE_SYNC();
+                }
+                const int lv = A.kHigh - k;
+                const uint32_t n = sCntQ[lv], ns = cachedN;
+                const float sc = event_score(k, n);
+                for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
+                    const uint32_t i = b0 + lane;
+                    if (i >= ns) continue;
+                    const uint32_t sg = i < (uint32_t)DQ_SEGS ? sSegQ[i] : rec_seg<RW>(w, A.pool, ns, i);
+                    if (!seg_covers(sg, (uint32_t)k)) continue;
+                    const uint32_t tx = sg & SEG_TAX_MASK;
+                    if (A.wantPerRead) { float v = score[tx]; for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, sc); score[tx] = v; }
+                    if (A.addProfile) aggAdd(lv, n, tx, c);
+                }
+                LDS_WAVE_SYNC();
+                return;
+            }
             const uint32_t nseg = rec_nseg<RW>(w, A.pool);
             uint32_t n = 0;
             for (uint32_t b0 = 0; b0 < nseg; b0 += 64) {
@@ -2482,7 +2777,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         if (ovf) {                                                            // hand the read on, leave no trace
             __syncthreads();
             const uint32_t m = sTouched;
-            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            if (!DENSE && m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
             else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
             for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
             if (lane == 0) A.ovList[atomicAdd(A.ovCount, 1u)] = r;
@@ -2502,7 +2797,11 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 
         // ---- emit the row (taxon ascending) and clear the dense row
         if (A.wantPerRead) {
-            const uint32_t m = sTouched;
+            uint32_t m = sTouched;
+            if constexpr (DENSE) {                                           // the row's taxa are counted, not listed
+                m = 0;
+                for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) { const uint32_t tx = b0 + lane; m += (uint32_t)__popcll(__ballot(tx < A.nTaxa && score[tx] > 0.0f)); }
+            }
             unsigned long long start = 0;
             if (lane == 0) {
                 start = m ? atomicAdd(A.stCursor, (unsigned long long)m) : 0ull;
@@ -2513,7 +2812,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
             start = lane_value<0>(start);
             __threadfence_block();
             if (m && start != ~0ull) {
-                if (m <= 64) {
+                if (!DENSE && m <= 64) {
                     const uint32_t mine = (lane < (int)m) ? sList[lane] : 0xFFFFFFFFu;
                     uint32_t rank = 0;
                     for (uint32_t i = 0; i < m; ++i) rank += (__shfl(mine, (int)i) < mine) ? 1u : 0u;
@@ -2533,7 +2832,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                 }
             }
             __syncthreads();
-            if (m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
+            if (!DENSE && m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
             else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
             __syncthreads();
         }
@@ -2559,30 +2858,6 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 //
 // Neither kernel touches the profile tables: everything leaves as records, so both can be rerun.
 // ------------------------------------------------------------------------------------------------
-// |T_k| of a level and the decoded record of one query, for both record widths
-// |T_k| tables of wide records in LDS: TWO levels per 32-bit word, 16 bits each (a query has fewer than 2^13 segments), so
-// that the tables -- which limit the resident wavefronts of the wide score kernels -- take half the room.  The +1 / -1 marks
-// at the ends of a segment's level range go into a word as +-1 or +-65536 (plain or atomic adds); a borrow out of the low
-// half is undone when the running sum reads the marks back as two SIGNED halves.
-__device__ __forceinline__ uint32_t lvp_rows(int levels) { return (uint32_t)(levels + 3) / 2u; }   // levels + 1 marks (one past the last level)
-__device__ __forceinline__ uint32_t lvp_unit(int lv) { return (lv & 1) ? 0x10000u : 1u; }
-__device__ __forceinline__ uint32_t lvp_get(const uint32_t *col, int stride, int lv) { return (col[(lv >> 1) * stride] >> (16 * (lv & 1))) & 0xFFFFu; }
-// marks -> sizes, in place; calls f(lv, size) for every level
-template <class F> __device__ __forceinline__ void lvp_running(uint32_t *col, int stride, int nK, F f)
-{
-    uint32_t running = 0;
-    for (int w = 0; 2 * w < nK; ++w) {
-        const uint32_t x = col[w * stride];
-        const int lo = (int)(int16_t)(x & 0xFFFFu);
-        const int hi = (int)(int16_t)((x - (uint32_t)lo) >> 16);
-        const uint32_t a = running + (uint32_t)lo, b = a + (uint32_t)hi;
-        running = b;
-        col[w * stride] = (a & 0xFFFFu) | (b << 16);
-        f(2 * w, a);
-        if (2 * w + 1 < nK) f(2 * w + 1, b);
-    }
-}
-
 template <int RW> struct QueryRec {
     typedef RecTraits<RW> RT;
     uint32_t p, fmax, nseg, nlev, split;
@@ -2668,12 +2943,13 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
 {
     typedef RecTraits<RW> RT;
     constexpr int NL = NLV, OB = RT::OBITS;
+    constexpr bool GP = GpOf<RW>::v;
     // hit counters per |T|: 4 (wide records: 2) fields of FB bits
     typedef typename std::conditional<RW == 8, typename std::conditional<FB == 16, unsigned long long, uint32_t>::type,
                                       typename std::conditional<FB == 16, uint32_t, uint16_t>::type>::type Counter;
     constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
     constexpr uint32_t FMASK = (1u << FB) - 1u;
-    __shared__ Counter cnt[FTA * NL][64];
+    __shared__ Counter cnt[GP ? 1 : FTA * NL][GP ? 1 : 64];
     __shared__ float sTab[NL][8];                                    // score of one hit by (level, |T| < 8)
     __shared__ EventTables evT;
     __shared__ uint32_t sPB[65], sPPtr[64], sPT0[64], sPT1[64], sPM0[64], sPM1[64], sPRec[64], sPKey[64];   // pool segments of the current queries
@@ -2700,7 +2976,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
         int na = 0;
         uint32_t mTax0 = 0xFFFFFFFFu, mTax1 = 0xFFFFFFFFu, nOther = 0, nKeys = 0;   // records / profile keys of the other taxa
         float mS0 = 0.0f, mS1 = 0.0f;
-        for (int l2 = 0; l2 < FTA * nK; ++l2) cnt[(l2 / nK) * NL + (l2 % nK)][lane] = 0;
+        if constexpr (!GP) for (int l2 = 0; l2 < FTA * nK; ++l2) cnt[(l2 / nK) * NL + (l2 % nK)][lane] = 0;
         uint64_t o0 = 0;
         uint32_t cnt0 = 0;
         const uint4 *rp0 = reinterpret_cast<const uint4 *>(A.rec);
@@ -2802,7 +3078,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     const uint32_t t = Q.sg[q] & SEG_TAX_MASK, m = seg_level_mask(Q.sg[q], A.kHigh);
                     if (t == mTax0) mask0 |= m;
                     else if (t == mTax1) mask1 |= m;
-                    else { nOther += seg_records<RW>(m, sat); nKeys += (uint32_t)__popc(m); }
+                    else { nOther += seg_records<RW>(m, sat); if constexpr (!GP) nKeys += (uint32_t)__popc(m); }
                 }
                 if constexpr (RW == 16) {
                     for (uint32_t w = 0; w < lvp_rows(nK); ++w) sLvN[w][lane] = 0u;
@@ -2840,14 +3116,15 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                             }
                             if (t == sPT0[own]) atomicOr(&sPM0[own], m);
                             else if (t == sPT1[own]) atomicOr(&sPM1[own], m);
-                            else { atomicAdd(&sPRec[own], seg_records<RW>(m, ((satMask >> own) & 1ull) != 0ull)); atomicAdd(&sPKey[own], (uint32_t)__popc(m)); }
+                            else { atomicAdd(&sPRec[own], seg_records<RW>(m, ((satMask >> own) & 1ull) != 0ull)); if constexpr (!GP) atomicAdd(&sPKey[own], (uint32_t)__popc(m)); }
                         }
                     }
                     LDS_WAVE_SYNC();
                     mask0 |= sPM0[lane]; mask1 |= sPM1[lane]; nOther += sPRec[lane]; nKeys += sPKey[lane];
                     LDS_WAVE_SYNC();
                 }
-                if ((mask0 | mask1) == 0u) continue;
+                if (live && nOther > (uint32_t)RMAX) { fb = true; live = false; atomicAdd(&A.why[2], 1u); }   // a row longer than row_merge handles: the read is the general kernel's, no need to count on
+                if ((mask0 | mask1) == 0u || !live) continue;
                 if constexpr (RW == 16) {
                     LDS_WAVE_SYNC();
                     lvp_running(&sLvN[0][lane], 64, nK, [](int, uint32_t) {});
@@ -2865,11 +3142,13 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                         mS0 = __fadd_rn(mS0, in0 ? s : 0.0f);
                         mS1 = __fadd_rn(mS1, in1 ? s : 0.0f);
                     }
-                    if (n <= CNT_FIELDS) {
-                        const Counter one = (Counter)1 << (FB * (n - 1u));
-                        cnt[lv][lane] += in0 ? one : (Counter)0;
-                        cnt[NL + lv][lane] += in1 ? one : (Counter)0;
-                    } else { nOther += in0 + in1; nKeys += in0 + in1; }       // a profile record, written by score_other_kernel
+                    if constexpr (!GP) {
+                        if (n <= CNT_FIELDS) {
+                            const Counter one = (Counter)1 << (FB * (n - 1u));
+                            cnt[lv][lane] += in0 ? one : (Counter)0;
+                            cnt[NL + lv][lane] += in1 ? one : (Counter)0;
+                        } else { nOther += in0 + in1; nKeys += in0 + in1; }   // a profile record, written by score_other_kernel
+                    }
                 }
             }
             }
@@ -2877,7 +3156,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
         // ---- the read's staging row: final scores of the register taxa, their counters as profile records, then room
         // for the other taxa's records
         uint32_t nprof = 0;
-        if (active && !fb)
+        if (!GP && active && !fb)
             for (int e = 0; e < na; ++e)
                 for (int lv = 0; lv < nK; ++lv) {
                     const unsigned long long pk = cnt[e * NL + lv][lane];
@@ -2912,7 +3191,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     uint32_t w = (uint32_t)start;
                     if (PERREAD && na > 0) A.st[w++] = make_uint2(mTax0 | RK_FINAL, __float_as_uint(mS0));
                     if (PERREAD && na > 1) A.st[w++] = make_uint2(mTax1 | RK_FINAL, __float_as_uint(mS1));
-                    for (int e = 0; e < na; ++e) {
+                    for (int e = 0; !GP && e < na; ++e) {
                         const uint32_t t = (e == 0) ? mTax0 : mTax1;
                         for (int lv = 0; lv < nK; ++lv) {
                             const unsigned long long pk = cnt[e * NL + lv][lane];
@@ -2949,6 +3228,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
     constexpr int OB = RT::OBITS;
+    constexpr bool GP = GpOf<RW>::v;
     constexpr uint32_t CNT_FIELDS = RW == 8 ? 4u : 2u;
     typedef typename std::conditional<RW == 8, uint32_t, unsigned __int128>::type Order;
     const int lane = threadIdx.x & 63;
@@ -3029,7 +3309,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         // and how many records that makes
         auto emitMask = [&](uint32_t sq, bool valid) -> uint32_t {
             const uint32_t t = sq & SEG_TAX_MASK, m = valid ? seg_level_mask(sq, A.kHigh) : 0u;
-            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+            return (t != mTax0 && t != mTax1) ? m : (GP ? 0u : (m & bigLv));
         };
         auto records = [&](uint32_t sq, uint32_t m) -> uint32_t {
             const uint32_t t = sq & SEG_TAX_MASK;
@@ -3128,6 +3408,7 @@ template <bool PERREAD>
 __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
 {
     constexpr int WV = 4;
+    constexpr bool GP = GpOf<8>::v;
     __shared__ uint32_t sBase[WV][65];                                    // exclusive prefix sums of the queries' item counts
     __shared__ uint32_t sSg[WV][4][64];                                    // the inline segments that leave records, compacted
     __shared__ uint32_t sW2[WV][64], sW3[WV][64], sT0[WV][64], sT1[WV][64], sRow[WV][64], sBig[WV][64], sSplit[WV][64], sPool[WV][64];
@@ -3169,7 +3450,7 @@ __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
         const uint32_t bigLv = (fl & 1u) | ((fl >> 2) & 2u) | ((fl >> 4) & 4u) | ((fl >> 6) & 8u) | ((fl >> 8) & 16u) | ((fl >> 10) & 32u) | ((fl >> 12) & 64u) | ((fl >> 14) & 128u);
         auto emitMask = [&](uint32_t sq) -> uint32_t {
             const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
-            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+            return (t != mTax0 && t != mTax1) ? m : (GP ? 0u : (m & bigLv));
         };
         uint32_t mineSplit = 0;                                                // a split query's records: one per (segment, level)
         if (__ballot(split) != 0ull && split) {
@@ -3223,7 +3504,7 @@ __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
             const uint32_t t = sq & SEG_TAX_MASK;
             const bool isMain = t == sT0[wv][own] || t == sT1[wv][own];
             const uint32_t m = seg ? seg_level_mask(sq, A.kHigh) : 0u;
-            const uint32_t em = isMain ? (m & sBig[wv][own]) : m;
+            const uint32_t em = isMain ? (GP ? 0u : (m & sBig[wv][own])) : m;
             const uint32_t pc = (uint32_t)__popc(em);
             const bool segRec = !isMain && pc <= 2u;                           // one segment record (seg_records)
             uint32_t c = segRec ? (pc ? 1u : 0u) : pc;
@@ -3302,6 +3583,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
 {
     typedef RecTraits<16> RT;
     constexpr int WV = 2, INL = RT::INL;
+    constexpr bool GP = GpOf<16>::v;
     constexpr uint32_t CNT_FIELDS = 2u;
     __shared__ uint32_t sBase[WV][65];
     __shared__ uint32_t sSg[WV][INL][64];                                  // inline segments (sweep 1: all; sweep 2: those that leave records)
@@ -3376,7 +3658,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
         Q.tab = &sLvN[wv][0][lane]; Q.tabStride = 64;
         auto emitMask = [&](uint32_t sq) -> uint32_t {
             const uint32_t t = sq & SEG_TAX_MASK, m = seg_level_mask(sq, A.kHigh);
-            return (t != mTax0 && t != mTax1) ? m : (m & bigLv);
+            return (t != mTax0 && t != mTax1) ? m : (GP ? 0u : (m & bigLv));
         };
         // ---- sweep 2: the records
         uint32_t mineSplit = 0;
@@ -3429,7 +3711,7 @@ __global__ __launch_bounds__(128) void score_other_flat16_kernel(ScoreArgs A)
             const uint32_t t = sq & SEG_TAX_MASK;
             const bool isMain = t == sT0[wv][own] || t == sT1[wv][own];
             const uint32_t m = seg ? seg_level_mask(sq, A.kHigh) : 0u;
-            const uint32_t em = isMain ? (m & sBig[wv][own]) : m;
+            const uint32_t em = isMain ? (GP ? 0u : (m & sBig[wv][own])) : m;
             uint32_t c = (uint32_t)__popc(em);
             if (act && isSplit) c = sSplit[wv][own];
             const int prevOwn = lane_before((int)own, prevOwnCarry);
@@ -3513,11 +3795,11 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
                 const uint32_t kind = e.x >> 30;
                 if (kind != 2u) key = ((e.x & 0xFFFFFu) << 11) | (kind == 1u ? 0u : (i & 0x7FFu));   // final score first in its run
             }
-            const uint32_t nk = i < m ? record_keys(e) : 0u;          // every event leaves as a profile key
+            const uint32_t nk = (profKeys && i < m) ? record_keys(e) : 0u;          // (once: every event left as a profile key)
             uint32_t incl = nk;
-            incl = wave_incl_sum(incl);
+            if (profKeys) incl = wave_incl_sum(incl);
             uint32_t kw = keyAt + incl - nk;
-            keyAt += lane_value<63>(incl);
+            if (profKeys) keyAt += lane_value<63>(incl);
             if (nk) {
                 if ((e.x >> 30) == 3u) {
                     const uint32_t kF = (e.x >> 20) & 31u;
@@ -3631,11 +3913,11 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             const uint32_t kind = e.x >> 30;
             const uint32_t t = e.x & 0xFFFFFu;
             if (i < m && kind != 2u) atomicOr(&bm[t >> 5], 1u << (t & 31u));
-            const uint32_t nk = i < m ? record_keys(e) : 0u;
+            const uint32_t nk = (profKeys && i < m) ? record_keys(e) : 0u;
             uint32_t incl = nk;
-            incl = wave_incl_sum(incl);
+            if (profKeys) incl = wave_incl_sum(incl);                  // (uniform: a kernel argument)
             uint32_t kw = keyAt + incl - nk;
-            keyAt += lane_value<63>(incl);
+            if (profKeys) keyAt += lane_value<63>(incl);
             if (nk) {
                 if (kind == 3u) {
                     const uint32_t kF = (e.x >> 20) & 31u;
@@ -3937,26 +4219,194 @@ static int slots_from_reads(kasa_ctx *c)
 }
 
 template <int RW>
-static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, int cov, unsigned long long *cursor)
+static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor)
 {
     const uint64_t nQ = c->nQ;
     if (c->ix->wide && RW == 16 && c->nK == 19)                       // the default -k 25 7 of a 128-bit index: loops over exactly 19 levels
         group_kernel<RW, key128, RW == 16 ? 19 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
+            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
     else if (c->ix->wide)
         group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
+            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
     else if (RW == 8 && c->nK == 6)                                  // the default -k 12 7: loops over exactly six levels
         group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
+            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
     else
         group_kernel<RW, uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
             c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa);
+            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
+            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
     HIPCHK(hipGetLastError());
+    return KASA_OK;
+}
+
+
+// profile_table_kernel for group keys: a key adds its hits to the cell of every level it spans; levels without a cell in
+// this workgroup's table leave as per-level keys of the classic layout (sorted and reduced afterwards); should that list be
+// full, straight to the tables.
+__global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, ProfTableLayout TL,
+                                                                         uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
+                                                                         uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL,
+                                                                         uint64_t *__restrict__ leftOut, unsigned long long *__restrict__ leftCursor, unsigned long long leftCap,
+                                                                         int rangeCells)
+{
+    extern __shared__ uint32_t tab[];                                  // [level][|T| - 1][nTaxa], TL.nn[level] values of |T| per level
+    const uint32_t cells = (uint32_t)TL.first[MAX_LEVELS] * nTaxa;
+    // ... followed, when there is room (rangeCells), by [first level][nTaxa]: keys with |T| = 1 whose levels run down to the
+    // shallowest one (a k-mer matched to depth d against one taxon: the bulk) take ONE add there instead of one per level
+    uint32_t *tabR = tab + cells;
+    const uint32_t rangeN = rangeCells ? (uint32_t)nK * nTaxa : 0u;
+    __shared__ uint64_t sLeft[PT_LEFT];                                // per-level keys without a cell wait here and leave in bulk
+    __shared__ uint32_t sLeftN;
+    __shared__ unsigned long long sLeftBase;
+    for (uint32_t i = threadIdx.x; i < cells + rangeN; i += PT_THREADS) tab[i] = 0u;
+    if (threadIdx.x == 0) sLeftN = 0;
+    __syncthreads();
+    auto direct = [&](uint64_t pk) {                                   // a classic per-level key straight to the tables (the list is full)
+        const uint64_t f = pk >> 16;
+        const uint32_t hits = (uint32_t)(pk & 0xFFFFull), tax = (uint32_t)(f & ((1ull << PL.tb) - 1ull));
+        const uint32_t n = (uint32_t)((f >> PL.tb) & ((1ull << PL.nb) - 1ull)), lv = (uint32_t)(f >> (PL.tb + PL.nb));
+        const size_t cell = (size_t)lv * nTaxa + tax;
+        if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)hits);
+        fixed_add(hiTab, midTab, loTab, cell, hits, n);
+    };
+    auto flush = [&]() {                                               // all threads
+        const uint32_t n = min(sLeftN, (uint32_t)PT_LEFT);
+        if (threadIdx.x == 0) sLeftBase = atomicAdd(leftCursor, (unsigned long long)n);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += PT_THREADS) {
+            if (sLeftBase + i < leftCap) leftOut[sLeftBase + i] = sLeft[i]; else direct(sLeft[i]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sLeftN = 0;
+        __syncthreads();
+    };
+    constexpr int PT_KEYS = 8;
+    const uint64_t step = (uint64_t)gridDim.x * PT_THREADS * PT_KEYS;
+    const uint64_t rounds = ((uint64_t)nKeys + step - 1) / step;
+    // a workgroup sees at most `rounds * PT_THREADS * PT_KEYS` keys: with hits <= maxHits no 32-bit counter can wrap
+    const uint32_t maxHits = (uint32_t)std::min<uint64_t>(65535ull, 0xFFFFFFFFull / std::max<uint64_t>(1, rounds * PT_THREADS * PT_KEYS));
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        const uint64_t i0 = rd * step + (uint64_t)blockIdx.x * PT_THREADS * PT_KEYS + threadIdx.x;
+        uint64_t kk[PT_KEYS];
+#pragma unroll
+        for (int q = 0; q < PT_KEYS; ++q) { const uint64_t i = i0 + (uint64_t)q * PT_THREADS; kk[q] = i < nKeys ? keys[i] : 0ull; }   // (hits = 0: skipped)
+#pragma unroll
+        for (int q = 0; q < PT_KEYS; ++q) {
+            const uint64_t key = kk[q];
+            const uint32_t hits = (uint32_t)(key & 0xFFFFull);
+            if (hits == 0u) continue;
+            const uint32_t tax = (uint32_t)(key >> 16) & SEG_TAX_MASK, n = (uint32_t)(key >> 38) & 0x1FFFu;
+            const uint32_t lvLo = (uint32_t)(key >> 51) & 31u, lvHi = lvLo + ((uint32_t)(key >> 56) & 31u);
+            if (rangeN && n == 1u && lvHi + 1u == (uint32_t)nK && hits <= maxHits) { atomicAdd(&tabR[lvLo * nTaxa + tax], hits); continue; }
+            for (uint32_t lv = lvLo; lv <= lvHi; ++lv) {                     // (one pass over all levels: no level windows here)
+                if ((int)lv >= TL.lvLo && (int)lv < TL.lvHi && n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
+                else {
+                    const uint64_t pk = profile_key_of(lv, n, tax, hits, PL);
+                    const uint32_t at = atomicAdd(&sLeftN, 1u);
+                    if (at < (uint32_t)PT_LEFT) sLeft[at] = pk;
+                    else { const unsigned long long g = atomicAdd(leftCursor, 1ull); if (g < leftCap) leftOut[g] = pk; else direct(pk); }   // (the buffer is full: straight to the list)
+                }
+            }
+        }
+        __syncthreads();
+        if (sLeftN > (uint32_t)(PT_LEFT / 2)) flush();                 // uniform: read after the barrier
+    }
+    flush();
+    if (rangeN)                                                        // the range cells folded into the tables: a running sum over the first levels
+        for (uint32_t tax = threadIdx.x; tax < nTaxa; tax += PT_THREADS) {
+            unsigned long long acc = 0;
+            for (int lv = 0; lv < nK; ++lv) {
+                acc += tabR[(uint32_t)lv * nTaxa + tax];
+                if (!acc) continue;
+                const size_t cell = (size_t)lv * nTaxa + tax;
+                atomicAdd((unsigned long long *)&cntUnique[cell], acc);
+                atomicAdd((unsigned long long *)&hiTab[cell], acc);        // (fixed_add with |T| = 1)
+            }
+        }
+    for (uint32_t i = threadIdx.x; i < cells; i += PT_THREADS) {
+        const uint32_t c = tab[i];
+        if (!c) continue;
+        const uint32_t tax = i % nTaxa, row = i / nTaxa;
+        uint32_t lv = 0;
+        while (row >= (uint32_t)TL.first[lv + 1]) ++lv;
+        const uint32_t n = row - (uint32_t)TL.first[lv] + 1u;
+        const size_t cell = (size_t)lv * nTaxa + tax;
+        if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)c);
+        fixed_add(hiTab, midTab, loTab, cell, c, n);
+    }
+}
+
+// The profile keys of a batch summed into the tables (grouped: group_kernel's range keys; else the per-read side's keys):
+// counted per (level, |T|, taxon) in LDS where the table of a workgroup has a cell, the rest sorted and reduced.
+// Up to 8 levels: one pass over the keys; more: the four shallowest levels (large taxon sets) in one pass, the deeper ones
+// eight at a time.
+static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
+{
+    if (nKeys == 0) return KASA_OK;
+    const uint32_t nTaxa = c->ix->nTaxa;
+    const int nK = c->nK;
+    int rc;
+    hipStream_t ps = c->stream;
+    const ProfLayout PL = prof_layout(nTaxa, nK);
+    // group keys may leave several per-level keys each (a few per cent do); the list is sorted back into the key buffer
+    const uint64_t leftCap = std::min<uint64_t>(std::max<uint64_t>(nKeys, 1u << 20), c->profKeys.cap / 8);
+    if ((rc = c->profSorted.reserve((size_t)leftCap * 8 + 64))) return rc;
+    uint64_t budgetCells = (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u;
+    // group keys: range cells [first level][taxon] for the keys with |T| = 1 (when a third of the table's room suffices)
+    const bool rangeCells = grouped && (uint64_t)nK * nTaxa <= budgetCells / 3;
+    if (rangeCells) budgetCells -= (uint64_t)nK * nTaxa;
+    std::vector<ProfTableLayout> passes;
+    if (nK <= 8 || grouped) passes.push_back(prof_table_layout(nK, 0, nK, nTaxa, budgetCells));
+    else {
+        passes.push_back(prof_table_layout(nK, nK - 4, nK, nTaxa, budgetCells));
+        for (int hi = nK - 4; hi > 0; hi -= 8) passes.push_back(prof_table_layout(nK, std::max(0, hi - 8), hi, nTaxa, budgetCells));
+    }
+    bool tables = !(c->debugFlags & 16) || grouped;
+    for (const auto &TL : passes) if (TL.lvHi <= TL.lvLo && !grouped) tables = false;      // a window without cells: everything is sorted
+    uint64_t *sortIn = c->profKeys.as<uint64_t>(), *sortOut = c->profSorted.as<uint64_t>();
+    uint64_t nSort = nKeys;
+    if (tables) {
+        int nCu = 0;
+        HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
+        unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
+        unsigned long long left = 0;
+        HIPCHK(hipMemsetAsync(leftCursor, 0, 8, ps));
+        for (const auto &TL : passes) {
+            const size_t shBytes = ((size_t)TL.first[MAX_LEVELS] * nTaxa + (rangeCells ? (size_t)nK * nTaxa : 0)) * 4;
+            HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
+            if (grouped) {
+                HIPCHK(hipFuncSetAttribute((const void *)profile_group_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
+                profile_group_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, ps>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
+                    c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
+                    c->profSorted.as<uint64_t>(), leftCursor, (unsigned long long)leftCap, rangeCells ? 1 : 0);
+            } else
+            profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, ps>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
+                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
+                c->profSorted.as<uint64_t>(), leftCursor);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(&left, leftCursor, 8, hipMemcpyDeviceToHost, ps));
+        HIPCHK(hipStreamSynchronize(ps));
+        nSort = std::min<uint64_t>(left, leftCap); sortIn = c->profSorted.as<uint64_t>(); sortOut = c->profKeys.as<uint64_t>();   // what is left, sorted back into the key buffer
+    }
+    if (nSort > 0) {
+        // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
+        const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
+        if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(nSort)))) return rc;
+        uint64_t *kRes = nullptr;
+        HIPCHK(kasa_radix::sort_pairs<uint64_t>(sortIn, nullptr, sortOut, nullptr, (uint32_t)nSort, 16, sortBits, c->sortTmp.p, ps, &kRes, nullptr));
+        profile_reduce_kernel<<<std::min<unsigned>(blocks_for(nSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, ps>>>(
+            kRes, (uint32_t)nSort, nTaxa,
+            c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
+        HIPCHK(hipGetLastError());
+    }
     return KASA_OK;
 }
 
@@ -3977,30 +4427,40 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
     if (!exportSorted && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
     if ((rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
-    unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging
+    unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging, [18] profile keys
     hipEvent_t a, b;
     if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ);   // (a word per query: a first batch with crowded taxon lists -- 0.75 words per query on the bench data -- need not run group_kernel twice)
+    if (c->keyCap == 0) c->keyCap = RW == 8 ? std::max<uint64_t>(1u << 20, nQ / 2 + nQ / 4) : 64;   // (group keys: narrow records only; at least 2^20: the buffer also takes the sorted leftovers of the table pass)
+    uint64_t nKeys = 0;
     for (int attempt = 0;; ++attempt) {
-        if ((rc = c->pool.reserve(c->poolCap * 4))) return rc;
-        const unsigned long long one = 1;
+        if (c->keyCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the profile of this batch needs %llu keys (limit 2^32); split the batch", (unsigned long long)c->keyCap);
+        if ((rc = c->pool.reserve(c->poolCap * 4)) || (rc = c->profKeys.reserve(c->keyCap * 8 + 64))) return rc;
+        const unsigned long long one = 1, zero = 0;
         HIPCHK(hipMemcpyAsync(cursor, &one, 8, hipMemcpyHostToDevice, c->stream)); // offset 0 is never handed out
+        HIPCHK(hipMemcpyAsync(cursor + 2, &zero, 8, hipMemcpyHostToDevice, c->stream));
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
         const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
-        const int cov = coverage && attempt == 0;
+        const int cov = ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;
-        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, cov, cursor) : launch_group<16>(c, slotOf, nTiles, cap, cov, cursor)))) return rc;
+        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor)))) return rc;
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_GROUP], ka, kb))) return rc;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
-        unsigned long long used = 0;
-        HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long used[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(used, cursor, 24, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (used <= c->poolCap) { c->poolUsed = (uint32_t)used; break; }
-        if (used >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the taxon lists of this batch need %llu pool entries (limit 2^32); split the batch", used);
-        c->poolCap = used + used / 8 + 1024;
+        if (used[0] <= c->poolCap && used[2] <= c->keyCap) { c->poolUsed = (uint32_t)used[0]; nKeys = used[2]; break; }
+        if (used[0] >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the taxon lists of this batch need %llu pool entries (limit 2^32); split the batch", used[0]);
+        if (used[0] > c->poolCap) c->poolCap = used[0] + used[0] / 8 + 1024;
+        if (used[2] > c->keyCap) c->keyCap = used[2] + used[2] / 8 + 1024;
         if (attempt > 3) return fail(KASA_E_LIMIT, "taxon-list pool did not converge");
     }
+    // the profile of the batch: the leaders' keys into the tables (the per-read score stage adds nothing to them)
+    if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
+    if (RW == 8 && (rc = profile_from_keys(c, nKeys, true))) return rc;
+    if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
+    c->lastKeys = nKeys;
     c->grouped = true;
     return KASA_OK;
 }
@@ -4050,27 +4510,29 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         return KASA_OK;
     }
     uint32_t *counters = c->misc.as<uint32_t>(); // [2] error flags, [3] fallback count, [5] second-pass count, [8..15] reasons; u64 [16] pool cursor, [17] staging cursor
-    unsigned long long *stCursor = c->misc.as<unsigned long long>() + 17, *keyCursor = c->misc.as<unsigned long long>() + 18;
+    const bool gp = RW == 8;                     // narrow records: the profile is group_stage's, the kernels here leave no keys (they still add their zero)
+    unsigned long long *stCursor = c->misc.as<unsigned long long>() + 17, *keyCursor = c->misc.as<unsigned long long>() + (gp ? 30 : 18);
     hipEvent_t a, b;
 
     if ((rc = c->rowPos.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowLen.reserve((size_t)nReads * 4 + 64)) || (rc = c->rowKey.reserve((size_t)nReads * 4 + 64)) ||
         (rc = c->rowOff.reserve(((size_t)nReads + 1) * 8 + 64)) || (rc = c->fbList.reserve((size_t)nReads * 4 + 64)))
         return rc;
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
-    if (c->keyCap == 0) c->keyCap = c->stCap;
     const bool fast = nK <= 25 && nTaxa <= (1u << 20) && !c->forceSlowScore;   // staging records keep the taxon in 20 bits
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
     c->lastOverflowReads = 0;
     uint64_t staged = 0, nKeys = 0;
+    if (!gp && c->keyCapScore == 0) c->keyCapScore = c->stCap;
     ScoreArgs A;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 4) return fail(KASA_E_LIMIT, "score staging did not converge");
         if (c->stCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the score rows of this batch need %llu staging records (limit 2^32); split the batch", (unsigned long long)c->stCap);
-        if (c->keyCap >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the profile of this batch needs %llu keys (limit 2^32); split the batch", (unsigned long long)c->keyCap);
-        if ((rc = c->st.reserve(c->stCap * 8)) || (rc = c->profKeys.reserve(c->keyCap * 8 + 64))) return rc;
+        if (!gp && c->keyCapScore >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the profile of this batch needs %llu keys (limit 2^32); split the batch", (unsigned long long)c->keyCapScore);
+        if ((rc = c->st.reserve(c->stCap * 8)) || (!gp && (rc = c->profKeys.reserve(c->keyCapScore * 8 + 64)))) return rc;
         HIPCHK(hipMemsetAsync(counters + 2, 0, 8, c->stream));  // error flags, fallback count
         HIPCHK(hipMemsetAsync(counters + 8, 0, 32, c->stream));
-        HIPCHK(hipMemsetAsync(stCursor, 0, 16, c->stream));            // staging and key cursors
+        HIPCHK(hipMemsetAsync(stCursor, 0, 8, c->stream));             // staging cursor
+        HIPCHK(hipMemsetAsync(keyCursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
         A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
@@ -4079,12 +4541,12 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         A.rowPos = c->rowPos.as<uint32_t>(); A.rowLen = c->rowLen.as<uint32_t>();
         A.st = c->st.as<uint2>();
         A.stCap = (uint32_t)c->stCap; A.stCursor = stCursor; A.errFlag = counters + 2;
-        A.rowKey = c->rowKey.as<uint32_t>(); A.keyCap = (uint32_t)c->keyCap; A.keyCursor = keyCursor;
+        A.rowKey = c->rowKey.as<uint32_t>(); A.keyCap = gp ? 0xFFFFFFFFu : (uint32_t)c->keyCapScore; A.keyCursor = keyCursor;
         A.wantPerRead = wantPerRead ? 1 : 0;
-        A.addProfile = slowProfileDone ? 0 : 1;
+        A.addProfile = gp ? 0 : (slowProfileDone ? 0 : 1);
         A.list = nullptr; A.nList = 0; A.flushPos = nullptr; A.flushOff = nullptr;
         A.fbList = c->fbList.as<uint32_t>(); A.fbCount = counters + 3; A.why = counters + 8;
-        A.ovList = nullptr; A.ovCount = nullptr; A.workCursor = nullptr;
+        A.ovList = nullptr; A.ovCount = nullptr; A.workCursor = nullptr; A.forceHandOn = (c->debugFlags & 16384) ? 1 : 0;
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         uint32_t nSlow = nReads;
         if (fast) {
@@ -4133,16 +4595,16 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_OTHER], ka, kb))) return rc;
             uint32_t h3 = 0; unsigned long long want[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(&h3, counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(want, stCursor, 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(want, stCursor, gp ? 8 : 16, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             nSlow = h3;
-            if (want[0] > c->stCap || want[1] > c->keyCap) {   // the fast kernels have no side effects: grow and rerun
+            if (want[0] > c->stCap || (!gp && want[1] > c->keyCapScore)) {   // the fast kernels have no side effects: grow and rerun
                 if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
                 if (want[0] > c->stCap) c->stCap = want[0] + want[0] / 8 + (uint64_t)nSlow * 64 + 1024;
-                if (want[1] > c->keyCap) c->keyCap = want[1] + want[1] / 8 + 1024;
+                if (!gp && want[1] > c->keyCapScore) c->keyCapScore = want[1] + want[1] / 8 + 1024;
                 continue;
             }
-            nKeys = want[1];
+            nKeys = gp ? 0 : want[1];
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         if (nSlow > 0) {
@@ -4171,6 +4633,16 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             HIPCHK(hipMemsetAsync(counters + 5, 0, 4, c->stream));
             A.scratch = c->scratch.as<float>();
             A.ovList = c->ovList.as<uint32_t>(); A.ovCount = counters + 5;
+            const bool dense = nTaxa <= (uint32_t)DENSE_TAXA && !(c->debugFlags & 8192);   // (test tap 8192: the lane-owns-its-cells form)
+            const size_t rowLds = dense ? (size_t)nTaxa * 4 : 0;
+            if (dense) {
+                HIPCHK(hipFuncSetAttribute((const void *)score_kernel<PCAP_SMALL, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                HIPCHK(hipFuncSetAttribute((const void *)score_kernel<PCAP_SMALL, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                HIPCHK(hipFuncSetAttribute((const void *)score_kernel<PCAP, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                HIPCHK(hipFuncSetAttribute((const void *)score_kernel<PCAP, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                if (RW == 8) score_kernel<PCAP_SMALL, 8, true><<<blocks, 64, rowLds, c->stream>>>(A);
+                else score_kernel<PCAP_SMALL, 16, true><<<blocks, 64, rowLds, c->stream>>>(A);
+            } else
             if (RW == 8) score_kernel<PCAP_SMALL, 8><<<blocks, 64, 0, c->stream>>>(A);      // leaves every score row zeroed again
             else score_kernel<PCAP_SMALL, 16><<<blocks, 64, 0, c->stream>>>(A);
             HIPCHK(hipGetLastError());
@@ -4197,6 +4669,10 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
                 A.flushPos = c->flushPos2.as<uint32_t>(); A.flushOff = c->flushOff2.as<uint64_t>();
                 A.ovList = nullptr; A.ovCount = nullptr;
                 const uint32_t b2 = std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u));
+                if (dense) {
+                    if (RW == 8) score_kernel<PCAP, 8, true><<<b2, 64, rowLds, c->stream>>>(A);
+                    else score_kernel<PCAP, 16, true><<<b2, 64, rowLds, c->stream>>>(A);
+                } else
                 if (RW == 8) score_kernel<PCAP, 8><<<b2, 64, 0, c->stream>>>(A);
                 else score_kernel<PCAP, 16><<<b2, 64, 0, c->stream>>>(A);
                 HIPCHK(hipGetLastError());
@@ -4214,74 +4690,42 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (want <= c->stCap) { staged = want; break; }
         c->stCap = want + want / 8 + 1024;
     }
-    // ---- resolve the fast kernels' records: per-read merge, then the profile contributions by sort + reduce
-    bool profPending = false, profTables = false;
-    hipStream_t ps = c->stream;                                // (a second stream for the profile side, beside the CSR packing, was measured: no gain)
-    unsigned long long profLeft = 0;
-    uint64_t *profSortIn = nullptr, *profSortOut = nullptr, profSort = 0;
+    // ---- resolve the fast kernels' records: per-read merge
+    bool mergePending = false;
     if (fast && staged > 0) {
         const ProfLayout PL = prof_layout(nTaxa, nK);
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
-        if ((rc = c->profSorted.reserve((size_t)nKeys * 8 + 64))) return rc;   // nKeys < 2^32; profKeys holds keyCap >= nKeys entries
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_ROW_MERGE], &ka, &kb))) return rc;
+        uint64_t *noKeys = gp ? nullptr : c->profKeys.as<uint64_t>();   // (narrow records: the rows' events leave no profile keys -- group_stage)
         if (nTaxa <= (uint32_t)BM_WORDS * 32u && !(c->debugFlags & 4)) {
             uint32_t mLo = 0;
             if (nTaxa <= 2048u) {
                 // (three sizes: the LDS a row needs is what limits the resident wavefronts of this latency-bound kernel)
                 row_merge_bitmap_kernel<256, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, 0u, PL);
                 row_merge_bitmap_kernel<512, 64><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 256u, PL);
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, 256u, PL);
                 mLo = 512;
             } else {                                                 // up to 16384 taxa: the same two sizes over the wide bitmap
                 row_merge_bitmap_kernel<256, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 32u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, 0u, PL);
+                    c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, 0u, PL);
                 mLo = 256;
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
-                c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, nTaxa, mLo, PL);
+                c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, mLo, PL);
         } else
             row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(),
-                c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), c->profKeys.as<uint64_t>(), c->kHigh, PL);
+                c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, PL);
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
-        c->lastStaged = staged; c->lastKeys = nKeys;
-        // the keys summed per (level, |T|, taxon): counted in LDS when the table fits a workgroup, else sorted and reduced
-        // Up to 8 levels: one pass; more: the four shallowest levels (large taxon sets) in one pass, the deeper ones eight at
-        // a time.  Keys no pass has a cell for collect in one list, which is sorted and reduced.
-        const uint64_t budgetCells = (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u;
-        std::vector<ProfTableLayout> passes;
-        if (nK <= 8) passes.push_back(prof_table_layout(nK, 0, nK, nTaxa, budgetCells));
-        else {
-            passes.push_back(prof_table_layout(nK, nK - 4, nK, nTaxa, budgetCells));
-            for (int hi = nK - 4; hi > 0; hi -= 8) passes.push_back(prof_table_layout(nK, std::max(0, hi - 8), hi, nTaxa, budgetCells));
-        }
-        bool tables = nKeys > 0 && !(c->debugFlags & 16);
-        for (const auto &TL : passes) if (TL.lvHi <= TL.lvLo) tables = false;      // a window without cells: everything is sorted
-        profSortIn = c->profKeys.as<uint64_t>(); profSortOut = c->profSorted.as<uint64_t>();
-        profSort = nKeys;
-        if (tables) {
-            int nCu = 0;
-            HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
-            unsigned long long *leftCursor = c->misc.as<unsigned long long>() + 19;
-            HIPCHK(hipMemsetAsync(leftCursor, 0, 8, ps));
-            for (const auto &TL : passes) {
-                const size_t shBytes = (size_t)TL.first[MAX_LEVELS] * nTaxa * 4;
-                HIPCHK(hipFuncSetAttribute((const void *)profile_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
-                profile_table_kernel<<<std::max(1, nCu), PT_THREADS, shBytes, ps>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, nK, TL,
-                    c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL,
-                    c->profSorted.as<uint64_t>(), leftCursor);
-                HIPCHK(hipGetLastError());
-            }
-            HIPCHK(hipMemcpyAsync(&profLeft, leftCursor, 8, hipMemcpyDeviceToHost, ps));
-            profTables = true;
-        }
-        profPending = true;
+        c->lastStaged = staged;
+        if (!gp) { c->lastKeys = nKeys; if ((rc = profile_from_keys(c, nKeys, false))) return rc; }
+        mergePending = true;
     }
     if (wantPerRead) {
         // CSR offsets = exclusive scan of the row lengths, then rows copied in read order
-        if (!profPending && (rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
+        if (!mergePending && (rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         DevBuf &len64 = c->qReadA; // reuse
         if ((rc = len64.reserve(((size_t)nReads + 1) * 8 + 64))) return rc;
         HIPCHK(hipMemsetAsync(len64.p, 0, ((size_t)nReads + 1) * 8, c->stream));
@@ -4301,24 +4745,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
         HIPCHK(hipGetLastError());
     }
-    if (profPending) {
-        // back to the profile side: what the tables had no cell for is sorted and reduced
-        HIPCHK(hipStreamSynchronize(ps));
-        if (profTables) { profSort = profLeft; profSortIn = c->profSorted.as<uint64_t>(); profSortOut = c->profKeys.as<uint64_t>(); }   // what is left, sorted back into the key buffer
-        if (profSort > 0) {
-            const ProfLayout PL = prof_layout(nTaxa, nK);
-            // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
-            const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
-            if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<uint64_t>(profSort)))) return rc;
-            uint64_t *kRes = nullptr;
-            HIPCHK(kasa_radix::sort_pairs<uint64_t>(profSortIn, nullptr, profSortOut, nullptr, (uint32_t)profSort, 16, sortBits, c->sortTmp.p, ps, &kRes, nullptr));
-            profile_reduce_kernel<<<std::min<unsigned>(blocks_for(profSort, PR_THREADS * PR_ITEMS), 256u * 16u), PR_THREADS, 0, ps>>>(
-                kRes, (uint32_t)profSort, nTaxa,
-                c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
-            HIPCHK(hipGetLastError());
-        }
-    }
-    if (profPending || wantPerRead) { if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc; }
+    if (mergePending || wantPerRead) { if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (wantPerRead) c->haveScores = true;
     c->state = 4;
@@ -4332,6 +4759,10 @@ extern "C" int kasa_batch_lookup_score(kasa_ctx *c, int wantPerRead, int coverag
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_lookup_score: batch not sorted");
     int rc = group_stage(c, coverage, false);
     if (rc) return rc;
+    if (c->recWords() == 8 && !wantPerRead && !c->forceSlowScore) {                  // kASA without -q: the profile is complete after the group stage
+        c->haveScores = false; c->nnz = 0; c->state = 4;
+        return KASA_OK;
+    }
     return score_stage(c, wantPerRead);
 }
 
@@ -5336,6 +5767,32 @@ static int profile_fetch_impl(kasa_ctx *c, double *countAll, uint64_t *countUniq
         if (countTotal) countTotal[i] = t[i];
         if (countAll) countAll[i] = (double)hi[i] + (double)lo[i] * 5.42101086242752217e-20; // 2^-64
     }
+    return KASA_OK;
+}
+
+__global__ void tables_absorb_kernel(uint64_t *__restrict__ dst, uint64_t *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { dst[i] += src[i]; src[i] = 0ull; }
+}
+
+// dst += src, src = 0: the tables of a context that only grouped (a partition worker: the profile is made where the
+// queries are grouped) go to the context that owns the file's profile.  Same device, same k range, same index content.
+extern "C" int kasa_profile_absorb(kasa_ctx *dst, kasa_ctx *src)
+{
+    if (!dst || !src) return fail(KASA_E_ARG, "kasa_profile_absorb: NULL argument");
+    if (dst == src) return KASA_OK;
+    if (dst->device != src->device || dst->nK != src->nK || dst->kHigh != src->kHigh || dst->ix->nTaxa != src->ix->nTaxa)
+        return fail(KASA_E_ARG, "kasa_profile_absorb: the contexts differ in device, k range or number of taxa");
+    HIPCHK(hipSetDevice(dst->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    const size_t cells = (size_t)dst->nK * dst->ix->nTaxa;
+    DevBuf *d[5] = {&dst->cntUnique, &dst->cntTotal, &dst->cntAllHi, &dst->cntAllMid, &dst->cntAllLo};
+    DevBuf *q[5] = {&src->cntUnique, &src->cntTotal, &src->cntAllHi, &src->cntAllMid, &src->cntAllLo};
+    for (int k = 0; k < 5; ++k)
+        tables_absorb_kernel<<<blocks_for(cells, 256), 256, 0, dst->stream>>>(d[k]->as<uint64_t>(), q[k]->as<uint64_t>(), cells);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(dst->stream));
     return KASA_OK;
 }
 

@@ -222,7 +222,7 @@ def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool
     rec_out = torch.empty(total_in * rw, dtype=torch.uint8, device=dev)
     pools, pool_counts, at = [], [], 0
     for s in range(world):                                        # the slices of every rank, against my partition
-        rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s])
+        rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s], sink=ctx)   # (the slice's profile stays on this rank: the reduce sums the ranks)
         _device_copy(rec_out.data_ptr() + at * rw, rp, nrw * 4)   # the worker's buffers are reused by the next slice
         p = torch.empty(npw * 4, dtype=torch.uint8, device=dev)
         _device_copy(p.data_ptr(), pp, npw * 4)
@@ -275,7 +275,7 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
     n_in = all_to_all_arrays([np.asarray([ctx.n_reads], dtype=np.int64) for _ in range(world)])
     rec_out, pool_out = [], []
     for s in range(world):                                        # the slices of every rank, against my partition
-        rec, pool = worker.group_slice(km_in[s], rd_in[s], int(n_in[s][0]))
+        rec, pool = worker.group_slice(km_in[s], rd_in[s], int(n_in[s][0]), sink=ctx)   # (the slice's profile stays on this rank: the reduce sums the ranks)
         rec_out.append(rec.reshape(-1))
         pool_out.append(pool)
     rec_back = all_to_all_arrays(rec_out)

@@ -79,17 +79,23 @@ class Worker:
     def __init__(self, dix: capi.DeviceIndex, k_high: int, k_low: int, frames: int):
         self.ctx = capi.Context(dix, k_high, k_low, frames)
 
-    def group_slice(self, km: np.ndarray, rd: np.ndarray, n_reads: int):
+    def group_slice(self, km: np.ndarray, rd: np.ndarray, n_reads: int, sink: capi.Context = None):
+        """sink: the context that collects this rank's profile -- the profile of a slice is made where the slice is grouped
+        (kasa_batch_group), i.e. here; the sum over the ranks' sinks is the file's profile."""
         self.ctx.set_queries(km, rd, n_reads)
         self.ctx.sort_and_range()                                  # already sorted; the sort is stable
         self.ctx.group()
+        if sink is not None:
+            sink.profile_absorb(self.ctx)
         return self.ctx.records()
 
-    def group_slice_device(self, ptr: int, n: int):
+    def group_slice_device(self, ptr: int, n: int, sink: capi.Context = None):
         """The same for a slice that is already in device memory (`ptr`: its sorted k-mers); returns device pointers
         (records pointer, record words, pool pointer, pool words), valid until the worker's next slice."""
         self.ctx.set_sorted_device(ptr, n)
         self.ctx.group()
+        if sink is not None:
+            sink.profile_absorb(self.ctx)
         return self.ctx.records_device()
 
     def close(self):
@@ -115,13 +121,13 @@ class LocalExchange:
         if self.device_resident:
             ptr, n, kb = ctx.queries_device()
             starts = ctx.slice_starts(self.cuts)
-            parts = [w.group_slice_device(ptr + int(starts[j]) * kb, int(starts[j + 1] - starts[j])) for j, w in enumerate(self.workers)]
+            parts = [w.group_slice_device(ptr + int(starts[j]) * kb, int(starts[j + 1] - starts[j]), sink=ctx) for j, w in enumerate(self.workers)]
             ctx.records_import_device(parts)
             ctx.score(want_per_read)
             return ctx
         km, rd = ctx.queries()
         starts = slice_starts(km, self.cuts, self.K)
-        parts = [w.group_slice(km[starts[j]:starts[j + 1]], rd[starts[j]:starts[j + 1]], ctx.n_reads)
+        parts = [w.group_slice(km[starts[j]:starts[j + 1]], rd[starts[j]:starts[j + 1]], ctx.n_reads, sink=ctx)
                  for j, w in enumerate(self.workers)]
         rec, pool = assemble_records(parts, starts)
         ctx.records_import(rec, pool)

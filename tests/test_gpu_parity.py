@@ -550,8 +550,8 @@ def test_wide_index_synthetic(krange, flags):
 
 
 # ---- BASELINE.json's full size (C2): properties that do not need the oracle to run 1.3e9 queries ---------------------
-@pytest.mark.parametrize("K", [12, 25], ids=["C2_64bit_k12_7", "C3_128bit_k25_7"])
-def test_full_size_properties(K):
+@pytest.mark.parametrize("K,workload", [(12, "pairs"), (25, "pairs"), (12, "crowded")], ids=["C2_64bit_k12_7", "C3_128bit_k25_7", "crowded_64bit_k12_7"])
+def test_full_size_properties(K, workload):
     """BASELINE.json configs[1] (64-bit index, -k 12 7) and configs[2] (128-bit index, -k 25 7, 64-byte event records) at
     full size.  10 M x 150 bp reads against the 4.2e8-record index of bench.py (scaled down with KASA_TEST_FULL_READS /
     KASA_TEST_FULL_TAXA when the box is small):
@@ -561,12 +561,16 @@ def test_full_size_properties(K):
       * conservation: per level, sum over taxa of countAll = number of sorted queries whose match reaches that level;
       * shard invariance of the per-read taxon sets (scores may move in the last float digit with the batch);
       * a random sample of reads against the CPU oracle on the same 5 GB index;
-      * the first 300 000 reads as a batch of their own: every score bit-equal to the oracle's on the same index."""
+      * the first 300 000 reads as a batch of their own: every score bit-equal to the oracle's on the same index.
+    "crowded": the same index size, but the taxa come in clades of 50-200 that share conserved genes (synth.genomes_crowded;
+    bench.py's `tertiary`): a third of the reads meet tens to hundreds of taxa per k-mer (long taxon lists, reads on the
+    general score kernel, groups with thousands of hits).  2 M reads, 100 000 of them bit for bit against the oracle."""
     _gpu_or_fail()
     from kasa_amd import synth
-    n_reads = int(os.environ.get("KASA_TEST_FULL_READS", "10000000"))
+    crowded = workload == "crowded"
+    n_reads = int(os.environ.get("KASA_TEST_FULL_READS", "2000000" if crowded else "10000000"))
     n_taxa = int(os.environ.get("KASA_TEST_FULL_TAXA", "1400"))
-    g = synth.genomes(n_taxa, 300_000, seed=11)
+    g = synth.genomes_crowded(n_taxa, 300_000, seed=11) if crowded else synth.genomes(n_taxa, 300_000, seed=11)
     kh = 12 if K == 12 else 25
     nK = kh - 7 + 1
     ix = synth.index_from_genomes(g, K=K)
@@ -629,7 +633,7 @@ def test_full_size_properties(K):
     del res
     # a whole batch, bit for bit: the first reads as a batch of their own on the device and in the oracle (per-read
     # float sums depend on the reads that share a batch, so only equal batches can be compared exactly)
-    n_exact = min(batch.n, int(os.environ.get("KASA_TEST_EXACT_READS", "300000")))
+    n_exact = min(batch.n, int(os.environ.get("KASA_TEST_EXACT_READS", "100000" if crowded else "300000")))
     part = batch.slice(0, n_exact)
     ctx.profile_reset()
     o, t, v = run(part)
@@ -642,6 +646,9 @@ def test_full_size_properties(K):
     assert np.array_equal(o, np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=part.n)))).astype(np.uint64))
     assert np.array_equal(t, (cols + 1).astype(np.uint32))
     assert np.array_equal(v.view(np.uint32), res.M[rows, cols + 1].astype(np.float32).view(np.uint32))   # every float, every bit
+    if crowded:                                                   # the workload is what it claims to be
+        st = ctx.batch_stats()
+        assert st["general_reads"] > n_exact // 20, st
     ctx.close(); dix.close()
 
 
@@ -792,9 +799,12 @@ def test_random_configurations(seed):
     _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
 
 
-def test_general_kernel_second_pass_is_reached():
-    """Reads with hundreds of distinct (level, |T|, taxon) keys overflow the per-read aggregation table of the general
-    score kernel's first pass; they are handed to its second pass, which must give the same result."""
+@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192], ids=["dense_rows", "second_pass", "lane_owned_cells"])
+def test_general_kernel_on_huge_taxon_sets(flags):
+    """Every taxon a light mutation of one root: a query meets hundreds of taxa per level.  On the general score kernel: with
+    the read's row in LDS and an event's taxa dealt out to the lanes (the product path for such reads), through its second
+    pass (debug flag 16384 hands every read on: the pass with the full pending window must give the same result), and in the
+    lane-owns-its-cells form that indices beyond 16 384 taxa take (flag 8192)."""
     _gpu_or_fail()
     rng = np.random.default_rng(19)
     alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -818,10 +828,10 @@ def test_general_kernel_second_pass_is_reached():
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
-    ctx.debug_flags(1)                                           # everything on the general kernel
+    ctx.debug_flags(flags)                                       # everything on the general kernel
     ctx.run_batch(batch.bases, batch.offsets, True)
     general, second = ctx.counters()
-    assert general == batch.n and second > 0, (general, second)
+    assert general == batch.n and (second == batch.n if flags & 16384 else second == 0), (general, second)
     ca, cu, _ = ctx.profile()
     assert np.array_equal(cu, res.count_unique)
     np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
