@@ -531,6 +531,25 @@ def file_to_file(args, ix, reads, device, memories=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def make_comm(rank, world, share, torch, dist, kdist):
+    """The C ABI's own RCCL communicator for the profile reduce (N > 1) -> (comm, ranks RCCL reports, how the reduce runs)."""
+    comm, rccl_ranks, reduce_how = 0, None, None
+    if world > 1 and not share:
+        try:
+            comm, rccl_ranks = kdist.rccl_communicator(rank, world)
+            reduce_how = "kasa_profile_allreduce (C ABI: limbs packed on the device, ncclAllReduce on the context's stream)"
+        except Exception as ex:                          # never lose the measurement to the plumbing: torch.distributed carries the same sum
+            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed: %s)" % str(ex)[:200]
+        ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks the same way
+        if int(ok.item()) == 0 and comm:
+            kdist.rccl_destroy(comm)
+            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed on another rank)"
+    elif world > 1:
+        reduce_how = "gloo all_reduce of the limbs through the host (KASA_BENCH_SHARE_GPU test hook)"
+    return comm, rccl_ranks, reduce_how
+
+
 def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, synth, kdist):
     """BASELINE.json configs[4] (C5): an index too large for one GPU, range-partitioned over the ranks at 30-bit prefix
     boundaries (kasa_amd/partition.py, dist.py).  Every rank's slice = the genomes' records of its prefix range plus random
@@ -593,12 +612,21 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
         n_reads = int(t.item())
     reads = synth.reads_from_genomes(g, n_reads, L, seed=1000 + rank)
     stats = {}
+    comm, rccl_ranks, reduce_how = make_comm(rank, world, share, torch, dist, kdist)
+    acc = {"reduce_s": 0.0}
 
     def step():
         owner.profile_reset()                                              # a step is a whole "file"
         kdist.partitioned_batch(owner, worker, cuts, 12, reads, not args.profile_only, False, stats=stats)
         if world > 1:
-            owner.profile_set_limbs(kdist.allreduce_limbs(owner.profile_limbs(), device=None if share else "cuda"))
+            owner.synchronize()
+            t0 = time.perf_counter()
+            if comm:
+                owner.profile_allreduce(comm)                              # the C ABI's reduce, as in the read-sharded run
+            else:
+                owner.profile_set_limbs(kdist.allreduce_limbs(owner.profile_limbs(), device=None if share else "cuda"))
+            owner.synchronize()
+            acc["reduce_s"] += time.perf_counter() - t0
 
     def fence():
         owner.synchronize(); worker.ctx.synchronize()
@@ -609,14 +637,21 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
     for _ in range(args.warmup):
         step()
     fence()
+    acc["reduce_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    owner.synchronize(); worker.ctx.synchronize()
+    mine = time.perf_counter() - t0
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+    tdev = "cpu" if share else dev
+    tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    every = [torch.zeros(1, dtype=torch.float64, device=tdev) for _ in range(world)]
+    dist.all_gather(every, torch.tensor([mine], dtype=torch.float64, device=tdev))
+    rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
     ca, cu, _ = owner.profile()
     n_kmers = owner.n_kmers
     out = {"metric": "reads/s in identify (150bp reads vs range-partitioned k=12 index, cross-rank lookup)",
@@ -631,7 +666,12 @@ def bench_partitioned(args, rank, local_rank, world, share, torch, dist, capi, s
                       "exchange": "gloo, host-staged (KASA_BENCH_SHARE_GPU test hook)" if share else "RCCL all_to_all on device tensors"},
            "kmers_per_s": n_kmers * world * args.steps / dt,
            "identified_fraction": float(ca[-1].sum()) / max(1, n_kmers * world),
+           "rank_step_ms": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+           "reduce_ms_per_step": acc["reduce_s"] / max(1, args.steps) * 1e3,
            "exchange_bytes_per_step_this_rank": stats}
+    out["config"].update({"reduce": reduce_how, "rccl_ranks": rccl_ranks})
+    if comm:
+        kdist.rccl_destroy(comm)
     owner.close(); worker.close(); dix.close()
     return out
 
@@ -711,21 +751,7 @@ def main():
         dist.destroy_process_group()
         return
 
-    # the C ABI's own RCCL communicator for the profile reduce (N > 1)
-    comm, rccl_ranks, reduce_how = 0, None, None
-    if world > 1 and not share:
-        try:
-            comm, rccl_ranks = kdist.rccl_communicator(rank, world)
-            reduce_how = "kasa_profile_allreduce (C ABI: limbs packed on the device, ncclAllReduce on the context's stream)"
-        except Exception as ex:                          # never lose the measurement to the plumbing: torch.distributed carries the same sum
-            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed: %s)" % str(ex)[:200]
-        ok = torch.tensor([1 if comm else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # all ranks the same way
-        if int(ok.item()) == 0 and comm:
-            kdist.rccl_destroy(comm)
-            comm, reduce_how = 0, "torch.distributed all_reduce of the limbs (C-ABI communicator failed on another rank)"
-    elif world > 1:
-        reduce_how = "gloo all_reduce of the limbs through the host (KASA_BENCH_SHARE_GPU test hook)"
+    comm, rccl_ranks, reduce_how = make_comm(rank, world, share, torch, dist, kdist)
 
     holder = {}
 

@@ -150,6 +150,10 @@ int kasa_batch_lookup_score(kasa_ctx *ctx, int wantPerRead, int coverage);
  *                             to a context whose batch is sorted, which files them by read;
  *   kasa_batch_score          replays the records per read (scores, profile) exactly as kasa_batch_lookup_score does. */
 int kasa_batch_group(kasa_ctx *ctx, int coverage);
+/* kasa_batch_group with the records written straight into the caller's device buffer (room for
+ * number of queries x record words u32): the partition worker groups a slice into the tensor its collective sends, no copy
+ * in between.  kasa_batch_records_device then reports that pointer; the pool stays the context's. */
+int kasa_batch_group_to(kasa_ctx *ctx, int coverage, uint32_t *recordsOutDev);
 int kasa_batch_score(kasa_ctx *ctx, int wantPerRead);
 int kasa_batch_records_size(kasa_ctx *ctx, uint64_t *nRecordWords, uint64_t *nPoolWords);
 int kasa_batch_records_fetch(kasa_ctx *ctx, uint32_t *records, uint32_t *pool);

@@ -20,7 +20,7 @@ STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
 EXPORTS = [
     "kasa_last_error", "kasa_device_count", "kasa_index_create", "kasa_index_destroy", "kasa_index_size",
     "kasa_index_device_bytes", "kasa_builtin_codon_table", "kasa_ctx_create", "kasa_ctx_set_protein", "kasa_ctx_destroy", "kasa_batch_upload", "kasa_batch_upload_device", "kasa_batch_upload_segments", "kasa_batch_encode",
-    "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_score", "kasa_batch_records_size",
+    "kasa_batch_sort_and_range", "kasa_batch_lookup_score", "kasa_batch_group", "kasa_batch_group_to", "kasa_batch_score", "kasa_batch_records_size",
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_absorb", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs", "kasa_profile_allreduce",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
@@ -339,6 +339,10 @@ class Context:
 
     def group(self, coverage: bool = False):
         _check(lib().kasa_batch_group(self.h, C.c_int(int(coverage))))
+
+    def group_to(self, records_ptr: int, coverage: bool = False):
+        """group() with the records written straight into device memory at `records_ptr` (kasa_batch_group_to)."""
+        _check(lib().kasa_batch_group_to(self.h, C.c_int(int(coverage)), C.c_void_p(records_ptr)))
 
     def score(self, want_per_read: bool = True):
         _check(lib().kasa_batch_score(self.h, C.c_int(int(want_per_read))))

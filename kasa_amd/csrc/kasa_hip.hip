@@ -515,7 +515,9 @@ struct kasa_ctx {
     uint64_t txtTotal = 0; bool txtValid = false;
     const float *cohScores = nullptr;                          // device: the scores of the last kasa_batch_coherence of this batch
     bool grouped = false; uint32_t poolUsed = 1; // event records + pool of this batch are in place (group stage or import)
+    bool groupCoop = false;                     // group_kernel's cooperative form (long taxon lists were met; sticky)
     bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
+    uint32_t *recOut = nullptr;                 // ... written straight into the caller's buffer (kasa_batch_group_to), not into `rec`
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
     // buffers
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
@@ -1718,7 +1720,7 @@ extern "C" int kasa_batch_sort_and_range(kasa_ctx *c, int unique)
 
 static constexpr int GITEMS = 2;                  // the group kernel gives a thread two queries of the tile
 static constexpr int GTHREADS = TILE / GITEMS;    // 512
-static constexpr int GOVF = 1536;                 // segments beyond the inline ones a tile can park in LDS (narrow records)
+static constexpr int GOVF = 1024;                 // segments beyond the inline ones a tile can park in LDS (narrow records)
 static constexpr int GSPAN = 3072;                // index entries around the tile's matches staged in LDS (taxon + neighbour counts)
 static constexpr uint32_t GMARGIN = 96;           // ... this many beyond the first and last representative
 
@@ -1800,8 +1802,9 @@ __device__ __forceinline__ uint32_t block_excl_prefix_sum(uint32_t v, uint32_t *
 // = min(d, letters shared by all neighbours between i and j) -- `meta` holds the neighbour counts.  Both directions are
 // merged so that the segments come in descending order of their last level.  Calls emit(seg).
 // `meta(i)` / `tax(i)` read the index arrays (group_kernel serves them from the tile's span staged in LDS).
+// maxSteps: give up (false) after that many entries beyond j -- a long walk is the whole wavefront's (coop_walk).
 template <class Meta, class GetMeta, class GetTax, class Emit>
-__device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, GetMeta meta, GetTax tax, uint32_t nIdx, Emit emit)
+__device__ __forceinline__ bool walk_segments(uint32_t j, int d, int kLow, GetMeta meta, GetTax tax, uint32_t nIdx, Emit emit, uint32_t maxSteps = 0xFFFFFFFFu)
 {
     constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;
     const int gLow = group_letters(kLow);
@@ -1819,7 +1822,9 @@ __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, GetMe
     uint32_t mri = ri < nIdx ? (uint32_t)meta(ri) : 0u;           // meta[ri]: letters ri shares with ri - 1
     int lc = li > 0 ? ((int)(mli & LM) < chain0 ? (int)(mli & LM) : chain0) : -1;   // letters the next left entry shares with the query
     int rc = ri < nIdx ? ((int)(mri & LM) < chain0 ? (int)(mri & LM) : chain0) : -1;
+    uint32_t steps = 0;
     while (lc >= gLow || rc >= gLow) {
+        if (++steps > maxSteps) return false;
         if (lc >= rc) {
             --li;
             mli = meta(li);
@@ -1832,7 +1837,58 @@ __device__ __forceinline__ void walk_segments(uint32_t j, int d, int kLow, GetMe
             if (ri < nIdx) { mri = meta(ri); const int l = (int)(mri & LM); rc = l < rc ? l : rc; } else rc = -1;
         }
     }
+    return true;
 }
+
+// A LONG walk (a conserved k-mer: hundreds of index entries around the query's place) is not one lane's business: every step
+// is a dependent read, and the other 63 lanes of its wavefront wait.  coop_walk gives the entries to all 64 lanes, 64 at a
+// time: first those left of j (nearest first), then those to the right.  An entry's letters in common with the query are the
+// running minimum of the neighbour counts between it and j (a prefix minimum over the lanes, carried from chunk to chunk),
+// capped at max(d, 6); the side ends where that falls below the kLow-group's letters.  f(ok, idx, v, side) is called by ALL
+// lanes for every chunk (it may hold wavefront-wide operations); `ok` marks the lanes whose entry belongs to the walk.
+#define KASA_DPP_ID(v, ctrl, rows, id) __builtin_amdgcn_update_dpp((int)(id), (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ int wave_incl_min(int v)
+{
+    constexpr int TOP = 0x7fffffff;
+    { const int o = KASA_DPP_ID(v, 0x111, 0xf, TOP); v = o < v ? o : v; }
+    { const int o = KASA_DPP_ID(v, 0x112, 0xf, TOP); v = o < v ? o : v; }
+    { const int o = KASA_DPP_ID(v, 0x114, 0xf, TOP); v = o < v ? o : v; }
+    { const int o = KASA_DPP_ID(v, 0x118, 0xf, TOP); v = o < v ? o : v; }
+    { const int o = KASA_DPP_ID(v, 0x142, 0xa, TOP); v = o < v ? o : v; }
+    { const int o = KASA_DPP_ID(v, 0x143, 0xc, TOP); v = o < v ? o : v; }
+    return v;
+}
+template <class Meta, class F>
+__device__ __forceinline__ void coop_walk(const Meta *__restrict__ meta, uint32_t nIdx, uint32_t j, int d, int kLow, int lane, F f)
+{
+    constexpr int LM = sizeof(Meta) == 1 ? 15 : 255;
+    const int gLow = group_letters(kLow);
+    const int chain0 = d > RANGE_LETTERS ? d : RANGE_LETTERS;
+    int run = chain0;
+    for (uint32_t a0 = 1;; a0 += 64) {                            // left: entry j - a shares with the query what j - a + 1 .. j share with their predecessors
+        const uint32_t a = a0 + (uint32_t)lane;
+        const bool valid = a <= j;
+        const uint32_t idx = valid ? j - a : 0u;
+        int v = wave_incl_min(valid ? (int)((uint32_t)meta[idx + 1] & (uint32_t)LM) : -1);
+        v = v < run ? v : run;
+        const bool ok = valid && v >= gLow;
+        f(ok, idx, v, 0);
+        if (__ballot(ok) != ~0ull) break;
+        run = __builtin_amdgcn_readlane(v, 63);
+    }
+    run = chain0;
+    for (uint32_t b0 = 1;; b0 += 64) {                            // right: entry j + b shares what j + 1 .. j + b share with their predecessors
+        const uint32_t idx = j + b0 + (uint32_t)lane;
+        const bool valid = idx < nIdx && idx > j;
+        int v = wave_incl_min(valid ? (int)((uint32_t)meta[valid ? idx : 0u] & (uint32_t)LM) : -1);
+        v = v < run ? v : run;
+        const bool ok = valid && v >= gLow;
+        f(ok, idx, v, 1);
+        if (__ballot(ok) != ~0ull) break;
+        run = __builtin_amdgcn_readlane(v, 63);
+    }
+}
+static constexpr uint32_t LONG_STEPS = 48;        // entries a query's walk may visit lane by lane; beyond: the wavefront takes it (coop_walk)
 
 // Profile key of a record: {level | |T| | taxon | hits:16}.  The three upper fields are as wide as the batch needs
 // (taxon: enough bits that the all-ones value is no taxon -- it marks unused slots; |T| <= 8191 and < nTaxa), so the
@@ -1906,6 +1962,7 @@ __device__ __forceinline__ uint64_t group_key(uint32_t lvLo, uint32_t lvHi, uint
     return (uint64_t)hits | ((uint64_t)tax << 16) | ((uint64_t)n << 38) | ((uint64_t)lvLo << 51) | ((uint64_t)(lvHi - lvLo) << 56);
 }
 
+#define LDS_WAVE_SYNC_G() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 // group: one workgroup per tile of TILE sorted queries, a thread owns GITEMS consecutive ones.
 //   1. flush positions F_k(p) = next position after p that closes level k: inside the wavefront from two ballots per
 //      level, across wavefronts through one LDS table (one barrier), across tiles from tileNext;
@@ -1913,15 +1970,19 @@ __device__ __forceinline__ uint64_t group_key(uint32_t lvLo, uint32_t lvHi, uint
 //   3. the taxon segments (walk_segments), the first INL of them inline, longer lists in the pool with one allocation
 //      per workgroup;
 //   4. the record goes to rec[slot]: slotOf[p], or p itself when slotOf is NULL (records exported in sorted order).
-template <int RW, class Key, int NKT>                              // NKT: kHigh - kLow + 1 when known at compile time, else 0
-__global__ __launch_bounds__(GTHREADS) void group_kernel(
+// COOP (narrow records): long lists are counted and placed by whole wavefronts (coop_walk).  The lean form walks every list
+// lane by lane and only REPORTS a list of 255 or more segments (*needCoop; its 8-bit level counts would wrap): the host then
+// groups the batch again with COOP -- and stays with it for the context's further batches, as it does when the taxon lists of
+// a batch are long on average.  Data without crowded k-mers never pays for the cooperative code's registers.
+template <int RW, class Key, int NKT, bool COOP = false>           // NKT: kHigh - kLow + 1 when known at compile time, else 0
+__global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
     const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
     uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa,
     uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
-    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo)
+    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo, uint32_t *__restrict__ needCoop)
 {
     const int coverage = flags & 1;                                // bit 1: every query walks the index itself (test tap); bit 2: no LDS span for 64-byte records
     typedef RecTraits<RW> RT;
@@ -1950,6 +2011,9 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     // and where a run of equal (|T|, hits) begins
     __shared__ unsigned long long sHitsQ[RW == 8 ? TILE : 1], sSizeQ[RW == 8 ? TILE : 1];
     __shared__ uint16_t sRunQ[RW == 8 ? TILE : 1];
+    // a wavefront's scratch for its long lists: level marks / sizes [32], segments per class [64], class offsets [64]; the
+    // first segments of the list (the record's inline ones)
+    __shared__ uint32_t sCo[(RW == 8 && COOP) ? GTHREADS / 64 : 1][(RW == 8 && COOP) ? 160 : 1], sInl[(RW == 8 && COOP) ? GTHREADS / 64 : 1][INL];
     if (threadIdx.x == 0) sOvfN = 0u;
     const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
@@ -2045,6 +2109,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
     auto getTax = [&](uint32_t i) -> uint32_t { const uint32_t x = i - spanLo; return x < spanN ? sTax[x] : tax[i]; };
     // ---- 2. + 3. per query: order of its events, taxon segments
     uint32_t w2[GITEMS], w3[GITEMS], fmax[GITEMS], nseg[GITEMS], seg[GITEMS][INL];
+    bool isLong[GITEMS] = {false, false};                        // the query's walk exceeded LONG_STEPS entries
     unsigned long long cnt8x[GITEMS] = {0ull, 0ull};
     unsigned __int128 ord[GITEMS];
     uint32_t need = 0;
@@ -2094,9 +2159,10 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         fmax[i] = fm;
         w2[i] = (uint32_t)d[i] | (RW == 8 ? ((uint32_t)ord[i] << 5) : 0u);
         uint32_t n = 0, nlev = 0;                                 // nlev: |T_k| per level, 3 bits each, saturating at 7 (RW = 8)
-        unsigned long long cnt8 = 0;                              // |T_k| per level, 8 bits each (exact below 255 segments)
+        unsigned long long cnt8 = 0;                              // |T_k| per level, 8 bits each (a long list: saturated at 255)
         bool split = false;                                       // a taxon may own several segments (an entry continues an earlier one of its taxon)
-        if (!fol[i]) walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
+        bool done = true;
+        if (!fol[i]) done = walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
 #pragma unroll
             for (int q = 0; q < INL; ++q) if (n == (uint32_t)q) seg[i][q] = s;
             if constexpr (RW == 8) {
@@ -2110,7 +2176,9 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             }
             ++n;
             if ((int)((s >> 22) & 31u) > kLow) split = true;
-        });
+        }, (RW == 8 && COOP) ? LONG_STEPS : 0xFFFFFFFFu);
+        if (!done) { isLong[i] = true; n = 0; cnt8 = 0; split = false; }   // a LONG list: counted by the whole wavefront below (what was parked is never looked at)
+        if (RW == 8 && !COOP && n >= 255u) atomicOr(needCoop, 1u);           // this form cannot count it: the batch is grouped again
         if constexpr (RW == 8) {
 #pragma unroll
             for (int lv = 0; lv < 8; ++lv) { const uint32_t cl = (uint32_t)(cnt8 >> (8 * lv)) & 255u; nlev |= (cl < 7u ? cl : 7u) << (3 * lv); }
@@ -2128,6 +2196,69 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                 for (int k = (int)((s >> 22) & 31u); k <= (int)(s >> 27); ++k)
                     if (ql < group_letters(k)) atomicAdd((unsigned long long *)&cntTotal[(size_t)(kHigh - k) * nTaxa + (s & SEG_TAX_MASK)], 1ull);
             });
+        }
+    }
+    // ---- long lists, pass 1 (narrow records): every lane of the wavefront takes entries of the list.  A segment's place in the
+    // list is given by its class -- letters in common with the query, descending; left of j before right; nearest first -- so
+    // counting the segments per class is enough to place them later (pass 2, once the pool block is allocated).  Here: the
+    // number of segments, |T_k| per level (marks at the ends of the level ranges, running sum), the split flag.
+    constexpr int LMc = sizeof(Meta) == 1 ? 15 : 255, DSc = sizeof(Meta) == 1 ? 4 : 8;
+    auto segOf = [&](bool ok, uint32_t idx, int v, int dd, uint32_t &sg) -> bool {   // the segment entry idx yields, seen from a query of depth dd
+        if (!ok) return false;
+        const int dup = (int)((uint32_t)meta[idx] >> DSc);
+        const int kFirst = dup < RANGE_LETTERS ? kLow : (dup + 1 > kLow ? dup + 1 : kLow);
+        const int kLast = v < dd ? v : dd;
+        sg = tax[idx] | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27);
+        return kFirst <= kLast;
+    };
+    // counts of one long list into the wavefront's scratch; returns whether entry j itself yields a segment
+    auto coopCount = [&](uint32_t j, int dd, uint32_t &selfSeg, bool &anySplit) -> bool {
+        uint32_t *cM = &sCo[wv][0], *cH = &sCo[wv][32];
+        if (lane < 32) cM[lane] = 0u;
+        cH[lane] = 0u;
+        LDS_WAVE_SYNC_G();
+        const int chain0 = dd > RANGE_LETTERS ? dd : RANGE_LETTERS;
+        const bool selfEmits = segOf(true, j, dd, dd, selfSeg);
+        anySplit = selfEmits && (int)((selfSeg >> 22) & 31u) > kLow;
+        if (selfEmits && lane == 0) { atomicAdd(&cM[kHigh - (int)(selfSeg >> 27)], 1u); atomicSub(&cM[kHigh - (int)((selfSeg >> 22) & 31u) + 1], 1u); }
+        coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int side) {
+            uint32_t sg = 0;
+            const bool emits = segOf(ok, idx, v, dd, sg);
+            if (emits) {
+                atomicAdd(&cH[(chain0 - v) * 2 + side], 1u);
+                atomicAdd(&cM[kHigh - (int)(sg >> 27)], 1u);
+                atomicSub(&cM[kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+            }
+            if (__ballot(emits && (int)((sg >> 22) & 31u) > kLow) != 0ull) anySplit = true;
+        });
+        LDS_WAVE_SYNC_G();
+        return selfEmits;
+    };
+    if constexpr (RW == 8 && COOP) {
+#pragma unroll
+        for (int i = 0; i < GITEMS; ++i) {
+            unsigned long long todo = __ballot(isLong[i]);
+            while (todo) {                                           // (uniform)
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t j = (uint32_t)__shfl((int)rp[i], src);
+                const int dd = __shfl(d[i], src);
+                uint32_t selfSeg = 0; bool anySplit = false;
+                const bool selfEmits = coopCount(j, dd, selfSeg, anySplit);
+                const uint32_t n = wave_total(wave_incl_sum(sCo[wv][32 + lane])) + (selfEmits ? 1u : 0u);
+                const uint32_t sz = wave_incl_sum(lane < 32 ? sCo[wv][lane] : 0u);     // lane lv: |T| of level lv
+                unsigned long long c8 = 0; uint32_t nl = 0;
+#define KASA_LV(lv) { const uint32_t c = lane_value<lv>(sz); c8 |= (unsigned long long)(c < 255u ? c : 255u) << (8 * lv); nl |= (c < 7u ? c : 7u) << (3 * lv); }
+                KASA_LV(0) KASA_LV(1) KASA_LV(2) KASA_LV(3) KASA_LV(4) KASA_LV(5) KASA_LV(6) KASA_LV(7)
+#undef KASA_LV
+                if (lane == src) {
+                    nseg[i] = n; cnt8x[i] = c8;
+                    w3[i] = (n < 255u ? n : 255u) | (nl << 8);
+                    if (anySplit) w2[i] |= REC_SPLIT;
+                    if (n > (uint32_t)INL) { w2[i] |= REC_SAT; need += n - (uint32_t)(INL - 1) + 1u + POOL_SIZES; }   // (a long list always carries its exact sizes)
+                }
+                LDS_WAVE_SYNC_G();
+            }
         }
     }
     bool poolOk = true;                                              // the workgroup's pool block was allocated (else the host grows the pool and reruns)
@@ -2149,7 +2280,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         if constexpr (RW == 8) {
             bool mineOk = true;
 #pragma unroll
-            for (int i = 0; i < GITEMS; ++i) if (nseg[i] >= 255u) mineOk = false;
+            for (int i = 0; i < GITEMS; ++i) if (nseg[i] >= 255u || isLong[i]) mineOk = false;
             again = __syncthreads_or((!mineOk || sOvfN > (uint32_t)GOVF) ? 1 : 0) != 0;
             parked = !again;
             if (!again) {
@@ -2191,7 +2322,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                     pool[off] = nseg[i];
                     uint32_t w = off + 1 + (sat ? POOL_SIZES : 0u), idx = 0;
                     unsigned long long cA = 0, cB = 0;               // exact |T| of the levels 0..3 and 4..7, 16 bits each
-                    walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
+                    if (!isLong[i]) walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t s) {
                         if (idx >= (uint32_t)(INL - 1)) pool[w++] = s;
                         ++idx;
                         if (sat)
@@ -2199,11 +2330,74 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                                 if (lv < 4) cA += 1ull << (16 * lv); else cB += 1ull << (16 * (lv - 4));
                             }
                     });
-                    if (sat) { pool[off + 1] = (uint32_t)cA; pool[off + 2] = (uint32_t)(cA >> 32); pool[off + 3] = (uint32_t)cB; pool[off + 4] = (uint32_t)(cB >> 32); }
+                    if (sat && !isLong[i]) { pool[off + 1] = (uint32_t)cA; pool[off + 2] = (uint32_t)(cA >> 32); pool[off + 3] = (uint32_t)cB; pool[off + 4] = (uint32_t)(cB >> 32); }
                 }
                 seg[i][INL - 1] = off;
                 off += nseg[i] - (uint32_t)(INL - 1) + 1u + (sat ? POOL_SIZES : 0u);
             }
+    }
+    // ---- long lists, pass 2: the segments to their places -- the first INL (or INL - 1) into the record, the rest into the pool
+    // block: place = first place of the segment's class (running sum over the classes) + segments of the class met so far.
+    if constexpr (RW == 8 && COOP) {
+#pragma unroll
+        for (int i = 0; i < GITEMS; ++i) {
+            unsigned long long todo = __ballot(isLong[i]);
+            while (todo) {                                           // (uniform)
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t j = (uint32_t)__shfl((int)rp[i], src);
+                const int dd = __shfl(d[i], src);
+                const uint32_t n = (uint32_t)__shfl((int)nseg[i], src), off = (uint32_t)__shfl((int)seg[i][INL - 1], src);
+                const bool toPool = n > (uint32_t)INL && poolOk;
+                const int chain0 = dd > RANGE_LETTERS ? dd : RANGE_LETTERS;
+                uint32_t selfSeg = 0; bool anySplit = false;
+                const bool selfEmits = coopCount(j, dd, selfSeg, anySplit);
+                uint32_t *cH = &sCo[wv][32], *cO = &sCo[wv][96];
+                {
+                    const uint32_t cnt = cH[lane];
+                    cO[lane] = wave_incl_sum(cnt) - cnt + (selfEmits ? 1u : 0u);       // first place of class `lane`
+                    const uint32_t sz = wave_incl_sum(lane < 32 ? sCo[wv][lane] : 0u);
+                    const uint32_t s0 = lane_value<0>(sz), s1 = lane_value<1>(sz), s2 = lane_value<2>(sz), s3 = lane_value<3>(sz);
+                    const uint32_t s4 = lane_value<4>(sz), s5 = lane_value<5>(sz), s6 = lane_value<6>(sz), s7 = lane_value<7>(sz);
+                    auto f16 = [](uint32_t x) -> uint32_t { return x < 0xFFFFu ? x : 0xFFFFu; };
+                    if (toPool && lane == 0) {
+                        pool[off] = n;
+                        pool[off + 1] = f16(s0) | (f16(s1) << 16); pool[off + 2] = f16(s2) | (f16(s3) << 16);
+                        pool[off + 3] = f16(s4) | (f16(s5) << 16); pool[off + 4] = f16(s6) | (f16(s7) << 16);
+                    }
+                    if (selfEmits && lane == 0) sInl[wv][0] = selfSeg;
+                }
+                LDS_WAVE_SYNC_G();
+                coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int side) {
+                    uint32_t sg = 0;
+                    const bool emits = segOf(ok, idx, v, dd, sg);
+                    const uint32_t c = emits ? (uint32_t)((chain0 - v) * 2 + side) : 0xFFFFu;
+                    uint32_t place = 0;
+                    unsigned long long rem = __ballot(emits);
+                    while (rem) {                                    // class by class (two or three per chunk): places in lane order
+                        const int l0 = __ffsll((long long)rem) - 1;
+                        const uint32_t c0 = (uint32_t)__shfl((int)c, l0);
+                        const unsigned long long m = __ballot(c == c0);
+                        if (c == c0) place = cO[c0] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        LDS_WAVE_SYNC_G();
+                        if (lane == l0) cO[c0] += (uint32_t)__popcll(m);
+                        LDS_WAVE_SYNC_G();
+                        rem &= ~m;
+                    }
+                    if (emits) {
+                        if (place < (uint32_t)INL) sInl[wv][place] = sg;
+                        if (toPool && place >= (uint32_t)(INL - 1)) pool[off + 1u + POOL_SIZES + place - (uint32_t)(INL - 1)] = sg;
+                    }
+                });
+                LDS_WAVE_SYNC_G();
+                if (lane == src) {
+                    const uint32_t inl = n <= (uint32_t)INL ? n : (uint32_t)(INL - 1);
+#pragma unroll
+                    for (int q = 0; q < INL; ++q) if ((uint32_t)q < inl) seg[i][q] = sInl[wv][q];
+                }
+                LDS_WAVE_SYNC_G();
+            }
+        }
     }
     // ---- followers take their leader's words (all lanes run the shuffles)
     {
@@ -2314,9 +2508,9 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             for (int q = 0; q < INL; ++q) if ((uint32_t)q < inl) f(seg[i][q]);
             if (!parked) for (uint32_t q = inl; q < ns; ++q) f(segAt(i, q));
         };
-        auto coveringWalk = [&](int i, int lv, auto f) {             // 255 or more segments (the 8-bit fields of cnt8 have wrapped): level by level
-            walk_segments<Meta>(rp[i], d[i], kLow, getMeta, getTax, nIdx, [&](uint32_t sg) { if (seg_covers(sg, (uint32_t)(kHigh - lv))) f(sg); });
-        };
+        // a long list: |T| per level from the exact sizes in its pool block (8-bit fields saturate), its segments by a walk
+        auto longSize = [&](int i, int lv) -> uint32_t { return (pool[seg[i][INL - 1] + 1u + (uint32_t)(lv >> 1)] >> (16 * (lv & 1))) & 0xFFFFu; };
+        auto longList = [&](int i) -> bool { return isLong[i] && nseg[i] > (uint32_t)INL; };
         auto startsOf = [](uint32_t M, uint32_t V, uint32_t B) -> uint32_t { return (B & M) | (V & M & (0u - M)); };
         // one key per run: levels lo .. hi, |T| and hits of level lo
         auto cutRuns = [](uint32_t M, uint32_t V, uint32_t B, auto emit) {
@@ -2333,11 +2527,12 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
         for (int i = 0; i < GITEMS; ++i) {
             Vm[i] = 0; Bm[i] = 0;
             if (nseg[i] == 0u || gq[i] == 0ull || (nseg[i] > (uint32_t)INL && !poolOk)) gq[i] = 0ull;
-            if (gq[i] != 0ull && nseg[i] < 255u) {
+            if (gq[i] != 0ull) {
                 uint32_t pn = 0, pg = 0;
+                const bool lng = longList(i);
 #pragma unroll
                 for (int lv = 0; lv < NL; ++lv) {
-                    const uint32_t n = (uint32_t)(cnt8x[i] >> (8 * lv)) & 255u;
+                    const uint32_t n = lng ? longSize(i, lv) : ((uint32_t)(cnt8x[i] >> (8 * lv)) & 255u);
                     const uint32_t h = (uint32_t)(gq[i] >> (8 * lv)) & 255u;
                     if (h) { Vm[i] |= 1u << lv; if (!(pg == h && pn == n)) Bm[i] |= 1u << lv; }
                     pn = n; pg = h;                                   // (pg = 0 after a level without hits: the next one begins a run)
@@ -2345,11 +2540,30 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             }
             sHitsQ[t * GITEMS + i] = gq[i]; sSizeQ[t * GITEMS + i] = cnt8x[i]; sRunQ[t * GITEMS + i] = (uint16_t)(Vm[i] | (Bm[i] << 8));
             if (gq[i] == 0ull) continue;
-            if (nseg[i] >= 255u) {
-                for (int lv = 0; lv < nK; ++lv) if ((gq[i] >> (8 * lv)) & 255ull) coveringWalk(i, lv, [&](uint32_t) { ++needK; });
-                continue;
-            }
+            if (longList(i)) continue;                                // (counted by the whole wavefront, below)
             forSegs(i, [&](uint32_t sg) { needK += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), Vm[i], Bm[i])); });
+        }
+        // long lists: the keys of their segments, counted (and, further down, written) by all lanes of the wavefront
+        uint32_t longKeys[GITEMS] = {0u, 0u};
+        if constexpr (COOP) {
+#pragma unroll
+        for (int i = 0; i < GITEMS; ++i) {
+            unsigned long long todo = __ballot(gq[i] != 0ull && longList(i));
+            while (todo) {                                           // (uniform)
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const uint32_t j = (uint32_t)__shfl((int)rp[i], src), V = (uint32_t)__shfl((int)Vm[i], src), B = (uint32_t)__shfl((int)Bm[i], src);
+                const int dd = __shfl(d[i], src);
+                uint32_t mine = 0, selfSeg = 0;
+                if (segOf(true, j, dd, dd, selfSeg) && lane == 0) mine += (uint32_t)__popc(startsOf(seg_level_mask(selfSeg, kHigh), V, B));
+                coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int) {
+                    uint32_t sg = 0;
+                    if (segOf(ok, idx, v, dd, sg)) mine += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B));
+                });
+                const uint32_t total = wave_total(wave_incl_sum(mine));
+                if (lane == src) { longKeys[i] = total; needK += total; }
+            }
+        }
         }
         __syncthreads();                                             // the owners' level data, the pool blocks (other threads have filled them)
         const uint32_t nPark = (parked && poolOk) ? sOvfN : 0u;
@@ -2374,8 +2588,51 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
             constexpr uint32_t KSTAGE = (uint32_t)(SPAN_BYTES / 8);
             const bool staged = parked && totalK <= KSTAGE && sBaseK != NOPOS;
             unsigned long long *sKeys = reinterpret_cast<unsigned long long *>(sRaw);
+            if (COOP && sBaseK != NOPOS) {                              // (uniform) the long lists' keys, by all lanes: a leader's keys begin with them
+#pragma unroll
+                for (int i = 0; i < GITEMS; ++i) {
+                    unsigned long long todo = __ballot(longKeys[i] != 0u);
+                    uint32_t before = 0;                                // keys of the leader's long item 0 (they come first)
+                    if (i == 1) before = longKeys[0];
+                    while (todo) {
+                        const int src = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const uint32_t j = (uint32_t)__shfl((int)rp[i], src), V = (uint32_t)__shfl((int)Vm[i], src), B = (uint32_t)__shfl((int)Bm[i], src);
+                        const int dd = __shfl(d[i], src);
+                        const uint32_t off = (uint32_t)__shfl((int)seg[i][INL - 1], src);
+                        const uint32_t hLo = (uint32_t)__shfl((int)(uint32_t)gq[i], src), hHi = (uint32_t)__shfl((int)(uint32_t)(gq[i] >> 32), src);
+                        const unsigned long long hq = ((unsigned long long)hHi << 32) | hLo;
+                        uint32_t at = sBaseK + (uint32_t)__shfl((int)(kw + before), src);
+                        auto putL = [&](uint32_t sg, uint32_t &w) {
+                            cutRuns(seg_level_mask(sg, kHigh), V, B, [&](int lo, int hi) {
+                                const uint32_t n = (pool[off + 1u + (uint32_t)(lo >> 1)] >> (16 * (lo & 1))) & 0xFFFFu, hits = (uint32_t)(hq >> (8 * lo)) & 255u, tx = sg & SEG_TAX_MASK;
+                                if (flags & 16) { ++w; return; }
+                                unsigned long long key = 0ull;
+                                if (n < (1u << PL.nb)) key = group_key((uint32_t)lo, (uint32_t)hi, n, tx, hits);
+                                else for (int lv = lo; lv <= hi; ++lv) fixed_add(cntAllHi, cntAllMid, cntAllLo, (size_t)lv * nTaxa + tx, hits, n);
+                                profKeys[w++] = key;
+                            });
+                        };
+                        uint32_t selfSeg = 0;
+                        if (segOf(true, j, dd, dd, selfSeg)) {          // entry j's own segment: lane 0
+                            const uint32_t c = (uint32_t)__popc(startsOf(seg_level_mask(selfSeg, kHigh), V, B));
+                            if (lane == 0) { uint32_t w = at; putL(selfSeg, w); }
+                            at += c;
+                        }
+                        coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int) {
+                            uint32_t sg = 0;
+                            const bool emits = segOf(ok, idx, v, dd, sg);
+                            const uint32_t c = emits ? (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B)) : 0u;
+                            const uint32_t incl = wave_incl_sum(c);
+                            if (c) { uint32_t w = at + incl - c; putL(sg, w); }
+                            at += wave_total(incl);
+                        });
+                    }
+                }
+            }
             if (sBaseK != NOPOS && needK) {
                 if (!staged) kw += sBaseK;
+                kw += longKeys[0] + longKeys[1];
                 auto put = [&](int lo, int hi, uint32_t n, uint32_t hits, uint32_t tx) {
                     if (flags & 16) { ++kw; return; }
                     unsigned long long key = 0ull;                      // (hits = 0: skipped by the table kernel)
@@ -2386,17 +2643,7 @@ __global__ __launch_bounds__(GTHREADS) void group_kernel(
                 };
 #pragma unroll
                 for (int i = 0; i < GITEMS; ++i) {
-                    if (gq[i] == 0ull) continue;
-                    if (nseg[i] >= 255u) {
-                        for (int lv = 0; lv < nK; ++lv) {
-                            const uint32_t hits = (uint32_t)(gq[i] >> (8 * lv)) & 255u;
-                            if (!hits) continue;
-                            uint32_t n = 0;
-                            coveringWalk(i, lv, [&](uint32_t) { ++n; });
-                            coveringWalk(i, lv, [&](uint32_t sg) { put(lv, lv, n, hits, sg & SEG_TAX_MASK); });
-                        }
-                        continue;
-                    }
+                    if (gq[i] == 0ull || longList(i)) continue;
                     forSegs(i, [&](uint32_t sg) {
                         cutRuns(seg_level_mask(sg, kHigh), Vm[i], Bm[i], [&](int lo, int hi) {
                             put(lo, hi, (uint32_t)(cnt8x[i] >> (8 * lo)) & 255u, (uint32_t)(gq[i] >> (8 * lo)) & 255u, sg & SEG_TAX_MASK);
@@ -2578,20 +2825,24 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     extern __shared__ float sRowDyn[];
     __shared__ uint32_t sSegQ[DENSE ? DQ_SEGS : 1];
     __shared__ uint32_t sCntQ[DENSE ? 32 : 1];
-    __shared__ unsigned long long aKey[AGG];
-    __shared__ uint32_t aCnt[AGG];
+    // (the dense form of narrow records keeps no profile -- group_stage's -- and no list of touched taxa: the LDS they would
+    // take is what limits the resident wavefronts of this latency-bound kernel)
+    constexpr bool LEAN = DENSE && GpOf<RW>::v;
+    constexpr int AGGN = LEAN ? 1 : AGG, TLN = LEAN ? 1 : TLIST;
+    __shared__ unsigned long long aKey[AGGN];
+    __shared__ uint32_t aCnt[AGGN];
     __shared__ uint32_t pF[PC], pRef[PC];
     __shared__ uint32_t pCnt[PC];
     __shared__ uint8_t pK[PC];
     __shared__ uint32_t sTouched;
-    __shared__ uint32_t sList[TLIST];
+    __shared__ uint32_t sList[TLN];
     const int lane = threadIdx.x;
     const int nK = A.kHigh - A.kLow + 1;
     float *score = DENSE ? sRowDyn : A.scratch + (size_t)blockIdx.x * A.nTaxa;
     if constexpr (DENSE) for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f;
     uint32_t cachedSlot = NOPOS, cachedN = 0;     // DENSE: the query whose segments and level sizes lie in LDS (uniform)
 
-    for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
+    for (int i = lane; i < AGGN; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
     const uint32_t nWork = A.list ? A.nList : A.nReads;
     for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
         const uint32_t r = A.list ? A.list[wi] : wi;
@@ -2779,7 +3030,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
             const uint32_t m = sTouched;
             if (!DENSE && m <= (uint32_t)TLIST) { for (uint32_t i = lane; i < m; i += 64) score[sList[i]] = 0.0f; }
             else { for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f; }
-            for (int i = lane; i < AGG; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
+            for (int i = lane; i < AGGN; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
             if (lane == 0) A.ovList[atomicAdd(A.ovCount, 1u)] = r;
             __syncthreads();
             continue;
@@ -2788,7 +3039,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         __threadfence_block();
         __syncthreads();
         if (A.addProfile)
-            for (int i = lane; i < AGG; i += 64) {
+            for (int i = lane; i < AGGN; i += 64) {
                 const unsigned long long key = aKey[i];
                 if (key == AGG_EMPTY) continue;
                 profile_add(A, (int)(key >> 56), (uint32_t)key, (uint32_t)(key >> 32) & 0xFFFFFFu, aCnt[i]);
@@ -4219,29 +4470,26 @@ static int slots_from_reads(kasa_ctx *c)
 }
 
 template <int RW>
-static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor)
+static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, bool coop)
 {
     const uint64_t nQ = c->nQ;
+    uint32_t *needCoop = reinterpret_cast<uint32_t *>(cursor + 3);        // (misc word [19]: free during the kernel)
+#define KASA_GROUP_ARGS(KEY, META) c->keys<KEY>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ, \
+        c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
+        c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa, \
+        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), needCoop
     if (c->ix->wide && RW == 16 && c->nK == 19)                       // the default -k 25 7 of a 128-bit index: loops over exactly 19 levels
-        group_kernel<RW, key128, RW == 16 ? 19 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
-            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
-            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+        group_kernel<RW, key128, RW == 16 ? 19 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
     else if (c->ix->wide)
-        group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<key128>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
-            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint16_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
-            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
-    else if (RW == 8 && c->nK == 6)                                  // the default -k 12 7: loops over exactly six levels
-        group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
-            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
-            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+        group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
+    else if (RW == 8 && c->nK == 6) {                                // the default -k 12 7: loops over exactly six levels
+        if (coop) group_kernel<RW, uint64_t, RW == 8 ? 6 : 0, RW == 8><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+        else group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+    } else if (coop && RW == 8)
+        group_kernel<RW, uint64_t, 0, RW == 8><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
     else
-        group_kernel<RW, uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(c->keys<uint64_t>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ,
-            c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<uint8_t>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n,
-            c->kHigh, c->kLow, c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa,
-            c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+        group_kernel<RW, uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+#undef KASA_GROUP_ARGS
     HIPCHK(hipGetLastError());
     return KASA_OK;
 }
@@ -4415,18 +4663,18 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
 // records can travel: with a range-partitioned index the partition owner runs `group` on a slice
 // of another rank's sorted queries and exports the records in sorted order, the read owner imports them into their slots
 // and runs `score`.
-static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
+static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *recordsOut = nullptr)
 {
     if (c->state < 3) return fail(KASA_E_STATE, "kasa_batch_group: batch not sorted");
     HIPCHK(hipSetDevice(c->ix->device));
     const uint64_t nQ = c->nQ;
     const int RW = c->recWords();
     int rc;
-    c->haveScores = false; c->nnz = 0; c->grouped = false; c->poolUsed = 1; c->recSorted = exportSorted;
+    c->haveScores = false; c->nnz = 0; c->grouped = false; c->poolUsed = 1; c->recSorted = exportSorted; c->recOut = exportSorted ? recordsOut : nullptr;
     if (nQ == 0) { c->grouped = true; return KASA_OK; }
     if (!exportSorted && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
-    if ((rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
+    if (!c->recOut && (rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging, [18] profile keys
     hipEvent_t a, b;
     if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ);   // (a word per query: a first batch with crowded taxon lists -- 0.75 words per query on the bench data -- need not run group_kernel twice)
@@ -4444,12 +4692,21 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted)
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;
-        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor)))) return rc;
+        HIPCHK(hipMemcpyAsync(cursor + 3, &zero, 8, hipMemcpyHostToDevice, c->stream));   // "a list too long for the lean kernel"
+        if (c->debugFlags & 262144) c->groupCoop = true;                   // (test tap 262144: the cooperative form from the first batch on)
+        const bool coop = c->groupCoop && !(c->debugFlags & 131072);       // (test tap 131072: never the cooperative form)
+        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_GROUP], ka, kb))) return rc;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
-        unsigned long long used[3] = {0, 0, 0};
-        HIPCHK(hipMemcpyAsync(used, cursor, 24, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long used[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(used, cursor, 32, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (RW == 8 && !coop && !(c->debugFlags & 131072) && ((used[3] & 1ull) || used[0] > 6ull * nQ)) {
+            // a list of 255 or more segments (the lean kernel cannot count it), or long lists on average: whole wavefronts
+            // take the long lists from here on -- this batch again if it must be, the context's further batches anyway
+            c->groupCoop = true;
+            if (used[3] & 1ull) { if (used[0] > c->poolCap) c->poolCap = used[0] + used[0] / 8 + 1024; continue; }
+        }
         if (used[0] <= c->poolCap && used[2] <= c->keyCap) { c->poolUsed = (uint32_t)used[0]; nKeys = used[2]; break; }
         if (used[0] >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "the taxon lists of this batch need %llu pool entries (limit 2^32); split the batch", used[0]);
         if (used[0] > c->poolCap) c->poolCap = used[0] + used[0] / 8 + 1024;
@@ -4772,6 +5029,12 @@ extern "C" int kasa_batch_group(kasa_ctx *c, int coverage)
     return group_stage(c, coverage, true);
 }
 
+extern "C" int kasa_batch_group_to(kasa_ctx *c, int coverage, uint32_t *recordsOut)
+{
+    if (!c || !recordsOut) return fail(KASA_E_ARG, "kasa_batch_group_to: NULL argument");
+    return group_stage(c, coverage, true, recordsOut);
+}
+
 extern "C" int kasa_batch_score(kasa_ctx *c, int wantPerRead)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
@@ -4949,7 +5212,7 @@ extern "C" int kasa_batch_records_device(kasa_ctx *c, const uint32_t **records, 
         HIPCHK(hipMemsetAsync(c->pool.p, 0, 64, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    *records = c->rec.as<uint32_t>(); *nRecordWords = c->nQ * (uint64_t)c->recWords();
+    *records = c->recOut ? c->recOut : c->rec.as<uint32_t>(); *nRecordWords = c->nQ * (uint64_t)c->recWords();
     *pool = c->pool.as<uint32_t>(); *nPoolWords = c->poolUsed;
     return KASA_OK;
 }

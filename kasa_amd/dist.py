@@ -222,10 +222,18 @@ def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool
     rec_out = torch.empty(total_in * rw, dtype=torch.uint8, device=dev)
     pools, pool_counts, at = [], [], 0
     for s in range(world):                                        # the slices of every rank, against my partition
-        rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s], sink=ctx)   # (the slice's profile stays on this rank: the reduce sums the ranks)
-        _device_copy(rec_out.data_ptr() + at * rw, rp, nrw * 4)   # the worker's buffers are reused by the next slice
-        p = torch.empty(npw * 4, dtype=torch.uint8, device=dev)
-        _device_copy(p.data_ptr(), pp, npw * 4)
+        # grouped straight into the send tensor (kasa_batch_group_to: no copy of the records); the slice's profile stays on
+        # this rank (the reduce sums the ranks).  records_device() waits for the worker's stream -- not for the device
+        rp, nrw, pp, npw = worker.group_slice_device(km_in.data_ptr() + at * kb, n_in[s], sink=ctx, records_out=rec_out.data_ptr() + at * rw)
+        if n_in[s] == 0 and nrw:
+            _device_copy(rec_out.data_ptr() + at * rw, rp, nrw * 4)
+        p = torch.empty(npw * 4, dtype=torch.uint8, device=dev)   # the pool is the worker's own buffer, reused by the next slice: a small copy
+        src = _device_view(pp, npw * 4, dev)
+        if src is not None:
+            p.copy_(src)
+            torch.cuda.current_stream(dev).synchronize()          # (before the worker overwrites its pool)
+        else:
+            _device_copy(p.data_ptr(), pp, npw * 4)
         pools.append(p); pool_counts.append(npw)
         at += n_in[s]
     del km_in

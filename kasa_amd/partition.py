@@ -89,11 +89,15 @@ class Worker:
             sink.profile_absorb(self.ctx)
         return self.ctx.records()
 
-    def group_slice_device(self, ptr: int, n: int, sink: capi.Context = None):
+    def group_slice_device(self, ptr: int, n: int, sink: capi.Context = None, records_out: int = 0):
         """The same for a slice that is already in device memory (`ptr`: its sorted k-mers); returns device pointers
-        (records pointer, record words, pool pointer, pool words), valid until the worker's next slice."""
+        (records pointer, record words, pool pointer, pool words), valid until the worker's next slice.
+        records_out: device memory the records are written to directly (the send buffer of the exchange)."""
         self.ctx.set_sorted_device(ptr, n)
-        self.ctx.group()
+        if records_out and n:
+            self.ctx.group_to(records_out)
+        else:
+            self.ctx.group()
         if sink is not None:
             sink.profile_absorb(self.ctx)
         return self.ctx.records_device()
