@@ -539,7 +539,8 @@ struct kasa_ctx {
     DevBuf flushOff, flushPos, flushOff2, flushPos2;   // general score kernel: flush positions of the listed reads' queries
     DevBuf ovList;                             // reads the first general pass hands to the second
     uint32_t lastOverflowReads = 0;
-    DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted;           // per-block dense score rows; reads left to the slow kernel
+    DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profSorted2;   // per-block dense score rows; reads left to the slow kernel
+    uint64_t profLeftHint = 0;                  // per-level keys the last batch's table pass left over, when the list was too short for them
     bool forceSlowScore = false; uint32_t lastSlowReads = 0; int debugFlags = 0;
     DevBuf rowPos, rowLen, rowKey, rowOff, st, outTax, outScore;
     DevBuf cntUnique, cntTotal, cntAllHi, cntAllMid, cntAllLo; // u64[nK*nTaxa] each
@@ -663,7 +664,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                      &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
+                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profSorted2, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                      &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
                      &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
                      &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};
@@ -2891,13 +2892,19 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     cachedSlot = slot;
                     if (lane < 32) sCntQ[lane] = 0u;
                     LDS_WAVE_SYNC();
-                    for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
-                        const uint32_t i = b0 + lane;
-                        if (i < ns) {
-                            const uint32_t sg = rec_seg<RW>(w, A.pool, ns, i);
-                            if (i < (uint32_t)DQ_SEGS) sSegQ[i] = sg;
-                            atomicAdd(&sCntQ[A.kHigh - (int)(sg >> 27)], 1u);
-                            atomicSub(&sCntQ[A.kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+                    for (uint32_t b0 = 0; b0 < ns; b0 += 256) {                  // four loads in flight per lane: the kernel waits for memory, not for arithmetic
+                        uint32_t sg4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const uint32_t i = b0 + 64u * u + lane; sg4[u] = i < ns ? rec_seg<RW>(w, A.pool, ns, i) : 0u; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t i = b0 + 64u * u + lane;
+                            if (i < ns) {
+                                const uint32_t sg = sg4[u];
+                                if (i < (uint32_t)DQ_SEGS) sSegQ[i] = sg;
+                                atomicAdd(&sCntQ[A.kHigh - (int)(sg >> 27)], 1u);
+                                atomicSub(&sCntQ[A.kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+                            }
                         }
                     }
                     LDS_WAVE_SYNC();
@@ -4495,9 +4502,12 @@ static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, ui
 }
 
 
-// profile_table_kernel for group keys: a key adds its hits to the cell of every level it spans; levels without a cell in
-// this workgroup's table leave as per-level keys of the classic layout (sorted and reduced afterwards); should that list be
-// full, straight to the tables.
+// profile_table_kernel for group keys: a key adds its hits to the cell of every level it spans -- range cells [first level][taxon]
+// for the bulk (|T| = 1 down to the shallowest level: ONE add), per-level cells [level][|T| - 1][taxon] for the rest.  Levels
+// without a cell in this workgroup's table leave as per-level keys of the classic layout (sorted and reduced afterwards).  With
+// a crowded index that is most of them, so they leave without any per-key atomic: a round's keys are looked at twice -- first
+// the cells are served and the leftovers counted, then (one running sum over the workgroup, ONE add to the list's cursor) every
+// thread writes its leftovers to its own place.  Should the list be full: straight to the tables.
 __global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int nK, ProfTableLayout TL,
                                                                          uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
                                                                          uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab, ProfLayout PL,
@@ -4506,34 +4516,17 @@ __global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const u
 {
     extern __shared__ uint32_t tab[];                                  // [level][|T| - 1][nTaxa], TL.nn[level] values of |T| per level
     const uint32_t cells = (uint32_t)TL.first[MAX_LEVELS] * nTaxa;
-    // ... followed, when there is room (rangeCells), by [first level][nTaxa]: keys with |T| = 1 whose levels run down to the
-    // shallowest one (a k-mer matched to depth d against one taxon: the bulk) take ONE add there instead of one per level
-    uint32_t *tabR = tab + cells;
+    uint32_t *tabR = tab + cells;                                      // ... followed, when there is room (rangeCells), by [first level][nTaxa]
     const uint32_t rangeN = rangeCells ? (uint32_t)nK * nTaxa : 0u;
-    __shared__ uint64_t sLeft[PT_LEFT];                                // per-level keys without a cell wait here and leave in bulk
-    __shared__ uint32_t sLeftN;
-    __shared__ unsigned long long sLeftBase;
+    __shared__ uint32_t sWave[PT_THREADS / 64];
+    __shared__ unsigned long long sBase;
     for (uint32_t i = threadIdx.x; i < cells + rangeN; i += PT_THREADS) tab[i] = 0u;
-    if (threadIdx.x == 0) sLeftN = 0;
     __syncthreads();
-    auto direct = [&](uint64_t pk) {                                   // a classic per-level key straight to the tables (the list is full)
-        const uint64_t f = pk >> 16;
-        const uint32_t hits = (uint32_t)(pk & 0xFFFFull), tax = (uint32_t)(f & ((1ull << PL.tb) - 1ull));
-        const uint32_t n = (uint32_t)((f >> PL.tb) & ((1ull << PL.nb) - 1ull)), lv = (uint32_t)(f >> (PL.tb + PL.nb));
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    auto direct = [&](uint32_t lv, uint32_t n, uint32_t tax, uint32_t hits) {
         const size_t cell = (size_t)lv * nTaxa + tax;
         if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)hits);
         fixed_add(hiTab, midTab, loTab, cell, hits, n);
-    };
-    auto flush = [&]() {                                               // all threads
-        const uint32_t n = min(sLeftN, (uint32_t)PT_LEFT);
-        if (threadIdx.x == 0) sLeftBase = atomicAdd(leftCursor, (unsigned long long)n);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += PT_THREADS) {
-            if (sLeftBase + i < leftCap) leftOut[sLeftBase + i] = sLeft[i]; else direct(sLeft[i]);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) sLeftN = 0;
-        __syncthreads();
     };
     constexpr int PT_KEYS = 8;
     const uint64_t step = (uint64_t)gridDim.x * PT_THREADS * PT_KEYS;
@@ -4545,28 +4538,57 @@ __global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const u
         uint64_t kk[PT_KEYS];
 #pragma unroll
         for (int q = 0; q < PT_KEYS; ++q) { const uint64_t i = i0 + (uint64_t)q * PT_THREADS; kk[q] = i < nKeys ? keys[i] : 0ull; }   // (hits = 0: skipped)
-#pragma unroll
-        for (int q = 0; q < PT_KEYS; ++q) {
-            const uint64_t key = kk[q];
+        // what a key's level does: 0 nothing, 1 a cell, 2 left over
+        auto levelsOf = [&](uint64_t key, auto cell, auto left) {
             const uint32_t hits = (uint32_t)(key & 0xFFFFull);
-            if (hits == 0u) continue;
+            if (hits == 0u) return;
             const uint32_t tax = (uint32_t)(key >> 16) & SEG_TAX_MASK, n = (uint32_t)(key >> 38) & 0x1FFFu;
             const uint32_t lvLo = (uint32_t)(key >> 51) & 31u, lvHi = lvLo + ((uint32_t)(key >> 56) & 31u);
-            if (rangeN && n == 1u && lvHi + 1u == (uint32_t)nK && hits <= maxHits) { atomicAdd(&tabR[lvLo * nTaxa + tax], hits); continue; }
+            if (rangeN && n == 1u && lvHi + 1u == (uint32_t)nK && hits <= maxHits) { cell(&tabR[lvLo * nTaxa + tax], hits); return; }
             for (uint32_t lv = lvLo; lv <= lvHi; ++lv) {                     // (one pass over all levels: no level windows here)
-                if ((int)lv >= TL.lvLo && (int)lv < TL.lvHi && n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) atomicAdd(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
-                else {
-                    const uint64_t pk = profile_key_of(lv, n, tax, hits, PL);
-                    const uint32_t at = atomicAdd(&sLeftN, 1u);
-                    if (at < (uint32_t)PT_LEFT) sLeft[at] = pk;
-                    else { const unsigned long long g = atomicAdd(leftCursor, 1ull); if (g < leftCap) leftOut[g] = pk; else direct(pk); }   // (the buffer is full: straight to the list)
+                if ((int)lv >= TL.lvLo && (int)lv < TL.lvHi && n >= 1u && n <= (uint32_t)TL.nn[lv] && hits <= maxHits) cell(&tab[((uint32_t)TL.first[lv] + (n - 1u)) * nTaxa + tax], hits);
+                else left(lv, n, tax, hits);
+            }
+        };
+        uint32_t nLeft = 0;
+        unsigned long long which = 0;                                        // the leftovers of this thread's keys: bit 8 q + level (up to 8 levels)
+#pragma unroll
+        for (int q = 0; q < PT_KEYS; ++q)
+            levelsOf(kk[q], [&](uint32_t *c, uint32_t hits) { atomicAdd(c, hits); }, [&](uint32_t lv, uint32_t, uint32_t, uint32_t) { ++nLeft; which |= 1ull << (8 * q + (int)(lv & 7u)); });
+        // the leftovers' places: running sum over the workgroup, one add to the list's cursor
+        const uint32_t incl = wave_incl_sum(nLeft);
+        if (lane == 63) sWave[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < PT_THREADS / 64; ++w) { const uint32_t o = sWave[w]; if (w < wv) before += o; total += o; }
+        if (total == 0u) { __syncthreads(); continue; }                      // (uniform)
+        if (threadIdx.x == 0) sBase = atomicAdd(leftCursor, (unsigned long long)total);
+        __syncthreads();
+        unsigned long long at = sBase + before + incl - nLeft;
+        if (nLeft && nK <= 8) {                                              // straight from the marks
+#pragma unroll
+            for (int q = 0; q < PT_KEYS; ++q) {
+                uint32_t m = (uint32_t)(which >> (8 * q)) & 255u;
+                const uint64_t key = kk[q];
+                const uint32_t hits = (uint32_t)(key & 0xFFFFull), tax = (uint32_t)(key >> 16) & SEG_TAX_MASK, n = (uint32_t)(key >> 38) & 0x1FFFu;
+                while (m) {
+                    const uint32_t lv = (uint32_t)__ffs((int)m) - 1u;
+                    m &= m - 1u;
+                    if (at < leftCap) leftOut[at] = profile_key_of(lv, n, tax, hits, PL); else direct(lv, n, tax, hits);
+                    ++at;
                 }
             }
+        } else if (nLeft) {
+#pragma unroll
+            for (int q = 0; q < PT_KEYS; ++q)
+                levelsOf(kk[q], [&](uint32_t *, uint32_t) {}, [&](uint32_t lv, uint32_t n, uint32_t tax, uint32_t hits) {
+                    if (at < leftCap) leftOut[at] = profile_key_of(lv, n, tax, hits, PL); else direct(lv, n, tax, hits);
+                    ++at;
+                });
         }
-        __syncthreads();
-        if (sLeftN > (uint32_t)(PT_LEFT / 2)) flush();                 // uniform: read after the barrier
+        __syncthreads();                                                     // (sWave, sBase are written again in the next round)
     }
-    flush();
+    __syncthreads();
     if (rangeN)                                                        // the range cells folded into the tables: a running sum over the first levels
         for (uint32_t tax = threadIdx.x; tax < nTaxa; tax += PT_THREADS) {
             unsigned long long acc = 0;
@@ -4591,10 +4613,6 @@ __global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const u
     }
 }
 
-// The profile keys of a batch summed into the tables (grouped: group_kernel's range keys; else the per-read side's keys):
-// counted per (level, |T|, taxon) in LDS where the table of a workgroup has a cell, the rest sorted and reduced.
-// Up to 8 levels: one pass over the keys; more: the four shallowest levels (large taxon sets) in one pass, the deeper ones
-// eight at a time.
 static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
 {
     if (nKeys == 0) return KASA_OK;
@@ -4602,10 +4620,17 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
     const int nK = c->nK;
     int rc;
     hipStream_t ps = c->stream;
+    static const char *timing = getenv("KASA_PROF_TIMING");               // diagnostics: the phases' times on stderr
+    auto now = [&]() { if (timing) (void)hipStreamSynchronize(ps); return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
     const ProfLayout PL = prof_layout(nTaxa, nK);
-    // group keys may leave several per-level keys each (a few per cent do); the list is sorted back into the key buffer
-    const uint64_t leftCap = std::min<uint64_t>(std::max<uint64_t>(nKeys, 1u << 20), c->profKeys.cap / 8);
+    // Keys without a cell in a workgroup's table leave as per-level keys for the sort + reduce: a few per cent of them with sparse
+    // taxon sets, several per group key with a crowded index (|T| in the tens and hundreds).  The list is as long as the last
+    // batch needed (what does not fit goes to the tables key by key -- slow, and the next batch gets the room).
+    uint64_t leftCap = grouped ? std::max<uint64_t>(std::max<uint64_t>(nKeys / 4, 1u << 20), c->profLeftHint) : std::max<uint64_t>(nKeys, 1u << 20);
+    leftCap = std::min<uint64_t>(leftCap, 0xFFFFFFF0ull);
     if ((rc = c->profSorted.reserve((size_t)leftCap * 8 + 64))) return rc;
+    if (grouped && (rc = c->profSorted2.reserve((size_t)leftCap * 8 + 64))) return rc;
     uint64_t budgetCells = (160u * 1024u - PT_LEFT * 8u - 1024u) / 4u;
     // group keys: range cells [first level][taxon] for the keys with |T| = 1 (when a third of the table's room suffices)
     const bool rangeCells = grouped && (uint64_t)nK * nTaxa <= budgetCells / 3;
@@ -4642,8 +4667,11 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
         }
         HIPCHK(hipMemcpyAsync(&left, leftCursor, 8, hipMemcpyDeviceToHost, ps));
         HIPCHK(hipStreamSynchronize(ps));
-        nSort = std::min<uint64_t>(left, leftCap); sortIn = c->profSorted.as<uint64_t>(); sortOut = c->profKeys.as<uint64_t>();   // what is left, sorted back into the key buffer
+        nSort = std::min<uint64_t>(left, leftCap); sortIn = c->profSorted.as<uint64_t>();
+        sortOut = grouped ? c->profSorted2.as<uint64_t>() : c->profKeys.as<uint64_t>();   // (per-read keys: what is left is sorted back into the key buffer)
+        if (grouped && left > leftCap) c->profLeftHint = left + left / 4;
     }
+    const auto t1 = now();
     if (nSort > 0) {
         // keys only, by the bits above the 16-bit hit count (whole bytes: the bits beyond the key's fields are zero)
         const int sortBits = (int)((PL.bits() + 7u) / 8u) * 8;
@@ -4654,6 +4682,11 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
             kRes, (uint32_t)nSort, nTaxa,
             c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), PL);
         HIPCHK(hipGetLastError());
+    }
+    if (timing) {
+        const auto t2 = now();
+        fprintf(stderr, "kasa: profile keys %llu: tables %.1f ms, %llu left over (list %llu), sort + reduce %.1f ms\n", (unsigned long long)nKeys,
+                std::chrono::duration<double>(t1 - t0).count() * 1e3, (unsigned long long)nSort, (unsigned long long)leftCap, std::chrono::duration<double>(t2 - t1).count() * 1e3);
     }
     return KASA_OK;
 }
@@ -6356,7 +6389,7 @@ extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
     const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
                            &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
+                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profSorted2, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
                            &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
                            &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
                      &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};

@@ -963,7 +963,7 @@ struct Batcher {
     ReadSet pending; size_t pendPos = 0;          // parsed reads not yet handed out
     vector<uint32_t> pendSeg;                     // paired-end: the whole (merged) input sits in `pending`
     uint64_t nextRead = 0, nextId = 0;
-    int64_t refBudget = 0; bool useRef = false, firstBatch = true, warned = false;
+    int64_t refBudget = 0; bool useRef = false, firstBatch = true, warned = false, warnedLong = false;
     uint64_t maxKmersPerBatch;
     double parseSeconds = 0;
     bool protein = false;
@@ -1084,6 +1084,13 @@ struct Batcher {
                     const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
                     len += (uint64_t)l;
                     if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
+                }
+                if (useRef && cost > 100ll * 1024 * 1024 && !warnedLong) {
+                    // kASA cuts a sequence whose k-mers outrun what is left of its batch budget into pieces with a 3K - 1 overhang and
+                    // merges the pieces' scores (Read.hpp:343-356,678-695; Compare.hpp:2344-2426); here a sequence is always scored whole
+                    std::cerr << "WARNING: sequence " << (nextRead + n) << " (" << len << " letters) is long enough for kASA to split it across its batches (-m); "
+                                 "it is scored in one piece here: its per-read line differs from kASA's." << std::endl;
+                    warnedLong = true;
                 }
                 const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
                 if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; full = true; break; }

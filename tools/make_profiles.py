@@ -5,15 +5,21 @@
     FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE = HBM bytes per launch, SQ_INSTS_VALU / SALU,
     SQ_WAVES, SQ_BUSY_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY
   * the bench lines (headline, and with --secondary the 128-bit configuration) -> <tag>_bench_1gpu.json
-    python3 tools/make_profiles.py r02 [--secondary]
+    python3 tools/make_profiles.py r04 [--wide] [--pmc-only]
 """
 import csv, glob, json, os, re, subprocess, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
+WIDE = "--wide" in sys.argv          # the 128-bit configuration (C3): its own kernel summary and counter passes, files <tag>_*_wide.*
+SFX = "_wide" if WIDE else ""
+WARGS = ["--wide"] if WIDE else []
 out = "gpurun_out/profiles"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|row_copy_kernel"
+KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_flat16_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|profile_group_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|bucket_rank_kernel|row_copy_kernel"
+sys.path.insert(0, os.getcwd())
+import bench as _bench
+SHA = _bench.source_sha16()
 
 
 def run(cmd, **kw):
@@ -27,23 +33,23 @@ d = os.path.join(out, "stats")
 if PMC_ONLY:
     pass
 else:
-  with open(os.path.join(out, tag + "_bench_under_rocprof.json"), "w") as f:
+  with open(os.path.join(out, tag + "_bench_under_rocprof" + SFX + ".json"), "w") as f:
       run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
-           "--no-cpu", "--no-e2e", "--no-secondary"], stdout=f, stderr=subprocess.DEVNULL)
+           "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"] + WARGS, stdout=f, stderr=subprocess.DEVNULL)
   src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
   rows = list(csv.DictReader(open(src)))
-  with open(os.path.join(out, tag + "_kernel_stats_bench_10M.csv"), "w") as f:
+  with open(os.path.join(out, tag + "_kernel_stats_bench_10M" + SFX + ".csv"), "w") as f:
       w = csv.writer(f)
       w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
       for r in rows:
           w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
   md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
-  open(os.path.join(out, tag + "_kernel_stats_bench_10M.md"), "w").write(
-      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-secondary` on one MI355X\n"
-      "(10 M reads x 150 bp, 419,951,000-record index).  The run holds the index build (one call of encode / lookup of its own) plus 1 warm-up\n"
-      "and 3 timed steps.  The warm-up step launches score_main / score_other twice (the first attempt sizes the staging rows, stops early\n"
-      "and is repeated with the capacity it asked for): their 5th call is that short one, so their averages here are below the per-launch\n"
-      "averages of bench.py's HIP events (total = 4 full launches + 1 short one).  Full names: the .csv next to this file.\n\n" + md)
+  open(os.path.join(out, tag + "_kernel_stats_bench_10M" + SFX + ".md"), "w").write(
+      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-secondary --no-tertiary --no-pmc" + (" --wide" if WIDE else "") + "` on one MI355X\n"
+      "(10 M reads x 150 bp, 4.2e8-record " + ("128-bit index, -k 25 7" if WIDE else "64-bit index, -k 12 7") + "; kernel sources " + SHA + ").  The run holds the index build (one call of encode / the sort of its own) plus 1 warm-up\n"
+      "and 3 timed steps.  The warm-up step launches group / score_main / score_other twice where a first attempt only sizes a buffer (it stops early\n"
+      "and is repeated with the capacity it asked for): such a short call lowers the average here below the per-launch average of bench.py's HIP\n"
+      "events.  Full names: the .csv next to this file.\n\n" + md)
 
 # 2. PMC passes (counters only; one step of 10 M reads)
 passes = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS",
@@ -52,12 +58,13 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i, p in enumerate(passes):
     dd = os.path.join(out, "pmc%d" % i)
     run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", dd, "--", "python3", "bench.py",
-         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"] + WARGS, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             name = re.sub(r"[<(].*", "", row["Kernel_Name"]).replace("void ", "")
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-res = {"command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-secondary",
+res = {"source_sha16": SHA,
+       "command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-secondary --no-tertiary --no-pmc" + (" --wide" if WIDE else ""),
        "workload": "10M x 150bp reads vs 419951000-record index (bench.py default); per kernel the LARGEST dispatch (the 1.3e9-query batch; the index build "
                    "launches encode/lookup once on its own input)",
        "correction": "hbm_bytes_per_launch = FETCH_SIZE[KB] x 1024 x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM; exact for "
@@ -68,11 +75,11 @@ for name, cs in acc.items():
         e["hbm_read_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2
         e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-    res[{"row_merge_bitmap_kernel": "row_merge_kernel", "score_other_flat_kernel": "score_other_kernel"}.get(name, name)] = e
-json.dump(res, open(os.path.join(out, tag + "_kernel_pmc.json"), "w"), indent=1)
+    res[{"row_merge_bitmap_kernel": "row_merge_kernel", "score_other_flat_kernel": "score_other_kernel", "score_other_flat16_kernel": "score_other_kernel"}.get(name, name)] = e
+json.dump(res, open(os.path.join(out, tag + "_kernel_pmc" + SFX + ".json"), "w"), indent=1)
 
 # 3. the bench line(s)
-if PMC_ONLY:
+if PMC_ONLY or WIDE:
     for k, e in res.items():
         if isinstance(e, dict) and "SQ_INSTS_VALU" in e:
             ins = e["SQ_INSTS_VALU"] + e["SQ_INSTS_SALU"]
