@@ -2826,6 +2826,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     extern __shared__ float sRowDyn[];
     __shared__ uint32_t sSegQ[DENSE ? DQ_SEGS : 1];
     __shared__ uint32_t sCntQ[DENSE ? 32 : 1];
+    __shared__ uint32_t sPreQ[DENSE ? 32 : 1];     // segments of the staged query whose last level reaches level lv: they are the FIRST ones of its list
     // (the dense form of narrow records keeps no profile -- group_stage's -- and no list of touched taxa: the LDS they would
     // take is what limits the resident wavefronts of this latency-bound kernel)
     constexpr bool LEAN = DENSE && GpOf<RW>::v;
@@ -2890,7 +2891,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     const uint32_t ns = rec_nseg<RW>(w, A.pool);
                     cachedN = ns;
                     cachedSlot = slot;
-                    if (lane < 32) sCntQ[lane] = 0u;
+                    if (lane < 32) { sCntQ[lane] = 0u; sPreQ[lane] = 0u; }
                     LDS_WAVE_SYNC();
                     for (uint32_t b0 = 0; b0 < ns; b0 += 256) {                  // four loads in flight per lane: the kernel waits for memory, not for arithmetic
                         uint32_t sg4[4];
@@ -2904,23 +2905,28 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                                 if (i < (uint32_t)DQ_SEGS) sSegQ[i] = sg;
                                 atomicAdd(&sCntQ[A.kHigh - (int)(sg >> 27)], 1u);
                                 atomicSub(&sCntQ[A.kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+                                atomicAdd(&sPreQ[A.kHigh - (int)(sg >> 27)], 1u);
                             }
                         }
                     }
                     LDS_WAVE_SYNC();
-                    uint32_t v = lane < 32 ? sCntQ[lane] : 0u;
+                    uint32_t v = lane < 32 ? sCntQ[lane] : 0u, pv = lane < 32 ? sPreQ[lane] : 0u;
                     v = wave_incl_sum(v);
+                    pv = wave_incl_sum(pv);
                     LDS_WAVE_SYNC();
-                    if (lane < 32) sCntQ[lane] = v;
+                    if (lane < 32) { sCntQ[lane] = v; sPreQ[lane] = pv; }
                     LDS_WAVE_SYNC();
                 }
                 const int lv = A.kHigh - k;
-                const uint32_t n = sCntQ[lv], ns = cachedN;
+                // the list comes in descending order of the segments' last level: those that reach level k are its first
+                // sPreQ[lv] -- an event looks at no more (a conserved k-mer's list: hundreds of shallow chance matches behind a
+                // handful of deep ones)
+                const uint32_t n = sCntQ[lv], ns = sPreQ[lv];
                 const float sc = event_score(k, n);
                 for (uint32_t b0 = 0; b0 < ns; b0 += 64) {
                     const uint32_t i = b0 + lane;
                     if (i >= ns) continue;
-                    const uint32_t sg = i < (uint32_t)DQ_SEGS ? sSegQ[i] : rec_seg<RW>(w, A.pool, ns, i);
+                    const uint32_t sg = i < (uint32_t)DQ_SEGS ? sSegQ[i] : rec_seg<RW>(w, A.pool, cachedN, i);
                     if (!seg_covers(sg, (uint32_t)k)) continue;
                     const uint32_t tx = sg & SEG_TAX_MASK;
                     if (A.wantPerRead) { float v = score[tx]; for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, sc); score[tx] = v; }
