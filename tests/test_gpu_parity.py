@@ -204,6 +204,46 @@ def test_coverage_counts_groups():
     ctx.close(); dix.close()
 
 
+def test_resident_upload_and_profile_only_mode():
+    """kasa_batch_upload_device (bases and offsets in device memory, read in place: bench.py's step at every N) gives the batch
+    kasa_batch_upload gives; and a batch without per-read output -- the profile is complete after the group stage, no score
+    stage runs -- has the oracle's profile."""
+    _gpu_or_fail()
+    import torch
+    ix, batch = synthetic_world(5, 12, 9000, 4000)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    ref = (ctx.scores(), ctx.profile_limbs().copy())
+    dev_bases = torch.from_numpy(np.ascontiguousarray(batch.bases)).to("cuda")
+    dev_off = torch.from_numpy(np.ascontiguousarray(batch.offsets, dtype=np.int64)).to("cuda")
+    torch.cuda.synchronize()
+    for half in (False, True):                                   # the whole batch; then its second half (offsets not starting at 0)
+        a = batch.n // 2 if half else 0
+        ctx.profile_reset()
+        ctx.upload_resident(dev_bases.data_ptr(), dev_off.data_ptr() + 8 * a, batch.n - a)
+        ctx.encode(); ctx.sort_and_range(); ctx.lookup_score(True, False)
+        if not half:
+            got = (ctx.scores(), ctx.profile_limbs().copy())
+            assert all(np.array_equal(x, y) for x, y in zip(got[0], ref[0])) and np.array_equal(got[1], ref[1])
+        else:
+            part = batch.slice(a, batch.n)
+            res, nq = oracle.identify_batch(ix, part.bases, part.offsets, oracle.params(12, 7, 3), True)
+            assert ctx.n_kmers == nq
+            assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    # profile only
+    res, _ = oracle.identify_batch(ix, batch.bases, batch.offsets, oracle.params(12, 7, 3), True)
+    ctx.profile_reset()
+    ctx.run_batch(batch.bases, batch.offsets, False)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert ctx.stage_ms()["score"][1] >= 0
+    with pytest.raises(RuntimeError):
+        ctx.scores()                                             # there are none
+    ctx.close(); dix.close()
+
+
 def test_profile_limbs_roundtrip_and_sum():
     _gpu_or_fail()
     d, ix = helpers.load_case("pairs")

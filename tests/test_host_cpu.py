@@ -169,3 +169,18 @@ def test_cpp_parser_equals_python_parser(name, block, run, golden_dir):
         head, body = part.split("\n", 1)
         assert head.startswith("protein=%d" % (1 if ref.protein else 0)), head
         assert body == want
+
+
+def test_crowded_genomes_share_what_they_claim():
+    """synth.genomes_crowded (bench.py's `tertiary`, the crowded id of the full-size test): members of a clade agree on the
+    clade's gene intervals up to their 1-5 % of substitutions, every taxon carries the universal intervals, the rest is its own."""
+    from kasa_amd import synth
+    g = synth.genomes_crowded(40, 30_000, seed=3, clade_sizes=(10, 20))
+    assert g.shape == (40, 30_000) and set(np.unique(g)) <= set(b"ACGT")
+    same01 = float((g[0] == g[1]).mean())                       # two members of the first clade: 30 % + 5 % shared (at ~94 % identity) + chance
+    assert 0.42 < same01 < 0.54, same01
+    far = float((g[0] == g[39]).mean())                         # another clade: only the universal 5 % + chance (25 % of the rest)
+    assert 0.26 < far < 0.34, far
+    g2 = synth.genomes_crowded(40, 30_000, seed=3, clade_sizes=(10, 20))
+    assert np.array_equal(g, g2)                                # seeded
+

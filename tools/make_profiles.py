@@ -29,7 +29,7 @@ def run(cmd, **kw):
 
 PMC_ONLY = "--pmc-only" in sys.argv
 # 1. kernel stats
-d = os.path.join(out, "stats")
+d = os.path.join(out, "stats" + SFX)
 if PMC_ONLY:
     pass
 else:
@@ -56,7 +56,7 @@ passes = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ
           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA", "FETCH_SIZE", "WRITE_SIZE"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i, p in enumerate(passes):
-    dd = os.path.join(out, "pmc%d" % i)
+    dd = os.path.join(out, "pmc%d%s" % (i, SFX))
     run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", dd, "--", "python3", "bench.py",
          "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"] + WARGS, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
