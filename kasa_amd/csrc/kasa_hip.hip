@@ -739,8 +739,11 @@ __global__ void upload_geometry_kernel(const int64_t *__restrict__ raw, int64_t 
 }
 __global__ void upload_max_kernel(const uint64_t *__restrict__ readCnt, int64_t nReads, uint32_t *__restrict__ maxCnt)
 {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t v = r < nReads ? (uint32_t)(readCnt[r] < 0xFFFFFFFFull ? readCnt[r] : 0xFFFFFFFFull) : 0u;
+    uint32_t v = 0;                                               // (a few thousand wavefronts stride over the reads: one atomic each, not one per 64 reads)
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nReads; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t c = readCnt[r];
+        v = max(v, (uint32_t)(c < 0xFFFFFFFFull ? c : 0xFFFFFFFFull));
+    }
     for (int off = 32; off; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
     if ((threadIdx.x & 63) == 0 && v) atomicMax(maxCnt, v);
 }
@@ -790,7 +793,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     upload_geometry_kernel<<<blocks_for((uint64_t)nSeq + 1, 256), 256, 0, c->stream>>>(c->rawOff.as<int64_t>(), nSeq, seqRead ? c->seqRead.as<uint32_t>() : nullptr, nReads,
         c->enc_mode(), c->K(), c->kLow, c->strands(), c->baseOff.as<int64_t>(), seqCnt, readCnt, flags, errAt, flags + 1);
     HIPCHK(hipGetLastError());
-    if (nReads) upload_max_kernel<<<blocks_for((uint64_t)nReads, 256), 256, 0, c->stream>>>(readCnt, nReads, flags + 1);
+    if (nReads) upload_max_kernel<<<std::min<unsigned>(blocks_for((uint64_t)nReads, 256), 2048u), 256, 0, c->stream>>>(readCnt, nReads, flags + 1);
     size_t tmpBytes = 0, tmp2 = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, seqCnt, seqCnt, (uint64_t)0, (size_t)nSeq + 1, rocprim::plus<uint64_t>(), c->stream));
     HIPCHK(rocprim::exclusive_scan(nullptr, tmp2, readCnt, readCnt, (uint64_t)0, (size_t)nReads + 1, rocprim::plus<uint64_t>(), c->stream));
