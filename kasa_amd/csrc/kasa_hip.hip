@@ -54,7 +54,7 @@ static constexpr int TILE = 1024;                 // sorted queries per workgrou
 static constexpr int TILE_THREADS = 256;
 static constexpr int ITEMS = TILE / TILE_THREADS; // 4
 static constexpr uint32_t NOPOS = 0xFFFFFFFFu;
-static constexpr int PCAP = 1024;                 // pending (not yet flushed) groups per read
+static constexpr int PCAP = 4096;                 // pending (not yet flushed) groups per read (the second pass of the general score kernel: 53 KB of LDS, one wavefront per CU -- rare reads)
 static constexpr int TLIST = 256;                // touched taxa of a read kept as a list (else dense scan)
 
 static thread_local std::string g_err;

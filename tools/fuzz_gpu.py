@@ -40,7 +40,7 @@ for seed in range(first, first + count):
         break
     try:
         T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
-        T.test_adversarial_queries_vs_oracle(seed, [0, 1, 2, 4][seed % 4])
+        T.test_adversarial_queries_vs_oracle(seed, [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192][seed % 8])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells)
         if os.environ.get("FUZZ_TEXT"):
             fuzz_text(seed)
     except Exception:
