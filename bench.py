@@ -400,7 +400,64 @@ def pmc_traffic(args, wide, kernel, live=True):
         return {"traffic": None, "traffic_source": "none"}
 
 
-def pcie_inclusive(ctx, reads, want, ix, k_high):
+def pcie_pipelined(ctx, dix, reads, bases, offsets, den, rclass, csr_buf, rank_buf, k_high, k_low, per_ctx=3):
+    """The long-lived host of INTEGRATION.md section 2b: TWO contexts on one device index, one host thread each, every
+    context with its own stream and page-locked buffers -- the upload of one batch and the ranking + download of another
+    run beside the kernels of a third (the reference has its own output thread for the same reason, Compare.hpp:3390-3392).
+    2 x per_ctx batches of the same reads, everything inside the clock: reads up, the five stages, ranking on the
+    device (-b 3), ranked hits down (+ the CSR when a read is handed back), the profile down once per context at the end."""
+    import threading
+    import numpy as np
+    from kasa_amd import capi
+    other = capi.Context(dix, k_high, k_low, 3)
+    try:
+        nnz = csr_buf[1].shape[0]
+        bufs = [(csr_buf, rank_buf),
+                ((capi.pinned_empty(reads.n + 1, np.uint64), capi.pinned_empty(nnz, np.uint32), capi.pinned_empty(nnz, np.float32)),
+                 (capi.pinned_empty(reads.n * 4, np.uint32), capi.pinned_empty(reads.n * 8, capi.RANK_ENTRY)))]
+        ctxs = [ctx, other]
+        errors, got = [], [0, 0]
+
+        def batch(i):
+            c = ctxs[i]
+            c.upload(bases, offsets)
+            c.encode()
+            c.sort_and_range()
+            c.lookup_score(True, False)
+            meta, ent, flagged = c.rank(den, rclass, 0.0, 3, out=bufs[i][1])
+            if flagged:
+                c.scores(out=bufs[i][0])
+            got[i] = int(ent.shape[0])
+
+        batch(1)                                                               # the second context sizes its buffers outside the clock, as the first has
+        start = threading.Barrier(3)
+
+        def work(i):
+            try:
+                start.wait()
+                for _ in range(per_ctx):
+                    batch(i)
+                ctxs[i].profile()
+            except Exception as ex:                                            # pragma: no cover
+                errors.append(str(ex)[:200])
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        if errors:
+            return {"pcie_pipelined_error": errors[0]}
+        return {"pcie_pipelined_reads_per_s": 2 * per_ctx * reads.n / dt, "pcie_pipelined_s_per_batch": dt / (2 * per_ctx),
+                "pcie_pipelined_batches": 2 * per_ctx, "pcie_pipelined_contexts": 2, "pcie_pipelined_ranked_entries_per_batch": got[0]}
+    finally:
+        other.close()
+
+
+def pcie_inclusive(ctx, reads, want, ix, k_high, dix=None, k_low=7):
     """Two more passes with the PCIe legs inside the clock (never `value`): host reads in, and out either what the per-read
     file can print (ranked on the device, kasa_batch_rank; page-locked buffers) or the whole CSR (pageable memory, the
     round-1 path).  The file-to-file rate of the C++ driver is measured by file_to_file() below."""
@@ -435,6 +492,11 @@ def pcie_inclusive(ctx, reads, want, ix, k_high):
         out.update({"pcie_inclusive_reads_per_s": reads.n / dt, "pcie_inclusive_s_per_batch": dt,
                     "ranked_entries": int(ent.shape[0]), "reads_ranked_by_host": int(flagged), "downloaded_bytes": nbytes,
                     "upload_and_device_s": t1 - t0, "rank_and_fetch_s": t2 - t1, "csr_and_profile_s": t0 + dt - t2})
+        if dix is not None:
+            try:
+                out.update(pcie_pipelined(ctx, dix, reads, bases, offsets, den, rclass, csr_buf, rank_buf, k_high, k_low))
+            except Exception as ex:                                        # (e.g. no memory for a second context)
+                out["pcie_pipelined_error"] = str(ex)[:300]
     t0 = time.perf_counter()
     ctx.upload(reads.bases, reads.offsets)
     ctx.encode()
@@ -445,8 +507,9 @@ def pcie_inclusive(ctx, reads, want, ix, k_high):
     ctx.profile()
     dt = time.perf_counter() - t0
     out.update({"csr_download_reads_per_s": reads.n / dt, "csr_download_s_per_batch": dt,
-                "note": "pcie_inclusive: page-locked reads up, device, ranking on the device (-b 3), ranked hits + profile down "
+                "note": "pcie_inclusive: ONE batch, nothing overlapped: page-locked reads up, device, ranking on the device (-b 3), ranked hits + profile down "
                         "(+ the CSR into page-locked memory when the device hands reads back); "
+                        "pcie_pipelined: the same legs for 6 batches through two contexts on two host threads (copies of one batch beside the kernels of another); "
                         "csr_download: the same with the whole CSR down into pageable memory; file_to_file_*: the C++ driver as a child process (text written on the device)"})
     if not want:
         out["pcie_inclusive_reads_per_s"] = out["csr_download_reads_per_s"]
@@ -793,7 +856,7 @@ def main():
             out = report(args, ctx, reads, ix, world, res, wide, per_rank, n_batches, "weak" if total_reads is None else "strong", extra_cfg)
             if legs and world == 1 and not args.no_e2e and workload == "pairs":
                 try:                                               # an extra pass: it must never cost the headline line
-                    out["e2e"] = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high)
+                    out["e2e"] = pcie_inclusive(ctx, reads, not args.profile_only, ix, k_high, dix, k_low)
                 except Exception as ex:                            # e.g. no memory left for the page-locked buffers
                     out["e2e"] = {"error": str(ex)[:300]}
         ctx.close()
