@@ -33,12 +33,33 @@ EXPORTS = [
 ]
 
 
+def _one_hip_runtime():
+    """A torch wheel brings its own libamdhip64.so (same SONAME as ROCm's).  Imported AFTER this library was loaded it
+    becomes a second HIP runtime in the process, and torch then finds no device ("No HIP GPUs are available"): a host that
+    uses both (bench.py, dist.py, tests that keep reads in torch tensors) must have them share one.  So torch's copy is
+    loaded first -- without importing torch -- and libkasa_hip.so's libamdhip64.so.7 resolves to it."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(SO_PATH):
             raise RuntimeError(f"{SO_PATH} is missing: build it with `python -m kasa_amd.build` "
                                "(there is no CPU fallback for the identify path)")
+        _one_hip_runtime()
         L = C.CDLL(SO_PATH)
         L.kasa_last_error.restype = C.c_char_p
         L.kasa_index_size.restype = C.c_uint64

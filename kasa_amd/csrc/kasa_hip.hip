@@ -641,7 +641,7 @@ extern "C" int kasa_ctx_create(const kasa_index *ix, int kHigh, int kLow, int fr
     if (hipMemcpy(c->lut.p, lut, 366, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(KASA_E_HIP, "LUT upload failed"));
     const size_t cells = (size_t)c->nK * ix->nTaxa * 8;
     if ((rc = c->cntUnique.reserve(cells)) || (rc = c->cntTotal.reserve(cells)) || (rc = c->cntAllHi.reserve(cells)) ||
-        (rc = c->cntAllMid.reserve(cells)) || (rc = c->cntAllLo.reserve(cells)) || (rc = c->misc.reserve(256)))
+        (rc = c->cntAllMid.reserve(cells)) || (rc = c->cntAllLo.reserve(cells)) || (rc = c->misc.reserve(512)))
         return bail(rc);
     *out = c;
     rc = kasa_profile_reset(c);
@@ -1394,12 +1394,13 @@ __global__ void slot_to_read_kernel(const uint32_t *__restrict__ slot, uint32_t 
 template <class Key> static int lookup_part(kasa_ctx *c);
 
 // Second half of the query sort.  The pairs arrive ordered (stably) by the top SORT_TOP bits of the key; queries that
-// share those bits -- a *bucket*: eight letters, i.e. little more than the copies of one k-mer prefix the reads' coverage brings --
+// share those bits -- a *bucket*: six letters and two bits of the seventh, i.e. the copies of a k-mer the reads' coverage brings
+// and the few other k-mers with that prefix, 17 members for the average query of the bench data (three with SORT_TOP_OLD) --
 // are contiguous.  Every query finds its place inside its bucket by counting: the bucket members before it with a key
 // not larger, those after it with a smaller key (= the stable order).  One pass over the pairs instead of the remaining
-// 20 (85) bits' worth of radix passes.  Buckets of more than SORT_BUCKET_LIMIT members (an input that repeats itself) are
+// 28 (93) bits' worth of radix passes (round 4: a fifth radix pass costs 8 ms at 1.15e9 pairs, the longer buckets 4).  Buckets of more than SORT_BUCKET_LIMIT members (an input that repeats itself) are
 // copied through and listed in `bigHead`; the caller sorts each of them by its remaining bits.
-static constexpr unsigned SORT_TOP = 40;
+static constexpr unsigned SORT_TOP = 32, SORT_TOP_OLD = 40;
 static constexpr uint32_t SORT_BUCKET_LIMIT = 1024;
 static constexpr uint32_t SORT_BIG_CAP = 1u << 18;     // long buckets sorted one by one; more of them (or one beyond SORT_BIG_LONGEST): the library over all bits
 static constexpr uint32_t SORT_BIG_LONGEST = 1u << 20;
@@ -1582,30 +1583,35 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         if (c->debugFlags & 64) {                                       // test tap: the library sort over all key bits
             if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, 0u, BITS))) return rc;
         } else {
-            // radix passes over the top 40 bits only (5 of the 8 resp. 16 passes), then every query finds its place
+            // radix passes over the top 32 bits only (4 of the 8 resp. 16 passes), then every query finds its place
             // inside its bucket (bucket_rank_kernel)
+            // (test tap 2097152: five passes over the top 40 bits and buckets of 20 (85) bits' worth, the form of rounds 2-3)
+            const unsigned top = (c->debugFlags & 2097152) ? SORT_TOP_OLD : SORT_TOP;
             uint32_t *big = c->misc.as<uint32_t>() + 43, *longest = c->misc.as<uint32_t>() + 44;
             if ((rc = c->sortBig.reserve((size_t)SORT_BIG_CAP * 12 + 64))) return rc;
             uint32_t *bigHead = c->sortBig.as<uint32_t>(), *segBegin = bigHead + SORT_BIG_CAP, *segEnd = segBegin + SORT_BIG_CAP;
             if (c->debugFlags & 512) {                                  // test tap: the library's passes over the same bits
-                if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - SORT_TOP, BITS))) return rc;
+                if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, BITS - top, BITS))) return rc;
             } else {
-                // the hand-written passes (kasa_radix.h): A -> B -> A ... ; five passes end in B
-                static_assert((SORT_TOP / 8) % 2 == 1, "an odd number of passes leaves the pairs in the other buffer");
+                // the hand-written passes (kasa_radix.h): A -> B -> A ... ; four passes end in A, which then takes B's name
                 if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<Key>(nQ)))) return rc;
                 Key *kRes; uint32_t *vRes;
                 HIPCHK(kasa_radix::sort_pairs<Key>(c->qKmerA.as<Key>(), c->qReadA.as<uint32_t>(), c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), (uint32_t)nQ,
-                                                   (int)(BITS - SORT_TOP), (int)SORT_TOP, c->sortTmp.p, c->stream, &kRes, &vRes));
+                                                   (int)(BITS - top), (int)top, c->sortTmp.p, c->stream, &kRes, &vRes, (c->debugFlags & 524288) ? kasa_radix::MODE_FIRST : 0));   // (test tap 524288: the look-back before the keys are ordered in LDS)
+                if (kRes == c->qKmerA.as<Key>() && (top / 8) % 2 == 0) { std::swap(c->qKmerA, c->qKmerB); std::swap(c->qReadA, c->qReadB); }   // (an even number of passes ends where it began)
                 if (kRes != c->qKmerB.as<Key>()) return fail(KASA_E_HIP, "query sort: unexpected result buffer");
             }
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
-            static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP + 12 <= 32, "bucket_rank32_kernel: low key bits and window position share a word");
-            if constexpr (sizeof(Key) == 8)
+            static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP_OLD + 12 <= 32, "bucket_rank32_kernel: low key bits and window position share a word");
+            if (sizeof(Key) == 8 && top != SORT_TOP_OLD)
+                bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
+                                                                                          c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
+            else if constexpr (sizeof(Key) == 8)
                 bucket_rank32_kernel<<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<uint64_t>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<uint64_t>(),
-                                                                                      c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
+                                                                                      c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
             else
                 bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
-                                                                                          c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), big, bigHead);
+                                                                                          c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
             HIPCHK(hipGetLastError());
             uint32_t hBig = 0;
             HIPCHK(hipMemcpyAsync(&hBig, big, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1617,7 +1623,7 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
                 // B is a stable rearrangement of the input, so its full sort is the full sort of the input.
                 uint32_t hLongest = 0;
                 if (hBig <= SORT_BIG_CAP) {
-                    bucket_bounds_kernel<Key><<<blocks_for(hBig, 256), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), (uint32_t)nQ, (int)(BITS - SORT_TOP), bigHead, hBig,
+                    bucket_bounds_kernel<Key><<<blocks_for(hBig, 256), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), (uint32_t)nQ, (int)(BITS - top), bigHead, hBig,
                                                                                          segBegin, segEnd, longest);
                     HIPCHK(hipGetLastError());
                     HIPCHK(hipMemcpyAsync(&hLongest, longest, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1626,10 +1632,10 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
                 if (hBig <= SORT_BIG_CAP && hLongest <= SORT_BIG_LONGEST && !(c->debugFlags & 128)) {   // (test tap 128: the last resort)
                     size_t tmpBytes = 0;
                     HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, tmpBytes, c->qKmerB.as<Key>(), c->qKmerA.as<Key>(), c->qReadB.as<uint32_t>(), c->qReadA.as<uint32_t>(),
-                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - SORT_TOP, c->stream));
+                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - top, c->stream));
                     if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
                     HIPCHK(rocprim::segmented_radix_sort_pairs(c->sortTmp.p, tmpBytes, c->qKmerB.as<Key>(), c->qKmerA.as<Key>(), c->qReadB.as<uint32_t>(), c->qReadA.as<uint32_t>(),
-                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - SORT_TOP, c->stream));
+                                                               (unsigned)nQ, hBig, segBegin, segEnd, 0u, BITS - top, c->stream));
                 } else if ((rc = radix(c->qKmerB, c->qReadB, c->qKmerA, c->qReadA, 0u, BITS))) return rc;
             }
             std::swap(c->qKmerA, c->qKmerB);                            // the sorted pairs are in "B" again
@@ -5360,12 +5366,15 @@ extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint3
 // relative score is flagged and ranked by the host from its full row (so is one with more than RANK_ROWS hits or a
 // prefix beyond RANK_CAP).
 static constexpr int RANK_CAP = 64, RANK_ROWS = 256, RANK_SLAB = 256;
+// rank_exact_kernel keeps a read's hits in LDS: reads with few hits take little of it, so they go to a launch of their own
+// that brings more wavefronts to a CU (classes by hit count: <= 32, <= 64, <= 128, more)
+__host__ __device__ inline int rank_exact_class(uint32_t cnt) { return cnt <= 32u ? 0 : cnt <= 64u ? 1 : cnt <= 128u ? 2 : 3; }
 struct RankEntry { uint32_t tax; float score; double rel; };
 __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
                                                    uint32_t nReads, const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
                                                    double thr, uint32_t beasts, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
                                                    unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged,
-                                                   RankEntry *__restrict__ handOver, uint16_t *__restrict__ handKey)
+                                                   RankEntry *__restrict__ handOver, uint16_t *__restrict__ handKey, uint32_t *__restrict__ nClass)
 {
     // the read's hits, compacted (taxon ascending, as in the row): everything after the first pass runs out of LDS
     __shared__ uint32_t sTax[4][RANK_ROWS];
@@ -5379,6 +5388,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
     // not fit stays unused
     unsigned long long slabAt = 0;
     uint32_t slabLeft = 0, flaggedMine = 0;
+    uint32_t classMine[4] = {0u, 0u, 0u, 0u};                              // flagged reads with <= 32, <= 64, <= 128, more hits
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += gridDim.x * 4u) {
         const uint64_t lo = rowOff[r];
         const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
@@ -5466,9 +5476,18 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
         if (at + nOut <= cap) for (uint32_t x = lane; x < nOut; x += 64) entries[at + x] = sOut[wv][x];
         if (lane == 0) meta[r] = make_uint4((uint32_t)at, nOut | (flag ? 0x80000000u : 0u), __float_as_uint(maxV), cnt);
         flaggedMine += flag ? 1u : 0u;
+        if (flag) {
+            const int cl = rank_exact_class(cnt);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) classMine[x] += cl == x ? 1u : 0u;
+        }
         LDS_WAVE_SYNC();
     }
-    if (lane == 0 && flaggedMine) atomicAdd(nFlagged, flaggedMine);
+    if (lane == 0 && flaggedMine) {
+        atomicAdd(nFlagged, flaggedMine);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (classMine[x]) atomicAdd(&nClass[x], classMine[x]);
+    }
 }
 
 // The reads rank_kernel left: a tie among more than 16 hits inside the printed prefix (std::sort's own order decides who is
@@ -5514,12 +5533,27 @@ struct PrintWalk {                                                         // th
 };
 
 // One thread's column of an LDS array ([element][lane]) or a piece of global memory, indexed alike.
+template <class T>
 struct LaneIds {
-    uint16_t *p; int stride;
-    __device__ __forceinline__ uint16_t &operator[](int i) const { return p[(size_t)i * stride]; }
+    T *p; int stride;
+    __device__ __forceinline__ T &operator[](int i) const { return p[(size_t)i * stride]; }
 };
 static constexpr int RANK_EXACT_LANES = 64;                                 // reads per workgroup
-static constexpr size_t RANK_EXACT_SHMEM = (size_t)RANK_ROWS * RANK_EXACT_LANES * (2 + 2);
+// std::sort's waiting ranges of one thread, in its column of an LDS array: up to 256 elements, so first and last take 9
+// bits each and the depth limit (2 log2 n <= 16) five
+template <int CAP_>
+struct LaneStack {
+    static constexpr int CAP = CAP_;
+    uint32_t *p;
+    __device__ __forceinline__ void put(int at, int first, int last, int depth) { p[(size_t)at * RANK_EXACT_LANES] = (uint32_t)first | ((uint32_t)last << 9) | ((uint32_t)depth << 18); }
+    __device__ __forceinline__ void get(int at, int &first, int &last, int &depth) const
+    {
+        const uint32_t w = p[(size_t)at * RANK_EXACT_LANES];
+        first = (int)(w & 511u); last = (int)((w >> 9) & 511u); depth = (int)(w >> 18);
+    }
+};
+__host__ __device__ constexpr int rank_exact_stack_cap(int rows) { int lg = 0; while ((rows >> (lg + 1)) != 0) ++lg; return 2 * lg + 2; }
+template <int ROWS>
 __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ rowOff,
                                                         const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
                                                         const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
@@ -5531,8 +5565,11 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
     // (the number of hits with a larger relative score, from rank_kernel: equal scores, equal keys) -- and the ids live in
     // this thread's columns of two LDS arrays (from global scratch the same took 0.5 s for 3.3 M reads).  Reads with more
     // than RANK_ROWS hits (rank_kernel handed nothing over) compact their row themselves and sort in global memory.
-    extern __shared__ unsigned char shRaw[];
-    uint16_t *shKey = reinterpret_cast<uint16_t *>(shRaw), *shId = shKey + RANK_ROWS * RANK_EXACT_LANES;
+    // ROWS: the most hits a read of this launch has (the list is sorted by that number; the host cuts it into classes)
+    static_assert(ROWS <= 256, "LaneStack packs positions into 9 bits");
+    constexpr int SCAP = rank_exact_stack_cap(ROWS);
+    __shared__ uint8_t shKey[ROWS * RANK_EXACT_LANES], shId[ROWS * RANK_EXACT_LANES];   // (up to 256 hits: positions and order keys fit a byte)
+    __shared__ uint32_t shStack[SCAP * RANK_EXACT_LANES];
     const uint32_t x = blockIdx.x * RANK_EXACT_LANES + threadIdx.x;
     const int lane = threadIdx.x;
     const bool have = x < nList;
@@ -5545,10 +5582,10 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
         lo = rowOff[r];
         const uint4 mt = meta[r];
         cnt = mt.w; maxV = __uint_as_float(mt.z);
-        inLds = cnt <= (uint32_t)RANK_ROWS;
+        inLds = cnt <= (uint32_t)ROWS;
         const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
         if (inLds) {
-            for (uint32_t i = 0; i < cnt; ++i) { shKey[(size_t)i * RANK_EXACT_LANES + lane] = keyS[lo + i]; shId[(size_t)i * RANK_EXACT_LANES + lane] = (uint16_t)i; }
+            for (uint32_t i = 0; i < cnt; ++i) { shKey[(size_t)i * RANK_EXACT_LANES + lane] = (uint8_t)keyS[lo + i]; shId[(size_t)i * RANK_EXACT_LANES + lane] = (uint8_t)i; }
         } else if (m < 65536u) {                                           // a long row: compacted here, in place
             const double *dr = den + (size_t)readClass[r] * nTaxa;
             uint32_t n = 0;
@@ -5563,9 +5600,9 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
             const RankEntry *hs = hits + lo;
             // only the hits a writer prints have to be in std::sort's order: the first RANK_CAP positions, as a rule.
             // (Two instantiations, so that the LDS columns are reached with LDS instructions, not through flat pointers.)
-            auto rankRead = [&](auto ids, auto less) {
+            auto rankRead = [&](auto ids, auto less, auto stack) {
                 int covered = 0;
-                ok = stdsort_order(ids, (int)cnt, less, RANK_CAP, &covered);
+                ok = stdsort_order(ids, (int)cnt, less, RANK_CAP, &covered, stack);
                 for (int pass = 0; ok && pass < 2; ++pass) {
                     PrintWalk w;                                           // how many hits a writer prints
                     bool more = false;
@@ -5577,14 +5614,15 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
                     }
                     if (!more) break;
                     for (uint32_t i = 0; i < cnt; ++i) ids[(int)i] = (uint16_t)i;   // it prints beyond what is final: all of it, from the start
-                    ok = stdsort_order(ids, (int)cnt, less, (int)cnt, &covered);
+                    ok = stdsort_order(ids, (int)cnt, less, (int)cnt, &covered, stack);
                 }
             };
             if (inLds) {
-                const uint16_t *ky = shKey + lane;
-                rankRead(LaneIds{shId + lane, RANK_EXACT_LANES}, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; });
-            } else
-                rankRead(LaneIds{idS + lo, 1}, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; });
+                const uint8_t *ky = shKey + lane;
+                rankRead(LaneIds<uint8_t>{shId + lane, RANK_EXACT_LANES}, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; },
+                         LaneStack<SCAP>{shStack + lane});
+            } else if constexpr (ROWS == RANK_ROWS)                        // (only the last class holds reads with more hits than its LDS takes)
+                rankRead(LaneIds<uint16_t>{idS + lo, 1}, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; }, StdsortLocalStack());
         }
     }
     uint32_t incl = nOut;                                                  // one allocation per wavefront
@@ -5623,7 +5661,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
     HIPCHK(hipMemcpyAsync(c->rankDen.p, den, (size_t)nClasses * nTaxa * 8, hipMemcpyHostToDevice, c->stream));
     if (nReads) HIPCHK(hipMemcpyAsync(c->rankClass.p, readClass, (size_t)nReads * 4, hipMemcpyHostToDevice, c->stream));
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 20;
-    uint32_t *flagged = c->misc.as<uint32_t>() + 42;
+    uint32_t *flagged = c->misc.as<uint32_t>() + 42, *nClass = c->misc.as<uint32_t>() + 64;   // ([64..67]: flagged reads per class of hit count)
     if (c->rankCap == 0) c->rankCap = std::max<uint64_t>(1 << 20, (uint64_t)nReads * 4 + (uint64_t)RANK_SLAB * 256u * 32u * 4u);
     c->rankEntries = 0; *nEntries = 0; *nFlagged = 0; c->rankValid = false; c->txtValid = false;
     if (nReads == 0) { c->rankValid = true; c->rankFlagged = 0; return KASA_OK; }
@@ -5631,6 +5669,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         if ((rc = c->rankOut.reserve(c->rankCap * sizeof(RankEntry)))) return rc;
         HIPCHK(hipMemsetAsync(cursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(flagged, 0, 4, c->stream));
+        HIPCHK(hipMemsetAsync(nClass, 0, 16, c->stream));
         // reads with tied hits are handed to rank_exact_kernel: their compacted hits wait where the row lies (16 bytes per cell)
         const bool exact = c->nnz > 0 && !(c->debugFlags & 256);           // (test tap 256: leave them to the host)
         // (20 bytes per CSR cell.  The event records are dead once the batch is scored: their buffer serves when it is large
@@ -5643,11 +5682,12 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         const unsigned blocks = std::min<unsigned>(blocks_for(nReads, 4), 256u * 32u);
         rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->outTax.as<uint32_t>(), c->outScore.as<float>(), nReads,
                                                    c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
-                                                   c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged, handOver, handKey);
+                                                   c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged, handOver, handKey, nClass);
         HIPCHK(hipGetLastError());
-        unsigned long long used = 0; uint32_t nf = 0;
+        unsigned long long used = 0; uint32_t nf = 0, hClass[4] = {0u, 0u, 0u, 0u};
         HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hClass, nClass, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (nf > 0 && used <= c->rankCap && exact) {
             // the reads the wavefront-per-read kernel left: std::sort's own order, one thread per read (rank_exact_kernel)
@@ -5663,11 +5703,24 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
                 if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
                 HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, key0, key1, list0, list1, (size_t)nf, 0u, 16u, c->stream));
             }
-            HIPCHK(hipFuncSetAttribute((const void *)rank_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RANK_EXACT_SHMEM));
-            rank_exact_kernel<<<blocks_for(nf, RANK_EXACT_LANES), RANK_EXACT_LANES, RANK_EXACT_SHMEM, c->stream>>>(list1, nf, c->rowOff.as<uint64_t>(),
-                c->outTax.as<uint32_t>(), c->outScore.as<float>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
-                handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged);
-            HIPCHK(hipGetLastError());
+            // the list is sorted by the number of hits: one launch per class, the LDS a read's hits take cut to the class
+            if (hClass[0] + hClass[1] + hClass[2] + hClass[3] != nf) return fail(KASA_E_HIP, "kasa_batch_rank: the classes of the flagged reads do not add up");
+            uint32_t from = 0;
+            for (int cl = 0; cl < 4; ++cl) {
+                const uint32_t nCl = hClass[cl];
+                if (nCl == 0) continue;
+#define KASA_RANK_EXACT(ROWS) rank_exact_kernel<ROWS><<<blocks_for(nCl, RANK_EXACT_LANES), RANK_EXACT_LANES, 0, c->stream>>>(list1 + from, nCl, c->rowOff.as<uint64_t>(), \
+                c->outTax.as<uint32_t>(), c->outScore.as<float>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts, \
+                handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged)
+                if (c->debugFlags & 1048576) KASA_RANK_EXACT(RANK_ROWS);   // (test tap: every class in the largest form)
+                else if (cl == 0) KASA_RANK_EXACT(32);
+                else if (cl == 1) KASA_RANK_EXACT(64);
+                else if (cl == 2) KASA_RANK_EXACT(128);
+                else KASA_RANK_EXACT(RANK_ROWS);
+#undef KASA_RANK_EXACT
+                HIPCHK(hipGetLastError());
+                from += nCl;
+            }
             HIPCHK(hipMemcpyAsync(&used, cursor, 8, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipMemcpyAsync(&nf, flagged, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));

@@ -61,16 +61,17 @@ __global__ __launch_bounds__(256) void starts_kernel(uint32_t *__restrict__ hist
 }
 
 // one pass: pairs (kin, vin) -> (kout, vout), stably by the 8 key bits at `shift`
-// GROUP: tiles are numbered so that the workgroups of one XCD (blockIdx.x % 8) take runs of GROUP consecutive tiles: the
-// lines two neighbouring tiles share at the ends of every digit's run then meet in ONE L2 before they go to memory.  A
-// workgroup still only waits for tiles that were handed out before its own by the same counter or belong to an earlier
-// group of GROUP * 8 tiles (whose counters are ahead), so nothing waits for a tile that cannot start.
-template <class Key, bool PAIRS, int GROUP>
+// MODE (taps of tools/pass_probe.hip and of the tests; the product runs MODE 0): bit 3 = the look-back right after the tile's
+// counts are out, before its keys are ordered in LDS (rounds 2-3: 41 ms for five passes over 1.15e9 pairs against 38); bit 1 =
+// no look-back (timing only, pairs land in wrong places: 27 ms).
+static constexpr int MODE_NOLOOK = 2, MODE_FIRST = 8;
+template <class Key, bool PAIRS, int MODE>
 __global__ __launch_bounds__(THREADS, 8) void pass_kernel(const Key *__restrict__ kin, const uint32_t *__restrict__ vin, Key *__restrict__ kout,
                                                        uint32_t *__restrict__ vout, uint32_t n, int shift, const uint32_t *__restrict__ start,
                                                        unsigned long long *__restrict__ status, uint32_t *__restrict__ tileCounter, uint32_t nTiles)
 {
     constexpr int ITEMS = Tile<Key>::ITEMS, TILE = Tile<Key>::SIZE;
+    constexpr bool LATE = (MODE & MODE_FIRST) == 0;
     // one LDS area, three lives: the waves' digit counters while ranking, then the tile's keys in output order, then its payloads
     __shared__ __attribute__((aligned(16))) unsigned char sArea[TILE * sizeof(Key) > WAVES * RADIX * 4 ? TILE * sizeof(Key) : WAVES * RADIX * 4];
     __shared__ uint32_t sBase[RADIX];      // first place of a digit inside the tile
@@ -81,35 +82,26 @@ __global__ __launch_bounds__(THREADS, 8) void pass_kernel(const Key *__restrict_
     Key *sKey = reinterpret_cast<Key *>(sArea);
     uint32_t *sVal = reinterpret_cast<uint32_t *>(sArea);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) {
-        if constexpr (GROUP == 0) sTile = atomicAdd(tileCounter, 1u);
-        else {
-            // counter x hands out the tiles {s * 8 GROUP + x GROUP + i}: s = 0, 1, ..., i < GROUP; a counter that has run past the
-            // last tile passes its workgroup on to the next counter (the grid holds exactly one workgroup per tile)
-            uint32_t t = 0xFFFFFFFFu;
-            for (uint32_t x = blockIdx.x & 7u, tries = 0; tries < 8u; ++tries, x = (x + 1u) & 7u) {
-                const uint32_t c = atomicAdd(&tileCounter[x], 1u);
-                const uint32_t cand = (c / GROUP) * (8u * GROUP) + x * GROUP + (c % GROUP);
-                if (cand < nTiles) { t = cand; break; }
-            }
-            sTile = t;
-        }
-    }
+    if (tid == 0) sTile = atomicAdd(tileCounter, 1u);                  // tiles are numbered in the order the workgroups start
 #pragma unroll
     for (int i = 0; i < RADIX / 64; ++i) sCnt[wv][lane + 64 * i] = 0u;
     __syncthreads();
-    const uint32_t tile = sTile;
-    if (tile == 0xFFFFFFFFu) return;                                  // (GROUP: every counter ran dry -- cannot happen with one workgroup per tile)
-    const uint64_t base = (uint64_t)tile * TILE + (uint64_t)wv * (64 * ITEMS) + lane;   // wave-striped: row i of a wave = 64 consecutive pairs
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)sTile);
+    // wave-striped: row i of a wave = 64 consecutive pairs.  The tile's first pair is a scalar address, a thread adds one 32-bit
+    // offset and the row's constant: eight loads from one address register
+    const Key *__restrict__ kt = kin + (uint64_t)tile * TILE;
+    const uint32_t *__restrict__ vt = vin + (uint64_t)tile * TILE;
+    const uint32_t base = (uint32_t)wv * (64 * ITEMS) + (uint32_t)lane;
+    const uint32_t left = (uint64_t)tile * TILE < (uint64_t)n ? (uint32_t)((uint64_t)n - (uint64_t)tile * TILE) : 0u;
+    const uint32_t count = left < (uint32_t)TILE ? left : (uint32_t)TILE;   // pairs of this tile
     Key k[ITEMS];
     uint32_t rank[ITEMS];                                             // rank: inside the wave first, then the pair's place in the tile
     uint32_t okMask = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const uint64_t at = base + (uint64_t)i * 64;
-        const bool ok = at < (uint64_t)n;
+        const bool ok = base + (uint32_t)i * 64u < count;
         okMask |= ok ? (1u << i) : 0u;
-        k[i] = ok ? kin[at] : (Key)0;
+        k[i] = ok ? kt[base + (uint32_t)i * 64u] : (Key)0;
     }
     // ---- rank inside the wave: pairs of one row with the same digit find each other by ballots; the first of them books the
     // digit's running count of this wave (LDS, wave-private: a wave's LDS instructions execute in order)
@@ -132,49 +124,62 @@ __global__ __launch_bounds__(THREADS, 8) void pass_kernel(const Key *__restrict_
         __builtin_amdgcn_wave_barrier();
         old = __shfl(old, leader < 0 ? 0 : leader);
         rank[i] = old + (uint32_t)__popcll(m & below);
+        __builtin_amdgcn_sched_barrier(0);                            // (rows one after the other: interleaved, their temporaries cost registers the payloads need)
     }
+    uint32_t v[ITEMS];
     __syncthreads();
     // ---- per digit: the waves' counts become running sums, the tile's total is published, the digits' places in the tile
     // and -- by looking back over the earlier tiles -- in the output follow
-    uint32_t total = 0;
+    uint32_t total = 0, digitBase = 0;
     if (tid < RADIX) {
         for (int w = 0; w < WAVES; ++w) { const uint32_t c = sCnt[w][tid]; sCnt[w][tid] = total; total += c; }
         __hip_atomic_store(&status[(size_t)tile * RADIX + tid], (tile == 0 ? ST_INCL : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t incl = total;                                        // running sum over the 256 digits: inside the wave ...
         for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
         if (lane == 63) sScan[wv] = incl;
-        sBase[tid] = incl - total;
+        digitBase = incl - total;
     }
     __syncthreads();
     if (tid < RADIX) {
-        uint32_t before = 0;                                          // ... and over the four waves that hold the digits
-        for (int w = 0; w < wv; ++w) before += sScan[w];
-        const uint32_t digitBase = sBase[tid] + before;
-        unsigned long long prev = 0;                                  // pairs with this digit in all earlier tiles
-        for (int64_t t = (int64_t)tile - 1; t >= 0; --t) {
-            unsigned long long s;
-            do { s = __hip_atomic_load(&status[(size_t)t * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((s & ST_MASK) == 0ull);
-            prev += s & ~ST_MASK;
-            if ((s & ST_MASK) == ST_INCL) break;
+        for (int w = 0; w < wv; ++w) digitBase += sScan[w];           // ... and over the four waves that hold the digits
+        sBase[tid] = digitBase;
+    }
+    // The tile's own counts are out (ST_AGG); where its digits go in the output -- the pairs with the digit in all earlier
+    // tiles, found by looking back over them -- is only needed when the keys leave.  So the tile first orders its keys in LDS
+    // and asks for its payloads, and looks back then: the tiles before it have had that time to publish, and the payloads are
+    // on their way while it waits.  (Rounds 2-3 looked back first.)  What the walk is like, from tools/pass_probe.hip: the
+    // tiles before are mostly as far as this one -- counts out, sums not -- so it is 15 tiles long on average (69 at most) and
+    // hardly ever polls an empty word; it still takes a quarter of the pass (38 ms for five passes over 1.15e9 pairs, 27 with
+    // the walk cut out).  Neither more loads in flight (4 / 8 / 16 tiles asked for at once: 38.0 / 39.1 / 84 ms; four lanes
+    // per digit: 52 ms) nor fewer bytes (16-bit counts, four digits to a word, read by one wavefront, the 64-bit sums fetched
+    // where the walk ends: 61 ms -- the extra round trip at the end delays every tile behind) did better than this.
+    auto look_back = [&]() {
+        if (tid < RADIX) {
+            unsigned long long prev = 0;
+            if constexpr ((MODE & MODE_NOLOOK) == 0)
+                for (int64_t t = (int64_t)tile - 1; t >= 0; --t) {
+                    unsigned long long sv;
+                    do { sv = __hip_atomic_load(&status[(size_t)t * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((sv & ST_MASK) == 0ull);
+                    prev += sv & ~ST_MASK;
+                    if ((sv & ST_MASK) == ST_INCL) break;
+                }
+            if (tile != 0) __hip_atomic_store(&status[(size_t)tile * RADIX + tid], ST_INCL | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sOff[tid] = start[tid] + (uint32_t)prev - digitBase;
         }
-        if (tile != 0) __hip_atomic_store(&status[(size_t)tile * RADIX + tid], ST_INCL | (prev + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sOff[tid] = start[tid] + (uint32_t)prev - digitBase;
-    }
-    __syncthreads();                                                  // (sBase is read by the four waves' neighbours above)
-    if (tid < RADIX) {
-        uint32_t before = 0;
-        for (int w = 0; w < wv; ++w) before += sScan[w];
-        sBase[tid] += before;
-    }
+    };
+    if constexpr (!LATE) look_back();
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) { const uint32_t d = digit_of<Key>(k[i], shift); rank[i] += sBase[d] + sCnt[wv][d]; }
     __syncthreads();                                                  // the counters are dead: their area takes the keys
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) if ((okMask >> i) & 1u) sKey[rank[i]] = k[i];
+    if constexpr (PAIRS && LATE) {                                    // (the keys' registers are free now)
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) v[i] = ((okMask >> i) & 1u) ? vt[base + (uint32_t)i * 64u] : 0u;
+    }
+    if constexpr (LATE) look_back();
     __syncthreads();
-    const uint32_t left = (uint64_t)tile * TILE < (uint64_t)n ? (uint32_t)((uint64_t)n - (uint64_t)tile * TILE) : 0u;
-    const uint32_t count = left < (uint32_t)TILE ? left : (uint32_t)TILE;   // pairs of this tile
     unsigned long long digits = 0;                                    // digit of the pair this thread writes in round j, 8 bits each
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {                                 // neighbouring threads write neighbouring pairs of a run
@@ -187,12 +192,12 @@ __global__ __launch_bounds__(THREADS, 8) void pass_kernel(const Key *__restrict_
         }
     }
     if constexpr (!PAIRS) return;
-    (void)nTiles;
     // the payloads follow the same way (loaded only now: the keys' registers are free, and the other workgroup of the CU
     // covers the wait)
-    uint32_t v[ITEMS];
+    if constexpr (!LATE) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) v[i] = ((okMask >> i) & 1u) ? vin[base + (uint64_t)i * 64] : 0u;
+        for (int i = 0; i < ITEMS; ++i) v[i] = ((okMask >> i) & 1u) ? vt[base + (uint32_t)i * 64u] : 0u;
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) if ((okMask >> i) & 1u) sVal[rank[i]] = v[i];
@@ -235,10 +240,12 @@ inline hipError_t sort_pairs(Key *kA, uint32_t *vA, Key *kB, uint32_t *vB, uint3
     for (int p = 0; p < nPasses; ++p) {
         if ((e = hipMemsetAsync(status, 0, (size_t)nTiles * RADIX * 8, stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(counter, 0, 32, stream)) != hipSuccess) return e;
-        if (vA && variant == 1) pass_kernel<Key, true, 8><<<nTiles, THREADS, 0, stream>>>(ki, vi, ko, vo, n, firstBit + 8 * p, hist + p * RADIX, status, counter, nTiles);
-        else if (vA && variant == 2) pass_kernel<Key, true, 32><<<nTiles, THREADS, 0, stream>>>(ki, vi, ko, vo, n, firstBit + 8 * p, hist + p * RADIX, status, counter, nTiles);
-        else if (vA) pass_kernel<Key, true, 0><<<nTiles, THREADS, 0, stream>>>(ki, vi, ko, vo, n, firstBit + 8 * p, hist + p * RADIX, status, counter, nTiles);
-        else pass_kernel<Key, false, 0><<<nTiles, THREADS, 0, stream>>>(ki, nullptr, ko, nullptr, n, firstBit + 8 * p, hist + p * RADIX, status, counter, nTiles);
+#define KASA_PASS(PAIRS_, MODE_) pass_kernel<Key, PAIRS_, MODE_><<<nTiles, THREADS, 0, stream>>>(ki, vi, ko, vo, n, firstBit + 8 * p, hist + p * RADIX, status, counter, nTiles)
+        if (!vA) KASA_PASS(false, 0);
+        else if (variant == MODE_FIRST) KASA_PASS(true, MODE_FIRST);
+        else if (variant == MODE_NOLOOK) KASA_PASS(true, MODE_NOLOOK);
+        else KASA_PASS(true, 0);
+#undef KASA_PASS
         Key *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }

@@ -24,8 +24,16 @@
 // sorting of a right-hand range nor the final insertion of its elements moves anything across the cut; so the ranges
 // are finished from the left and the rest is dropped once `need` positions are covered.  *covered (may be NULL) receives
 // how many leading positions are final (>= min(need, n)).
-template <class Ids, class Less>
-__host__ __device__ inline bool stdsort_order(Ids a, int n, Less less, int need = 0x7fffffff, int *covered = nullptr)
+// The ranges still to be partitioned wait on a stack; where it lives is the caller's choice (the device keeps it in LDS).
+struct StdsortLocalStack {
+    static constexpr int CAP = 34;
+    int32_t f[CAP], l[CAP], d[CAP];
+    __host__ __device__ inline void put(int at, int first, int last, int depth) { f[at] = first; l[at] = last; d[at] = depth; }
+    __host__ __device__ inline void get(int at, int &first, int &last, int &depth) const { first = f[at]; last = l[at]; depth = d[at]; }
+};
+
+template <class Ids, class Less, class Stack = StdsortLocalStack>
+__host__ __device__ inline bool stdsort_order(Ids a, int n, Less less, int need = 0x7fffffff, int *covered = nullptr, Stack st = Stack())
 {
     if (covered) *covered = n;
     if (n <= 1) return true;
@@ -33,13 +41,13 @@ __host__ __device__ inline bool stdsort_order(Ids a, int n, Less less, int need 
     int lg = 0;
     while ((n >> (lg + 1)) != 0) ++lg;
     // ranges still to be partitioned (the recursion of __introsort_loop on the right-hand parts)
-    int32_t stFirst[34], stLast[34], stDepth[34];
     int top = 0;
-    stFirst[0] = 0; stLast[0] = n; stDepth[0] = 2 * lg;
+    st.put(0, 0, n, 2 * lg);
     ++top;
     while (top > 0) {
         --top;
-        int first = stFirst[top], last = stLast[top], depth = stDepth[top];
+        int first, last, depth;
+        st.get(top, first, last, depth);
         while (last - first > 16) {
             if (depth == 0) return false;                              // libstdc++ heap-sorts this range
             --depth;
@@ -62,8 +70,8 @@ __host__ __device__ inline bool stdsort_order(Ids a, int n, Less less, int need 
                 swap_at(lo, hi);
                 ++lo;
             }
-            if (top >= 34) return false;
-            stFirst[top] = lo; stLast[top] = last; stDepth[top] = depth;
+            if (top >= Stack::CAP) return false;
+            st.put(top, lo, last, depth);
             ++top;
             last = lo;
         }

@@ -414,7 +414,7 @@ def test_repeated_reads_fill_a_sort_bucket(K):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, 7, 3)
     outs = []
-    for flags in (0, 64, 128, 512):
+    for flags in (0, 64, 128, 512, 524288, 2097152, 2097152 | 524288, 2097152 | 128):   # (524288: look-back first; 2097152: five passes, 20-bit buckets)
         ctx.debug_flags(flags)
         ctx.upload(big.bases, big.offsets); ctx.encode(); ctx.sort_and_range()
         km, rd = ctx.queries()
@@ -429,7 +429,7 @@ def test_repeated_reads_fill_a_sort_bucket(K):
 @pytest.mark.parametrize("tail", [200, 7, 1500])
 @pytest.mark.parametrize("members", [500, 129, 1024])
 def test_last_sort_bucket_straddles_the_last_tile(tail, members):
-    """Round-2 advisor finding: the bucket pass of the query sort (bucket_rank32_kernel) scans a bucket left and right of
+    """Round-2 advisor finding: the bucket pass of the query sort (bucket_rank_kernel; bucket_rank32_kernel with flag 2097152) scans a bucket left and right of
     every member inside a staged window; a bucket that begins more than the halo before the LAST tile and runs to the end of
     the batch must still be recognised as leaving the window.  The highest 8-letter prefix is repeated `members` times, the
     batch ends `tail` queries into its last 2048-query tile."""
@@ -446,7 +446,7 @@ def test_last_sort_bucket_straddles_the_last_tile(tail, members):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
     qs, rs_ = oracle.sort_queries(q, rd)
-    for flags in (0, 64, 512):
+    for flags in (0, 64, 512, 524288, 2097152, 2097152 | 512):
         ctx.debug_flags(flags)
         ctx.set_queries(q, rd, 50)
         ctx.sort_and_range()
@@ -460,7 +460,8 @@ def test_last_sort_bucket_straddles_the_last_tile(tail, members):
 def test_query_sort_of_any_size(n, K):
     """The hand-written radix passes (kasa_radix.h: tiles of 8192 / 4096 pairs, look-back over the tiles before) followed
     by the bucket pass, on batches that end anywhere in a tile: equal to a stable sort, payload included.  Half of the keys
-    share their top 40 bits with another key; a fifth are equal."""
+    share their top 40 bits with another key; a fifth are equal.  (Flags: 512 = the library's passes, 524288 = look-back first,
+    2097152 = five passes and 20-bit buckets.)"""
     _gpu_or_fail()
     rng = np.random.default_rng(1234 + n)
     ix, _ = synthetic_world(71 + K, 4, 3000, 10, K=K)
@@ -479,7 +480,7 @@ def test_query_sort_of_any_size(n, K):
     qs, rs_ = oracle.sort_queries(q, rd)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, K, 7, 3)
-    for flags in (0, 512):
+    for flags in (0, 512, 524288, 2097152, 2097152 | 524288):
         ctx.debug_flags(flags)
         ctx.set_queries(q, rd, 30)
         ctx.sort_and_range()
