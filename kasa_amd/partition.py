@@ -109,11 +109,17 @@ class Worker:
 class LocalExchange:
     """All partitions in this process (one GPU): the reference implementation of the exchange, used by the tests."""
 
-    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0, device_resident: bool = False):
+    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0, device_resident: bool = False, K: int = None):
+        """parts: formats.Index objects, or capi.DeviceIndex objects that are on the device already (then K = letters per
+        index k-mer must be given).  This is also how ONE device holds an index of more than 2^32 records (positions in an
+        index are 32-bit, kasa_index_create refuses more): as several range partitions, every one an index of its own."""
         self.cuts = cuts
         self.device_resident = device_resident      # slices and records never leave HBM (kasa_batch_*_device)
-        self.K = parts[0].K
-        self.dix = [capi.DeviceIndex(p, device) for p in parts]
+        given = len(parts) > 0 and isinstance(parts[0], capi.DeviceIndex)
+        self.K = K if given else parts[0].K
+        if self.K is None:
+            raise ValueError("LocalExchange over device indices: K (12 or 25) must be given")
+        self.dix = list(parts) if given else [capi.DeviceIndex(p, device) for p in parts]
         self.workers = [Worker(d, k_high, k_low, frames) for d in self.dix]
         self.owner = capi.Context(self.dix[0], k_high, k_low, frames)   # the owner needs an index only for its key width
 

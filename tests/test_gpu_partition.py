@@ -303,3 +303,81 @@ def test_bench_partitioned(gpus, share):
     x = out["exchange_bytes_per_step_this_rank"]
     if gpus > 1:
         assert x["queries_sent"] > 0 and x["records_received"] > 0
+
+
+def test_index_beyond_2_32_records_in_device_partitions():
+    """Positions in an index are 32-bit (kasa_index_create refuses more than 2^32 - 1 records): ONE device holds a larger index
+    as several range partitions, every one an index of its own, behind partition.LocalExchange (device-resident slices and
+    records).  Here: 4.5e9 records (54 GB as a file) -- the records of 40 genomes plus random filler, synthesised on the
+    device per quarter of the prefix range -- as four partitions and as two: per-read scores and profile must not depend on
+    the cut (bit for bit), every read must have found its genome's records (hits at k = 12 can only come from them), and
+    the batch must have met filler (hits at k = 7 from taxa the read does not come from)."""
+    assert capi.device_count() > 0
+    import torch
+    from kasa_amd import synth
+    free, _ = capi.device_memory(0)
+    if free < 200e9:
+        pytest.skip("needs 200 GB of free HBM")
+    dev = torch.device("cuda", 0)
+    n_taxa, per_quarter = 40, 1_120_000_000
+    g = synth.genomes(n_taxa, 60_000, seed=5)
+    ix = synth.index_from_genomes(g, device=0)
+    parts4, cuts4 = partition.split_index(ix, 4)
+    parts2, cuts2 = partition.split_index(ix, 2)
+    assert int(cuts2[1]) == int(cuts4[2])                          # the halves are pairs of quarters
+    quarters = []
+    for q in range(4):
+        lo = int(cuts4[q]) << 30
+        hi = (int(cuts4[q + 1]) if q < 3 else (1 << 30)) << 30
+        mine = parts4[q]
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(777 + q)
+        km = torch.empty(mine.n + per_quarter, dtype=torch.int64, device=dev)
+        td = torch.empty(mine.n + per_quarter, dtype=torch.int32, device=dev)
+        km[:mine.n] = torch.from_numpy(mine.kmer.astype(np.int64)).to(dev)
+        td[:mine.n] = torch.from_numpy(mine.taxid.astype(np.int32)).to(dev)
+        for a in range(mine.n, mine.n + per_quarter, 1 << 28):
+            b = min(mine.n + per_quarter, a + (1 << 28))
+            km[a:b] = torch.randint(lo, hi, (b - a,), dtype=torch.int64, device=dev, generator=gen)
+            td[a:b] = torch.randint(100, 100 + n_taxa, (b - a,), dtype=torch.int32, device=dev, generator=gen)
+        td, order = torch.sort(td, stable=True)                    # (kmer, taxid) order
+        km = km[order]
+        km, order = torch.sort(km, stable=True)
+        td = td[order]
+        del order
+        keep = torch.ones(km.shape[0], dtype=torch.bool, device=dev)
+        keep[1:] = (km[1:] != km[:-1]) | (td[1:] != td[:-1])
+        km, td = km[keep], td[keep]
+        del keep
+        rec = torch.empty((int(km.shape[0]), 12), dtype=torch.uint8, device=dev)   # the index file's records: {u64 kmer, u32 taxid}
+        rec[:, :8] = km.view(torch.uint8).view(-1, 8)
+        rec[:, 8:] = td.view(torch.uint8).view(-1, 4)
+        del km, td
+        quarters.append(rec)
+    torch.cuda.synchronize()
+    total = sum(int(r.shape[0]) for r in quarters)
+    assert total > (1 << 32)
+    batch = synth.reads_from_genomes(g, 20_000, 150, seed=9)
+
+    def run(recs, cuts):
+        dix = [capi.DeviceIndex.from_device_records(r.data_ptr(), int(r.shape[0]), 12, ix.content.taxids, 0) for r in recs]
+        ex = partition.LocalExchange(dix, cuts, 12, 7, 3, device_resident=True, K=12)
+        ctx = ex.run_batch(batch)
+        out = (ctx.scores(), ctx.profile_limbs().copy(), ctx.profile())
+        ex.close()
+        return out
+
+    (o4, t4, s4), limbs4, (ca, cu, _) = run(quarters, cuts4)
+    halves = [torch.cat(quarters[0:2]), torch.cat(quarters[2:4])]
+    del quarters
+    torch.cuda.empty_cache()
+    (o2, t2, s2), limbs2, _ = run(halves, cuts2)
+    del halves
+    torch.cuda.empty_cache()
+    assert np.array_equal(o4, o2) and np.array_equal(t4, t2) and np.array_equal(s4.view(np.uint32), s2.view(np.uint32))
+    assert np.array_equal(limbs4, limbs2)
+    n_kmers = 3 * 20_000 * (150 // 3 - 12 + 1) - 2 * 20_000       # (frames 1 and 2 hold one window less: 39 + 38 + 38 per read)
+    assert 0.60 * n_kmers < float(ca[0].sum()) <= n_kmers           # k = 12: the genomes' own records (0.99^36 = 70 % of the windows carry no substitution)
+    assert float(ca[-1].sum()) > float(ca[0].sum())                 # k = 7: filler joins in
+    per_read = np.diff(o4.astype(np.int64))
+    assert per_read.min() >= 1 and per_read.mean() > 10            # rows hold the genome and filler taxa
