@@ -1545,6 +1545,77 @@ __global__ __launch_bounds__(256) void bucket_rank32_kernel(const uint64_t *__re
     }
 }
 
+// 64-bit keys with up to 40 bits below the bucket's (SORT_TOP = 32: 28): the same with one 64-bit word per query -- those bits
+// above its position in the window -- so that members still compare like (key, position) with ONE compare, two members
+// per step.
+__global__ __launch_bounds__(256) void bucket_rank64_kernel(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
+                                                            uint32_t *__restrict__ vout, uint32_t n, int shift, uint32_t *__restrict__ big,
+                                                            uint32_t *__restrict__ bigHead)
+{
+    constexpr uint32_t WIN = RANK_TILE + 2 * RANK_HALO, POS_BITS = 12;
+    static_assert(WIN % 256 == 0 && WIN <= (1u << POS_BITS), "window positions fit the low bits of the LDS word; whole wavefronts stage it");
+    __shared__ __attribute__((aligned(16))) uint64_t sW[WIN + 2];
+    __shared__ uint64_t sHead[WIN / 64];
+    const uint32_t base = blockIdx.x * RANK_TILE;
+    const uint32_t lo = base >= RANK_HALO ? base - RANK_HALO : 0u;
+    const uint32_t hi = (uint64_t)base + RANK_TILE + RANK_HALO < (uint64_t)n ? base + RANK_TILE + RANK_HALO : n;
+    const uint32_t win = hi - lo;
+    const uint64_t lowMask = (1ull << shift) - 1ull;                      // (shift + POS_BITS <= 52: checked by the caller)
+    for (uint32_t x = threadIdx.x; x < WIN; x += 256u) {
+        bool head = false;
+        if (x < win) {
+            const uint32_t q = lo + x;
+            const uint64_t k = kin[q];
+            head = q == 0u || (kin[q - 1u] >> shift) != (k >> shift);
+            sW[x] = ((k & lowMask) << POS_BITS) | x;
+        }
+        const uint64_t m = __ballot(head);
+        if ((threadIdx.x & 63u) == 0u) sHead[x >> 6] = m;
+    }
+    __syncthreads();
+    const uint32_t lastWord = (win - 1u) >> 6;
+    for (uint32_t e = threadIdx.x; e < RANK_TILE; e += 256u) {
+        const uint32_t p = base + e;
+        if (p >= n) break;
+        const uint32_t i0 = p - lo, bit = i0 & 63u;
+        const uint64_t my = sW[i0];
+        bool edge = false;
+        uint32_t m = i0 >> 6;
+        uint64_t w = sHead[m] & (~0ull >> (63u - bit));                   // the bucket's first member: the last flag at or before me
+        while (w == 0ull && m > 0u) w = sHead[--m];
+        uint32_t hs = 0;
+        if (w == 0ull) edge = true; else hs = m * 64u + 63u - (uint32_t)__clzll((long long)w);
+        m = i0 >> 6;
+        w = sHead[m] & ((~0ull << bit) << 1);                             // its end: the first flag after me
+        while (w == 0ull && m < lastWord) w = sHead[++m];
+        uint32_t he = win;
+        if (w == 0ull) edge = edge || (hi < n); else he = m * 64u + (uint32_t)__ffsll((unsigned long long)w) - 1u;
+        uint32_t L = i0 - hs, members = he - hs, rank = 0;
+        if (!edge && members <= SORT_BUCKET_LIMIT) {
+            uint32_t j = hs;
+            if (j & 1u) { rank += sW[j] < my ? 1u : 0u; ++j; }            // (pairs of words are read from even positions: 16-byte LDS reads)
+            for (; j + 1u < he; j += 2u) {
+                const ulonglong2 ab = *reinterpret_cast<const ulonglong2 *>(&sW[j]);
+                rank += (ab.x < my ? 1u : 0u) + (ab.y < my ? 1u : 0u);
+            }
+            if (j < he) rank += sW[j] < my ? 1u : 0u;
+        }
+        const uint64_t k = kin[p];
+        if (edge) {                                                       // the bucket leaves the window: the whole scan again, from global memory
+            const uint64_t top = k >> shift;
+            uint32_t R = 0;
+            rank = 0; L = 0;
+            for (uint32_t q = p; q > 0 && L < SORT_BUCKET_LIMIT;) { --q; const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++L; rank += (o <= k) ? 1u : 0u; }
+            for (uint32_t q = p + 1; q < n && R < SORT_BUCKET_LIMIT; ++q) { const uint64_t o = kin[q]; if ((o >> shift) != top) break; ++R; rank += (o < k) ? 1u : 0u; }
+            members = L + R + 1u;
+        }
+        if (members > SORT_BUCKET_LIMIT) {
+            kout[p] = k; vout[p] = vin[p];
+            if (L == 0u) { const uint32_t at = atomicAdd(big, 1u); if (at < SORT_BIG_CAP) bigHead[at] = p; }
+        } else { const uint32_t at = p - L + rank; kout[at] = k; vout[at] = vin[p]; }
+    }
+}
+
 // [begin, end) of the listed buckets: the end by bisection over the top bits (the pairs are ordered by them)
 template <class Key>
 __global__ void bucket_bounds_kernel(const Key *__restrict__ kin, uint32_t n, int shift, const uint32_t *__restrict__ head, uint32_t nHead,
@@ -1603,7 +1674,11 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
             }
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
             static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP_OLD + 12 <= 32, "bucket_rank32_kernel: low key bits and window position share a word");
-            if (sizeof(Key) == 8 && top != SORT_TOP_OLD)
+            static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP + 12 <= 52, "bucket_rank64_kernel: low key bits and window position share a word");
+            if (sizeof(Key) == 8 && top != SORT_TOP_OLD && !(c->debugFlags & 4194304))   // (test tap 4194304: the kernel for any key width)
+                bucket_rank64_kernel<<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<uint64_t>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<uint64_t>(),
+                                                                                      c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
+            else if (sizeof(Key) == 8 && top != SORT_TOP_OLD)
                 bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
                                                                                           c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
             else if constexpr (sizeof(Key) == 8)

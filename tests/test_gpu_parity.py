@@ -414,7 +414,7 @@ def test_repeated_reads_fill_a_sort_bucket(K):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, 7, 3)
     outs = []
-    for flags in (0, 64, 128, 512, 524288, 2097152, 2097152 | 524288, 2097152 | 128):   # (524288: look-back first; 2097152: five passes, 20-bit buckets)
+    for flags in (0, 64, 128, 512, 524288, 2097152, 2097152 | 524288, 2097152 | 128, 4194304):   # (524288: look-back first; 2097152: five passes, 20-bit buckets)
         ctx.debug_flags(flags)
         ctx.upload(big.bases, big.offsets); ctx.encode(); ctx.sort_and_range()
         km, rd = ctx.queries()
@@ -446,7 +446,7 @@ def test_last_sort_bucket_straddles_the_last_tile(tail, members):
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, 12, 7, 3)
     qs, rs_ = oracle.sort_queries(q, rd)
-    for flags in (0, 64, 512, 524288, 2097152, 2097152 | 512):
+    for flags in (0, 64, 512, 524288, 2097152, 2097152 | 512, 4194304):   # (4194304: the bucket pass for any key width)
         ctx.debug_flags(flags)
         ctx.set_queries(q, rd, 50)
         ctx.sort_and_range()
@@ -480,7 +480,7 @@ def test_query_sort_of_any_size(n, K):
     qs, rs_ = oracle.sort_queries(q, rd)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, K, 7, 3)
-    for flags in (0, 512, 524288, 2097152, 2097152 | 524288):
+    for flags in (0, 512, 524288, 2097152, 2097152 | 524288, 4194304):
         ctx.debug_flags(flags)
         ctx.set_queries(q, rd, 30)
         ctx.sort_and_range()
