@@ -373,16 +373,20 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * a stable sort by read id, as for long or paired reads), bit 4 = the profile keys are sorted and reduced even
  * when the LDS counting table would fit, bit 5 = score_other_kernel (one lane per query) instead of
  * score_other_flat_kernel (work items = segments) for 32-byte records, bit 6 = the library's radix sort over all
- * key bits instead of 5 passes + bucket_rank_kernel, bit 7 = long sort buckets are not sorted one by one but by the
+ * key bits instead of 4 (5) passes + bucket_rank_kernel, bit 7 = long sort buckets are not sorted one by one but by the
  * library over all bits (the path for inputs with too many or too long ones), bit 8 = kasa_batch_rank leaves reads with
  * tied hits to the host instead of ranking them with std::sort's order on the device, bit 9 = the library's radix passes
- * over the top 40 key bits instead of the hand-written ones (kasa_amd/csrc/kasa_radix.h), bit 10 = score_main_kernel with the
+ * over the top 32 (40) key bits instead of the hand-written ones (kasa_amd/csrc/kasa_radix.h), bit 10 = score_main_kernel with the
  * next line of records prefetched into registers (fewer resident wavefronts), bit 11 = no followers (every query walks the
  * index itself), bit 12 = 64-byte records without the index span in LDS, bit 13 = the general score kernel in its
  * lane-owns-its-cells form (what indices beyond 16 384 taxa take) instead of the row in LDS, bit 14 = the general kernel's
  * first pass hands every read to its second pass, bits 15 / 16 = timing taps of group_kernel (no profile keys at all; keys
  * counted but not stored: the profile is wrong), bit 17 = never the cooperative form of group_kernel (long taxon lists lane
- * by lane; level sizes beyond 255 wrap), bit 18 = the cooperative form from the first batch on; lastSlowReads (may be
+ * by lane; level sizes beyond 255 wrap), bit 18 = the cooperative form from the first batch on, bit 19 = the radix passes of the
+ * query sort look back over the earlier tiles before they order their keys in LDS (the form of rounds 2-3), bit 20 =
+ * rank_exact_kernel in its largest form for every read (no classes by hit count), bit 21 = the other split of the query
+ * sort (64-bit keys: five passes over 40 bits + buckets of 20 bits' worth; 128-bit keys: four passes over 32 bits + buckets
+ * of 93), bit 22 = the bucket pass of 64-bit keys by the kernel for any key width; lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

@@ -1654,10 +1654,12 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
         if (c->debugFlags & 64) {                                       // test tap: the library sort over all key bits
             if ((rc = radix(c->qKmerA, c->qReadA, c->qKmerB, c->qReadB, 0u, BITS))) return rc;
         } else {
-            // radix passes over the top 32 bits only (4 of the 8 resp. 16 passes), then every query finds its place
+            // radix passes over the top 32 (40) bits only (4 of 8 resp. 5 of 16 passes), then every query finds its place
             // inside its bucket (bucket_rank_kernel)
-            // (test tap 2097152: five passes over the top 40 bits and buckets of 20 (85) bits' worth, the form of rounds 2-3)
-            const unsigned top = (c->debugFlags & 2097152) ? SORT_TOP_OLD : SORT_TOP;
+            // 64-bit keys: four passes and buckets of 28 bits' worth; 128-bit keys: five passes and buckets of 85 bits' worth, the
+            // form of rounds 2-3 (measured at C3: a pass costs 12.6 ms, the longer buckets with 128-bit compares 14.4).  Test
+            // tap 2097152: the other choice.
+            const unsigned top = ((sizeof(Key) == 8) != ((c->debugFlags & 2097152) != 0)) ? SORT_TOP : SORT_TOP_OLD;
             uint32_t *big = c->misc.as<uint32_t>() + 43, *longest = c->misc.as<uint32_t>() + 44;
             if ((rc = c->sortBig.reserve((size_t)SORT_BIG_CAP * 12 + 64))) return rc;
             uint32_t *bigHead = c->sortBig.as<uint32_t>(), *segBegin = bigHead + SORT_BIG_CAP, *segEnd = segBegin + SORT_BIG_CAP;

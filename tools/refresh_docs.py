@@ -57,8 +57,10 @@ measured = (
     f"PCIe-inclusive (`e2e`, never `value`): page-locked reads up, device, ranking on the device (`-b 3`), ranked hits + profile down = "
     f"{e['pcie_inclusive_s_per_batch']:.2f} s per batch = **{e['pcie_inclusive_reads_per_s'] / 1e6:.1f} M reads/s** ({e['upload_and_device_s']:.2f} s upload + device, "
     f"{e['rank_and_fetch_s']:.2f} s ranking + {e['downloaded_bytes'] / 1e9:.2f} GB of hits; {e['reads_ranked_by_host']} reads go back to the host; all 1400 synthetic taxa have the "
-    "same k-mer frequency, so a third of the reads have tied third-best hits and take the `std::sort`-order kernel). The whole CSR into pageable memory: "
-    f"{e['csr_download_s_per_batch']:.2f} s.\n\n"
+    "same k-mer frequency, so a third of the reads have tied third-best hits and take the `std::sort`-order kernel). "
+    + (f"A host that keeps two contexts busy from two threads -- the copies of one batch beside the kernels of another (`pcie_pipelined`, {e['pcie_pipelined_batches']} batches): "
+       f"{e['pcie_pipelined_s_per_batch']:.3f} s per batch = **{e['pcie_pipelined_reads_per_s'] / 1e6:.1f} M reads/s**, i.e. the device's own time for step + ranking. " if "pcie_pipelined_reads_per_s" in e else "")
+    + f"The whole CSR into pageable memory: {e['csr_download_s_per_batch']:.2f} s.\n\n"
     f"File to file (`kasa_identify identify --jsonl`, 10 M reads = {e['input_bytes'] / 1e9:.2f} GB of FASTQ in, {e['output_bytes'] / 1e9:.2f} GB of JSON lines out, both in `/dev/shm`, "
     f"host threads = the box's cgroup quota; the text is written on the device and leaves through one writer thread): **{e['file_to_file_reads_per_s'] / 1e6:.2f} M reads/s** with `-m {e['memory_gib']}` "
     f"({e['batches']} batches in a pipeline: parse {e['parse_s']:.2f} s, device incl. ranking, text and its download {e['device_s']:.2f} s of which {e['text_s']:.2f} s waiting for the writer; "
