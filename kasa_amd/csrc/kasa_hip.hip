@@ -2916,7 +2916,11 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     // (the dense form of narrow records keeps no profile -- group_stage's -- and no list of touched taxa: the LDS they would
     // take is what limits the resident wavefronts of this latency-bound kernel)
     constexpr bool LEAN = DENSE && GpOf<RW>::v;
-    constexpr int AGGN = LEAN ? 1 : AGG, TLN = LEAN ? 1 : TLIST;
+    // (64-byte records, first pass: 19 levels make more distinct (level, |T|, taxon) counts per read than 256 -- at C3 4749 of the
+    // 5663 reads of this kernel overflowed the table and took the second pass, 12 ms at two wavefronts per CU)
+    constexpr int AGGN = LEAN ? 1 : (RW == 16 && PC == PCAP_SMALL) ? 4 * AGG : AGG, TLN = LEAN ? 1 : TLIST;
+    constexpr int AGGB = AGGN == 4 * AGG ? 10 : 8;
+    static_assert(AGG == 256, "aggAdd's hash takes log2(AGGN) bits");
     __shared__ unsigned long long aKey[AGGN];
     __shared__ uint32_t aCnt[AGGN];
     __shared__ uint32_t pF[PC], pRef[PC];
@@ -2961,8 +2965,8 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         // per distinct key at the end of the read (device-scope atomics are the scarce resource); any lane may call it
         auto aggAdd = [&](const int lv, const uint32_t n, const uint32_t tx, const uint32_t c) {
             const unsigned long long key = ((unsigned long long)lv << 56) | ((unsigned long long)n << 32) | tx;
-            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 56) & (AGG - 1);
-            for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (AGG - 1)) {
+            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - AGGB)) & (uint32_t)(AGGN - 1);
+            for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (uint32_t)(AGGN - 1)) {
                 const unsigned long long seen = atomicCAS(&aKey[h], AGG_EMPTY, key);
                 if (seen == AGG_EMPTY || seen == key) { atomicAdd(&aCnt[h], c); return; }
             }
