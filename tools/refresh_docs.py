@@ -90,7 +90,8 @@ r = open(p).read()
 r = block(r, "<!-- measured:begin -->", "<!-- measured:end -->",
           f"One MI355X, 10 M × 150 bp reads against a 4.2e8-record (5 GB) index, profile + per-read scores: **{d['value'] / 1e6:.0f} M reads/s**\n"
           f"({d['ms_per_step']:.0f} ms per batch; round 3: 47 M, round 2: 40 M, round 1: 21 M), {e['pcie_inclusive_reads_per_s'] / 1e6:.0f} M reads/s with the PCIe legs inside the clock (reads up, ranking\n"
-          f"on the device, printable hits down), {e['file_to_file_reads_per_s'] / 1e6:.1f} M reads/s file to file through the C++ driver (FASTQ in, JSON lines out);\n"
+          f"on the device, printable hits down" + (f"; {e['pcie_pipelined_reads_per_s'] / 1e6:.0f} M with two contexts in flight" if "pcie_pipelined_reads_per_s" in e else "") + "), "
+          f"{e['file_to_file_reads_per_s'] / 1e6:.1f} M reads/s file to file through the C++ driver (FASTQ in, JSON lines out);\n"
           f"{sec['value'] / 1e6:.0f} M reads/s against a 128-bit index with `-k 25 7`"
           + (f", {ter['value'] / 1e6:.1f} M reads/s against a crowded index (clades sharing conserved genes: a third of the reads meet tens to hundreds of taxa per k-mer)" if ter and "value" in ter else "")
           + f". The CPU restatement of the reference does {cb['single_thread_value'] / 1e3:.0f} k reads/s on one\n"
