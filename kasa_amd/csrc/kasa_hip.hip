@@ -1945,6 +1945,7 @@ __device__ __forceinline__ int wave_incl_min(int v)
     { const int o = KASA_DPP_ID(v, 0x143, 0xc, TOP); v = o < v ? o : v; }
     return v;
 }
+__device__ __forceinline__ int wave_max_int(int v) { return ~__builtin_amdgcn_readlane(wave_incl_min(~v), 63); }   // (every lane gets it)
 template <class Meta, class F>
 __device__ __forceinline__ void coop_walk(const Meta *__restrict__ meta, uint32_t nIdx, uint32_t j, int d, int kLow, int lane, F f)
 {
@@ -5506,10 +5507,28 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
                 if (k > 0 && !(rel < lastRel || (rel == lastRel && t > lastTax))) continue;   // selected before
                 if (!have || rel > bRel || (rel == bRel && t < bTax)) { have = true; bRel = rel; bTax = t; bScore = sScore[wv][i]; }
             }
-            for (int off = 32; off; off >>= 1) {
-                const double oRel = __shfl_xor(bRel, off); const uint32_t oTax = (uint32_t)__shfl_xor((int)bTax, off);
-                const float oSc = __shfl_xor(bScore, off); const bool oHave = __shfl_xor((int)have, off) != 0;
-                if (oHave && (!have || oRel > bRel || (oRel == bRel && oTax < bTax))) { have = true; bRel = oRel; bTax = oTax; bScore = oSc; }
+            // The best of the lanes' candidates: three wavefront-wide reductions in the ALU (DPP) -- over the two halves of the
+            // relative score's bit pattern, made to order like the doubles, then over the taxon -- and three register reads from
+            // the winning lane.  (The butterfly of 64-bit shuffles through the LDS crossbar that stood here, six rounds of five
+            // dependent exchanges per selected hit, was most of this kernel's time.)
+            {
+                unsigned long long u = (unsigned long long)__double_as_longlong(bRel == 0.0 ? 0.0 : bRel);   // (-0.0 and 0.0 are one value)
+                u ^= (u >> 63) ? ~0ull : 0x8000000000000000ull;                // unsigned order = the doubles' order
+                const int hi = have ? (int)((uint32_t)(u >> 32) ^ 0x80000000u) : (int)0x80000000;
+                const int hiMax = wave_max_int(hi);
+                const bool c1 = have && hi == hiMax;
+                const int lo = c1 ? (int)((uint32_t)u ^ 0x80000000u) : (int)0x80000000;
+                const int loMax = wave_max_int(lo);
+                const bool c2 = c1 && lo == loMax;
+                const int txMin = __builtin_amdgcn_readlane(wave_incl_min(c2 ? (int)bTax : 0x7fffffff), 63);
+                const unsigned long long win = __ballot(c2 && (int)bTax == txMin);
+                if (win == 0ull) { flag = true; break; }                        // (cannot happen while k < cnt: left to the exact kernel)
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)win) - 1);   // one lane: a read's hits have distinct taxa
+                const unsigned long long rb = (unsigned long long)__double_as_longlong(bRel);
+                const uint32_t rLo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rb, src), rHi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rb >> 32), src);
+                bRel = __longlong_as_double((long long)(((unsigned long long)rHi << 32) | rLo));
+                bScore = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bScore), src));
+                bTax = (uint32_t)txMin; have = true;
             }
             // ties: other remaining hits with the same relative score (their order is only defined for stable sorts)
             uint32_t same = 0;
