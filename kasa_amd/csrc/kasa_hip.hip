@@ -5448,6 +5448,7 @@ extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint3
 // relative score is flagged and ranked by the host from its full row (so is one with more than RANK_ROWS hits or a
 // prefix beyond RANK_CAP).
 static constexpr int RANK_CAP = 64, RANK_ROWS = 256, RANK_SLAB = 256;
+static constexpr int RANK_FIRST = 12;   // leading positions rank_exact_kernel's first attempt makes final (a writer prints 3-6 hits as a rule; more: the whole sort)
 // rank_exact_kernel keeps a read's hits in LDS: reads with few hits take little of it, so they go to a launch of their own
 // that brings more wavefronts to a CU (classes by hit count: <= 32, <= 64, <= 128, more)
 __host__ __device__ inline int rank_exact_class(uint32_t cnt) { return cnt <= 32u ? 0 : cnt <= 64u ? 1 : cnt <= 128u ? 2 : 3; }
@@ -5698,11 +5699,11 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
         }
         if (inLds || m < 65536u) {
             const RankEntry *hs = hits + lo;
-            // only the hits a writer prints have to be in std::sort's order: the first RANK_CAP positions, as a rule.
+            // only the hits a writer prints have to be in std::sort's order: the first RANK_FIRST positions, as a rule (else the whole sort).
             // (Two instantiations, so that the LDS columns are reached with LDS instructions, not through flat pointers.)
             auto rankRead = [&](auto ids, auto less, auto stack) {
                 int covered = 0;
-                ok = stdsort_order(ids, (int)cnt, less, RANK_CAP, &covered, stack);
+                ok = stdsort_order(ids, (int)cnt, less, RANK_FIRST, &covered, stack);
                 for (int pass = 0; ok && pass < 2; ++pass) {
                     PrintWalk w;                                           // how many hits a writer prints
                     bool more = false;
