@@ -1575,6 +1575,19 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         std::cout << "OUT: Number of k-mers in input: " << totalKmers.load() << " of which " << ident / (double)totalKmers.load() * 100. << " % were identified." << std::endl;
         std::cout << "OUT: Time fastq: " << batcher.parseSeconds << " s (" << p.threads << " threads)\nOUT: Time compare: " << dev << " s (" << nDev << " device" << (nDev > 1 ? "s" : "")
                   << ")\nOUT: Time output: " << txt << " s\nOUT: Time file: " << std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count() << " s" << std::endl;   // Compare.hpp:3689-3690
+        // (ours) how busy the device was: the five stages' HIP-event time of device 0 against the file's wall time.  The
+        // reference's -m cuts batches for ITS memory budget; here it only decides how many reads meet the device at once.
+        double stagesMs = 0;
+        for (int st = 0; st < 6; ++st) { double ms = 0; uint64_t n = 0; if (!kasa_ctx_stage_ms(ctx[0], st, &ms, &n)) stagesMs += ms; }
+        const double fileS = std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count();
+        if (stagesMs > 0 && fileS > 0) {
+            const double util = stagesMs / 1000. / fileS * 100.;
+            std::cout << "OUT: Device: " << nBatches << " batch" << (nBatches == 1 ? "" : "es") << " of " << (nBatches ? nReads / nBatches : 0) << " reads on average; its identify stages ran "
+                      << stagesMs / 1000. << " s = " << util << " % of the file's time";
+            if (util < 50. && nBatches > 1 && nReads / nBatches < 2000000)
+                std::cout << " -- batches this small leave it waiting for the host: a larger -m (the results do not depend on it unless they are compared with kASA's byte for byte) keeps it busier";
+            std::cout << std::endl;
+        }
     }
 }
 
