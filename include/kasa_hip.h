@@ -366,6 +366,10 @@ int kasa_ctx_reserve(kasa_ctx *ctx, uint64_t nQueries, uint64_t nBases, int want
 /* Of the last batch: reads scored by the general kernel (score_kernel) instead of the lane-per-read one, and how many of
  * those needed its second pass (full pending window / direct profile adds).  Diagnostics for tests and bench.py. */
 int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPassReads);
+/* ... and how many of those kept more groups pending than the second pass's window holds (4096) and were ordered through a
+ * window in device memory (narrow records; 64-byte records return KASA_E_LIMIT there).  Ours: the reference's flush is a
+ * hash map per thread and has no such window (Compare.hpp:917-955). */
+int kasa_ctx_third_pass_reads(kasa_ctx *ctx, uint32_t *thirdPassReads);
 
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row
@@ -386,7 +390,8 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * query sort look back over the earlier tiles before they order their keys in LDS (the form of rounds 2-3), bit 20 =
  * rank_exact_kernel in its largest form for every read (no classes by hit count), bit 21 = the other split of the query
  * sort (64-bit keys: five passes over 40 bits + buckets of 20 bits' worth; 128-bit keys: four passes over 32 bits + buckets
- * of 93), bit 22 = the bucket pass of 64-bit keys by the kernel for any key width; lastSlowReads (may be
+ * of 93), bit 22 = the bucket pass of 64-bit keys by the kernel for any key width, bit 23 = the general kernel's second pass
+ * hands every read to its third (pending window in device memory; narrow records); lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

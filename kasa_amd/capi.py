@@ -24,7 +24,7 @@ EXPORTS = [
     "kasa_batch_records_fetch", "kasa_batch_records_import", "kasa_batch_scores_size", "kasa_batch_scores_fetch",
     "kasa_profile_reset", "kasa_profile_absorb", "kasa_profile_fetch", "kasa_profile_export_limbs", "kasa_profile_import_limbs", "kasa_profile_allreduce",
     "kasa_ctx_stage_ms", "kasa_ctx_stage_reset", "kasa_ctx_kernel_ms", "kasa_ctx_batch_stats", "kasa_batch_query_count", "kasa_batch_fetch_queries",
-    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
+    "kasa_batch_fetch_lookup", "kasa_ctx_device_bytes", "kasa_device_memory", "kasa_batch_bytes_per_query", "kasa_ctx_counters", "kasa_ctx_third_pass_reads", "kasa_ctx_synchronize", "kasa_batch_set_queries", "kasa_ctx_debug",
     "kasa_refbatch_budget", "kasa_refbatch_sequence_cost", "kasa_refbatch_read_overhead", "kasa_refbatch_cut",
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
@@ -567,6 +567,12 @@ class Context:
             _check(lib().kasa_ctx_kernel_ms(self.h, C.c_int(i), C.byref(ms), C.byref(n)))
             out[name] = (ms.value, int(n.value))
         return out
+
+    def third_pass_reads(self) -> int:
+        """Reads of the last batch whose pending window did not fit the second pass either (kasa_ctx_third_pass_reads)."""
+        n = C.c_uint32(0)
+        _check(lib().kasa_ctx_third_pass_reads(self.h, C.byref(n)))
+        return int(n.value)
 
     def batch_stats(self):
         st = np.zeros(8, dtype=np.uint64)

@@ -538,6 +538,8 @@ struct kasa_ctx {
     bool payloadIsSlot = false;                // what the encoder gave the sort as payload: slots (ranked reads) or read ids
     DevBuf flushOff, flushPos, flushOff2, flushPos2;   // general score kernel: flush positions of the listed reads' queries
     DevBuf ovList;                             // reads the first general pass hands to the second
+    DevBuf ovList2, gwin;                      // ... the second to the third (narrow records); the third pass's pending windows
+    uint32_t lastThirdPassReads = 0;
     uint32_t lastOverflowReads = 0;
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profSorted2;   // per-block dense score rows; reads left to the slow kernel
     uint64_t profLeftHint = 0;                  // per-level keys the last batch's table pass left over, when the list was too short for them
@@ -2833,6 +2835,7 @@ struct ScoreArgs {
     uint32_t *why;                               // fast kernel: fallback reasons (diagnostics)
     uint32_t *workCursor;                        // fast kernel: next read a wavefront takes
     int forceHandOn;                             // general kernel, first pass: every read goes to the second pass (test tap 16384)
+    uint32_t *gwin; uint32_t gwinCap;            // general kernel, third pass (GWIN): pending windows in device memory, per block 4 arrays of gwinCap words
 };
 
 static constexpr int AGG = 256;                                   // per-read profile aggregation table (LDS)
@@ -2906,7 +2909,10 @@ __global__ __launch_bounds__(256) void flush_positions_kernel(
 // the lanes' read-modify-writes never meet; LDS operations of a wavefront execute in order, so events do not overtake.
 static constexpr int DENSE_TAXA = 16384;      // 64 KB of LDS for the row at most
 static constexpr int DQ_SEGS = 1024;          // segments of one query kept in LDS
-template <int PC, int RW, bool DENSE = false>
+// GWIN (third pass, narrow records): the pending window lives in device memory instead of LDS -- as long as the read has
+// queries times levels, so it cannot overflow.  Every access is a round trip past the L1 (agent-scope atomics, a fence where
+// lanes read what other lanes wrote): slow, exact, and only for reads that keep more than PCAP groups pending.
+template <int PC, int RW, bool DENSE = false, bool GWIN = false>
 __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
@@ -2927,6 +2933,18 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     __shared__ uint32_t pF[PC], pRef[PC];
     __shared__ uint32_t pCnt[PC];
     __shared__ uint8_t pK[PC];
+    // the pending window: entry e = {flush position, slot of its query, hits, level}; in LDS, or (GWIN) in this block's piece of A.gwin
+    uint32_t *gw = GWIN ? A.gwin + (size_t)blockIdx.x * 4u * A.gwinCap : nullptr;
+    const int pcap = GWIN ? (int)A.gwinCap : PC;
+    auto wGet = [&](int field, int e) -> uint32_t {
+        if constexpr (GWIN) return __hip_atomic_load(gw + (size_t)field * A.gwinCap + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return field == 0 ? pF[e] : field == 1 ? pRef[e] : field == 2 ? pCnt[e] : (uint32_t)pK[e];
+    };
+    auto wPut = [&](int field, int e, uint32_t v) {
+        if constexpr (GWIN) __hip_atomic_store(gw + (size_t)field * A.gwinCap + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else { if (field == 0) pF[e] = v; else if (field == 1) pRef[e] = v; else if (field == 2) pCnt[e] = v; else pK[e] = (uint8_t)v; }
+    };
+    auto wSync = [&]() { if constexpr (GWIN) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent"); __syncthreads(); };   // lanes read what other lanes wrote
     __shared__ uint32_t sTouched;
     __shared__ uint32_t sList[TLN];
     const int lane = threadIdx.x;
@@ -3044,7 +3062,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                 if (A.addProfile) aggAdd(lv, n, tx, c);
             }
         };
-        auto apply = [&](int e) { applyVals((int)pK[e], pRef[e], pCnt[e]); };   // the pending entry at `e`
+        auto apply = [&](int e) { applyVals((int)wGet(3, e), wGet(1, e), wGet(2, e)); };   // the pending entry at `e`
 
         uint32_t pnext = cnt ? A.rec[(size_t)o0 * RW] : 0u;
         for (uint32_t j = 0; j < cnt; ++j) {
@@ -3053,7 +3071,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
             pnext = (j + 1 < cnt) ? A.rec[(size_t)(slot + 1) * RW] : 0xFFFFFFFFu;
             if (mayHandOn && __ballot(ovf) != 0ull) { ovf = true; break; }
             // everything that flushes at or before p precedes all events of this and later queries
-            while (head < tail && pF[head] <= p) { apply(head); ++head; }
+            while (head < tail && wGet(0, head) <= p) { apply(head); ++head; }
             if (head == tail) head = tail = 0;
             const int d = (int)(A.rec[(size_t)slot * RW + 2] & 31u);
             if (d == 0) continue;
@@ -3087,7 +3105,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     const int e = b0 + lane;
                     bool ge = false, eq = false;
                     if (e < tail) {
-                        const uint32_t eF = pF[e]; const int eK = pK[e];
+                        const uint32_t eF = wGet(0, e); const int eK = (int)wGet(3, e);
                         ge = (eF > F) || (eF == F && eK >= k);
                         eq = (eF == F && eK == k);
                     }
@@ -3095,35 +3113,35 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
                     if (m) { pos = b0 + __ffsll((long long)m) - 1; same = (__ballot(eq) != 0ull); break; }
                 }
                 if (same) {
-                    if (lane == 0) pCnt[pos] = pCnt[pos] + 1;
-                    __syncthreads();
+                    if (lane == 0) wPut(2, pos, wGet(2, pos) + 1u);
+                    wSync();
                     continue;
                 }
-                if (tail >= PC) {
+                if (tail >= pcap) {
                     if (head > 0) {                                           // compact the window to the front
                         for (int b0 = head; b0 < tail; b0 += 64) {
                             const int e = b0 + lane;
-                            uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
-                            if (e < tail) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
-                            __syncthreads();
-                            if (e < tail) { pF[e - head] = f; pRef[e - head] = rf; pCnt[e - head] = cc; pK[e - head] = kk; }
-                            __syncthreads();
+                            uint32_t f = 0, rf = 0, cc = 0, kk = 0;
+                            if (e < tail) { f = wGet(0, e); rf = wGet(1, e); cc = wGet(2, e); kk = wGet(3, e); }
+                            wSync();
+                            if (e < tail) { wPut(0, e - head, f); wPut(1, e - head, rf); wPut(2, e - head, cc); wPut(3, e - head, kk); }
+                            wSync();
                         }
                         pos -= head; tail -= head; head = 0;
                     }
-                    if (tail >= PC) { if (mayHandOn) ovf = true; else if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
+                    if (tail >= pcap) { if (mayHandOn) ovf = true; else if (lane == 0) atomicOr(A.errFlag, 2u); continue; }
                 }
                 for (int hi = tail; hi > pos; hi -= 64) {                     // shift [pos, tail) right by one
                     const int e = hi - 1 - lane;
-                    uint32_t f = 0, rf = 0, cc = 0; uint8_t kk = 0;
-                    if (e >= pos) { f = pF[e]; rf = pRef[e]; cc = pCnt[e]; kk = pK[e]; }
-                    __syncthreads();
-                    if (e >= pos) { pF[e + 1] = f; pRef[e + 1] = rf; pCnt[e + 1] = cc; pK[e + 1] = kk; }
-                    __syncthreads();
+                    uint32_t f = 0, rf = 0, cc = 0, kk = 0;
+                    if (e >= pos) { f = wGet(0, e); rf = wGet(1, e); cc = wGet(2, e); kk = wGet(3, e); }
+                    wSync();
+                    if (e >= pos) { wPut(0, e + 1, f); wPut(1, e + 1, rf); wPut(2, e + 1, cc); wPut(3, e + 1, kk); }
+                    wSync();
                 }
-                if (lane == 0) { pF[pos] = F; pRef[pos] = slot; pCnt[pos] = 1; pK[pos] = (uint8_t)k; }
+                if (lane == 0) { wPut(0, pos, F); wPut(1, pos, slot); wPut(2, pos, 1u); wPut(3, pos, (uint32_t)k); }
                 ++tail;
-                __syncthreads();
+                wSync();
             }
         }
         ovf = mayHandOn && (__ballot(ovf) != 0ull);
@@ -4867,10 +4885,16 @@ static int launch_flush(kasa_ctx *c, const uint32_t *list, uint32_t nList, const
     return KASA_OK;
 }
 
-__global__ void list_counts_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ kmerOff, uint64_t *__restrict__ cnt)
+__global__ void list_counts_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ kmerOff, uint64_t *__restrict__ cnt,
+                                   uint32_t *__restrict__ longest = nullptr)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nList) { const uint32_t r = list[i]; cnt[i] = kmerOff[r + 1] - kmerOff[r]; }
+    if (i < nList) {
+        const uint32_t r = list[i];
+        const uint64_t n = kmerOff[r + 1] - kmerOff[r];
+        cnt[i] = n;
+        if (longest) atomicMax(longest, (uint32_t)(n < 0xFFFFFFFFull ? n : 0xFFFFFFFFull));   // (the listed reads' most queries)
+    }
     if (i == nList) cnt[i] = 0;
 }
 
@@ -4907,7 +4931,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
     const bool fast = nK <= 25 && nTaxa <= (1u << 20) && !c->forceSlowScore;   // staging records keep the taxon in 20 bits
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
-    c->lastOverflowReads = 0;
+    c->lastOverflowReads = 0; c->lastThirdPassReads = 0;
     uint64_t staged = 0, nKeys = 0;
     if (!gp && c->keyCapScore == 0) c->keyCapScore = c->stCap;
     ScoreArgs A;
@@ -5036,33 +5060,69 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             uint32_t nOver = 0;
             HIPCHK(hipMemcpyAsync(&nOver, counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            if (nOver > 0) {
-                // second pass: the same reads' flush positions are addressed through the first list, so the second pass
-                // walks that list again and skips what the first pass finished (rowLen / ovList membership is not kept):
-                // simpler -- recompute offsets for the overflow list
-                const uint32_t *ov = c->ovList.as<uint32_t>();
-                if ((rc = c->flushOff2.reserve(((size_t)nOver + 1) * 8 + 64))) return rc;
-                list_counts_kernel<<<blocks_for((uint64_t)nOver + 1, 256), 256, 0, c->stream>>>(ov, nOver, c->kmerOff.as<uint64_t>(), c->flushOff2.as<uint64_t>());
+            // Later passes over a list of reads: the flush positions are addressed through the list, so its offsets are made anew.
+            // which = 2: the window of PCAP groups in LDS; narrow records hand a read whose window overflows even that to
+            // which = 3: the window in device memory (GWIN), as long as the longest read has queries times levels.
+            auto laterPass = [&](const uint32_t *list, uint32_t n, int which, uint32_t *ovOut, uint32_t *ovCnt) -> int {
+                int rc2;
+                if ((rc2 = c->flushOff2.reserve(((size_t)n + 1) * 8 + 64))) return rc2;
+                uint32_t *longest = counters + 4;
+                HIPCHK(hipMemsetAsync(longest, 0, 4, c->stream));
+                list_counts_kernel<<<blocks_for((uint64_t)n + 1, 256), 256, 0, c->stream>>>(list, n, c->kmerOff.as<uint64_t>(), c->flushOff2.as<uint64_t>(), longest);
                 size_t tmpBytes = 0;
-                HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)nOver + 1, rocprim::plus<uint64_t>(), c->stream));
-                if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-                HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)nOver + 1, rocprim::plus<uint64_t>(), c->stream));
-                uint64_t nFq2 = 0;
-                HIPCHK(hipMemcpyAsync(&nFq2, c->flushOff2.as<uint64_t>() + nOver, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), c->stream));
+                if ((rc2 = c->sortTmp.reserve(tmpBytes))) return rc2;
+                HIPCHK(rocprim::exclusive_scan(c->sortTmp.p, tmpBytes, c->flushOff2.as<uint64_t>(), c->flushOff2.as<uint64_t>(), (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), c->stream));
+                uint64_t nFq2 = 0; uint32_t hLongest = 0;
+                HIPCHK(hipMemcpyAsync(&nFq2, c->flushOff2.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(&hLongest, longest, 4, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));
-                if ((rc = c->flushPos2.reserve(nFq2 * (size_t)nK * 4 + 64))) return rc;
-                if ((rc = (RW == 8 ? launch_flush<8>(c, ov, nOver, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>()) : launch_flush<16>(c, ov, nOver, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>())))) return rc;
-                A.list = ov; A.nList = nOver;
+                if ((rc2 = c->flushPos2.reserve(nFq2 * (size_t)nK * 4 + 64))) return rc2;
+                if ((rc2 = (RW == 8 ? launch_flush<8>(c, list, n, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>()) : launch_flush<16>(c, list, n, c->flushOff2.as<uint64_t>(), c->flushPos2.as<uint32_t>())))) return rc2;
+                A.list = list; A.nList = n;
                 A.flushPos = c->flushPos2.as<uint32_t>(); A.flushOff = c->flushOff2.as<uint64_t>();
-                A.ovList = nullptr; A.ovCount = nullptr;
-                const uint32_t b2 = std::min<uint32_t>(nOver, std::min<uint32_t>(blocks, 256u * 16u));
-                if (dense) {
-                    if (RW == 8) score_kernel<PCAP, 8, true><<<b2, 64, rowLds, c->stream>>>(A);
-                    else score_kernel<PCAP, 16, true><<<b2, 64, rowLds, c->stream>>>(A);
-                } else
-                if (RW == 8) score_kernel<PCAP, 8><<<b2, 64, 0, c->stream>>>(A);
-                else score_kernel<PCAP, 16><<<b2, 64, 0, c->stream>>>(A);
+                A.ovList = ovOut; A.ovCount = ovCnt;
+                A.forceHandOn = (ovOut && (c->debugFlags & 8388608)) ? 1 : 0;   // (test tap 8388608: the second pass hands every read to the third)
+                if (which == 3) {
+                    // (per block four arrays as long as the batch's longest read has queries times levels: no read can overflow them)
+                    const uint64_t cap = std::max<uint64_t>(64, (uint64_t)hLongest * (uint64_t)nK + 64);
+                    const uint32_t b3 = std::min<uint32_t>(n, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(256, (2ull << 30) / (cap * 16))));
+                    if (cap > 0xFFFFFFFFull) return fail(KASA_E_LIMIT, "a read of %llu k-mers keeps more groups pending than this build can hold", (unsigned long long)hLongest);
+                    if ((rc2 = c->gwin.reserve((size_t)b3 * cap * 16 + 64))) return rc2;
+                    A.gwin = c->gwin.as<uint32_t>(); A.gwinCap = (uint32_t)cap;
+                    if (dense) {
+                        HIPCHK(hipFuncSetAttribute((const void *)score_kernel<1, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                        score_kernel<1, 8, true, true><<<b3, 64, rowLds, c->stream>>>(A);
+                    } else score_kernel<1, 8, false, true><<<b3, 64, 0, c->stream>>>(A);
+                } else {
+                    const uint32_t b2 = std::min<uint32_t>(n, std::min<uint32_t>(blocks, 256u * 16u));
+                    if (dense) {
+                        if (RW == 8) score_kernel<PCAP, 8, true><<<b2, 64, rowLds, c->stream>>>(A);
+                        else score_kernel<PCAP, 16, true><<<b2, 64, rowLds, c->stream>>>(A);
+                    } else
+                    if (RW == 8) score_kernel<PCAP, 8><<<b2, 64, 0, c->stream>>>(A);
+                    else score_kernel<PCAP, 16><<<b2, 64, 0, c->stream>>>(A);
+                }
                 HIPCHK(hipGetLastError());
+                return KASA_OK;
+            };
+            if (nOver > 0) {
+                // second pass.  64-byte records add to the profile as they go (nothing to take back): their window must hold --
+                // KASA_E_LIMIT otherwise.  Narrow records leave no trace of a read they hand on (the profile is group_stage's).
+                uint32_t *ov2 = nullptr, *ov2Cnt = nullptr;
+                if (RW == 8 && gp) {
+                    if ((rc = c->ovList2.reserve((size_t)nOver * 4 + 64))) return rc;
+                    ov2 = c->ovList2.as<uint32_t>(); ov2Cnt = counters + 7;
+                    HIPCHK(hipMemsetAsync(ov2Cnt, 0, 4, c->stream));
+                }
+                if ((rc = laterPass(c->ovList.as<uint32_t>(), nOver, 2, ov2, ov2Cnt))) return rc;
+                if (ov2) {
+                    uint32_t nOver2 = 0;
+                    HIPCHK(hipMemcpyAsync(&nOver2, ov2Cnt, 4, hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipStreamSynchronize(c->stream));
+                    if (nOver2 > 0 && (rc = laterPass(ov2, nOver2, 3, nullptr, nullptr))) return rc;
+                    c->lastThirdPassReads = std::max(c->lastThirdPassReads, nOver2);
+                }
             }
             c->lastOverflowReads = std::max(c->lastOverflowReads, nOver);   // over the staging retries of this batch
             slowProfileDone = true;
@@ -6611,6 +6671,13 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
         (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))
         return rc;
     (void)wantPerRead;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_third_pass_reads(kasa_ctx *c, uint32_t *thirdPassReads)
+{
+    if (!c || !thirdPassReads) return fail(KASA_E_ARG, "kasa_ctx_third_pass_reads: NULL argument");
+    *thirdPassReads = c->lastThirdPassReads;
     return KASA_OK;
 }
 

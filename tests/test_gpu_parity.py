@@ -76,10 +76,11 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
         ctx.close(); dix.close()
 
 
-@pytest.mark.parametrize("slow", [0, 1, 2, 4], ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge"])
+@pytest.mark.parametrize("slow", [0, 1, 2, 4, 1 | 16384 | 8388608], ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge", "general_third_pass"])
 @pytest.mark.parametrize("seed", range(24))
 def test_adversarial_queries_vs_oracle(seed, slow):
-    """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles."""
+    """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles.  (general_third_pass: every
+    read through the general kernel's pending window in device memory.)"""
     _gpu_or_fail()
     rng = np.random.default_rng(5000 + seed)
     letters = [[1, 2], [1, 2, 30], [3, 4, 5, 30, 31], list(range(1, 21))][seed % 4]
@@ -842,12 +843,15 @@ def test_random_configurations(seed):
     _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
 
 
-@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1], ids=["dense_rows", "second_pass", "lane_owned_cells", "coop_group", "coop_group_general"])
+@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192],
+                         ids=["dense_rows", "second_pass", "lane_owned_cells", "coop_group", "coop_group_general", "third_pass", "third_pass_lane_owned_cells"])
 def test_general_kernel_on_huge_taxon_sets(flags):
     """Every taxon a light mutation of one root: a query meets hundreds of taxa per level.  On the general score kernel: with
     the read's row in LDS and an event's taxa dealt out to the lanes (the product path for such reads), through its second
     pass (debug flag 16384 hands every read on: the pass with the full pending window must give the same result), and in the
-    lane-owns-its-cells form that indices beyond 16 384 taxa take (flag 8192)."""
+    lane-owns-its-cells form that indices beyond 16 384 taxa take (flag 8192).  Flag 8388608 lets the second pass hand every
+    read on as well: to the third, whose pending window lies in device memory (what a read takes that keeps more than 4096
+    groups pending -- a limit, KASA_E_LIMIT, until round 4)."""
     _gpu_or_fail()
     rng = np.random.default_rng(19)
     alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -875,6 +879,7 @@ def test_general_kernel_on_huge_taxon_sets(flags):
     ctx.run_batch(batch.bases, batch.offsets, True)
     general, second = ctx.counters()
     assert (general == batch.n or not flags & 1) and (second == batch.n if flags & 16384 else second == 0), (general, second)
+    assert ctx.third_pass_reads() == (batch.n if flags & 8388608 else 0)
     ca, cu, _ = ctx.profile()
     assert np.array_equal(cu, res.count_unique)
     np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)

@@ -40,7 +40,7 @@ for seed in range(first, first + count):
         break
     try:
         T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
-        T.test_adversarial_queries_vs_oracle(seed, [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192][seed % 8])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells)
+        T.test_adversarial_queries_vs_oracle(seed, [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192, 1 | 16384 | 8388608][seed % 9])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
         if os.environ.get("FUZZ_TEXT"):
             fuzz_text(seed)
     except Exception:
