@@ -184,3 +184,20 @@ def test_crowded_genomes_share_what_they_claim():
     g2 = synth.genomes_crowded(40, 30_000, seed=3, clade_sizes=(10, 20))
     assert np.array_equal(g, g2)                                # seeded
 
+
+
+def test_one_hip_runtime_when_torch_comes_after_the_library():
+    """A torch wheel carries its own libamdhip64.so.  Imported after libkasa_hip.so had pulled in ROCm's copy it was a second
+    HIP runtime in the process and torch found no device (round 4: a GPU test that keeps its reads in a torch tensor failed
+    with "No HIP GPUs are available").  capi.lib() therefore loads torch's copy first: one runtime, whatever the order."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from kasa_amd import capi\n"
+            "capi.lib()\n"
+            "import torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print(len(libs), libs)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.split()[0] == "1", r.stdout
