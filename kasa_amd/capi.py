@@ -39,7 +39,7 @@ def _one_hip_runtime():
     uses both (bench.py, dist.py, tests that keep reads in torch tensors) must have them share one.  So torch's copy is
     loaded first -- without importing torch -- and libkasa_hip.so's libamdhip64.so.7 resolves to it."""
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("KASA_OWN_HIP_RUNTIME") == "1":   # (the switch: for a process that never imports torch)
         return
     try:
         import importlib.util

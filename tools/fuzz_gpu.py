@@ -33,14 +33,21 @@ def fuzz_text(seed):
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 480.0
+CYCLE = [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192, 1 | 16384 | 8388608]
+if os.environ.get("FUZZ_NO_THIRD"):
+    CYCLE = CYCLE[:-1]
+import faulthandler
+faulthandler.enable()                                   # a crash inside the library names the Python frame it came from
 t0 = time.time()
 done = 0
 for seed in range(first, first + count):
     if time.time() - t0 > budget:
         break
+    if done % 50 == 0:
+        print("at seed", seed, file=sys.stderr, flush=True)
     try:
         T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
-        T.test_adversarial_queries_vs_oracle(seed, [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192, 1 | 16384 | 8388608][seed % 9])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
+        T.test_adversarial_queries_vs_oracle(seed, CYCLE[seed % len(CYCLE)])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
         if os.environ.get("FUZZ_TEXT"):
             fuzz_text(seed)
     except Exception:
