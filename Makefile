@@ -6,7 +6,7 @@ HOST   = kasa_amd/host/kasa_identify
 all: $(LIB) $(HOST) oracle
 
 $(LIB): kasa_amd/csrc/kasa_hip.hip kasa_amd/csrc/kasa_refbatch.cpp kasa_amd/csrc/stdsort_order.h kasa_amd/csrc/kasa_radix.h kasa_amd/csrc/kasa_text.h kasa_amd/host/grisu_powers.inc include/kasa_hip.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-result -o $@ kasa_amd/csrc/kasa_hip.hip kasa_amd/csrc/kasa_refbatch.cpp -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-result -o $@ kasa_amd/csrc/kasa_hip.hip kasa_amd/csrc/kasa_refbatch.cpp -ldl -Wl,-rpath,/opt/rocm/lib
 
 $(HOST): kasa_amd/host/kasa_identify.cpp kasa_amd/host/grisu_powers.inc include/kasa_hip.h $(LIB)
 	g++ -O2 -std=c++17 -pthread -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -o $@ $< -Lkasa_amd -lkasa_hip -lz -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib

@@ -124,19 +124,35 @@ def stage_bytes(n_q, n_bases, n_idx, rec_bytes, rec_words, stats):
 
 
 def run_with_retry():
-    """The default line is measured by a child process (this one has not touched a GPU), and measured once more if the child
-    ends without its line: one of the dozen default runs of round 4 died within seconds of its start on a box where the same
-    command ran through a minute later (unexplained) -- a line must not be lost to that."""
+    """The default line is measured by a child process (this one has not touched a GPU).  If the child ends without its line
+    it is measured ONCE more -- and the line says so: `attempts`, `retried`, `first_rc` (negative: the signal) and the tail of
+    the failed child's stderr travel in the JSON (round 4 retried silently, which hid an unexplained crash from the record)."""
+    import tempfile
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
-    rc = 1
+    rc, first = 1, None
     for attempt in (1, 2):
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        with tempfile.TemporaryFile(mode="w+") as err:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=err, text=True)
+            err.seek(0)
+            tail = err.read()
+        sys.stderr.write(tail)
+        sys.stderr.flush()
         lines = [ln for ln in (r.stdout or "").splitlines() if ln.startswith("{")]
         if r.returncode == 0 and lines:
-            sys.stdout.write(r.stdout)
-            sys.stdout.flush()
+            try:
+                out = json.loads(lines[-1])
+                out["attempts"] = attempt
+                out["retried"] = attempt > 1
+                if first is not None:
+                    out["first_rc"], out["first_stderr_tail"] = first
+                print(json.dumps(out), flush=True)
+            except ValueError:
+                sys.stdout.write(r.stdout)
+                sys.stdout.flush()
             return 0
         log(f"bench.py: the measuring process ended with code {r.returncode} and {'a' if lines else 'no'} line (attempt {attempt} of 2)")
+        if first is None:
+            first = (r.returncode, tail[-1500:])
         rc = r.returncode or 1
     return rc
 
@@ -929,6 +945,9 @@ def main():
         if rank == 0 and out is not None and c4 is not None:
             out["c4"] = {k: c4[k] for k in KEEP}
     if rank == 0:
+        out["runtime"] = capi.runtime_info()                        # HIP / RCCL the library was built with and runs on (one runtime per process)
+        out.setdefault("attempts", 1)
+        out.setdefault("retried", False)
         print(json.dumps(out), flush=True)
     if comm:
         kdist.rccl_destroy(comm)

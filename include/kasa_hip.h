@@ -292,6 +292,13 @@ int kasa_profile_import_limbs(kasa_ctx *ctx, const uint64_t *limbs);
  * needs no RCCL include), carries folded back.  Afterwards every rank's tables hold the global sums.  Collective:
  * every rank of the communicator must call it. */
 int kasa_profile_allreduce(kasa_ctx *ctx, void *rcclComm);
+/* RCCL is bound at run time to the copy the process already holds -- the one that made `rcclComm` (the host's own link,
+ * a torch wheel's bundled librccl, a ctypes load); librccl.so.1 is loaded only when the process has none.  What this
+ * library was built with and what it runs on: HIP versions as HIP_VERSION (major * 10^7 + minor * 10^5 + patch), RCCL's as
+ * NCCL_VERSION_CODE; *rcclRuntime = 0 when no RCCL is in the process.  Any pointer may be NULL.  (No reference
+ * counterpart: kASA is one statically linked binary; this is what lets a host that shares its process with another ROCm
+ * stack see a mismatch instead of running on it unawares.) */
+int kasa_runtime_versions(int *hipBuilt, int *hipRuntime, int *hipDriver, int *rcclBuilt, int *rcclRuntime);
 
 /* ---- measurement + test taps ------------------------------------------------------------------ */
 /* HIP-event time (ms) and launch count of a stage, accumulated since the last reset. */

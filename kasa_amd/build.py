@@ -26,7 +26,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-result", "-o", SO, SRC] + HOST_SRCS + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+           "-Wall", "-Wno-unused-result", "-o", SO, SRC] + HOST_SRCS + ["-ldl", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return SO
 

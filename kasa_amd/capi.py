@@ -29,17 +29,37 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions",
 ]
 
 
+_share_torch = False
+_runtime_from = "ROCm (this library's own link)"
+
+
+def share_torch_runtime():
+    """Opt in, BEFORE the library is loaded: this process will import torch later (bench.py, dist.py, a test that keeps reads
+    in torch tensors).  A torch wheel brings its own libamdhip64.so (same SONAME as ROCm's); imported after ROCm's copy it
+    would be a second HIP runtime in the process and torch would find no device.  With this call torch's copy is loaded first
+    -- without importing torch -- and libkasa_hip.so's libamdhip64.so.7 resolves to it: one runtime.  A process that never
+    imports torch (the C++ driver, __graft_entry__.smoke, tools/fuzz_gpu.py) does NOT do this and runs on the runtime the
+    library was built for.  A process that has imported torch already needs nothing: its runtime is the one in the process.
+    Either way lib() compares the version the library was built with against the one it runs on (runtime_info())."""
+    global _share_torch
+    if _lib is not None and not _share_torch and "torch" not in __import__("sys").modules:
+        raise RuntimeError("capi.share_torch_runtime() must be called before the library is loaded (capi.lib())")
+    _share_torch = True
+
+
 def _one_hip_runtime():
-    """A torch wheel brings its own libamdhip64.so (same SONAME as ROCm's).  Imported AFTER this library was loaded it
-    becomes a second HIP runtime in the process, and torch then finds no device ("No HIP GPUs are available"): a host that
-    uses both (bench.py, dist.py, tests that keep reads in torch tensors) must have them share one.  So torch's copy is
-    loaded first -- without importing torch -- and libkasa_hip.so's libamdhip64.so.7 resolves to it."""
+    """Which HIP runtime libkasa_hip.so will run on (see share_torch_runtime): torch's when torch is in the process or was
+    asked for (call, or KASA_TORCH_HIP_RUNTIME=1), else ROCm's own."""
     import sys
-    if "torch" in sys.modules or os.environ.get("KASA_OWN_HIP_RUNTIME") == "1":   # (the switch: for a process that never imports torch)
+    global _runtime_from
+    if "torch" in sys.modules:
+        _runtime_from = "torch wheel (torch was imported first)"
+        return
+    if not (_share_torch or os.environ.get("KASA_TORCH_HIP_RUNTIME") == "1"):
         return
     try:
         import importlib.util
@@ -49,8 +69,61 @@ def _one_hip_runtime():
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            _runtime_from = "torch wheel (share_torch_runtime)"
     except (OSError, ImportError, ValueError):
         pass
+
+
+def _hip_version_text(v: int) -> str:
+    return "%d.%d.%d" % (v // 10_000_000, (v // 100_000) % 100, v % 100_000) if v else "none"
+
+
+def runtime_info() -> dict:
+    """What the library was built with and what it runs on (kasa_runtime_versions) + the shared objects really mapped."""
+    L = lib()
+    v = [C.c_int(0) for _ in range(5)]
+    L.kasa_runtime_versions(*[C.byref(x) for x in v])
+    hb, hr, hd, rb, rr = [x.value for x in v]
+    mapped = {}
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.split()[-1]
+            base = os.path.basename(path)
+            for key in ("libamdhip64", "librccl", "libhsa-runtime64"):
+                if base.startswith(key):
+                    mapped.setdefault(key, set()).add(path)
+    except OSError:
+        pass
+    return {"hip_built": _hip_version_text(hb), "hip_runtime": _hip_version_text(hr), "hip_driver": _hip_version_text(hd),
+            "hip_runtime_matches_build": (hb // 100_000) == (hr // 100_000), "runtime_from": _runtime_from,
+            "rccl_built": rb, "rccl_runtime": rr, "mapped": {k: sorted(x) for k, x in mapped.items()}}
+
+
+def _check_runtime(L):
+    """One HIP runtime in the process, and the one the library was built for -- or the host is told.  A different MINOR
+    version under the same SONAME (ROCm 7.2's hipcc over a torch wheel's 7.0 runtime) is announced once on stderr and refused
+    with KASA_STRICT_HIP_RUNTIME=1; two copies of libamdhip64 in one process are always an error."""
+    import sys
+    hb, hr = C.c_int(0), C.c_int(0)
+    L.kasa_runtime_versions(C.byref(hb), C.byref(hr), None, None, None)
+    copies = set()
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.split()[-1]
+            if os.path.basename(path).startswith("libamdhip64"):
+                copies.add(os.path.realpath(path))
+    except OSError:
+        pass
+    if len(copies) > 1:
+        raise RuntimeError("two HIP runtimes in this process (%s): import torch before kasa_amd.capi loads its library, or call "
+                           "capi.share_torch_runtime() first" % ", ".join(sorted(copies)))
+    if hr.value and (hb.value // 100_000) != (hr.value // 100_000):
+        msg = ("kasa_amd: libkasa_hip.so was built with HIP %s and runs on HIP runtime %s (%s)"
+               % (_hip_version_text(hb.value), _hip_version_text(hr.value), _runtime_from))
+        if os.environ.get("KASA_STRICT_HIP_RUNTIME") == "1":
+            raise RuntimeError(msg + "; KASA_STRICT_HIP_RUNTIME=1 refuses that")
+        if os.environ.get("KASA_QUIET_HIP_RUNTIME") != "1":
+            sys.stderr.write(msg + "\n")
 
 
 def lib():
@@ -84,6 +157,8 @@ def lib():
         L.kasa_host_free.argtypes = [C.c_void_p]
         L.kasa_batch_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p]
         L.kasa_batch_rank_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.kasa_runtime_versions.argtypes = [C.c_void_p] * 5
+        _check_runtime(L)
         _lib = L
     return _lib
 

@@ -31,13 +31,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
 
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>                                  // types only: the library is bound at run time (rccl_api below)
 
 #include "../../include/kasa_hip.h"
 #include "stdsort_order.h"
@@ -96,10 +98,16 @@ extern "C" int kasa_device_count(int *count)
     return KASA_OK;
 }
 
-// grow-only device buffer
+// grow-only device buffer; owns its memory (released with the object that holds it: a context buffer nobody listed cannot leak)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~DevBuf() { release(); }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return KASA_OK;
@@ -125,7 +133,7 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
-struct ScopedBuf : DevBuf { ~ScopedBuf() { release(); } };   // a function's own scratch (context buffers are released by kasa_ctx_destroy)
+typedef DevBuf ScopedBuf;                                     // a function's own scratch
 
 // ------------------------------------------------------------------------------------------------
 // device helpers
@@ -557,6 +565,16 @@ struct kasa_ctx {
     DevBuf rawOff;                             // the caller's sequence offsets as uploaded
     DevBuf cohLen, cohState;                   // kasa_batch_coherence: match length of every emitted k-mer; walk state per chunk of reads + scores
     uint64_t nEmitted = 0; bool uniqueDone = false, readsUploaded = false;   // k-mers the encoder emitted (nQ shrinks with -e); -e was applied to this batch
+    // every device buffer of the context: what kasa_ctx_destroy releases and kasa_ctx_device_bytes adds up (ONE list)
+    std::vector<DevBuf *> buffers()
+    {
+        return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds,
+                &tileChunks, &rec, &pool, &plist, &sortTmp, &slotBuf, &recIn, &flushOff, &flushPos, &flushOff2, &flushPos2, &misc, &scratch, &ovList, &ovList2,
+                &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
+                &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
+                &rankList, &rankScratch, &scanTmp, &taxText, &taxTextOff, &taxTextIds, &txtNames, &txtNameOff, &txtLen, &txtBest, &txtBytes, &txtOff, &txtOut,
+                &txtFlags};
+    }
 };
 
 static int timer_begin(kasa_ctx *c, StageTimer &t, hipEvent_t *a, hipEvent_t *b)
@@ -664,12 +682,7 @@ extern "C" void kasa_ctx_destroy(kasa_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device); // the index may already be gone: never touch it here
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                     &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                     &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profSorted2, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
-                     &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                     &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
-                     &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};
+    std::vector<DevBuf *> all = c->buffers();
     for (DevBuf *b : all) b->release();
     auto drop = [](StageTimer &t) {
         for (auto &pr : t.open) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -762,6 +775,7 @@ static int upload_impl(kasa_ctx *c, const uint8_t *bases, const int64_t *offsets
     if ((uint64_t)nReads >= 0xFFFFFFF0ull || (uint64_t)nSeq >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_upload: more than 2^32 reads in one batch");
     HIPCHK(hipSetDevice(c->ix->device));
     c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->nReads = nReads; c->nSeq = nSeq; c->nQ = 0;
+    c->recOut = nullptr; c->recSorted = false;
     const int64_t zero = 0;
     if (nSeq == 0) { offsets = &zero; resident = false; }
     int64_t ends[2] = {0, 0};                                               // offsets[0], offsets[nSeq]
@@ -5247,7 +5261,8 @@ extern "C" int kasa_batch_records_fetch(kasa_ctx *c, uint32_t *records, uint32_t
     HIPCHK(hipSetDevice(c->ix->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint64_t n = c->nQ * (uint64_t)c->recWords();
-    if (n && records) HIPCHK(hipMemcpy(records, c->rec.p, n * 4, hipMemcpyDeviceToHost));
+    // (kasa_batch_group_to wrote them into the caller's buffer, not into `rec`)
+    if (n && records) HIPCHK(hipMemcpy(records, c->recOut ? (const void *)c->recOut : c->rec.p, n * 4, hipMemcpyDeviceToHost));
     if (pool && c->poolUsed) {
         if (c->nQ) HIPCHK(hipMemcpy(pool, c->pool.p, (size_t)c->poolUsed * 4, hipMemcpyDeviceToHost));
         pool[0] = 0;                                                   // word 0 is the cursor's start: never referenced
@@ -5380,6 +5395,7 @@ extern "C" int kasa_batch_set_sorted_device(kasa_ctx *c, const void *kmersDev, u
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_sorted_device: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
     c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr;
+    c->recOut = nullptr; c->recSorted = false;                       // the last batch's exported records (the caller's buffer) are not this batch's
     int rc;
     if ((rc = c->qKmerB.reserve(n * c->keyBytes() + 64))) return rc;
     if (n) HIPCHK(hipMemcpyAsync(c->qKmerB.p, kmersDev, n * c->keyBytes(), hipMemcpyDefault, c->stream));   // same device or a peer's memory
@@ -6393,9 +6409,57 @@ __global__ void limbs_unpack_kernel(const uint64_t *__restrict__ limbs, size_t c
     hi[i] = (uint64_t)(v >> 64); mid[i] = (uint64_t)v >> 32; lo[i] = (uint64_t)v & 0xFFFFFFFFull;
 }
 
+// RCCL is bound at run time, to the copy the PROCESS already has: the communicator the caller hands over was made by that
+// copy (the host's own link, torch's bundled librccl, a ctypes load), and a second RCCL -- or ROCm's RCCL over another HIP
+// runtime than the one it was built for -- has no business in the process.  Only when none is loaded: librccl.so.1 by the
+// usual search (this library's RUNPATH: /opt/rocm/lib).
+struct RcclApi {
+    ncclResult_t (*allReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*errorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*getVersion)(int *) = nullptr;
+    bool loadedHere = false;                            // no copy was in the process: this library loaded one
+};
+static const RcclApi *rccl_api(bool mayLoad)
+{
+    static std::mutex mu;
+    static RcclApi api;
+    std::lock_guard<std::mutex> lock(mu);
+    if (api.allReduce) return &api;
+    void *h = nullptr;
+    if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = RTLD_DEFAULT;                            // linked into the host, or loaded globally
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);                             // loaded privately (ctypes, torch): found by its SONAME
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h && mayLoad) { h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL); api.loadedHere = h != nullptr; }
+    if (!h) return nullptr;
+    api.errorString = reinterpret_cast<decltype(api.errorString)>(dlsym(h, "ncclGetErrorString"));
+    api.getVersion = reinterpret_cast<decltype(api.getVersion)>(dlsym(h, "ncclGetVersion"));
+    api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(h, "ncclAllReduce"));
+    return api.allReduce ? &api : nullptr;
+}
+
+// What this library was built with and what it runs on (HIP: major * 10^7 + minor * 10^5 + patch; RCCL: its own code, 0 when
+// no RCCL is in the process).  A host that shares its process with another ROCm stack (a torch wheel brings its own
+// libamdhip64 / librccl) can see -- and refuse -- a mismatch.
+extern "C" int kasa_runtime_versions(int *hipBuilt, int *hipRuntime, int *hipDriver, int *rcclBuilt, int *rcclRuntime)
+{
+    if (hipBuilt) *hipBuilt = HIP_VERSION;
+    if (hipRuntime) { int v = 0; if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; } *hipRuntime = v; }
+    if (hipDriver) { int v = 0; if (hipDriverGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; } *hipDriver = v; }
+    if (rcclBuilt) *rcclBuilt = NCCL_VERSION_CODE;
+    if (rcclRuntime) {
+        int v = 0;
+        const RcclApi *r = rccl_api(false);
+        if (r && r->getVersion) (void)r->getVersion(&v);
+        *rcclRuntime = v;
+    }
+    return KASA_OK;
+}
+
 extern "C" int kasa_profile_allreduce(kasa_ctx *c, void *rcclComm)
 {
     if (!c || !rcclComm) return fail(KASA_E_ARG, "kasa_profile_allreduce: NULL argument");
+    const RcclApi *R = rccl_api(true);
+    if (!R) return fail(KASA_E_HIP, "kasa_profile_allreduce: no RCCL library in this process and librccl.so.1 cannot be loaded: %s", dlerror());
     HIPCHK(hipSetDevice(c->ix->device));
     const size_t cells = (size_t)c->nK * c->ix->nTaxa;
     int rc = c->profSorted.reserve(cells * 6 * 8 + 64);                 // (free between batches)
@@ -6404,8 +6468,8 @@ extern "C" int kasa_profile_allreduce(kasa_ctx *c, void *rcclComm)
     limbs_pack_kernel<<<blocks_for(cells, 256), 256, 0, c->stream>>>(c->cntUnique.as<uint64_t>(), c->cntTotal.as<uint64_t>(), c->cntAllHi.as<uint64_t>(),
         c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), cells, limbs);
     HIPCHK(hipGetLastError());
-    const ncclResult_t nr = ncclAllReduce(limbs, limbs, cells * 6, ncclUint64, ncclSum, static_cast<ncclComm_t>(rcclComm), c->stream);
-    if (nr != ncclSuccess) return fail(KASA_E_HIP, "ncclAllReduce failed: %s", ncclGetErrorString(nr));
+    const ncclResult_t nr = R->allReduce(limbs, limbs, cells * 6, ncclUint64, ncclSum, static_cast<ncclComm_t>(rcclComm), c->stream);
+    if (nr != ncclSuccess) return fail(KASA_E_HIP, "ncclAllReduce failed: %s", R->errorString ? R->errorString(nr) : "?");
     limbs_unpack_kernel<<<blocks_for(cells, 256), 256, 0, c->stream>>>(limbs, cells, c->cntUnique.as<uint64_t>(), c->cntTotal.as<uint64_t>(),
         c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
     HIPCHK(hipGetLastError());
@@ -6566,7 +6630,7 @@ static int batch_set_queries_impl(kasa_ctx *c, const void *kmers, const uint32_t
     if (nReads < 0 || (n && (!kmers || !reads))) return fail(KASA_E_ARG, "kasa_batch_set_queries: bad arguments");
     if (n >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_set_queries: too many queries for one batch");
     HIPCHK(hipSetDevice(c->ix->device));
-    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->readsUploaded = false;
+    c->state = 0; c->haveScores = false; c->grouped = false; c->slotOf = nullptr; c->payloadIsSlot = false; c->rankValid = false; c->txtValid = false; c->cohScores = nullptr; c->readsUploaded = false; c->recOut = nullptr; c->recSorted = false;
     std::vector<uint64_t> koff((size_t)nReads + 1, 0);
     uint32_t maxCnt = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -6610,12 +6674,7 @@ extern "C" int kasa_batch_fetch_lookup(kasa_ctx *c, uint8_t *depth, uint32_t *in
 extern "C" int kasa_ctx_device_bytes(kasa_ctx *c, uint64_t *bytes)
 {
     if (!c || !bytes) return fail(KASA_E_ARG, "NULL argument");
-    const DevBuf *all[] = {&c->lut, &c->bases, &c->baseOff, &c->kmerOff, &c->seqOff, &c->seqRead, &c->qKmerA, &c->qKmerB, &c->qReadA, &c->qReadB,
-                           &c->depth, &c->rep, &c->tileFirst, &c->tileNext, &c->tileBounds, &c->tileChunks, &c->rec, &c->pool, &c->plist, &c->sortTmp,
-                           &c->slotBuf, &c->recIn, &c->flushOff, &c->flushPos, &c->flushOff2, &c->flushPos2, &c->misc, &c->scratch, &c->ovList, &c->touched, &c->fbList, &c->fastScratch, &c->profKeys, &c->profSorted, &c->profSorted2, &c->rowPos, &c->rowLen, &c->rowKey, &c->rowOff, &c->st, &c->cntAllMid,
-                           &c->outTax, &c->outScore, &c->cntUnique, &c->cntTotal, &c->cntAllHi, &c->cntAllLo,
-                           &c->rawOff, &c->cohLen, &c->cohState, &c->sortBig, &c->rankDen, &c->rankClass, &c->rankMeta, &c->rankOut, &c->rankList, &c->rankScratch, &c->scanTmp,
-                     &c->taxText, &c->taxTextOff, &c->taxTextIds, &c->txtNames, &c->txtNameOff, &c->txtLen, &c->txtBest, &c->txtBytes, &c->txtOff, &c->txtOut, &c->txtFlags};
+    const std::vector<DevBuf *> all = c->buffers();
     uint64_t s = 0;
     for (const DevBuf *b : all) s += b->cap;
     *bytes = s;

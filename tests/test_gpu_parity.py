@@ -885,3 +885,69 @@ def test_general_kernel_on_huge_taxon_sets(flags):
     np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
     assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
     ctx.close(); dix.close()
+
+
+def test_context_releases_every_device_buffer():
+    """kasa_ctx_destroy gives back everything a context allocated, the third pass's window and list included (round 4
+    leaked `gwin` and `ovList2`: up to 2 GB per context that ever ran the third pass)."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(5, 12, 6000, 400)
+    dix = capi.DeviceIndex(ix)
+    warm = capi.Context(dix, 12, 7, 3)                           # first use of the kernels: the runtime's own allocations
+    warm.debug_flags(1 | 16384 | 8388608)
+    warm.run_batch(batch.bases, batch.offsets, True)
+    warm.close()
+    free0, _ = capi.device_memory(0)
+    for _ in range(3):
+        ctx = capi.Context(dix, 12, 7, 3)
+        ctx.debug_flags(1 | 16384 | 8388608)                     # every read through the second and the third pass
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        assert ctx.third_pass_reads() == batch.n
+        assert ctx.device_bytes() > 0
+        ctx.close()
+    free1, _ = capi.device_memory(0)
+    assert free0 - free1 < (4 << 20), (free0, free1)             # (the allocator's granularity, not a buffer)
+    dix.close()
+
+
+def test_records_after_group_to():
+    """kasa_batch_group_to writes the records into the caller's buffer; kasa_batch_records_fetch must hand out THOSE, not
+    what an earlier batch left in the context's own buffer (advisor finding of round 4)."""
+    _gpu_or_fail()
+    import torch
+    ix, batch = synthetic_world(7, 10, 8000, 900)
+    dix = capi.DeviceIndex(ix)
+    a = capi.Context(dix, 12, 7, 3)
+    a.upload(batch.bases, batch.offsets); a.encode(); a.sort_and_range()
+    ptr, n, kb = a.queries_device()
+    b = capi.Context(dix, 12, 7, 3)
+    half = n // 2
+    b.set_sorted_device(ptr + half * kb, n - half)               # an earlier, different slice leaves its records in b's own buffer
+    b.group()
+    b.set_sorted_device(ptr, half)
+    b.group()
+    rec0, pool0 = b.records()
+    out = torch.empty(half * b.rec_words, dtype=torch.int32, device="cuda:0")
+    b.set_sorted_device(ptr + half * kb, n - half); b.group()     # ... and once more something else
+    b.set_sorted_device(ptr, half)
+    b.group_to(out.data_ptr())
+    rec1, pool1 = b.records()
+    def canon(rec, pool):                                       # pool blocks are handed out in the order the workgroups arrive
+        rows = []
+        for w in rec:
+            n = int(w[3] & 255)
+            if n <= 4:
+                rows.append(tuple(int(x) for x in w))
+                continue
+            at = int(w[7])
+            n = int(pool[at])
+            skip = 4 if (int(w[2]) >> 30) & 1 else 0
+            rows.append(tuple(int(x) for x in w[:7]) + tuple(int(x) for x in pool[at:at + 1 + skip + n - 3]))
+        return rows
+    assert canon(rec0, pool0) == canon(rec1, pool1)
+    a.synchronize()
+    assert canon(out.cpu().numpy().view(np.uint32).reshape(-1, b.rec_words), pool1) == canon(rec1, pool1)
+    b.set_sorted_device(ptr, half)                               # a new batch: the caller's buffer is forgotten
+    with pytest.raises(RuntimeError):
+        b.records()
+    a.close(); b.close(); dix.close()

@@ -186,18 +186,75 @@ def test_crowded_genomes_share_what_they_claim():
 
 
 
-def test_one_hip_runtime_when_torch_comes_after_the_library():
-    """A torch wheel carries its own libamdhip64.so.  Imported after libkasa_hip.so had pulled in ROCm's copy it was a second
-    HIP runtime in the process and torch found no device (round 4: a GPU test that keeps its reads in a torch tensor failed
-    with "No HIP GPUs are available").  capi.lib() therefore loads torch's copy first: one runtime, whatever the order."""
+def _run_py(code):
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from kasa_amd import capi\n"
-            "capi.lib()\n"
-            "import torch\n"
-            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
-            "print(len(libs), libs)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % root + code], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, KASA_QUIET_HIP_RUNTIME="1"))
+
+
+def _lib_and_torch_or_skip():
+    import importlib.util
+    from kasa_amd import capi
+    if not os.path.exists(capi.SO_PATH) or importlib.util.find_spec("torch") is None:
+        pytest.skip("libkasa_hip.so or torch is not here")
+
+
+def test_one_hip_runtime_when_torch_comes_after_the_library():
+    """A torch wheel carries its own libamdhip64.so.  Imported after libkasa_hip.so had pulled in ROCm's copy it is a second
+    HIP runtime in the process and torch finds no device.  A host that will import torch says so first
+    (capi.share_torch_runtime()): then there is ONE runtime, whatever the order -- and it is an explicit choice (round 4 made
+    the swap for every process, torch or not)."""
+    _lib_and_torch_or_skip()
+    r = _run_py("from kasa_amd import capi\n"
+                "capi.share_torch_runtime()\n"
+                "capi.lib()\n"
+                "import torch\n"
+                "info = capi.runtime_info()\n"
+                "print(len(info['mapped']['libamdhip64']), info['runtime_from'])\n")
     assert r.returncode == 0, r.stderr[-500:]
-    assert r.stdout.split()[0] == "1", r.stdout
+    assert r.stdout.split()[0] == "1" and "torch" in r.stdout, r.stdout
+
+
+def test_own_hip_runtime_without_torch():
+    """A process that never asks for torch runs on the runtime the library was built for (ROCm's own): versions equal."""
+    _lib_and_torch_or_skip()
+    r = _run_py("from kasa_amd import capi\n"
+                "info = capi.runtime_info()\n"
+                "import sys\n"
+                "assert 'torch' not in sys.modules\n"
+                "print(info['hip_built'], info['hip_runtime'], info['hip_runtime_matches_build'], info['mapped']['libamdhip64'])\n")
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "True" in r.stdout and "/opt/rocm" in r.stdout, r.stdout
+
+
+def test_torch_first_is_one_runtime_and_a_mismatch_is_told():
+    """torch imported first: its runtime is the process's; the library announces (or, strict, refuses) a build/runtime
+    mismatch instead of running on it unawares."""
+    _lib_and_torch_or_skip()
+    code = ("import torch\n"
+            "from kasa_amd import capi\n"
+            "info = capi.runtime_info()\n"
+            "print(len(info['mapped']['libamdhip64']), info['hip_runtime_matches_build'])\n")
+    r = _run_py(code)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.split()[0] == "1"
+    if r.stdout.split()[1] == "False":
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r2 = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % root + code], capture_output=True, text=True, timeout=300,
+                            env=dict(os.environ, KASA_STRICT_HIP_RUNTIME="1"))
+        assert r2.returncode != 0 and "KASA_STRICT_HIP_RUNTIME" in r2.stderr
+
+
+def test_library_does_not_link_rccl():
+    """RCCL is bound at run time to the copy the process holds (kasa_profile_allreduce): the library itself must not pull a
+    second one in."""
+    import subprocess
+    from kasa_amd import capi
+    if not os.path.exists(capi.SO_PATH):
+        pytest.skip("libkasa_hip.so is not built")
+    out = subprocess.run(["readelf", "-d", capi.SO_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in out and "libamdhip64.so" in out
