@@ -336,12 +336,15 @@ def report(args, ctx, reads, ix, world, res, wide, n_reads, n_batches, scaling, 
     kb = kernel_bytes(n_kmers, ix.n, rec_bytes, ctx.rec_words, stats)
     kernels = {}
     for name, (ms, n) in kern.items():
-        if n:
+        if n and name in kb:
             avg = ms / n
             kernels[name] = {"avg_launch_ms": avg, "algorithmic_bytes_per_launch": kb[name],
                              "achieved": kb[name] / (avg * 1e-3) / 1e9, "frac": kb[name] / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    # the roofline line is the kernel with the largest share of the step
-    dom = max(kernels, key=lambda k: kernels[k]["avg_launch_ms"]) if kernels else None
+        elif n:                                                            # groups of kernels timed together (no single byte count): ms per step
+            kernels[name] = {"ms_per_step": ms / max(1, args.steps), "timed_sections_per_step": n / max(1, args.steps)}
+    # the roofline line is the single kernel with the largest share of the step
+    single = [k for k in kernels if "avg_launch_ms" in kernels[k]]
+    dom = max(single, key=lambda k: kernels[k]["avg_launch_ms"]) if single else None
     per_batch_reads = n_reads // max(1, n_batches)
     sb = stage_bytes(n_kmers, per_batch_reads * args.read_len, ix.n, rec_bytes, ctx.rec_words, stats)
     sb = {k: v * n_batches for k, v in sb.items()}
@@ -391,15 +394,16 @@ def pmc_traffic(args, wide, kernel, live=True):
     import re
     import shutil
     import tempfile
-    want = {"score_other_kernel": "score_other_flat", "row_merge_kernel": "row_merge_bitmap_kernel"}.get(kernel, kernel)
+    want = {"score_other_kernel": "score_other_flat", "row_merge_kernel": "row_merge_bitmap_kernel", "group_kernel": "group2?_kernel"}.get(kernel, kernel)   # (regular expressions)
     got = {}
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if live and os.path.exists(exe):
         d = tempfile.mkdtemp(prefix="kasa_pmc_")
         try:
-            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU")):
+                counter = counters[0]
                 dd = os.path.join(d, counter)
-                cmd = [exe, "--pmc", counter, "--kernel-include-regex", want, "--output-format", "csv", "-d", dd, "--", sys.executable,
+                cmd = [exe, "--pmc", *counters, "--kernel-include-regex", want, "--output-format", "csv", "-d", dd, "--", sys.executable,
                        os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc",
                        "--reads", str(args.reads), "--taxa", str(args.taxa), "--genome-len", str(args.genome_len), "--read-len", str(args.read_len)]
                 if wide:
@@ -408,20 +412,25 @@ def pmc_traffic(args, wide, kernel, live=True):
                 for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                     env.pop(k, None)
                 subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, cwd="/tmp")
-                vals = []
+                vals = {c: [] for c in counters}
                 for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
                     for row in csv.DictReader(open(f)):
-                        if row["Counter_Name"] == counter and want in row["Kernel_Name"]:
-                            vals.append(float(row["Counter_Value"]))
-                if vals:
-                    got[counter] = max(vals)                               # the largest dispatch: the batch (the index build launches some kernels too)
+                        if row["Counter_Name"] in vals and re.search(want, row["Kernel_Name"]):
+                            vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                for c, v in vals.items():
+                    if v:
+                        got[c] = max(v)                                    # the largest dispatch: the batch (the index build launches some kernels too)
         except Exception as ex:
             got["error"] = str(ex)[:200]
         finally:
             shutil.rmtree(d, ignore_errors=True)
     if "FETCH_SIZE" in got and "WRITE_SIZE" in got:
-        return {"traffic": got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024,
-                "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child passes of one step each; FETCH_SIZE x 2, gfx950)"}
+        out = {"traffic": got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024,
+               "traffic_source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child passes of one step each; FETCH_SIZE x 2, gfx950)"}
+        if "SQ_INSTS_VALU" in got and "SQ_INSTS_SALU" in got:
+            out["insts"] = {"valu": got["SQ_INSTS_VALU"], "salu": got["SQ_INSTS_SALU"],
+                            "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (a third child pass of one step)"}
+        return out
     if (args.reads, args.taxa, args.genome_len, args.read_len) != (10_000_000, 1400, 300_000, 150):
         return {"traffic": None, "traffic_source": "none: the committed counter passes are of the default workload"}
     try:
@@ -906,7 +915,16 @@ def main():
         if rank == 0 and world == 1 and out["roofline"].get("kernel") and workload == "pairs":
             # HBM bytes of the dominant kernel from the counters (the device is free now)
             live = not args.no_pmc and (args.pmc_secondary if (wide and not args.wide) else True)
-            out["roofline"].update(pmc_traffic(args, wide, out["roofline"]["kernel"], live))
+            pm = pmc_traffic(args, wide, out["roofline"]["kernel"], live)
+            insts = pm.pop("insts", None)
+            out["roofline"].update(pm)
+            if insts and out["roofline"].get("avg_launch_ms"):
+                # instruction issue: a SIMD issues one wavefront instruction per 4 cycles -- (VALU + SALU) x 4 / (1024 SIMDs x 2.4 GHz)
+                pred = (insts["valu"] + insts["salu"]) * 4.0 / (1024 * 2.4e9) * 1e3
+                out["roofline"]["third_bound"] = {"bound": "issue", "kernel": out["roofline"]["kernel"], "wave_insts_valu": insts["valu"],
+                                                  "wave_insts_salu": insts["salu"], "predicted_ms": pred,
+                                                  "frac": pred / out["roofline"]["avg_launch_ms"], "source": insts["source"],
+                                                  "formula": "(SQ_INSTS_VALU + SQ_INSTS_SALU) * 4 cycles / (1024 SIMDs * 2.4 GHz)"}
         return out
 
     KEEP = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "kmers_per_s", "identified_fraction", "rank_step_ms",

@@ -311,12 +311,21 @@ enum {
     KASA_KERNEL_SCORE_MAIN = 2,   /* score_main_kernel: the float chains of a read's register taxa */
     KASA_KERNEL_SCORE_OTHER = 3,  /* score_other_kernel: staging records of all other taxa */
     KASA_KERNEL_ROW_MERGE = 4,    /* row_merge_*: staging rows -> final {taxon, score} rows + profile keys */
-    KASA_KERNEL_COUNT = 5
+    KASA_KERNEL_SCORE_GENERAL = 5,/* flush_positions_kernel + score_kernel (all its passes): the reads the fast kernels hand over */
+    KASA_KERNEL_PROFILE_TABLES = 6,/* profile_(group_)table_kernel + the sort and reduce of the keys it leaves over */
+    KASA_KERNEL_ROW_COPY = 7,     /* row lengths -> CSR offsets (scan) + row_copy_kernel */
+    KASA_KERNEL_SORT_PASSES = 8,  /* kasa_radix: hist_kernel + the radix passes of the query sort */
+    KASA_KERNEL_BUCKET_RANK = 9,  /* bucket_rank*_kernel: the query sort's last step */
+    KASA_KERNEL_COUNT = 10
 };
 int kasa_ctx_kernel_ms(kasa_ctx *ctx, int kernel, double *ms, uint64_t *launches);
 /* Of the last batch: {queries, staging records, profile keys, pool words, reads on the general kernel, of those on its
  * second pass, non-zero score cells, 1 if the encoder ranked the reads' k-mers (no slot fix-up)}. */
 int kasa_ctx_batch_stats(kasa_ctx *ctx, uint64_t *stats8);
+/* Of the last batch's group stage: the tiles of 1024 sorted queries it had, and how many of them the dense-leader kernel
+ * (group2_kernel) left to the general one -- tiles with long taxon lists (Compare.hpp:396-441, a conserved k-mer) or walks
+ * beyond its staged index span; 0 when the general kernel ran alone. */
+int kasa_ctx_group_tiles(kasa_ctx *ctx, uint32_t *tiles, uint32_t *listed);
 /* Number of query records the batch holds right now: the k-mer count of kasa_batch_encode, less the
  * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
 int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);

@@ -29,7 +29,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles",
 ]
 
 
@@ -632,7 +632,8 @@ class Context:
     def stage_reset(self):
         _check(lib().kasa_ctx_stage_reset(self.h))
 
-    KERNELS = ("lookup_tile_kernel", "group_kernel", "score_main_kernel", "score_other_kernel", "row_merge_kernel")
+    KERNELS = ("lookup_tile_kernel", "group_kernel", "score_main_kernel", "score_other_kernel", "row_merge_kernel",
+               "score_general_kernels", "profile_table_kernels", "row_copy_kernels", "sort_pass_kernels", "bucket_rank_kernel")
 
     def kernel_ms(self):
         """HIP-event time of single kernels alone since stage_reset(): {name: (ms, launches)}."""
@@ -653,7 +654,15 @@ class Context:
         st = np.zeros(8, dtype=np.uint64)
         _check(lib().kasa_ctx_batch_stats(self.h, _p(st)))
         keys = ("queries", "staging_records", "profile_keys", "pool_words", "general_reads", "second_pass_reads", "nnz", "encoder_ranked")
-        return {k: int(v) for k, v in zip(keys, st)}
+        out = {k: int(v) for k, v in zip(keys, st)}
+        out["group_tiles"], out["group_tiles_listed"] = self.group_tiles()
+        return out
+
+    def group_tiles(self):
+        """(tiles of the last batch's group stage, tiles group2_kernel left to group_kernel) -- kasa_ctx_group_tiles."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().kasa_ctx_group_tiles(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def max_queries_per_batch(self, device: int = 0, fraction: float = 0.8) -> int:
         """How many query k-mers fit one batch in the HBM that is free right now (at most 2^32 - 16)."""

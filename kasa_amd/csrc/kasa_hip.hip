@@ -514,6 +514,7 @@ struct kasa_ctx {
     uint32_t maxCnt = 0;
     int state = 0; // 0 none, 1 uploaded, 2 encoded, 3 sorted+lookup, 4 scored
     bool haveScores = false;
+    bool csrPacked = false;                    // the rows of this batch have been packed into outTax / outScore (kasa_batch_scores_fetch)
     DevBuf rankDen, rankClass, rankMeta, rankOut, rankList, rankScratch; uint64_t rankCap = 0, rankEntries = 0;   // kasa_batch_rank
     bool rankValid = false; uint32_t rankFlagged = 0;          // ... of THIS batch; reads it left to the host
     uint32_t rankClasses = 0;                                  // denominator rows kasa_batch_rank was given (kasa_batch_text's bestScore has as many)
@@ -536,6 +537,8 @@ struct kasa_ctx {
     DevBuf sortBig;                            // heads / begins / ends of the long buckets (sort_and_range)
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
+    DevBuf tileList;                           // tiles group2_kernel leaves to group_kernel (long lists, walks beyond the staged span)
+    uint32_t lastSlowTiles = 0;
     DevBuf tileChunks;                         // tile_suffix: minima of chunks of 1024 tiles
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // event records, recWords() u32 each, by slot
@@ -568,7 +571,7 @@ struct kasa_ctx {
     // every device buffer of the context: what kasa_ctx_destroy releases and kasa_ctx_device_bytes adds up (ONE list)
     std::vector<DevBuf *> buffers()
     {
-        return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds,
+        return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds, &tileList,
                 &tileChunks, &rec, &pool, &plist, &sortTmp, &slotBuf, &recIn, &flushOff, &flushPos, &flushOff2, &flushPos2, &misc, &scratch, &ovList, &ovList2,
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
@@ -1685,12 +1688,17 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
                 // the hand-written passes (kasa_radix.h): A -> B -> A ... ; four passes end in A, which then takes B's name
                 if ((rc = c->sortTmp.reserve(kasa_radix::scratch_bytes<Key>(nQ)))) return rc;
                 Key *kRes; uint32_t *vRes;
+                hipEvent_t ka, kb;
+                if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SORT_PASSES], &ka, &kb))) return rc;
                 HIPCHK(kasa_radix::sort_pairs<Key>(c->qKmerA.as<Key>(), c->qReadA.as<uint32_t>(), c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), (uint32_t)nQ,
                                                    (int)(BITS - top), (int)top, c->sortTmp.p, c->stream, &kRes, &vRes, (c->debugFlags & 524288) ? kasa_radix::MODE_FIRST : 0));   // (test tap 524288: the look-back before the keys are ordered in LDS)
+                if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SORT_PASSES], ka, kb))) return rc;
                 if (kRes == c->qKmerA.as<Key>() && (top / 8) % 2 == 0) { std::swap(c->qKmerA, c->qKmerB); std::swap(c->qReadA, c->qReadB); }   // (an even number of passes ends where it began)
                 if (kRes != c->qKmerB.as<Key>()) return fail(KASA_E_HIP, "query sort: unexpected result buffer");
             }
             HIPCHK(hipMemsetAsync(big, 0, 8, c->stream));
+            hipEvent_t ra, rb;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_BUCKET_RANK], &ra, &rb))) return rc;
             static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP_OLD + 12 <= 32, "bucket_rank32_kernel: low key bits and window position share a word");
             static_assert(KeyTraits<uint64_t>::BITS - SORT_TOP + 12 <= 52, "bucket_rank64_kernel: low key bits and window position share a word");
             if (sizeof(Key) == 8 && top != SORT_TOP_OLD && !(c->debugFlags & 4194304))   // (test tap 4194304: the kernel for any key width)
@@ -1706,6 +1714,7 @@ static int sort_and_range_impl(kasa_ctx *c, int unique)
                 bucket_rank_kernel<Key><<<blocks_for(nQ, RANK_TILE), 256, 0, c->stream>>>(c->qKmerB.as<Key>(), c->qReadB.as<uint32_t>(), c->qKmerA.as<Key>(),
                                                                                           c->qReadA.as<uint32_t>(), (uint32_t)nQ, (int)(BITS - top), big, bigHead);
             HIPCHK(hipGetLastError());
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_BUCKET_RANK], ra, rb))) return rc;
             uint32_t hBig = 0;
             HIPCHK(hipMemcpyAsync(&hBig, big, 4, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -2086,8 +2095,10 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
     uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa,
     uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
-    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo, uint32_t *__restrict__ needCoop)
+    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo, uint32_t *__restrict__ needCoop,
+    const uint32_t *__restrict__ tileList)
 {
+    const uint32_t tileId = tileList ? (tileList[blockIdx.x] & 0x0FFFFFFFu) : blockIdx.x;   // (the tiles group2_kernel left to this one; the top bits say why)
     const int coverage = flags & 1;                                // bit 1: every query walks the index itself (test tap); bit 2: no LDS span for 64-byte records
     typedef RecTraits<RW> RT;
     constexpr int NL = NKT ? NKT : RT::LEVELS, INL = RT::INL;       // levels the unrolled loops run over
@@ -2122,7 +2133,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
     const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t base = blockIdx.x * TILE + t * GITEMS;
+    const uint32_t base = tileId * TILE + t * GITEMS;
     int d[GITEMS];
     uint32_t rp[GITEMS], sp[GITEMS];
 #pragma unroll
@@ -2176,14 +2187,14 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
         const unsigned long long hi = any & above;
         if (hi) {
             const int l2 = __ffsll((long long)hi) - 1;
-            next = blockIdx.x * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u);
+            next = tileId * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u);
         }
         F[1][lv] = next;
         F[0][lv] = ((sp[1] >> lv) & 1u) ? base + 1 : next;
         if (next == NOPOS) { open1 |= 1u << lv; if (!((sp[1] >> lv) & 1u)) open0 |= 1u << lv; }
         if (lane == 0) {
             uint32_t first = NOPOS;
-            if (any) { const int l2 = __ffsll((long long)any) - 1; first = blockIdx.x * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u); }
+            if (any) { const int l2 = __ffsll((long long)any) - 1; first = tileId * TILE + (uint32_t)(wv * 64 + l2) * GITEMS + (((b0 >> l2) & 1ull) ? 0u : 1u); }
             sFirst[wv][lv] = first;
         }
     }
@@ -2194,7 +2205,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
             if (!((open1 >> lv) & 1u)) continue;
             uint32_t v = NOPOS;
             for (int w = wv + 1; w < GTHREADS / 64; ++w) { const uint32_t o = sFirst[w][lv]; if (o != NOPOS) { v = o; break; } }
-            if (v == NOPOS) v = tileNext[(size_t)lv * nTiles + blockIdx.x];
+            if (v == NOPOS) v = tileNext[(size_t)lv * nTiles + tileId];
             F[1][lv] = v;
             if ((open0 >> lv) & 1u) F[0][lv] = v;
         }
@@ -2317,7 +2328,9 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
     };
     // counts of one long list into the wavefront's scratch; returns whether entry j itself yields a segment
     auto coopCount = [&](uint32_t j, int dd, uint32_t &selfSeg, bool &anySplit) -> bool {
-        uint32_t *cM = &sCo[wv][0], *cH = &sCo[wv][32];
+        if constexpr (!(RW == 8 && COOP)) return false;               // (the scratch exists in the cooperative form only)
+        constexpr int CH = (RW == 8 && COOP) ? 32 : 0;
+        uint32_t *cM = &sCo[wv][0], *cH = &sCo[wv][CH];
         if (lane < 32) cM[lane] = 0u;
         cH[lane] = 0u;
         LDS_WAVE_SYNC_G();
@@ -2770,6 +2783,455 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                 for (uint32_t x = t; x < totalK; x += GTHREADS) profKeys[(size_t)sBaseK + x] = sKeys[x];
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// group2: the group stage of ordinary tiles (narrow records), leaders compacted onto lanes
+// ------------------------------------------------------------------------------------------------
+// group_kernel gives a thread two sorted queries and lets every lane do everything for its own queries.  But 60 % of the
+// queries are FOLLOWERS (their (representative, depth) is their predecessor's): lanes that hold them idle in lockstep while
+// their neighbours walk the index and cut profile keys -- the two loops that are most of the kernel's instructions -- and the
+// kernel, which ends in a scatter the chip could retire in 48 ms, took 71 issuing them (round 4: 45e9 wavefront
+// instructions).  Here the work is dealt out twice:
+//   A  (sorted layout, two queries per thread)  flush positions, order of the events, hits of the groups a query heads --
+//      the ballot work over neighbours in sorted order.  Leaders are numbered through the tile and leave {rep, depth, hits} in LDS.
+//   B  (ONE LEADER PER LANE, dense: ~410 of a tile's 1024 queries)  the walk over the index span in LDS: segments straight
+//      into LDS (the first four of a list; further ones parked), level sizes as a histogram of the segments' last levels
+//      (|T_k| = its running sum: a multiplication), the leader's own profile keys counted.
+//   C  ONE allocation for pool block and keys (a single running sum over the workgroup, two atomics).
+//   D  (sorted layout)  every query takes its leader's words from LDS and stores its record.
+//   E  (leaders, dense)  the profile keys, staged in the dead index span and written in whole lines.
+// What does not fit this scheme is not handled here at all: a tile with a walk that leaves the staged span, runs beyond
+// G2_STEPS entries (a conserved k-mer: the cooperative walk's business) or parks more than G2_OVF segments puts its number on
+// a list before it has written anything, and the host gives the listed tiles to group_kernel<COOP> (tileList).  Semantics as
+// group_kernel: Compare.hpp:747-766 (duplicates join their group), :841-853, :917-955 (markTaxIDs), :922-925 (profile).
+static constexpr int G2_SPAN = 1792;              // index entries staged per tile (the tile's representatives +- GMARGIN: ~520 at C2)
+static constexpr int G2_OVF = 1024;               // parked segments per tile (the default level count; 512 with up to eight levels: LDS)
+static constexpr uint32_t G2_STEPS = 40;          // entries one leader's walk may visit (so that n < 255: 8-bit level sizes)
+
+// two running sums over the workgroup at once (one barrier); sh: 2 * GTHREADS / 64 words
+__device__ __forceinline__ void block_excl_prefix_sum2(uint32_t a, uint32_t b, uint32_t *sh, uint32_t &offA, uint32_t &offB, uint32_t &totA, uint32_t &totB)
+{
+    constexpr int NW = GTHREADS / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ia = wave_incl_sum(a), ib = wave_incl_sum(b);
+    if (lane == 63) { sh[wv] = ia; sh[NW + wv] = ib; }
+    __syncthreads();
+    uint32_t ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const uint32_t x = sh[w], y = sh[NW + w]; if (w < wv) { ba += x; bb += y; } ta += x; tb += y; }
+    offA = ba + ia - a; offB = bb + ib - b; totA = ta; totB = tb;
+}
+
+template <class Key, int NKT>
+__global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
+    const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
+    const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
+    const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
+    uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
+    uint32_t nTaxa, uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
+    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
+    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList)
+{
+    typedef RecTraits<8> RT;
+    constexpr int NL = NKT ? NKT : RT::LEVELS, INL = RT::INL, NW = GTHREADS / 64;
+    typedef typename KeyTraits<Key>::Meta Meta;
+    constexpr int LM = sizeof(Meta) == 1 ? 15 : 255, DS = sizeof(Meta) == 1 ? 4 : 8;
+    constexpr int SPAN_BYTES = G2_SPAN * 4 + (G2_SPAN + 8) * (int)sizeof(Meta);      // (+ the sentinel entry behind the span)
+    __shared__ __attribute__((aligned(16))) unsigned char sRaw[SPAN_BYTES];
+    uint32_t *sTax = reinterpret_cast<uint32_t *>(sRaw);
+    Meta *sMeta = reinterpret_cast<Meta *>(sRaw + G2_SPAN * 4);
+    // per LEADER of the tile (numbered in sorted order):
+    __shared__ uint32_t sA[TILE];                       // its representative index entry; from phase B on word [3] of its record
+    __shared__ uint32_t sDF[TILE];                      // depth | flags << 8 (1 split, 2 saturated) | levels with hits << 16 | run starts << 24
+    __shared__ uint4 sSeg[TILE];                        // the first four segments; [3] = the pool block of a longer list
+    // hits of the groups it heads inside its wavefront and |T| per level, 8 bits per level each: two 64-bit words, or -- six
+    // levels, the default -- 48 + 48 bits in three 32-bit words (the room that saves is the park buffer's second half)
+    constexpr bool PACK6 = NL <= 6;
+    constexpr int OVF = PACK6 ? G2_OVF : G2_OVF / 2;
+    __shared__ uint32_t sHS[(PACK6 ? 3 : 4) * TILE];
+    __shared__ uint2 sOvf[OVF];                         // {segment, leader | place in its pool list << 10}: segments beyond the FOURTH
+    auto putHits = [&](uint32_t L, unsigned long long h) {
+        sHS[L] = (uint32_t)h;
+        if constexpr (PACK6) sHS[TILE + L] = (uint32_t)(h >> 32) & 0xFFFFu; else sHS[TILE + L] = (uint32_t)(h >> 32);
+    };
+    auto getHits = [&](uint32_t L) -> unsigned long long {
+        const uint32_t hi = sHS[TILE + L];
+        return (unsigned long long)sHS[L] | ((unsigned long long)(PACK6 ? (hi & 0xFFFFu) : hi) << 32);
+    };
+    auto putSizes = [&](uint32_t L, unsigned long long c8) {       // (after putHits, by the same thread)
+        if constexpr (PACK6) { sHS[TILE + L] |= (uint32_t)(c8 & 0xFFFFull) << 16; sHS[2 * TILE + L] = (uint32_t)(c8 >> 16); }
+        else { sHS[2 * TILE + L] = (uint32_t)c8; sHS[3 * TILE + L] = (uint32_t)(c8 >> 32); }
+    };
+    auto getSizes = [&](uint32_t L) -> unsigned long long {
+        if constexpr (PACK6) return (unsigned long long)(sHS[TILE + L] >> 16) | ((unsigned long long)sHS[2 * TILE + L] << 16);
+        else return (unsigned long long)sHS[2 * TILE + L] | ((unsigned long long)sHS[3 * TILE + L] << 32);
+    };
+    __shared__ uint32_t shU[2 * NW], sFirst[NW][NL], sRepLo[NW], sRepHi[NW], sLeadN[NW];
+    __shared__ uint32_t sBase, sBaseK, sOvfN, sBail;
+    if (threadIdx.x == 0) { sOvfN = 0u; sBail = 0u; }
+    const int nK = NKT ? NKT : kHigh - kLow + 1;
+    const uint32_t allLv = (1u << nK) - 1u;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * TILE + (uint32_t)t * 2u;
+    // ---- A. sorted layout
+    int d[2];
+    uint32_t rp[2], sp[2], slot[2];
+    {
+        const bool in0 = base < nQ, in1 = base + 1u < nQ;
+        // (all four arrays carry 64 bytes of slack: the pair loads of the last thread stay inside them)
+        const uint32_t dd2 = in0 ? (uint32_t)*reinterpret_cast<const uint16_t *>(depth + base) : 0u;
+        const uint2 rr = in0 ? *reinterpret_cast<const uint2 *>(rep + base) : make_uint2(0u, 0u);
+        uint2 ss = make_uint2(base, base + 1u);
+        if (slotOf && in0) ss = *reinterpret_cast<const uint2 *>(slotOf + base);
+        const Key q0 = in0 ? qKmer[base] : (Key)0, q1 = in1 ? qKmer[base + 1u] : (Key)0;
+        const int ql0 = (!in0 || base == 0u) ? 0 : lcp_letters<Key>(qKmer[base - 1u], q0);
+        const int ql1 = in1 ? lcp_letters<Key>(q0, q1) : 0;
+        d[0] = in0 ? (int)(dd2 & 255u) : 0; d[1] = in1 ? (int)(dd2 >> 8) : 0;
+        rp[0] = in0 ? rr.x : 0u; rp[1] = in1 ? rr.y : 0u;
+        slot[0] = in0 ? ss.x : NOPOS; slot[1] = in1 ? ss.y : NOPOS;
+        sp[0] = in0 ? special_mask(ql0, d[0], kHigh, allLv) : 0u;
+        sp[1] = in1 ? special_mask(ql1, d[1], kHigh, allLv) : 0u;
+    }
+    bool fol[2];
+    {
+        const uint32_t prevRp = (uint32_t)__shfl_up((int)rp[1], 1);
+        const int prevD = __shfl_up(d[1], 1);
+        fol[0] = lane > 0 && d[0] != 0 && d[0] == prevD && rp[0] == prevRp;
+        fol[1] = d[1] != 0 && d[1] == d[0] && rp[1] == rp[0];
+    }
+    const unsigned long long lead0 = __ballot(d[0] != 0 && !fol[0]), lead1 = __ballot(d[1] != 0 && !fol[1]);
+    {   // span of the representatives (nearly monotone in p): first and last matched query of the wavefront
+        const unsigned long long m0 = __ballot(d[0] != 0), m1 = __ballot(d[1] != 0);
+        const unsigned long long any = m0 | m1;
+        uint32_t lo = NOPOS, hi = 0;
+        if (any) {
+            const int lf = __ffsll((long long)any) - 1, ll = 63 - __clzll((long long)any);
+            const uint32_t a0 = __shfl(rp[0], lf), a1 = __shfl(rp[1], lf), b0 = __shfl(rp[0], ll), b1 = __shfl(rp[1], ll);
+            lo = ((m0 >> lf) & 1ull) ? a0 : a1;
+            hi = ((m1 >> ll) & 1ull) ? b1 : b0;
+        }
+        if (lane == 0) { sRepLo[wv] = lo; sRepHi[wv] = hi; sLeadN[wv] = (uint32_t)(__popcll(lead0) + __popcll(lead1)); }
+    }
+    // flush positions F_k(p) (as group_kernel) and, from the same masks, the hits of the groups a query heads
+    const unsigned long long above = (lane == 63) ? 0ull : (~0ull << (lane + 1)), fromMe = ~0ull << lane;
+    uint32_t F[2][NL];
+    uint32_t open0 = 0, open1 = 0;
+    unsigned long long gq[2] = {0ull, 0ull};
+#pragma unroll
+    for (int lv = 0; lv < NL; ++lv) {
+        F[0][lv] = NOPOS; F[1][lv] = NOPOS;
+        if (lv >= nK) continue;
+        const bool s0 = (sp[0] >> lv) & 1u, s1 = (sp[1] >> lv) & 1u;
+        const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1);
+        const unsigned long long any = b0 | b1;
+        uint32_t next = NOPOS;
+        const unsigned long long hi = any & above;
+        if (hi) {
+            const int l2 = __ffsll((long long)hi) - 1;
+            next = tile * TILE + (uint32_t)(wv * 64 + l2) * 2u + (((b0 >> l2) & 1ull) ? 0u : 1u);
+        }
+        F[1][lv] = next;
+        F[0][lv] = s1 ? base + 1u : next;
+        if (next == NOPOS) { open1 |= 1u << lv; if (!s1) open0 |= 1u << lv; }
+        if (lane == 0) {
+            uint32_t first = NOPOS;
+            if (any) { const int l2 = __ffsll((long long)any) - 1; first = tile * TILE + (uint32_t)(wv * 64 + l2) * 2u + (((b0 >> l2) & 1ull) ? 0u : 1u); }
+            sFirst[wv][lv] = first;
+        }
+        if (!(flags & 8)) {
+            // members of the level's group from this query on, if it is the group's first in the wavefront: the group ends at the
+            // next head or the next query that is not matched this deep
+            const int k = kHigh - lv;
+            const bool mem0 = d[0] >= k, mem1 = d[1] >= k;
+            const bool head0 = mem0 && (s0 || lane == 0), head1 = mem1 && s1;
+            const unsigned long long stop0 = __ballot(head0 || !mem0), stop1 = __ballot(head1 || !mem1);
+            const unsigned long long t0 = stop0 & above, t1f = stop1 & fromMe, t1b = stop1 & above;
+            const uint32_t e0 = t0 ? 2u * (uint32_t)(__ffsll((long long)t0) - 1) : 128u;
+            const uint32_t e1f = t1f ? 2u * (uint32_t)(__ffsll((long long)t1f) - 1) + 1u : 128u;
+            const uint32_t e1b = t1b ? 2u * (uint32_t)(__ffsll((long long)t1b) - 1) + 1u : 128u;
+            if (head0) gq[0] |= (unsigned long long)(min(e0, e1f) - 2u * (uint32_t)lane) << (8 * lv);
+            if (head1) gq[1] |= (unsigned long long)(min(e0, e1b) - (2u * (uint32_t)lane + 1u)) << (8 * lv);
+        }
+    }
+    __syncthreads();
+    {   // levels not closed inside the wavefront: the first closing position in the wavefronts behind, else the tiles behind.
+        // Lane lv looks that up for level lv (one short loop per wavefront, not one per lane and level); all take it from there.
+        uint32_t nx = NOPOS;
+        if (lane < nK) {
+            for (int w = wv + 1; w < NW; ++w) { const uint32_t o = sFirst[w][lane]; if (o != NOPOS) { nx = o; break; } }
+            if (nx == NOPOS) nx = tileNext[(size_t)lane * nTiles + tile];
+        }
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)nx, lv);
+            if ((open1 >> lv) & 1u) F[1][lv] = v;
+            if ((open0 >> lv) & 1u) F[0][lv] = v;
+        }
+    }
+    uint32_t spanLo = NOPOS, spanHi = 0, lbase = 0, nLead = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        spanLo = min(spanLo, sRepLo[w]); spanHi = max(spanHi, sRepHi[w]);
+        const uint32_t o = sLeadN[w];
+        if (w < wv) lbase += o;
+        nLead += o;
+    }
+    uint32_t spanN = 0;
+    if (spanLo != NOPOS) {
+        spanLo = spanLo > GMARGIN ? spanLo - GMARGIN : 0u;
+        spanHi = min(spanHi + GMARGIN + 1u, nIdx);
+        spanN = min(spanHi - spanLo, (uint32_t)G2_SPAN);
+        for (uint32_t x = t; x < spanN; x += GTHREADS) { sTax[x] = tax[spanLo + x]; sMeta[x] = meta[spanLo + x]; }
+        if (t == 0) sMeta[spanN] = (Meta)0;                          // the sentinel: shares nothing, ends a walk (which is then reported)
+    }
+    // the tile's leaders, numbered in sorted order: myL = the last leader at or before the query
+    uint32_t myL[2];
+    {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t c0 = (uint32_t)(__popcll(lead0 & below) + __popcll(lead1 & below));
+        const uint32_t isL0 = (uint32_t)((lead0 >> lane) & 1ull), isL1 = (uint32_t)((lead1 >> lane) & 1ull);
+        myL[0] = lbase + c0 + isL0 - 1u;
+        myL[1] = myL[0] + isL1;
+        if (isL0) { sA[myL[0]] = rp[0]; putHits(myL[0], gq[0]); sDF[myL[0]] = (uint32_t)d[0]; }
+        if (isL1) { sA[myL[1]] = rp[1]; putHits(myL[1], gq[1]); sDF[myL[1]] = (uint32_t)d[1]; }
+    }
+    // order of the query's events (rank = events flushed before: smaller F, or equal F and smaller k), Fmax
+    uint32_t fmax[2], w2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        fmax[i] = 0; w2[i] = 0;
+        if (d[i] == 0) continue;
+        const int lvTop = kHigh - d[i];
+        uint32_t rank[NL];
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) rank[lv] = 0;
+#pragma unroll
+        for (int a = 0; a < NL; ++a)
+#pragma unroll
+            for (int b2 = a + 1; b2 < NL; ++b2) {
+                const bool both = a >= lvTop && b2 < nK;
+                const bool aFirst = F[i][a] < F[i][b2];           // a tie goes to b2 (the smaller k)
+                rank[b2] += (both && aFirst) ? 1u : 0u;
+                rank[a] += (both && !aFirst) ? 1u : 0u;
+            }
+        uint32_t fm = 0, ord = 0;
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) {
+            if (lv < lvTop || lv >= nK) continue;
+            const uint32_t f = F[i][lv];
+            if (f > fm) fm = f;
+            ord |= (uint32_t)lv << (RT::OBITS * rank[lv]);
+        }
+        fmax[i] = fm;
+        w2[i] = (uint32_t)d[i] | (ord << 5);
+    }
+    __syncthreads();
+    if (flags & 32) return;                                          // (timing taps 32 / 64 / 128: the kernel up to here)
+    // ---- B. one leader per lane: the walk
+    const int gLow = group_letters(kLow);
+    auto startsOf = [](uint32_t M, uint32_t V, uint32_t B) -> uint32_t { return (B & M) | (V & M & (0u - M)); };
+    uint32_t need[2] = {0u, 0u}, needK[2] = {0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t L = (uint32_t)t + (uint32_t)r * GTHREADS;
+        if (L >= nLead) continue;
+        const uint32_t j = sA[L];
+        const int dd = (int)sDF[L];
+        const unsigned long long hq = getHits(L);
+        uint32_t n = 0;
+        sSeg[L] = make_uint4(0u, 0u, 0u, 0u);                         // (unused segment words of a record are zero)
+        unsigned long long hist = 0, histEnd = 0;                     // segments per LAST level; ends of segments that begin above kLow
+        bool split = false, bad = false;
+        auto metaAt = [&](uint32_t i) -> uint32_t { const uint32_t x = i - spanLo; bad |= x >= spanN; return (uint32_t)sMeta[x < spanN ? x : spanN]; };
+        auto one = [&](uint32_t i, int kLast, uint32_t m) {
+            const int dup = (int)(m >> DS);
+            const int kFirst = dup < RANGE_LETTERS ? kLow : (dup + 1 > kLow ? dup + 1 : kLow);
+            if (kFirst > kLast) return;
+            const uint32_t x = i - spanLo;
+            const uint32_t s = sTax[x < spanN ? x : 0u] | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27);
+            if (n < (uint32_t)INL) reinterpret_cast<uint32_t *>(&sSeg[L])[n] = s;
+            else {                                                     // a list: the fifth and further segments wait for the pool block
+                const uint32_t at = atomicAdd(&sOvfN, 1u);           // (the fourth moves there from the record, by its leader)
+                if (at < (uint32_t)OVF) sOvf[at] = make_uint2(s, L | ((n - (uint32_t)(INL - 1)) << 10));
+            }
+            hist += 1ull << (8 * (kHigh - kLast));
+            if (kFirst > kLow) { split = true; histEnd += 1ull << (8 * (kHigh - kFirst + 1)); }
+            ++n;
+        };
+        {   // the merged walk of walk_segments over the staged span
+            const uint32_t mj = metaAt(j);
+            one(j, dd, mj);
+            const int chain0 = dd > RANGE_LETTERS ? dd : RANGE_LETTERS;
+            uint32_t li = j, ri = j + 1u;
+            uint32_t mri = ri < nIdx ? metaAt(ri) : 0u;
+            int lc = li > 0 ? ((int)(mj & LM) < chain0 ? (int)(mj & LM) : chain0) : -1;
+            int rc = ri < nIdx ? ((int)(mri & LM) < chain0 ? (int)(mri & LM) : chain0) : -1;
+            uint32_t steps = 0;
+            while (lc >= gLow || rc >= gLow) {
+                if (++steps > G2_STEPS) { bad = true; break; }
+                if (lc >= rc) {
+                    --li;
+                    const uint32_t mli = metaAt(li);
+                    one(li, lc < dd ? lc : dd, mli);
+                    const int l = (int)(mli & LM);
+                    lc = li > 0 ? (l < lc ? l : lc) : -1;
+                } else {
+                    one(ri, rc < dd ? rc : dd, mri);
+                    ++ri;
+                    if (ri < nIdx) { mri = metaAt(ri); const int l = (int)(mri & LM); rc = l < rc ? l : rc; } else rc = -1;
+                }
+            }
+        }
+        if (bad) atomicOr(&sBail, n > G2_STEPS / 2 ? 1u : 2u);          // (1: a long list; 2: a walk that left the staged span)
+        // |T_k| = segments whose last level is k or deeper, less those that begin above k: running sums over the byte fields
+        unsigned long long cnt8 = hist * 0x0101010101010101ull;
+        if (split) cnt8 -= histEnd * 0x0101010101010101ull;
+        uint32_t nlev = 0, V = 0, B = 0, pn = 0, pg = 0;
+#pragma unroll
+        for (int lv = 0; lv < NL; ++lv) {
+            const uint32_t c = (uint32_t)(cnt8 >> (8 * lv)) & 255u, h = (uint32_t)(hq >> (8 * lv)) & 255u;
+            nlev |= (c < 7u ? c : 7u) << (3 * lv);
+            if (h) { V |= 1u << lv; if (!(pg == h && pn == c)) B |= 1u << lv; }   // a run of levels with the same (|T|, hits): one key
+            pn = c; pg = h;                                           // (pg = 0 after a level without hits: the next one begins a run)
+        }
+        const bool sat = (nlev & (nlev >> 1) & (nlev >> 2) & 0x249249u) != 0u;
+        sA[L] = (n & 255u) | (nlev << 8);
+        sDF[L] = (uint32_t)dd | (split ? 0x100u : 0u) | (sat ? 0x200u : 0u) | (V << 16) | (B << 24);
+        putSizes(L, cnt8);
+        if (n > (uint32_t)INL) need[r] = n - (uint32_t)(INL - 1) + 1u + (sat ? POOL_SIZES : 0u);
+        if (V) {                                                      // its own keys: the segments of the record (a list's further ones: phase C)
+            const uint4 sg = sSeg[L];
+            const uint32_t inl = n <= (uint32_t)INL ? n : (uint32_t)INL;   // (a list's fourth segment is still in the record's place)
+            uint32_t k = 0;
+            if (inl > 0u) k += (uint32_t)__popc(startsOf(seg_level_mask(sg.x, kHigh), V, B));
+            if (inl > 1u) k += (uint32_t)__popc(startsOf(seg_level_mask(sg.y, kHigh), V, B));
+            if (inl > 2u) k += (uint32_t)__popc(startsOf(seg_level_mask(sg.z, kHigh), V, B));
+            if (inl > 3u) k += (uint32_t)__popc(startsOf(seg_level_mask(sg.w, kHigh), V, B));
+            needK[r] = k;
+        }
+    }
+    __syncthreads();
+    if (flags & 64) return;
+    const uint32_t nOvf = sOvfN;
+    if (sBail != 0u || nOvf > (uint32_t)OVF) {                    // (uniform) nothing has left the workgroup yet: the tile is group_kernel's
+        if (t == 0) slowList[atomicAdd(slowCount, 1u)] = tile | (sBail << 28) | (nOvf > (uint32_t)OVF ? 4u << 28 : 0u);   // (why: diagnostics)
+        return;
+    }
+    // ---- C. one allocation: pool blocks and keys
+    uint32_t nkPark = 0;
+    for (uint32_t x = t; x < nOvf; x += GTHREADS) {
+        const uint2 e = sOvf[x];
+        const uint32_t o = e.y & 1023u;
+        const uint32_t df = sDF[o];
+        nkPark += (uint32_t)__popc(startsOf(seg_level_mask(e.x, kHigh), (df >> 16) & 255u, df >> 24));
+    }
+    uint32_t offP, offK, totP, totK;
+    block_excl_prefix_sum2(need[0] + need[1], needK[0] + needK[1] + nkPark, shU, offP, offK, totP, totK);
+    if (t == 0) {
+        sBase = NOPOS;
+        if (totP) { const unsigned long long at = atomicAdd(poolCursor, (unsigned long long)totP); if (at + totP <= (unsigned long long)poolCap) sBase = (uint32_t)at; }
+    }
+    if (t == 64) {
+        sBaseK = NOPOS;
+        if (totK) { const unsigned long long at = atomicAdd(keyCursor, (unsigned long long)totK); if (at + totK <= (unsigned long long)keyCap) sBaseK = (uint32_t)at; }
+    }
+    // a list's place inside the workgroup's pool block is known before the block's own place is: it goes into the leader's
+    // words now, so that ONE barrier serves both (the block's base is added where the word is used)
+    uint32_t sFourth[2] = {0u, 0u}, relP[2] = {0u, 0u};               // (a list's fourth segment: its keys are its leader's)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t L = (uint32_t)t + (uint32_t)r * GTHREADS;
+        if (L >= nLead || need[r] == 0u) continue;
+        sFourth[r] = sSeg[L].w;
+        relP[r] = offP;
+        reinterpret_cast<uint32_t *>(&sSeg[L])[INL - 1] = offP;
+        offP += need[r];
+    }
+    __syncthreads();
+    const bool fits = sBase != NOPOS;
+    const uint32_t poolBase = fits ? sBase : 0u;
+    if (fits) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t L = (uint32_t)t + (uint32_t)r * GTHREADS;
+            if (L >= nLead || need[r] == 0u) continue;
+            const uint32_t at = poolBase + relP[r];
+            const bool sat = (sDF[L] & 0x200u) != 0u;
+            pool[at] = sA[L] & 255u;
+            if (sat) {
+                const unsigned long long c8 = getSizes(L);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pool[at + 1u + (uint32_t)q] = ((uint32_t)(c8 >> (16 * q)) & 255u) | (((uint32_t)(c8 >> (16 * q + 8)) & 255u) << 16);
+            }
+            pool[at + 1u + (sat ? POOL_SIZES : 0u)] = sFourth[r];    // the list's first segment of the pool block
+        }
+    }
+    // ---- D. sorted layout: the records
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (slot[i] == NOPOS) continue;
+        uint4 o0 = make_uint4(base + (uint32_t)i, fmax[i], w2[i], 0u), o1 = make_uint4(0u, 0u, 0u, 0u);
+        if (d[i] != 0) {
+            const uint32_t df = sDF[myL[i]];
+            o0.w = sA[myL[i]];
+            o0.z |= ((df & 0x100u) ? REC_SPLIT : 0u) | ((df & 0x200u) ? REC_SAT : 0u);
+            o1 = sSeg[myL[i]];
+            if ((o0.w & 255u) > (uint32_t)INL) o1.w += poolBase;     // (a list: [3] = its pool block)
+        }
+        uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot[i] * 8u);
+        o[0] = o0; o[1] = o1;
+    }
+    if (fits)
+        for (uint32_t x = t; x < nOvf; x += GTHREADS) {
+            const uint2 e = sOvf[x];
+            const uint32_t o = e.y & 1023u;
+            pool[poolBase + sSeg[o].w + 1u + ((sDF[o] & 0x200u) ? POOL_SIZES : 0u) + (e.y >> 10)] = e.x;
+        }
+    // ---- E. the profile keys (as group_kernel: one key {levels, |T|, taxon, hits} per run of levels of a segment)
+    if (totK == 0u || sBaseK == NOPOS || (flags & 128)) return;      // (uniform)
+    constexpr uint32_t KSTAGE = (uint32_t)(SPAN_BYTES / 8);
+    const bool staged = totK <= KSTAGE;
+    unsigned long long *sKeys = reinterpret_cast<unsigned long long *>(sRaw);   // the index span is dead
+    uint32_t kw = offK + (staged ? 0u : sBaseK);
+    auto cutRuns = [&](uint32_t sg, uint32_t V, uint32_t B, unsigned long long hq, unsigned long long c8) {
+        const uint32_t M = seg_level_mask(sg, kHigh);
+        uint32_t starts = (B & M) | (V & M & (0u - M));
+        const uint32_t stops = (B | ~V) & M;                         // a run ends before the next run's start, a level without hits, or with the segment
+        while (starts) {
+            const int lo = __ffs((int)starts) - 1;
+            starts &= starts - 1u;
+            const uint32_t beyond = stops & ~((2u << lo) - 1u);
+            const int hi = beyond ? __ffs((int)beyond) - 2 : 31 - __clz((int)M);
+            const uint32_t n = (uint32_t)(c8 >> (8 * lo)) & 255u, hits = (uint32_t)(hq >> (8 * lo)) & 255u, tx = sg & SEG_TAX_MASK;
+            if (flags & 16) { ++kw; continue; }
+            // (|T| <= G2_STEPS + 1 and < nTaxa: it always fits the key's field of min(tb, 13) bits -- no straight-to-the-tables path here)
+            const unsigned long long key = group_key((uint32_t)lo, (uint32_t)hi, n, tx, hits);
+            if (staged) sKeys[kw++] = key; else profKeys[kw++] = key;
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t L = (uint32_t)t + (uint32_t)r * GTHREADS;
+        if (L >= nLead || needK[r] == 0u) continue;
+        const uint32_t df = sDF[L], V = (df >> 16) & 255u, B = df >> 24;
+        const unsigned long long hq = getHits(L), c8 = getSizes(L);
+        const uint4 sg = sSeg[L];
+        const uint32_t n = sA[L] & 255u, w4 = n > (uint32_t)INL ? sFourth[r] : sg.w, nn = n < (uint32_t)INL ? n : (uint32_t)INL;
+#pragma unroll 1
+        for (uint32_t q = 0; q < nn; ++q) cutRuns(q == 0u ? sg.x : q == 1u ? sg.y : q == 2u ? sg.z : w4, V, B, hq, c8);   // (one copy of the loop body: code size)
+    }
+    for (uint32_t x = t; x < nOvf; x += GTHREADS) {
+        const uint2 e = sOvf[x];
+        const uint32_t o = e.y & 1023u;
+        const uint32_t df = sDF[o];
+        if ((df >> 16) & 255u) cutRuns(e.x, (df >> 16) & 255u, df >> 24, getHits(o), getSizes(o));
+    }
+    if (staged && !(flags & 16)) {                                   // (uniform)
+        __syncthreads();
+        for (uint32_t x = t; x < totK; x += GTHREADS) profKeys[(size_t)sBaseK + x] = sKeys[x];
     }
 }
 
@@ -4606,26 +5068,45 @@ static int slots_from_reads(kasa_ctx *c)
 }
 
 template <int RW>
-static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, bool coop)
+static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, bool coop,
+                        const uint32_t *tileList = nullptr, uint32_t nListed = 0)
 {
     const uint64_t nQ = c->nQ;
     uint32_t *needCoop = reinterpret_cast<uint32_t *>(cursor + 3);        // (misc word [19]: free during the kernel)
+    const uint32_t grid = tileList ? nListed : nTiles;                    // (a list: only the tiles group2_kernel left over)
 #define KASA_GROUP_ARGS(KEY, META) c->keys<KEY>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ, \
         c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
         c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa, \
-        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), needCoop
+        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), needCoop, tileList
     if (c->ix->wide && RW == 16 && c->nK == 19)                       // the default -k 25 7 of a 128-bit index: loops over exactly 19 levels
-        group_kernel<RW, key128, RW == 16 ? 19 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
+        group_kernel<RW, key128, RW == 16 ? 19 : 0><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
     else if (c->ix->wide)
-        group_kernel<RW, key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
+        group_kernel<RW, key128, 0><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
     else if (RW == 8 && c->nK == 6) {                                // the default -k 12 7: loops over exactly six levels
-        if (coop) group_kernel<RW, uint64_t, RW == 8 ? 6 : 0, RW == 8><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
-        else group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+        if (coop) group_kernel<RW, uint64_t, RW == 8 ? 6 : 0, RW == 8><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+        else group_kernel<RW, uint64_t, RW == 8 ? 6 : 0><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
     } else if (coop && RW == 8)
-        group_kernel<RW, uint64_t, 0, RW == 8><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+        group_kernel<RW, uint64_t, 0, RW == 8><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
     else
-        group_kernel<RW, uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
+        group_kernel<RW, uint64_t, 0><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(uint64_t, uint8_t));
 #undef KASA_GROUP_ARGS
+    HIPCHK(hipGetLastError());
+    return KASA_OK;
+}
+
+// group2_kernel over all tiles (narrow records); the tiles it lists are the caller's to give to group_kernel
+static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, uint32_t *slowCount)
+{
+    const uint64_t nQ = c->nQ;
+#define KASA_GROUP2_ARGS(KEY, META) c->keys<KEY>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ, \
+        c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
+        c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->ix->nTaxa, \
+        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), \
+        slowCount, c->tileList.as<uint32_t>()
+    if (c->ix->wide) group2_kernel<key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
+    else if (c->nK == 6) group2_kernel<uint64_t, 6><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));   // the default -k 12 7
+    else group2_kernel<uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+#undef KASA_GROUP2_ARGS
     HIPCHK(hipGetLastError());
     return KASA_OK;
 }
@@ -4850,20 +5331,46 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
         HIPCHK(hipMemcpyAsync(cursor + 2, &zero, 8, hipMemcpyHostToDevice, c->stream));
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
         const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
-        const int cov = ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
+        static const int g2tap = getenv("KASA_G2_TAP") ? atoi(getenv("KASA_G2_TAP")) : 0;   // (timing taps of group2_kernel: 32, 64, 128)
+        const int cov = (g2tap & (32 | 64 | 128)) | ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;
-        HIPCHK(hipMemcpyAsync(cursor + 3, &zero, 8, hipMemcpyHostToDevice, c->stream));   // "a list too long for the lean kernel"
+        HIPCHK(hipMemcpyAsync(cursor + 3, &zero, 8, hipMemcpyHostToDevice, c->stream));   // "a list too long for the lean kernel" | tiles group2_kernel lists << 32
         if (c->debugFlags & 262144) c->groupCoop = true;                   // (test tap 262144: the cooperative form from the first batch on)
         const bool coop = c->groupCoop && !(c->debugFlags & 131072);       // (test tap 131072: never the cooperative form)
-        if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;
+        // narrow records: group2_kernel (leaders dense on the lanes) takes every ordinary tile and LISTS the others -- long taxon
+        // lists, walks beyond its staged index span -- for group_kernel's cooperative form.  Not for a context whose batches are
+        // mostly such tiles (groupCoop), not with --coverage, not under the test taps of the older kernel (16777216: never).
+        const bool g2 = RW == 8 && !coop && !(cov & 1) && !(c->debugFlags & (16777216 | 2048 | 131072));
+        unsigned long long used[4] = {0, 0, 0, 0};
+        if (g2) {
+            if ((rc = c->tileList.reserve((size_t)nTiles * 4 + 64))) return rc;
+            if ((rc = launch_group2(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, reinterpret_cast<uint32_t *>(cursor + 3) + 1))) return rc;
+            HIPCHK(hipMemcpyAsync(used, cursor, 32, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            const uint32_t nListed = (uint32_t)(used[3] >> 32);
+            c->lastSlowTiles = nListed;
+            if (nListed && getenv("KASA_DEBUG_WHY")) {
+                std::vector<uint32_t> h(nListed);
+                HIPCHK(hipMemcpy(h.data(), c->tileList.p, (size_t)nListed * 4, hipMemcpyDeviceToHost));
+                uint32_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t x : h) why[(x >> 28) & 7u]++;
+                fprintf(stderr, "[kasa] group2 left %u of %u tiles: long list %u, span %u, both %u, parked only %u, parked + long %u, parked + span %u, all %u\n",
+                        nListed, nTiles, why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
+            }
+            if (nListed && (rc = launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, true, c->tileList.as<uint32_t>(), nListed))) return rc;
+            if ((uint64_t)nListed * 4 > nTiles) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to group_kernel<COOP> directly
+        } else {
+            c->lastSlowTiles = 0;
+            if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;
+        }
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_GROUP], ka, kb))) return rc;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
-        unsigned long long used[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(used, cursor, 32, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (RW == 8 && !coop && !(c->debugFlags & 131072) && ((used[3] & 1ull) || used[0] > 6ull * nQ)) {
+        if (g2 && (used[3] & 1ull)) return fail(KASA_E_LIMIT, "a query meets 255 or more taxa of a 128-bit index through narrow records; use the index's own k range");
+        if (RW == 8 && !g2 && !coop && !(c->debugFlags & 131072) && ((used[3] & 1ull) || used[0] > 6ull * nQ)) {
             // a list of 255 or more segments (the lean kernel cannot count it), or long lists on average: whole wavefronts
             // take the long lists from here on -- this batch again if it must be, the context's further batches anyway
             c->groupCoop = true;
@@ -4877,7 +5384,12 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
     }
     // the profile of the batch: the leaders' keys into the tables (the per-read score stage adds nothing to them)
     if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
-    if (RW == 8 && (rc = profile_from_keys(c, nKeys, true))) return rc;
+    {
+        hipEvent_t ka, kb;
+        if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_PROFILE_TABLES], &ka, &kb))) return rc;
+        if (RW == 8 && (rc = profile_from_keys(c, nKeys, true))) return rc;
+        if ((rc = timer_end(c, c->kernels[KASA_KERNEL_PROFILE_TABLES], ka, kb))) return rc;
+    }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_GROUP], a, b))) return rc;
     c->lastKeys = nKeys;
     c->grouped = true;
@@ -4929,7 +5441,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             if ((rc = c->rowOff.reserve(((size_t)nReads + 1) * 8))) return rc;
             HIPCHK(hipMemsetAsync(c->rowOff.p, 0, ((size_t)nReads + 1) * 8, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
-            c->haveScores = true;
+            c->haveScores = true; c->csrPacked = true;
         }
         c->state = 4;
         return KASA_OK;
@@ -5032,6 +5544,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             nKeys = gp ? 0 : want[1];
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
+        hipEvent_t ga = nullptr, gb = nullptr;
+        if (nSlow > 0 && (rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], &ga, &gb))) return rc;
         if (nSlow > 0) {
             // flush positions of the listed reads' queries (the records hold only the order inside a query)
             const uint64_t *flushOff = c->kmerOff.as<uint64_t>();
@@ -5140,6 +5654,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             }
             c->lastOverflowReads = std::max(c->lastOverflowReads, nOver);   // over the staging retries of this batch
             slowProfileDone = true;
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], ga, gb))) return rc;
         }
         c->lastSlowReads = nSlow;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
@@ -5181,7 +5696,12 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipGetLastError());
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_MERGE], ka, kb))) return rc;
         c->lastStaged = staged;
-        if (!gp) { c->lastKeys = nKeys; if ((rc = profile_from_keys(c, nKeys, false))) return rc; }
+        if (!gp) {
+            c->lastKeys = nKeys;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_PROFILE_TABLES], &ka, &kb))) return rc;
+            if ((rc = profile_from_keys(c, nKeys, false))) return rc;
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_PROFILE_TABLES], ka, kb))) return rc;
+        }
         mergePending = true;
     }
     if (wantPerRead) {
@@ -5189,6 +5709,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         if (!mergePending && (rc = timer_begin(c, c->timers[KASA_STAGE_SCORE], &a, &b))) return rc;
         DevBuf &len64 = c->qReadA; // reuse
         if ((rc = len64.reserve(((size_t)nReads + 1) * 8 + 64))) return rc;
+        hipEvent_t ca, cb;
+        if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_ROW_COPY], &ca, &cb))) return rc;
         HIPCHK(hipMemsetAsync(len64.p, 0, ((size_t)nReads + 1) * 8, c->stream));
         widen_kernel<<<blocks_for(nReads, 256), 256, 0, c->stream>>>(c->rowLen.as<uint32_t>(), len64.as<uint64_t>(), nReads);
         size_t tmpBytes = 0;
@@ -5201,10 +5723,11 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipMemcpyAsync(&nnz, c->rowOff.as<uint64_t>() + nReads, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->nnz = nnz;
-        if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
-        row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
-            nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
-        HIPCHK(hipGetLastError());
+        // The rows stay where the score kernels left them ({taxon, score} pairs in the staging buffer, row r at rowPos[r], rowOff
+        // = the running sum of their lengths): kasa_batch_rank reads them there.  Only a host that asks for the whole CSR
+        // (kasa_batch_scores_fetch) has them packed into two arrays first (csr_pack: the copy every batch paid until round 4).
+        c->csrPacked = false;
+        if ((rc = timer_end(c, c->kernels[KASA_KERNEL_ROW_COPY], ca, cb))) return rc;
     }
     if (mergePending || wantPerRead) { if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc; }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -5501,11 +6024,27 @@ extern "C" int kasa_batch_scores_size(kasa_ctx *c, uint64_t *nnz)
     return KASA_OK;
 }
 
+// the batch's rows packed into the CSR arrays (read order), once per batch and only when somebody wants them
+static int csr_pack(kasa_ctx *c)
+{
+    if (c->csrPacked || c->nnz == 0 || c->nReads == 0) { c->csrPacked = true; return KASA_OK; }
+    int rc;
+    if ((rc = c->outTax.reserve(c->nnz * 4 + 64)) || (rc = c->outScore.reserve(c->nnz * 4 + 64))) return rc;
+    const uint32_t nReads = (uint32_t)c->nReads;
+    row_copy_kernel<<<std::min<unsigned>(blocks_for(nReads, 4), 256u * 8u), 256, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(), c->rowOff.as<uint64_t>(),
+        nReads, c->st.as<uint2>(), c->outTax.as<uint32_t>(), c->outScore.as<float>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->csrPacked = true;
+    return KASA_OK;
+}
+
 extern "C" int kasa_batch_scores_fetch(kasa_ctx *c, uint64_t *readOffsets, uint32_t *taxIdx, float *score)
 {
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (!c->haveScores) return fail(KASA_E_STATE, "kasa_batch_scores_fetch: no per-read scores");
     HIPCHK(hipSetDevice(c->ix->device));
+    if (taxIdx || score) { const int rc = csr_pack(c); if (rc) return rc; }
     if (readOffsets) HIPCHK(hipMemcpy(readOffsets, c->rowOff.p, ((size_t)c->nReads + 1) * 8, hipMemcpyDeviceToHost));
     if (c->nnz && taxIdx) HIPCHK(hipMemcpy(taxIdx, c->outTax.p, c->nnz * 4, hipMemcpyDeviceToHost));
     if (c->nnz && score) HIPCHK(hipMemcpy(score, c->outScore.p, c->nnz * 4, hipMemcpyDeviceToHost));
@@ -5529,7 +6068,8 @@ static constexpr int RANK_FIRST = 12;   // leading positions rank_exact_kernel's
 // that brings more wavefronts to a CU (classes by hit count: <= 32, <= 64, <= 128, more)
 __host__ __device__ inline int rank_exact_class(uint32_t cnt) { return cnt <= 32u ? 0 : cnt <= 64u ? 1 : cnt <= 128u ? 2 : 3; }
 struct RankEntry { uint32_t tax; float score; double rel; };
-__global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
+// (rows: where the score stage left them -- {taxon, score} pairs in the staging buffer at rowPos[r]; rowOff = their running sum)
+__global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ rowOff, const uint32_t *__restrict__ rowPos, const uint2 *__restrict__ rows,
                                                    uint32_t nReads, const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
                                                    double thr, uint32_t beasts, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
                                                    unsigned long long cap, unsigned long long *__restrict__ cursor, uint32_t *__restrict__ nFlagged,
@@ -5551,6 +6091,7 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
     for (uint32_t r = blockIdx.x * 4u + wv; r < nReads; r += gridDim.x * 4u) {
         const uint64_t lo = rowOff[r];
         const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
+        const uint2 *__restrict__ row = rows + rowPos[r];
         const double *dr = den + (size_t)readClass[r] * nTaxa;
         uint32_t cnt = 0;
         float maxV = 0.0f;
@@ -5558,7 +6099,8 @@ __global__ __launch_bounds__(256) void rank_kernel(const uint64_t *__restrict__ 
             const uint32_t i = c0 + lane;
             bool ok = false; float sc = 0.0f; uint32_t t = 0; double rel = 0.0;
             if (i < m) {
-                sc = rowScore[lo + i]; t = rowTax[lo + i];
+                const uint2 e = row[i];
+                sc = __uint_as_float(e.y); t = e.x;
                 rel = (double)sc / dr[t];                                     // Compare.hpp:1506-1511, the denominator is the host's
                 ok = sc > 0.0f && rel >= thr;
             }
@@ -5732,7 +6274,7 @@ struct LaneStack {
 __host__ __device__ constexpr int rank_exact_stack_cap(int rows) { int lg = 0; while ((rows >> (lg + 1)) != 0) ++lg; return 2 * lg + 2; }
 template <int ROWS>
 __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ rowOff,
-                                                        const uint32_t *__restrict__ rowTax, const float *__restrict__ rowScore,
+                                                        const uint32_t *__restrict__ rowPos, const uint2 *__restrict__ rows,
                                                         const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
                                                         double thr, uint32_t beasts, RankEntry *__restrict__ hits, uint16_t *__restrict__ keyS,
                                                         uint16_t *__restrict__ idS, uint4 *__restrict__ meta, RankEntry *__restrict__ entries,
@@ -5767,8 +6309,9 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
             const double *dr = den + (size_t)readClass[r] * nTaxa;
             uint32_t n = 0;
             for (uint32_t i = 0; i < m; ++i) {
-                const float sc = rowScore[lo + i];
-                const uint32_t t = rowTax[lo + i];
+                const uint2 e = rows[(size_t)rowPos[r] + i];
+                const float sc = __uint_as_float(e.y);
+                const uint32_t t = e.x;
                 const double rel = (double)sc / dr[t];
                 if (sc > 0.0f && rel >= thr) { hits[lo + n] = RankEntry{t, sc, rel}; idS[lo + n] = (uint16_t)n; ++n; }
             }
@@ -5857,7 +6400,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
         RankEntry *handOver = exact ? scratch->as<RankEntry>() : nullptr;
         uint16_t *handKey = exact ? reinterpret_cast<uint16_t *>(handOver + c->nnz) : nullptr, *idS = handKey ? handKey + c->nnz : nullptr;
         const unsigned blocks = std::min<unsigned>(blocks_for(nReads, 4), 256u * 32u);
-        rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->outTax.as<uint32_t>(), c->outScore.as<float>(), nReads,
+        rank_kernel<<<blocks, 256, 0, c->stream>>>(c->rowOff.as<uint64_t>(), c->rowPos.as<uint32_t>(), c->st.as<uint2>(), nReads,
                                                    c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts,
                                                    c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged, handOver, handKey, nClass);
         HIPCHK(hipGetLastError());
@@ -5887,7 +6430,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
                 const uint32_t nCl = hClass[cl];
                 if (nCl == 0) continue;
 #define KASA_RANK_EXACT(ROWS) rank_exact_kernel<ROWS><<<blocks_for(nCl, RANK_EXACT_LANES), RANK_EXACT_LANES, 0, c->stream>>>(list1 + from, nCl, c->rowOff.as<uint64_t>(), \
-                c->outTax.as<uint32_t>(), c->outScore.as<float>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts, \
+                c->rowPos.as<uint32_t>(), c->st.as<uint2>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts, \
                 handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged)
                 if (c->debugFlags & 1048576) KASA_RANK_EXACT(RANK_ROWS);   // (test tap: every class in the largest form)
                 else if (cl == 0) KASA_RANK_EXACT(32);
@@ -6730,6 +7273,14 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
         (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))
         return rc;
     (void)wantPerRead;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_group_tiles(kasa_ctx *c, uint32_t *tiles, uint32_t *listed)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (tiles) *tiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
+    if (listed) *listed = c->lastSlowTiles;
     return KASA_OK;
 }
 

@@ -58,8 +58,13 @@ def main():
             ctx.synchronize()
             dt = (time.perf_counter() - t0) / args.steps
             st = {k: round(v[0] / max(1, v[1]), 3) for k, v in ctx.stage_ms().items()}
-            print(json.dumps({"flags": fl, "ms_per_step_wall": round(dt * 1e3, 2), "stage_ms": st, "profile_same_as_flags0": same}), flush=True)
+            km = {k: round(v[0] / max(1, v[1]), 3) for k, v in ctx.kernel_ms().items() if v[1]}
+            print(json.dumps({"flags": fl, "ms_per_step_wall": round(dt * 1e3, 2), "stage_ms": st, "kernel_ms": km, "group_tiles": ctx.group_tiles(),
+                              "profile_same_as_flags0": same}), flush=True)
     ctx.debug_flags(0)
+    if not args.rank_flags:
+        ctx.close(); dix.close()
+        return
     step()
     den, rclass = report.rank_denominators(ix.freq_at(12), reads.lengths, ix.K, False)
     den = np.ascontiguousarray(den, dtype=np.float64)
