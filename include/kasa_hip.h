@@ -316,7 +316,8 @@ enum {
     KASA_KERNEL_ROW_COPY = 7,     /* row lengths -> CSR offsets (scan) + row_copy_kernel */
     KASA_KERNEL_SORT_PASSES = 8,  /* kasa_radix: hist_kernel + the radix passes of the query sort */
     KASA_KERNEL_BUCKET_RANK = 9,  /* bucket_rank*_kernel: the query sort's last step */
-    KASA_KERNEL_COUNT = 10
+    KASA_KERNEL_SCORE_DENSE = 10, /* score_dense_kernel: reads with long rows that keep the fast kernels' order rule (crowded indices) */
+    KASA_KERNEL_COUNT = 11
 };
 int kasa_ctx_kernel_ms(kasa_ctx *ctx, int kernel, double *ms, uint64_t *launches);
 /* Of the last batch: {queries, staging records, profile keys, pool words, reads on the general kernel, of those on its
@@ -326,6 +327,10 @@ int kasa_ctx_batch_stats(kasa_ctx *ctx, uint64_t *stats8);
  * (group2_kernel) left to the general one -- tiles with long taxon lists (Compare.hpp:396-441, a conserved k-mer) or walks
  * beyond its staged index span; 0 when the general kernel ran alone. */
 int kasa_ctx_group_tiles(kasa_ctx *ctx, uint32_t *tiles, uint32_t *listed);
+/* Of the last batch's score stage: the reads score_dense_kernel scored -- reads with long rows (many taxa per k-mer:
+ * Compare.hpp:396-441) whose groups all close before the read's next matched query, replayed query by query from the row in
+ * LDS; the others of the fast kernels' leftovers are the general kernel's (kasa_ctx_counters). */
+int kasa_ctx_dense_reads(kasa_ctx *ctx, uint32_t *denseReads);
 /* Number of query records the batch holds right now: the k-mer count of kasa_batch_encode, less the
  * duplicates once kasa_batch_sort_and_range ran with unique != 0. */
 int kasa_batch_query_count(kasa_ctx *ctx, uint64_t *n);

@@ -36,7 +36,10 @@ HOST_BIN = os.path.join(HERE, "host", "kasa_identify")
 
 
 def build_host(force: bool = False) -> str:
-    """The C++ host driver (kASA's `identify` CLI over the C ABI)."""
+    """The C++ host driver (kASA's `identify` CLI over the C ABI).  KASA_IDENTIFY: another build of it (tools/asan_run.sh)."""
+    other = os.environ.get("KASA_IDENTIFY")
+    if other and os.path.exists(other):
+        return other
     build()
     newest = max(os.path.getmtime(p) for p in (HOST_SRC, HEADER, os.path.join(HERE, "host", "grisu_powers.inc")))
     if not force and os.path.exists(HOST_BIN) and os.path.getmtime(HOST_BIN) >= newest:

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libkasa_hip.so")
+# KASA_LIB: another build of the same library (tools/asan_run.sh: the host half compiled with -fsanitize=address,undefined)
+SO_PATH = os.environ.get("KASA_LIB") or os.path.join(_HERE, "libkasa_hip.so")
 _lib = None
 
 STAGES = ("encode", "sort", "lookup", "group", "regroup", "score")
@@ -29,7 +30,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads",
 ]
 
 
@@ -633,7 +634,7 @@ class Context:
         _check(lib().kasa_ctx_stage_reset(self.h))
 
     KERNELS = ("lookup_tile_kernel", "group_kernel", "score_main_kernel", "score_other_kernel", "row_merge_kernel",
-               "score_general_kernels", "profile_table_kernels", "row_copy_kernels", "sort_pass_kernels", "bucket_rank_kernel")
+               "score_general_kernels", "profile_table_kernels", "row_copy_kernels", "sort_pass_kernels", "bucket_rank_kernel", "score_dense_kernel")
 
     def kernel_ms(self):
         """HIP-event time of single kernels alone since stage_reset(): {name: (ms, launches)}."""
@@ -656,6 +657,9 @@ class Context:
         keys = ("queries", "staging_records", "profile_keys", "pool_words", "general_reads", "second_pass_reads", "nnz", "encoder_ranked")
         out = {k: int(v) for k, v in zip(keys, st)}
         out["group_tiles"], out["group_tiles_listed"] = self.group_tiles()
+        n = C.c_uint32(0)
+        _check(lib().kasa_ctx_dense_reads(self.h, C.byref(n)))
+        out["dense_reads"] = int(n.value)
         return out
 
     def group_tiles(self):

@@ -549,6 +549,8 @@ struct kasa_ctx {
     bool payloadIsSlot = false;                // what the encoder gave the sort as payload: slots (ranked reads) or read ids
     DevBuf flushOff, flushPos, flushOff2, flushPos2;   // general score kernel: flush positions of the listed reads' queries
     DevBuf ovList;                             // reads the first general pass hands to the second
+    DevBuf fbList2;                            // reads score_dense_kernel hands to the general kernel
+    uint32_t lastDenseReads = 0;               // reads of the last batch score_dense_kernel kept
     DevBuf ovList2, gwin;                      // ... the second to the third (narrow records); the third pass's pending windows
     uint32_t lastThirdPassReads = 0;
     uint32_t lastOverflowReads = 0;
@@ -572,7 +574,7 @@ struct kasa_ctx {
     std::vector<DevBuf *> buffers()
     {
         return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds, &tileList,
-                &tileChunks, &rec, &pool, &plist, &sortTmp, &slotBuf, &recIn, &flushOff, &flushPos, &flushOff2, &flushPos2, &misc, &scratch, &ovList, &ovList2,
+                &tileChunks, &rec, &pool, &plist, &sortTmp, &slotBuf, &recIn, &flushOff, &flushPos, &flushOff2, &flushPos2, &misc, &scratch, &ovList, &ovList2, &fbList2,
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
                 &rankList, &rankScratch, &scanTmp, &taxText, &taxTextOff, &taxTextIds, &txtNames, &txtNameOff, &txtLen, &txtBest, &txtBytes, &txtOff, &txtOut,
@@ -2825,7 +2827,7 @@ __device__ __forceinline__ void block_excl_prefix_sum2(uint32_t a, uint32_t b, u
 }
 
 template <class Key, int NKT>
-__global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
+__device__ __forceinline__ void group2_tile(const uint32_t tile,
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
     const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
@@ -2874,7 +2876,6 @@ __global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
     const int nK = NKT ? NKT : kHigh - kLow + 1;
     const uint32_t allLv = (1u << nK) - 1u;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint32_t tile = blockIdx.x;
     const uint32_t base = tile * TILE + (uint32_t)t * 2u;
     // ---- A. sorted layout
     int d[2];
@@ -3707,6 +3708,159 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 //
 // Neither kernel touches the profile tables: everything leaves as records, so both can be rerun.
 // ------------------------------------------------------------------------------------------------
+
+// A workgroup takes tiles gridDim.x apart.  The product launches one workgroup per tile.  (Tried, KASA_G2_GRID: persistent
+// workgroups, three per CU, so that a tile's 1024 scattered record stores -- what bounds the stage, tools/scatter_probe.hip --
+// drain while the workgroup computes its next tile: 71.7 ms against 63.7 at C2.  The hardware's own scheduler of fresh
+// workgroups overlaps the phases better than a loop with a barrier at every tile's end.)
+template <class Key, int NKT>
+__global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
+    const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
+    const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
+    const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
+    uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
+    uint32_t nTaxa, uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
+    uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
+    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList)
+{
+    for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        group2_tile<Key, NKT>(tile, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
+                              nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList);
+        __syncthreads();                                              // (the tile's LDS is the next tile's)
+    }
+}
+
+// Reads with LONG ROWS that keep the fast kernels' rule -- every group of a query is closed before the read's next matched
+// query (Fmax <= p of the next) -- need no pending window: a query's events go to the row in the record's own order.  With a
+// crowded index (conserved genes in clades of 50-200 taxa) a third of the reads are such: their staging rows would exceed
+// RMAX records, score_main_kernel hands them over, and the general kernel replayed them event by event through its sorted
+// window at ~1000 wavefront instructions per query.  Here: one wavefront per read, the read's row (nTaxa floats) in LDS, a
+// query's segments dealt out to the lanes 64 at a time; a lane owns ITS segment's taxon for the query -- one LDS read of the
+// cell, the query's events in flush order added in a register (a taxon's float chain only ever meets its own cell:
+// Compare.hpp:528-530 adds hit by hit, the order that matters is per (read, taxon)), one LDS write.  A query in which a taxon
+// may own several segments (REC_SPLIT) is taken segment by segment.  A read that breaks the rule is handed on to the general
+// kernel (`hand`), its row cleared.  Narrow records (the profile is the group stage's).
+template <int NLV>
+__global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *__restrict__ hand, uint32_t *__restrict__ handCount)
+{
+    extern __shared__ float sRowDyn[];                                 // the row: nTaxa floats; then nTaxa bytes (REC_SPLIT queries)
+    __shared__ EventTables evT;
+    float *row = sRowDyn;
+    uint32_t *sUni = reinterpret_cast<uint32_t *>(sRowDyn + A.nTaxa);
+    const int lane = threadIdx.x;
+    event_tables_init(evT);
+    for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) row[tx] = 0.0f;
+    for (uint32_t x = lane; x < (A.nTaxa + 3u) / 4u; x += 64) sUni[x] = 0u;
+    __syncthreads();
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.rec);
+    for (uint32_t wi = blockIdx.x; wi < A.nList; wi += gridDim.x) {
+        const uint32_t r = A.list[wi];
+        const uint64_t o0 = A.kmerOff[r];
+        const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
+        uint32_t prevF = 0;
+        bool broke = false;
+        uint4 h = make_uint4(0, 0, 0, 0), b = h;
+        if (cnt) { h = rec4[o0 * 2]; b = rec4[o0 * 2 + 1]; }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            uint4 ch = h;
+            const uint4 cb = b;
+            if (j + 1 < cnt) { h = rec4[(o0 + j + 1) * 2]; b = rec4[(o0 + j + 1) * 2 + 1]; }   // (the next record is on its way)
+            // (the record is the whole wavefront's: its header words as scalars)
+            ch.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.x); ch.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.y);
+            ch.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.z); ch.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.w);
+            const int d = (int)(ch.z & 31u);
+            if (d == 0) continue;
+            if (prevF > ch.x) { broke = true; break; }               // an earlier group of the read is still open: the general kernel's
+            prevF = ch.y;
+            const uint32_t order = (ch.z >> 5) & 0xFFFFFFu;
+            const bool sat = (ch.z & REC_SAT) != 0u, split = (ch.z & REC_SPLIT) != 0u;
+            uint32_t nseg = ch.w & 255u;
+            const uint32_t nlev = ch.w >> 8;
+            if (nseg == 255u) nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.pool[cb.w]);
+            const uint32_t nInl = nseg <= 4u ? nseg : 3u;
+            const uint32_t *sizes = A.pool + cb.w + 1u;              // (valid with REC_SAT)
+            const uint32_t *more = sizes + (sat ? POOL_SIZES : 0u);  // (valid beyond nInl)
+            const int nEv = d - A.kLow + 1;
+            // lane e: level and score of the query's e-th event (Compare.hpp:923-924)
+            int lvMine = 0; float sMine = 0.0f;
+            if (lane < nEv) {
+                lvMine = (int)((order >> (3 * lane)) & 7u);
+                uint32_t n = (nlev >> (3 * lvMine)) & 7u;
+                if (n == 7u) n = (sizes[lvMine >> 1] >> (16 * (lvMine & 1))) & 0xFFFFu;   // "7 or more": the exact size is in the pool
+                sMine = event_score(evT, A.kHigh - lvMine, n);
+            }
+            auto replay = [&](uint32_t levels, float acc) -> float {  // the query's events at the taxon's levels (bit lv = kHigh - k), in flush order
+#pragma unroll
+                for (int e = 0; e < NLV; ++e) {
+                    if (e >= nEv) break;                              // (uniform)
+                    const int lv = __builtin_amdgcn_readlane(lvMine, e);
+                    const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sMine), e));
+                    acc = __fadd_rn(acc, ((levels >> lv) & 1u) ? s : 0.0f);   // (+ 0.0f leaves a score as it is)
+                }
+                return acc;
+            };
+            // A taxon may own several segments of a REC_SPLIT query (disjoint level ranges): its chain takes the query's events in
+            // ONE pass over the union of their levels.  First sweep: the unions, 8 bits per taxon (sUni, LDS atomics); second
+            // sweep: the first lane to fetch-and-clear a taxon's byte replays it, the others find nothing.
+            if (split)
+                for (uint32_t c0 = 0; c0 < nseg; c0 += 64) {
+                    const uint32_t i = c0 + (uint32_t)lane;
+                    if (i >= nseg) continue;
+                    const uint32_t sq = i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : more[i - nInl];
+                    const uint32_t t = sq & SEG_TAX_MASK;
+                    atomicOr(&sUni[t >> 2], seg_level_mask(sq, A.kHigh) << (8u * (t & 3u)));
+                }
+            if (split) LDS_WAVE_SYNC();
+            for (uint32_t c0 = 0; c0 < nseg; c0 += 64) {
+                const uint32_t i = c0 + (uint32_t)lane;
+                const bool has = i < nseg;
+                uint32_t sq = 0;
+                if (has) sq = i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : more[i - nInl];
+                const uint32_t t = sq & SEG_TAX_MASK;
+                uint32_t levels = has ? seg_level_mask(sq, A.kHigh) : 0u;
+                if (split && has) {
+                    const uint32_t sh = 8u * (t & 3u);
+                    levels = (atomicAnd(&sUni[t >> 2], ~(0xFFu << sh)) >> sh) & 0xFFu;   // (0: another lane has taken the taxon)
+                }
+                const bool mine = has && levels != 0u;
+                float acc = mine ? row[t] : 0.0f;
+                acc = replay(levels, acc);
+                if (mine) row[t] = acc;
+            }
+        }
+        if (broke) {                                                  // hand the read on, leave no trace
+            for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) row[tx] = 0.0f;
+            if (lane == 0) hand[atomicAdd(handCount, 1u)] = r;
+            LDS_WAVE_SYNC();
+            continue;
+        }
+        LDS_WAVE_SYNC();
+        // the row (taxon ascending), as the general kernel emits it; the LDS row is cleared for the next read
+        uint32_t m = 0;
+        for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) { const uint32_t tx = b0 + lane; m += (uint32_t)__popcll(__ballot(tx < A.nTaxa && row[tx] > 0.0f)); }
+        unsigned long long start = 0;
+        if (lane == 0) {
+            start = m ? atomicAdd(A.stCursor, (unsigned long long)m) : 0ull;
+            const bool fits = start + m <= (unsigned long long)A.stCap;
+            A.rowPos[r] = fits ? (uint32_t)start : 0u; A.rowLen[r] = fits ? m : 0u;
+            if (!fits) start = ~0ull;
+        }
+        start = lane_value<0>(start);
+        unsigned long long w = start;
+        for (uint32_t b0 = 0; b0 < A.nTaxa; b0 += 64) {
+            const uint32_t tx = b0 + lane;
+            const float v = (tx < A.nTaxa) ? row[tx] : 0.0f;
+            const unsigned long long mk = __ballot(v > 0.0f);
+            if (v > 0.0f) {
+                if (start != ~0ull) A.st[w + __popcll(mk & ((1ull << lane) - 1ull))] = make_uint2(tx, __float_as_uint(v));
+                row[tx] = 0.0f;
+            }
+            w += __popcll(mk);
+        }
+        LDS_WAVE_SYNC();
+    }
+}
+
 template <int RW> struct QueryRec {
     typedef RecTraits<RW> RT;
     uint32_t p, fmax, nseg, nlev, split;
@@ -5103,9 +5257,15 @@ static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, u
         c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->ix->nTaxa, \
         c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), \
         slowCount, c->tileList.as<uint32_t>()
-    if (c->ix->wide) group2_kernel<key128, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
-    else if (c->nK == 6) group2_kernel<uint64_t, 6><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));   // the default -k 12 7
-    else group2_kernel<uint64_t, 0><<<nTiles, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+    static const size_t pad = getenv("KASA_G2_PADLDS") ? (size_t)atoi(getenv("KASA_G2_PADLDS")) : 0;   // (occupancy experiments: unused dynamic LDS)
+    static const int perCuEnv = getenv("KASA_G2_GRID") ? atoi(getenv("KASA_G2_GRID")) : -1;              // (workgroups per CU; 0: one per tile)
+    int nCu = 0;
+    HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
+    const int perCu = perCuEnv >= 0 ? perCuEnv : 0;          // (0: one workgroup per tile -- measured at C2: 63.7 ms; 3 persistent ones per CU: 71.7)
+    const uint32_t grid = perCu > 0 ? std::min<uint32_t>(nTiles, (uint32_t)(std::max(1, nCu) * perCu)) : nTiles;
+    if (c->ix->wide) group2_kernel<key128, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
+    else if (c->nK == 6) group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));   // the default -k 12 7
+    else group2_kernel<uint64_t, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
 #undef KASA_GROUP2_ARGS
     HIPCHK(hipGetLastError());
     return KASA_OK;
@@ -5543,6 +5703,32 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             }
             nKeys = gp ? 0 : want[1];
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
+        }
+        c->lastDenseReads = 0;
+        if (fast && nSlow > 0 && gp && wantPerRead && nTaxa <= (uint32_t)DENSE_TAXA && !(c->debugFlags & 33554432)) {   // (test tap 33554432: never)
+            // reads the fast kernels handed over (long rows, as a rule): those that keep the order rule need no pending window
+            hipEvent_t da, db;
+            if ((rc = c->fbList2.reserve((size_t)nSlow * 4 + 64))) return rc;
+            uint32_t *handCount = counters + 70;
+            HIPCHK(hipMemsetAsync(handCount, 0, 4, c->stream));
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_DENSE], &da, &db))) return rc;
+            const size_t rowLds = (size_t)nTaxa * 4 + (((size_t)nTaxa + 3) / 4) * 4;
+            const uint32_t dblocks = std::min<uint32_t>(nSlow, 256u * 32u);
+            if (nK <= 6) {
+                HIPCHK(hipFuncSetAttribute((const void *)score_dense_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                score_dense_kernel<6><<<dblocks, 64, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
+            } else {
+                HIPCHK(hipFuncSetAttribute((const void *)score_dense_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
+                score_dense_kernel<8><<<dblocks, 64, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
+            }
+            HIPCHK(hipGetLastError());
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_DENSE], da, db))) return rc;
+            uint32_t handed = 0;
+            HIPCHK(hipMemcpyAsync(&handed, handCount, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            c->lastDenseReads = nSlow - handed;
+            nSlow = handed;
+            A.list = c->fbList2.as<uint32_t>(); A.nList = nSlow;
         }
         hipEvent_t ga = nullptr, gb = nullptr;
         if (nSlow > 0 && (rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], &ga, &gb))) return rc;
@@ -7273,6 +7459,13 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
         (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))
         return rc;
     (void)wantPerRead;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_dense_reads(kasa_ctx *c, uint32_t *denseReads)
+{
+    if (!c || !denseReads) return fail(KASA_E_ARG, "kasa_ctx_dense_reads: NULL argument");
+    *denseReads = c->lastDenseReads;
     return KASA_OK;
 }
 
