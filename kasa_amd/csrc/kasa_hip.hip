@@ -537,6 +537,7 @@ struct kasa_ctx {
     DevBuf sortBig;                            // heads / begins / ends of the long buckets (sort_and_range)
     DevBuf depth, rep;                         // u8[nQ], u32[nQ]
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
+    DevBuf rTab;                               // floor(2^64 / n) for n < 8192 (profile_group_accum_kernel)
     DevBuf tileList;                           // tiles group2_kernel leaves to group_kernel (long lists, walks beyond the staged span)
     uint32_t lastSlowTiles = 0;
     DevBuf tileChunks;                         // tile_suffix: minima of chunks of 1024 tiles
@@ -573,7 +574,7 @@ struct kasa_ctx {
     // every device buffer of the context: what kasa_ctx_destroy releases and kasa_ctx_device_bytes adds up (ONE list)
     std::vector<DevBuf *> buffers()
     {
-        return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds, &tileList,
+        return {&lut, &bases, &baseOff, &kmerOff, &seqOff, &seqRead, &qKmerA, &qKmerB, &qReadA, &qReadB, &depth, &rep, &tileFirst, &tileNext, &tileBounds, &tileList, &rTab,
                 &tileChunks, &rec, &pool, &plist, &sortTmp, &slotBuf, &recIn, &flushOff, &flushPos, &flushOff2, &flushPos2, &misc, &scratch, &ovList, &ovList2, &fbList2,
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
@@ -2826,7 +2827,7 @@ __device__ __forceinline__ void block_excl_prefix_sum2(uint32_t a, uint32_t b, u
     offA = ba + ia - a; offB = bb + ib - b; totA = ta; totB = tb;
 }
 
-template <class Key, int NKT>
+template <class Key, int NKT, int VAR = 0>                            // VAR: timing variants (KASA_G2_VAR), the product is 0
 __device__ __forceinline__ void group2_tile(const uint32_t tile,
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
@@ -3170,6 +3171,7 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
             pool[at + 1u + (sat ? POOL_SIZES : 0u)] = sFourth[r];    // the list's first segment of the pool block
         }
     }
+    if constexpr ((VAR & 2) != 0) __syncthreads();
     // ---- D. sorted layout: the records
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -3221,8 +3223,15 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
         const unsigned long long hq = getHits(L), c8 = getSizes(L);
         const uint4 sg = sSeg[L];
         const uint32_t n = sA[L] & 255u, w4 = n > (uint32_t)INL ? sFourth[r] : sg.w, nn = n < (uint32_t)INL ? n : (uint32_t)INL;
+        if constexpr ((VAR & 1) != 0) {
+            if (nn > 0u) cutRuns(sg.x, V, B, hq, c8);
+            if (nn > 1u) cutRuns(sg.y, V, B, hq, c8);
+            if (nn > 2u) cutRuns(sg.z, V, B, hq, c8);
+            if (nn > 3u) cutRuns(w4, V, B, hq, c8);
+        } else {
 #pragma unroll 1
-        for (uint32_t q = 0; q < nn; ++q) cutRuns(q == 0u ? sg.x : q == 1u ? sg.y : q == 2u ? sg.z : w4, V, B, hq, c8);   // (one copy of the loop body: code size)
+            for (uint32_t q = 0; q < nn; ++q) cutRuns(q == 0u ? sg.x : q == 1u ? sg.y : q == 2u ? sg.z : w4, V, B, hq, c8);   // (one copy of the loop body: code size)
+        }
     }
     for (uint32_t x = t; x < nOvf; x += GTHREADS) {
         const uint2 e = sOvf[x];
@@ -3709,11 +3718,11 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // Neither kernel touches the profile tables: everything leaves as records, so both can be rerun.
 // ------------------------------------------------------------------------------------------------
 
-// A workgroup takes tiles gridDim.x apart.  The product launches one workgroup per tile.  (Tried, KASA_G2_GRID: persistent
-// workgroups, three per CU, so that a tile's 1024 scattered record stores -- what bounds the stage, tools/scatter_probe.hip --
-// drain while the workgroup computes its next tile: 71.7 ms against 63.7 at C2.  The hardware's own scheduler of fresh
-// workgroups overlaps the phases better than a loop with a barrier at every tile's end.)
-template <class Key, int NKT>
+// One workgroup per tile.  (Tried: persistent workgroups, three per CU, each taking tiles gridDim.x apart, so that a tile's 1024
+// scattered record stores -- what bounds the stage, tools/scatter_probe.hip -- drain while the workgroup computes its next
+// tile: 71.7 ms against 63.7 at C2.  The hardware's own scheduling of fresh workgroups overlaps the phases better than a
+// loop with a barrier at every tile's end.)
+template <class Key, int NKT, int VAR = 0>
 __global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
@@ -3723,11 +3732,8 @@ __global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
     uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
     uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList)
 {
-    for (uint32_t tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-        group2_tile<Key, NKT>(tile, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
-                              nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList);
-        __syncthreads();                                              // (the tile's LDS is the next tile's)
-    }
+    group2_tile<Key, NKT, VAR>(blockIdx.x, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
+                          nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList);
 }
 
 // Reads with LONG ROWS that keep the fast kernels' rule -- every group of a query is closed before the read's next matched
@@ -3740,31 +3746,59 @@ __global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
 // Compare.hpp:528-530 adds hit by hit, the order that matters is per (read, taxon)), one LDS write.  A query in which a taxon
 // may own several segments (REC_SPLIT) is taken segment by segment.  A read that breaks the rule is handed on to the general
 // kernel (`hand`), its row cleared.  Narrow records (the profile is the group stage's).
+static constexpr int SD_WAVES = 4;                                      // wavefronts (reads in flight) per workgroup
 template <int NLV>
-__global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *__restrict__ hand, uint32_t *__restrict__ handCount)
+__global__ __launch_bounds__(64 * SD_WAVES) void score_dense_kernel(ScoreArgs A, uint32_t *__restrict__ hand, uint32_t *__restrict__ handCount)
 {
-    extern __shared__ float sRowDyn[];                                 // the row: nTaxa floats; then nTaxa bytes (REC_SPLIT queries)
+    extern __shared__ float sRowDyn[];                                 // per wavefront: the row, nTaxa floats; then nTaxa bytes (REC_SPLIT queries)
     __shared__ EventTables evT;
-    float *row = sRowDyn;
-    uint32_t *sUni = reinterpret_cast<uint32_t *>(sRowDyn + A.nTaxa);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t perWave = A.nTaxa + (A.nTaxa + 3u) / 4u;            // (words)
+    float *row = sRowDyn + (size_t)wv * perWave;
+    uint32_t *sUni = reinterpret_cast<uint32_t *>(row + A.nTaxa);
     event_tables_init(evT);
     for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) row[tx] = 0.0f;
     for (uint32_t x = lane; x < (A.nTaxa + 3u) / 4u; x += 64) sUni[x] = 0u;
     __syncthreads();
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.rec);
-    for (uint32_t wi = blockIdx.x; wi < A.nList; wi += gridDim.x) {
+    for (uint32_t wi = blockIdx.x * SD_WAVES + (uint32_t)wv; wi < A.nList; wi += gridDim.x * SD_WAVES) {
         const uint32_t r = A.list[wi];
         const uint64_t o0 = A.kmerOff[r];
         const uint32_t cnt = (uint32_t)(A.kmerOff[r + 1] - o0);
         uint32_t prevF = 0;
         bool broke = false;
-        uint4 h = make_uint4(0, 0, 0, 0), b = h;
+        // Three queries in flight: record j + 2 is being loaded, the pool words query j + 1 needs first -- its list's length if
+        // 255 or more, the exact level sizes its events ask for, the first 64 segments -- are being loaded (their addresses come
+        // from record j + 1 alone), query j is replayed.  One wavefront works on one read: without this every query was two
+        // dependent round trips to memory with nothing else to do (71 ms for 700 000 reads of the crowded workload).
+        struct Pre { uint32_t cnt, size, seg; };
+        // (every load is issued on every path -- a word that is not needed is read from pool[0] -- so that the number of loads in
+        // flight is the same whatever the records hold: the compiler can then wait for the OLDER ones only)
+        auto prefetch = [&](const uint4 &ph, const uint4 &pb) -> Pre {
+            const int d = (int)(ph.z & 31u);
+            const uint32_t nf = ph.w & 255u, off = pb.w;
+            const bool live = d != 0, sat = live && (ph.z & REC_SAT) != 0u;
+            const uint32_t lv = ((ph.z >> 5) >> (3 * (lane & 7))) & 7u;
+            const bool wantSize = sat && lane < d - A.kLow + 1 && (((ph.w >> 8) >> (3u * lv)) & 7u) == 7u;
+            const uint32_t nInl = nf <= 4u ? nf : 3u;
+            const bool wantSeg = live && (uint32_t)lane >= nInl && (uint32_t)lane < (nf == 255u ? 64u : nf);
+            Pre P;
+            P.cnt = A.pool[(live && nf == 255u) ? off : 0u];
+            P.size = A.pool[wantSize ? off + 1u + (lv >> 1) : 0u];
+            P.seg = A.pool[wantSeg ? off + 1u + (sat ? POOL_SIZES : 0u) + (uint32_t)lane - nInl : 0u];
+            return P;
+        };
+        uint4 h = make_uint4(0, 0, 0, 0), b = h, h2 = h, b2 = h;
         if (cnt) { h = rec4[o0 * 2]; b = rec4[o0 * 2 + 1]; }
+        if (cnt) { const uint64_t s1 = o0 + (cnt > 1 ? 1u : 0u); h2 = rec4[s1 * 2]; b2 = rec4[s1 * 2 + 1]; }
+        Pre pre = cnt ? prefetch(h, b) : Pre{0u, 0u, 0u};
         for (uint32_t j = 0; j < cnt; ++j) {
             uint4 ch = h;
             const uint4 cb = b;
-            if (j + 1 < cnt) { h = rec4[(o0 + j + 1) * 2]; b = rec4[(o0 + j + 1) * 2 + 1]; }   // (the next record is on its way)
+            const Pre cp = pre;
+            h = h2; b = b2;
+            { const uint64_t s2 = o0 + (j + 2 < cnt ? j + 2 : cnt - 1); h2 = rec4[s2 * 2]; b2 = rec4[s2 * 2 + 1]; }   // (past the end: the last record again)
+            pre = prefetch(h, b);
             // (the record is the whole wavefront's: its header words as scalars)
             ch.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.x); ch.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.y);
             ch.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.z); ch.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.w);
@@ -3776,7 +3810,7 @@ __global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *
             const bool sat = (ch.z & REC_SAT) != 0u, split = (ch.z & REC_SPLIT) != 0u;
             uint32_t nseg = ch.w & 255u;
             const uint32_t nlev = ch.w >> 8;
-            if (nseg == 255u) nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.pool[cb.w]);
+            if (nseg == 255u) nseg = (uint32_t)__builtin_amdgcn_readfirstlane((int)cp.cnt);
             const uint32_t nInl = nseg <= 4u ? nseg : 3u;
             const uint32_t *sizes = A.pool + cb.w + 1u;              // (valid with REC_SAT)
             const uint32_t *more = sizes + (sat ? POOL_SIZES : 0u);  // (valid beyond nInl)
@@ -3786,9 +3820,12 @@ __global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *
             if (lane < nEv) {
                 lvMine = (int)((order >> (3 * lane)) & 7u);
                 uint32_t n = (nlev >> (3 * lvMine)) & 7u;
-                if (n == 7u) n = (sizes[lvMine >> 1] >> (16 * (lvMine & 1))) & 0xFFFFu;   // "7 or more": the exact size is in the pool
+                if (n == 7u) n = (cp.size >> (16 * (lvMine & 1))) & 0xFFFFu;   // "7 or more": the exact size is in the pool
                 sMine = event_score(evT, A.kHigh - lvMine, n);
             }
+            auto segAt = [&](uint32_t i) -> uint32_t {                // segment i of the query (the first 64 were fetched a query ahead)
+                return i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : (i < 64u ? cp.seg : more[i - nInl]);
+            };
             auto replay = [&](uint32_t levels, float acc) -> float {  // the query's events at the taxon's levels (bit lv = kHigh - k), in flush order
 #pragma unroll
                 for (int e = 0; e < NLV; ++e) {
@@ -3802,23 +3839,35 @@ __global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *
             // A taxon may own several segments of a REC_SPLIT query (disjoint level ranges): its chain takes the query's events in
             // ONE pass over the union of their levels.  First sweep: the unions, 8 bits per taxon (sUni, LDS atomics); second
             // sweep: the first lane to fetch-and-clear a taxon's byte replays it, the others find nothing.
-            if (split)
+            const int tap = A.forceHandOn;                            // (timing taps, KASA_DENSE_TAP: 1 no union sweep, 2 no replay, 4 one chunk per query)
+            if (tap & 4) nseg = nseg < 64u ? nseg : 64u;
+            // A long list's chunks of 64 segments: the loads of the next two chunks leave before this one is worked on (always
+            // both, from a clamped place: the number of loads in flight is fixed), so that a list of 1400 taxa -- a k-mer every
+            // genome shares -- is not 22 round trips to memory one after the other (43 of the kernel's 71 ms).
+            auto forChunks = [&](auto f) {
+                const uint32_t lastSeg = nseg - 1u;                    // (nseg >= 1: the query is matched)
+                auto poolAt = [&](uint32_t i) -> uint32_t { const uint32_t x = i < lastSeg ? i : lastSeg; return more[(x < nInl ? nInl : x) - nInl]; };
+                uint32_t s0 = segAt((uint32_t)lane < nseg ? (uint32_t)lane : 0u);     // chunk 0: fetched a query ahead
+                uint32_t s1 = nseg > 64u ? poolAt(64u + (uint32_t)lane) : 0u, s2 = nseg > 128u ? poolAt(128u + (uint32_t)lane) : 0u;
                 for (uint32_t c0 = 0; c0 < nseg; c0 += 64) {
+                    const uint32_t cur = s0;
+                    s0 = s1; s1 = s2;
+                    if (c0 + 192u < nseg) s2 = poolAt(c0 + 192u + (uint32_t)lane);
                     const uint32_t i = c0 + (uint32_t)lane;
-                    if (i >= nseg) continue;
-                    const uint32_t sq = i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : more[i - nInl];
-                    const uint32_t t = sq & SEG_TAX_MASK;
-                    atomicOr(&sUni[t >> 2], seg_level_mask(sq, A.kHigh) << (8u * (t & 3u)));
+                    f(i, i < nseg, cur);
                 }
+            };
+            if (split && !(tap & 1))
+                forChunks([&](uint32_t, bool has, uint32_t sq) {
+                    const uint32_t t = sq & SEG_TAX_MASK;
+                    if (has) atomicOr(&sUni[t >> 2], seg_level_mask(sq, A.kHigh) << (8u * (t & 3u)));
+                });
             if (split) LDS_WAVE_SYNC();
-            for (uint32_t c0 = 0; c0 < nseg; c0 += 64) {
-                const uint32_t i = c0 + (uint32_t)lane;
-                const bool has = i < nseg;
-                uint32_t sq = 0;
-                if (has) sq = i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : more[i - nInl];
+            forChunks([&](uint32_t, bool has, uint32_t sq) {
                 const uint32_t t = sq & SEG_TAX_MASK;
                 uint32_t levels = has ? seg_level_mask(sq, A.kHigh) : 0u;
-                if (split && has) {
+                if (tap & 2) return;
+                if (split && has && !(tap & 1)) {
                     const uint32_t sh = 8u * (t & 3u);
                     levels = (atomicAnd(&sUni[t >> 2], ~(0xFFu << sh)) >> sh) & 0xFFu;   // (0: another lane has taken the taxon)
                 }
@@ -3826,7 +3875,7 @@ __global__ __launch_bounds__(64) void score_dense_kernel(ScoreArgs A, uint32_t *
                 float acc = mine ? row[t] : 0.0f;
                 acc = replay(levels, acc);
                 if (mine) row[t] = acc;
-            }
+            });
         }
         if (broke) {                                                  // hand the read on, leave no trace
             for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) row[tx] = 0.0f;
@@ -5258,13 +5307,15 @@ static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, u
         c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), \
         slowCount, c->tileList.as<uint32_t>()
     static const size_t pad = getenv("KASA_G2_PADLDS") ? (size_t)atoi(getenv("KASA_G2_PADLDS")) : 0;   // (occupancy experiments: unused dynamic LDS)
-    static const int perCuEnv = getenv("KASA_G2_GRID") ? atoi(getenv("KASA_G2_GRID")) : -1;              // (workgroups per CU; 0: one per tile)
-    int nCu = 0;
-    HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
-    const int perCu = perCuEnv >= 0 ? perCuEnv : 0;          // (0: one workgroup per tile -- measured at C2: 63.7 ms; 3 persistent ones per CU: 71.7)
-    const uint32_t grid = perCu > 0 ? std::min<uint32_t>(nTiles, (uint32_t)(std::max(1, nCu) * perCu)) : nTiles;
+    const uint32_t grid = nTiles;
     if (c->ix->wide) group2_kernel<key128, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
-    else if (c->nK == 6) group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));   // the default -k 12 7
+    else if (c->nK == 6) {                                                                                // the default -k 12 7
+        static const int var = getenv("KASA_G2_VAR") ? atoi(getenv("KASA_G2_VAR")) : 0;
+        if (var == 1) group2_kernel<uint64_t, 6, 1><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+        else if (var == 2) group2_kernel<uint64_t, 6, 2><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+        else if (var == 3) group2_kernel<uint64_t, 6, 3><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+        else group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+    }
     else group2_kernel<uint64_t, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
 #undef KASA_GROUP2_ARGS
     HIPCHK(hipGetLastError());
@@ -5383,6 +5434,83 @@ __global__ __launch_bounds__(PT_THREADS) void profile_group_table_kernel(const u
     }
 }
 
+// Group keys straight into the tables, whatever |T| is: a workgroup keeps, for a WINDOW of levels, the exact 64.64 sums of every
+// (level, taxon) cell in LDS as the limbs the global tables hold -- A += low 32 bits of x, B += next 32 bits, C += x >> 64,
+// U += hits iff |T| = 1, where x = hits * floor(2^64 / |T|) (fixed_add) -- 64-bit LDS counters that cannot wrap between two
+// flushes (hits < 2^16, at most 2^22 keys between them), and adds them to the tables cell by cell.  No per-|T| cells, no
+// leftover keys, no sort: with a crowded index (|T| in the tens and hundreds) nine keys in ten used to leave
+// profile_group_table_kernel as per-level leftovers -- 3e9 of them sorted and reduced, 53 ms for 2 M reads.  floor(2^64 / n)
+// comes from a table (rTab[n], n < 8192; [1] unused: |T| = 1 adds hits to C and U).  Compare.hpp:922-925.
+static constexpr int PA_THREADS = 1024, PA_NMAX = 8192;
+__global__ void profile_rtab_kernel(uint64_t *__restrict__ rTab)
+{
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (uint32_t)PA_NMAX) return;
+    uint64_t R = n ? 0xFFFFFFFFFFFFFFFFull / n : 0ull;
+    if (n && (n & (n - 1)) == 0) R += 1;                               // n divides 2^64 (n = 1: wraps to 0, never used)
+    rTab[n] = R;
+}
+__global__ __launch_bounds__(PA_THREADS) void profile_group_accum_kernel(const uint64_t *__restrict__ keys, uint32_t nKeys, uint32_t nTaxa, int winLo, int winHi,
+                                                                         const uint64_t *__restrict__ rTab, uint64_t *__restrict__ cntUnique, uint64_t *__restrict__ hiTab,
+                                                                         uint64_t *__restrict__ midTab, uint64_t *__restrict__ loTab)
+{
+    extern __shared__ unsigned long long shAcc[];                      // [3][cells]: A, B, C | U << 32
+    const uint32_t cells = (uint32_t)(winHi - winLo) * nTaxa;
+    unsigned long long *sA = shAcc, *sB = shAcc + cells, *sCU = shAcc + 2 * (size_t)cells;
+    auto flush = [&]() {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < cells; i += PA_THREADS) {
+            const unsigned long long a = sA[i], b = sB[i], cu = sCU[i];
+            if ((a | b | cu) == 0ull) continue;
+            const size_t cell = (size_t)winLo * nTaxa + i;             // (window rows are consecutive levels)
+            if (a) atomicAdd((unsigned long long *)&loTab[cell], a);
+            if (b) atomicAdd((unsigned long long *)&midTab[cell], b);
+            if (cu & 0xFFFFFFFFull) atomicAdd((unsigned long long *)&hiTab[cell], cu & 0xFFFFFFFFull);
+            if (cu >> 32) atomicAdd((unsigned long long *)&cntUnique[cell], cu >> 32);
+            sA[i] = 0ull; sB[i] = 0ull; sCU[i] = 0ull;
+        }
+        __syncthreads();
+    };
+    for (uint32_t i = threadIdx.x; i < 3u * cells; i += PA_THREADS) shAcc[i] = 0ull;
+    __syncthreads();
+    const uint64_t step = (uint64_t)gridDim.x * PA_THREADS;
+    uint32_t sinceFlush = 0;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * PA_THREADS; i0 < nKeys; i0 += step) {   // (uniform per workgroup)
+        const uint64_t i = i0 + threadIdx.x;
+        const uint64_t key = i < nKeys ? keys[i] : 0ull;
+        const uint32_t hits = (uint32_t)(key & 0xFFFFull);
+        if (hits) {
+            const uint32_t tax = (uint32_t)(key >> 16) & SEG_TAX_MASK, n = (uint32_t)(key >> 38) & 0x1FFFu;
+            int lo = (int)((key >> 51) & 31u), hi = lo + (int)((key >> 56) & 31u);
+            lo = lo < winLo ? winLo : lo; hi = hi >= winHi ? winHi - 1 : hi;
+            if (lo <= hi && hits >= 256u) {                                // (group keys carry at most 128 hits; whatever else: straight to the tables)
+                for (int lv = lo; lv <= hi; ++lv) {
+                    const size_t cell = (size_t)lv * nTaxa + tax;
+                    if (n == 1u) atomicAdd((unsigned long long *)&cntUnique[cell], (unsigned long long)hits);
+                    fixed_add(hiTab, midTab, loTab, cell, hits, n);
+                }
+            } else if (lo <= hi) {
+                unsigned long long a = 0, b = 0, cu;
+                if (n == 1u) cu = (unsigned long long)hits | ((unsigned long long)hits << 32);
+                else {
+                    const uint64_t R = rTab[n];
+                    const uint64_t lo64 = (uint64_t)hits * R;
+                    a = lo64 & 0xFFFFFFFFull; b = lo64 >> 32; cu = __umul64hi((uint64_t)hits, R);
+                }
+                for (int lv = lo; lv <= hi; ++lv) {
+                    const uint32_t cell = (uint32_t)(lv - winLo) * nTaxa + tax;
+                    if (a) atomicAdd(&sA[cell], a);
+                    if (b) atomicAdd(&sB[cell], b);
+                    if (cu) atomicAdd(&sCU[cell], cu);
+                }
+            }
+        }
+        sinceFlush += PA_THREADS;
+        if (sinceFlush >= (1u << 22)) { flush(); sinceFlush = 0; }   // (C and U: at most 2^22 adds of less than 2^8 each between two flushes)
+    }
+    flush();
+}
+
 static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
 {
     if (nKeys == 0) return KASA_OK;
@@ -5394,6 +5522,30 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
     auto now = [&]() { if (timing) (void)hipStreamSynchronize(ps); return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     const ProfLayout PL = prof_layout(nTaxa, nK);
+    if (grouped && !(c->debugFlags & 67108864)) {                      // (test tap 67108864: the per-|T| cells + leftover sort of round 4)
+        // exact accumulation of every cell in LDS, a window of levels per pass (24 bytes per cell)
+        const uint64_t budget = 152u * 1024u;
+        const int perPass = (int)std::min<uint64_t>((uint64_t)nK, budget / ((uint64_t)nTaxa * 24u));
+        if (perPass >= 1 && (nK + perPass - 1) / perPass <= 3) {       // (more than three passes over the keys: the older way)
+            if (!c->rTab.p) {
+                if ((rc = c->rTab.reserve((size_t)PA_NMAX * 8))) return rc;
+                profile_rtab_kernel<<<PA_NMAX / 256, 256, 0, ps>>>(c->rTab.as<uint64_t>());
+                HIPCHK(hipGetLastError());
+            }
+            int nCu = 0;
+            HIPCHK(hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, c->device));
+            for (int lo = 0; lo < nK; lo += perPass) {
+                const int hi = std::min(nK, lo + perPass);
+                const size_t shBytes = (size_t)(hi - lo) * nTaxa * 24;
+                HIPCHK(hipFuncSetAttribute((const void *)profile_group_accum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shBytes));
+                profile_group_accum_kernel<<<std::max(1, nCu), PA_THREADS, shBytes, ps>>>(c->profKeys.as<uint64_t>(), (uint32_t)nKeys, nTaxa, lo, hi,
+                    c->rTab.as<uint64_t>(), c->cntUnique.as<uint64_t>(), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>());
+                HIPCHK(hipGetLastError());
+            }
+            if (timing) { const auto t1 = now(); fprintf(stderr, "kasa: profile keys %llu: exact LDS accumulation, %d level(s) per pass, %.1f ms\n", (unsigned long long)nKeys, perPass, std::chrono::duration<double>(t1 - t0).count() * 1e3); }
+            return KASA_OK;
+        }
+    }
     // Keys without a cell in a workgroup's table leave as per-level keys for the sort + reduce: a few per cent of them with sparse
     // taxon sets, several per group key with a crowded index (|T| in the tens and hundreds).  The list is as long as the last
     // batch needed (what does not fit goes to the tables key by key -- slow, and the next batch gets the room).
@@ -5705,23 +5857,27 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             A.list = c->fbList.as<uint32_t>(); A.nList = nSlow;
         }
         c->lastDenseReads = 0;
-        if (fast && nSlow > 0 && gp && wantPerRead && nTaxa <= (uint32_t)DENSE_TAXA && !(c->debugFlags & 33554432)) {   // (test tap 33554432: never)
+        if (fast && nSlow > 0 && gp && wantPerRead && nTaxa * 5u * SD_WAVES <= 160u * 1024u - 1024u && !(c->debugFlags & 33554432)) {   // (the rows of a workgroup's reads fit LDS; test tap 33554432: never)
             // reads the fast kernels handed over (long rows, as a rule): those that keep the order rule need no pending window
             hipEvent_t da, db;
             if ((rc = c->fbList2.reserve((size_t)nSlow * 4 + 64))) return rc;
             uint32_t *handCount = counters + 70;
             HIPCHK(hipMemsetAsync(handCount, 0, 4, c->stream));
             if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_DENSE], &da, &db))) return rc;
-            const size_t rowLds = (size_t)nTaxa * 4 + (((size_t)nTaxa + 3) / 4) * 4;
-            const uint32_t dblocks = std::min<uint32_t>(nSlow, 256u * 32u);
+            static const int denseTap = getenv("KASA_DENSE_TAP") ? atoi(getenv("KASA_DENSE_TAP")) : 0;
+            const int keepHandOn = A.forceHandOn;
+            A.forceHandOn = denseTap;
+            const size_t rowLds = ((size_t)nTaxa * 4 + (((size_t)nTaxa + 3) / 4) * 4) * SD_WAVES;
+            const uint32_t dblocks = std::min<uint32_t>((nSlow + SD_WAVES - 1) / SD_WAVES, 256u * 8u);
             if (nK <= 6) {
                 HIPCHK(hipFuncSetAttribute((const void *)score_dense_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
-                score_dense_kernel<6><<<dblocks, 64, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
+                score_dense_kernel<6><<<dblocks, 64 * SD_WAVES, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
             } else {
                 HIPCHK(hipFuncSetAttribute((const void *)score_dense_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rowLds));
-                score_dense_kernel<8><<<dblocks, 64, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
+                score_dense_kernel<8><<<dblocks, 64 * SD_WAVES, rowLds, c->stream>>>(A, c->fbList2.as<uint32_t>(), handCount);
             }
             HIPCHK(hipGetLastError());
+            A.forceHandOn = keepHandOn;
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_DENSE], da, db))) return rc;
             uint32_t handed = 0;
             HIPCHK(hipMemcpyAsync(&handed, handCount, 4, hipMemcpyDeviceToHost, c->stream));
