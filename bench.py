@@ -14,8 +14,9 @@ torch.distributed).  `value` = all reads of all ranks / max-over-ranks time.
           C++ driver: FASTQ in, JSONL + profile out, index load excluded) and `cpu_baseline` (the oracle with the
           reference's threading model on the host cores).
   N > 1   the same 10 M-read batch on EVERY rank, index replicated ("weak": N x 10 M reads per step; N = 1 and N = 8 differ
-          by the reduce only).  The same line carries `c4` = BASELINE.json configs[3]: 100 M reads in all, 100 M / N per
-          rank in batches of at most 10 M ("strong").  `--total-reads T` makes that the headline instead.
+          by the reduce only).  The same line carries `c2_strong` = BASELINE.json's metric read literally (10 M reads in all,
+          10 M / N per rank) and `c4` = BASELINE.json configs[3]: 100 M reads in all, 100 M / N per rank in batches of at
+          most 10 M (both "strong").  `--total-reads T` makes that form the headline instead.
   --partitioned   BASELINE.json configs[4] (C5): the index range-partitioned over the ranks (kasa_amd/dist.py), one
           slice per rank made of the genomes' k-mers of its prefix range plus random filler records.
 
@@ -384,7 +385,7 @@ def report(args, ctx, reads, ix, world, res, wide, n_reads, n_batches, scaling, 
     return out
 
 
-def pmc_traffic(args, wide, kernel, live=True):
+def pmc_traffic(args, wide, kernel, live=True, crowded=False):
     """HBM bytes per launch of `kernel`, measured NOW: two child runs of this file under `rocprofv3 --pmc` (FETCH_SIZE, then
     WRITE_SIZE: separate passes, counters only, as MI355X_MICROARCH.md prescribes; FETCH_SIZE x 2 on gfx950), one step of the
     same workload each.  The caller has released its device memory.  Falls back to the committed passes of the same kernel
@@ -408,6 +409,8 @@ def pmc_traffic(args, wide, kernel, live=True):
                        "--reads", str(args.reads), "--taxa", str(args.taxa), "--genome-len", str(args.genome_len), "--read-len", str(args.read_len)]
                 if wide:
                     cmd.append("--wide")
+                if crowded:
+                    cmd += ["--crowded", "--crowded-reads", str(args.crowded_reads), "--warmup", "1"]   # (the first step sizes its buffers; the largest dispatch is taken)
                 env = dict(os.environ, TMPDIR="/tmp")
                 for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
                     env.pop(k, None)
@@ -431,14 +434,25 @@ def pmc_traffic(args, wide, kernel, live=True):
             out["insts"] = {"valu": got["SQ_INSTS_VALU"], "salu": got["SQ_INSTS_SALU"],
                             "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (a third child pass of one step)"}
         return out
+    if crowded:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_kernel_pmc_crowded.json")))
+            e = pmc.get(kernel, {})
+            if pmc.get("source_sha16") == source_sha16() and e.get("hbm_bytes_per_launch"):
+                return {"traffic": e["hbm_bytes_per_launch"], "traffic_source": "profiles/r05_kernel_pmc_crowded.json (same kernel sources, source_sha16 %s)" % pmc["source_sha16"]}
+        except Exception:
+            pass
+        return {"traffic": None, "traffic_source": "none: rocprofv3 pass failed here (%s) and no committed pass of these kernel sources" % got.get("error", "no counters")}
     if (args.reads, args.taxa, args.genome_len, args.read_len) != (10_000_000, 1400, 300_000, 150):
         return {"traffic": None, "traffic_source": "none: the committed counter passes are of the default workload"}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_kernel_pmc.json" if not wide else "r04_kernel_pmc_wide.json")))
+        name = "r05_kernel_pmc%s.json" % ("_wide" if wide else "")
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         if pmc.get("source_sha16") != source_sha16():
-            return {"traffic": None, "traffic_source": "none: rocprofv3 pass failed here (%s) and profiles/r04_kernel_pmc*.json was taken from other kernel sources" % got.get("error", "no counters")}
-        return {"traffic": pmc.get(kernel, {}).get("hbm_bytes_per_launch"),
-                "traffic_source": "profiles/r04_kernel_pmc%s.json (same kernel sources, source_sha16 %s)" % ("_wide" if wide else "", pmc["source_sha16"])}
+            return {"traffic": None, "traffic_source": "none: rocprofv3 pass failed here (%s) and profiles/%s was taken from other kernel sources" % (got.get("error", "no counters"), name)}
+        e = pmc.get("group2_kernel" if kernel == "group_kernel" and "group2_kernel" in pmc else kernel, {})
+        return {"traffic": e.get("hbm_bytes_per_launch"),
+                "traffic_source": "profiles/%s (same kernel sources, source_sha16 %s)" % (name, pmc["source_sha16"])}
     except Exception:
         return {"traffic": None, "traffic_source": "none"}
 
@@ -791,6 +805,7 @@ def main():
     ap.add_argument("--total-reads", type=int, default=None, help="reads of all ranks together, taken in batches of at most --reads (\"strong\"); default: --reads on every rank (\"weak\")")
     ap.add_argument("--c4-reads", type=int, default=100_000_000, help="N > 1: total reads of the `c4` leg (BASELINE.json configs[3])")
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the `c4` leg")
+    ap.add_argument("--no-c2-strong", action="store_true", help="N > 1: skip the `c2_strong` leg (--reads reads in all over the N ranks)")
     ap.add_argument("--no-tertiary", action="store_true", help="skip the crowded-index workload")
     ap.add_argument("--crowded", action="store_true", help="the crowded-index workload as the only measurement (profiling)")
     ap.add_argument("--crowded-reads", type=int, default=2_000_000, help="reads of the crowded-index batch (its (event, taxon) contributions per read are ten times the headline's)")
@@ -891,7 +906,8 @@ def main():
         n_batches = len(batches)
         extra_cfg = {"database": workload}
         if world > 1:
-            extra_cfg.update({"total_reads": per_rank * world, "reduce": reduce_how, "rccl_ranks": rccl_ranks})
+            extra_cfg.update({"total_reads": per_rank * world, "reduce": reduce_how, "rccl_ranks": rccl_ranks,
+                              "rccl_ranks_tested": 1})   # (what the builder could run: one GPU per box -- RCCL refuses two ranks on a device; the N-rank path is covered over gloo)
         log(f"[rank {rank}] reads: {per_rank} x {args.read_len} bp in {n_batches} batch(es), {time.perf_counter() - t0:.1f} s")
         warm = args.warmup
         if workload == "crowded":
@@ -912,6 +928,9 @@ def main():
         torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not wide and legs and workload == "pairs":
             holder["ix"], holder["reads"], holder["k"] = ix, reads, (k_high, k_low)
+        if rank == 0 and world == 1 and out["roofline"].get("kernel") and workload == "crowded" and not args.crowded:
+            # the crowded workload's dominant kernel: HBM bytes from the counters, measured now (two child passes)
+            out["roofline"].update({k: v for k, v in pmc_traffic(args, wide, out["roofline"]["kernel"], not args.no_pmc, crowded=True).items() if k != "insts"})
         if rank == 0 and world == 1 and out["roofline"].get("kernel") and workload == "pairs":
             # HBM bytes of the dominant kernel from the counters (the device is free now)
             live = not args.no_pmc and (args.pmc_secondary if (wide and not args.wide) else True)
@@ -958,6 +977,11 @@ def main():
             ter = {"error": str(ex)[:400]}
         if rank == 0 and out is not None and ter is not None:
             out["tertiary"] = {k: ter[k] for k in KEEP} if "error" not in ter else ter
+    if world > 1 and args.total_reads is None and not args.no_c2_strong:
+        # BASELINE.json's metric read literally: 10 M reads IN ALL at 1/2/4/8 GPUs ("strong": 10 M / N per rank, one batch each)
+        c2s = one(args.wide, total_reads=args.reads, legs=False)
+        if rank == 0 and out is not None and c2s is not None:
+            out["c2_strong"] = {k: c2s[k] for k in KEEP}
     if world > 1 and args.total_reads is None and not args.no_c4:
         c4 = one(args.wide, total_reads=args.c4_reads, legs=False)   # BASELINE.json configs[3]: 100 M reads in all ("strong")
         if rank == 0 and out is not None and c4 is not None:

@@ -1975,33 +1975,60 @@ __device__ __forceinline__ int wave_incl_min(int v)
 }
 __device__ __forceinline__ int wave_max_int(int v) { return ~__builtin_amdgcn_readlane(wave_incl_min(~v), 63); }   // (every lane gets it)
 template <class Meta, class F>
-__device__ __forceinline__ void coop_walk(const Meta *__restrict__ meta, uint32_t nIdx, uint32_t j, int d, int kLow, int lane, F f)
+__device__ __forceinline__ void coop_walk(const Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, uint32_t j, int d, int kLow, int lane, F f)
 {
+    // f(ok, idx, v, side, m, tx): m = meta[idx], tx = tax[idx] -- loaded here, ONE CHUNK AHEAD: where a chunk lies does not
+    // depend on what the chunk before held (only whether it is needed does), so its three loads leave before the chunk before
+    // is looked at; with the loads inside f every chunk was two dependent round trips to memory (a list of a conserved k-mer
+    // lies beyond the tile's LDS span), five sweeps over every long list: most of the cooperative kernel's time.
     constexpr int LM = sizeof(Meta) == 1 ? 15 : 255;
     const int gLow = group_letters(kLow);
     const int chain0 = d > RANGE_LETTERS ? d : RANGE_LETTERS;
+    const uint32_t lastIdx = nIdx - 1u;
     int run = chain0;
-    for (uint32_t a0 = 1;; a0 += 64) {                            // left: entry j - a shares with the query what j - a + 1 .. j share with their predecessors
-        const uint32_t a = a0 + (uint32_t)lane;
-        const bool valid = a <= j;
-        const uint32_t idx = valid ? j - a : 0u;
-        int v = wave_incl_min(valid ? (int)((uint32_t)meta[idx + 1] & (uint32_t)LM) : -1);
-        v = v < run ? v : run;
-        const bool ok = valid && v >= gLow;
-        f(ok, idx, v, 0);
-        if (__ballot(ok) != ~0ull) break;
-        run = __builtin_amdgcn_readlane(v, 63);
+    {   // left: entry j - a shares with the query what j - a + 1 .. j share with their predecessors
+        auto load = [&](uint32_t a0, uint32_t &mc, uint32_t &mo, uint32_t &tx) {
+            const uint32_t a = a0 + (uint32_t)lane;
+            const uint32_t idx = a <= j ? j - a : 0u;
+            mc = (uint32_t)meta[idx < lastIdx ? idx + 1u : lastIdx]; mo = (uint32_t)meta[idx]; tx = tax[idx];
+        };
+        uint32_t mc, mo, tx, mcN = 0, moN = 0, txN = 0;
+        load(1u, mc, mo, tx);
+        for (uint32_t a0 = 1;; a0 += 64) {
+            load(a0 + 64u, mcN, moN, txN);
+            const uint32_t a = a0 + (uint32_t)lane;
+            const bool valid = a <= j;
+            const uint32_t idx = valid ? j - a : 0u;
+            int v = wave_incl_min(valid ? (int)(mc & (uint32_t)LM) : -1);
+            v = v < run ? v : run;
+            const bool ok = valid && v >= gLow;
+            f(ok, idx, v, 0, mo, tx);
+            if (__ballot(ok) != ~0ull) break;
+            run = __builtin_amdgcn_readlane(v, 63);
+            mc = mcN; mo = moN; tx = txN;
+        }
     }
     run = chain0;
-    for (uint32_t b0 = 1;; b0 += 64) {                            // right: entry j + b shares what j + 1 .. j + b share with their predecessors
-        const uint32_t idx = j + b0 + (uint32_t)lane;
-        const bool valid = idx < nIdx && idx > j;
-        int v = wave_incl_min(valid ? (int)((uint32_t)meta[valid ? idx : 0u] & (uint32_t)LM) : -1);
-        v = v < run ? v : run;
-        const bool ok = valid && v >= gLow;
-        f(ok, idx, v, 1);
-        if (__ballot(ok) != ~0ull) break;
-        run = __builtin_amdgcn_readlane(v, 63);
+    {   // right: entry j + b shares what j + 1 .. j + b share with their predecessors
+        auto load = [&](uint32_t b0, uint32_t &mo, uint32_t &tx) {
+            const uint32_t idx0 = j + b0 + (uint32_t)lane;
+            const uint32_t idx = (idx0 < nIdx && idx0 > j) ? idx0 : 0u;
+            mo = (uint32_t)meta[idx]; tx = tax[idx];
+        };
+        uint32_t mo, tx, moN = 0, txN = 0;
+        load(1u, mo, tx);
+        for (uint32_t b0 = 1;; b0 += 64) {
+            load(b0 + 64u, moN, txN);
+            const uint32_t idx = j + b0 + (uint32_t)lane;
+            const bool valid = idx < nIdx && idx > j;
+            int v = wave_incl_min(valid ? (int)(mo & (uint32_t)LM) : -1);
+            v = v < run ? v : run;
+            const bool ok = valid && v >= gLow;
+            f(ok, idx, v, 1, mo, tx);
+            if (__ballot(ok) != ~0ull) break;
+            run = __builtin_amdgcn_readlane(v, 63);
+            mo = moN; tx = txN;
+        }
     }
 }
 static constexpr uint32_t LONG_STEPS = 48;        // entries a query's walk may visit lane by lane; beyond: the wavefront takes it (coop_walk)
@@ -2321,13 +2348,17 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
     // counting the segments per class is enough to place them later (pass 2, once the pool block is allocated).  Here: the
     // number of segments, |T_k| per level (marks at the ends of the level ranges, running sum), the split flag.
     constexpr int LMc = sizeof(Meta) == 1 ? 15 : 255, DSc = sizeof(Meta) == 1 ? 4 : 8;
-    auto segOf = [&](bool ok, uint32_t idx, int v, int dd, uint32_t &sg) -> bool {   // the segment entry idx yields, seen from a query of depth dd
+    auto segOfV = [&](bool ok, uint32_t m, uint32_t tx, int v, int dd, uint32_t &sg) -> bool {   // the segment an entry {meta m, taxon tx} yields, seen from a query of depth dd
         if (!ok) return false;
-        const int dup = (int)((uint32_t)meta[idx] >> DSc);
+        const int dup = (int)(m >> DSc);
         const int kFirst = dup < RANGE_LETTERS ? kLow : (dup + 1 > kLow ? dup + 1 : kLow);
         const int kLast = v < dd ? v : dd;
-        sg = tax[idx] | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27);
+        sg = tx | ((uint32_t)kFirst << 22) | ((uint32_t)kLast << 27);
         return kFirst <= kLast;
+    };
+    auto segOf = [&](bool ok, uint32_t idx, int v, int dd, uint32_t &sg) -> bool {   // ... entry idx
+        if (!ok) return false;
+        return segOfV(true, (uint32_t)meta[idx], tax[idx], v, dd, sg);
     };
     // counts of one long list into the wavefront's scratch; returns whether entry j itself yields a segment
     auto coopCount = [&](uint32_t j, int dd, uint32_t &selfSeg, bool &anySplit) -> bool {
@@ -2341,9 +2372,9 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
         const bool selfEmits = segOf(true, j, dd, dd, selfSeg);
         anySplit = selfEmits && (int)((selfSeg >> 22) & 31u) > kLow;
         if (selfEmits && lane == 0) { atomicAdd(&cM[kHigh - (int)(selfSeg >> 27)], 1u); atomicSub(&cM[kHigh - (int)((selfSeg >> 22) & 31u) + 1], 1u); }
-        coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int side) {
+        coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int side, uint32_t em, uint32_t et) {
             uint32_t sg = 0;
-            const bool emits = segOf(ok, idx, v, dd, sg);
+            const bool emits = segOfV(ok, em, et, v, dd, sg);
             if (emits) {
                 atomicAdd(&cH[(chain0 - v) * 2 + side], 1u);
                 atomicAdd(&cM[kHigh - (int)(sg >> 27)], 1u);
@@ -2488,9 +2519,9 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                     if (selfEmits && lane == 0) sInl[wv][0] = selfSeg;
                 }
                 LDS_WAVE_SYNC_G();
-                coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int side) {
+                coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int side, uint32_t em, uint32_t et) {
                     uint32_t sg = 0;
-                    const bool emits = segOf(ok, idx, v, dd, sg);
+                    const bool emits = segOfV(ok, em, et, v, dd, sg);
                     const uint32_t c = emits ? (uint32_t)((chain0 - v) * 2 + side) : 0xFFFFu;
                     uint32_t place = 0;
                     unsigned long long rem = __ballot(emits);
@@ -2676,9 +2707,9 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                 const int dd = __shfl(d[i], src);
                 uint32_t mine = 0, selfSeg = 0;
                 if (segOf(true, j, dd, dd, selfSeg) && lane == 0) mine += (uint32_t)__popc(startsOf(seg_level_mask(selfSeg, kHigh), V, B));
-                coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int) {
+                coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int, uint32_t em, uint32_t et) {
                     uint32_t sg = 0;
-                    if (segOf(ok, idx, v, dd, sg)) mine += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B));
+                    if (segOfV(ok, em, et, v, dd, sg)) mine += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B));
                 });
                 const uint32_t total = wave_total(wave_incl_sum(mine));
                 if (lane == src) { longKeys[i] = total; needK += total; }
@@ -2739,9 +2770,9 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                             if (lane == 0) { uint32_t w = at; putL(selfSeg, w); }
                             at += c;
                         }
-                        coop_walk<Meta>(meta, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t idx, int v, int) {
+                        coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int, uint32_t em, uint32_t et) {
                             uint32_t sg = 0;
-                            const bool emits = segOf(ok, idx, v, dd, sg);
+                            const bool emits = segOfV(ok, em, et, v, dd, sg);
                             const uint32_t c = emits ? (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B)) : 0u;
                             const uint32_t incl = wave_incl_sum(c);
                             if (c) { uint32_t w = at + incl - c; putL(sg, w); }

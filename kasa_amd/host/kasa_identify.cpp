@@ -605,6 +605,7 @@ struct Params {
     unsigned threads = 0;                       // -n: host threads for parsing and text output (0: all cores, at most 32)
     bool hostRank = false;                         // --host-rank: the whole CSR comes back and the host ranks every read
     bool hostText = false;                         // --host-text: the hits come back and the host writes the per-read text
+    bool allowDeviceSplit = false;                 // --allow-device-split: a reference batch larger than the device holds is cut (last digits of scores may differ)
     int memoryGiB = 0, refThreads = 1; bool ram = false;   // -m / -n / -r as the reference's batch budget sees them (kasa_refbatch_*)
     float threshold = 0.f;
     enum Fmt { Kraken, Json, JsonL, Tsv } fmt = Json;
@@ -1109,8 +1110,13 @@ struct Batcher {
                 pendPos = r;
             }
         }
+        if (useRef && deviceFull && !p.allowDeviceSplit)
+            // per-read scores are float sums whose order depends on the reads that share a batch (Compare.hpp:528-530): a batch cut
+            // elsewhere than kASA cuts it is not kASA's result -- an error, not a warning with different digits
+            throw std::runtime_error("a batch of the reference's size (-m " + std::to_string(p.memoryGiB) + ") does not fit the device; use a smaller -m (kASA's batches shrink with it), "
+                                     "more devices' memory, or --allow-device-split (the batch is cut where the device is full: per-read scores may differ from kASA's in their last digit)");
         if (useRef && deviceFull && !warned) {
-            std::cerr << "WARNING: a batch of the reference's size does not fit the device; per-read scores may differ in their last digit." << std::endl;
+            std::cerr << "WARNING: a batch of the reference's size does not fit the device; it is cut (--allow-device-split): per-read scores may differ in their last digit." << std::endl;
             warned = true;
         }
         firstBatch = false;
@@ -1685,6 +1691,7 @@ static int run(int argc, char **argv)
         else if (s == "-t" || s == "--temp" || s == "-x" || s == "--callidx") next();
         else if (s == "--host-rank") p.hostRank = true;
         else if (s == "--host-text") p.hostText = true;
+        else if (s == "--allow-device-split") p.allowDeviceSplit = true;
         else if (s == "--filter") { p.filter = true; p.filterClean = next(); p.filterCont = next(); }
         else if (s == "--errorThreshold") p.errorThreshold = std::stof(next());
         else if (s == "--gzip") p.gzipOut = true;                                                  // main.cpp:570-572

@@ -226,6 +226,10 @@ def test_bench_same_step_at_every_n(tmp_path):
     assert out["upload_ms_per_batch"] > 0 and 0.5 < out["identified_fraction"] <= 1.0
     c4 = out["c4"]
     assert c4["scaling"] == "strong" and c4["config"]["total_reads"] == 30000 and c4["config"]["batches_per_step"] == 2 and c4["value"] > 0
+    c2s = out["c2_strong"]                                        # BASELINE.json's metric read literally: --reads reads in all over the ranks
+    assert c2s["scaling"] == "strong" and c2s["config"]["total_reads"] == 8000 and c2s["config"]["reads_per_gpu"] == 4000 and c2s["value"] > 0
+    assert out["config"]["rccl_ranks_tested"] == 1 and out["attempts"] == 1 and out["retried"] is False
+    assert out["runtime"]["hip_built"] and out["runtime"]["hip_runtime"]
     one = _bench(["--steps", "2", "--warmup", "1", "--reads", "8000", "--total-reads", "20000", "--taxa", "8", "--genome-len", "20000",
                   "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"], share=False)
     assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["config"]["batches_per_step"] == 3 and one["reduce_ms_per_step"] == 0
@@ -248,6 +252,11 @@ def test_bench_default_line_carries_every_leg(tmp_path):
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["single_thread_value"] > 0 and c["speedup_over_1"] > 0
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    assert out["attempts"] == 1 and out["retried"] is False and out["runtime"]["hip_runtime"]       # (no silent second attempt)
+    assert "score_dense_kernel" in out["tertiary"]["kernels"] or out["tertiary"]["batch"]["dense_reads"] == 0
+    assert out["tertiary"]["roofline"]["traffic_source"]
+    if out["roofline"].get("third_bound"):
+        assert out["roofline"]["third_bound"]["bound"] == "issue" and out["roofline"]["third_bound"]["predicted_ms"] > 0
 
 
 def test_c_abi_reduce_with_a_communicator_of_its_own(tmp_path):

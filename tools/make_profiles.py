@@ -5,18 +5,19 @@
     FETCH_SIZE (x2 on gfx950, MI355X_MICROARCH.md section HBM) + WRITE_SIZE = HBM bytes per launch, SQ_INSTS_VALU / SALU,
     SQ_WAVES, SQ_BUSY_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY
   * the bench lines (headline, and with --secondary the 128-bit configuration) -> <tag>_bench_1gpu.json
-    python3 tools/make_profiles.py r04 [--wide] [--pmc-only]
+    python3 tools/make_profiles.py r05 [--wide | --crowded] [--pmc-only]
 """
 import csv, glob, json, os, re, subprocess, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r05"
 WIDE = "--wide" in sys.argv          # the 128-bit configuration (C3): its own kernel summary and counter passes, files <tag>_*_wide.*
-SFX = "_wide" if WIDE else ""
-WARGS = ["--wide"] if WIDE else []
+CROWDED = "--crowded" in sys.argv    # the crowded-index workload (`tertiary` of the bench line): files <tag>_*_crowded.*
+SFX = "_wide" if WIDE else ("_crowded" if CROWDED else "")
+WARGS = ["--wide"] if WIDE else (["--crowded", "--warmup", "2"] if CROWDED else [])
 out = "gpurun_out/profiles"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-KERNELS = "lookup_tile_kernel|group_kernel|score_main_kernel|score_other_flat_kernel|score_other_flat16_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|profile_group_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|bucket_rank_kernel|row_copy_kernel"
+KERNELS = "lookup_tile_kernel|group_kernel|group2_kernel|score_dense_kernel|score_kernel|profile_group_accum_kernel|profile_reduce_kernel|bucket_rank64_kernel|score_main_kernel|score_other_flat_kernel|score_other_flat16_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|profile_group_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|bucket_rank_kernel|row_copy_kernel"
 sys.path.insert(0, os.getcwd())
 import bench as _bench
 SHA = _bench.source_sha16()
@@ -81,14 +82,14 @@ json.dump(res, open(os.path.join(out, tag + "_kernel_pmc" + SFX + ".json"), "w")
 # 3. the bench line(s).  (Counter passes of this run's kernel sources that are not committed yet -- e.g. the --wide ones made a
 # moment ago -- are put where bench.py looks for its fallback, so that the line's `secondary.roofline.traffic` is filled.)
 import shutil
-for name in (tag + "_kernel_pmc.json", tag + "_kernel_pmc_wide.json"):
+for name in (tag + "_kernel_pmc.json", tag + "_kernel_pmc_wide.json", tag + "_kernel_pmc_crowded.json"):
     src = os.path.join(out, name)
     try:
         if os.path.exists(src) and json.load(open(src)).get("source_sha16") == SHA:
             shutil.copy(src, os.path.join("profiles", name))
     except Exception:
         pass
-if PMC_ONLY or WIDE:
+if PMC_ONLY or WIDE or CROWDED:
     for k, e in res.items():
         if isinstance(e, dict) and "SQ_INSTS_VALU" in e:
             ins = e["SQ_INSTS_VALU"] + e["SQ_INSTS_SALU"]
