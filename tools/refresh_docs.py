@@ -4,7 +4,7 @@ tools/make_profiles.py stored) so that the prose never drifts from the committed
 import json, os, re, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 d = json.load(open(os.path.join(root, "profiles", tag + "_bench_1gpu.json")))
 K, st, e, sec, cb = d["kernels"], d["stage_ms_per_step"], d["e2e"], d["secondary"], d["cpu_baseline"]
 ter = d.get("tertiary", {})
@@ -30,54 +30,73 @@ def krow(label, k, note):
             f"{(t / 1e9 if t else float('nan')):.1f} GB | {note} |\n")
 
 
+tb = roof.get("third_bound") or {}
+TK = ter.get("kernels", {}) if ter else {}
+
+
+def kms(table, name):
+    v = table.get(name, {})
+    return v.get("avg_launch_ms", v.get("ms_per_step", float("nan")))
+
+
 measured = (
-    f"Round 4, one MI355X (`profiles/{tag}_bench_1gpu.json`, `{tag}_kernel_stats_bench_10M*.*`, `{tag}_kernel_pmc*.json`, `{tag}_scatter_probe.json`):\n\n"
+    f"Round 5, one MI355X (`profiles/{tag}_bench_1gpu.json`, `{tag}_kernel_stats_bench_10M*.*`, `{tag}_kernel_pmc*.json`; the scatter floor: `r04_scatter_probe.json`):\n\n"
     "| config | reads/s | ms per batch | stages (ms): encode / sort / lookup / group / score |\n|---|---|---|---|\n"
-    f"| C2: 10 M × 150 bp, 4.2e8-record 64-bit index, `-k 12 7` | **{d['value'] / 1e6:.1f} M** (round 3: 46.6 M, round 2: 40.1 M, round 1: 21.3 M) | {d['ms_per_step']:.0f} | "
-    f"{st['encode']:.0f} / {st['sort']:.0f} / {st['lookup']:.0f} / {st['group']:.0f} / {st['score']:.0f} (round 3: 14 / 56 / 5 / 59 / 81; the group stage now makes the profile) |\n"
-    f"| C3: the same reads, 4.2e8-record 128-bit index, `-k 25 7` (`secondary` of the same line) | {sec['value'] / 1e6:.1f} M (round 3: 25.4 M, round 2: 19.3 M) | {sec['ms_per_step']:.0f} | "
-    f"{ss['encode']:.0f} / {ss['sort']:.0f} / {ss['lookup']:.0f} / {ss['group']:.0f} / {ss['score']:.0f} (round 3: 20 / 92 / 11 / 116 / 156) |\n"
-    + (f"| crowded index (`tertiary`): {ter['config']['reads_per_gpu'] / 1e6:.0f} M reads, clades of 50-200 taxa sharing conserved genes, same index size | {ter['value'] / 1e6:.2f} M (round 3: `KASA_E_LIMIT`) | {ter['ms_per_step']:.0f} | "
-       f"{ter['stage_ms_per_step']['encode']:.0f} / {ter['stage_ms_per_step']['sort']:.0f} / {ter['stage_ms_per_step']['lookup']:.0f} / {ter['stage_ms_per_step']['group']:.0f} / {ter['stage_ms_per_step']['score']:.0f}; "
-       f"{ter['batch']['general_reads']} reads on the general kernel, {ter['batch']['pool_words'] / ter['batch']['queries']:.1f} pool words and {ter['batch']['profile_keys'] / ter['batch']['queries']:.1f} profile keys per query |\n" if ter and "value" in ter else "")
-    + f"\nThe step includes `kasa_batch_upload_device` ({d['upload_ms_per_batch']:.1f} ms per batch: read geometry on the device). `roofline`: `{roof['kernel']}` "
-    f"{roof['avg_launch_ms']:.1f} ms = {roof['frac'] * 100:.1f} % of the HBM peak by its algorithmic bytes, HBM traffic {((roof.get('traffic') or 0) / 1e9):.1f} GB ({roof.get('traffic_source', '')}); "
-    + (f"against the scatter rate of the chip ({roof['second_bound']['peak']:.1f} G records/s, `profiles/r04_scatter_probe.json`): {roof['second_bound']['achieved']:.1f} G records/s = {roof['second_bound']['frac'] * 100:.0f} %.\n\n" if roof.get("second_bound") else "\n\n")
+    f"| C2: 10 M × 150 bp, 4.2e8-record 64-bit index, `-k 12 7` | **{d['value'] / 1e6:.1f} M** (round 4: 50.3 M, round 3: 46.6 M, round 2: 40.1 M, round 1: 21.3 M) | {d['ms_per_step']:.0f} | "
+    f"{st['encode']:.0f} / {st['sort']:.0f} / {st['lookup']:.0f} / {st['group']:.0f} / {st['score']:.0f} (round 4: 13 / 43 / 5 / 79 / 57) |\n"
+    f"| C3: the same reads, 4.2e8-record 128-bit index, `-k 25 7` (`secondary` of the same line) | {sec['value'] / 1e6:.1f} M (round 4: 29.0 M, round 3: 25.4 M, round 2: 19.3 M) | {sec['ms_per_step']:.0f} | "
+    f"{ss['encode']:.0f} / {ss['sort']:.0f} / {ss['lookup']:.0f} / {ss['group']:.0f} / {ss['score']:.0f} (round 4: 20 / 85 / 11 / 75 / 154) |\n"
+    + (f"| crowded index (`tertiary`): {ter['config']['reads_per_gpu'] / 1e6:.0f} M reads, clades of 50-200 taxa sharing conserved genes, same index size | **{ter['value'] / 1e6:.2f} M** (round 4: 3.45 M, round 3: `KASA_E_LIMIT`) | {ter['ms_per_step']:.0f} | "
+       f"{ter['stage_ms_per_step']['encode']:.0f} / {ter['stage_ms_per_step']['sort']:.0f} / {ter['stage_ms_per_step']['lookup']:.0f} / {ter['stage_ms_per_step']['group']:.0f} / {ter['stage_ms_per_step']['score']:.0f} (round 4: 3 / 11 / 3 / 212 / 350); "
+       f"{ter['batch'].get('dense_reads', 0)} reads on `score_dense_kernel` ({kms(TK, 'score_dense_kernel'):.0f} ms), {ter['batch']['general_reads']} on the general kernel; `group_kernel<COOP>` {kms(TK, 'group_kernel'):.0f} ms, "
+       f"profile tables {kms(TK, 'profile_table_kernels'):.0f} ms (round 4: 53); {ter['batch']['pool_words'] / ter['batch']['queries']:.1f} pool words and {ter['batch']['profile_keys'] / ter['batch']['queries']:.1f} profile keys per query; "
+       f"HBM traffic of its dominant kernel: {((ter['roofline'].get('traffic') or 0) / 1e9):.1f} GB per launch ({ter['roofline'].get('traffic_source', '')}) |\n" if ter and "value" in ter else "")
+    + f"\nThe step includes `kasa_batch_upload_device` ({d['upload_ms_per_batch']:.1f} ms per batch: read geometry on the device). `roofline`: the group stage's kernels (`group2_kernel` over all tiles + `group_kernel<COOP>` over the "
+    f"{d['batch'].get('group_tiles_listed', 0)} of {d['batch'].get('group_tiles', 0)} tiles it lists; timed together as `group_kernel`) {roof['avg_launch_ms']:.1f} ms = {roof['frac'] * 100:.1f} % of the HBM peak by their algorithmic bytes, "
+    f"HBM traffic {((roof.get('traffic') or 0) / 1e9):.1f} GB ({roof.get('traffic_source', '')}); "
+    + (f"`second_bound`, the scatter rate of the chip ({roof['second_bound']['peak']:.1f} G records/s): {roof['second_bound']['achieved']:.1f} G records/s = {roof['second_bound']['frac'] * 100:.0f} % (round 4: 67 %); " if roof.get("second_bound") else "")
+    + (f"`third_bound`, instruction issue: {tb['wave_insts_valu'] / 1e9:.1f}e9 VALU + {tb['wave_insts_salu'] / 1e9:.1f}e9 SALU wavefront instructions of `group2_kernel` (round 4's kernel: 32.6e9 + 12.4e9) = {tb['predicted_ms']:.1f} ms at 4 cycles each, "
+       f"{tb['frac'] * 100:.0f} % of the measured time ({tb.get('source', '')}).\n\n" if tb else "\n\n")
     +
     "Individually timed kernels of C2 (HIP events on the library's stream; algorithmic bytes: `bench.py:kernel_bytes`, SURVEY §8(d); "
     "HBM traffic: PMC, FETCH_SIZE × 2 + WRITE_SIZE):\n\n"
     "| kernel | per launch | algorithmic bytes | rate, % of 8 TB/s | HBM traffic | |\n|---|---|---|---|---|---|\n"
     + krow("lookup_tile_kernel", "lookup_tile_kernel", "the kernel BASELINE's ≥ 40 % target names")
-    + krow("group_kernel<8, u64, 6>", "group_kernel", "the `roofline` object of the line: scatter-rate-bound (§5); emits the profile keys (§3b)")
+    + krow("group2_kernel<u64, 6> (+ group_kernel<8, u64, 6, COOP> on the listed tiles)", "group_kernel", "the `roofline` object of the line: scatter-rate-bound (§5); emits the profile keys (§3b); traffic: `group2_kernel` alone")
     + krow("score_main_kernel<8, true, 8>", "score_main_kernel", "line-aligned record loads")
     + krow("score_other_flat_kernel", "score_other_kernel", "")
     + krow("row_merge_bitmap_kernel", "row_merge_kernel", "")
-    + f"\n64-byte records (C3): `group_kernel<16>` {SK['group_kernel']['avg_launch_ms']:.0f} (round 3: 115; records stored by lane quads), `score_main_kernel<16>` {SK['score_main_kernel']['avg_launch_ms']:.0f}, "
-    f"`score_other_flat16_kernel` {SK['score_other_kernel']['avg_launch_ms']:.0f} ms; kernel summary and counter passes: `profiles/{tag}_kernel_stats_bench_10M_wide.*`, `{tag}_kernel_pmc_wide.json`.\n\n"
+    + f"\nGroups of kernels timed together (ms per step): query sort = `hist_kernel` + four radix passes {kms(K, 'sort_pass_kernels'):.1f} + `bucket_rank64_kernel` {kms(K, 'bucket_rank_kernel'):.1f} (the passes take 8.0 ms each on the 1.3e9-pair batch: the 6.8 of "
+    f"the kernel summary is an average over the index build's smaller sorts as well -- that was the \"6.6 ms between the listed kernels\" of round 4's review); profile tables (`profile_group_accum_kernel`, two windows of levels) {kms(K, 'profile_table_kernels'):.1f}; "
+    f"general score kernel {kms(K, 'score_general_kernels'):.1f}; offsets of the rows (the CSR is packed on demand: `row_copy_kernel` is gone from the step) {kms(K, 'row_copy_kernels'):.2f}.\n"
+    + f"\n64-byte records (C3): `group_kernel<16>` {SK['group_kernel']['avg_launch_ms']:.0f}, `score_main_kernel<16>` {SK['score_main_kernel']['avg_launch_ms']:.0f}, "
+    f"`score_other_flat16_kernel` {SK['score_other_kernel']['avg_launch_ms']:.0f}, row merge {kms(SK, 'row_merge_kernel'):.0f}, profile tables {kms(SK, 'profile_table_kernels'):.0f}, sort passes {kms(SK, 'sort_pass_kernels'):.0f} + bucket rank {kms(SK, 'bucket_rank_kernel'):.0f} ms; "
+    f"kernel summary and counter passes: `profiles/{tag}_kernel_stats_bench_10M_wide.*`, `{tag}_kernel_pmc_wide.json`; the crowded workload's: `{tag}_kernel_stats_bench_10M_crowded.*`, `{tag}_kernel_pmc_crowded.json`.\n\n"
     f"PCIe-inclusive (`e2e`, never `value`): page-locked reads up, device, ranking on the device (`-b 3`), ranked hits + profile down = "
     f"{e['pcie_inclusive_s_per_batch']:.2f} s per batch = **{e['pcie_inclusive_reads_per_s'] / 1e6:.1f} M reads/s** ({e['upload_and_device_s']:.2f} s upload + device, "
     f"{e['rank_and_fetch_s']:.2f} s ranking + {e['downloaded_bytes'] / 1e9:.2f} GB of hits; {e['reads_ranked_by_host']} reads go back to the host; all 1400 synthetic taxa have the "
     "same k-mer frequency, so a third of the reads have tied third-best hits and take the `std::sort`-order kernel). "
     + (f"A host that keeps two contexts busy from two threads -- the copies of one batch beside the kernels of another (`pcie_pipelined`, {e['pcie_pipelined_batches']} batches): "
        f"{e['pcie_pipelined_s_per_batch']:.3f} s per batch = **{e['pcie_pipelined_reads_per_s'] / 1e6:.1f} M reads/s**, i.e. the device's own time for step + ranking. " if "pcie_pipelined_reads_per_s" in e else "")
-    + f"The whole CSR into pageable memory: {e['csr_download_s_per_batch']:.2f} s.\n\n"
+    + f"The whole CSR into pageable memory (packed on the device only now, when the host asks for it): {e['csr_download_s_per_batch']:.2f} s.\n\n"
     f"File to file (`kasa_identify identify --jsonl`, 10 M reads = {e['input_bytes'] / 1e9:.2f} GB of FASTQ in, {e['output_bytes'] / 1e9:.2f} GB of JSON lines out, both in `/dev/shm`, "
     f"host threads = the box's cgroup quota; the text is written on the device and leaves through one writer thread): **{e['file_to_file_reads_per_s'] / 1e6:.2f} M reads/s** with `-m {e['memory_gib']}` "
     f"({e['batches']} batches in a pipeline: parse {e['parse_s']:.2f} s, device incl. ranking, text and its download {e['device_s']:.2f} s of which {e['text_s']:.2f} s waiting for the writer; "
     f"file {e['file_to_file_s']:.2f} s; hipMalloc calls over 20 ms: {e.get('slow_hipmalloc_s', 0):.2f} s), {ob.get('file_to_file_reads_per_s', 0) / 1e6:.2f} M reads/s as one batch "
-    f"(`-m {ob.get('memory_gib', 0)}`: parse {ob.get('parse_s', 0):.2f} s, device {ob.get('device_s', 0):.2f} s, file {ob.get('file_to_file_s', 0):.2f} s, slow hipMalloc {ob.get('slow_hipmalloc_s', 0):.2f} s; "
-    "round 2: 1.4 M on 20 M reads). "
+    f"(`-m {ob.get('memory_gib', 0)}`: parse {ob.get('parse_s', 0):.2f} s, device {ob.get('device_s', 0):.2f} s, file {ob.get('file_to_file_s', 0):.2f} s, slow hipMalloc {ob.get('slow_hipmalloc_s', 0):.2f} s). "
     "The reference binary itself ran at 35 k reads/s with `-n 8` on the calibration box (`profiles/cpu_calibration.json`).\n\n"
     f"CPU baseline (`cpu_baseline`, kind `port`): {cb['value'] / 1e3:.0f} k reads/s with {cb['threads']} threads, {cb['single_thread_value'] / 1e3:.1f} k with one "
     f"({cb['speedup_over_1']:.1f} ×) on {cb['cpu']}: the box shows {cb['host_cpus']['logical']} CPUs but grants the job a cgroup quota of "
-    f"{cb['host_cpus']['cgroup_quota_cpus']:.0f} — more threads than that run slower (measured: 19 s with 16, 23 s with 64, 27 s with 256 on the same 5 M reads).\n\n"
+    f"{cb['host_cpus']['cgroup_quota_cpus']:.0f} — more threads than that run slower (measured in round 3: 19 s with 16, 23 s with 64, 27 s with 256 on the same 5 M reads).\n\n"
+    f"The line itself: `attempts` {d.get('attempts')}, `retried` {d.get('retried')}; `runtime`: library built with HIP {d.get('runtime', {}).get('hip_built')}, runs on {d.get('runtime', {}).get('hip_runtime')} "
+    f"({d.get('runtime', {}).get('runtime_from')}) -- bench.py shares its process with torch (torch.distributed), so the torch wheel's runtime is the one in the process; hosts without torch run on ROCm's own (§7).\n\n"
 )
 p = os.path.join(root, "DESIGN.md")
 s = open(p).read()
-s = block(s, "<!-- r04:measured:begin (generated by tools/refresh_docs.py from profiles/r04_bench_1gpu.json) -->", "<!-- r04:measured:end -->", measured)
+s = block(s, "<!-- r05:measured:begin (generated by tools/refresh_docs.py from profiles/r05_bench_1gpu.json) -->", "<!-- r05:measured:end -->", measured)
 s = re.sub(r"\| `encode_kernel` \| 150 B in \+ 130·12 B out per read \| [^|]* \|", f"| `encode_kernel` | 150 B in + 130·12 B out per read | {st['encode']:.0f} ms (stage) |", s)
 s = re.sub(r"\| 5 passes × 24 B \+ one pass of 24 B per query \| [^|]* \|", f"| 5 passes × 24 B + one pass of 24 B per query | {st['sort']:.0f} ms (round 2, library passes: 66 ms) |", s)
-for name, k in (("`tile_bounds_kernel` + `lookup_tile_kernel`", "lookup_tile_kernel"), ("`group_kernel<RW, Key, NK>`", "group_kernel"), ("`score_main_kernel<RW>`", "score_main_kernel"),
+for name, k in (("`tile_bounds_kernel` + `lookup_tile_kernel`", "lookup_tile_kernel"), ("`group2_kernel<Key, NK>` (narrow records; `group_kernel<RW, Key, NK, COOP>` for the tiles it lists and for 64-byte records)", "group_kernel"), ("`score_main_kernel<RW>`", "score_main_kernel"),
                 ("`score_other_flat_kernel` (32-byte records)", "score_other_kernel"), ("`row_merge_bitmap_kernel`", "row_merge_kernel")):
     i = s.index("| " + name + " |")
     cols = s[i:s.index("\n", i)].split(" | ")
@@ -89,7 +108,7 @@ p = os.path.join(root, "README.md")
 r = open(p).read()
 r = block(r, "<!-- measured:begin -->", "<!-- measured:end -->",
           f"One MI355X, 10 M × 150 bp reads against a 4.2e8-record (5 GB) index, profile + per-read scores: **{d['value'] / 1e6:.0f} M reads/s**\n"
-          f"({d['ms_per_step']:.0f} ms per batch; round 3: 47 M, round 2: 40 M, round 1: 21 M), {e['pcie_inclusive_reads_per_s'] / 1e6:.0f} M reads/s with the PCIe legs inside the clock (reads up, ranking\n"
+          f"({d['ms_per_step']:.0f} ms per batch; round 4: 50 M, round 3: 47 M, round 2: 40 M, round 1: 21 M), {e['pcie_inclusive_reads_per_s'] / 1e6:.0f} M reads/s with the PCIe legs inside the clock (reads up, ranking\n"
           f"on the device, printable hits down" + (f"; {e['pcie_pipelined_reads_per_s'] / 1e6:.0f} M with two contexts in flight" if "pcie_pipelined_reads_per_s" in e else "") + "), "
           f"{e['file_to_file_reads_per_s'] / 1e6:.1f} M reads/s file to file through the C++ driver (FASTQ in, JSON lines out);\n"
           f"{sec['value'] / 1e6:.0f} M reads/s against a 128-bit index with `-k 25 7`"
