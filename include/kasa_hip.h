@@ -274,9 +274,10 @@ int kasa_thread_device(int device);
 /* ---- profile tables: vCount_all / vCount_unique / vCount_total (Compare.hpp:2830-2839) ---------- */
 int kasa_profile_reset(kasa_ctx *ctx);
 /* dst += src, src = 0.  The profile of a batch is made where its queries are GROUPED (kasa_batch_lookup_score, kasa_batch_group):
- * a sum over (group, taxon) of the group's hits (Compare.hpp:922-925), from the sorted queries -- kasa_batch_score adds
- * nothing to the tables.  A context that groups slices for another one (the partition worker of a range-partitioned index)
- * hands its tables on with this call.  Same device, k range and taxa. */
+ * a sum over (group, taxon) of the group's hits (Compare.hpp:922-925), from the sorted queries -- with 32-byte records (up to 8
+ * levels) kasa_batch_score adds nothing to the tables; with 64-byte records (9-25 levels, the 128-bit index's default k range)
+ * the profile still comes from the per-read side, i.e. from kasa_batch_score.  A context that groups slices for another one
+ * (the partition worker of a range-partitioned index) hands its tables on with this call.  Same device, k range and taxa. */
 int kasa_profile_absorb(kasa_ctx *dst, kasa_ctx *src);
 /* countAll as double (exact 64.64 fixed-point sums rounded once), countUnique, countTotal; any may
  * be NULL.  nK * nTaxa entries each. */

@@ -2343,6 +2343,31 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
             });
         }
     }
+    // (cooperative form: the hits of the groups a query heads are needed by the long lists' second pass already -- it counts
+    // their profile keys while it places their segments, which saves a sweep over every long list -- so they are made here
+    // and parked in LDS; the key phase at the end makes them again for everybody)
+    uint32_t longKeysPre[GITEMS] = {0u, 0u};
+    if constexpr (RW == 8 && COOP) {
+        if (!(flags & 8)) {
+            unsigned long long gqE[GITEMS] = {0ull, 0ull};
+            const unsigned long long beyondE = lane == 63 ? 0ull : (~0ull << (lane + 1)), fromMeE = ~0ull << lane;
+#pragma unroll
+            for (int lv = 0; lv < NL; ++lv) {
+                if (lv >= nK) continue;
+                const int k = kHigh - lv;
+                const bool mem0 = d[0] >= k, mem1 = d[1] >= k;
+                const bool head0 = mem0 && (((sp[0] >> lv) & 1u) || lane == 0), head1 = mem1 && ((sp[1] >> lv) & 1u);
+                const unsigned long long stop0 = __ballot(head0 || !mem0), stop1 = __ballot(head1 || !mem1);
+                const unsigned long long s0 = stop0 & beyondE, s1f = stop1 & fromMeE, s1b = stop1 & beyondE;
+                const uint32_t e0 = s0 ? 2u * (uint32_t)(__ffsll((long long)s0) - 1) : 128u;
+                const uint32_t e1f = s1f ? 2u * (uint32_t)(__ffsll((long long)s1f) - 1) + 1u : 128u;
+                const uint32_t e1b = s1b ? 2u * (uint32_t)(__ffsll((long long)s1b) - 1) + 1u : 128u;
+                if (head0) gqE[0] |= (unsigned long long)(min(e0, e1f) - 2u * (uint32_t)lane) << (8 * lv);
+                if (head1) gqE[1] |= (unsigned long long)(min(e0, e1b) - (2u * (uint32_t)lane + 1u)) << (8 * lv);
+            }
+            sHitsQ[t * GITEMS + 0] = gqE[0]; sHitsQ[t * GITEMS + 1] = gqE[1];
+        }
+    }
     // ---- long lists, pass 1 (narrow records): every lane of the wavefront takes entries of the list.  A segment's place in the
     // list is given by its class -- letters in common with the query, descending; left of j before right; nearest first -- so
     // counting the segments per class is enough to place them later (pass 2, once the pool block is allocated).  Here: the
@@ -2504,6 +2529,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                 uint32_t selfSeg = 0; bool anySplit = false;
                 const bool selfEmits = coopCount(j, dd, selfSeg, anySplit);
                 uint32_t *cH = &sCo[wv][32], *cO = &sCo[wv][96];
+                uint32_t Vl = 0, Bl = 0, mineK = 0;                   // the list's profile keys, counted in this sweep
                 {
                     const uint32_t cnt = cH[lane];
                     cO[lane] = wave_incl_sum(cnt) - cnt + (selfEmits ? 1u : 0u);       // first place of class `lane`
@@ -2517,11 +2543,23 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                         pool[off + 3] = f16(s4) | (f16(s5) << 16); pool[off + 4] = f16(s6) | (f16(s7) << 16);
                     }
                     if (selfEmits && lane == 0) sInl[wv][0] = selfSeg;
+                    // the levels with hits and the starts of the runs of equal (|T|, hits), as the key phase will see them
+                    const unsigned long long hqL = (flags & 8) ? 0ull : sHitsQ[(wv * 64 + src) * GITEMS + i];
+                    const uint32_t szl[8] = {f16(s0), f16(s1), f16(s2), f16(s3), f16(s4), f16(s5), f16(s6), f16(s7)};
+                    uint32_t pn = 0, pg = 0;
+#pragma unroll
+                    for (int lv = 0; lv < NL; ++lv) {
+                        const uint32_t h = (uint32_t)(hqL >> (8 * lv)) & 255u;
+                        if (h) { Vl |= 1u << lv; if (!(pg == h && pn == szl[lv])) Bl |= 1u << lv; }
+                        pn = szl[lv]; pg = h;
+                    }
+                    if (selfEmits && lane == 0 && Vl) mineK += (uint32_t)__popc(((Bl & seg_level_mask(selfSeg, kHigh)) | (Vl & seg_level_mask(selfSeg, kHigh) & (0u - seg_level_mask(selfSeg, kHigh)))));
                 }
                 LDS_WAVE_SYNC_G();
                 coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int side, uint32_t em, uint32_t et) {
                     uint32_t sg = 0;
                     const bool emits = segOfV(ok, em, et, v, dd, sg);
+                    if (emits && Vl) { const uint32_t M = seg_level_mask(sg, kHigh); mineK += (uint32_t)__popc((Bl & M) | (Vl & M & (0u - M))); }
                     const uint32_t c = emits ? (uint32_t)((chain0 - v) * 2 + side) : 0xFFFFu;
                     uint32_t place = 0;
                     unsigned long long rem = __ballot(emits);
@@ -2541,10 +2579,12 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
                     }
                 });
                 LDS_WAVE_SYNC_G();
+                const uint32_t keysOfList = wave_total(wave_incl_sum(mineK));
                 if (lane == src) {
                     const uint32_t inl = n <= (uint32_t)INL ? n : (uint32_t)(INL - 1);
 #pragma unroll
                     for (int q = 0; q < INL; ++q) if ((uint32_t)q < inl) seg[i][q] = sInl[wv][q];
+                    longKeysPre[i] = keysOfList;
                 }
                 LDS_WAVE_SYNC_G();
             }
@@ -2694,27 +2734,13 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
             if (longList(i)) continue;                                // (counted by the whole wavefront, below)
             forSegs(i, [&](uint32_t sg) { needK += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), Vm[i], Bm[i])); });
         }
-        // long lists: the keys of their segments, counted (and, further down, written) by all lanes of the wavefront
+        // long lists: the keys of their segments were counted by the second pass (longKeysPre); they are written, further down,
+        // by all lanes of the wavefront
         uint32_t longKeys[GITEMS] = {0u, 0u};
         if constexpr (COOP) {
 #pragma unroll
-        for (int i = 0; i < GITEMS; ++i) {
-            unsigned long long todo = __ballot(gq[i] != 0ull && longList(i));
-            while (todo) {                                           // (uniform)
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const uint32_t j = (uint32_t)__shfl((int)rp[i], src), V = (uint32_t)__shfl((int)Vm[i], src), B = (uint32_t)__shfl((int)Bm[i], src);
-                const int dd = __shfl(d[i], src);
-                uint32_t mine = 0, selfSeg = 0;
-                if (segOf(true, j, dd, dd, selfSeg) && lane == 0) mine += (uint32_t)__popc(startsOf(seg_level_mask(selfSeg, kHigh), V, B));
-                coop_walk<Meta>(meta, tax, nIdx, j, dd, kLow, lane, [&](bool ok, uint32_t, int v, int, uint32_t em, uint32_t et) {
-                    uint32_t sg = 0;
-                    if (segOfV(ok, em, et, v, dd, sg)) mine += (uint32_t)__popc(startsOf(seg_level_mask(sg, kHigh), V, B));
-                });
-                const uint32_t total = wave_total(wave_incl_sum(mine));
-                if (lane == src) { longKeys[i] = total; needK += total; }
-            }
-        }
+            for (int i = 0; i < GITEMS; ++i)
+                if (gq[i] != 0ull && longList(i)) { longKeys[i] = longKeysPre[i]; needK += longKeysPre[i]; }
         }
         __syncthreads();                                             // the owners' level data, the pool blocks (other threads have filled them)
         const uint32_t nPark = (parked && poolOk) ? sOvfN : 0u;
@@ -3857,19 +3883,20 @@ __global__ __launch_bounds__(64 * SD_WAVES) void score_dense_kernel(ScoreArgs A,
             auto segAt = [&](uint32_t i) -> uint32_t {                // segment i of the query (the first 64 were fetched a query ahead)
                 return i < nInl ? (i == 0u ? cb.x : i == 1u ? cb.y : i == 2u ? cb.z : cb.w) : (i < 64u ? cp.seg : more[i - nInl]);
             };
+            // the query's events as scalars, once per query: level and score of event e (events beyond the query's last: level 0,
+            // score 0 -- adding + 0.0f leaves a score as it is, so the replay below needs no branch)
+            int lvE[NLV]; float sE[NLV];
+#pragma unroll
+            for (int e = 0; e < NLV; ++e) {
+                lvE[e] = __builtin_amdgcn_readlane(lvMine, e);
+                sE[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sMine), e));   // (lanes >= nEv hold 0.0f)
+            }
             auto replay = [&](uint32_t levels, float acc) -> float {  // the query's events at the taxon's levels (bit lv = kHigh - k), in flush order
 #pragma unroll
-                for (int e = 0; e < NLV; ++e) {
-                    if (e >= nEv) break;                              // (uniform)
-                    const int lv = __builtin_amdgcn_readlane(lvMine, e);
-                    const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sMine), e));
-                    acc = __fadd_rn(acc, ((levels >> lv) & 1u) ? s : 0.0f);   // (+ 0.0f leaves a score as it is)
-                }
+                for (int e = 0; e < NLV; ++e)                          // acc + s or acc + 0: one fused multiply-add by 1.0f or 0.0f (exact: the product is s or 0)
+                    acc = __fmaf_rn((float)((levels >> lvE[e]) & 1u), sE[e], acc);
                 return acc;
             };
-            // A taxon may own several segments of a REC_SPLIT query (disjoint level ranges): its chain takes the query's events in
-            // ONE pass over the union of their levels.  First sweep: the unions, 8 bits per taxon (sUni, LDS atomics); second
-            // sweep: the first lane to fetch-and-clear a taxon's byte replays it, the others find nothing.
             const int tap = A.forceHandOn;                            // (timing taps, KASA_DENSE_TAP: 1 no union sweep, 2 no replay, 4 one chunk per query)
             if (tap & 4) nseg = nseg < 64u ? nseg : 64u;
             // A long list's chunks of 64 segments: the loads of the next two chunks leave before this one is worked on (always
@@ -5703,7 +5730,7 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
                         nListed, nTiles, why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
             }
             if (nListed && (rc = launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, true, c->tileList.as<uint32_t>(), nListed))) return rc;
-            if ((uint64_t)nListed * 4 > nTiles) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to group_kernel<COOP> directly
+            if ((uint64_t)nListed * 4 > nTiles) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to the older kernel directly
         } else {
             c->lastSlowTiles = 0;
             if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;

@@ -310,7 +310,9 @@ def test_device_coherence_first_match_late_in_a_large_batch(matches):
     ctx.close(); dix.close()
     assert np.array_equal(got.view(np.uint32), coh.view(np.uint32))
     assert (coh > 0).any() == matches
-    assert dt < 2.0, f"{dt:.2f} s: the walk's fix-up rounds did not settle quickly"
+    # (a guard against the round-per-chunk pathology -- minutes for this input -- not a timing test: a busy or freshly started
+    # box may take a second or two for what normally takes 50 ms)
+    assert dt < 30.0, f"{dt:.2f} s: the walk's fix-up rounds did not settle"
 
 
 @pytest.mark.gpu

@@ -957,3 +957,42 @@ def test_records_after_group_to():
     with pytest.raises(RuntimeError):
         b.records()
     a.close(); b.close(); dix.close()
+
+
+@pytest.mark.parametrize("flags", [0], ids=["product_path"])
+@pytest.mark.parametrize("n_taxa", [30, 300], ids=["lists_of_tens", "lists_of_hundreds"])
+def test_wide_records_on_large_taxon_sets(n_taxa, flags):
+    """64-byte records (128-bit index, -k 25 7) where a query meets tens or hundreds of taxa: every score equals the oracle's."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    L = 600
+    root = alphabet[rng.integers(0, 4, size=L)]
+    genomes = []
+    for g in range(n_taxa):
+        s = root.copy()
+        m = rng.random(L) < 0.03
+        s[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+        genomes.append(s)
+    content = formats.Content(["non_unique"] + [f"T{g}" for g in range(n_taxa)],
+                              np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
+    p = oracle.params(25, 7, 3, K=25)
+    kms, tids = [], []
+    for g, s in enumerate(genomes):
+        km, _ = oracle.encode(s, np.array([0, L], dtype=np.int64), p)
+        kms.append(km); tids.append(np.full(km.shape[0], 100 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, 80, 150, 9)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 25, 7, 3)
+    ctx.debug_flags(flags)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    assert ctx.n_kmers == nq and ctx.rec_words == 16
+    tiles, listed = ctx.group_tiles()
+    assert listed == 0 or not flags, (tiles, listed)     # (the product path lists tiles for the older kernel -- or, once a pool retry has made the context sticky, runs it alone)
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.close(); dix.close()
