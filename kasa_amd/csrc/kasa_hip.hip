@@ -2031,7 +2031,13 @@ __device__ __forceinline__ void coop_walk(const Meta *__restrict__ meta, const u
         }
     }
 }
-static constexpr uint32_t LONG_STEPS = 48;        // entries a query's walk may visit lane by lane; beyond: the wavefront takes it (coop_walk)
+// Entries a query's walk may visit lane by lane before its wavefront takes the list (coop_walk).  Measured (KASA_LONG_STEPS): on a
+// crowded index, where lists are either a handful of entries or a clade's 50-200, every lane-by-lane step of a long list is
+// lost (the wavefront waits for it and the list is then walked again): 147 / 128 / 121 / 119 / 119 / 122 / 124 ms at 48 / 24 / 12 /
+// 8 / 6 / 4 / 3 for the 2 M-read batch; on the tiles group2_kernel lists at C2 (heavy 7-letter groups of 20-40 entries) the
+// lane walk is the cheaper one: 60.0 / 66.9 / 70.9 ms at 48 / 12 / 6.  So: 8 for a context on the cooperative kernel for
+// good, 48 for listed tiles.
+static constexpr uint32_t LONG_STEPS = 48, LONG_STEPS_CROWDED = 8;
 
 // Profile key of a record: {level | |T| | taxon | hits:16}.  The three upper fields are as wide as the batch needs
 // (taxon: enough bits that the all-ones value is no taxon -- it marks unused slots; |T| <= 8191 and < nTaxa), so the
@@ -2321,7 +2327,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
             }
             ++n;
             if ((int)((s >> 22) & 31u) > kLow) split = true;
-        }, (RW == 8 && COOP) ? LONG_STEPS : 0xFFFFFFFFu);
+        }, (RW == 8 && COOP) ? (((uint32_t)flags >> 9) & 127u ? ((uint32_t)flags >> 9) & 127u : LONG_STEPS) : 0xFFFFFFFFu);   // (flags bits 9-15: another cut, KASA_LONG_STEPS)
         if (!done) { isLong[i] = true; n = 0; cnt8 = 0; split = false; }   // a LONG list: counted by the whole wavefront below (what was parked is never looked at)
         if (RW == 8 && !COOP && n >= 255u) atomicOr(needCoop, 1u);           // this form cannot count it: the batch is grouped again
         if constexpr (RW == 8) {
@@ -5580,7 +5586,12 @@ static int profile_from_keys(kasa_ctx *c, uint64_t nKeys, bool grouped)
     auto now = [&]() { if (timing) (void)hipStreamSynchronize(ps); return std::chrono::steady_clock::now(); };
     const auto t0 = now();
     const ProfLayout PL = prof_layout(nTaxa, nK);
-    if (grouped && !(c->debugFlags & 67108864)) {                      // (test tap 67108864: the per-|T| cells + leftover sort of round 4)
+    // Which way: the per-|T| cells of round 4 serve sparse taxon sets a little better (C2: 8.0 against 8.4 ms -- one pass over
+    // the keys, |T| = 1 keys one add for all their levels), the exact accumulation below whatever |T| is (crowded: 11 against
+    // 53 ms).  A context on the cooperative group kernel, or whose last batch left a quarter of its keys over, takes the latter.
+    // (test taps: 67108864 always the cells, 268435456 always the accumulation)
+    const bool accum = grouped && !(c->debugFlags & 67108864) && (c->groupCoop || c->profLeftHint > nKeys / 4 || (c->debugFlags & 268435456));
+    if (accum) {
         // exact accumulation of every cell in LDS, a window of levels per pass (24 bytes per cell)
         const uint64_t budget = 152u * 1024u;
         const int perPass = (int)std::min<uint64_t>((uint64_t)nK, budget / ((uint64_t)nTaxa * 24u));
@@ -5702,7 +5713,8 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
         if ((rc = timer_begin(c, c->timers[KASA_STAGE_GROUP], &a, &b))) return rc;
         const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
         static const int g2tap = getenv("KASA_G2_TAP") ? atoi(getenv("KASA_G2_TAP")) : 0;   // (timing taps of group2_kernel: 32, 64, 128)
-        const int cov = (g2tap & (32 | 64 | 128)) | ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
+        static const int longSteps = getenv("KASA_LONG_STEPS") ? (atoi(getenv("KASA_LONG_STEPS")) & 127) : 0;   // (experiments: where a lane gives its walk to the wavefront)
+        const int cov = (g2tap & (32 | 64 | 128)) | ((longSteps ? longSteps : (c->groupCoop ? (int)LONG_STEPS_CROWDED : 0)) << 9) | ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;

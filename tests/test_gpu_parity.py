@@ -840,12 +840,14 @@ def test_random_configurations(seed):
             seg.append(r)
     batch = reads.ReadBatch(np.concatenate(parts) if parts else np.zeros(0, np.uint8), np.asarray(off, dtype=np.int64), None,
                             np.ones(n_reads, dtype=np.uint32), False, np.asarray(seg, dtype=np.uint32) if paired else None)
+    if seed % 5 == 4:
+        flags |= 268435456                                          # (the exact LDS accumulation of the profile keys on sparse taxon sets as well)
     _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
 
 
-@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192, 0, 33554432, 16777216],
+@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192, 0, 33554432, 16777216, 268435456, 67108864 | 262144],
                          ids=["dense_rows", "second_pass", "lane_owned_cells", "coop_group", "coop_group_general", "third_pass", "third_pass_lane_owned_cells",
-                              "product_path", "no_dense_fast_kernel", "older_group_kernel"])
+                              "product_path", "no_dense_fast_kernel", "older_group_kernel", "exact_tables_always", "coop_group_table_cells"])
 def test_general_kernel_on_huge_taxon_sets(flags):
     """Every taxon a light mutation of one root: a query meets hundreds of taxa per level.  On the general score kernel: with
     the read's row in LDS and an event's taxa dealt out to the lanes (the product path for such reads), through its second
