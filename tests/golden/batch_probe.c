@@ -4,6 +4,9 @@
  * starts threads for the batch; so counting memset calls of exactly KASA_PROBE_BYTES bytes between thread creations
  * gives the number of reads in every batch.  Nothing of the reference is copied or changed; the shim only counts.
  *
+ * With KASA_PROBE_KEEP set, remove() of a file whose name holds that string does nothing: the reference's list of the
+ * pieces it reads its input in (Read.hpp:372-600, deleted at Compare.hpp:3694) stays for make_fixtures.py to store.
+ *
  *   gcc -O2 -shared -fPIC -o batch_probe.so batch_probe.c -ldl
  *   KASA_PROBE_BYTES=<4*nTaxa> KASA_PROBE_OUT=<file> LD_PRELOAD=./batch_probe.so kASA identify ...
  */
@@ -48,6 +51,24 @@ int pthread_create(pthread_t *t, const pthread_attr_t *a, void *(*fn)(void *), v
     if (!real_create) init();
     if (out && count != last_logged) { fprintf(out, "%lu\n", count - last_logged); fflush(out); last_logged = count; }
     return real_create(t, a, fn, arg);
+}
+
+int remove(const char *path)
+{
+    static int (*real_remove)(const char *);
+    if (!real_remove) real_remove = dlsym(RTLD_NEXT, "remove");
+    const char *keep = getenv("KASA_PROBE_KEEP");
+    if (keep && *keep && strstr(path, keep)) return 0;
+    return real_remove(path);
+}
+
+int unlink(const char *path)
+{
+    static int (*real_unlink)(const char *);
+    if (!real_unlink) real_unlink = dlsym(RTLD_NEXT, "unlink");
+    const char *keep = getenv("KASA_PROBE_KEEP");
+    if (keep && *keep && strstr(path, keep)) return 0;
+    return real_unlink(path);
 }
 
 __attribute__((destructor)) static void fini(void)

@@ -15,6 +15,7 @@ The binary is started through the dynamic loader because the read-only mount dro
 """
 import gzip
 import json
+import lzma
 import os
 import random
 import shutil
@@ -338,12 +339,12 @@ def build_probe():
     return so
 
 
-def run_probed(args, cwd, n_taxa, probe):
+def run_probed(args, cwd, n_taxa, probe, keep=""):
     """Run the reference and return the number of reads in each of its batches (see batch_probe.c)."""
     tmp = os.path.join(cwd, "tmp")
     os.makedirs(tmp, exist_ok=True)
     log = os.path.join(tmp, "probe.txt")
-    env = dict(os.environ, LD_PRELOAD=probe, KASA_PROBE_BYTES=str(4 * n_taxa), KASA_PROBE_OUT=log)
+    env = dict(os.environ, LD_PRELOAD=probe, KASA_PROBE_BYTES=str(4 * n_taxa), KASA_PROBE_OUT=log, KASA_PROBE_KEEP=keep)
     p = subprocess.run(KASA + args + ["-t", tmp + "/"], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=900)
     if p.returncode != 0:
@@ -436,6 +437,80 @@ def case_batches(out):
         gz(os.path.join(out, big))
 
 
+def case_longseq(out):
+    """A sequence the reference cuts into pieces (Read.hpp:372-467: a piece ends where its k-mers pass 100 MiB) and
+    carries across two batches (strTransfer, Read.hpp:343-356; the pieces' scores merged in Compare.hpp:2344-2426).
+    The database, content file and index are the `batches` case's (rebuilt here from its committed inputs and checked
+    against its committed index); only the input and the reference's outputs are new, and they are stored next to it:
+    short reads that use up most of the -m 1 budget, then one 9.5 Mbp sequence made of mutated copies of the database's
+    genomes (three pieces: the first ends batch 1, the other two share a read id in batch 2), then more short reads."""
+    src = os.path.join(HERE, "batches")
+    for name in ("db.fasta", "content.txt"):
+        with gzip.open(os.path.join(src, name + ".gz"), "rb") as f, open(os.path.join(out, name), "wb") as g:
+            shutil.copyfileobj(f, g)
+    genomes, cur = [], []
+    for line in open(os.path.join(out, "db.fasta")):
+        if line.startswith(">"):
+            if cur:
+                genomes.append("".join(cur))
+            cur = []
+        else:
+            cur.append(line.strip())
+    genomes.append("".join(cur))
+    G, L = len(genomes), len(genomes[0])
+    n_taxa = sum(1 for _ in open(os.path.join(out, "content.txt"))) + 1
+    run(["build", "-c", "content.txt", "-d", "idx", "-i", "db.fasta", "-m", "4", "-n", "1"], out)
+    n = int(open(os.path.join(out, "idx_info.txt")).read().split()[0])
+    with open(os.path.join(out, "idx"), "rb") as f, open(os.path.join(src, "idx"), "rb") as g:
+        assert f.read(n * 12) == g.read(), "the rebuilt index differs from tests/golden/batches/idx"
+    rng = random.Random(41)
+    NS, TAIL, LONG = int(os.environ.get("KASA_LONGSEQ_SHORT", "2100")), 40, 9500000
+    with open(os.path.join(out, "long.fasta"), "w") as f:
+        def short(r):
+            g = rng.randrange(G)
+            p = rng.randrange(L - 150)
+            f.write(">s%d_t%d\n%s\n" % (r, g, mutate(genomes[g][p:p + 150], 0.02, rng)))
+        for r in range(NS):
+            short(r)
+        f.write(">contig made of the database\n")
+        col, left = 0, LONG
+        while left > 0:
+            s = mutate(genomes[rng.randrange(G)], 0.003, rng)[:left]
+            left -= len(s)
+            i = 0
+            while i < len(s):                                  # 70 letters per line
+                take = min(70 - col, len(s) - i)
+                f.write(s[i:i + take])
+                i += take
+                col += take
+                if col == 70:
+                    f.write("\n")
+                    col = 0
+        if col:
+            f.write("\n")
+        for r in range(TAIL):
+            short(NS + 1 + r)
+    probe = build_probe()
+    sizes = {}
+    for name, extra in (("long", []), ("long_six", ["--six"])):
+        batches = run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", "long.fasta", "--jsonl", "-b", "100", "-m", "1"] + extra +
+                             ["-q", "out_%s.jsonl" % name, "-p", "prof_%s.csv" % name], out, n_taxa, probe, keep="_fileInfo.txt")
+        # the reference's own list of pieces (skip lines, getChunk calls, pieces left), kept from deletion by the probe: the
+        # lines of the long sequence are what the restatement of Read.hpp:372-467 has to reproduce
+        info = os.path.join(out, "tmp", "long_fileInfo.txt")
+        pieces = [l.strip() for l in open(info) if not l.strip().endswith(",1") or l.startswith("0,")]
+        os.remove(info)
+        sizes[name] = {"batches": batches, "pieces_of_the_long_sequence": pieces}
+    with open(os.path.join(src, "long.json"), "w") as f:
+        json.dump(sizes, f, indent=1)
+    with open(os.path.join(out, "long.fasta"), "rb") as f, lzma.open(os.path.join(src, "long.fasta.xz"), "wb", preset=9) as g:
+        shutil.copyfileobj(f, g)
+    for name in sizes:
+        with open(os.path.join(out, "out_%s.jsonl" % name), "rb") as f, gzip.GzipFile(os.path.join(src, "out_%s.jsonl.gz" % name), "wb", mtime=0) as g:
+            shutil.copyfileobj(f, g)
+        shutil.copy(os.path.join(out, "prof_%s.csv" % name), os.path.join(src, "prof_%s.csv" % name))
+
+
 def finish(out):
     trim_index(out)
     for junk in ("tmp", "stxxl.log", "stxxl.errlog"):
@@ -460,6 +535,13 @@ def main():
         fn(out)
         finish(out)
         print("wrote", out, sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+    if not only or "longseq" in only or "batches" in only:      # lives in batches/ (same database): goes when that is rebuilt
+        keep = os.environ.get("KASA_LONGSEQ_DIR")
+        with tempfile.TemporaryDirectory() as tmp:
+            work = keep or tmp
+            os.makedirs(work, exist_ok=True)
+            case_longseq(work)
+        print("wrote the long-sequence case into", os.path.join(HERE, "batches"))
     ver = subprocess.run(KASA, stdout=subprocess.PIPE, text=True, timeout=60).stdout.splitlines()[0]
     with open(os.path.join(HERE, "PROVENANCE.json"), "w") as f:
         json.dump({"reference_binary": "binaries/kASA_linux", "banner": ver.split(" ran on")[0],
