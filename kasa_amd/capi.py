@@ -259,6 +259,32 @@ class RefBatcher:
         return out
 
 
+    def piece_batches(self, pieced, want_per_read: bool = True) -> list:
+        """The reference's batches over an input with sequences read in PIECES (ReadBatch.with_pieces): [0, p1, p2, ..., nPieces],
+        piece indices.  A piece takes its k-mers and text from the budget when it is read, the read's own share (specifier,
+        score row) goes with its last piece (Read.hpp:1157-1194); a batch may end between two pieces of one read."""
+        L = lib()
+        protein = bool(pieced.protein)
+        mode = 2 if protein else (1 if self.frames == 1 else 0)
+        strands = 2 if (self.frames == 6 and not protein) else 1
+        seq_len = np.diff(pieced.offsets).astype(np.int64)
+        cost = np.array([L.kasa_refbatch_sequence_cost(self.K, self.k_low, mode, strands, int(x), self.coherence) for x in seq_len], dtype=np.int64)
+        seg = pieced.seg_read.astype(np.int64)
+        last = np.ones(len(seg), bool)
+        last[:-1] = seg[1:] != seg[:-1]
+        if want_per_read:
+            over = np.array([L.kasa_refbatch_read_overhead(len(n.encode("latin-1", "replace")), self.n_taxa, self.coherence) for n in pieced.names], dtype=np.int64)
+            cost[last] += over[seg[last]]
+        cost = np.ascontiguousarray(cost)
+        out, done, first = [0], 0, 1
+        while done < len(cost):
+            n = int(L.kasa_refbatch_cut(self.budget, first, cost[done:].ctypes.data, len(cost) - done))
+            done += max(n, 1)
+            out.append(done)
+            first = 0
+        return out
+
+
 RANK_ENTRY = np.dtype([("tax", np.uint32), ("score", np.float32), ("rel", np.float64)])
 
 

@@ -287,19 +287,25 @@ struct ReadSet {
     HugeVec<uint8_t> bases; HugeVec<int64_t> off;              // off[nSequences + 1], off[0] = 0
     HugeVec<char> nameBlob; HugeVec<uint64_t> nameOff;         // specifier of read r = nameBlob[nameOff[r] .. nameOff[r + 1])
     HugeVec<uint32_t> lengths;                                 // "Length" of read r
-    bool protein = false;
+    bool protein = false, fasta = true;
+    // A record of a million letters and more: how the reference's reader cuts its lines (Utilities::FileReader hands out text
+    // up to the next line feed or the end of its 2048-byte buffer, Utilities.hpp:448-539) -- it reads such a record in
+    // pieces that end with one of those calls (Read.hpp:371-600; Batcher::piecesOf).
+    struct LongRec { size_t read; vector<uint32_t> letters; vector<uint8_t> feed; };
+    vector<LongRec> longRecs;
     ReadSet() { off.push_back(0); nameOff.push_back(0); }
     ReadSet(ReadSet &&) = default;
     ReadSet &operator=(ReadSet &&) = default;
     size_t size() const { return lengths.size(); }
     size_t nameLen(size_t r) const { return (size_t)(nameOff[r + 1] - nameOff[r]); }
     std::string_view name(size_t r) const { return std::string_view(nameBlob.data() + nameOff[r], nameLen(r)); }
-    void clear() { bases.clear(); off.clear(); off.push_back(0); nameBlob.clear(); nameOff.clear(); nameOff.push_back(0); lengths.clear(); }
+    void clear() { bases.clear(); off.clear(); off.push_back(0); nameBlob.clear(); nameOff.clear(); nameOff.push_back(0); lengths.clear(); longRecs.clear(); }
     // reads [first, last) as a set of their own (spr sequences per read; offsets rebased); `threads` copy the bases
     ReadSet slice(size_t first, size_t last, size_t spr, unsigned threads) const
     {
         ReadSet o;
-        o.protein = protein;
+        o.protein = protein; o.fasta = fasta;
+        for (const LongRec &lr : longRecs) if (lr.read >= first && lr.read < last) { o.longRecs.push_back(lr); o.longRecs.back().read -= first; }
         const size_t m = last - first;
         const int64_t s0 = off[first * spr], s1 = off[last * spr];
         o.bases.resize((size_t)(s1 - s0)); parCopy(o.bases.data(), bases.data() + s0, (size_t)(s1 - s0), threads);
@@ -316,6 +322,7 @@ struct ReadSet {
     void appendSet(const ReadSet &q, unsigned threads)
     {
         const size_t b0 = bases.size(), n0 = nameBlob.size(), r0 = size(), s0 = off.size() - 1, ns = q.off.size() - 1;
+        for (const LongRec &lr : q.longRecs) { longRecs.push_back(lr); longRecs.back().read += r0; }
         bases.resize(b0 + q.bases.size()); parCopy(bases.data() + b0, q.bases.data(), q.bases.size(), threads);
         nameBlob.append(q.nameBlob.data(), q.nameBlob.size());
         off.resize(s0 + ns + 1); nameOff.resize(r0 + q.size() + 1); lengths.resize(r0 + q.size());
@@ -346,8 +353,11 @@ static bool detectProtein(const char *data, size_t size, bool verbose)
 
 // One run of whole records, data[begin, end) with begin at a header line: what Read.hpp:699-760 hands on, for reads that
 // fit one chunk.  A '\r' stays part of its line, as with the reference's getline.
-static void parseRecords(const char *data, size_t begin, size_t end, bool fasta, ReadSet &rs)
+static const size_t kLongSequence = 1000000;      // shorter records are one piece whatever the options (100 MiB / 48 B / 2 strands)
+
+static void parseRecords(const char *data, size_t begin, size_t end, bool fasta, ReadSet &rs, size_t streamBase)
 {
+    rs.fasta = fasta;
     size_t a = begin;
     auto nextLine = [&](size_t &lb, size_t &le) -> bool {          // [lb, le) without the line feed
         if (a >= end) return false;
@@ -366,14 +376,26 @@ static void parseRecords(const char *data, size_t begin, size_t end, bool fasta,
         rs.nameBlob.append(data + lb + 1, le - lb - 1);             // Read.hpp:711-714: header without its first character
         rs.nameBlob.push_back(' ');                                 // ... plus a trailing space
         rs.nameOff.push_back(rs.nameBlob.size());
-        uint32_t nLines = 0; const size_t b0 = rs.bases.size();
+        uint32_t nLines = 0; const size_t b0 = rs.bases.size(), seqBegin = a;
         while ((have = nextLine(lb, le))) {
             const bool empty = lb == le;
             if (!empty && data[lb] == (fasta ? '>' : '+')) break;
             if (!empty) rs.bases.append((const uint8_t *)data + lb, le - lb);
             if (!empty || !fasta) ++nLines;
         }
-        const size_t len = rs.bases.size() - b0;
+        const size_t len = rs.bases.size() - b0, seqEnd = have ? lb : end;
+        if (len >= kLongSequence) {
+            // the getChunk calls over the record's lines: each ends at a line feed or at the next multiple of 2048 bytes of the file
+            ReadSet::LongRec lr; lr.read = rs.lengths.size();
+            for (size_t pos = seqBegin; pos < seqEnd;) {
+                const size_t bufEnd = ((streamBase + pos) / 2048 + 1) * 2048 - streamBase, limit = std::min(bufEnd, seqEnd);
+                const void *nl = memchr(data + pos, '\n', limit - pos);
+                if (nl) { const size_t q = (size_t)((const char *)nl - data); lr.letters.push_back((uint32_t)(q - pos)); lr.feed.push_back(1); pos = q + 1; }
+                else if (limit == bufEnd) { lr.letters.push_back((uint32_t)(limit - pos)); lr.feed.push_back(0); pos = limit; }
+                else { lr.letters.push_back((uint32_t)(seqEnd - pos)); lr.feed.push_back(1); pos = seqEnd; }   // the file ends without a line feed: the reader supplies one
+            }
+            rs.longRecs.push_back(std::move(lr));
+        }
         for (size_t k = b0; k < rs.bases.size(); ++k)
             if (rs.bases[k] == ' ' || rs.bases[k] == '\t') throw std::runtime_error("Spaces or tabs inside read, please check your input."); // Read.hpp:659
         if (!fasta) {                                               // the '+' line is current: quality lines follow
@@ -418,7 +440,7 @@ static size_t findRecordStart(const char *data, size_t size, size_t from, bool f
 // A piece of whole records parsed by several threads and put behind the reads `out` holds: the piece is cut into one run per
 // thread at safe record starts, every run is parsed into a set of its own (`parts`: kept by the caller over its pieces, so
 // that their pages are touched once), and the same threads copy the runs to their places in `out`.
-static void parsePiece(const char *data, size_t size, bool fasta, unsigned threads, size_t minRun, ReadSet &out, vector<ReadSet> &parts)
+static void parsePiece(const char *data, size_t size, bool fasta, unsigned threads, size_t minRun, ReadSet &out, vector<ReadSet> &parts, size_t streamBase)
 {
     if (const char *e = getenv("KASA_PARSE_CHUNK")) minRun = std::max<size_t>(1, (size_t)atoll(e));   // tests force small runs
     const size_t want = std::max<size_t>(1, std::min<size_t>(threads ? threads : 1, size / minRun));
@@ -437,15 +459,17 @@ static void parsePiece(const char *data, size_t size, bool fasta, unsigned threa
         for (auto &t : pool) t.join();
         for (auto &e : err) if (e) std::rethrow_exception(e);          // like Compare.hpp:3312-3314
     };
-    if (nc == 1 && out.size() == 0 && out.bases.empty()) { ScopedTimer tm(g_ht.parse); parseRecords(data, 0, size, fasta, out); return; }
+    if (nc == 1 && out.size() == 0 && out.bases.empty()) { ScopedTimer tm(g_ht.parse); parseRecords(data, 0, size, fasta, out, streamBase); return; }
     if (parts.size() < nc) parts.resize(nc);
-    { ScopedTimer tm(g_ht.parse); inParallel([&](size_t c) { parts[c].clear(); parseRecords(data, cut[c], cut[c + 1], fasta, parts[c]); }); }
+    { ScopedTimer tm(g_ht.parse); inParallel([&](size_t c) { parts[c].clear(); parseRecords(data, cut[c], cut[c + 1], fasta, parts[c], streamBase); }); }
     ScopedTimer tmMerge(g_ht.merge);
     // the runs' reads behind the pending ones: places from running sums, copies by the same threads
     vector<size_t> b0(nc), r0(nc), m0(nc);
     size_t nb = out.bases.size(), nr = out.size(), nm = out.nameBlob.size();
     for (size_t c = 0; c < nc; ++c) { b0[c] = nb; r0[c] = nr; m0[c] = nm; nb += parts[c].bases.size(); nr += parts[c].size(); nm += parts[c].nameBlob.size(); }
     out.bases.resize(nb); out.off.resize(nr + 1); out.nameBlob.resize(nm); out.nameOff.resize(nr + 1); out.lengths.resize(nr);
+    out.fasta = fasta;
+    for (size_t c = 0; c < nc; ++c) for (ReadSet::LongRec &lr : parts[c].longRecs) { out.longRecs.push_back(std::move(lr)); out.longRecs.back().read += r0[c]; }
     inParallel([&](size_t c) {
         const ReadSet &q = parts[c];
         if (!q.bases.empty()) memcpy(out.bases.data() + b0[c], q.bases.data(), q.bases.size());
@@ -473,7 +497,7 @@ static ReadSet readInput(const string &path, bool verbose, unsigned threads)
     const bool fasta = data[0] == '>';
     rs.protein = detectProtein(data.data(), data.size(), verbose);
     vector<ReadSet> parts;
-    parsePiece(data.data(), data.size(), fasta, threads, 8u << 20, rs, parts);
+    parsePiece(data.data(), data.size(), fasta, threads, 8u << 20, rs, parts, 0);
     return rs;
 }
 
@@ -510,6 +534,7 @@ struct ChunkReader {
     }
     ~ChunkReader() { if (g) gzclose(g); if (fd >= 0) ::close(fd); }
     off_t filePos = 0, fileSize = -1;
+    size_t handedOut = 0, chunkStart = 0;         // where the chunk last handed out starts in the (inflated) file
     long readSome(char *dst, size_t want)
     {
         if (g) return gzread(g, dst, (unsigned)std::min<size_t>(want, 1u << 30));
@@ -583,9 +608,10 @@ struct ChunkReader {
             std::memcpy(T.data(), D.data() + cut, have - cut);
             chunk = D.data(); size = cut;
             have -= cut; cur ^= 1;
+            chunkStart = handedOut; handedOut += size;
             return true;
         }
-        if (have > 0) { chunk = buf[cur].data(); size = have; have = 0; return true; }
+        if (have > 0) { chunk = buf[cur].data(); size = have; have = 0; chunkStart = handedOut; handedOut += size; return true; }
         return false;
     }
 };
@@ -943,14 +969,47 @@ template <class T> struct PcieBuf {
     const T &operator[](size_t i) const { return p[i]; }
 };
 
+struct SplitCarry;
 struct Batch {
     uint64_t id = 0, firstRead = 0;
+    SplitCarry *carry = nullptr;
     ReadSet rs;                                   // the batch's reads (offsets start at 0)
     vector<uint32_t> segRead;                     // paired-end: read of every sequence
     vector<uint64_t> flagged;                     // --filter: read numbers of contaminants
     uint64_t kmers = 0;
     uint32_t flaggedByDevice = 0;                 // reads kasa_batch_rank handed back to the host's std::sort
     bool done = false;
+    bool head = false, tail = false;              // read 0 goes on from the batch before / the last read goes on in the next batch (pieces, below)
+};
+
+// What an unfinished read has scored so far (Compare::saveResults' vSavedScores, Compare.hpp:2324-2443): left by the batch
+// that ends inside a read for the batch that goes on with it -- which may be another worker's, hence the lock.
+struct SplitCarry {
+    std::mutex mu; std::condition_variable cv;
+    std::map<uint64_t, vector<std::pair<uint32_t, float>>> after;   // batch id -> what waits behind it
+    bool abandoned = false;
+    void put(uint64_t id, vector<std::pair<uint32_t, float>> v) { { std::lock_guard<std::mutex> lk(mu); after[id] = std::move(v); } cv.notify_all(); }
+    vector<std::pair<uint32_t, float>> take(uint64_t id)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return abandoned || after.count(id); });
+        if (abandoned) throw std::runtime_error("another batch failed");
+        auto v = std::move(after[id]); after.erase(id);
+        return v;
+    }
+    void abandon() { { std::lock_guard<std::mutex> lk(mu); abandoned = true; } cv.notify_all(); }
+    // taxa ascending on both sides; a taxon on both sides gets the float sum (Compare.hpp:2347-2360)
+    static vector<std::pair<uint32_t, float>> merge(const vector<std::pair<uint32_t, float>> &a, const uint32_t *tax, const float *sc, uint64_t n)
+    {
+        vector<std::pair<uint32_t, float>> o; o.reserve(a.size() + n);
+        size_t i = 0; uint64_t j = 0;
+        while (i < a.size() || j < n) {
+            if (j == n || (i < a.size() && a[i].first < tax[j])) o.push_back(a[i++]);
+            else if (i == a.size() || tax[j] < a[i].first) { o.emplace_back(tax[j], sc[j]); ++j; }
+            else { o.emplace_back(tax[j], a[i].second + sc[j]); ++i; ++j; }
+        }
+        return o;
+    }
 };
 
 // Cuts the reads of one input into batches.  With per-read output the batches are the reference's own: per-read scores
@@ -968,6 +1027,9 @@ struct Batcher {
     uint64_t maxKmersPerBatch;
     double parseSeconds = 0;
     bool protein = false;
+    // pieces (nextPieced): the read at pendPos has handed out `midPiece` of its pieces; "Length" as the reader's calls count it
+    bool midRead = false; size_t midPiece = 0;
+    int64_t carriedLen = 0;                       // strTransfer::lengthOfDNA (Read.hpp:1181)
 
     Batcher(const Params &pp, const IndexFiles &f, bool rows, uint64_t maxKmers) : p(pp), ixf(f), wantRows(rows), paired(!pp.input2.empty()), maxKmersPerBatch(maxKmers)
     {
@@ -1022,7 +1084,7 @@ struct Batcher {
             pending.bases.reserve(left / 2 + left / 8 + 1024); pending.nameBlob.reserve(left / 8 + 1024);
             pending.nameOff.reserve(left / 160 + 17); pending.lengths.reserve(left / 160 + 16); pending.off.reserve(left / 160 + 17);
         }
-        parsePiece(chunk, chunkBytes, reader->fasta, p.threads, 1u << 20, pending, parts);
+        parsePiece(chunk, chunkBytes, reader->fasta, p.threads, 1u << 20, pending, parts, reader->chunkStart);
     }
     // What the first batch will need on the device, from the reads parsed so far and the size of the file: the device buffers
     // are allocated while the rest of the input is parsed (kasa_ctx_reserve).
@@ -1052,11 +1114,154 @@ struct Batcher {
         nQueries = (uint64_t)(q * 1.01); nBases = (uint64_t)(reads * bases * 1.01);
     }
     // the next batch; false at the end of the input
+    // --- sequences the reference reads in pieces -------------------------------------------------------------------
+    // Read::readFileAndGenerateInfos (Read.hpp:371-600) ends a piece after the getChunk call with which the k-mers of what
+    // it has read of the record so far would take more than 100 MiB of the input vector (FASTA: line feeds count as
+    // letters there); what is left when the record ends is the last piece, possibly empty.  -> letters before every cut,
+    // and what every piece adds to "Length" (letters + line feeds, Read.hpp:723-731).
+    struct Pieces { vector<int64_t> cut, add; };
+    Pieces piecesOf(const ReadSet::LongRec &lr, bool fasta) const
+    {
+        const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
+        const int64_t K = p.K, elem = p.coherence ? (K > 12 ? 40 : 32) : (K > 12 ? 32 : 24);      // InputType::sizeOf, MetaHeader.h:221-223
+        const int64_t mult = elem * ((strands == 2 && mode != 2) ? 2 : 1), limit = 100ll * 1024 * 1024;
+        auto count = [&](int64_t len) -> int64_t {                                                  // Read.hpp:36-57
+            if (mode == 2) return len > K + 1 ? len - K + 1 : 0;
+            if (mode == 1) return len / 3 > K + 1 ? len / 3 - K + 1 : 0;
+            return len > 3 * K + 1 ? len - 3 * K + 1 : 0;
+        };
+        Pieces pc; pc.cut.push_back(0);
+        int64_t chars = 0, letters = 0, total = 0, totalAtCut = 0;
+        for (size_t i = 0; i < lr.letters.size(); ++i) {
+            const int64_t l = lr.letters[i], f = lr.feed[i];
+            letters += l; total += l + f;
+            if (l > 0) chars += l + (fasta ? f : 0);                                                // (a call without text is not counted: Read.hpp:394,445)
+            if (l > 0 && count(chars) * mult > limit) { pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut); totalAtCut = total; chars = 0; }
+        }
+        pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut);
+        return pc;
+    }
+    std::map<size_t, Pieces> pieceCache;           // read (index in `pending`) -> its pieces, for records with more than one
+    size_t cachedFor = ~(size_t)0, cachedRecs = 0;
+    const Pieces *piecesOfRead(size_t r)
+    {
+        if (cachedFor != pending.bases.size() || cachedRecs != pending.longRecs.size()) {          // `pending` changed: its reads have other numbers
+            pieceCache.clear();
+            for (const ReadSet::LongRec &lr : pending.longRecs) { Pieces pc = piecesOf(lr, pending.fasta); if (pc.cut.size() > 2) pieceCache.emplace(lr.read, std::move(pc)); }
+            cachedFor = pending.bases.size(); cachedRecs = pending.longRecs.size();
+        }
+        auto it = pieceCache.find(r);
+        return it == pieceCache.end() ? nullptr : &it->second;
+    }
+    bool pendingHasPieces() { (void)piecesOfRead(0); for (auto &kv : pieceCache) if (kv.first >= pendPos) return true; return false; }
+    // A batch over an input with such records: the unit is the piece.  A piece takes its k-mers and its text from the budget
+    // when it is read, the read's own share goes with its last piece (Read.hpp:1157-1194); the batch may end between two
+    // pieces of a read (strTransfer, Read.hpp:343-356) -- the read is then the unfinished last one of this batch and read 0
+    // of the next (Batch::tail / head; runBatch keeps its scores).  Every piece but a read's first starts with the last 3K-1
+    // letters of the text before it (Read.hpp:678-697,738-741).
+    bool nextPieced(Batch &b, std::chrono::steady_clock::time_point t0)
+    {
+        if (p.coherence) throw std::runtime_error("--coherence over sequences long enough for kASA to read them in pieces is not supported");
+        const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
+        const uint32_t nTaxa = (uint32_t)ixf.content.taxids.size();
+        const int64_t over = (protein ? p.K : 3 * p.K) - 1;
+        int64_t left = refBudget;
+        if (useRef && !firstBatch && refBudget - (int64_t)(refBudget * 0.001) > 0) left -= (int64_t)(refBudget * 0.001);
+        struct Item { size_t r; size_t piece, nPieces; int64_t from, to; };     // letters [from, to) of read r (from: with the overhang)
+        vector<Item> items;
+        uint64_t est = 0;
+        bool full = false, deviceFull = false;
+        size_t r = pendPos, piece = midRead ? midPiece : 0;
+        b.head = midRead;
+        while (!full) {
+            if (r == pending.size()) {
+                if (!items.empty() || midRead) {
+                    // (refill drops the reads before pendPos: the items of this batch must stay, so the chunk goes behind them)
+                    const size_t before = pending.size();
+                    const char *chunk = nullptr; size_t chunkBytes = 0;
+                    if (!reader || !reader->next(chunk, chunkBytes, p.verbose)) break;
+                    parsePiece(chunk, chunkBytes, reader->fasta, p.threads, 1u << 20, pending, parts, reader->chunkStart);
+                    if (pending.size() == before) break;
+                } else {
+                    const size_t before = pending.size() - pendPos;
+                    refill();
+                    r = pendPos;
+                    if (pending.size() - pendPos == before) break;
+                }
+            }
+            ScopedTimer tmForm(g_ht.form);
+            for (; r < pending.size() && !full; ++r, piece = 0) {
+                const Pieces *pc = piecesOfRead(r);
+                const int64_t len = pending.off[r + 1] - pending.off[r];
+                const size_t nP = pc ? pc->cut.size() - 1 : 1;
+                int64_t textLen = 0;                                             // of the piece before (for the overhang)
+                for (size_t i = 0; i < piece; ++i) textLen = std::min(over, textLen) + pc->cut[i + 1] - pc->cut[i];
+                for (; piece < nP; ++piece) {
+                    if (useRef && left <= 100ll * 1024 * 1024 && !items.empty()) { full = true; break; }     // Read.hpp:1147
+                    const int64_t c0 = pc ? pc->cut[piece] : 0, c1 = pc ? pc->cut[piece + 1] : len;
+                    const int64_t keep = piece ? std::min(over, textLen) : 0;
+                    const int64_t tl = keep + c1 - c0;
+                    int64_t cost = 0;
+                    if (useRef) {
+                        cost = kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, tl, 0);
+                        if (piece + 1 == nP) cost += kasa_refbatch_read_overhead((int64_t)pending.nameLen(r), nTaxa, 0);
+                    }
+                    const uint64_t k = (uint64_t)(tl + 64) * (uint64_t)strands;
+                    if (!items.empty() && est + k > maxKmersPerBatch) { deviceFull = true; full = true; break; }
+                    est += k; left -= cost;
+                    items.push_back({r, piece, nP, c0 - keep, c1});
+                    textLen = tl;
+                }
+                if (full) break;
+            }
+        }
+        if (items.empty()) { parseSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); return false; }
+        {
+            ScopedTimer tmForm(g_ht.form);
+            ReadSet &o = b.rs;
+            o.protein = pending.protein; o.fasta = pending.fasta;
+            int64_t runLen = carriedLen;                                         // iLengthOfRead starts from what the batches before have read of the read (Read.hpp:1117)
+            size_t lastR = ~(size_t)0; uint32_t local = 0;
+            for (const Item &it : items) {
+                if (it.r != lastR) {
+                    if (lastR != ~(size_t)0) ++local;
+                    lastR = it.r;
+                    o.nameBlob.append(pending.nameBlob.data() + pending.nameOff[it.r], pending.nameLen(it.r));
+                    o.nameOff.push_back(o.nameBlob.size());
+                    o.lengths.push_back(pending.lengths[it.r]);
+                }
+                o.bases.append(pending.bases.data() + pending.off[it.r] + it.from, (size_t)(it.to - it.from));
+                o.off.push_back((int64_t)o.bases.size());
+                b.segRead.push_back(local);
+                if (it.nPieces > 1) {
+                    const Pieces *pc = piecesOfRead(it.r);
+                    runLen += pc->add[it.piece];
+                    if (it.piece + 1 == it.nPieces) { o.lengths[local] = (uint32_t)runLen; runLen = 0; carriedLen = 0; }
+                    else carriedLen += runLen;                                   // Read.hpp:1181: grows by the running length at every unfinished piece
+                } else runLen = 0;
+            }
+            const Item &lastItem = items.back();
+            b.tail = lastItem.piece + 1 < lastItem.nPieces;
+            midRead = b.tail; midPiece = b.tail ? lastItem.piece + 1 : 0;
+            pendPos = b.tail ? lastItem.r : lastItem.r + 1;
+            const uint64_t nLocal = (uint64_t)local + 1;
+            b.firstRead = nextRead;
+            nextRead += nLocal - (b.tail ? 1 : 0);
+        }
+        if (useRef && deviceFull && !p.allowDeviceSplit)
+            throw std::runtime_error("a batch of the reference's size (-m " + std::to_string(p.memoryGiB) + ") does not fit the device; use a smaller -m, more devices' memory, or --allow-device-split");
+        firstBatch = false;
+        parseSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return true;
+    }
     bool next(Batch &b)
     {
         const auto t0 = std::chrono::steady_clock::now();
         b = Batch();
         b.id = nextId++; b.firstRead = nextRead;
+        if (!paired && (midRead || pendingHasPieces())) return nextPieced(b, t0);
+        if (paired && !pending.longRecs.empty() && pendingHasPieces())
+            throw std::runtime_error("a paired-end input with sequences long enough for kASA to read them in pieces is not supported");
         const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
         const size_t spr = seqPerRead();
         int64_t left = refBudget;
@@ -1075,6 +1280,7 @@ struct Batcher {
                 refill();                                                   // (may drop the reads before pendPos)
                 r = pendPos + keep;
                 if (pending.size() - pendPos == before) break;             // end of the input
+                if (!paired && pendingHasPieces()) return nextPieced(b, t0);   // a record the reference reads in pieces has come in: the batch is formed piece by piece
             }
             ScopedTimer tmForm(g_ht.form);
             for (; r < pending.size(); ++r) {
@@ -1085,13 +1291,6 @@ struct Batcher {
                     const int64_t l = pending.off[r * spr + q + 1] - pending.off[r * spr + q];
                     len += (uint64_t)l;
                     if (useRef) cost += kasa_refbatch_sequence_cost(p.K, p.kLow, mode, strands, l, p.coherence ? 1 : 0);
-                }
-                if (useRef && cost > 100ll * 1024 * 1024 && !warnedLong) {
-                    // kASA cuts a sequence whose k-mers outrun what is left of its batch budget into pieces with a 3K - 1 overhang and
-                    // merges the pieces' scores (Read.hpp:343-356,678-695; Compare.hpp:2344-2426); here a sequence is always scored whole
-                    std::cerr << "WARNING: sequence " << (nextRead + n) << " (" << len << " letters) is long enough for kASA to split it across its batches (-m); "
-                                 "it is scored in one piece here: its per-read line differs from kASA's." << std::endl;
-                    warnedLong = true;
                 }
                 const uint64_t k = (len + 64 * spr) * (uint64_t)strands;
                 if (n > 0 && est + k > maxKmersPerBatch) { deviceFull = true; full = true; break; }
@@ -1299,7 +1498,8 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
     // std::sort's unstable regime) or when there are too many distinct lengths for a table.
     PcieBuf<uint32_t> &meta = wb.meta; PcieBuf<Writer::DeviceHit> &hits = wb.hits;
     uint32_t nFlagged = 0;
-    bool deviceRank = nr > 0 && !p.hostRank;
+    const bool split = b.head || b.tail;                         // a read of this batch is scored over several batches: its rows come to the host
+    bool deviceRank = nr > 0 && !p.hostRank && !split;
     if (deviceRank) {
         std::map<uint32_t, uint32_t> classOf;
         { uint32_t last = ~0u; for (uint64_t r = 0; r < nr; ++r) if (b.rs.lengths[r] != last) { last = b.rs.lengths[r]; classOf.emplace(last, 0u); } }   // (runs of equal lengths: one lookup)
@@ -1363,11 +1563,30 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
         if (kasa_batch_scores_fetch(ctx, ro.data(), tx.data(), sc.data())) throwLast();
     }
     b.flaggedByDevice = nFlagged;
+    // Compare::saveResults (Compare.hpp:2324-2443): what is waiting of an unfinished read joins read 0 when this batch ends
+    // with a finished read; otherwise it stays and takes the unfinished last read's row as well -- the reference's own rule
+    vector<uint32_t> mergedTax; vector<float> mergedSc; bool read0Merged = false;
+    if (split) {
+        if (!b.carry) throw std::runtime_error("a batch with an unfinished read has nowhere to leave its scores");
+        vector<std::pair<uint32_t, float>> saved;
+        if (b.head) saved = b.carry->take(b.id - 1);
+        if (!saved.empty() && !b.tail) {
+            const auto m = SplitCarry::merge(saved, tx.data() + ro[0], sc.data() + ro[0], ro[1] - ro[0]);
+            for (const auto &e : m) { mergedTax.push_back(e.first); mergedSc.push_back(e.second); }
+            read0Merged = true;
+            saved.clear();
+        }
+        if (b.tail) {
+            if (ro[nr] > ro[nr - 1]) saved = SplitCarry::merge(saved, tx.data() + ro[nr - 1], sc.data() + ro[nr - 1], ro[nr] - ro[nr - 1]);
+            b.carry->put(b.id, std::move(saved));
+        }
+    }
+    const uint64_t nPrinted = b.tail ? nr - 1 : nr;            // the unfinished read is printed by the batch that finishes it
     tDevice += secondsSince(tDev);
     const auto tTxt = std::chrono::steady_clock::now();
     const uint64_t slab = 1u << 15;
-    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, (nr + slab - 1) / slab));
-    const uint64_t nSlabs = (nr + slab - 1) / slab;
+    const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(p.threads, (nPrinted + slab - 1) / slab));
+    const uint64_t nSlabs = (nPrinted + slab - 1) / slab;
     out.begin(b.id, (size_t)nSlabs);
     vector<vector<uint64_t>> flagged(nSlabs);
     vector<std::exception_ptr> err(nt);
@@ -1378,12 +1597,14 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
             for (;;) {
                 const uint64_t sidx = nextSlab.fetch_add(1);
                 if (sidx >= nSlabs) break;
-                const uint64_t a = sidx * slab, e = std::min<uint64_t>(nr, a + slab);
+                const uint64_t a = sidx * slab, e = std::min<uint64_t>(nPrinted, a + slab);
                 string text;
                 text.reserve((size_t)(e - a) * (p.fmt == Params::Json ? 900 : 600));
                 for (uint64_t r = a; r < e; ++r) {
                     if (p.coherence) w.coherence = coherence[r];
-                    if (deviceRank && !(meta[4 * r + 1] >> 31)) {
+                    if (r == 0 && read0Merged)
+                        w.read(text, b.firstRead, b.rs.name(0), b.rs.lengths[0], mergedTax.data(), mergedSc.data(), mergedTax.size());
+                    else if (deviceRank && !(meta[4 * r + 1] >> 31)) {
                         float maxV; std::memcpy(&maxV, &meta[4 * r + 2], 4);
                         w.readRanked(text, b.firstRead + r, b.rs.name(r), b.rs.lengths[r], hits.data() + meta[4 * r], meta[4 * r + 1], maxV);
                     } else
@@ -1469,6 +1690,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     std::exception_ptr failure;
     vector<double> tDevice(nDev, 0.0), tText(nDev, 0.0);
     std::atomic<uint64_t> totalKmers{0};
+    SplitCarry carry;
     auto worker = [&](size_t d) {
         WorkerBuffers &wb = wbs[d];
         try {
@@ -1493,7 +1715,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         } catch (...) {
             std::lock_guard<std::mutex> lk(mu);
             if (!failure) failure = std::current_exception();       // like Compare.hpp:1060-1067: parked, rethrown by the driver thread
-            out.abandon();
+            out.abandon(); carry.abandon();
             cvDone.notify_all(); cvSpace.notify_all(); cvWork.notify_all();
         }
     };
@@ -1522,7 +1744,8 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
         for (;;) {
             std::unique_ptr<Batch> b(new Batch());
             if (!batcher.next(*b)) break;
-            if (p.verbose) std::cout << "OUT: Batch of " << b->rs.size() << " reads" << std::endl;
+            b->carry = &carry;
+            if (p.verbose) std::cout << "OUT: Batch of " << b->rs.size() << " reads" << (b->head ? ", the first goes on from the batch before" : "") << (b->tail ? ", the last goes on in the next" : "") << std::endl;
             ++nBatches;
             mark("batch formed", b->id);
             if (reserver.joinable()) { reserver.join(); mark("device buffers reserved"); }
@@ -1643,7 +1866,7 @@ static int run(int argc, char **argv)
         const auto t0 = std::chrono::steady_clock::now();
         ChunkReader cr(a[2]);
         const char *chunk; size_t chunkBytes; ReadSet all; vector<ReadSet> parts;
-        while (cr.next(chunk, chunkBytes, false)) parsePiece(chunk, chunkBytes, cr.fasta, nt, 1u << 20, all, parts);
+        while (cr.next(chunk, chunkBytes, false)) parsePiece(chunk, chunkBytes, cr.fasta, nt, 1u << 20, all, parts, cr.chunkStart);
         std::cout << "protein=" << cr.protein << " fasta=" << cr.fasta << "\n";
         if (!quiet) dump(all, 0);
         else std::cout << all.size() << " reads, " << all.bases.size() << " bases in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s; read " << g_ht.read

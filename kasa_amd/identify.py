@@ -48,6 +48,9 @@ class Identify:
             memory_gib: int = None, threads: int = 1, ram: bool = False, keep_csr: bool = False):
         """-> (per-read text or None, profile CSV text, list of CSR batches (with keep_csr))."""
         ix = self.index
+        pieced = reads.with_pieces(ix.K, self.frames, self.coherence) if reads.layout else reads
+        if pieced is not reads:
+            return self._run_pieced(pieced, want_per_read, coverage, memory_gib, threads, ram, keep_csr)
         writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts, coherence=self.coherence)
         freq = ix.freq_at(self.k_high)
         out = [writer.header()] if want_per_read else None
@@ -139,4 +142,95 @@ class Identify:
         prof = report.profile_csv(ca, cu, ix.content.names, ix.content.taxids, self.k_high, self.k_low,
                                   self.n_kmers, self.n_reads, 3 if (protein and self.frames == 6) else self.frames,
                                   count_total=ct if coverage else None, freq=freq_lv)
+        return ("".join(out) if want_per_read else None), prof, csr
+
+    def _run_pieced(self, pieced: ReadBatch, want_per_read: bool, coverage: bool, memory_gib: int, threads: int, ram: bool, keep_csr: bool):
+        """An input with sequences the reference reads in PIECES (reads.py; Read.hpp:371-600): the pieces of a read are
+        sequences of one read id on the device, and where a batch ends between two of them (Read.hpp:1147-1186, strTransfer)
+        the read's scores so far wait on the host for the rest (Compare::saveResults, Compare.hpp:2324-2443): the taxa found
+        on both sides get the float sum, and the read is ranked and printed when its last piece has been scored.  Ranking is
+        the host's here (a file of contigs has few reads)."""
+        if self.coherence:
+            raise RuntimeError("--coherence over sequences long enough for kASA to read them in pieces is not supported")
+        ix = self.index
+        writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts)
+        freq = ix.freq_at(self.k_high)
+        out = [writer.header()] if want_per_read else None
+        self.ctx.profile_reset()
+        protein = bool(pieced.protein)
+        self.ctx.set_protein(protein)
+        self.n_kmers = self.n_reads = self.flagged_reads = self.device_text_batches = 0
+        self.contaminants = []
+        seg = pieced.seg_read.astype(np.int64)
+        n_pieces = len(seg)
+        if memory_gib is not None:
+            bounds = capi.RefBatcher(ix, self.k_high, self.k_low, self.frames, memory_gib, threads, ram, record_bytes=getattr(ix, "record_bytes", None),
+                                     coherence=False).piece_batches(pieced, want_per_read)
+        else:
+            bounds = [0, n_pieces]
+        self.batch_sizes = []
+        saved_tax, saved_sc = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+        carried = 0            # strTransfer::lengthOfDNA (Read.hpp:1181: it grows by the running length at every unfinished piece)
+        csr = []
+
+        def merge(t0, s0, t1, s1):
+            allt = np.union1d(t0, t1)
+            acc = np.zeros(allt.shape[0], np.float32)
+            has = np.zeros(allt.shape[0], bool)
+            for t, s in ((t0, s0), (t1, s1)):
+                at = np.searchsorted(allt, t)
+                acc[at] = np.where(has[at], (acc[at] + s).astype(np.float32), s)
+                has[at] = True
+            return allt.astype(np.uint32), acc
+
+        for pa, pb in zip(bounds[:-1], bounds[1:]):
+            r0 = int(seg[pa])
+            local = (seg[pa:pb] - r0).astype(np.uint32)
+            n_local = int(local[-1]) + 1
+            tail = pb < n_pieces and seg[pb] == seg[pb - 1]          # the last read goes on in the next batch (addTail)
+            o = pieced.offsets[pa:pb + 1]
+            self.batch_sizes.append(n_local)
+            self.ctx.run_batch(pieced.bases[int(o[0]):int(o[-1])], o - o[0], want_per_read, coverage, self.unique, local, n_local)
+            self.n_kmers += self.ctx.n_kmers
+            # "Length" as the reader counts it across its calls (Read.hpp:1117,1166-1186)
+            length = carried
+            lengths = np.zeros(n_local, np.int64)
+            for q in range(pa, pb):
+                length += int(pieced.piece_chars[q])
+                lr = int(local[q - pa])
+                is_last = q + 1 == n_pieces or seg[q + 1] != seg[q]
+                if is_last:
+                    lengths[lr], length, carried = length, 0, 0
+                else:
+                    carried += length
+            if want_per_read:
+                off, tax, sc = self.ctx.scores(pinned=not keep_csr)
+                if keep_csr:
+                    csr.append((off, tax, sc))
+                # Compare::saveResults: what is waiting joins read 0 only when the batch ends with a finished read (:2344);
+                # otherwise it stays and takes the unfinished read's row as well (:2388-2409) -- the reference's own rule
+                for lr in range(n_local):
+                    lo, hi = int(off[lr]), int(off[lr + 1])
+                    t, s_ = tax[lo:hi], sc[lo:hi]
+                    if lr == 0 and saved_tax.shape[0] and not tail:
+                        t, s_ = merge(saved_tax, saved_sc, t, s_)
+                        saved_tax, saved_sc = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+                    if lr == n_local - 1 and tail:
+                        if hi > lo:
+                            saved_tax, saved_sc = merge(saved_tax, saved_sc, t, s_)
+                        continue
+                    rd = r0 + lr
+                    ln = int(lengths[lr]) & 0xFFFFFFFF
+                    rk = report.rank_read(t, s_, ln, freq, self.k_high, self.k_low, self.frames, self.threshold, self.beasts, K=ix.K, protein=protein)
+                    max_score = max((h.score for h in rk.hits), default=np.float32(0))
+                    out.append(writer.read(rd, pieced.names[rd], ln, rk, None))
+                    if rk.hits and report.is_contaminant(rk.best, max_score, self.error_threshold):
+                        self.contaminants.append(rd)
+            self.n_reads = r0 + n_local - (1 if tail else 0)
+        if want_per_read:
+            out.append(writer.footer())
+        ca, cu, ct = self.ctx.profile()
+        freq_lv = np.stack([ix.freq_at(k) for k in range(self.k_high, self.k_low - 1, -1)], axis=1) if coverage else None
+        prof = report.profile_csv(ca, cu, ix.content.names, ix.content.taxids, self.k_high, self.k_low, self.n_kmers, self.n_reads,
+                                  3 if (protein and self.frames == 6) else self.frames, count_total=ct if coverage else None, freq=freq_lv)
         return ("".join(out) if want_per_read else None), prof, csr

@@ -9,6 +9,12 @@ reads fit one batch chunk (every read shorter than ~100 MiB of k-mers, i.e. all 
   reader reports (Read.hpp:723-731): a one-line 150 bp read has length 151;
 * the sequence handed on is the concatenation of its lines, untouched -- cleaning, padding and the
   ``X`` marker are applied on the device (kasa_amd/csrc/encode.hip) exactly as Read.hpp:612-675 does.
+
+A sequence so long that its k-mers would take more than 100 MiB of the reference's input vector (4.4 Mbp in three
+frames) is read by the reference in PIECES (Read.hpp:371-600): every piece but the first starts with the last 3K-1
+letters of the one before, every piece ends with the marker, and where a piece ends depends on how the 2048-byte
+buffers of Utilities::FileReader (Utilities.hpp:448-539) cut the file's lines.  `parse_reads` keeps that cut of a long
+record (`ReadBatch.layout`), `ReadBatch.with_pieces` turns it into the pieces the reference scores.
 """
 from __future__ import annotations
 
@@ -17,6 +23,11 @@ import re
 from dataclasses import dataclass
 
 import numpy as np
+
+
+LONG_SEQUENCE = 1_000_000    # shorter records are one piece whatever the options (the smallest piece: 100 MiB / 48 B / 2 strands)
+_BUFFER = 2048               # Utilities.hpp:451
+PIECE_BYTES = 100 * 1024 * 1024   # Read.hpp:438,507
 
 
 @dataclass
@@ -28,10 +39,52 @@ class ReadBatch:
     lengths: np.ndarray   # u32[n]  ("Length" of the reference's output)
     protein: bool = False  # amino-acid input as kASA::detectAlphabet decides (kASA.hpp:155-183)
     seg_read: np.ndarray = None  # paired-end: u32[nSequences], read of every sequence (offsets delimit sequences then)
+    layout: dict = None   # read -> u32[nParts, 2] for records of LONG_SEQUENCE letters and more: (letters, 1 = ended by a line feed) of every getChunk call
+    fasta: bool = True
+    piece_chars: np.ndarray = None  # with_pieces: what every piece adds to "Length" (its letters + line feeds)
 
     @property
     def n(self) -> int:
         return int(self.lengths.shape[0]) if self.seg_read is not None else int(self.offsets.shape[0] - 1)
+
+    def with_pieces(self, K: int, frames: int, coherence: bool = False, piece_bytes: int = PIECE_BYTES) -> "ReadBatch":
+        """The batch as the reference reads it: a record it cuts into pieces (module text) becomes several sequences of one
+        read -- every piece but the first starts with the overhang of the one before (Read.hpp:678-697, 738-741) --,
+        `seg_read` names the read of every sequence and `piece_chars` what the piece adds to the read's "Length".
+        Returns self when no record is cut."""
+        if not self.layout:
+            return self
+        if self.seg_read is not None:
+            raise RuntimeError("a paired-end input with sequences long enough for kASA to read them in pieces is not supported")
+        mode = 2 if self.protein else (1 if frames == 1 else 0)
+        strands = 2 if (frames == 6 and not self.protein) else 1
+        over = (K if self.protein else 3 * K) - 1
+        cuts = {}
+        for r, parts in self.layout.items():
+            c, add = piece_cuts(parts, self.fasta, K, mode, strands, coherence, piece_bytes)
+            if len(c) > 2:
+                cuts[r] = (c, add)
+        if not cuts:
+            return self
+        chunks, off, seg, chars = [], [0], [], []
+        for r in range(self.n):
+            a, b = int(self.offsets[r]), int(self.offsets[r + 1])
+            if r not in cuts:
+                pieces, adds = [self.bases[a:b]], [int(self.lengths[r])]
+            else:
+                c, adds = cuts[r]
+                pieces, text_len = [], 0
+                for i in range(len(c) - 1):
+                    keep = min(over, text_len)                      # generateOverhang: the last 3K-1 letters of the text before, or all of it
+                    pieces.append(self.bases[a + c[i] - keep:a + c[i + 1]])
+                    text_len = keep + c[i + 1] - c[i]
+            for pc, add in zip(pieces, adds):
+                chunks.append(pc)
+                off.append(off[-1] + pc.shape[0])
+                seg.append(r)
+                chars.append(add)
+        return ReadBatch(np.concatenate(chunks) if chunks else np.zeros(0, np.uint8), np.asarray(off, np.int64), self.names, self.lengths,
+                         self.protein, np.asarray(seg, np.uint32), None, self.fasta, np.asarray(chars, np.int64))
 
     def slice(self, a: int, b: int) -> "ReadBatch":
         names = self.names[a:b] if self.names is not None else None
@@ -42,6 +95,68 @@ class ReadBatch:
                              (self.seg_read[sa:sb] - np.uint32(a)).astype(np.uint32))
         o = self.offsets[a:b + 1]
         return ReadBatch(self.bases[int(o[0]):int(o[-1])], o - o[0], names, self.lengths[a:b], self.protein)
+
+
+def _kmer_count(length: int, K: int, mode: int) -> int:
+    """Read.hpp:36-57.  mode: 0 = DNA in 3 or 6 frames, 1 = --one, 2 = amino acids."""
+    if mode == 2:
+        return length - K + 1 if length > K + 1 else 0
+    if mode == 1:
+        return length // 3 - K + 1 if length // 3 > K + 1 else 0
+    return length - 3 * K + 1 if length > 3 * K + 1 else 0
+
+
+def _chunk_parts(data: bytes, begin: int, end: int) -> np.ndarray:
+    """The getChunk calls (Utilities.hpp:514-533) that cover data[begin, end), a run of whole lines that starts where a
+    call starts: every call ends at a line feed or at the next multiple of 2048 bytes in the file."""
+    parts = []
+    pos, n = begin, len(data)
+    while pos < end:
+        limit = min((pos // _BUFFER + 1) * _BUFFER, n)
+        q = data.find(b"\n", pos, limit)
+        if q >= 0:
+            parts.append((q - pos, 1))
+            pos = q + 1
+        elif limit < n or n % _BUFFER == 0:
+            parts.append((limit - pos, 0))
+            pos = limit
+        else:                                  # the file's last line has no line feed: the reader supplies one (Utilities.hpp:477-481)
+            parts.append((n - pos, 1))
+            pos = n
+    return np.asarray(parts, dtype=np.uint32).reshape(-1, 2)
+
+
+def piece_cuts(parts: np.ndarray, fasta: bool, K: int, mode: int, strands: int, coherence: bool = False,
+               piece_bytes: int = PIECE_BYTES):
+    """Where Read::readFileAndGenerateInfos ends the pieces of one record (Read.hpp:434-443, 503-512): after the getChunk
+    call with which the k-mers of the letters (FASTA: and line feeds) read so far pass `piece_bytes` of the input vector.
+    -> (letters before every cut, [0, ..., all]; what every piece adds to "Length")."""
+    elem = (40 if K > 12 else 32) if coherence else (32 if K > 12 else 24)      # InputType::sizeOf, MetaHeader.h:221-223
+    mult = elem * (2 if (strands == 2 and mode != 2) else 1)                    # Read.hpp:361-367
+    # the smallest count of characters whose k-mers pass the limit
+    lo, hi = 0, 1 << 40
+    while lo + 1 < hi:
+        mid = (lo + hi) // 2
+        if _kmer_count(mid, K, mode) * mult > piece_bytes:
+            hi = mid
+        else:
+            lo = mid
+    need = hi
+    letters = parts[:, 0].astype(np.int64)
+    feeds = parts[:, 1].astype(np.int64)
+    counted = np.where(letters > 0, letters + (feeds if fasta else 0), 0)       # (a call that returns no text is not counted: Read.hpp:394,445)
+    cl, cc, ct = np.cumsum(letters), np.cumsum(counted), np.cumsum(letters + feeds)   # Read.hpp:723-731: "Length" counts the line feeds
+    cuts, adds, base_c, base_t = [0], [], 0, 0
+    while True:
+        i = int(np.searchsorted(cc, base_c + need, side="left"))               # the call with which the count reaches `need`
+        if i >= len(cc):
+            break
+        cuts.append(int(cl[i]))
+        adds.append(int(ct[i]) - base_t)
+        base_c, base_t = int(cc[i]), int(ct[i])
+    cuts.append(int(cl[-1]))                                                    # the last piece: what is left, possibly nothing (Read.hpp:411-421)
+    adds.append(int(ct[-1]) - base_t)
+    return cuts, adds
 
 
 def _open(path: str):
@@ -74,7 +189,7 @@ def parse_reads(path: str) -> ReadBatch:
     lines = data.split(b"\n")
     if lines and lines[-1] == b"":
         lines.pop()
-    names, seqs, lens = [], [], []
+    names, seqs, lens, span = [], [], [], []
     i, n = 0, len(lines)
     if first == b">":
         while i < n:
@@ -83,7 +198,7 @@ def parse_reads(path: str) -> ReadBatch:
                 continue
             name = lines[i][1:].decode("latin-1") + " "
             i += 1
-            parts = []
+            parts, i0 = [], i
             while i < n and not lines[i].startswith(b">"):
                 if lines[i] != b"":
                     parts.append(lines[i])
@@ -92,6 +207,7 @@ def parse_reads(path: str) -> ReadBatch:
             names.append(name)
             seqs.append(seq)
             lens.append(len(seq) + len(parts))
+            span.append((i0, i))
     else:
         while i < n:
             if lines[i] == b"":
@@ -99,11 +215,12 @@ def parse_reads(path: str) -> ReadBatch:
                 continue
             name = lines[i][1:].decode("latin-1") + " "
             i += 1
-            parts = []
+            parts, i0 = [], i
             while i < n and not lines[i].startswith(b"+"):
                 parts.append(lines[i])
                 i += 1
             seq = b"".join(parts)
+            span.append((i0, i))
             i += 1  # '+' line
             q = 0
             while i < n and q < len(seq):  # quality: as many characters as bases
@@ -121,7 +238,12 @@ def parse_reads(path: str) -> ReadBatch:
     if seqs:
         np.cumsum([len(s) for s in seqs], out=off[1:])
     bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
-    return ReadBatch(bases, off, names, np.asarray(lens, dtype=np.uint32), detect_protein(data))
+    layout = None
+    long_ones = [r for r, s in enumerate(seqs) if len(s) >= LONG_SEQUENCE]
+    if long_ones:                       # how the reference's reader cuts these records' lines (see the module text)
+        starts = np.concatenate([[0], np.cumsum(np.fromiter((len(l) + 1 for l in lines), np.int64, len(lines)))])
+        layout = {r: _chunk_parts(data, int(starts[span[r][0]]), min(int(starts[span[r][1]]), len(data))) for r in long_ones}
+    return ReadBatch(bases, off, names, np.asarray(lens, dtype=np.uint32), detect_protein(data), layout=layout, fasta=first == b">")
 
 
 def parse_pairs(path1: str, path2: str) -> ReadBatch:

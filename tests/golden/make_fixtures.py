@@ -463,48 +463,60 @@ def case_longseq(out):
     n = int(open(os.path.join(out, "idx_info.txt")).read().split()[0])
     with open(os.path.join(out, "idx"), "rb") as f, open(os.path.join(src, "idx"), "rb") as g:
         assert f.read(n * 12) == g.read(), "the rebuilt index differs from tests/golden/batches/idx"
-    rng = random.Random(41)
-    NS, TAIL, LONG = int(os.environ.get("KASA_LONGSEQ_SHORT", "2100")), 40, 9500000
-    with open(os.path.join(out, "long.fasta"), "w") as f:
-        def short(r):
-            g = rng.randrange(G)
-            p = rng.randrange(L - 150)
-            f.write(">s%d_t%d\n%s\n" % (r, g, mutate(genomes[g][p:p + 150], 0.02, rng)))
-        for r in range(NS):
-            short(r)
-        f.write(">contig made of the database\n")
-        col, left = 0, LONG
-        while left > 0:
-            s = mutate(genomes[rng.randrange(G)], 0.003, rng)[:left]
-            left -= len(s)
-            i = 0
-            while i < len(s):                                  # 70 letters per line
-                take = min(70 - col, len(s) - i)
-                f.write(s[i:i + take])
-                i += take
-                col += take
-                if col == 70:
+    def write_input(path, rng, layout):
+        count = [0]
+        with open(path, "w") as f:
+            for item in layout:
+                if item[0] == "short":
+                    for _ in range(item[1]):
+                        g = rng.randrange(G)
+                        p = rng.randrange(L - 150)
+                        f.write(">s%d_t%d\n%s\n" % (count[0], g, mutate(genomes[g][p:p + 150], 0.02, rng)))
+                        count[0] += 1
+                    continue
+                _, title, left, rate = item
+                f.write(">%s\n" % title)
+                count[0] += 1
+                col = 0
+                while left > 0:
+                    s = mutate(genomes[rng.randrange(G)], rate, rng)[:left]
+                    left -= len(s)
+                    i = 0
+                    while i < len(s):                              # 70 letters per line
+                        take = min(70 - col, len(s) - i)
+                        f.write(s[i:i + take])
+                        i += take
+                        col += take
+                        if col == 70:
+                            f.write("\n")
+                            col = 0
+                if col:
                     f.write("\n")
-                    col = 0
-        if col:
-            f.write("\n")
-        for r in range(TAIL):
-            short(NS + 1 + r)
+
+    write_input(os.path.join(out, "long.fasta"), random.Random(41),
+                [("short", int(os.environ.get("KASA_LONGSEQ_SHORT", "2100"))), ("contig", "contig made of the database", 9500000, 0.003), ("short", 40)])
+    # ... and an input whose batches end inside sequences in every way there is (six frames: pieces of 2.2 Mbp): sequence A in
+    # two pieces across batches 1 and 2; batch 2 goes on with short reads and ends after the first piece of sequence B (a
+    # batch that begins AND ends inside a sequence); batch 3 lies inside B altogether; batch 4 finishes it
+    S1, S2 = int(os.environ.get("KASA_LONGSEQ_S1", "2150")), int(os.environ.get("KASA_LONGSEQ_S2", "1900"))
+    write_input(os.path.join(out, "long2.fasta"), random.Random(43),
+                [("short", S1), ("contig", "sequence A", 3000000, 0.001), ("short", S2), ("contig", "sequence B", 24500000, 0.0005), ("short", 25)])
     probe = build_probe()
     sizes = {}
-    for name, extra in (("long", []), ("long_six", ["--six"])):
-        batches = run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", "long.fasta", "--jsonl", "-b", "100", "-m", "1"] + extra +
+    for name, stem, extra in (("long", "long", []), ("long_six", "long", ["--six"]), ("long2_six", "long2", ["--six"])):
+        batches = run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", stem + ".fasta", "--jsonl", "-b", "100", "-m", "1"] + extra +
                              ["-q", "out_%s.jsonl" % name, "-p", "prof_%s.csv" % name], out, n_taxa, probe, keep="_fileInfo.txt")
         # the reference's own list of pieces (skip lines, getChunk calls, pieces left), kept from deletion by the probe: the
         # lines of the long sequence are what the restatement of Read.hpp:372-467 has to reproduce
-        info = os.path.join(out, "tmp", "long_fileInfo.txt")
+        info = os.path.join(out, "tmp", stem + "_fileInfo.txt")
         pieces = [l.strip() for l in open(info) if not l.strip().endswith(",1") or l.startswith("0,")]
         os.remove(info)
         sizes[name] = {"batches": batches, "pieces_of_the_long_sequence": pieces}
     with open(os.path.join(src, "long.json"), "w") as f:
         json.dump(sizes, f, indent=1)
-    with open(os.path.join(out, "long.fasta"), "rb") as f, lzma.open(os.path.join(src, "long.fasta.xz"), "wb", preset=9) as g:
-        shutil.copyfileobj(f, g)
+    for stem in ("long", "long2"):
+        with open(os.path.join(out, stem + ".fasta"), "rb") as f, lzma.open(os.path.join(src, stem + ".fasta.xz"), "wb", preset=9) as g:
+            shutil.copyfileobj(f, g)
     for name in sizes:
         with open(os.path.join(out, "out_%s.jsonl" % name), "rb") as f, gzip.GzipFile(os.path.join(src, "out_%s.jsonl.gz" % name), "wb", mtime=0) as g:
             shutil.copyfileobj(f, g)

@@ -24,7 +24,7 @@ from oracle import reader
 from tests import helpers
 
 SRC = os.path.join(helpers.GOLDEN, "batches")
-CONFIGS = {"long": 3, "long_six": 6}
+CONFIGS = {"long": ("long", 3), "long_six": ("long", 6), "long2_six": ("long2", 6)}   # name -> (input, frames)
 
 
 @pytest.fixture(scope="module")
@@ -35,11 +35,13 @@ def case(tmp_path_factory):
             shutil.copyfileobj(g, o)
     for f in ("idx", "idx_info.txt", "idx_trie", "idx_trie.txt"):
         shutil.copy(os.path.join(SRC, f), os.path.join(d, f))
-    with lzma.open(os.path.join(SRC, "long.fasta.xz"), "rb") as g, open(os.path.join(d, "long.fasta"), "wb") as o:
-        shutil.copyfileobj(g, o)
+    data = {}
+    for stem in ("long", "long2"):
+        with lzma.open(os.path.join(SRC, stem + ".fasta.xz"), "rb") as g:
+            data[stem] = g.read()
+        with open(os.path.join(d, stem + ".fasta"), "wb") as o:
+            o.write(data[stem])
     ix = formats.load_index(os.path.join(d, "idx"), os.path.join(d, "content.txt"))
-    with open(os.path.join(d, "long.fasta"), "rb") as f:
-        data = f.read()
     return d, ix, data, json.load(open(os.path.join(SRC, "long.json")))
 
 
@@ -53,23 +55,30 @@ def _golden(name):
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_oracle_reader_reproduces_the_pieces_and_batches(case, name):
     d, ix, data, gold = case
-    frames = CONFIGS[name]
+    stem, frames = CONFIGS[name]
+    data = data[stem]
     lines = reader.info_lines(data, True, 12, 0, 2 if frames == 6 else 1)
     long_ones = ["%d,%d,%d" % l for l in lines if l[2] != 1 or l[0] == 0]
     assert long_ones == gold[name]["pieces_of_the_long_sequence"]
-    assert len(lines) == 2140 + len(long_ones)
+    assert len(lines) == data.count(b">") - data.count(b">sequence") - data.count(b">contig") + len(long_ones)
     budget = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1).budget
     batches = reader.read_batches(data, True, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
     assert [b.n_reads for b in batches] == gold[name]["batches"]
-    assert [b.add_tail for b in batches] == [True, False]
-    assert batches[0].entry_read[-2:] == [2099, 2100]                       # the first piece alone ends batch 1 ...
-    assert batches[1].entry_read[:len(long_ones)] == [0] * (len(long_ones) - 1) + [1]   # ... the others are read 0 of batch 2
+    if stem == "long":
+        assert [b.add_tail for b in batches] == [True, False]
+        assert batches[0].entry_read[-2:] == [2099, 2100]                       # the first piece alone ends batch 1 ...
+        assert batches[1].entry_read[:len(long_ones)] == [0] * (len(long_ones) - 1) + [1]   # ... the others are read 0 of batch 2
+    else:
+        # batch 2 begins AND ends inside a sequence, batch 3 lies inside one altogether
+        assert [(b.entry_read[0] == 0 and i > 0, b.add_tail) for i, b in enumerate(batches)] == [(False, True), (True, True), (True, True), (True, False)]
+        assert len(batches[2].texts) == 9 and batches[2].n_reads == 1
 
 
-@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True)])
+@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True), ("long2_six", True)])
 def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
     d, ix, data, gold = case
-    frames = CONFIGS[name]
+    stem, frames = CONFIGS[name]
+    data = data[stem]
     budget = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1).budget
     batches = reader.read_batches(data, True, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
     rows, names, lengths = [], [], []
@@ -105,3 +114,146 @@ def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
     want_text, want_prof = _golden(name)
     assert prof == want_prof
     assert text == want_text
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_host_pieces_and_batches_equal_the_oracle_reader(case, name):
+    """kasa_amd/reads.py + capi.RefBatcher.piece_batches (the product's own code for this) against oracle/reader.py."""
+    d, ix, data, gold = case
+    stem, frames = CONFIGS[name]
+    data = data[stem]
+    batch = reads.parse_reads(os.path.join(d, stem + ".fasta"))
+    pieced = batch.with_pieces(12, frames)
+    rb = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1)
+    bounds = rb.piece_batches(pieced, True)
+    want = reader.read_batches(data, True, rb.budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
+    assert len(bounds) - 1 == len(want)
+    for (pa, pb), b in zip(zip(bounds[:-1], bounds[1:]), want):
+        assert pb - pa == len(b.texts)
+        for q in range(pa, pb):
+            assert pieced.bases[int(pieced.offsets[q]):int(pieced.offsets[q + 1])].tobytes() == b.texts[q - pa]
+        assert list(pieced.seg_read[pa:pb] - pieced.seg_read[pa]) == b.entry_read
+    for r in batch.layout:
+        assert int(pieced.piece_chars[pieced.seg_read == r].sum()) == int(batch.lengths[r])
+    assert batch.with_pieces(12, frames, piece_bytes=1 << 40) is batch        # nothing to cut: the batch itself
+
+
+def test_pieces_of_small_inputs_follow_the_oracle_reader():
+    """Line lengths, buffer ends and record ends in every position against each other, with a piece limit of a few hundred
+    k-mers: reads.py's cuts against the oracle reader's list of pieces (FASTA and FASTQ, all three k-mer geometries)."""
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        fasta = trial % 2 == 0
+        width = int(rng.integers(20, 3000))
+        recs = []
+        for r in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(1, 9000))
+            seq = "".join(rng.choice(list("ACGT"), n))
+            body = "\n".join(seq[i:i + width] for i in range(0, n, width))
+            recs.append((">r%d %s\n%s\n" % (r, "x" * int(rng.integers(0, 40)), body)) if fasta else
+                        ("@r%d\n%s\n+\n%s\n" % (r, body, "\n".join("I" * len(l) for l in body.split("\n")))))
+        data = "".join(recs).encode()
+        if trial % 5 == 4:
+            data = data[:-1]                                                    # no line feed at the end
+        mode, strands = [(0, 1), (0, 2), (1, 1)][trial % 3]
+        limit = int(rng.integers(2000, 60000))
+        lines = reader.info_lines(data, fasta, 12, mode, strands, piece_bytes=limit)
+        want = {}
+        rec = -1
+        for skip, parts, left in lines:
+            if skip:
+                rec += 1
+            if left:
+                want.setdefault(rec, []).append(parts)
+        # the product's parts and cuts of every record
+        text = data.split(b"\n")
+        starts = np.concatenate([[0], np.cumsum([len(l) + 1 for l in text])])
+        i, rec = 0, -1
+        while i < len(text):
+            if text[i][:1] not in (b">", b"@"):
+                i += 1
+                continue
+            rec += 1
+            i0 = i + 1
+            i = i0
+            while i < len(text) and text[i][:1] != (b">" if fasta else b"+") and not (i == len(text) - 1 and text[i] == b""):
+                i += 1
+            parts = reads._chunk_parts(data, int(starts[i0]), min(int(starts[i]), len(data)))
+            cuts, adds = reads.piece_cuts(parts, fasta, 12, mode, strands, piece_bytes=limit)
+            cl = np.concatenate([[0], np.cumsum(parts[:, 0])])
+            calls = [int(np.searchsorted(cl, c, side="left")) if k else 0 for k, c in enumerate(cuts)]
+            calls[-1] = len(parts)
+            got = list(np.diff(calls))
+            ref = want[rec]
+            if rec == len(recs) - 1 and fasta:
+                ref = ref[:-1] + [ref[-1] - 1]          # the call at the end of the file that returns nothing (Read.hpp:445)
+            assert got == ref, (trial, rec, got, ref)
+            if not fasta:                               # skip the '+' and quality lines
+                i += 1
+                while i < len(text) and text[i][:1] != b"@":
+                    i += 1
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+# (one wavefront replays a read's events in their order: a sequence of 20 M k-mers takes the device half a minute -- DESIGN.md
+# section 8 --, so the GPU cases are a selection: every input through both hosts once)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["long", "long2_six"])
+def test_python_host_byte_identical_over_the_pieces(case, name):
+    from kasa_amd import identify
+    d, ix, data, gold = case
+    stem, frames = CONFIGS[name]
+    data = data[stem]
+    batch = reads.parse_reads(os.path.join(d, stem + ".fasta"))
+    run = identify.Identify(ix, 0, 12, 7, frames, 0.0, 100, "jsonl")
+    text, prof, _ = run.run(batch, True, memory_gib=1, threads=1)
+    assert run.batch_sizes == gold[name]["batches"]
+    want_text, want_prof = _golden(name)
+    assert prof == want_prof
+    assert text == want_text                                 # scores of the long sequence included, nothing stripped
+    # without per-read output the pieces still decide the k-mers (every piece ends with the marker): same profile
+    _, prof_only, _ = run.run(batch, False)
+    assert prof_only == want_prof
+    run.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [("long_six", []), ("long", ["gz", "KASA_READ_BLOCK=3000000", "KASA_PARSE_CHUNK=300000"]),
+                                        ("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"])])
+def test_cpp_host_byte_identical_over_the_pieces(case, name, extra, tmp_path):
+    """kasa_identify streams the file in blocks and parses them with several threads: where the blocks and the threads' runs
+    end must not move the pieces (the reader's 2048-byte buffers are counted from the start of the file)."""
+    from kasa_amd import build as hipbuild
+    d, ix, data, gold = case
+    stem, frames = CONFIGS[name]
+    data = data[stem]
+    exe = hipbuild.build_host()
+    src = os.path.join(d, stem + ".fasta")
+    env = dict(os.environ)
+    if "gz" in extra:
+        with open(src, "rb") as f, gzip.open(str(tmp_path / "in.fasta.gz"), "wb", compresslevel=1) as g:
+            shutil.copyfileobj(f, g)
+        src = str(tmp_path / "in.fasta.gz")
+        env.update(e.split("=") for e in extra if "=" in e)
+    out, prof = str(tmp_path / "out.jsonl"), str(tmp_path / "prof.csv")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", src, "-q", out, "-p", prof,
+           "--jsonl", "-b", "100", "-m", "1", "-n", "1", "-v"] + (["--six"] if frames == 6 else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sizes = [int(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("OUT: Batch of")]
+    assert sizes == gold[name]["batches"], r.stdout
+    assert "the last goes on in the next" in r.stdout and "the first goes on from the batch before" in r.stdout
+    want_text, want_prof = _golden(name)
+    with open(prof, "rb") as f:
+        assert f.read().decode("latin-1") == want_prof
+    with open(out, "rb") as f:
+        assert f.read().decode("latin-1") == want_text
+    # a profile-only run reads the same pieces
+    prof2 = str(tmp_path / "prof2.csv")
+    cmd2 = list(cmd)
+    del cmd2[cmd2.index("-q"):cmd2.index("-q") + 2]
+    cmd2[cmd2.index(prof)] = prof2
+    r = subprocess.run(cmd2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(prof2, "rb") as f:
+        assert f.read().decode("latin-1") == want_prof
