@@ -648,7 +648,17 @@ struct IndexFiles {                               // what Compare::ReadIndex loa
     vector<uint8_t> lut;
     uint64_t nameBytes = 0;
     vector<kasa_index *> onDevice;                // one immutable index object per device, shared by all contexts there
-    ~IndexFiles() { for (auto *ix : onDevice) kasa_index_destroy(ix); }
+    // An index of 2^32 records and more (positions in an index object are 32-bit) lives on the device as several range
+    // partitions, every one an index object of its own, cut between entries of the `_trie` file (a prefix range never
+    // straddles a cut): parts[d][j] on device d, cuts[j] = first 30-bit prefix of partition j (cuts[0] = 0).  The reference
+    // streams an index of any size from disk (Compare.hpp:286-318).  onDevice[d] = parts[d][0] then.
+    vector<vector<kasa_index *>> parts;
+    vector<uint64_t> cuts;
+    ~IndexFiles()
+    {
+        if (parts.empty()) { for (auto *ix : onDevice) kasa_index_destroy(ix); }
+        else for (auto &v : parts) for (auto *ix : v) kasa_index_destroy(ix);
+    }
 };
 
 static float weightOf(int k) { return (float)(k * k) / 625.f; }
@@ -1466,7 +1476,7 @@ struct WorkerBuffers {
     ~WorkerBuffers() { for (auto &f : written) if (f.valid()) f.wait(); }      // the writer still reads the buffers
 };
 
-static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb, OrderedOut &out)
+static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, const vector<kasa_ctx *> &partCtx, Batch &b, bool wantRows, double &tDevice, double &tText, WorkerBuffers &wb, OrderedOut &out)
 {
     const auto tDev = std::chrono::steady_clock::now();
     auto secondsSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
@@ -1481,7 +1491,28 @@ static void runBatch(const Params &p, const IndexFiles &ixf, kasa_ctx *ctx, Batc
         ScopedTimerMt tm(g_ht.compute, g_ht.mu);
         { ScopedTimerMt t2(g_ht.encode, g_ht.mu); if (kasa_batch_encode(ctx, &nk)) throwLast(); }
         { ScopedTimerMt t2(g_ht.sort, g_ht.mu); if (kasa_batch_sort_and_range(ctx, p.unique ? 1 : 0)) throwLast(); }
-        { ScopedTimerMt t2(g_ht.score, g_ht.mu); if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast(); }
+        ScopedTimerMt t2(g_ht.score, g_ht.mu);
+        if (partCtx.empty()) { if (kasa_batch_lookup_score(ctx, wantRows, p.coverage)) throwLast(); }
+        else {
+            // a partitioned index: the sorted queries are cut at the partitions' first prefixes; every slice is grouped against
+            // its partition by that partition's context (the slice is a batch of its own there: its first query opens a new
+            // prefix range), the records come back in partition order = sorted order and are scored here (kasa_hip.h, C5 seam)
+            const size_t nP = partCtx.size();
+            const void *km = nullptr; uint64_t nq = 0;
+            if (kasa_batch_queries_device(ctx, &km, &nq)) throwLast();
+            vector<uint64_t> starts(nP + 1);
+            if (kasa_batch_slice_starts(ctx, ixf.cuts.data(), (uint32_t)nP, starts.data())) throwLast();
+            const size_t keyBytes = p.K > 12 ? 16 : 8;
+            vector<const uint32_t *> recs(nP), pools(nP); vector<uint64_t> nRecW(nP), nPoolW(nP);
+            for (size_t j = 0; j < nP; ++j) {
+                if (kasa_batch_set_sorted_device(partCtx[j], (const char *)km + starts[j] * keyBytes, starts[j + 1] - starts[j])) throwLast();
+                if (kasa_batch_group(partCtx[j], p.coverage)) throwLast();
+                if (kasa_profile_absorb(ctx, partCtx[j])) throwLast();
+                if (kasa_batch_records_device(partCtx[j], &recs[j], &nRecW[j], &pools[j], &nPoolW[j])) throwLast();
+            }
+            if (kasa_batch_records_import_device(ctx, (uint32_t)nP, recs.data(), nRecW.data(), pools.data(), nPoolW.data())) throwLast();
+            if (kasa_batch_score(ctx, wantRows)) throwLast();
+        }
     }
     b.kmers = nk;
     if (!wantRows) { tDevice += secondsSince(tDev); out.begin(b.id, 0); return; }
@@ -1637,6 +1668,15 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     struct CtxGuard { vector<kasa_ctx *> &c; ~CtxGuard() { for (auto *x : c) kasa_ctx_destroy(x); } } guard{ctx};
     for (size_t d = 0; d < nDev; ++d)
         if (kasa_ctx_create(ixf.onDevice[(size_t)devSlots[d]], p.kHigh, p.kLow, p.frames, ixf.lut.empty() ? nullptr : ixf.lut.data(), &ctx[d])) throwLast();
+    vector<vector<kasa_ctx *>> partCtx(nDev);                          // a partitioned index: one context per partition and device
+    struct PartGuard { vector<vector<kasa_ctx *>> &c; ~PartGuard() { for (auto &v : c) for (auto *x : v) kasa_ctx_destroy(x); } } partGuard{partCtx};
+    if (!ixf.parts.empty())
+        for (size_t d = 0; d < nDev; ++d)
+            for (kasa_index *ix : ixf.parts[(size_t)devSlots[d]]) {
+                kasa_ctx *c = nullptr;
+                if (kasa_ctx_create(ix, p.kHigh, p.kLow, p.frames, ixf.lut.empty() ? nullptr : ixf.lut.data(), &c)) throwLast();
+                partCtx[d].push_back(c);
+            }
     // device batches: up to 2^32 k-mers, and what fits the HBM that is free next to the index
     uint64_t maxKmersPerBatch = 3000000000ull;
     {
@@ -1657,6 +1697,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
     mark("first chunk parsed");
     p.protein = batcher.protein;
     for (auto *c : ctx) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
+    for (auto &v : partCtx) for (auto *c : v) if (kasa_ctx_set_protein(c, p.protein ? 1 : 0)) throwLast();
     if (wantRows && !p.hostRank && !p.hostText) {                     // what the device prints for a taxon (kasa_batch_text)
         vector<uint64_t> off(ixf.content.names.size() + 1, 0);
         string blob;
@@ -1704,7 +1745,7 @@ static void identifyFile(Params p, const IndexFiles &ixf, const vector<int> &dev
                     cvSpace.notify_all();
                 }
                 mark("device takes batch", b->id);
-                runBatch(p, ixf, ctx[d], *b, wantRows, tDevice[d], tText[d], wb, out);
+                runBatch(p, ixf, ctx[d], partCtx[d], *b, wantRows, tDevice[d], tText[d], wb, out);
                 mark("device done with batch", b->id);
                 totalKmers += b->kmers;
                 b->rs = ReadSet();                                   // the reads are done with
@@ -1957,11 +1998,46 @@ static int run(int argc, char **argv)
         vector<char> raw(m * 12); tf.read(raw.data(), (std::streamsize)raw.size());
         for (uint64_t i = 0; i < m; ++i) { memcpy(&ixf.tc[i], &raw[i * 12], 8); memcpy(&ixf.tp[i], &raw[i * 12 + 8], 4); }
     }
-    for (int dev : p.devices) {
-        kasa_index *ix = nullptr;
-        if (kasa_index_create(dev, rec, ixf.nRec, ixf.recBytes, ixf.tp.data(), ixf.tc.data(), ixf.tp.size(), ixf.content.taxids.data(),
-                              (uint32_t)ixf.content.taxids.size(), &ix)) throwLast();
-        ixf.onDevice.push_back(ix);
+    uint64_t maxPart = 0xFFFFFFF0ull - 1;                               // what one index object holds (kasa_index_create)
+    if (const char *e = getenv("KASA_INDEX_PART_RECORDS")) maxPart = std::max<uint64_t>(1, (uint64_t)atoll(e));   // tests: partitions of a small index
+    if (ixf.nRec <= maxPart) {
+        for (int dev : p.devices) {
+            kasa_index *ix = nullptr;
+            if (kasa_index_create(dev, rec, ixf.nRec, ixf.recBytes, ixf.tp.data(), ixf.tc.data(), ixf.tp.size(), ixf.content.taxids.data(),
+                                  (uint32_t)ixf.content.taxids.size(), &ix)) throwLast();
+            ixf.onDevice.push_back(ix);
+        }
+    } else {
+        // about equal partitions, as few as hold the index, cut between `_trie` entries
+        const uint64_t m = ixf.tp.size();
+        uint64_t nParts = (ixf.nRec + maxPart - 1) / maxPart;
+        vector<uint64_t> tLo, rLo;                                         // first trie entry and first record of every partition, + the ends
+        for (;; ++nParts) {
+            tLo.assign(1, 0); rLo.assign(1, 0);
+            uint64_t t = 0, r = 0; bool ok = true;
+            for (uint64_t j = 0; j < nParts; ++j) {
+                const uint64_t r0 = r;
+                if (j + 1 == nParts) while (t < m) r += ixf.tc[t++];
+                else { const uint64_t target = ixf.nRec / nParts * (j + 1); while (t < m && (r == r0 || r + ixf.tc[t] <= target)) r += ixf.tc[t++]; }
+                if (r == r0 || r - r0 > maxPart) ok = false;
+                tLo.push_back(t); rLo.push_back(r);
+            }
+            if (ok) { if (r != ixf.nRec) throw std::runtime_error("the trie file does not add up to the index's records"); break; }
+            if (nParts >= m) throw std::runtime_error("the index cannot be cut into partitions of at most " + std::to_string(maxPart) + " records between its trie entries");
+        }
+        if (p.coherence) throw std::runtime_error("--coherence over an index of 2^32 records and more is not supported");
+        ixf.parts.resize(p.devices.size());
+        for (uint64_t j = 0; j < nParts; ++j) ixf.cuts.push_back(j == 0 ? 0 : (uint64_t)ixf.tp[tLo[j]]);
+        for (size_t d = 0; d < p.devices.size(); ++d) {
+            for (uint64_t j = 0; j < nParts; ++j) {
+                kasa_index *ix = nullptr;
+                if (kasa_index_create(p.devices[d], (const char *)rec + rLo[j] * (uint64_t)ixf.recBytes, rLo[j + 1] - rLo[j], ixf.recBytes, ixf.tp.data() + tLo[j], ixf.tc.data() + tLo[j],
+                                      tLo[j + 1] - tLo[j], ixf.content.taxids.data(), (uint32_t)ixf.content.taxids.size(), &ix)) throwLast();
+                ixf.parts[d].push_back(ix);
+            }
+            ixf.onDevice.push_back(ixf.parts[d][0]);
+        }
+        if (p.verbose) std::cout << "OUT: Index of " << ixf.nRec << " records in " << nParts << " partitions on every device" << std::endl;
     }
     munmap(rec, ixf.nRec * ixf.recBytes); close(fd);
     if (p.threads == 0) {

@@ -292,3 +292,52 @@ def test_cpp_host_paths_agree_at_scale(fmt, extra, tmp_path):
     assert outs[0][0] == outs[1][0], "device text != host text over the device's ranking"
     assert outs[0][0] == outs[2][0], "device ranking + text != host ranking + text"
     assert outs[0][0].count(b"\n") > n // 2
+
+
+@pytest.mark.parametrize("case", PAIRS, ids=[c[0] for c in PAIRS])
+def test_cpp_host_partitioned_index_byte_identical(case, tmp_path):
+    """An index of 2^32 records and more runs as range partitions on the device (Compare.hpp:286-318 streams any size); with
+    KASA_INDEX_PART_RECORDS the driver cuts the small golden indexes the same way -- several partitions, the same bytes."""
+    exe = hipbuild.build_host()
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, idx), "-i", os.path.join(d, infile),
+           "-q", out, "-p", prof, FLAGS[fmt], "-b", str(beasts), "-k", str(kh), str(kl), "-m", "4", "-n", "1", "-t", str(tmp_path), "-v"]
+    cmd += (["--six"] if frames == 6 else []) + (["--one"] if frames == 1 else []) + (["-e"] if uniq else [])
+    cmd += (["--coverage"] if wants_coverage(case) else []) + (["--threshold", str(thr)] if thr else [])
+    n_rec = int(open(os.path.join(d, idx + "_info.txt")).read().split()[0])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, KASA_INDEX_PART_RECORDS=str(n_rec // 5 + 1)))
+    assert r.returncode == 0, r.stderr
+    parts = [int(l.split()[6]) for l in r.stdout.splitlines() if l.startswith("OUT: Index of")]
+    assert parts and parts[0] >= 5, r.stdout
+    assert _read(out) == _read(os.path.join(d, "out_" + stem))
+    assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+
+
+def test_cpp_host_partitioned_index_across_batches_and_pieces(tmp_path):
+    """... and with the reference's batches and a sequence read in pieces on top (tests/golden/batches: m1 and long)."""
+    import gzip
+    import lzma
+    import shutil
+    exe = hipbuild.build_host()
+    src = os.path.join(helpers.GOLDEN, "batches")
+    d = str(tmp_path)
+    for f in ("content.txt.gz", "idx_f.txt.gz"):
+        with gzip.open(os.path.join(src, f), "rb") as g, open(os.path.join(d, f[:-3]), "wb") as o:
+            shutil.copyfileobj(g, o)
+    for f in ("idx", "idx_info.txt", "idx_trie", "idx_trie.txt", "reads.fastq.gz"):
+        shutil.copy(os.path.join(src, f), os.path.join(d, f))
+    with lzma.open(os.path.join(src, "long.fasta.xz"), "rb") as g, open(os.path.join(d, "long.fasta"), "wb") as o:
+        shutil.copyfileobj(g, o)
+    for infile, gold in (("reads.fastq.gz", "m1"), ("long.fasta", "long")):
+        out, prof = os.path.join(d, "out.jsonl"), os.path.join(d, "prof.csv")
+        cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, infile), "-q", out, "-p", prof,
+               "--jsonl", "-b", "100", "-m", "1", "-n", "1", "-v"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ, KASA_INDEX_PART_RECORDS="30000"))
+        assert r.returncode == 0, r.stderr
+        assert "partitions on every device" in r.stdout
+        with gzip.open(os.path.join(src, "out_%s.jsonl.gz" % gold), "rb") as f:
+            assert _read(out) == f.read().decode("latin-1")
+        assert _read(prof) == _read(os.path.join(src, "prof_%s.csv" % gold))
