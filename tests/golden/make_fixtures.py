@@ -463,6 +463,23 @@ def case_longseq(out):
     n = int(open(os.path.join(out, "idx_info.txt")).read().split()[0])
     with open(os.path.join(out, "idx"), "rb") as f, open(os.path.join(src, "idx"), "rb") as g:
         assert f.read(n * 12) == g.read(), "the rebuilt index differs from tests/golden/batches/idx"
+    # a repeat unit none of whose k-mers (any frame, either strand) shares a 7-letter prefix with the index: most of sequence B
+    # is made of it, so that the device (which replays the events of ONE read with one wavefront)
+    # and the oracle get through its 24.5 Mbp quickly -- what the case is about are the pieces and the batches
+    seen7 = set()
+    for s_ in genomes:
+        for fr in range(3):
+            aa = translate(s_[fr:])
+            seen7.update(aa[i:i + 7] for i in range(len(aa) - 6))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    urng = random.Random(44)
+    while True:
+        unit = "".join(urng.choice("ACGT") for _ in range(11))
+        rep = unit * 12
+        both = [rep, "".join(comp[c] for c in reversed(rep))]
+        if not any(translate(x[fr:])[i:i + 7] in seen7 for x in both for fr in range(3) for i in range(30)):
+            break
+
     def write_input(path, rng, layout):
         count = [0]
         with open(path, "w") as f:
@@ -474,12 +491,16 @@ def case_longseq(out):
                         f.write(">s%d_t%d\n%s\n" % (count[0], g, mutate(genomes[g][p:p + 150], 0.02, rng)))
                         count[0] += 1
                     continue
-                _, title, left, rate = item
+                _, title, left, rate = item[:4]
+                filler = item[4] if len(item) > 4 else 0       # letters of `unit` (matches nothing in the index) behind every genome copy
                 f.write(">%s\n" % title)
                 count[0] += 1
                 col = 0
                 while left > 0:
-                    s = mutate(genomes[rng.randrange(G)], rate, rng)[:left]
+                    s = mutate(genomes[rng.randrange(G)], rate, rng)
+                    if filler:
+                        s += (unit * (filler // len(unit) + 1))[:filler]
+                    s = s[:left]
                     left -= len(s)
                     i = 0
                     while i < len(s):                              # 70 letters per line
@@ -500,7 +521,7 @@ def case_longseq(out):
     # batch that begins AND ends inside a sequence); batch 3 lies inside B altogether; batch 4 finishes it
     S1, S2 = int(os.environ.get("KASA_LONGSEQ_S1", "2150")), int(os.environ.get("KASA_LONGSEQ_S2", "1900"))
     write_input(os.path.join(out, "long2.fasta"), random.Random(43),
-                [("short", S1), ("contig", "sequence A", 3000000, 0.001), ("short", S2), ("contig", "sequence B", 24500000, 0.0005), ("short", 25)])
+                [("short", S1), ("contig", "sequence A", 3000000, 0.001), ("short", S2), ("contig", "sequence B", 24500000, 0.0005, 190000), ("short", 25)])
     probe = build_probe()
     sizes = {}
     for name, stem, extra in (("long", "long", []), ("long_six", "long", ["--six"]), ("long2_six", "long2", ["--six"])):

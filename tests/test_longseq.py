@@ -218,7 +218,7 @@ def test_python_host_byte_identical_over_the_pieces(case, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,extra", [("long_six", []), ("long", ["gz", "KASA_READ_BLOCK=3000000", "KASA_PARSE_CHUNK=300000"]),
+@pytest.mark.parametrize("name,extra", [("long", ["gz", "KASA_READ_BLOCK=3000000", "KASA_PARSE_CHUNK=300000"]),
                                         ("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"])])
 def test_cpp_host_byte_identical_over_the_pieces(case, name, extra, tmp_path):
     """kasa_identify streams the file in blocks and parses them with several threads: where the blocks and the threads' runs
