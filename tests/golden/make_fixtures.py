@@ -522,21 +522,32 @@ def case_longseq(out):
     S1, S2 = int(os.environ.get("KASA_LONGSEQ_S1", "2150")), int(os.environ.get("KASA_LONGSEQ_S2", "1900"))
     write_input(os.path.join(out, "long2.fasta"), random.Random(43),
                 [("short", S1), ("contig", "sequence A", 3000000, 0.001), ("short", S2), ("contig", "sequence B", 24500000, 0.0005, 190000), ("short", 25)])
+    # ... and the first input once more as FASTQ, the long sequence and its quality string on ONE line each: the reader's
+    # pieces end where its 2048-byte buffers end, line feeds are not counted (Read.hpp:469-598)
+    with open(os.path.join(out, "long.fasta")) as f, open(os.path.join(out, "long3.fastq"), "w") as g:
+        name, seq = None, []
+        for line in list(f) + [">"]:
+            if line.startswith(">"):
+                if name is not None:
+                    g.write("@%s\n%s\n+\n%s\n" % (name, "".join(seq), "I" * sum(len(x) for x in seq)))
+                name, seq = line[1:].rstrip("\n"), []
+            else:
+                seq.append(line.rstrip("\n"))
     probe = build_probe()
     sizes = {}
-    for name, stem, extra in (("long", "long", []), ("long_six", "long", ["--six"]), ("long2_six", "long2", ["--six"])):
-        batches = run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", stem + ".fasta", "--jsonl", "-b", "100", "-m", "1"] + extra +
+    for name, stem, extra in (("long", "long.fasta", []), ("long_six", "long.fasta", ["--six"]), ("long2_six", "long2.fasta", ["--six"]), ("long3", "long3.fastq", [])):
+        batches = run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", stem, "--jsonl", "-b", "100", "-m", "1"] + extra +
                              ["-q", "out_%s.jsonl" % name, "-p", "prof_%s.csv" % name], out, n_taxa, probe, keep="_fileInfo.txt")
         # the reference's own list of pieces (skip lines, getChunk calls, pieces left), kept from deletion by the probe: the
         # lines of the long sequence are what the restatement of Read.hpp:372-467 has to reproduce
-        info = os.path.join(out, "tmp", stem + "_fileInfo.txt")
-        pieces = [l.strip() for l in open(info) if not l.strip().endswith(",1") or l.startswith("0,")]
+        info = os.path.join(out, "tmp", stem.rsplit(".", 1)[0] + "_fileInfo.txt")
+        pieces = [l.strip() for l in open(info) if int(l.split(",")[2]) > 1 or (l.startswith("0,") and not l.strip().endswith(",0"))]
         os.remove(info)
         sizes[name] = {"batches": batches, "pieces_of_the_long_sequence": pieces}
     with open(os.path.join(src, "long.json"), "w") as f:
         json.dump(sizes, f, indent=1)
-    for stem in ("long", "long2"):
-        with open(os.path.join(out, stem + ".fasta"), "rb") as f, lzma.open(os.path.join(src, stem + ".fasta.xz"), "wb", preset=9) as g:
+    for stem in ("long.fasta", "long2.fasta", "long3.fastq"):
+        with open(os.path.join(out, stem), "rb") as f, lzma.open(os.path.join(src, stem + ".xz"), "wb", preset=9) as g:
             shutil.copyfileobj(f, g)
     for name in sizes:
         with open(os.path.join(out, "out_%s.jsonl" % name), "rb") as f, gzip.GzipFile(os.path.join(src, "out_%s.jsonl.gz" % name), "wb", mtime=0) as g:

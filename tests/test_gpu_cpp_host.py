@@ -77,6 +77,14 @@ def test_cpp_host_wide_index(tmp_path):
                                      "jsonl", kh, kl, frames, 0.0, 100)
         assert _read(out) == text
         assert _read(prof) == ptext
+        # ... and the same over a partitioned index (64-byte records through the partitions' contexts)
+        n_rec = int(open(_os.path.join(d, "idx25_info.txt")).read().split()[0])
+        r = subprocess.run(cmd + ["-v"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                           env=dict(_os.environ, KASA_INDEX_PART_RECORDS=str(n_rec // 4 + 1)))
+        assert r.returncode == 0, r.stderr
+        assert "partitions on every device" in r.stdout
+        assert _read(out) == text
+        assert _read(prof) == ptext
 
 
 def test_cpp_host_paired_end(tmp_path):

@@ -24,7 +24,7 @@ from oracle import reader
 from tests import helpers
 
 SRC = os.path.join(helpers.GOLDEN, "batches")
-CONFIGS = {"long": ("long", 3), "long_six": ("long", 6), "long2_six": ("long2", 6)}   # name -> (input, frames)
+CONFIGS = {"long": ("long.fasta", 3), "long_six": ("long.fasta", 6), "long2_six": ("long2.fasta", 6), "long3": ("long3.fastq", 3)}   # name -> (input, frames)
 
 
 @pytest.fixture(scope="module")
@@ -36,10 +36,10 @@ def case(tmp_path_factory):
     for f in ("idx", "idx_info.txt", "idx_trie", "idx_trie.txt"):
         shutil.copy(os.path.join(SRC, f), os.path.join(d, f))
     data = {}
-    for stem in ("long", "long2"):
-        with lzma.open(os.path.join(SRC, stem + ".fasta.xz"), "rb") as g:
+    for stem in ("long.fasta", "long2.fasta", "long3.fastq"):
+        with lzma.open(os.path.join(SRC, stem + ".xz"), "rb") as g:
             data[stem] = g.read()
-        with open(os.path.join(d, stem + ".fasta"), "wb") as o:
+        with open(os.path.join(d, stem), "wb") as o:
             o.write(data[stem])
     ix = formats.load_index(os.path.join(d, "idx"), os.path.join(d, "content.txt"))
     return d, ix, data, json.load(open(os.path.join(SRC, "long.json")))
@@ -56,15 +56,18 @@ def _golden(name):
 def test_oracle_reader_reproduces_the_pieces_and_batches(case, name):
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
-    data = data[stem]
-    lines = reader.info_lines(data, True, 12, 0, 2 if frames == 6 else 1)
-    long_ones = ["%d,%d,%d" % l for l in lines if l[2] != 1 or l[0] == 0]
+    data, fasta = data[stem], stem.endswith(".fasta")
+    lines = reader.info_lines(data, fasta, 12, 0, 2 if frames == 6 else 1)
+    long_ones = ["%d,%d,%d" % l for l in lines if l[2] > 1 or (l[0] == 0 and l[2] == 1)]
     assert long_ones == gold[name]["pieces_of_the_long_sequence"]
-    assert len(lines) == data.count(b">") - data.count(b">sequence") - data.count(b">contig") + len(long_ones)
+    if fasta:
+        assert len(lines) == data.count(b">") - data.count(b">sequence") - data.count(b">contig") + len(long_ones)
+    else:
+        assert len(lines) == 2140 + len(long_ones) + 1 and lines[-1] == (2, 0, 0)      # the file's end: quality line and nothing (Read.hpp:591-598)
     budget = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1).budget
-    batches = reader.read_batches(data, True, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
+    batches = reader.read_batches(data, fasta, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
     assert [b.n_reads for b in batches] == gold[name]["batches"]
-    if stem == "long":
+    if stem != "long2.fasta":
         assert [b.add_tail for b in batches] == [True, False]
         assert batches[0].entry_read[-2:] == [2099, 2100]                       # the first piece alone ends batch 1 ...
         assert batches[1].entry_read[:len(long_ones)] == [0] * (len(long_ones) - 1) + [1]   # ... the others are read 0 of batch 2
@@ -74,13 +77,13 @@ def test_oracle_reader_reproduces_the_pieces_and_batches(case, name):
         assert len(batches[2].texts) == 9 and batches[2].n_reads == 1
 
 
-@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True), ("long2_six", True)])
+@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True), ("long2_six", True), ("long3", True)])
 def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
-    data = data[stem]
+    data, fasta = data[stem], stem.endswith(".fasta")
     budget = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1).budget
-    batches = reader.read_batches(data, True, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
+    batches = reader.read_batches(data, fasta, budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
     rows, names, lengths = [], [], []
     saved = reader.SavedScores()
     ca = cu = None
@@ -121,12 +124,12 @@ def test_host_pieces_and_batches_equal_the_oracle_reader(case, name):
     """kasa_amd/reads.py + capi.RefBatcher.piece_batches (the product's own code for this) against oracle/reader.py."""
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
-    data = data[stem]
-    batch = reads.parse_reads(os.path.join(d, stem + ".fasta"))
+    data, fasta = data[stem], stem.endswith(".fasta")
+    batch = reads.parse_reads(os.path.join(d, stem))
     pieced = batch.with_pieces(12, frames)
     rb = capi.RefBatcher(ix, 12, 7, frames, memory_gib=1, threads=1)
     bounds = rb.piece_batches(pieced, True)
-    want = reader.read_batches(data, True, rb.budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
+    want = reader.read_batches(data, fasta, rb.budget, 12, 7, 0, 2 if frames == 6 else 1, len(ix.content.taxids))
     assert len(bounds) - 1 == len(want)
     for (pa, pb), b in zip(zip(bounds[:-1], bounds[1:]), want):
         assert pb - pa == len(b.texts)
@@ -198,13 +201,13 @@ def test_pieces_of_small_inputs_follow_the_oracle_reader():
 # (one wavefront replays a read's events in their order: a sequence of 20 M k-mers takes the device half a minute -- DESIGN.md
 # section 8 --, so the GPU cases are a selection: every input through both hosts once)
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["long", "long2_six"])
+@pytest.mark.parametrize("name", ["long2_six", "long3"])
 def test_python_host_byte_identical_over_the_pieces(case, name):
     from kasa_amd import identify
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
-    data = data[stem]
-    batch = reads.parse_reads(os.path.join(d, stem + ".fasta"))
+    data, fasta = data[stem], stem.endswith(".fasta")
+    batch = reads.parse_reads(os.path.join(d, stem))
     run = identify.Identify(ix, 0, 12, 7, frames, 0.0, 100, "jsonl")
     text, prof, _ = run.run(batch, True, memory_gib=1, threads=1)
     assert run.batch_sizes == gold[name]["batches"]
@@ -219,21 +222,21 @@ def test_python_host_byte_identical_over_the_pieces(case, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,extra", [("long", ["gz", "KASA_READ_BLOCK=3000000", "KASA_PARSE_CHUNK=300000"]),
-                                        ("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"])])
+                                        ("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"]), ("long3", [])])
 def test_cpp_host_byte_identical_over_the_pieces(case, name, extra, tmp_path):
     """kasa_identify streams the file in blocks and parses them with several threads: where the blocks and the threads' runs
     end must not move the pieces (the reader's 2048-byte buffers are counted from the start of the file)."""
     from kasa_amd import build as hipbuild
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
-    data = data[stem]
+    data, fasta = data[stem], stem.endswith(".fasta")
     exe = hipbuild.build_host()
-    src = os.path.join(d, stem + ".fasta")
+    src = os.path.join(d, stem)
     env = dict(os.environ)
     if "gz" in extra:
-        with open(src, "rb") as f, gzip.open(str(tmp_path / "in.fasta.gz"), "wb", compresslevel=1) as g:
+        with open(src, "rb") as f, gzip.open(str(tmp_path / ("in." + stem.rsplit(".", 1)[1] + ".gz")), "wb", compresslevel=1) as g:
             shutil.copyfileobj(f, g)
-        src = str(tmp_path / "in.fasta.gz")
+        src = str(tmp_path / ("in." + stem.rsplit(".", 1)[1] + ".gz"))
         env.update(e.split("=") for e in extra if "=" in e)
     out, prof = str(tmp_path / "out.jsonl"), str(tmp_path / "prof.csv")
     cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", src, "-q", out, "-p", prof,
