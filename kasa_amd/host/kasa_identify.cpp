@@ -1033,7 +1033,7 @@ struct Batcher {
     ReadSet pending; size_t pendPos = 0;          // parsed reads not yet handed out
     vector<uint32_t> pendSeg;                     // paired-end: the whole (merged) input sits in `pending`
     uint64_t nextRead = 0, nextId = 0;
-    int64_t refBudget = 0; bool useRef = false, firstBatch = true, warned = false, warnedLong = false;
+    int64_t refBudget = 0; bool useRef = false, firstBatch = true, warned = false;
     uint64_t maxKmersPerBatch;
     double parseSeconds = 0;
     bool protein = false;
