@@ -25,7 +25,10 @@ def main():
         formats.write_index(ix, os.path.join(d, "idx"), os.path.join(d, "content.txt"))
         rng = np.random.default_rng(3)
         res = {"index_records": int(ix.n)}
+        only = os.environ.get("KASA_CONTIG_ONLY")
         for name, picks in (("different_genomes", list(range(0, 64, 2))), ("one_genome_32_times", [0] * 32)):
+            if only and name != only:
+                continue
             seq = np.concatenate([g[t] for t in picks])
             m = rng.random(seq.shape[0]) < 0.01
             seq = seq.copy()
@@ -51,6 +54,8 @@ def main():
                 if line.startswith("OUT: Number of k-mers in input:"):
                     t["kmers"] = int(line.split(":")[2].split()[0])
                     t["identified_percent"] = float(line.split("which")[1].split()[0])
+                if line.startswith("kasa-probe:"):                   # (an instrumented build of the library, preloaded)
+                    t.setdefault("probe", []).append(line)
                 if line.startswith("OUT: Batch of"):
                     t.setdefault("batches", []).append(line[5:])
             if t.get("kmers") and t.get("file_s"):
