@@ -353,7 +353,9 @@ static bool detectProtein(const char *data, size_t size, bool verbose)
 
 // One run of whole records, data[begin, end) with begin at a header line: what Read.hpp:699-760 hands on, for reads that
 // fit one chunk.  A '\r' stays part of its line, as with the reference's getline.
-static const size_t kLongSequence = 1000000;      // shorter records are one piece whatever the options (100 MiB / 48 B / 2 strands)
+// shorter records are one piece whatever the options (100 MiB / 48 B / 2 strands); tests lower both numbers
+static const size_t kLongSequence = getenv("KASA_LONG_SEQUENCE") ? (size_t)atoll(getenv("KASA_LONG_SEQUENCE")) : 1000000;
+static const int64_t kPieceBytes = getenv("KASA_PIECE_BYTES") ? (int64_t)atoll(getenv("KASA_PIECE_BYTES")) : 100ll * 1024 * 1024;   // Read.hpp:438,507
 
 static void parseRecords(const char *data, size_t begin, size_t end, bool fasta, ReadSet &rs, size_t streamBase)
 {
@@ -1022,6 +1024,34 @@ struct SplitCarry {
     }
 };
 
+// --- sequences the reference reads in pieces ---------------------------------------------------------------------------
+// Read::readFileAndGenerateInfos (Read.hpp:371-600) ends a piece after the getChunk call with which the k-mers of what it has
+// read of the record so far would take more than 100 MiB of the input vector (FASTA: line feeds count as letters there); what
+// is left when the record ends is the last piece, possibly empty.  -> letters before every cut, and what every piece adds
+// to "Length" (letters + line feeds, Read.hpp:723-731).
+struct Pieces { vector<int64_t> cut, add; };
+static Pieces readerPieces(const ReadSet::LongRec &lr, bool fasta, bool protein, int frames, int64_t K, bool coherence)
+{
+    const int mode = protein ? 2 : (frames == 1 ? 1 : 0), strands = (frames == 6 && !protein) ? 2 : 1;
+    const int64_t elem = coherence ? (K > 12 ? 40 : 32) : (K > 12 ? 32 : 24);                  // InputType::sizeOf, MetaHeader.h:221-223
+    const int64_t mult = elem * ((strands == 2 && mode != 2) ? 2 : 1), limit = kPieceBytes;
+    auto count = [&](int64_t len) -> int64_t {                                                  // Read.hpp:36-57
+        if (mode == 2) return len > K + 1 ? len - K + 1 : 0;
+        if (mode == 1) return len / 3 > K + 1 ? len / 3 - K + 1 : 0;
+        return len > 3 * K + 1 ? len - 3 * K + 1 : 0;
+    };
+    Pieces pc; pc.cut.push_back(0);
+    int64_t chars = 0, letters = 0, total = 0, totalAtCut = 0;
+    for (size_t i = 0; i < lr.letters.size(); ++i) {
+        const int64_t l = lr.letters[i], f = lr.feed[i];
+        letters += l; total += l + f;
+        if (l > 0) chars += l + (fasta ? f : 0);                                                // (a call without text is not counted: Read.hpp:394,445)
+        if (l > 0 && count(chars) * mult > limit) { pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut); totalAtCut = total; chars = 0; }
+    }
+    pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut);
+    return pc;
+}
+
 // Cuts the reads of one input into batches.  With per-read output the batches are the reference's own: per-read scores
 // are float sums whose order depends on the reads sharing a batch, so the input is cut exactly where `kASA identify -m`
 // cuts it (kasa_refbatch_*: Compare.hpp:2803-2818,3129-3132; Read.hpp:612-630,1147,1165-1195).  A profile-only run
@@ -1124,33 +1154,7 @@ struct Batcher {
         nQueries = (uint64_t)(q * 1.01); nBases = (uint64_t)(reads * bases * 1.01);
     }
     // the next batch; false at the end of the input
-    // --- sequences the reference reads in pieces -------------------------------------------------------------------
-    // Read::readFileAndGenerateInfos (Read.hpp:371-600) ends a piece after the getChunk call with which the k-mers of what
-    // it has read of the record so far would take more than 100 MiB of the input vector (FASTA: line feeds count as
-    // letters there); what is left when the record ends is the last piece, possibly empty.  -> letters before every cut,
-    // and what every piece adds to "Length" (letters + line feeds, Read.hpp:723-731).
-    struct Pieces { vector<int64_t> cut, add; };
-    Pieces piecesOf(const ReadSet::LongRec &lr, bool fasta) const
-    {
-        const int mode = protein ? 2 : (p.frames == 1 ? 1 : 0), strands = (p.frames == 6 && !protein) ? 2 : 1;
-        const int64_t K = p.K, elem = p.coherence ? (K > 12 ? 40 : 32) : (K > 12 ? 32 : 24);      // InputType::sizeOf, MetaHeader.h:221-223
-        const int64_t mult = elem * ((strands == 2 && mode != 2) ? 2 : 1), limit = 100ll * 1024 * 1024;
-        auto count = [&](int64_t len) -> int64_t {                                                  // Read.hpp:36-57
-            if (mode == 2) return len > K + 1 ? len - K + 1 : 0;
-            if (mode == 1) return len / 3 > K + 1 ? len / 3 - K + 1 : 0;
-            return len > 3 * K + 1 ? len - 3 * K + 1 : 0;
-        };
-        Pieces pc; pc.cut.push_back(0);
-        int64_t chars = 0, letters = 0, total = 0, totalAtCut = 0;
-        for (size_t i = 0; i < lr.letters.size(); ++i) {
-            const int64_t l = lr.letters[i], f = lr.feed[i];
-            letters += l; total += l + f;
-            if (l > 0) chars += l + (fasta ? f : 0);                                                // (a call without text is not counted: Read.hpp:394,445)
-            if (l > 0 && count(chars) * mult > limit) { pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut); totalAtCut = total; chars = 0; }
-        }
-        pc.cut.push_back(letters); pc.add.push_back(total - totalAtCut);
-        return pc;
-    }
+    Pieces piecesOf(const ReadSet::LongRec &lr, bool fasta) const { return readerPieces(lr, fasta, protein, p.frames, p.K, p.coherence); }
     std::map<size_t, Pieces> pieceCache;           // read (index in `pending`) -> its pieces, for records with more than one
     size_t cachedFor = ~(size_t)0, cachedRecs = 0;
     const Pieces *piecesOfRead(size_t r)
@@ -1912,6 +1916,22 @@ static int run(int argc, char **argv)
         if (!quiet) dump(all, 0);
         else std::cout << all.size() << " reads, " << all.bases.size() << " bases in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s; read " << g_ht.read
                        << " cut " << g_ht.cut << " parse " << g_ht.parse << " merge " << g_ht.merge << "\n";
+        return 0;
+    }
+    if (argc >= 6 && a[1] == "pieces-dump") {                    // test tap: the pieces of every long record -- <file> <threads> <frames> <K> (no device involved)
+        const unsigned nt = (unsigned)std::stoul(a[3]);
+        ChunkReader cr(a[2]);
+        const char *chunk; size_t chunkBytes; ReadSet all; vector<ReadSet> parts;
+        while (cr.next(chunk, chunkBytes, false)) parsePiece(chunk, chunkBytes, cr.fasta, nt, 1u << 20, all, parts, cr.chunkStart);
+        std::sort(all.longRecs.begin(), all.longRecs.end(), [](const ReadSet::LongRec &x, const ReadSet::LongRec &y) { return x.read < y.read; });
+        for (const ReadSet::LongRec &lr : all.longRecs) {
+            const Pieces pc = readerPieces(lr, cr.fasta, cr.protein, std::stoi(a[4]), std::stoi(a[5]), false);
+            std::cout << lr.read << "\t";
+            for (size_t i = 0; i < pc.cut.size(); ++i) std::cout << (i ? "," : "") << pc.cut[i];
+            std::cout << "\t";
+            for (size_t i = 0; i < pc.add.size(); ++i) std::cout << (i ? "," : "") << pc.add[i];
+            std::cout << "\n";
+        }
         return 0;
     }
     if (argc < 2 || (a[1] != "identify" && a[1] != "identify_multiple")) throw std::runtime_error("only the modes `identify` and `identify_multiple` are available on this path");

@@ -260,3 +260,45 @@ def test_cpp_host_byte_identical_over_the_pieces(case, name, extra, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     with open(prof2, "rb") as f:
         assert f.read().decode("latin-1") == want_prof
+
+
+@pytest.mark.parametrize("block,run", [(None, None), ("1500", "400"), ("4099", "777")])
+def test_cpp_driver_cuts_pieces_like_the_python_host(block, run, tmp_path, monkeypatch):
+    """kasa_identify's own cutting code (parseRecords' reader calls, readerPieces) without a device: its `pieces-dump` tap over
+    small files with every record "long" and a piece limit of a few hundred k-mers, streamed in small blocks and parsed in
+    small runs, against kasa_amd/reads.py (which the test above holds against the restated reader)."""
+    from kasa_amd import build as hipbuild
+    exe = hipbuild.HOST_BIN
+    if not os.path.exists(exe):
+        pytest.skip("host driver not built (python -m kasa_amd.build)")
+    monkeypatch.setattr(reads, "LONG_SEQUENCE", 1)
+    rng = np.random.default_rng(9)
+    for trial in range(24):
+        fasta = trial % 2 == 0
+        width = int(rng.integers(20, 3000))
+        recs = []
+        for r in range(int(rng.integers(1, 6))):
+            n = int(rng.integers(40, 12000))
+            seq = "".join(rng.choice(list("ACGT"), n))
+            body = "\n".join(seq[i:i + width] for i in range(0, n, width))
+            recs.append((">r%d %s\n%s\n" % (r, "x" * int(rng.integers(0, 40)), body)) if fasta else
+                        ("@r%d\n%s\n+\n%s\n" % (r, body, "\n".join("I" * len(l) for l in body.split("\n")))))
+        data = "".join(recs).encode()
+        if trial % 5 == 4:
+            data = data[:-1]
+        path = str(tmp_path / ("t%d.%s" % (trial, "fasta" if fasta else "fastq")))
+        with open(path, "wb") as f:
+            f.write(data)
+        frames = [3, 6, 1][trial % 3]
+        limit = int(rng.integers(2000, 60000))
+        env = dict(os.environ, KASA_LONG_SEQUENCE="1", KASA_PIECE_BYTES=str(limit))
+        if block:
+            env.update(KASA_READ_BLOCK=block, KASA_PARSE_CHUNK=run)
+        r = subprocess.run([exe, "pieces-dump", path, "3", str(frames), "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60, env=env)
+        assert r.returncode == 0, r.stderr[-400:]
+        got = {int(l.split("\t")[0]): l.split("\t")[1:] for l in r.stdout.splitlines() if l[:1].isdigit()}
+        batch = reads.parse_reads(path)
+        assert sorted(got) == sorted(batch.layout)
+        for rd, parts in batch.layout.items():
+            cuts, adds = reads.piece_cuts(parts, fasta, 12, 1 if frames == 1 else 0, 2 if frames == 6 else 1, piece_bytes=limit)
+            assert got[rd] == [",".join(map(str, cuts)), ",".join(map(str, adds))], (trial, rd)
