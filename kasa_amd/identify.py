@@ -40,6 +40,8 @@ class Identify:
         self.device_text = True         # kasa_batch_text: the device writes the per-read file's bytes (needs device_rank, no flagged reads)
         self.device_text_batches = 0    # batches whose text came from the device
         self.flagged_reads = 0          # reads the device handed back to the host's std::sort emulation
+        self.piece_bytes = None         # tests: another limit than the reference's 100 MiB for the pieces of a long sequence (reads.py)
+        self.piece_bounds = None        # tests: the batches over the pieces, [0, p1, ..., nPieces], instead of the reference's (-m) or one batch
 
     def close(self):
         self.ctx.close()
@@ -48,7 +50,8 @@ class Identify:
             memory_gib: int = None, threads: int = 1, ram: bool = False, keep_csr: bool = False):
         """-> (per-read text or None, profile CSV text, list of CSR batches (with keep_csr))."""
         ix = self.index
-        pieced = reads.with_pieces(ix.K, self.frames, self.coherence) if reads.layout else reads
+        pieced = reads if not reads.layout else (reads.with_pieces(ix.K, self.frames, self.coherence) if self.piece_bytes is None else
+                                                 reads.with_pieces(ix.K, self.frames, self.coherence, self.piece_bytes))
         if pieced is not reads:
             return self._run_pieced(pieced, want_per_read, coverage, memory_gib, threads, ram, keep_csr)
         writer = report.ReadWriter(self.fmt, ix.content.names, ix.content.taxids, self.beasts, coherence=self.coherence)
@@ -163,7 +166,9 @@ class Identify:
         self.contaminants = []
         seg = pieced.seg_read.astype(np.int64)
         n_pieces = len(seg)
-        if memory_gib is not None:
+        if self.piece_bounds is not None:
+            bounds = list(self.piece_bounds)
+        elif memory_gib is not None:
             bounds = capi.RefBatcher(ix, self.k_high, self.k_low, self.frames, memory_gib, threads, ram, record_bytes=getattr(ix, "record_bytes", None),
                                      coherence=False).piece_batches(pieced, want_per_read)
         else:

@@ -302,3 +302,119 @@ def test_cpp_driver_cuts_pieces_like_the_python_host(block, run, tmp_path, monke
         for rd, parts in batch.layout.items():
             cuts, adds = reads.piece_cuts(parts, fasta, 12, 1 if frames == 1 else 0, 2 if frames == 6 else 1, piece_bytes=limit)
             assert got[rd] == [",".join(map(str, cuts)), ",".join(map(str, adds))], (trial, rd)
+
+
+def _oracle_over_pieces(ix, pieced, bounds, frames, fmt="jsonl"):
+    """The oracle over explicit batches of pieces with Compare::saveResults' rules and the reader's "Length" (test-side restatement,
+    the one test_oracle_over_the_pieces_equals_the_reference pins on the reference's files)."""
+    seg = pieced.seg_read.astype(np.int64)
+    n_pieces = len(seg)
+    rows, names, lengths = [], [], []
+    saved = reader.SavedScores()
+    ca = cu = None
+    nq = carried = 0
+    for pa, pb in zip(bounds[:-1], bounds[1:]):
+        r0 = int(seg[pa])
+        local = (seg[pa:pb] - r0).astype(np.uint32)
+        n_local = int(local[-1]) + 1
+        tail = pb < n_pieces and seg[pb] == seg[pb - 1]
+        o = pieced.offsets[pa:pb + 1]
+        part = reads.ReadBatch(pieced.bases[int(o[0]):int(o[-1])], o - o[0], None, np.zeros(n_local, np.uint32), pieced.protein, local)
+        res, n = helpers.oracle_identify(ix, part, 12, 7, frames, closed_form=True)
+        row = lambda r: (lambda t: (t.astype(np.uint32), res.M[r, t].astype(np.float32)))(np.flatnonzero(res.M[r, 1:] > 0) + 1)
+        length = carried                                          # Read.hpp:1117,1166-1186
+        for q in range(pa, pb):
+            length += int(pieced.piece_chars[q])
+            if q + 1 == n_pieces or seg[q + 1] != seg[q]:
+                names.append(pieced.names[int(seg[q])])
+                lengths.append(length & 0xFFFFFFFF)
+                length = carried = 0
+            else:
+                carried += length
+        first = 0
+        if saved and not tail:                                    # Compare.hpp:2344-2386
+            saved.add(*row(0))
+            rows.append(saved.take())
+            first = 1
+        if tail:                                                  # Compare.hpp:2388-2409
+            t, s = row(n_local - 1)
+            if t.shape[0]:
+                saved.add(t, s)
+        rows += [row(r) for r in range(first, n_local - (1 if tail else 0))]
+        ca = res.count_all if ca is None else ca + res.count_all
+        cu = res.count_unique if cu is None else cu + res.count_unique
+        nq += n
+    allr = reads.ReadBatch(None, np.zeros(len(names) + 1, np.int64), names, np.asarray(lengths, np.uint32))
+    return helpers.render(ix, allr, rows, ca, cu, nq, fmt, 12, 7, frames, 0.0, 100)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_batches_that_end_inside_reads_three_ways(seed, tmp_path, monkeypatch):
+    """Random inputs over the small golden index with every record "long", a piece limit of a few hundred k-mers and device
+    batches of a few thousand: batches end inside reads in every constellation (several unfinished reads in a row, a batch
+    that is one piece, a read that finishes where the next begins to be unfinished, pieces without a match).  The C++ driver,
+    the Python host and the oracle over the same pieces must write the same bytes."""
+    from kasa_amd import build as hipbuild, identify
+    d, ix = helpers.load_case("pairs")
+    genomes = [l.strip() for l in open(os.path.join(d, "db.fasta")) if not l.startswith(">")]
+    monkeypatch.setattr(reads, "LONG_SEQUENCE", 1)
+    rng = np.random.default_rng(100 + seed)
+    frames = [3, 6, 1][seed % 3]
+    fasta = seed % 2 == 0
+    width = int(rng.integers(50, 400))
+    db = "".join(genomes)
+    recs = []
+    for r in range(int(rng.integers(6, 14))):
+        n = int(rng.integers(60, 9000)) if rng.random() < 0.7 else int(rng.integers(30, 200))
+        if rng.random() < 0.75:
+            a = int(rng.integers(0, max(1, len(db) - n)))
+            seq = list(db[a:a + n])
+            for i in np.flatnonzero(rng.random(len(seq)) < 0.02):
+                seq[i] = "ACGT"[int(rng.integers(0, 4))]
+            seq = "".join(seq)
+        else:
+            seq = "".join(rng.choice(list("ACGT"), n))                # matches next to nothing
+        body = "\n".join(seq[i:i + width] for i in range(0, len(seq), width))
+        recs.append((">r%d\n%s\n" % (r, body)) if fasta else ("@r%d\n%s\n+\n%s\n" % (r, body, "\n".join("I" * len(l) for l in body.split("\n")))))
+    path = str(tmp_path / ("in.fasta" if fasta else "in.fastq"))
+    with open(path, "w") as f:
+        f.write("".join(recs))
+    limit, max_kmers = int(rng.integers(6000, 40000)), int(rng.integers(1500, 9000))
+    # the C++ driver
+    exe = hipbuild.build_host()
+    out, prof = str(tmp_path / "out.jsonl"), str(tmp_path / "prof.csv")
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", path, "-q", out, "-p", prof, "--jsonl", "-b", "100", "-n", "1", "-v"]
+    cmd += ["--six"] if frames == 6 else (["--one"] if frames == 1 else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, KASA_LONG_SEQUENCE="1", KASA_PIECE_BYTES=str(limit), KASA_MAX_BATCH_KMERS=str(max_kmers)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    sizes = [int(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("OUT: Batch of")]
+    # the same batches for the other two: the driver takes pieces while (letters + 64) x strands of them fit its device batch
+    batch = reads.parse_reads(path)
+    pieced = batch.with_pieces(12, frames, False, limit)
+    assert pieced is not batch
+    strands = 2 if frames == 6 else 1
+    bounds, est = [0], 0
+    for q, tl in enumerate(np.diff(pieced.offsets)):
+        k = (int(tl) + 64) * strands
+        if q > bounds[-1] and est + k > max_kmers:
+            bounds.append(q)
+            est = 0
+        est += k
+    bounds.append(len(pieced.seg_read))
+    seg = pieced.seg_read.astype(np.int64)
+    assert sizes == [int(seg[b - 1] - seg[a]) + 1 for a, b in zip(bounds[:-1], bounds[1:])], r.stdout
+    assert sum(1 for b in bounds[1:-1] if seg[b] == seg[b - 1]) >= 2          # batches do end inside reads
+    want_text, want_prof = _oracle_over_pieces(ix, pieced, bounds, frames)
+    with open(out, "rb") as f:
+        assert f.read().decode("latin-1") == want_text
+    with open(prof, "rb") as f:
+        assert f.read().decode("latin-1") == want_prof
+    # the Python host
+    run = identify.Identify(ix, 0, 12, 7, frames, 0.0, 100, "jsonl")
+    run.piece_bytes, run.piece_bounds = limit, bounds
+    text, ptext, _ = run.run(batch, True)
+    assert run.batch_sizes == sizes
+    assert text == want_text and ptext == want_prof
+    run.close()
