@@ -1110,6 +1110,7 @@ struct Batcher {
     void refill()                                  // parse the next chunk of the file behind the pending reads
     {
         if (!reader) return;
+        ++pendingGen;
         if (pendPos > 0 && pendPos == pending.size()) { pending.clear(); pendPos = 0; }
         const char *chunk = nullptr; size_t chunkBytes = 0;
         if (!reader->next(chunk, chunkBytes, p.verbose)) return;
@@ -1156,13 +1157,13 @@ struct Batcher {
     // the next batch; false at the end of the input
     Pieces piecesOf(const ReadSet::LongRec &lr, bool fasta) const { return readerPieces(lr, fasta, protein, p.frames, p.K, p.coherence); }
     std::map<size_t, Pieces> pieceCache;           // read (index in `pending`) -> its pieces, for records with more than one
-    size_t cachedFor = ~(size_t)0, cachedRecs = 0;
+    uint64_t pendingGen = 0, cachedGen = ~0ull;    // `pending` changes (reads come, handed-out ones go: other numbers) -> the cache is made again
     const Pieces *piecesOfRead(size_t r)
     {
-        if (cachedFor != pending.bases.size() || cachedRecs != pending.longRecs.size()) {          // `pending` changed: its reads have other numbers
+        if (cachedGen != pendingGen) {
             pieceCache.clear();
             for (const ReadSet::LongRec &lr : pending.longRecs) { Pieces pc = piecesOf(lr, pending.fasta); if (pc.cut.size() > 2) pieceCache.emplace(lr.read, std::move(pc)); }
-            cachedFor = pending.bases.size(); cachedRecs = pending.longRecs.size();
+            cachedGen = pendingGen;
         }
         auto it = pieceCache.find(r);
         return it == pieceCache.end() ? nullptr : &it->second;
@@ -1195,6 +1196,7 @@ struct Batcher {
                     const char *chunk = nullptr; size_t chunkBytes = 0;
                     if (!reader || !reader->next(chunk, chunkBytes, p.verbose)) break;
                     parsePiece(chunk, chunkBytes, reader->fasta, p.threads, 1u << 20, pending, parts, reader->chunkStart);
+                    ++pendingGen;
                     if (pending.size() == before) break;
                 } else {
                     const size_t before = pending.size() - pendPos;
@@ -1316,7 +1318,7 @@ struct Batcher {
             const size_t first = pendPos, m = r - first;
             if (m > 0 && first == 0 && r == pending.size() && !paired) {
                 b.rs = std::move(pending);                              // everything that is pending: nothing is copied
-                pending = ReadSet(); pendPos = 0;
+                pending = ReadSet(); pendPos = 0; ++pendingGen;
             } else if (m > 0) {
                 b.rs = pending.slice(first, r, spr, p.threads);
                 if (paired) { b.segRead.resize(2 * m); for (size_t x = 0; x < m; ++x) b.segRead[2 * x] = b.segRead[2 * x + 1] = (uint32_t)x; }
