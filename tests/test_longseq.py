@@ -153,11 +153,14 @@ def test_pieces_of_small_inputs_follow_the_oracle_reader():
             n = int(rng.integers(1, 9000))
             seq = "".join(rng.choice(list("ACGT"), n))
             body = "\n".join(seq[i:i + width] for i in range(0, n, width))
-            recs.append((">r%d %s\n%s\n" % (r, "x" * int(rng.integers(0, 40)), body)) if fasta else
-                        ("@r%d\n%s\n+\n%s\n" % (r, body, "\n".join("I" * len(l) for l in body.split("\n")))))
+            tag = "x" * int(rng.integers(0, 40) if trial % 4 else rng.integers(1500, 5000))   # (a header longer than the reader's buffer)
+            recs.append((">r%d %s\n%s\n" % (r, tag, body)) if fasta else
+                        ("@r%d %s\n%s\n+\n%s\n" % (r, tag, body, "\n".join("I" * len(l) for l in body.split("\n")))))
         data = "".join(recs).encode()
         if trial % 5 == 4:
             data = data[:-1]                                                    # no line feed at the end
+        if trial % 7 == 3 and fasta:
+            data = data.replace(b"\n", b"\r\n")                                # the '\r' stays a letter of its line
         mode, strands = [(0, 1), (0, 2), (1, 1)][trial % 3]
         limit = int(rng.integers(2000, 60000))
         lines = reader.info_lines(data, fasta, 12, mode, strands, piece_bytes=limit)
@@ -281,11 +284,14 @@ def test_cpp_driver_cuts_pieces_like_the_python_host(block, run, tmp_path, monke
             n = int(rng.integers(40, 12000))
             seq = "".join(rng.choice(list("ACGT"), n))
             body = "\n".join(seq[i:i + width] for i in range(0, n, width))
-            recs.append((">r%d %s\n%s\n" % (r, "x" * int(rng.integers(0, 40)), body)) if fasta else
-                        ("@r%d\n%s\n+\n%s\n" % (r, body, "\n".join("I" * len(l) for l in body.split("\n")))))
+            tag = "x" * int(rng.integers(0, 40) if trial % 4 else rng.integers(1500, 5000))
+            recs.append((">r%d %s\n%s\n" % (r, tag, body)) if fasta else
+                        ("@r%d %s\n%s\n+\n%s\n" % (r, tag, body, "\n".join("I" * len(l) for l in body.split("\n")))))
         data = "".join(recs).encode()
         if trial % 5 == 4:
             data = data[:-1]
+        if trial % 7 == 3 and fasta:
+            data = data.replace(b"\n", b"\r\n")
         path = str(tmp_path / ("t%d.%s" % (trial, "fasta" if fasta else "fastq")))
         with open(path, "wb") as f:
             f.write(data)
