@@ -544,12 +544,23 @@ def case_longseq(out):
         pieces = [l.strip() for l in open(info) if int(l.split(",")[2]) > 1 or (l.startswith("0,") and not l.strip().endswith(",0"))]
         os.remove(info)
         sizes[name] = {"batches": batches, "pieces_of_the_long_sequence": pieces}
+    # ... and the first input with --filter and the TSV writer (-b 3): the read that is finished from what a batch before
+    # left of it goes through the reference's one-read writer (Compare.hpp:1894-2265) and its own filter test
+    import hashlib
+    run_probed(["identify", "-c", "content.txt", "-d", "idx", "-n", "1", "-i", "long.fasta", "--tsv", "-b", "3", "-m", "1", "--filter", "lflt_clean", "lflt_cont",
+                "-q", "out_long_flt.tsv", "-p", "prof_long_flt.csv"], out, n_taxa, probe)
+    sizes["long_flt"] = {"sha256": {n: hashlib.sha256(open(os.path.join(out, n), "rb").read()).hexdigest() for n in ("lflt_clean.fasta", "lflt_cont.fasta")},
+                         "reads": {n: sum(1 for l in open(os.path.join(out, n)) if l.startswith(">")) for n in ("lflt_clean.fasta", "lflt_cont.fasta")}}
+    with open(os.path.join(out, "out_long_flt.tsv"), "rb") as f, gzip.GzipFile(os.path.join(src, "out_long_flt.tsv.gz"), "wb", mtime=0) as g:
+        shutil.copyfileobj(f, g)
     with open(os.path.join(src, "long.json"), "w") as f:
         json.dump(sizes, f, indent=1)
     for stem in ("long.fasta", "long2.fasta", "long3.fastq"):
         with open(os.path.join(out, stem), "rb") as f, lzma.open(os.path.join(src, stem + ".xz"), "wb", preset=9) as g:
             shutil.copyfileobj(f, g)
     for name in sizes:
+        if name == "long_flt":
+            continue
         with open(os.path.join(out, "out_%s.jsonl" % name), "rb") as f, gzip.GzipFile(os.path.join(src, "out_%s.jsonl.gz" % name), "wb", mtime=0) as g:
             shutil.copyfileobj(f, g)
         shutil.copy(os.path.join(out, "prof_%s.csv" % name), os.path.join(src, "prof_%s.csv" % name))

@@ -77,8 +77,9 @@ def test_oracle_reader_reproduces_the_pieces_and_batches(case, name):
         assert len(batches[2].texts) == 9 and batches[2].n_reads == 1
 
 
-@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True), ("long2_six", True), ("long3", True)])
-def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
+def _oracle_over_reference_batches(case, name, closed_form):
+    """-> (rows, names, lengths, countAll, countUnique, nQueries) of the oracle run over the restated reader's batches, the
+    unfinished reads' scores carried over as Compare::saveResults does."""
     d, ix, data, gold = case
     stem, frames = CONFIGS[name]
     data, fasta = data[stem], stem.endswith(".fasta")
@@ -112,11 +113,42 @@ def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
         cu = res.count_unique if cu is None else cu + res.count_unique
         nq += n
         del res
+    return rows, names, lengths, ca, cu, nq
+
+
+@pytest.mark.parametrize("name,closed_form", [("long", True), ("long", False), ("long_six", True), ("long2_six", True), ("long3", True)])
+def test_oracle_over_the_pieces_equals_the_reference(case, name, closed_form):
+    d, ix, data, gold = case
+    frames = CONFIGS[name][1]
+    rows, names, lengths, ca, cu, nq = _oracle_over_reference_batches(case, name, closed_form)
     allr = reads.ReadBatch(None, np.zeros(len(names) + 1, np.int64), names, np.asarray(lengths, np.uint32))
     text, prof = helpers.render(ix, allr, rows, ca, cu, nq, "jsonl", 12, 7, frames, 0.0, 100)
     want_text, want_prof = _golden(name)
     assert prof == want_prof
     assert text == want_text
+
+
+def test_oracle_over_the_pieces_tsv_and_filter(case, tmp_path):
+    """The same input through the TSV writer (-b 3) with --filter: the read finished from what batch 1 left of it takes the
+    reference's one-read writer and filter test (Compare.hpp:1894-2265); its files are the fixture (the filter's two files by
+    their SHA-256: 10 MB each)."""
+    import hashlib
+    from kasa_amd import report
+    d, ix, data, gold = case
+    rows, names, lengths, ca, cu, nq = _oracle_over_reference_batches(case, "long", True)
+    allr = reads.ReadBatch(None, np.zeros(len(names) + 1, np.int64), names, np.asarray(lengths, np.uint32))
+    text, prof = helpers.render(ix, allr, rows, ca, cu, nq, "tsv", 12, 7, 3, 0.0, 3)
+    with gzip.open(os.path.join(SRC, "out_long_flt.tsv.gz"), "rb") as f:
+        assert text == f.read().decode("latin-1")
+    flagged = []
+    for r in range(len(rows)):
+        rk = report.rank_read(rows[r][0], rows[r][1], int(lengths[r]), ix.freq_at(12), 12, 7, 3, 0.0, 3)
+        if rk.hits and report.is_contaminant(rk.best, max(h.score for h in rk.hits), 0.5):
+            flagged.append(r)
+    report.filter_reads([os.path.join(d, "long.fasta")], flagged, str(tmp_path / "c"), str(tmp_path / "x"))
+    for mine, ref in (("c.fasta", "lflt_clean.fasta"), ("x.fasta", "lflt_cont.fasta")):
+        with open(str(tmp_path / mine), "rb") as f:
+            assert hashlib.sha256(f.read()).hexdigest() == gold["long_flt"]["sha256"][ref], ref
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -224,8 +256,7 @@ def test_python_host_byte_identical_over_the_pieces(case, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,extra", [("long", ["gz", "KASA_READ_BLOCK=3000000", "KASA_PARSE_CHUNK=300000"]),
-                                        ("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"]), ("long3", [])])
+@pytest.mark.parametrize("name,extra", [("long2_six", ["gz", "KASA_READ_BLOCK=5000000", "KASA_PARSE_CHUNK=200000"]), ("long3", [])])
 def test_cpp_host_byte_identical_over_the_pieces(case, name, extra, tmp_path):
     """kasa_identify streams the file in blocks and parses them with several threads: where the blocks and the threads' runs
     end must not move the pieces (the reader's 2048-byte buffers are counted from the start of the file)."""
@@ -426,3 +457,26 @@ def test_batches_that_end_inside_reads_three_ways(seed, tmp_path, monkeypatch):
     assert run.batch_sizes == sizes
     assert text == want_text and ptext == want_prof
     run.close()
+
+
+@pytest.mark.gpu
+def test_cpp_host_pieces_tsv_and_filter(case, tmp_path):
+    """The first input through the TSV writer (-b 3) with --filter: the reference's files (out_long_flt.tsv.gz; the filter's two
+    files by their SHA-256)."""
+    import hashlib
+    from kasa_amd import build as hipbuild
+    d, ix, data, gold = case
+    exe = hipbuild.build_host()
+    out, prof, c, x = (str(tmp_path / n) for n in ("out.tsv", "prof.csv", "c", "x"))
+    cmd = [exe, "identify", "-c", os.path.join(d, "content.txt"), "-d", os.path.join(d, "idx"), "-i", os.path.join(d, "long.fasta"), "-q", out, "-p", prof,
+           "--tsv", "-b", "3", "-m", "1", "-n", "1", "-v", "--filter", c, x]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [int(l.split()[3]) for l in r.stdout.splitlines() if l.startswith("OUT: Batch of")] == gold["long"]["batches"]
+    with gzip.open(os.path.join(SRC, "out_long_flt.tsv.gz"), "rb") as f, open(out, "rb") as g:
+        assert g.read() == f.read()
+    with open(prof, "rb") as f, open(os.path.join(SRC, "prof_long.csv"), "rb") as g:
+        assert f.read() == g.read()
+    for mine, ref in ((c + ".fasta", "lflt_clean.fasta"), (x + ".fasta", "lflt_cont.fasta")):
+        with open(mine, "rb") as f:
+            assert hashlib.sha256(f.read()).hexdigest() == gold["long_flt"]["sha256"][ref], ref
