@@ -318,7 +318,8 @@ enum {
     KASA_KERNEL_SORT_PASSES = 8,  /* kasa_radix: hist_kernel + the radix passes of the query sort */
     KASA_KERNEL_BUCKET_RANK = 9,  /* bucket_rank*_kernel: the query sort's last step */
     KASA_KERNEL_SCORE_DENSE = 10, /* score_dense_kernel: reads with long rows that keep the fast kernels' order rule (crowded indices) */
-    KASA_KERNEL_COUNT = 11
+    KASA_KERNEL_SCORE_REPLAY = 11,/* kasa_replay.h: very long reads -- events sorted by (read, taxon, flush position, level), float chains per (read, taxon) */
+    KASA_KERNEL_COUNT = 12
 };
 int kasa_ctx_kernel_ms(kasa_ctx *ctx, int kernel, double *ms, uint64_t *launches);
 /* Of the last batch: {queries, staging records, profile keys, pool words, reads on the general kernel, of those on its
@@ -392,6 +393,12 @@ int kasa_ctx_counters(kasa_ctx *ctx, uint32_t *generalReads, uint32_t *secondPas
  * window in device memory (narrow records; 64-byte records return KASA_E_LIMIT there).  Ours: the reference's flush is a
  * hash map per thread and has no such window (Compare.hpp:917-955). */
 int kasa_ctx_third_pass_reads(kasa_ctx *ctx, uint32_t *thirdPassReads);
+/* ... and the reads of that list that were long enough (16384 k-mers and more: a contig, a chromosome read in pieces under one
+ * read id) to be replayed from SORTED EVENTS instead -- every query of theirs turned into events {read, taxon, flush position,
+ * level} by all wavefronts, one radix sort, one float32 chain per (read, taxon) -- and the events that took.  The reference
+ * streams such a sequence at merge speed (Compare.hpp:747-1043; pieces: Read.hpp:437-443,678-695); one wavefront per read
+ * does not.  Narrow records. */
+int kasa_ctx_replay_stats(kasa_ctx *ctx, uint32_t *reads, uint64_t *events);
 
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row

@@ -10,7 +10,7 @@ SRC = os.path.join(HERE, "csrc", "kasa_hip.hip")
 HOST_SRCS = [os.path.join(HERE, "csrc", "kasa_refbatch.cpp")]   # host-only parts of the C ABI
 SO = os.path.join(HERE, "libkasa_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "kasa_hip.h")
-CSRC_HEADERS = [os.path.join(HERE, "csrc", "stdsort_order.h"), os.path.join(HERE, "csrc", "kasa_radix.h"), os.path.join(HERE, "csrc", "kasa_text.h"),
+CSRC_HEADERS = [os.path.join(HERE, "csrc", "stdsort_order.h"), os.path.join(HERE, "csrc", "kasa_radix.h"), os.path.join(HERE, "csrc", "kasa_text.h"), os.path.join(HERE, "csrc", "kasa_replay.h"),
                 os.path.join(HERE, "host", "grisu_powers.inc")]
 
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats",
 ]
 
 
@@ -660,7 +660,7 @@ class Context:
         _check(lib().kasa_ctx_stage_reset(self.h))
 
     KERNELS = ("lookup_tile_kernel", "group_kernel", "score_main_kernel", "score_other_kernel", "row_merge_kernel",
-               "score_general_kernels", "profile_table_kernels", "row_copy_kernels", "sort_pass_kernels", "bucket_rank_kernel", "score_dense_kernel")
+               "score_general_kernels", "profile_table_kernels", "row_copy_kernels", "sort_pass_kernels", "bucket_rank_kernel", "score_dense_kernel", "score_replay_kernels")
 
     def kernel_ms(self):
         """HIP-event time of single kernels alone since stage_reset(): {name: (ms, launches)}."""
@@ -686,6 +686,9 @@ class Context:
         n = C.c_uint32(0)
         _check(lib().kasa_ctx_dense_reads(self.h, C.byref(n)))
         out["dense_reads"] = int(n.value)
+        ev = C.c_uint64(0)
+        _check(lib().kasa_ctx_replay_stats(self.h, C.byref(n), C.byref(ev)))
+        out["replay_reads"], out["replay_events"] = int(n.value), int(ev.value)
         return out
 
     def group_tiles(self):

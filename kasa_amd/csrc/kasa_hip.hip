@@ -528,6 +528,11 @@ struct kasa_ctx {
     bool recSorted = false;                     // ... in sorted order (exported for another rank), not in their slots
     uint32_t *recOut = nullptr;                 // ... written straight into the caller's buffer (kasa_batch_group_to), not into `rec`
     int recWords() const { return nK <= 8 ? 8 : 16; }   // RecTraits: 32-byte records up to 8 levels, 64-byte ones up to 25
+    // words between two records in `rec` (the CELL): recWords(), or 16 for narrow records that group2_kernel stores as whole
+    // 64-byte cells -- a random 32-byte store is a partial write of a cell and leaves at 27 G records/s, a whole cell written
+    // by four lanes at 77 G (tools/scatter_probe.hip, profiles/r06_scatter_probe.json); the readers then stream cells
+    uint32_t recCW = 8;
+    bool noWideCells = false;                   // the device has no room for 64-byte cells (sticky)
     // buffers
     DevBuf lut, bases, baseOff, kmerOff;       // u8[366], u8[], i64[nSeq+1], u64[nReads+1] (k-mers per READ, running sum)
     const uint8_t *basesPtr = nullptr;         // the batch's bases: bases.p, or the caller's own device memory (kasa_batch_upload_device)
@@ -554,6 +559,9 @@ struct kasa_ctx {
     uint32_t lastDenseReads = 0;               // reads of the last batch score_dense_kernel kept
     DevBuf ovList2, gwin;                      // ... the second to the third (narrow records); the third pass's pending windows
     uint32_t lastThirdPassReads = 0;
+    // very long reads: events sorted by (read, taxon, flush position, level), float chains per (read, taxon) (kasa_replay.h)
+    DevBuf esrLong, esrShort, esrIota, esrQOff, esrReadEv, esrEvCnt, esrEvOff, esrKeyA, esrKeyB, esrValA, esrValB, esrChain, esrChainScore, esrBig;
+    uint32_t lastReplayReads = 0; uint64_t lastReplayEvents = 0;
     uint32_t lastOverflowReads = 0;
     DevBuf scratch, touched, fbList, fastScratch, profKeys, profSorted, profSorted2;   // per-block dense score rows; reads left to the slow kernel
     uint64_t profLeftHint = 0;                  // per-level keys the last batch's table pass left over, when the list was too short for them
@@ -579,7 +587,8 @@ struct kasa_ctx {
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
                 &rankList, &rankScratch, &scanTmp, &taxText, &taxTextOff, &taxTextIds, &txtNames, &txtNameOff, &txtLen, &txtBest, &txtBytes, &txtOff, &txtOut,
-                &txtFlags};
+                &txtFlags, &esrLong, &esrShort, &esrIota, &esrQOff, &esrReadEv, &esrEvCnt, &esrEvOff, &esrKeyA, &esrKeyB, &esrValA, &esrValB, &esrChain,
+                &esrChainScore, &esrBig};
     }
 };
 
@@ -2132,7 +2141,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
     uint64_t *__restrict__ cntTotal, uint32_t nTaxa,
     uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
     uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo, uint32_t *__restrict__ needCoop,
-    const uint32_t *__restrict__ tileList)
+    const uint32_t *__restrict__ tileList, uint32_t cellW)
 {
     const uint32_t tileId = tileList ? (tileList[blockIdx.x] & 0x0FFFFFFFu) : blockIdx.x;   // (the tiles group2_kernel left to this one; the top bits say why)
     const int coverage = flags & 1;                                // bit 1: every query walks the index itself (test tap); bit 2: no LDS span for 64-byte records
@@ -2630,7 +2639,7 @@ __global__ __launch_bounds__(GTHREADS, (RW == 8 && COOP) ? 6 : 1) void group_ker
         if (p >= nQ) continue;
         if constexpr (RW == 8) {
             const uint32_t slot = slotOf ? slotOf[p] : p;
-            uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * RW);
+            uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot * cellW);   // (cellW = 16: the few tiles group2_kernel lists, in its cells)
             o[0] = make_uint4(p, fmax[i], w2[i], w3[i]);
             o[1] = make_uint4(seg[i][0], seg[i][1], seg[i][2], seg[i][3]);
         }
@@ -2898,7 +2907,7 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
     uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
     uint32_t nTaxa, uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
     uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
-    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList)
+    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList, uint32_t cellW)
 {
     typedef RecTraits<8> RT;
     constexpr int NL = NKT ? NKT : RT::LEVELS, INL = RT::INL, NW = GTHREADS / 64;
@@ -3197,10 +3206,14 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
     block_excl_prefix_sum2(need[0] + need[1], needK[0] + needK[1] + nkPark, shU, offP, offK, totP, totK);
     if (t == 0) {
         sBase = NOPOS;
+        if constexpr ((VAR & 4) != 0) { if (totP) sBase = 1u + tile * 96u; }   // (timing variant: no cursor -- what do the two same-address atomics of 1.3 M workgroups cost?)
+        else
         if (totP) { const unsigned long long at = atomicAdd(poolCursor, (unsigned long long)totP); if (at + totP <= (unsigned long long)poolCap) sBase = (uint32_t)at; }
     }
     if (t == 64) {
         sBaseK = NOPOS;
+        if constexpr ((VAR & 4) != 0) { if (totK) sBaseK = (tile * 700u) % (keyCap - 8192u); }
+        else
         if (totK) { const unsigned long long at = atomicAdd(keyCursor, (unsigned long long)totK); if (at + totK <= (unsigned long long)keyCap) sBaseK = (uint32_t)at; }
     }
     // a list's place inside the workgroup's pool block is known before the block's own place is: it goes into the leader's
@@ -3235,7 +3248,40 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
         }
     }
     if constexpr ((VAR & 2) != 0) __syncthreads();
+    if (flags & 256) return;                                         // (timing tap: everything up to the allocation)
     // ---- D. sorted layout: the records
+    if (cellW == 16u) {
+        // WHOLE 64-byte cells: a lane owns a record, FOUR lanes store its cell in one instruction -- the record's two halves and 32
+        // bytes of zeros -- so that a store instruction touches 16 whole cells instead of halves of 64: a random partial write of
+        // a cell costs the memory side about three whole ones (tools/scatter_probe.hip: 27 against 77 G records/s).  The first half
+        // passes through the dead index span (a wavefront's 64 at a time), the second is the leader's words where they lie.
+        uint4 *sStage = reinterpret_cast<uint4 *>(sRaw) + wv * 64;
+        uint4 *rec4 = reinterpret_cast<uint4 *>(rec);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint4 o0 = make_uint4(base + (uint32_t)i, fmax[i], w2[i], 0u);
+            uint32_t lw = NOPOS;                                      // the query's leader | "a list" << 31
+            if (d[i] != 0) {
+                const uint32_t df = sDF[myL[i]];
+                o0.w = sA[myL[i]];
+                o0.z |= ((df & 0x100u) ? REC_SPLIT : 0u) | ((df & 0x200u) ? REC_SAT : 0u);
+                lw = myL[i] | (((o0.w & 255u) > (uint32_t)INL) ? 0x80000000u : 0u);
+            }
+            sStage[lane] = o0;
+            LDS_WAVE_SYNC_G();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                            // instruction k: the cells of lanes 16k .. 16k+15, a quad each
+                const int src = 16 * k + (lane >> 2);
+                const uint32_t sk = (uint32_t)__shfl((int)slot[i], src), lk = (uint32_t)__shfl((int)lw, src);
+                const uint32_t part = (uint32_t)lane & 3u;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (part == 0u) v = sStage[src];
+                else if (part == 1u && lk != NOPOS) { v = sSeg[lk & 1023u]; if (lk >> 31) v.w += poolBase; }
+                if (sk != NOPOS) rec4[(size_t)sk * 4u + part] = v;
+            }
+            LDS_WAVE_SYNC_G();
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         if (slot[i] == NOPOS) continue;
@@ -3250,6 +3296,7 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
         uint4 *o = reinterpret_cast<uint4 *>(rec + (size_t)slot[i] * 8u);
         o[0] = o0; o[1] = o1;
     }
+    }
     if (fits)
         for (uint32_t x = t; x < nOvf; x += GTHREADS) {
             const uint2 e = sOvf[x];
@@ -3258,6 +3305,7 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
         }
     // ---- E. the profile keys (as group_kernel: one key {levels, |T|, taxon, hits} per run of levels of a segment)
     if (totK == 0u || sBaseK == NOPOS || (flags & 128)) return;      // (uniform)
+    if (cellW == 16u) __syncthreads();                               // (the records' first halves have left the span)
     constexpr uint32_t KSTAGE = (uint32_t)(SPAN_BYTES / 8);
     const bool staged = totK <= KSTAGE;
     unsigned long long *sKeys = reinterpret_cast<unsigned long long *>(sRaw);   // the index span is dead
@@ -3367,6 +3415,7 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 // ------------------------------------------------------------------------------------------------
 struct ScoreArgs {
     const uint32_t *rec; const uint64_t *kmerOff; const uint32_t *pool;   // records by slot; slots of read r: kmerOff[r] .. kmerOff[r+1]
+    uint32_t recCW;                              // words from one record to the next (kasa_ctx::recCW: RW, or 16 for narrow records in 64-byte cells)
     uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
     float *scratch;                              // per block: nTaxa floats, all zero between reads
     uint64_t *cntUnique, *cntAllHi, *cntAllMid, *cntAllLo;
@@ -3406,7 +3455,7 @@ template <int RW, class Key>
 __global__ __launch_bounds__(256) void flush_positions_kernel(
     const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ flushOff, const uint64_t *__restrict__ kmerOff,
     const uint32_t *__restrict__ rec, const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, uint32_t nQ,
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, int kHigh, int kLow, uint32_t *__restrict__ out)
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, int kHigh, int kLow, uint32_t *__restrict__ out, uint32_t recCW)
 {
     const int nK = kHigh - kLow + 1;
     const uint32_t allLv = (nK >= 32) ? 0xFFFFFFFFu : ((1u << nK) - 1u);
@@ -3417,7 +3466,7 @@ __global__ __launch_bounds__(256) void flush_positions_kernel(
         const uint32_t cnt = (uint32_t)(kmerOff[r + 1] - o0);
         const uint64_t f0 = flushOff[wi];
         for (uint32_t j = wv; j < cnt; j += 4) {
-            const uint32_t *w = rec + (o0 + j) * RW;
+            const uint32_t *w = rec + (o0 + j) * recCW;
             const uint32_t p = w[0];
             const int d = (int)(w[2] & 31u);
             uint32_t myF = NOPOS;                                     // lane lv holds F of level lv
@@ -3543,7 +3592,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         // one flushed group: level k of the query at `slot`, c hits of this read; all lanes call it with the same values.
         // |T| = the segments covering k; every taxon is handled by the lane that owns its cell.
         auto applyVals = [&](const int k, const uint32_t slot, const uint32_t c) {
-            const uint32_t *w = A.rec + (size_t)slot * RW;
+            const uint32_t *w = A.rec + (size_t)slot * A.recCW;
             if constexpr (DENSE) {
                 if (slot != cachedSlot) {                                    // stage the query: segments, +1 / -1 at the ends of their level ranges, running sum
                     const uint32_t ns = rec_nseg<RW>(w, A.pool);
@@ -3613,16 +3662,16 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         };
         auto apply = [&](int e) { applyVals((int)wGet(3, e), wGet(1, e), wGet(2, e)); };   // the pending entry at `e`
 
-        uint32_t pnext = cnt ? A.rec[(size_t)o0 * RW] : 0u;
+        uint32_t pnext = cnt ? A.rec[(size_t)o0 * A.recCW] : 0u;
         for (uint32_t j = 0; j < cnt; ++j) {
             const uint32_t p = pnext;
             const uint32_t slot = (uint32_t)(o0 + j);
-            pnext = (j + 1 < cnt) ? A.rec[(size_t)(slot + 1) * RW] : 0xFFFFFFFFu;
+            pnext = (j + 1 < cnt) ? A.rec[(size_t)(slot + 1) * A.recCW] : 0xFFFFFFFFu;
             if (mayHandOn && __ballot(ovf) != 0ull) { ovf = true; break; }
             // everything that flushes at or before p precedes all events of this and later queries
             while (head < tail && wGet(0, head) <= p) { apply(head); ++head; }
             if (head == tail) head = tail = 0;
-            const int d = (int)(A.rec[(size_t)slot * RW + 2] & 31u);
+            const int d = (int)(A.rec[(size_t)slot * A.recCW + 2] & 31u);
             if (d == 0) continue;
             // lane lv holds the event of level k = kHigh - lv
             const bool has = lane < nK && (A.kHigh - lane) <= d;
@@ -3793,10 +3842,10 @@ __global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
     uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
     uint32_t nTaxa, uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
     uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
-    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList)
+    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList, uint32_t cellW)
 {
     group2_tile<Key, NKT, VAR>(blockIdx.x, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
-                          nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList);
+                          nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList, cellW);
 }
 
 // Reads with LONG ROWS that keep the fast kernels' rule -- every group of a query is closed before the read's next matched
@@ -3824,6 +3873,7 @@ __global__ __launch_bounds__(64 * SD_WAVES) void score_dense_kernel(ScoreArgs A,
     for (uint32_t x = lane; x < (A.nTaxa + 3u) / 4u; x += 64) sUni[x] = 0u;
     __syncthreads();
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(A.rec);
+    const uint64_t CQ = A.recCW / 4u;                                  // 16-byte words per cell
     for (uint32_t wi = blockIdx.x * SD_WAVES + (uint32_t)wv; wi < A.nList; wi += gridDim.x * SD_WAVES) {
         const uint32_t r = A.list[wi];
         const uint64_t o0 = A.kmerOff[r];
@@ -3852,15 +3902,15 @@ __global__ __launch_bounds__(64 * SD_WAVES) void score_dense_kernel(ScoreArgs A,
             return P;
         };
         uint4 h = make_uint4(0, 0, 0, 0), b = h, h2 = h, b2 = h;
-        if (cnt) { h = rec4[o0 * 2]; b = rec4[o0 * 2 + 1]; }
-        if (cnt) { const uint64_t s1 = o0 + (cnt > 1 ? 1u : 0u); h2 = rec4[s1 * 2]; b2 = rec4[s1 * 2 + 1]; }
+        if (cnt) { h = rec4[o0 * CQ]; b = rec4[o0 * CQ + 1]; }
+        if (cnt) { const uint64_t s1 = o0 + (cnt > 1 ? 1u : 0u); h2 = rec4[s1 * CQ]; b2 = rec4[s1 * CQ + 1]; }
         Pre pre = cnt ? prefetch(h, b) : Pre{0u, 0u, 0u};
         for (uint32_t j = 0; j < cnt; ++j) {
             uint4 ch = h;
             const uint4 cb = b;
             const Pre cp = pre;
             h = h2; b = b2;
-            { const uint64_t s2 = o0 + (j + 2 < cnt ? j + 2 : cnt - 1); h2 = rec4[s2 * 2]; b2 = rec4[s2 * 2 + 1]; }   // (past the end: the last record again)
+            { const uint64_t s2 = o0 + (j + 2 < cnt ? j + 2 : cnt - 1); h2 = rec4[s2 * CQ]; b2 = rec4[s2 * CQ + 1]; }   // (past the end: the last record again)
             pre = prefetch(h, b);
             // (the record is the whole wavefront's: its header words as scalars)
             ch.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.x); ch.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch.y);
@@ -4081,6 +4131,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
     }
     __syncthreads();
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
+    const size_t CQ = A.recCW / 4u;                                  // 16-byte words per cell (narrow records may lie in 64-byte cells)
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.workCursor, 64u);          // persistent wavefronts take 64 reads at a time
@@ -4100,11 +4151,11 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
             o0 = A.kmerOff[r];
             cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
             if (cnt0 > (FB == 16 ? 60000u : 255u)) { fb = true; atomicAdd(&A.why[0], 1u); }   // the counters' fields
-            rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * (RW / 4);
+            rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * CQ;
             // ---- A. the taxa that get the register slots: the first two with a deep match (segments come in descending
             // order of their last level: the search of a query ends at the first shallow one)
             for (uint32_t j = 0; j < cnt0 && na < FTA && !fb; ++j) {
-                const uint4 *q4 = rp0 + (size_t)j * (RW / 4);
+                const uint4 *q4 = rp0 + (size_t)j * CQ;
                 const uint4 h = q4[0];
                 if ((int)(h.z & 31u) < kPromote) continue;                 // no segment reaches deeper than d (unmatched: d = 0)
                 uint32_t sg[RT::INL];
@@ -4138,7 +4189,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
         // this one is replayed.
         constexpr uint32_t LN = 32u / (uint32_t)RW, LW = LN * (RW / 4);        // records, 16-byte words of a line
         const uint32_t ph = (uint32_t)(o0 & (uint64_t)(LN - 1u));
-        const uint4 *lp0 = rp0 - (size_t)ph * (RW / 4);
+        const uint4 *lp0 = rp0 - (size_t)ph * CQ;
         const uint32_t kEnd = (active && !fb) ? cnt0 + ph : 0u;               // this lane's steps: ph .. kEnd - 1
         uint32_t maxCnt = kEnd;
         for (int off = 32; off; off >>= 1) maxCnt = max(maxCnt, (uint32_t)__shfl_xor((int)maxCnt, off));
@@ -4152,7 +4203,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     const bool mineRec = !fb && k >= ph && k < kEnd;
 #pragma unroll
                     for (uint32_t i = 0; i < (uint32_t)(RW / 4); ++i)
-                        nxt[r2 * (RW / 4) + i] = mineRec ? lp0[(size_t)k * (RW / 4) + i] : make_uint4(0, 0, 0, 0);
+                        nxt[r2 * (RW / 4) + i] = mineRec ? lp0[(size_t)k * CQ + i] : make_uint4(0, 0, 0, 0);
                 }
             };
             if (PF) loadLine(0);
@@ -4369,7 +4420,7 @@ __global__ __launch_bounds__(256) void score_other_kernel(ScoreArgs A)
         uint4 mo = make_uint4(0, 0, 0, 0);
         if (inRange) {
 #pragma unroll
-            for (int i = 0; i < RW / 4; ++i) cur[i] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (RW / 4) + i];
+            for (int i = 0; i < RW / 4; ++i) cur[i] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u) + i];
             // the read of this slot: reads are mostly equally long, so the proportional guess is right; else search
             r = (uint32_t)((double)slot * readsPerSlot);
             if (r >= A.nReads) r = A.nReads - 1u;
@@ -4541,8 +4592,8 @@ __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
         uint64_t readStart = 0;
         uint4 mo = make_uint4(0, 0, 0, 0);
         if (inRange) {
-            cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2];
-            cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2 + 1];
+            cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u)];
+            cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u) + 1];
             r = (uint32_t)((double)slot * readsPerSlot);                       // reads are mostly equally long: the guess is right, else search
             if (r >= A.nReads) r = A.nReads - 1u;
             readStart = A.kmerOff[r];
@@ -5344,7 +5395,7 @@ static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, ui
 #define KASA_GROUP_ARGS(KEY, META) c->keys<KEY>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ, \
         c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
         c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->cntTotal.as<uint64_t>(), c->ix->nTaxa, \
-        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), needCoop, tileList
+        c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), needCoop, tileList, c->recOut ? (uint32_t)RW : c->recCW
     if (c->ix->wide && RW == 16 && c->nK == 19)                       // the default -k 25 7 of a 128-bit index: loops over exactly 19 levels
         group_kernel<RW, key128, RW == 16 ? 19 : 0><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP_ARGS(key128, uint16_t));
     else if (c->ix->wide)
@@ -5369,7 +5420,7 @@ static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, u
         c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
         c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->ix->nTaxa, \
         c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), \
-        slowCount, c->tileList.as<uint32_t>()
+        slowCount, c->tileList.as<uint32_t>(), c->recOut ? 8u : c->recCW
     static const size_t pad = getenv("KASA_G2_PADLDS") ? (size_t)atoi(getenv("KASA_G2_PADLDS")) : 0;   // (occupancy experiments: unused dynamic LDS)
     const uint32_t grid = nTiles;
     if (c->ix->wide) group2_kernel<key128, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
@@ -5378,6 +5429,7 @@ static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, u
         if (var == 1) group2_kernel<uint64_t, 6, 1><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else if (var == 2) group2_kernel<uint64_t, 6, 2><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else if (var == 3) group2_kernel<uint64_t, 6, 3><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+        else if (var == 4) group2_kernel<uint64_t, 6, 4><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
     }
     else group2_kernel<uint64_t, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
@@ -5698,7 +5750,18 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
     if (nQ == 0) { c->grouped = true; return KASA_OK; }
     if (!exportSorted && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     const uint32_t nTiles = (uint32_t)((nQ + TILE - 1) / TILE);
-    if (!c->recOut && (rc = c->rec.reserve(nQ * (size_t)RW * 4 + 64))) return rc;
+    // narrow records that go to random slots leave as whole 64-byte cells (group2_kernel, phase D) when the device has the room:
+    // not for records exported in sorted order (a stream anyway), not under the older kernels' test taps, not with --coverage
+    c->recCW = (uint32_t)RW;
+    if (RW == 8 && !exportSorted && !c->noWideCells && !c->groupCoop && !coverage && !(c->debugFlags & (16777216 | 2048 | 131072 | 262144 | 134217728))) {   // (test tap 134217728: 32-byte slots)
+        if (c->rec.cap < nQ * (size_t)64 + 64) {
+            size_t freeB = 0, totalB = 0;
+            HIPCHK(hipMemGetInfo(&freeB, &totalB));
+            if (freeB + c->rec.cap < nQ * (size_t)64 + 64 + ((size_t)24 << 30)) c->noWideCells = true;   // (24 GB are left to the later stages' buffers)
+        }
+        if (!c->noWideCells) c->recCW = 16u;
+    }
+    if (!c->recOut && (rc = c->rec.reserve(nQ * (size_t)c->recCW * 4 + 64))) return rc;
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging, [18] profile keys
     hipEvent_t a, b;
     if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ);   // (a word per query: a first batch with crowded taxon lists -- 0.75 words per query on the bench data -- need not run group_kernel twice)
@@ -5714,7 +5777,7 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
         const uint32_t cap = (uint32_t)std::min<uint64_t>(c->poolCap, 0xFFFFFFF0ull);
         static const int g2tap = getenv("KASA_G2_TAP") ? atoi(getenv("KASA_G2_TAP")) : 0;   // (timing taps of group2_kernel: 32, 64, 128)
         static const int longSteps = getenv("KASA_LONG_STEPS") ? (atoi(getenv("KASA_LONG_STEPS")) & 127) : 0;   // (experiments: where a lane gives its walk to the wavefront)
-        const int cov = (g2tap & (32 | 64 | 128)) | ((longSteps ? longSteps : (c->groupCoop ? (int)LONG_STEPS_CROWDED : 0)) << 9) | ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
+        const int cov = (g2tap & (32 | 64 | 128 | 256)) | ((longSteps ? longSteps : (c->groupCoop ? (int)LONG_STEPS_CROWDED : 0)) << 9) | ((coverage && attempt == 0) ? 1 : 0) | ((c->debugFlags & 2048) ? 2 : 0) | ((c->debugFlags & 4096) ? 4 : 0) | ((c->debugFlags & 32768) ? 8 : 0) | ((c->debugFlags & 65536) ? 16 : 0);   // (test taps: no followers; no LDS span for 64-byte records)
         const uint32_t *slotOf = exportSorted ? nullptr : c->slotOf;
         hipEvent_t ka, kb;
         if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_GROUP], &ka, &kb))) return rc;
@@ -5785,10 +5848,10 @@ static int launch_flush(kasa_ctx *c, const uint32_t *list, uint32_t nList, const
     const unsigned blocks = std::min<uint32_t>(nList, 256u * 32u);
     if (c->ix->wide)
         flush_positions_kernel<RW, key128><<<blocks, 256, 0, c->stream>>>(list, nList, flushOff, c->kmerOff.as<uint64_t>(), c->rec.as<uint32_t>(),
-            c->keys<key128>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out);
+            c->keys<key128>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out, c->recCW);
     else
         flush_positions_kernel<RW, uint64_t><<<blocks, 256, 0, c->stream>>>(list, nList, flushOff, c->kmerOff.as<uint64_t>(), c->rec.as<uint32_t>(),
-            c->keys<uint64_t>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out);
+            c->keys<uint64_t>(), c->depth.as<uint8_t>(), (uint32_t)c->nQ, c->tileNext.as<uint32_t>(), nTiles, c->kHigh, c->kLow, out, c->recCW);
     HIPCHK(hipGetLastError());
     return KASA_OK;
 }
@@ -5805,6 +5868,8 @@ __global__ void list_counts_kernel(const uint32_t *__restrict__ list, uint32_t n
     }
     if (i == nList) cnt[i] = 0;
 }
+
+#include "kasa_replay.h"
 
 static int score_stage(kasa_ctx *c, int wantPerRead)
 {
@@ -5853,7 +5918,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipMemsetAsync(stCursor, 0, 8, c->stream));             // staging cursor
         HIPCHK(hipMemsetAsync(keyCursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
-        A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>();
+        A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>();
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.mainOut = nullptr; A.otherOff64 = nullptr; A.nQ = (uint32_t)nQ;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
@@ -5955,6 +6020,18 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             c->lastDenseReads = nSlow - handed;
             nSlow = handed;
             A.list = c->fbList2.as<uint32_t>(); A.nList = nSlow;
+        }
+        c->lastReplayReads = 0; c->lastReplayEvents = 0;
+        if (nSlow > 0 && gp && wantPerRead && !(c->debugFlags & 536870912)) {   // (test tap 536870912: never)
+            // very long reads: events sorted by (read, taxon, flush position, level), one float chain per (read, taxon) (kasa_replay.h)
+            const uint32_t minEnv = getenv("KASA_ESR_MIN_KMERS") ? (uint32_t)strtoul(getenv("KASA_ESR_MIN_KMERS"), nullptr, 10) : 0u;   // (tests: short reads through it)
+            const uint32_t minK = (c->debugFlags & 1073741824) ? 1u : (minEnv ? minEnv : ESR_MIN_KMERS);   // (test tap 1073741824: every read of the general kernel's list)
+            hipEvent_t ea, eb;
+            if ((rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_REPLAY], &ea, &eb))) return rc;
+            const uint32_t *rest = nullptr; uint32_t nRest = 0;
+            if ((rc = esr_stage(c, A, nSlow, minK, &rest, &nRest, counters))) return rc;
+            if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_REPLAY], ea, eb))) return rc;
+            if (c->lastReplayReads) { A.list = rest; A.nList = nRest; nSlow = nRest; }
         }
         hipEvent_t ga = nullptr, gb = nullptr;
         if (nSlow > 0 && (rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], &ga, &gb))) return rc;
@@ -6254,6 +6331,7 @@ extern "C" int kasa_batch_records_import(kasa_ctx *c, const uint32_t *records, u
     int rc;
     if (c->nQ && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     if ((rc = c->rec.reserve(nRecordWords * 4 + 64)) || (rc = c->recIn.reserve(nRecordWords * 4 + 64)) || (rc = c->pool.reserve((nPoolWords + 1) * 4))) return rc;
+    c->recCW = (uint32_t)RW;
     c->poolCap = std::max<uint64_t>(c->poolCap, nPoolWords + 1);
     if (nRecordWords) HIPCHK(hipMemcpyAsync(c->recIn.p, records, nRecordWords * 4, hipMemcpyHostToDevice, c->stream));
     if (nPoolWords) HIPCHK(hipMemcpyAsync(c->pool.p, pool, nPoolWords * 4, hipMemcpyHostToDevice, c->stream));
@@ -6406,6 +6484,7 @@ extern "C" int kasa_batch_records_import_device(kasa_ctx *c, uint32_t nParts, co
     int rc;
     if (c->nQ && !c->slotOf && (rc = slots_from_reads(c))) return rc;
     if ((rc = c->rec.reserve(totalRec * 4 + 64)) || (rc = c->recIn.reserve(totalRec * 4 + 64)) || (rc = c->pool.reserve((totalPool + 1) * 4))) return rc;
+    c->recCW = (uint32_t)RW;
     c->poolCap = std::max<uint64_t>(c->poolCap, totalPool + 1);
     uint64_t start = 0, base = 1;
     HIPCHK(hipMemsetAsync(c->pool.p, 0, 4, c->stream));
@@ -7475,7 +7554,7 @@ __global__ __launch_bounds__(256) void record_stats_kernel(ScoreArgs A, unsigned
     uint4 cur[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     uint4 mo = make_uint4(0, 0, 0, 0);
     if (inRange) {
-        cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2]; cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * 2 + 1];
+        cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u)]; cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u) + 1];
         uint32_t lo = 0, hi = A.nReads;
         while (hi - lo > 1) { const uint32_t mid = lo + ((hi - lo) >> 1); if (A.kmerOff[mid] <= slot) lo = mid; else hi = mid; }
         mo = reinterpret_cast<const uint4 *>(A.mainOut)[lo];
@@ -7530,7 +7609,7 @@ extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
     HIPCHK(hipMemsetAsync(tmp.p, 0, 32 * 8, c->stream));
     ScoreArgs A;
     memset(&A, 0, sizeof(A));
-    A.rec = c->rec.as<uint32_t>(); A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
+    A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
     A.nReads = (uint32_t)c->nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nQ = (uint32_t)c->nQ; A.mainOut = c->fastScratch.as<uint32_t>();
     record_stats_kernel<<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(A, tmp.as<unsigned long long>());
     HIPCHK(hipGetLastError());
@@ -7668,7 +7747,7 @@ extern "C" int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *tot
 extern "C" uint64_t kasa_batch_bytes_per_query(const kasa_ctx *c)
 {
     if (!c) return 0;
-    return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)c->recWords() + 8 + 40;
+    return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)((c->recWords() == 8 && !c->noWideCells) ? 16 : c->recWords()) + 8 + 40;   // (narrow records lie in 64-byte cells when there is room)
 }
 
 // Room for a batch of about nQueries k-mers out of nBases bases before it arrives: hipMalloc takes 25-90 ms per GB on this
@@ -7682,7 +7761,7 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
     int rc;
     if ((rc = c->bases.reserve((size_t)nBases + 64)) || (rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64)) ||
         (rc = c->qKmerB.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) || (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)) ||
-        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))
+        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))   // (64-byte cells for narrow records: group_stage asks for them when there is room)
         return rc;
     (void)wantPerRead;
     return KASA_OK;
@@ -7700,6 +7779,14 @@ extern "C" int kasa_ctx_group_tiles(kasa_ctx *c, uint32_t *tiles, uint32_t *list
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (tiles) *tiles = (uint32_t)((c->nQ + TILE - 1) / TILE);
     if (listed) *listed = c->lastSlowTiles;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_replay_stats(kasa_ctx *c, uint32_t *reads, uint64_t *events)
+{
+    if (!c) return fail(KASA_E_ARG, "ctx is NULL");
+    if (reads) *reads = c->lastReplayReads;
+    if (events) *events = c->lastReplayEvents;
     return KASA_OK;
 }
 

@@ -76,7 +76,9 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
         ctx.close(); dix.close()
 
 
-@pytest.mark.parametrize("slow", [0, 1, 2, 4, 1 | 16384 | 8388608], ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge", "general_third_pass"])
+@pytest.mark.parametrize("slow", [0, 1, 2, 4, 1 | 16384 | 8388608, 134217728, 134217728 | 1, 1 | 1073741824, 1073741824],
+                         ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge", "general_third_pass", "slots_of_32_bytes", "slots_of_32_bytes_general",
+                              "sorted_event_replay", "sorted_event_replay_of_the_fallbacks"])
 @pytest.mark.parametrize("seed", range(24))
 def test_adversarial_queries_vs_oracle(seed, slow):
     """Tiny alphabets, many taxa per k-mer, duplicates, '^' letters; queries cross several tiles.  (general_third_pass: every
@@ -108,7 +110,8 @@ def test_adversarial_queries_vs_oracle(seed, slow):
     ctx.close(); dix.close()
 
 
-def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150, K=12):
+def synth_genomes_of(seed, n_taxa, genome_len):
+    """The genomes synthetic_world(seed, n_taxa, genome_len, ...) builds its index from."""
     rng = np.random.default_rng(seed)
     alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
     genomes = []
@@ -120,6 +123,12 @@ def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150, K=12):
         else:
             s = alphabet[rng.integers(0, 4, size=genome_len)]
         genomes.append(s)
+    return genomes
+
+
+def synthetic_world(seed, n_taxa, genome_len, n_reads, read_len=150, K=12):
+    rng = np.random.default_rng(seed)
+    genomes = synth_genomes_of(seed, n_taxa, genome_len)
     content = formats.Content(["non_unique"] + [f"Taxon {g}" for g in range(n_taxa)],
                               np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
     p = oracle.params(K, 7, 3, K=K)
@@ -315,6 +324,53 @@ def test_long_reads_and_mixed_lengths():
     for frames in (3, 6, 1):
         _check_against_oracle(ix, batch, 12, 7, frames)
     _check_against_oracle(ix, batch, 12, 7, 3, unique=True)
+
+
+@pytest.mark.parametrize("frames,round_events", [(3, 0), (6, 0), (3, 600000), (1, 0)], ids=["three_frames", "six_frames", "several_rounds", "one_frame"])
+def test_very_long_reads_replayed_from_sorted_events(frames, round_events, monkeypatch):
+    """Reads of tens of thousands of k-mers (a contig: pieces of the genomes behind each other, regions met twice and three
+    times, so that groups stay open across the read's later queries and one k-mer is hit several times) take the sorted-event
+    replay (kasa_replay.h): events {read, taxon, flush position, level} sorted once, one float chain per (read, taxon) -- short
+    chains a lane each, long ones a wavefront each.  Bit-equal to the oracle's sequential replay; with a budget of 600 000 events
+    per round the two long reads go through several sorts, and a read beyond the budget goes back to the general kernel."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(77 + frames)
+    ix, base = synthetic_world(41, 8, 30000, 40)
+    g = synth_genomes_of(41, 8, 30000)
+    def contig(n_pieces):
+        parts = []
+        for _ in range(n_pieces):
+            t = int(rng.integers(0, len(g)))
+            a = int(rng.integers(0, 30000 - 4000))
+            piece = g[t][a:a + int(rng.integers(500, 4000))].copy()
+            parts.append(piece)
+            if rng.integers(0, 3) == 0:
+                parts.append(piece[: int(rng.integers(100, piece.shape[0]))].copy())      # the same region once more
+        return np.concatenate(parts)
+    long_a, long_b = contig(30), contig(12)
+    seqs = [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(5)] + [long_a] + \
+           [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(5, 12)] + [long_b, np.tile(g[0][:300], 70)]
+    off = np.concatenate(([0], np.cumsum([x.shape[0] for x in seqs]))).astype(np.int64)
+    batch = reads.ReadBatch(np.concatenate(seqs), off, None, np.asarray([x.shape[0] + 1 for x in seqs], dtype=np.uint32))
+    if round_events:
+        monkeypatch.setenv("KASA_ESR_ROUND_EVENTS", str(round_events))
+    monkeypatch.setenv("KASA_ESR_MIN_KMERS", "16384" if frames != 1 else "5000")
+    p = oracle.params(12, 7, frames)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, frames)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    st = ctx.batch_stats()
+    assert st["replay_reads"] >= (2 if not round_events else 1) and st["replay_events"] > 0, st
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.debug_flags(536870912)                                    # (never the replay: the general kernel's answer is the same)
+    ctx.profile_reset()
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    assert ctx.batch_stats()["replay_reads"] == 0
+    assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+    ctx.close(); dix.close()
 
 
 @pytest.mark.parametrize("frames", [3, 6])
@@ -821,7 +877,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40, 64, 72]))
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40, 64, 72, 134217728, 134217728 | 32, 1 | 1073741824, 1073741824]))   # (134217728: narrow records in 32-byte slots, not in 64-byte cells; 1073741824: the general kernel's reads replayed from sorted events)
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
@@ -845,9 +901,9 @@ def test_random_configurations(seed):
     _check_against_oracle(ix, batch, k_high, k_low, frames, flags, unique=unique)
 
 
-@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192, 0, 33554432, 16777216, 268435456, 67108864 | 262144],
+@pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192, 0, 33554432, 16777216, 268435456, 67108864 | 262144, 134217728],
                          ids=["dense_rows", "second_pass", "lane_owned_cells", "coop_group", "coop_group_general", "third_pass", "third_pass_lane_owned_cells",
-                              "product_path", "no_dense_fast_kernel", "older_group_kernel", "exact_tables_always", "coop_group_table_cells"])
+                              "product_path", "no_dense_fast_kernel", "older_group_kernel", "exact_tables_always", "coop_group_table_cells", "slots_of_32_bytes"])
 def test_general_kernel_on_huge_taxon_sets(flags):
     """Every taxon a light mutation of one root: a query meets hundreds of taxa per level.  On the general score kernel: with
     the read's row in LDS and an event's taxa dealt out to the lanes (the product path for such reads), through its second

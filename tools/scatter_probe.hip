@@ -115,6 +115,87 @@ __global__ void scatter64_lds_kernel(uint4 *__restrict__ dst, uint32_t n, uint32
     }
 }
 
+
+// ROUND 6: a 32-byte payload written as a FULL 64-byte cell -- the payload and 32 bytes of anything else -- by lane quads
+// through LDS (one lane owns a record, four lanes store its cell in ONE instruction: 16 whole cells per instruction)
+__global__ void scatter32as64_lds_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_t mask)
+{
+    __shared__ uint4 sh[256 * 2];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = i < n ? perm(i, mask) : 0xFFFFFFFFu;
+    uint4 *mine = sh + wv * 128;
+    mine[lane * 2] = make_uint4(i, s, 0, 0); mine[lane * 2 + 1] = make_uint4(i, s, 1, 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sk = __shfl(s, 16 * k + (lane >> 2));
+        // lanes 0, 1 of a quad carry the payload, lanes 2, 3 the filler (here: the payload once more)
+        if (sk != 0xFFFFFFFFu) dst[(size_t)sk * 4 + (lane & 3)] = mine[(16 * k + (lane >> 2)) * 2 + (lane & 1)];
+    }
+}
+// the same, the filler being zeros made in registers (no second LDS read)
+__global__ void scatter32as64_zero_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_t mask)
+{
+    __shared__ uint4 sh[256 * 2];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = i < n ? perm(i, mask) : 0xFFFFFFFFu;
+    uint4 *mine = sh + wv * 128;
+    mine[lane * 2] = make_uint4(i, s, 0, 0); mine[lane * 2 + 1] = make_uint4(i, s, 1, 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sk = __shfl(s, 16 * k + (lane >> 2));
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((lane & 2) == 0) v = mine[(16 * k + (lane >> 2)) * 2 + (lane & 1)];
+        if (sk != 0xFFFFFFFFu) dst[(size_t)sk * 4 + (lane & 3)] = v;
+    }
+}
+// 32-byte records in 32-byte slots, but stored by lane PAIRS through LDS (one instruction = 32 records of 32 bytes, each a
+// contiguous half cell): is it the number of instructions or the partial cell that costs?
+__global__ void scatter32_pairs_lds_kernel(uint4 *__restrict__ dst, uint32_t n, uint32_t mask)
+{
+    __shared__ uint4 sh[256 * 2];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = i < n ? perm(i, mask) : 0xFFFFFFFFu;
+    uint4 *mine = sh + wv * 128;
+    mine[lane * 2] = make_uint4(i, s, 0, 0); mine[lane * 2 + 1] = make_uint4(i, s, 1, 0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t sk = __shfl(s, 32 * k + (lane >> 1));
+        if (sk != 0xFFFFFFFFu) dst[(size_t)sk * 2 + (lane & 1)] = mine[k * 64 + lane];
+    }
+}
+// what the READERS of such cells pay: a wavefront streams 64 consecutive cells and wants the first 32 bytes of each
+// (HALF = 1: loads the payload halves only; HALF = 0: loads whole cells), 64-byte cells; and 32-byte records back to back
+template <int CELL_WORDS, int READ_WORDS>
+__global__ void stream_read_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int w = 0; w < READ_WORDS; ++w) acc += src[(size_t)i * CELL_WORDS + w].x;
+    if (acc == 0x12345678u) out[i] = acc;
+}
+// the score kernels' pattern: a LANE streams its own run of RUN consecutive cells (a read's queries), a wavefront = 64 runs
+template <int CELL_WORDS, int READ_WORDS, int RUN>
+__global__ void lane_stream_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ out, uint32_t nRuns)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nRuns) return;
+    uint32_t acc = 0;
+    const uint4 *p = src + (size_t)r * RUN * CELL_WORDS;
+    for (int j = 0; j < RUN; ++j) {
+#pragma unroll
+        for (int w = 0; w < READ_WORDS; ++w) acc += p[(size_t)j * CELL_WORDS + w].x;
+    }
+    if (acc == 0x12345678u) out[r] = acc;
+}
+
 template <int WORDS>
 __global__ void gather_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ out, uint32_t n, uint32_t mask)
 {
@@ -210,6 +291,27 @@ int main(int argc, char **argv)
     note("scatter, runs of 4 records (128 B) share a random place", 32, timeit([&] { scatter_run_kernel<4><<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
     note("scatter, runs of 8 records (256 B) share a random place", 32, timeit([&] { scatter_run_kernel<8><<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
     note("scatter, runs of 16 records (512 B) share a random place", 32, timeit([&] { scatter_run_kernel<16><<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
+    note("ROUND 6: 32-byte payload written as a FULL 64-byte cell by lane quads through LDS (payload + 32 B of anything)", 32,
+         timeit([&] { scatter32as64_lds_kernel<<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
+    note("ROUND 6: the same, the other 32 bytes zeros from registers", 32,
+         timeit([&] { scatter32as64_zero_kernel<<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
+    note("ROUND 6: 32-byte records in 32-byte slots stored by lane pairs through LDS (2 instructions of 32 half cells)", 32,
+         timeit([&] { scatter32_pairs_lds_kernel<<<(n + 255) / 256, 256>>>(buf, n, mask); }), n);
+    note("ROUND 6 readers: wavefront streams consecutive 32-byte records (2 x 16 B per lane)", 32,
+         timeit([&] { stream_read_kernel<2, 2><<<(n + 255) / 256, 256>>>(buf, out, n); }), n);
+    note("ROUND 6 readers: wavefront streams 64-byte cells, loads the first 32 bytes of each", 32,
+         timeit([&] { stream_read_kernel<4, 2><<<(n + 255) / 256, 256>>>(buf, out, n); }), n);
+    note("ROUND 6 readers: wavefront streams 64-byte cells, loads all 64 bytes", 64,
+         timeit([&] { stream_read_kernel<4, 4><<<(n + 255) / 256, 256>>>(buf, out, n); }), n);
+    {
+        const uint32_t runs = n / 128;
+        note("ROUND 6 readers: a lane streams its own 128 consecutive 32-byte records (score_main's pattern)", 32,
+             timeit([&] { lane_stream_kernel<2, 2, 128><<<(runs + 255) / 256, 256>>>(buf, out, runs); }), runs * 128);
+        note("ROUND 6 readers: a lane streams its own 128 consecutive 64-byte cells, first 32 bytes of each", 32,
+             timeit([&] { lane_stream_kernel<4, 2, 128><<<(runs + 255) / 256, 256>>>(buf, out, runs); }), runs * 128);
+        note("ROUND 6 readers: a lane streams its own 128 consecutive 64-byte cells, all 64 bytes", 64,
+             timeit([&] { lane_stream_kernel<4, 4, 128><<<(runs + 255) / 256, 256>>>(buf, out, runs); }), runs * 128);
+    }
     if (json) {
         FILE *f = fopen(json, "w");
         if (!f) { perror(json); return 1; }
