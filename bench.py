@@ -41,6 +41,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+DEVICE = [0]                                           # the rank's device (main sets it)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -206,6 +209,25 @@ def resident_batches(torch, synth, g, per_rank, max_batch, L, seed0):
     [(bases pointer, offsets pointer, reads)], the first part as a host ReadBatch for the report and the e2e legs)."""
     n_batches = max(1, -(-per_rank // max_batch))
     per_batch = -(-per_rank // n_batches)
+    if torch is None:                                                      # one GPU: plain device buffers of the C ABI, no other GPU library in the process
+        import numpy as np
+        from kasa_amd import capi
+        dev = capi.DeviceBuffer(per_rank * L, DEVICE[0])
+        first, done = None, 0
+        while done < per_rank:
+            m = min(max_batch, per_rank - done)
+            part = synth.reads_from_genomes(g, m, L, seed=seed0 + done // max(1, max_batch))
+            dev.write(part.bases, done * L)
+            first = first or part
+            done += m
+        keep, batches = [dev], []
+        for b in range(n_batches):
+            a0, a1 = b * per_batch, min(per_rank, (b + 1) * per_batch)
+            off = capi.DeviceBuffer((a1 - a0 + 1) * 8, DEVICE[0])
+            off.write(np.arange(a1 - a0 + 1, dtype=np.int64) * L)
+            keep.append(off)
+            batches.append((dev.ptr + a0 * L, off.ptr, a1 - a0))
+        return keep, batches, first
     dev_reads = torch.empty(per_rank * L, dtype=torch.uint8, device="cuda")
     first = None
     done = 0
@@ -256,10 +278,12 @@ def measure(args, ctx, world, dist, share, torch, kdist, batches, comm=0):
 
     def fence():
         ctx.synchronize()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -405,7 +429,7 @@ def pmc_traffic(args, wide, kernel, live=True, crowded=False):
                 counter = counters[0]
                 dd = os.path.join(d, counter)
                 cmd = [exe, "--pmc", *counters, "--kernel-include-regex", want, "--output-format", "csv", "-d", dd, "--", sys.executable,
-                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc",
+                       os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-quaternary", "--no-pmc",
                        "--reads", str(args.reads), "--taxa", str(args.taxa), "--genome-len", str(args.genome_len), "--read-len", str(args.read_len)]
                 if wide:
                     cmd.append("--wide")
@@ -651,6 +675,69 @@ def file_to_file(args, ix, reads, device, memories=None):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def long_reads_leg(args, capi, synth, torch, device, read_len=10_000):
+    """`quaternary`: long reads against the headline's index.  (a) n_reads x read_len bp reads (a long-read data set: about a third
+    of 10 kb reads repeat one of their own 7-letter prefixes, break the fast kernels' order rule and take the general kernel, one
+    wavefront per read); (b) ONE 9.6 Mbp contig -- 32 different genomes behind each other -- and (c) one genome 32 times over (every
+    group of the read hit 32 times: its longest float chain has 5e7 addends): reads of 16384 k-mers and more are replayed from
+    sorted events (kasa_replay.h; round 5: one wavefront, 0.26-0.35 M k-mers/s).  Bases and offsets resident in HBM, the step as
+    in the headline: upload_device (geometry) + encode + sort + lookup + group + score."""
+    import numpy as np
+    g = synth.genomes(args.taxa, args.genome_len, seed=11)
+    ix = synth.index_from_genomes(g, device=device, K=12)
+    dix = capi.DeviceIndex(ix, device, check_trie=False)
+    ctx = capi.Context(dix, 12, 7, 3)
+    if args.debug_flags:
+        ctx.debug_flags(args.debug_flags)
+    out = {"index_records": int(ix.n), "step": "kasa_batch_upload_device + encode + sort + lookup + group + score, inputs resident in HBM"}
+
+    def run(name, bases, offsets, steps, what):
+        n = int(offsets.shape[0] - 1)
+        db, do = capi.DeviceBuffer(bases.shape[0], device), capi.DeviceBuffer(offsets.shape[0] * 8, device)
+        db.write(bases)
+        do.write(np.ascontiguousarray(offsets, dtype=np.int64))
+
+        def step():
+            ctx.profile_reset()
+            ctx.upload_resident(db.ptr, do.ptr, n)
+            ctx.encode()
+            ctx.sort_and_range()
+            ctx.lookup_score(True, False)
+        step(); step()
+        ctx.synchronize()
+        ctx.stage_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        kmers = ctx.n_kmers
+        ca, _, _ = ctx.profile()
+        st = ctx.batch_stats()
+        km = {k: v[0] / steps for k, v in ctx.kernel_ms().items() if v[1] and k in ("score_general_kernels", "score_replay_kernels", "score_dense_kernel", "score_main_kernel", "group_kernel")}
+        out[name] = {"workload": what, "reads": n, "kmers": int(kmers), "ms_per_step": dt * 1e3, "reads_per_s": n / dt, "kmers_per_s": kmers / dt,
+                     "identified_fraction": float(ca[-1].sum()) / max(1, kmers),
+                     "stage_ms_per_step": {k: v[0] / steps for k, v in ctx.stage_ms().items()}, "kernels_ms_per_step": km,
+                     "general_reads": st["general_reads"], "dense_reads": st["dense_reads"], "replay_reads": st["replay_reads"], "replay_events": st["replay_events"]}
+        db.close(); do.close()
+
+    n_reads = args.long_reads_n
+    read_len = min(read_len, args.genome_len)
+    r = synth.reads_from_genomes(g, n_reads, read_len, seed=4242, chunk=4096)
+    run("reads_10kb", r.bases, r.offsets, 2, f"{n_reads} synthetic {read_len} bp reads (1 % substitutions) in one batch")
+    del r
+    rng = np.random.default_rng(3)
+    for name, picks, what in (("contig_different_genomes", list(range(0, 64, 2)), "ONE sequence of 9.6 Mbp: 32 different genomes behind each other, 1 % substitutions"),
+                              ("contig_one_genome_32_times", [0] * 32, "ONE sequence of 9.6 Mbp: one genome 32 times over, 1 % substitutions")):
+        seq = np.concatenate([g[t % args.taxa] for t in picks]).copy()
+        m = rng.random(seq.shape[0]) < 0.01
+        seq[m] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(m.sum()))]
+        run(name, seq, np.array([0, seq.shape[0]], dtype=np.int64), 2, what)
+    ctx.close()
+    dix.close()
+    return out
+
+
 def make_comm(rank, world, share, torch, dist, kdist):
     """The C ABI's own RCCL communicator for the profile reduce (N > 1) -> (comm, ranks RCCL reports, how the reduce runs)."""
     comm, rccl_ranks, reduce_how = 0, None, None
@@ -807,6 +894,9 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="N > 1: skip the `c4` leg")
     ap.add_argument("--no-c2-strong", action="store_true", help="N > 1: skip the `c2_strong` leg (--reads reads in all over the N ranks)")
     ap.add_argument("--no-tertiary", action="store_true", help="skip the crowded-index workload")
+    ap.add_argument("--no-quaternary", action="store_true", help="skip the long-read workloads (100 000 x 10 kb reads; one 9.6 Mbp contig)")
+    ap.add_argument("--long-reads", action="store_true", help="the long-read workloads as the only measurement")
+    ap.add_argument("--long-reads-n", type=int, default=100_000, help="reads of the 10 kb workload")
     ap.add_argument("--crowded", action="store_true", help="the crowded-index workload as the only measurement (profiling)")
     ap.add_argument("--crowded-reads", type=int, default=2_000_000, help="reads of the crowded-index batch (its (event, taxon) contributions per read are ten times the headline's)")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes for roofline.traffic")
@@ -834,7 +924,7 @@ def main():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # (set by run_with_retry)
     args = ap.parse_args()
 
-    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.child and not args.no_pmc and not args.crowded and not args.wide
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.child and not args.no_pmc and not args.crowded and not args.long_reads and not args.wide
             and not args.partitioned and os.environ.get("KASA_BENCH_NO_RETRY") != "1"):
         raise SystemExit(run_with_retry())             # nothing has touched a GPU in this process
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -851,7 +941,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
+    # One GPU: no torch in the process -- the reads lie in plain device buffers of the C ABI (capi.DeviceBuffer) and the library
+    # runs on the HIP runtime it was built for.  N > 1 (and --partitioned) needs torch.distributed; its wheel brings its own
+    # HIP runtime, which is then the one in the process (capi.share_torch_runtime; the line's `runtime` says which it was).
+    torch = None
+    DEVICE[0] = local_rank
+    if world > 1 or args.partitioned or os.environ.get("KASA_BENCH_TORCH") == "1":
+        import torch
     dist = None
     if world > 1 or args.partitioned:
         import torch.distributed as dist
@@ -862,7 +958,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
+    elif torch is not None:
         torch.cuda.set_device(local_rank)
 
     from kasa_amd import capi, synth
@@ -924,8 +1020,12 @@ def main():
                     out["e2e"] = {"error": str(ex)[:300]}
         ctx.close()
         dix.close()
+        for k in keep:
+            if hasattr(k, "close"):
+                k.close()
         del keep, batches
-        torch.cuda.empty_cache()
+        if torch is not None:
+            torch.cuda.empty_cache()
         if rank == 0 and world == 1 and not wide and legs and workload == "pairs":
             holder["ix"], holder["reads"], holder["k"] = ix, reads, (k_high, k_low)
         if rank == 0 and world == 1 and out["roofline"].get("kernel") and workload == "crowded" and not args.crowded:
@@ -948,6 +1048,11 @@ def main():
 
     KEEP = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "kmers_per_s", "identified_fraction", "rank_step_ms",
             "reduce_ms_per_step", "upload_ms_per_batch", "batch", "stage_ms_per_step", "roofline", "kernels")
+    if args.long_reads:
+        out = long_reads_leg(args, capi, synth, torch, local_rank)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     if args.crowded:
         out = one(False, workload="crowded", legs=False)
         if rank == 0:
@@ -977,6 +1082,13 @@ def main():
             ter = {"error": str(ex)[:400]}
         if rank == 0 and out is not None and ter is not None:
             out["tertiary"] = {k: ter[k] for k in KEEP} if "error" not in ter else ter
+    if world == 1 and not args.wide and not args.no_quaternary:
+        try:
+            qua = long_reads_leg(args, capi, synth, torch, local_rank)
+        except Exception as ex:                                     # never lose the headline to the extra workload
+            qua = {"error": str(ex)[:400]}
+        if rank == 0 and out is not None:
+            out["quaternary"] = qua
     if world > 1 and args.total_reads is None and not args.no_c2_strong:
         # BASELINE.json's metric read literally: 10 M reads IN ALL at 1/2/4/8 GPUs ("strong": 10 M / N per rank, one batch each)
         c2s = one(args.wide, total_reads=args.reads, legs=False)
@@ -990,12 +1102,40 @@ def main():
         out["runtime"] = capi.runtime_info()                        # HIP / RCCL the library was built with and runs on (one runtime per process)
         out.setdefault("attempts", 1)
         out.setdefault("retried", False)
+        out["summary"] = summary_of(out)                            # LAST key, under 1900 characters: a reader that keeps only the line's tail still sees every leg
         print(json.dumps(out), flush=True)
     if comm:
         kdist.rccl_destroy(comm)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def summary_of(out):
+    """The line in small, as its last key (the driver's record keeps the standard keys and the last 2000 characters of stdout):
+    ms per stage and per kernel of the headline, the end-to-end rates, one figure per further leg."""
+    r1 = lambda v: None if v is None else round(float(v), 1)
+    def leg(o):
+        if not isinstance(o, dict) or "value" not in o:
+            return o if o is None else {"error": str(o.get("error"))[:80]} if isinstance(o, dict) else None
+        return {"reads_per_s": round(o["value"]), "ms": r1(o["ms_per_step"]), "stage_ms": {k: r1(v) for k, v in o.get("stage_ms_per_step", {}).items() if v},
+                "roofline": {"kernel": (o.get("roofline", {}).get("kernel") or "")[:24], "ms": r1(o.get("roofline", {}).get("avg_launch_ms")),
+                             "frac": None if o.get("roofline", {}).get("frac") is None else round(o["roofline"]["frac"], 3)}}
+    sm = {"stage_ms": {k: r1(v) for k, v in out.get("stage_ms_per_step", {}).items() if v},
+          "kernel_ms": {k: r1(v.get("avg_launch_ms", v.get("ms_per_step"))) for k, v in out.get("kernels", {}).items()}}
+    e = out.get("e2e") or {}
+    sm["e2e_reads_per_s"] = {k.replace("_reads_per_s", ""): round(v) for k, v in e.items() if k.endswith("_reads_per_s") and isinstance(v, (int, float))}
+    for name in ("secondary", "tertiary", "c2_strong", "c4"):
+        if name in out:
+            sm[name] = leg(out[name])
+    q = out.get("quaternary")
+    if isinstance(q, dict):
+        sm["quaternary"] = {k: {"kmers_per_s": round(v["kmers_per_s"]), "ms": r1(v["ms_per_step"]), "general_reads": v["general_reads"], "replay_reads": v["replay_reads"]}
+                            for k, v in q.items() if isinstance(v, dict) and "kmers_per_s" in v} or {"error": str(q.get("error"))[:80]}
+    txt = json.dumps(sm)
+    if len(txt) > 1900:                                              # (never longer than the tail a reader keeps)
+        sm.pop("kernel_ms", None)
+    return sm
 
 
 def host_cpus():

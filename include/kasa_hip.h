@@ -266,6 +266,12 @@ int kasa_text_dtoa(int device, const double *values, uint32_t n, char *out);
 /* Page-locked host memory for buffers that cross PCIe (reads in, ranked hits or CSR out).  NULL when it cannot be had. */
 void *kasa_host_alloc(size_t bytes);
 void kasa_host_free(void *p);
+/* Plain device memory for a host that keeps its inputs resident in HBM (kasa_batch_upload_device) and holds no other GPU
+ * library: allocate, fill from host memory, free.  Ours (the reference has no device): bench.py's one-GPU run keeps its reads
+ * in these, so that process never imports torch and the library runs on the HIP runtime it was built for. */
+int kasa_device_alloc(int device, size_t bytes, void **out);
+int kasa_device_free(int device, void *p);
+int kasa_device_write(int device, void *dst, const void *src, size_t bytes);
 /* Binds the CALLING host thread to a device.  A fresh thread stands on device 0, and kasa_host_alloc page-locks for the
  * thread's current device: a helper thread that prepares a worker's buffers calls this first (the kasa_ctx_* / kasa_batch_*
  * calls select their context's device themselves). */
@@ -420,7 +426,10 @@ int kasa_ctx_replay_stats(kasa_ctx *ctx, uint32_t *reads, uint64_t *events);
  * rank_exact_kernel in its largest form for every read (no classes by hit count), bit 21 = the other split of the query
  * sort (64-bit keys: five passes over 40 bits + buckets of 20 bits' worth; 128-bit keys: four passes over 32 bits + buckets
  * of 93), bit 22 = the bucket pass of 64-bit keys by the kernel for any key width, bit 23 = the general kernel's second pass
- * hands every read to its third (pending window in device memory; narrow records); lastSlowReads (may be
+ * hands every read to its third (pending window in device memory; narrow records), bit 27 = narrow records are stored as
+ * whole 64-byte cells (group2_kernel writes the record and 32 bytes of zeros by lane quads: a layout option, also
+ * KASA_WIDE_CELLS=1), bit 29 = never the sorted-event replay of very long reads (kasa_ctx_replay_stats), bit 30 = that replay for
+ * every read of the general kernel's list, whatever its length; lastSlowReads (may be
  * NULL) receives how many reads of the last batch took the general score kernel. */
 int kasa_ctx_debug(kasa_ctx *ctx, int forceSlowScore, uint32_t *lastSlowReads);
 int kasa_ctx_synchronize(kasa_ctx *ctx);

@@ -31,6 +31,7 @@ EXPORTS = [
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
     "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats",
+    "kasa_device_alloc", "kasa_device_free", "kasa_device_write",
 ]
 
 
@@ -315,6 +316,34 @@ def pinned_empty(n: int, dtype) -> np.ndarray:
     arr = np.frombuffer((C.c_char * nbytes).from_address(ptr), dtype=dtype, count=int(n))
     weakref.finalize(arr, lib().kasa_host_free, C.c_void_p(ptr))
     return arr
+
+
+class DeviceBuffer:
+    """Plain device memory through the C ABI (kasa_device_alloc / _write / _free): for hosts that keep inputs resident in HBM
+    without importing another GPU library (bench.py at N = 1).  `ptr` is the device address."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p(0)
+        _check(lib().kasa_device_alloc(C.c_int(self.device), C.c_size_t(self.nbytes), C.byref(p)))
+        self.ptr = int(p.value or 0)
+
+    def write(self, arr: np.ndarray, byte_offset: int = 0):
+        arr = np.ascontiguousarray(arr)
+        if byte_offset + arr.nbytes > self.nbytes:
+            raise ValueError("DeviceBuffer.write beyond the buffer")
+        _check(lib().kasa_device_write(C.c_int(self.device), C.c_void_p(self.ptr + int(byte_offset)), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+
+    def close(self):
+        if self.ptr:
+            _check(lib().kasa_device_free(C.c_int(self.device), C.c_void_p(self.ptr)))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_memory(device: int = 0):

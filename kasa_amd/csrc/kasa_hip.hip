@@ -560,6 +560,7 @@ struct kasa_ctx {
     DevBuf ovList2, gwin;                      // ... the second to the third (narrow records); the third pass's pending windows
     uint32_t lastThirdPassReads = 0;
     // very long reads: events sorted by (read, taxon, flush position, level), float chains per (read, taxon) (kasa_replay.h)
+    DevBuf encLong;                            // sequences the encoder spreads over all wavefronts (count, list)
     DevBuf esrLong, esrShort, esrIota, esrQOff, esrReadEv, esrEvCnt, esrEvOff, esrKeyA, esrKeyB, esrValA, esrValB, esrChain, esrChainScore, esrBig;
     uint32_t lastReplayReads = 0; uint64_t lastReplayEvents = 0;
     uint32_t lastOverflowReads = 0;
@@ -587,7 +588,7 @@ struct kasa_ctx {
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
                 &rankList, &rankScratch, &scanTmp, &taxText, &taxTextOff, &taxTextIds, &txtNames, &txtNameOff, &txtLen, &txtBest, &txtBytes, &txtOff, &txtOut,
-                &txtFlags, &esrLong, &esrShort, &esrIota, &esrQOff, &esrReadEv, &esrEvCnt, &esrEvOff, &esrKeyA, &esrKeyB, &esrValA, &esrValB, &esrChain,
+                &txtFlags, &encLong, &esrLong, &esrShort, &esrIota, &esrQOff, &esrReadEv, &esrEvCnt, &esrEvOff, &esrKeyA, &esrKeyB, &esrValA, &esrValB, &esrChain,
                 &esrChainScore, &esrBig};
     }
 };
@@ -873,6 +874,12 @@ extern "C" int kasa_batch_upload_segments(kasa_ctx *c, const uint8_t *bases, con
 static constexpr int ENC_CHUNK = 512;                       // windows per chunk
 static constexpr int ENC_WAVES = 4;
 static constexpr int ENC_RANK_MAX = 512;                    // k-mers of a read the encoder ranks itself (payload = slot)
+static constexpr uint32_t ENC_LONG_MIN = 65536;             // k-mers from which a SEQUENCE is encoded by all wavefronts, a chunk each
+__global__ void enc_long_list_kernel(const uint64_t *__restrict__ seqOff, int64_t nSeq, uint64_t longMin, uint32_t *__restrict__ list, uint32_t *__restrict__ n)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nSeq && seqOff[r + 1] - seqOff[r] >= longMin) list[atomicAdd(n, 1u)] = (uint32_t)r;
+}
 
 #define LDS_WAVE_SYNC_ENC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 // RM: capacity of the per-read ranking (k-mers of a read): 512, or 192 when no read of the batch has more (150-bp reads in
@@ -881,8 +888,11 @@ template <class Key, int RM = ENC_RANK_MAX>
 __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
     const uint32_t *__restrict__ seqRead, int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG,
-    Key *__restrict__ outKmer, uint32_t *__restrict__ outRead, int rankSlots)
+    Key *__restrict__ outKmer, uint32_t *__restrict__ outRead, int rankSlots,
+    const uint32_t *__restrict__ longList, const uint32_t *__restrict__ nLongPtr, uint64_t longMin)
 {
+    // A sequence of longMin k-mers and more (a contig: one wavefront took 87 ms for 9.6 M k-mers) is not one wavefront's: the
+    // first launch skips it, a second one (longList: the listed sequences) deals ITS chunks out to all wavefronts.
     constexpr int KLETTERS = KeyTraits<Key>::LETTERS;
     constexpr int ENC_SPAN = ENC_CHUNK + 3 * KLETTERS;      // bases needed for one chunk (+ slack)
     __shared__ uint8_t sLut[384];
@@ -903,7 +913,11 @@ __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kern
     const int ls = (mode == ENC_PROTEIN) ? 1 : 3;
     const int tail = (KLETTERS - 1) * ls + ((mode == ENC_PROTEIN) ? 1 : 3);   // bases of the last window
     const int chunk = (mode == ENC_ONE) ? ENC_CHUNK / 3 : ENC_CHUNK;
-    for (int64_t r = (int64_t)blockIdx.x * ENC_WAVES + wv; r < nReads; r += wavesTotal) {
+    const bool longK = longList != nullptr;                               // (uniform)
+    const int64_t waveId = (int64_t)blockIdx.x * ENC_WAVES + wv;
+    const int64_t nWork = longK ? (int64_t)*nLongPtr : nReads;
+    for (int64_t wi = longK ? 0 : waveId; wi < nWork; wi += longK ? 1 : wavesTotal) {
+        const int64_t r = longK ? (int64_t)longList[wi] : wi;
         const int64_t b0 = baseOff[r];
         const int64_t raw = baseOff[r + 1] - b0;
         if (raw <= 0) continue;
@@ -911,9 +925,10 @@ __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kern
         enc_geometry(mode, KLETTERS, kLow, raw, body, L, cnt);
         if (cnt == 0) continue;
         const uint64_t o0 = kmerOff[r];
+        if (!longK && kmerOff[r + 1] - o0 >= longMin) continue;           // (the second launch's)
         const uint32_t rid = seqRead ? seqRead[r] : (uint32_t)r;          // paired-end: both mates carry the pair's id
         for (int s = 0; s < strands; ++s) {
-            for (int64_t w0 = 0; w0 < cnt; w0 += chunk) {
+            for (int64_t w0 = longK ? waveId * chunk : 0; w0 < cnt; w0 += longK ? wavesTotal * chunk : chunk) {
                 const int nw = (int)((cnt - w0 < chunk) ? cnt - w0 : chunk);
                 const int span = (nw - 1) * ws + tail;      // bases w0*ws .. w0*ws+span-1
                 const int64_t base0 = w0 * ws;
@@ -1033,25 +1048,42 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
     // k-mers; else the payload is the read id and the slots come from a stable sort by read (slots_from_reads)
     const int rankSlots = (!c->haveSeqRead && c->maxCnt <= (uint32_t)ENC_RANK_MAX && !(c->debugFlags & 8)) ? 1 : 0;
     c->payloadIsSlot = rankSlots != 0;
+    const uint64_t longMin = (!rankSlots && c->maxCnt >= ENC_LONG_MIN) ? (uint64_t)ENC_LONG_MIN : ~0ull;   // (maxCnt: k-mers of the batch's longest READ)
     if (c->nSeq > 0 && nQ > 0) {
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide && rankSlots && c->maxCnt <= 192u)
             encode_kernel<key128, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
+                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots, nullptr, nullptr, longMin);
         else if (c->ix->wide)
             encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots);
+                c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), rankSlots, nullptr, nullptr, longMin);
         else if (rankSlots && c->maxCnt <= 192u)
             encode_kernel<uint64_t, 192><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
+                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots, nullptr, nullptr, longMin);
         else
             encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                 c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
-                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots);
+                c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), rankSlots, nullptr, nullptr, longMin);
         HIPCHK(hipGetLastError());
+        if (longMin != ~0ull) {                                            // the long sequences: their chunks over all wavefronts
+            if ((rc = c->encLong.reserve(((size_t)c->nSeq + 1) * 4 + 64))) return rc;
+            uint32_t *nLong = c->encLong.as<uint32_t>(), *list = nLong + 1;
+            HIPCHK(hipMemsetAsync(nLong, 0, 4, c->stream));
+            enc_long_list_kernel<<<blocks_for((uint64_t)c->nSeq, 256), 256, 0, c->stream>>>(c->seqOff.as<uint64_t>(), c->nSeq, longMin, list, nLong);
+            const unsigned lblocks = 256 * 8;
+            if (c->ix->wide)
+                encode_kernel<key128><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
+                    c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                    c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0, list, nLong, longMin);
+            else
+                encode_kernel<uint64_t><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
+                    c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
+                    c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0, list, nLong, longMin);
+            HIPCHK(hipGetLastError());
+        }
     }
     if ((rc = timer_end(c, c->timers[KASA_STAGE_ENCODE], a, b))) return rc;
     c->qKmer = c->qKmerA.p;
@@ -3415,6 +3447,7 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 // ------------------------------------------------------------------------------------------------
 struct ScoreArgs {
     const uint32_t *rec; const uint64_t *kmerOff; const uint32_t *pool;   // records by slot; slots of read r: kmerOff[r] .. kmerOff[r+1]
+    uint32_t rowPerQuery;                        // fast kernels: a read's staging row may hold max(RMAX, rowPerQuery * its k-mers) records (0: RMAX) -- long reads have long rows
     uint32_t recCW;                              // words from one record to the next (kasa_ctx::recCW: RW, or 16 for narrow records in 64-byte cells)
     uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
     float *scratch;                              // per block: nTaxa floats, all zero between reads
@@ -4145,11 +4178,15 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
         float mS0 = 0.0f, mS1 = 0.0f;
         if constexpr (!GP) for (int l2 = 0; l2 < FTA * nK; ++l2) cnt[(l2 / nK) * NL + (l2 % nK)][lane] = 0;
         uint64_t o0 = 0;
-        uint32_t cnt0 = 0;
+        uint32_t cnt0 = 0, rowCap = (uint32_t)RMAX;
         const uint4 *rp0 = reinterpret_cast<const uint4 *>(A.rec);
         if (active) {
             o0 = A.kmerOff[r];
             cnt0 = (uint32_t)(A.kmerOff[r + 1] - o0);
+            // a LONG read has a long row because it has many k-mers, about one chance match of a short prefix each -- the row
+            // merge streams such a row (row_merge_bitmap_kernel's LONG form); a row that is long because the taxon lists are
+            // (a crowded index) still goes to score_dense_kernel
+            rowCap = max((uint32_t)RMAX, (uint32_t)min((unsigned long long)A.rowPerQuery * cnt0, 0x0FFFFFFFull));
             if (cnt0 > (FB == 16 ? 60000u : 255u)) { fb = true; atomicAdd(&A.why[0], 1u); }   // the counters' fields
             rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * CQ;
             // ---- A. the taxa that get the register slots: the first two with a deep match (segments come in descending
@@ -4290,7 +4327,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     mask0 |= sPM0[lane]; mask1 |= sPM1[lane]; nOther += sPRec[lane]; nKeys += sPKey[lane];
                     LDS_WAVE_SYNC();
                 }
-                if (live && nOther > (uint32_t)RMAX) { fb = true; live = false; atomicAdd(&A.why[2], 1u); }   // a row longer than row_merge handles: the read is the general kernel's, no need to count on
+                if (live && nOther > rowCap) { fb = true; live = false; atomicAdd(&A.why[2], 1u); }   // a row longer than row_merge handles: the read is the general kernel's, no need to count on
                 if ((mask0 | mask1) == 0u || !live) continue;
                 if constexpr (RW == 16) {
                     LDS_WAVE_SYNC();
@@ -4330,7 +4367,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     for (uint32_t q = 0; q < CNT_FIELDS; ++q) nprof += ((pk >> (FB * q)) & FMASK) != 0 ? 1u : 0u;
                 }
         const uint32_t nFinal = PERREAD ? (uint32_t)na : 0u;
-        if (active && !fb && nFinal + nprof + nOther > (uint32_t)RMAX) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge handles
+        if (active && !fb && nFinal + nprof + nOther > rowCap) { fb = true; atomicAdd(&A.why[2], 1u); }   // longer than row_merge handles
         const uint32_t m = (active && !fb) ? nFinal + nprof + nOther : 0u;
         uint32_t incl = m;
         incl = wave_incl_sum(incl);
@@ -5040,7 +5077,11 @@ __global__ __launch_bounds__(64) void row_merge_kernel(const uint32_t *__restric
 // takes the large instantiation.  A row is processed by exactly one of them (mLo < m <= RCAP).
 static constexpr int BM_WORDS = 512;
 
-template <int RCAP, int BMW>
+// LONG: rows of ANY length over at most RCAP = BMW * 32 taxa -- the LDS arrays are per SLOT (distinct taxon of the row), and
+// a row has no more slots than the index has taxa: the records stream through twice, whatever their number (a 10 kb read's
+// row holds ten thousand chance matches; round 5 sent such reads to score_dense_kernel, a wavefront per read with two or
+// three lanes busy).
+template <int RCAP, int BMW, bool LONG = false>
 __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__restrict__ rowPos, uint32_t *__restrict__ rowLen,
                                                               const uint32_t *__restrict__ rowKey,
                                                               uint32_t nReads, uint2 *__restrict__ st, uint64_t *__restrict__ profKeys,
@@ -5063,7 +5104,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
         if (rNext < nReads) { nRaw = rowLen[rNext]; nPos = rowPos[rNext]; nKey = rowKey[rNext]; }
         if (!(raw & ROW_MERGE)) continue;                              // uniform per block
         const uint32_t m = raw & ~ROW_MERGE;
-        if (m <= mLo || m > (uint32_t)RCAP) continue;
+        if (m <= mLo || (!LONG && m > (uint32_t)RCAP)) continue;
         uint2 held[HELD];                                              // all loads of the first chunks go out together
 #pragma unroll
         for (int c = 0; c < HELD; ++c) {
@@ -5071,7 +5112,7 @@ __global__ __launch_bounds__(64) void row_merge_bitmap_kernel(const uint32_t *__
             held[c] = i < m ? st[s0 + i] : make_uint2(RK_FINAL, 0u);
         }
         for (uint32_t w = lane; w < W; w += 64) bm[w] = 0u;
-        for (uint32_t i = lane; i < m; i += 64) { val[i] = 0.0f; claim[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = lane; i < (LONG ? min(m, (uint32_t)RCAP) : m); i += 64) { val[i] = 0.0f; claim[i] = 0xFFFFFFFFu; }
         LDS_WAVE_SYNC();
         // pass 1: the row's taxa as a bitmap; every event leaves as a profile key (a prefix sum places the keys of a chunk)
         uint32_t keyAt = key0;
@@ -5753,7 +5794,12 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
     // narrow records that go to random slots leave as whole 64-byte cells (group2_kernel, phase D) when the device has the room:
     // not for records exported in sorted order (a stream anyway), not under the older kernels' test taps, not with --coverage
     c->recCW = (uint32_t)RW;
-    if (RW == 8 && !exportSorted && !c->noWideCells && !c->groupCoop && !coverage && !(c->debugFlags & (16777216 | 2048 | 131072 | 262144 | 134217728))) {   // (test tap 134217728: 32-byte slots)
+    // MEASURED (round 6, C2): group2_kernel 54.8 -> 48.8 ms (its stores 25 -> 12.8 ms: 83 GB at the chip's write rate instead of 1.3e9
+    // partial cells), but both record passes of the score stage then stream 83 GB instead of 41.6 and turn from issue-bound to
+    // HBM-bound (score_main 16.9 -> 20.3 ms, score_other_flat 19.6 -> 23.9): the step is where it was, with 41.6 GB more resident.
+    // So the cells are an OPTION (KASA_WIDE_CELLS=1, debug flag 134217728) until ONE pass reads the records; the default is 32-byte slots.
+    static const bool cellsEnv = getenv("KASA_WIDE_CELLS") && atoi(getenv("KASA_WIDE_CELLS")) != 0;
+    if (RW == 8 && !exportSorted && !c->noWideCells && !c->groupCoop && !coverage && (cellsEnv || (c->debugFlags & 134217728)) && !(c->debugFlags & (16777216 | 2048 | 131072 | 262144))) {
         if (c->rec.cap < nQ * (size_t)64 + 64) {
             size_t freeB = 0, totalB = 0;
             HIPCHK(hipMemGetInfo(&freeB, &totalB));
@@ -5919,6 +5965,8 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipMemsetAsync(keyCursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
         A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>();
+        // long rows for long reads: the streaming row merge keeps a slot per taxon in LDS (up to 4096 taxa), the bitmap merge must be the one in use (test tap 4: the sorting merge)
+        A.rowPerQuery = (nTaxa <= 4096u && !(c->debugFlags & 4) && !(getenv("KASA_NO_LONG_ROWS") && atoi(getenv("KASA_NO_LONG_ROWS")))) ? 4u : 0u;   // (KASA_NO_LONG_ROWS=1: round 5's limit, tests)
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.mainOut = nullptr; A.otherOff64 = nullptr; A.nQ = (uint32_t)nQ;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
@@ -6179,6 +6227,14 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                 c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, mLo, PL);
+            if (A.rowPerQuery && c->maxCnt > (uint32_t)RMAX / A.rowPerQuery) {   // long reads' rows (beyond RMAX records): streamed, slots in LDS
+                if (nTaxa <= 2048u)
+                    row_merge_bitmap_kernel<2048, 64, true><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                        c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, (uint32_t)RMAX, PL);
+                else
+                    row_merge_bitmap_kernel<4096, 128, true><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
+                        c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, (uint32_t)RMAX, PL);
+            }
         } else
             row_merge_kernel<<<std::min<uint32_t>(nReads, 256u * 24u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(), c->rowLen.as<uint32_t>(),
                 c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, PL);
@@ -7252,12 +7308,12 @@ extern "C" int kasa_batch_coherence(kasa_ctx *c, float *scores, uint64_t *throws
         const unsigned blocks = (unsigned)std::min<int64_t>((c->nSeq + ENC_WAVES - 1) / ENC_WAVES, 256 * 16);
         if (c->ix->wide) {
             encode_kernel<key128><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
-                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0);
+                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0, nullptr, nullptr, ~0ull);
             coh_depth_kernel<key128><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<key128>(), nE, c->ix->kmer.as<key128>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
         } else {
             encode_kernel<uint64_t><<<blocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(), c->seqOff.as<uint64_t>(), nullptr, c->nSeq,
-                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0);
+                c->kLow, c->strands(), c->enc_mode(), c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0, nullptr, nullptr, ~0ull);
             coh_depth_kernel<uint64_t><<<blocks_for(nE, 256), 256, 0, c->stream>>>(c->qKmerA.as<uint64_t>(), nE, c->ix->kmer.as<uint64_t>(), (uint32_t)c->ix->n,
                 c->ix->table.as<uint32_t>(), c->ix->tb, c->kHigh, c->kLow, c->cohLen.as<uint8_t>(), firstMatch);
         }
@@ -7296,6 +7352,31 @@ extern "C" void *kasa_host_alloc(size_t bytes)
     return p;
 }
 extern "C" void kasa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+// Plain device buffers for a host that keeps its inputs resident (kasa_batch_upload_device) without another GPU library in
+// the process: bench.py's one-GPU run allocates its reads through these and never imports torch, so the library runs on the
+// HIP runtime it was built for.
+extern "C" int kasa_device_alloc(int device, size_t bytes, void **out)
+{
+    if (!out) return fail(KASA_E_ARG, "kasa_device_alloc: NULL argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    if (hipMalloc(out, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return fail(KASA_E_NOMEM, "kasa_device_alloc: %zu bytes", bytes); }
+    return KASA_OK;
+}
+extern "C" int kasa_device_free(int device, void *p)
+{
+    if (!p) return KASA_OK;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(p));
+    return KASA_OK;
+}
+extern "C" int kasa_device_write(int device, void *dst, const void *src, size_t bytes)
+{
+    if (bytes && (!dst || !src)) return fail(KASA_E_ARG, "kasa_device_write: NULL argument");
+    HIPCHK(hipSetDevice(device));
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return KASA_OK;
+}
 extern "C" int kasa_thread_device(int device)
 {
     HIPCHK(hipSetDevice(device));
@@ -7609,7 +7690,7 @@ extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
     HIPCHK(hipMemsetAsync(tmp.p, 0, 32 * 8, c->stream));
     ScoreArgs A;
     memset(&A, 0, sizeof(A));
-    A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
+    A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.rowPerQuery = 0u; A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
     A.nReads = (uint32_t)c->nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nQ = (uint32_t)c->nQ; A.mainOut = c->fastScratch.as<uint32_t>();
     record_stats_kernel<<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(A, tmp.as<unsigned long long>());
     HIPCHK(hipGetLastError());
@@ -7747,7 +7828,7 @@ extern "C" int kasa_device_memory(int device, uint64_t *freeBytes, uint64_t *tot
 extern "C" uint64_t kasa_batch_bytes_per_query(const kasa_ctx *c)
 {
     if (!c) return 0;
-    return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)((c->recWords() == 8 && !c->noWideCells) ? 16 : c->recWords()) + 8 + 40;   // (narrow records lie in 64-byte cells when there is room)
+    return 2 * (c->keyBytes() + 4) + 5 + 4ull * (uint64_t)c->recWords() + 8 + 40;
 }
 
 // Room for a batch of about nQueries k-mers out of nBases bases before it arrives: hipMalloc takes 25-90 ms per GB on this
@@ -7761,7 +7842,7 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
     int rc;
     if ((rc = c->bases.reserve((size_t)nBases + 64)) || (rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64)) ||
         (rc = c->qKmerB.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) || (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)) ||
-        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))   // (64-byte cells for narrow records: group_stage asks for them when there is room)
+        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))   // (64-byte cells for narrow records, where asked for: group_stage)
         return rc;
     (void)wantPerRead;
     return KASA_OK;

@@ -166,19 +166,22 @@ __global__ void esr_chain_small_kernel(const float *__restrict__ vals, const uin
     for (uint32_t i = s; i < e; ++i) x = __fadd_rn(x, vals[i]);
     chainScore[c] = x;
 }
-// ... a long one: the wavefront loads ESR_CHUNK addends at a time (coalesced, the next chunk on its way while this one is
-// added), every lane adds them in order out of LDS (the same chain on all lanes: a chain is sequential by nature)
+// ... a long one: the wavefront loads ESR_CHUNK addends at a time (coalesced: lane l holds addends u * 64 + l of the chunk, the
+// next chunk on its way while this one is added).  The chain itself is ONE instruction per addend: x = rotate_right_1(x) + a,
+// a DPP add over the whole wavefront -- the true partial sum travels from lane to lane (at step t it sits in lane t mod 64,
+// which adds ITS addend; what the other lanes compute is never looked at) and after every 64 steps it is back in lane 63.
+// (Out of LDS, four addends per read: 11.5 ns per addend -- the 53 M-event chain of a contig that is one genome 32 times over
+// took 611 ms; v_readlane + v_add: 6.8 ns.)  Addends beyond the chain's end are +0.0f: they leave the (positive) sum as it is.
 __global__ __launch_bounds__(64) void esr_chain_big_kernel(const float *__restrict__ vals, const uint32_t *__restrict__ chainStart, uint32_t nChains,
                                                            const uint32_t *__restrict__ bigList, uint32_t nBig, float *__restrict__ chainScore)
 {
-    __shared__ __attribute__((aligned(16))) float sbuf[ESR_CHUNK];
     const int lane = threadIdx.x;
     constexpr int PER = ESR_CHUNK / 64;
     for (uint32_t bi = blockIdx.x; bi < nBig; bi += gridDim.x) {
         const uint32_t c = bigList[bi];
         const uint32_t s = chainStart[c], e = chainStart[c + 1];
         float x = 0.0f;
-        float reg[PER];
+        float reg[PER], cur[PER];
         auto load = [&](uint32_t b0) {
 #pragma unroll
             for (int u = 0; u < PER; ++u) { const uint32_t i = b0 + (uint32_t)(u * 64 + lane); reg[u] = i < e ? vals[i] : 0.0f; }
@@ -186,19 +189,19 @@ __global__ __launch_bounds__(64) void esr_chain_big_kernel(const float *__restri
         load(s);
         for (uint32_t b0 = s; b0 < e; b0 += ESR_CHUNK) {
 #pragma unroll
-            for (int u = 0; u < PER; ++u) sbuf[u * 64 + lane] = reg[u];
-            LDS_WAVE_SYNC();
+            for (int u = 0; u < PER; ++u) cur[u] = reg[u];
             if (b0 + ESR_CHUNK < e) load(b0 + ESR_CHUNK);
-            const uint32_t m = min((uint32_t)ESR_CHUNK, e - b0);
-            uint32_t i = 0;
-            for (; i + 4u <= m; i += 4u) {
-                const float4 q = *reinterpret_cast<const float4 *>(&sbuf[i]);
-                x = __fadd_rn(x, q.x); x = __fadd_rn(x, q.y); x = __fadd_rn(x, q.z); x = __fadd_rn(x, q.w);
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+#pragma unroll
+                for (int l = 0; l < 64; ++l) {
+                    const float prev = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x13C /* wave_ror:1 */, 0xf, 0xf, false));
+                    x = __fadd_rn(prev, cur[u]);
+                }
             }
-            for (; i < m; ++i) x = __fadd_rn(x, sbuf[i]);
-            LDS_WAVE_SYNC();
         }
-        if (lane == 0) chainScore[c] = x;
+        const float total = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), 63));
+        if (lane == 0) chainScore[c] = total;
     }
 }
 __global__ void esr_big_list_kernel(const uint32_t *__restrict__ chainStart, uint32_t nChains, uint32_t *__restrict__ bigList, uint32_t *__restrict__ nBig)

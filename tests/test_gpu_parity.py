@@ -77,7 +77,7 @@ def test_stages_vs_oracle_golden_inputs(frames, krange):
 
 
 @pytest.mark.parametrize("slow", [0, 1, 2, 4, 1 | 16384 | 8388608, 134217728, 134217728 | 1, 1 | 1073741824, 1073741824],
-                         ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge", "general_third_pass", "slots_of_32_bytes", "slots_of_32_bytes_general",
+                         ids=["fast+fallback", "general_score", "per_query_lookup", "sorting_row_merge", "general_third_pass", "cells_of_64_bytes", "cells_of_64_bytes_general",
                               "sorted_event_replay", "sorted_event_replay_of_the_fallbacks"])
 @pytest.mark.parametrize("seed", range(24))
 def test_adversarial_queries_vs_oracle(seed, slow):
@@ -324,6 +324,52 @@ def test_long_reads_and_mixed_lengths():
     for frames in (3, 6, 1):
         _check_against_oracle(ix, batch, 12, 7, frames)
     _check_against_oracle(ix, batch, 12, 7, 3, unique=True)
+
+
+@pytest.mark.parametrize("n_taxa", [24, 3000], ids=["slots_in_lds", "beyond_4096_taxa"])
+def test_long_reads_keep_the_fast_kernels(n_taxa, monkeypatch):
+    """Reads of thousands of k-mers made of pieces of many taxa: their staging rows hold thousands of records (one per query of
+    a taxon that is not one of the read's two register taxa).  Up to 4096 taxa the row merge streams such rows (its LDS arrays
+    are per taxon of the row, not per record) and the reads stay on the lane-per-read kernels; round 5 handed every row beyond
+    1024 records to score_dense_kernel -- what KASA_NO_LONG_ROWS=1 and indices beyond 4096 taxa still do.  Same bits either way."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(91)
+    g = synth_genomes_of(43, 24, 6000)
+    ix, _ = synthetic_world(43, 24, 6000, 4)
+    if n_taxa > 24:                                              # (the same k-mers under many more taxon ids: only the index's taxon count differs)
+        content = formats.Content(["non_unique"] + [f"Taxon {t}" for t in range(n_taxa)], np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
+        p12 = oracle.params(12, 7, 3)
+        kms, tids = [], []
+        for t, sq in enumerate(g):
+            km, _ = oracle.encode(sq, np.array([0, sq.shape[0]], dtype=np.int64), p12)
+            kms.append(km); tids.append(np.full(km.shape[0], 100 + (t * 113) % n_taxa, dtype=np.uint32))
+        ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    seqs = []
+    for r in range(40):
+        order = rng.permutation(len(g))
+        seqs.append(np.concatenate([g[t][a:a + 260] for t in order for a in [int(rng.integers(0, 5700))]]))   # 24 pieces of 260 bases: 6240 bases
+    seqs.append(g[3][:400].copy())
+    off = np.concatenate(([0], np.cumsum([x.shape[0] for x in seqs]))).astype(np.int64)
+    batch = reads.ReadBatch(np.concatenate(seqs), off, None, np.asarray([x.shape[0] + 1 for x in seqs], dtype=np.uint32))
+    p = oracle.params(12, 7, 3)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    want = helpers.csr_from_dense(res.M)
+    dix = capi.DeviceIndex(ix)
+    for no_long in ("0", "1"):
+        monkeypatch.setenv("KASA_NO_LONG_ROWS", no_long)
+        ctx = capi.Context(dix, 12, 7, 3)
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        st = ctx.batch_stats()
+        general, _ = ctx.counters()
+        if no_long == "0" and n_taxa <= 4096:
+            assert st["dense_reads"] == 0 and general <= 4, (st, general)        # (a read may still repeat a prefix of its own)
+        else:
+            assert st["dense_reads"] + general >= 30, (st, general)
+        ca, cu, _ = ctx.profile()
+        assert np.array_equal(cu, res.count_unique)
+        assert_csr_equal(csr_rows(*ctx.scores()), want)
+        ctx.close()
+    dix.close()
 
 
 @pytest.mark.parametrize("frames,round_events", [(3, 0), (6, 0), (3, 600000), (1, 0)], ids=["three_frames", "six_frames", "several_rounds", "one_frame"])
@@ -877,7 +923,7 @@ def test_random_configurations(seed):
         k_high, k_low = min(K, 12), 7
     frames = int(rng.choice([1, 3, 6]))
     unique = bool(rng.integers(0, 2))
-    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40, 64, 72, 134217728, 134217728 | 32, 1 | 1073741824, 1073741824]))   # (134217728: narrow records in 32-byte slots, not in 64-byte cells; 1073741824: the general kernel's reads replayed from sorted events)
+    flags = int(rng.choice([0, 0, 1, 2, 4, 8, 9, 16, 20, 32, 40, 64, 72, 134217728, 134217728 | 32, 1 | 1073741824, 1073741824]))   # (134217728: narrow records in whole 64-byte cells; 1073741824: the general kernel's reads replayed from sorted events)
     n_taxa = int(rng.integers(2, 24))
     ix, base = synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, int(rng.integers(600, 4000)), 400, K=K)
     pool = base.bases
@@ -903,7 +949,7 @@ def test_random_configurations(seed):
 
 @pytest.mark.parametrize("flags", [1, 1 | 16384, 1 | 8192, 262144, 262144 | 1, 1 | 16384 | 8388608, 1 | 16384 | 8388608 | 8192, 0, 33554432, 16777216, 268435456, 67108864 | 262144, 134217728],
                          ids=["dense_rows", "second_pass", "lane_owned_cells", "coop_group", "coop_group_general", "third_pass", "third_pass_lane_owned_cells",
-                              "product_path", "no_dense_fast_kernel", "older_group_kernel", "exact_tables_always", "coop_group_table_cells", "slots_of_32_bytes"])
+                              "product_path", "no_dense_fast_kernel", "older_group_kernel", "exact_tables_always", "coop_group_table_cells", "cells_of_64_bytes"])
 def test_general_kernel_on_huge_taxon_sets(flags):
     """Every taxon a light mutation of one root: a query meets hundreds of taxa per level.  On the general score kernel: with
     the read's row in LDS and an event's taxa dealt out to the lanes (the product path for such reads), through its second

@@ -231,17 +231,17 @@ def test_bench_same_step_at_every_n(tmp_path):
     assert out["config"]["rccl_ranks_tested"] == 1 and out["attempts"] == 1 and out["retried"] is False
     assert out["runtime"]["hip_built"] and out["runtime"]["hip_runtime"]
     one = _bench(["--steps", "2", "--warmup", "1", "--reads", "8000", "--total-reads", "20000", "--taxa", "8", "--genome-len", "20000",
-                  "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"], share=False)
+                  "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-quaternary", "--no-pmc"], share=False)
     assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["config"]["batches_per_step"] == 3 and one["reduce_ms_per_step"] == 0
     assert 0.5 < one["identified_fraction"] <= 1.0
 
 
 def test_bench_default_line_carries_every_leg(tmp_path):
-    """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), `tertiary` (the crowded index), the
+    """N = 1 in small: the headline (configs[1]), `secondary` (configs[2], 128-bit index), `tertiary` (the crowded index), `quaternary` (long reads), the
     PCIe-inclusive and the file-to-file rates, the CPU baseline with its one-thread rate, the dominant kernel's HBM traffic from
     counter passes run as children -- all in the one JSON line."""
     out = _bench(["--steps", "1", "--warmup", "1", "--reads", "30000", "--taxa", "8", "--genome-len", "20000",
-                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000", "--f2f-settle", "0", "--crowded-reads", "10000"], share=False)
+                  "--cpu-sample", "5000", "--cpu-sample-parallel", "20000", "--f2f-settle", "0", "--crowded-reads", "10000", "--long-reads-n", "300"], share=False)
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["dtype"] == "u64"
     assert out["secondary"]["dtype"] == "u128" and out["secondary"]["value"] > 0
     assert out["tertiary"]["value"] > 0 and out["tertiary"]["config"]["database"] == "crowded" and out["tertiary"]["config"]["reads_per_gpu"] == 10000
@@ -255,6 +255,9 @@ def test_bench_default_line_carries_every_leg(tmp_path):
     assert out["attempts"] == 1 and out["retried"] is False and out["runtime"]["hip_runtime"]       # (no silent second attempt)
     assert "score_dense_kernel" in out["tertiary"]["kernels"] or out["tertiary"]["batch"]["dense_reads"] == 0
     assert out["tertiary"]["roofline"]["traffic_source"]
+    q = out["quaternary"]                                            # long reads: 10 kb reads; one contig (replayed from sorted events)
+    assert q["reads_10kb"]["reads"] == 300 and q["reads_10kb"]["kmers_per_s"] > 0
+    assert q["contig_different_genomes"]["replay_reads"] == 1 and q["contig_one_genome_32_times"]["replay_events"] > 0
     if out["roofline"].get("third_bound"):
         assert out["roofline"]["third_bound"]["bound"] == "issue" and out["roofline"]["third_bound"]["predicted_ms"] > 0
 

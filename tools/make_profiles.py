@@ -36,7 +36,7 @@ if PMC_ONLY:
 else:
   with open(os.path.join(out, tag + "_bench_under_rocprof" + SFX + ".json"), "w") as f:
       run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", "python3", "bench.py", "--steps", "3", "--warmup", "1",
-           "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"] + WARGS, stdout=f, stderr=subprocess.DEVNULL)
+           "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-quaternary", "--no-pmc"] + WARGS, stdout=f, stderr=subprocess.DEVNULL)
   src = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)[0]
   rows = list(csv.DictReader(open(src)))
   with open(os.path.join(out, tag + "_kernel_stats_bench_10M" + SFX + ".csv"), "w") as f:
@@ -59,7 +59,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i, p in enumerate(passes):
     dd = os.path.join(out, "pmc%d%s" % (i, SFX))
     run(["rocprofv3", "--pmc"] + p.split() + ["--kernel-include-regex", KERNELS, "--output-format", "csv", "-d", dd, "--", "python3", "bench.py",
-         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-pmc"] + WARGS, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-e2e", "--no-secondary", "--no-tertiary", "--no-quaternary", "--no-pmc"] + WARGS, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(dd + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             name = re.sub(r"[<(].*", "", row["Kernel_Name"]).replace("void ", "")
