@@ -183,6 +183,17 @@ int kasa_batch_records_import_device(kasa_ctx *ctx, uint32_t nParts, const uint3
  * receives the slices' records THERE (back to back, in partition order) and names those places as `records[j]` spares the
  * batch a second copy of its records (32 or 64 bytes per query); they are then shifted in place. */
 int kasa_batch_records_inbox(kasa_ctx *ctx, uint64_t nRecordWords, uint32_t **records);
+/* The records of an exported slice PACKED for the wire (the return leg of the partitioned exchange; ours -- the reference streams
+ * its index from disk and exchanges nothing): one byte of classes per four records (2 bits each: unmatched / words [1..4] /
+ * [1..6] / [1..7] of a 32-byte record, [1..9] / [1..11] / [1..15] of a 64-byte one, by its number of segments), padded to 16
+ * bytes, then those words back to back; word [0] -- the query's place in the slice -- is implied.  SURVEY 8(e) sizes the
+ * exchange at 12-20 bytes per query.  pack_size (one pass over the records: the sizes) then pack, on the context that grouped
+ * the slice (records = what kasa_batch_group_to / kasa_batch_records_device gave); unpack on the read owner, into the place
+ * the whole records would have been received at (kasa_batch_records_inbox), before kasa_batch_records_import_device. */
+int kasa_batch_records_pack_size(kasa_ctx *ctx, const uint32_t *recordsDev, uint64_t nQueries, uint64_t *nBytes);
+int kasa_batch_records_pack(kasa_ctx *ctx, const uint32_t *recordsDev, uint64_t nQueries, void *outDev, uint64_t capBytes);
+int kasa_batch_records_unpack(kasa_ctx *ctx, const void *packedDev, uint64_t nBytes, uint64_t nQueries, uint32_t *recordsOutDev);
+
 
 /* CSR of the batch: readOffsets[nReads+1]; per read taxIdx ascending with score > 0 -- the cells
  * scoringFunc scans (Compare.hpp:1501-1522). */
@@ -272,6 +283,7 @@ void kasa_host_free(void *p);
 int kasa_device_alloc(int device, size_t bytes, void **out);
 int kasa_device_free(int device, void *p);
 int kasa_device_write(int device, void *dst, const void *src, size_t bytes);
+int kasa_device_read(int device, void *dst, const void *src, size_t bytes);
 /* Binds the CALLING host thread to a device.  A fresh thread stands on device 0, and kasa_host_alloc page-locks for the
  * thread's current device: a helper thread that prepares a worker's buffers calls this first (the kasa_ctx_* / kasa_batch_*
  * calls select their context's device themselves). */

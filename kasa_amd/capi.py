@@ -31,7 +31,7 @@ EXPORTS = [
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
     "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats",
-    "kasa_device_alloc", "kasa_device_free", "kasa_device_write",
+    "kasa_device_alloc", "kasa_device_free", "kasa_device_write", "kasa_device_read", "kasa_batch_records_pack_size", "kasa_batch_records_pack", "kasa_batch_records_unpack",
 ]
 
 
@@ -334,6 +334,12 @@ class DeviceBuffer:
             raise ValueError("DeviceBuffer.write beyond the buffer")
         _check(lib().kasa_device_write(C.c_int(self.device), C.c_void_p(self.ptr + int(byte_offset)), arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
 
+    def read(self, nbytes: int = None, byte_offset: int = 0) -> np.ndarray:
+        nbytes = self.nbytes - byte_offset if nbytes is None else int(nbytes)
+        out = np.empty(nbytes, dtype=np.uint8)
+        _check(lib().kasa_device_read(C.c_int(self.device), out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + int(byte_offset)), C.c_size_t(nbytes)))
+        return out
+
     def close(self):
         if self.ptr:
             _check(lib().kasa_device_free(C.c_int(self.device), C.c_void_p(self.ptr)))
@@ -547,6 +553,18 @@ class Context:
         p = C.c_void_p(0)
         _check(lib().kasa_batch_records_inbox(self.h, C.c_uint64(n_record_words), C.byref(p)))
         return int(p.value or 0)
+
+    def records_pack_size(self, records_ptr: int, n_queries: int) -> int:
+        """Bytes the exported records at `records_ptr` (device) take on the wire (kasa_batch_records_pack_size)."""
+        nb = C.c_uint64(0)
+        _check(lib().kasa_batch_records_pack_size(self.h, C.c_void_p(records_ptr), C.c_uint64(n_queries), C.byref(nb)))
+        return int(nb.value)
+
+    def records_pack(self, records_ptr: int, n_queries: int, out_ptr: int, cap_bytes: int):
+        _check(lib().kasa_batch_records_pack(self.h, C.c_void_p(records_ptr), C.c_uint64(n_queries), C.c_void_p(out_ptr), C.c_uint64(cap_bytes)))
+
+    def records_unpack(self, packed_ptr: int, n_bytes: int, n_queries: int, out_ptr: int):
+        _check(lib().kasa_batch_records_unpack(self.h, C.c_void_p(packed_ptr), C.c_uint64(n_bytes), C.c_uint64(n_queries), C.c_void_p(out_ptr)))
 
     def records_import_device(self, parts):
         """parts[j] = (records pointer, record words, pool pointer, pool words) of slice j, in partition order."""

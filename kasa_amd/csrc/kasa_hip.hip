@@ -561,6 +561,7 @@ struct kasa_ctx {
     uint32_t lastThirdPassReads = 0;
     // very long reads: events sorted by (read, taxon, flush position, level), float chains per (read, taxon) (kasa_replay.h)
     DevBuf encLong;                            // sequences the encoder spreads over all wavefronts (count, list)
+    DevBuf wireOff; uint64_t wireQueries = 0, wireWords = 0; const uint32_t *wireRecords = nullptr;   // kasa_batch_records_pack_size -> _pack: word offsets of the blocks
     DevBuf esrLong, esrShort, esrIota, esrQOff, esrReadEv, esrEvCnt, esrEvOff, esrKeyA, esrKeyB, esrValA, esrValB, esrChain, esrChainScore, esrBig;
     uint32_t lastReplayReads = 0; uint64_t lastReplayEvents = 0;
     uint32_t lastOverflowReads = 0;
@@ -588,7 +589,7 @@ struct kasa_ctx {
                 &gwin, &touched, &fbList, &fastScratch, &profKeys, &profSorted, &profSorted2, &rowPos, &rowLen, &rowKey, &rowOff, &st, &cntAllMid, &outTax,
                 &outScore, &cntUnique, &cntTotal, &cntAllHi, &cntAllLo, &rawOff, &cohLen, &cohState, &sortBig, &rankDen, &rankClass, &rankMeta, &rankOut,
                 &rankList, &rankScratch, &scanTmp, &taxText, &taxTextOff, &taxTextIds, &txtNames, &txtNameOff, &txtLen, &txtBest, &txtBytes, &txtOff, &txtOut,
-                &txtFlags, &encLong, &esrLong, &esrShort, &esrIota, &esrQOff, &esrReadEv, &esrEvCnt, &esrEvOff, &esrKeyA, &esrKeyB, &esrValA, &esrValB, &esrChain,
+                &txtFlags, &encLong, &wireOff, &esrLong, &esrShort, &esrIota, &esrQOff, &esrReadEv, &esrEvCnt, &esrEvOff, &esrKeyA, &esrKeyB, &esrValA, &esrValB, &esrChain,
                 &esrChainScore, &esrBig};
     }
 };
@@ -5966,7 +5967,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
         A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>();
         // long rows for long reads: the streaming row merge keeps a slot per taxon in LDS (up to 4096 taxa), the bitmap merge must be the one in use (test tap 4: the sorting merge)
-        A.rowPerQuery = (nTaxa <= 4096u && !(c->debugFlags & 4) && !(getenv("KASA_NO_LONG_ROWS") && atoi(getenv("KASA_NO_LONG_ROWS")))) ? 4u : 0u;   // (KASA_NO_LONG_ROWS=1: round 5's limit, tests)
+        A.rowPerQuery = (nTaxa <= 4096u && !(c->debugFlags & 4) && !(getenv("KASA_NO_LONG_ROWS") && atoi(getenv("KASA_NO_LONG_ROWS")))) ? 8u : 0u;   // (KASA_NO_LONG_ROWS=1: round 5's limit, tests)
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
         A.scratch = nullptr; A.mainOut = nullptr; A.otherOff64 = nullptr; A.nQ = (uint32_t)nQ;
         A.cntUnique = c->cntUnique.as<uint64_t>(); A.cntAllHi = c->cntAllHi.as<uint64_t>(); A.cntAllMid = c->cntAllMid.as<uint64_t>(); A.cntAllLo = c->cntAllLo.as<uint64_t>();
@@ -6510,6 +6511,155 @@ __global__ void shift_records_kernel(const uint4 *in, uint32_t n, uint32_t start
     if (matched && nseg > (uint32_t)RT::INL) v[RW / 4 - 1].w += poolShift;
 #pragma unroll
     for (int w = 0; w < RW / 4; ++w) out[(size_t)p * (RW / 4) + w] = v[w];
+}
+
+// ---- the records of a slice, packed for the wire (the return leg of the partitioned exchange).  A record of an exported
+// slice says little that its receiver does not know: word [0] is the query's place in the slice, an unmatched query's record
+// is empty, and most matched queries use one to three of their four (eight) segment words.  On the wire: one byte of
+// CLASSES per four records (2 bits each: 0 = unmatched, nothing follows; 1, 2, 3 = the record's words [1 .. n] with
+// n = 4 / 6 / 7 for 32-byte records -- up to one / up to three / more segments -- and 9 / 11 / 15 for 64-byte ones: up to two /
+// up to four / more), padded to 16 bytes, then the words back to back in slice order.  SURVEY 8(e) sizes the exchange at
+// 12-20 bytes per query; whole records are 32 / 64.
+template <int RW> __device__ __forceinline__ uint32_t wire_class(const uint32_t *w)
+{
+    if ((w[2] & 31u) == 0u) return 0u;
+    const uint32_t n = RW == 8 ? (w[3] & 255u) : w[3];
+    return RW == 8 ? (n <= 1u ? 1u : (n <= 3u ? 2u : 3u)) : (n <= 2u ? 1u : (n <= 4u ? 2u : 3u));
+}
+template <int RW> __device__ __forceinline__ uint32_t wire_words(uint32_t cls)
+{
+    return RW == 8 ? (cls == 0u ? 0u : cls == 1u ? 4u : cls == 2u ? 6u : 7u) : (cls == 0u ? 0u : cls == 1u ? 9u : cls == 2u ? 11u : 15u);
+}
+static constexpr int WIRE_BLOCK = 1024;                               // records per workgroup (256 threads, four records each)
+// words the records of every block put on the wire (pack: classes from the records; unpack: from the class bytes)
+template <int RW, bool FROM_RECORDS>
+__global__ __launch_bounds__(256) void wire_count_kernel(const uint32_t *__restrict__ rec, const uint8_t *__restrict__ classes, uint64_t n, uint64_t *__restrict__ blockWords)
+{
+    __shared__ uint32_t sh[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t words = 0;
+    if (FROM_RECORDS) { for (int q = 0; q < 4; ++q) if (i0 + q < n) words += wire_words<RW>(wire_class<RW>(rec + (i0 + q) * RW)); }
+    else if (i0 < n) { const uint32_t cb = classes[i0 >> 2]; for (int q = 0; q < 4; ++q) if (i0 + q < n) words += wire_words<RW>((cb >> (2 * q)) & 3u); }
+    words = wave_incl_sum(words);
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = words;
+    __syncthreads();
+    if (threadIdx.x == 0) blockWords[blockIdx.x] = (uint64_t)sh[0] + sh[1] + sh[2] + sh[3];
+}
+template <int RW>
+__global__ __launch_bounds__(256) void wire_pack_kernel(const uint32_t *__restrict__ rec, uint64_t n, const uint64_t *__restrict__ blockOff, uint8_t *__restrict__ classes,
+                                                        uint32_t *__restrict__ words)
+{
+    __shared__ uint32_t sh[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t cls[4] = {0u, 0u, 0u, 0u}, mine = 0;
+    for (int q = 0; q < 4; ++q) if (i0 + q < n) { cls[q] = wire_class<RW>(rec + (i0 + q) * RW); mine += wire_words<RW>(cls[q]); }
+    if (i0 < n) classes[i0 >> 2] = (uint8_t)(cls[0] | (cls[1] << 2) | (cls[2] << 4) | (cls[3] << 6));
+    const uint32_t incl = wave_incl_sum(mine);
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += sh[w];
+    uint32_t *o = words + blockOff[blockIdx.x] + before;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t nw = wire_words<RW>(cls[q]);
+        const uint32_t *w = rec + (i0 + q) * RW;
+        for (uint32_t x = 0; x < nw; ++x) *o++ = w[1u + x];
+    }
+}
+template <int RW>
+__global__ __launch_bounds__(256) void wire_unpack_kernel(const uint8_t *__restrict__ classes, const uint32_t *__restrict__ words, uint64_t n, const uint64_t *__restrict__ blockOff,
+                                                          uint32_t *__restrict__ rec)
+{
+    __shared__ uint32_t sh[4];
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+    uint32_t cls[4] = {0u, 0u, 0u, 0u}, mine = 0;
+    if (i0 < n) { const uint32_t cb = classes[i0 >> 2]; for (int q = 0; q < 4; ++q) if (i0 + q < n) { cls[q] = (cb >> (2 * q)) & 3u; mine += wire_words<RW>(cls[q]); } }
+    const uint32_t incl = wave_incl_sum(mine);
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += sh[w];
+    const uint32_t *in = words + blockOff[blockIdx.x] + before;
+    for (int q = 0; q < 4; ++q) {
+        if (i0 + q >= n) break;
+        uint32_t *w = rec + (i0 + q) * RW;
+        const uint32_t nw = wire_words<RW>(cls[q]);
+        w[0] = (uint32_t)(i0 + q);                                     // the query's place in its slice
+        for (uint32_t x = 0; x < (uint32_t)RW - 1u; ++x) w[1u + x] = x < nw ? *in++ : 0u;
+    }
+}
+static inline uint64_t wire_class_bytes(uint64_t n) { return ((n + 3) / 4 + 15) / 16 * 16; }
+// block offsets (a running sum over the blocks' word counts, in ctx->wireOff) -> total words
+template <bool FROM_RECORDS>
+static int wire_offsets(kasa_ctx *c, const uint32_t *rec, const uint8_t *classes, uint64_t n, uint64_t *totalWords)
+{
+    int rc;
+    const uint64_t nBlocks = (n + WIRE_BLOCK - 1) / WIRE_BLOCK;
+    *totalWords = 0;
+    if (n == 0) return KASA_OK;
+    if ((rc = c->wireOff.reserve((nBlocks + 1) * 8 + 64))) return rc;
+    uint64_t *off = c->wireOff.as<uint64_t>();
+    HIPCHK(hipMemsetAsync(off + nBlocks, 0, 8, c->stream));
+    if (c->recWords() == 8) wire_count_kernel<8, FROM_RECORDS><<<(unsigned)nBlocks, 256, 0, c->stream>>>(rec, classes, n, off);
+    else wire_count_kernel<16, FROM_RECORDS><<<(unsigned)nBlocks, 256, 0, c->stream>>>(rec, classes, n, off);
+    size_t tmpBytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, off, off, (uint64_t)0, (size_t)nBlocks + 1, rocprim::plus<uint64_t>(), c->stream));
+    if ((rc = c->scanTmp.reserve(tmpBytes))) return rc;
+    HIPCHK(rocprim::exclusive_scan(c->scanTmp.p, tmpBytes, off, off, (uint64_t)0, (size_t)nBlocks + 1, rocprim::plus<uint64_t>(), c->stream));
+    HIPCHK(hipMemcpyAsync(totalWords, off + nBlocks, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_pack_size(kasa_ctx *c, const uint32_t *recordsDev, uint64_t nQueries, uint64_t *nBytes)
+{
+    if (!c || !nBytes || (nQueries && !recordsDev)) return fail(KASA_E_ARG, "kasa_batch_records_pack_size: NULL argument");
+    if (nQueries >= 0xFFFFFFF0ull) return fail(KASA_E_LIMIT, "kasa_batch_records_pack_size: a slice holds fewer than 2^32 queries");
+    HIPCHK(hipSetDevice(c->ix->device));
+    uint64_t words = 0;
+    int rc = wire_offsets<true>(c, recordsDev, nullptr, nQueries, &words);
+    if (rc) return rc;
+    c->wireQueries = nQueries; c->wireRecords = recordsDev; c->wireWords = words;
+    *nBytes = wire_class_bytes(nQueries) + words * 4;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_pack(kasa_ctx *c, const uint32_t *recordsDev, uint64_t nQueries, void *outDev, uint64_t capBytes)
+{
+    if (!c || (nQueries && (!recordsDev || !outDev))) return fail(KASA_E_ARG, "kasa_batch_records_pack: NULL argument");
+    if (c->wireQueries != nQueries || c->wireRecords != recordsDev) return fail(KASA_E_STATE, "kasa_batch_records_pack: call kasa_batch_records_pack_size for these records first");
+    if (wire_class_bytes(nQueries) + c->wireWords * 4 > capBytes) return fail(KASA_E_ARG, "kasa_batch_records_pack: the buffer is too small");
+    if (nQueries == 0) return KASA_OK;
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint64_t nBlocks = (nQueries + WIRE_BLOCK - 1) / WIRE_BLOCK;
+    uint8_t *classes = static_cast<uint8_t *>(outDev);
+    uint32_t *words = reinterpret_cast<uint32_t *>(classes + wire_class_bytes(nQueries));
+    if (c->recWords() == 8) wire_pack_kernel<8><<<(unsigned)nBlocks, 256, 0, c->stream>>>(recordsDev, nQueries, c->wireOff.as<uint64_t>(), classes, words);
+    else wire_pack_kernel<16><<<(unsigned)nBlocks, 256, 0, c->stream>>>(recordsDev, nQueries, c->wireOff.as<uint64_t>(), classes, words);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->wireRecords = nullptr;
+    return KASA_OK;
+}
+
+extern "C" int kasa_batch_records_unpack(kasa_ctx *c, const void *packedDev, uint64_t nBytes, uint64_t nQueries, uint32_t *recordsOutDev)
+{
+    if (!c || (nQueries && (!packedDev || !recordsOutDev))) return fail(KASA_E_ARG, "kasa_batch_records_unpack: NULL argument");
+    if (nQueries == 0) return KASA_OK;
+    if (nBytes < wire_class_bytes(nQueries)) return fail(KASA_E_ARG, "kasa_batch_records_unpack: %llu bytes cannot hold the classes of %llu queries", (unsigned long long)nBytes, (unsigned long long)nQueries);
+    HIPCHK(hipSetDevice(c->ix->device));
+    const uint8_t *classes = static_cast<const uint8_t *>(packedDev);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(classes + wire_class_bytes(nQueries));
+    uint64_t total = 0;
+    int rc = wire_offsets<false>(c, nullptr, classes, nQueries, &total);
+    if (rc) return rc;
+    if (wire_class_bytes(nQueries) + total * 4 != nBytes) return fail(KASA_E_ARG, "kasa_batch_records_unpack: the classes announce %llu words, the buffer holds %llu bytes", (unsigned long long)total, (unsigned long long)nBytes);
+    const uint64_t nBlocks = (nQueries + WIRE_BLOCK - 1) / WIRE_BLOCK;
+    if (c->recWords() == 8) wire_unpack_kernel<8><<<(unsigned)nBlocks, 256, 0, c->stream>>>(classes, words, nQueries, c->wireOff.as<uint64_t>(), recordsOutDev);
+    else wire_unpack_kernel<16><<<(unsigned)nBlocks, 256, 0, c->stream>>>(classes, words, nQueries, c->wireOff.as<uint64_t>(), recordsOutDev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return KASA_OK;
 }
 
 extern "C" int kasa_batch_records_inbox(kasa_ctx *c, uint64_t nRecordWords, uint32_t **records)
@@ -7368,6 +7518,13 @@ extern "C" int kasa_device_free(int device, void *p)
     if (!p) return KASA_OK;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(p));
+    return KASA_OK;
+}
+extern "C" int kasa_device_read(int device, void *dst, const void *src, size_t bytes)
+{
+    if (bytes && (!dst || !src)) return fail(KASA_E_ARG, "kasa_device_read: NULL argument");
+    HIPCHK(hipSetDevice(device));
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return KASA_OK;
 }
 extern "C" int kasa_device_write(int device, void *dst, const void *src, size_t bytes)

@@ -9,6 +9,8 @@ normalised after the reduce.  Backend "nccl" is RCCL on ROCm; "gloo" runs the sa
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -237,27 +239,57 @@ def partitioned_batch_device(owner_ctx, worker, cuts, batch, want_per_read: bool
         pools.append(p); pool_counts.append(npw)
         at += n_in[s]
     del km_in
-    # records: received where kasa_batch_records_import_device files them from (its own staging buffer), shifted in place
+    # records: PACKED for the wire (kasa_batch_records_pack: classes + the words a record really uses -- matched queries only,
+    # 16 / 24 / 28 of a narrow record's 32 bytes by its number of segments), unpacked on arrival into the place
+    # kasa_batch_records_import_device files them from (the context's own staging buffer), shifted there in place
     inbox = ctx.records_inbox(n * ctx.rec_words)
-    rec_recv = _device_view(inbox, n * rw, dev)
-    rec_back, rec_n = _all_to_all_device(rec_out, n_in, rw, recv=rec_recv, recv_counts=out_counts)
-    del rec_out
+    compact = os.environ.get("KASA_WIRE_WHOLE_RECORDS") != "1"
+    if compact:
+        sizes, at = [], 0
+        for s in range(world):
+            sizes.append(worker.ctx.records_pack_size(rec_out.data_ptr() + at * rw, n_in[s]))
+            at += n_in[s]
+        packed = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        at, pa_ = 0, 0
+        for s in range(world):
+            worker.ctx.records_pack_size(rec_out.data_ptr() + at * rw, n_in[s])  # (the block offsets of THIS slice once more: one pass over its records)
+            worker.ctx.records_pack(rec_out.data_ptr() + at * rw, n_in[s], packed.data_ptr() + pa_, sizes[s])
+            at += n_in[s]; pa_ += sizes[s]
+        del rec_out
+        packed_back, bytes_in = _all_to_all_device(packed, sizes, 1)
+        del packed
+        pa_, ra_ = 0, 0
+        for j in range(world):
+            ctx.records_unpack(packed_back.data_ptr() + pa_, bytes_in[j], out_counts[j], inbox + ra_ * rw)
+            pa_ += bytes_in[j]; ra_ += out_counts[j]
+        rec_n = list(out_counts)
+        rec_base = inbox
+        wire_sent, wire_recv = sizes, bytes_in
+        del packed_back
+    else:
+        rec_recv = _device_view(inbox, n * rw, dev)
+        rec_back, rec_n = _all_to_all_device(rec_out, n_in, rw, recv=rec_recv, recv_counts=out_counts)
+        del rec_out
+        rec_base = rec_back.data_ptr()
+        wire_sent, wire_recv = [c * rw for c in n_in], [c * rw for c in rec_n]
     pool_back, pool_n = _all_to_all_device(torch.cat(pools) if pools else torch.empty(0, dtype=torch.uint8, device=dev), pool_counts, 4)
     del pools
     parts, ra, pa = [], 0, 0
     for j in range(world):
-        parts.append((rec_back.data_ptr() + ra * rw, rec_n[j] * ctx.rec_words, pool_back.data_ptr() + pa * 4, pool_n[j]))
+        parts.append((rec_base + ra * rw, rec_n[j] * ctx.rec_words, pool_back.data_ptr() + pa * 4, pool_n[j]))
         ra += rec_n[j]; pa += pool_n[j]
     ctx.records_import_device(parts)
     if stats is not None:
         me = dist.get_rank()
         stats.update({"queries_sent": sum(c for j, c in enumerate(out_counts) if j != me) * kb,
                       "queries_received": sum(c for j, c in enumerate(n_in) if j != me) * kb,
-                      "records_sent": sum(c for j, c in enumerate(n_in) if j != me) * rw,
-                      "records_received": sum(c for j, c in enumerate(rec_n) if j != me) * rw,
+                      "records_sent": sum(c for j, c in enumerate(wire_sent) if j != me),
+                      "records_received": sum(c for j, c in enumerate(wire_recv) if j != me),
+                      "records_whole": sum(c for j, c in enumerate(rec_n) if j != me) * rw,
+                      "records_on_the_wire": "packed (classes + used words)" if compact else "whole",
                       "pool_sent": sum(c for j, c in enumerate(pool_counts) if j != me) * 4,
                       "pool_received": sum(c for j, c in enumerate(pool_n) if j != me) * 4})
-    del rec_back, pool_back
+    del pool_back
     ctx.score(want_per_read)
     return ctx
 
@@ -286,12 +318,17 @@ def partitioned_batch(owner_ctx, worker, cuts, K: int, batch, want_per_read: boo
         rec, pool = worker.group_slice(km_in[s], rd_in[s], int(n_in[s][0]), sink=ctx)   # (the slice's profile stays on this rank: the reduce sums the ranks)
         rec_out.append(rec.reshape(-1))
         pool_out.append(pool)
-    rec_back = all_to_all_arrays(rec_out)
+    # the records travel packed (partition.pack_records: the numpy statement of kasa_batch_records_pack's wire format)
+    rw_words = ctx.rec_words
+    wire_back = all_to_all_arrays([partition.pack_records(r.reshape(-1, rw_words), rw_words) for r in rec_out])
+    out_n = [int(starts[j + 1] - starts[j]) for j in range(world)]
+    rec_back = [partition.unpack_records(wire_back[j], out_n[j], rw_words).reshape(-1) for j in range(world)]
     pool_back = all_to_all_arrays(pool_out)
     if stats is not None:
         me = dist.get_rank()
         stats.update({"queries_sent": sum(int(km[starts[j]:starts[j + 1]].nbytes) for j in range(world) if j != me),
-                      "records_received": sum(int(rec_back[j].nbytes) for j in range(world) if j != me),
+                      "records_received": sum(int(wire_back[j].nbytes) for j in range(world) if j != me),
+                      "records_whole": sum(int(rec_back[j].nbytes) for j in range(world) if j != me),
                       "pool_received": sum(int(pool_back[j].nbytes) for j in range(world) if j != me)})
     parts = [(rec_back[j].reshape(-1, ctx.rec_words), pool_back[j]) for j in range(world)]
     rec, pool = partition.assemble_records(parts, starts)

@@ -1889,9 +1889,80 @@ static const char *formatEnding(Params::Fmt f)    // Compare.hpp:367-381
 // ---------------------------------------------------------------------------------------------------
 // main
 // ---------------------------------------------------------------------------------------------------
+// `kASA --parameters <file>`: the reference reads its whole command line from a YAML-like file instead (source/main.cpp:264-302,
+// source/utils/Utilities.hpp:1114-1400: `Key: value` per line, '#' comments, quotes dropped, booleans "true").  Here the keys that
+// concern `identify` become the flags they stand for and pass through the one parser below; keys of other modes are ignored
+// as the reference ignores them in this mode.
+static vector<string> argsFromYaml(const string &exe, const string &file)
+{
+    std::ifstream in(file);
+    if (!in) throw std::runtime_error("Config file not found!");                    // Utilities.hpp:1115-1117
+    auto strip = [](string v) {
+        string o; for (char c : v) if (c != '"') o += c;
+        size_t b = 0; while (b < o.size() && (o[b] == ' ' || o[b] == '\t')) ++b;
+        size_t e = o.size(); while (e > b && (o[e - 1] == ' ' || o[e - 1] == '\t' || o[e - 1] == '\r' || o[e - 1] == '\n')) --e;
+        return o.substr(b, e - b);
+    };
+    string mode = "identify", kH, kL, alphaFile, alphaIdx, line;
+    vector<string> rest;
+    auto flag = [&](const string &f, const string &v) { if (v == "true") rest.push_back(f); };
+    auto opt = [&](const string &f, const string &v) { if (!v.empty()) { rest.push_back(f); rest.push_back(v); } };
+    while (std::getline(in, line)) {
+        size_t b = 0; while (b < line.size() && (line[b] == ' ' || line[b] == '\t')) ++b;
+        if (b >= line.size() || line[b] == '#') continue;
+        const size_t colon = line.find(':', b);
+        if (colon == string::npos) continue;
+        const string key = strip(line.substr(b, colon - b)), val = strip(line.substr(colon + 1));
+        if (key == "Mode") mode = val;
+        else if (key == "Index") opt("-d", val);
+        else if (key == "ContentFile") opt("-c", val);
+        else if (key == "kHigh") kH = val;
+        else if (key == "kLow") kL = val;
+        else if (key == "NumberOfThreads") opt("-n", val == "-1" ? std::to_string(std::max(1u, std::thread::hardware_concurrency())) : val);
+        else if (key == "AvailableRAMinGB") opt("-m", val);
+        else if (key == "FilePathForTemporaryFiles") opt("-t", val);
+        else if (key == "CallIndex") opt("-x", val);
+        else if (key == "Verbose") flag("-v", val);
+        else if (key == "AlphabetFile") alphaFile = val;
+        else if (key == "AlphabetIndex") alphaIdx = val;
+        else if (key == "InputFileOrFolder") opt("-i", val);
+        else if (key == "PairedEnd-First") opt("-1", val);
+        else if (key == "PairedEnd-Second") opt("-2", val);
+        else if (key == "AlreadyTranslated") flag("-z", val);
+        else if (key == "One") flag("--one", val);
+        else if (key == "Three") flag("--three", val);
+        else if (key == "Six") flag("--six", val);
+        else if (key == "ProfileOutputfile") opt("-p", val);
+        else if (key == "ReadIDtoTaxIDOutputfile") opt("-q", val);
+        else if (key == "ReadIDtoTaxIDOutputFormat") { if (val == "json" || val == "jsonl" || val == "kraken" || val == "tsv") rest.push_back("--" + val); }
+        else if (key == "UseRAMOnly") flag("-r", val);
+        else if (key == "NumberOfTaxaPerRead") opt("-b", val);
+        else if (key == "UniqueKmersOnly") flag("-e", val);
+        else if (key == "ThresholdForScore") opt("--threshold", val);
+        else if (key == "PrintCoverage") flag("--coverage", val);
+        else if (key == "Filter") {                                                  // "clean contaminated"; "_ _" = none (Utilities.hpp:1326-1334)
+            std::stringstream ss(val); string f0, f1; ss >> f0 >> f1;
+            if (!f1.empty() && (f0 != "_" || f1 != "_")) { rest.push_back("--filter"); rest.push_back(f0); rest.push_back(f1); }
+        }
+        else if (key == "ErrorThreshold") opt("--errorThreshold", val);
+        else if (key == "Gzip") flag("--gzip", val);
+    }
+    vector<string> out = {exe, mode};
+    if (!kH.empty() && !kL.empty()) { out.push_back("-k"); out.push_back(kH); out.push_back(kL); }
+    else if (!kH.empty()) { out.push_back("--kH"); out.push_back(kH); }
+    else if (!kL.empty()) { out.push_back("--kL"); out.push_back(kL); }
+    if (!alphaFile.empty()) { out.push_back("-a"); out.push_back(alphaFile); out.push_back(alphaIdx.empty() ? "1" : alphaIdx); }
+    out.insert(out.end(), rest.begin(), rest.end());
+    return out;
+}
+
 static int run(int argc, char **argv)
 {
     vector<string> a(argv, argv + argc);
+    if (argc >= 3 && a[1] == "--parameters") {                   // source/main.cpp:264
+        a = argsFromYaml(a[0], a[2]);
+        argc = (int)a.size();
+    }
     std::cout << "OUT: kasa_identify (MI355X path of kASA identify)\nOUT: ";
     for (auto &s : a) std::cout << s << " ";
     std::cout << std::endl;

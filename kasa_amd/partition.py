@@ -109,12 +109,14 @@ class Worker:
 class LocalExchange:
     """All partitions in this process (one GPU): the reference implementation of the exchange, used by the tests."""
 
-    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0, device_resident: bool = False, K: int = None):
+    def __init__(self, parts, cuts, k_high=12, k_low=7, frames=3, device: int = 0, device_resident: bool = False, K: int = None, packed: bool = True):
         """parts: formats.Index objects, or capi.DeviceIndex objects that are on the device already (then K = letters per
         index k-mer must be given).  This is also how ONE device holds an index of more than 2^32 records (positions in an
         index are 32-bit, kasa_index_create refuses more): as several range partitions, every one an index of its own."""
         self.cuts = cuts
         self.device_resident = device_resident      # slices and records never leave HBM (kasa_batch_*_device)
+        self.packed = packed                        # records cross between worker and owner in the wire format (matched queries only, used words only)
+        self.wire_bytes = self.whole_bytes = 0      # of the last batch: bytes of records on the wire, bytes whole records would have taken
         given = len(parts) > 0 and isinstance(parts[0], capi.DeviceIndex)
         self.K = K if given else parts[0].K
         if self.K is None:
@@ -128,10 +130,28 @@ class LocalExchange:
         ctx.upload(batch.bases, batch.offsets, batch.seg_read, batch.n if batch.seg_read is not None else None)
         ctx.encode()
         ctx.sort_and_range(unique)
+        rw = ctx.rec_words
+        self.wire_bytes = self.whole_bytes = 0
         if self.device_resident:
             ptr, n, kb = ctx.queries_device()
             starts = ctx.slice_starts(self.cuts)
-            parts = [w.group_slice_device(ptr + int(starts[j]) * kb, int(starts[j + 1] - starts[j]), sink=ctx) for j, w in enumerate(self.workers)]
+            if not self.packed:
+                parts = [w.group_slice_device(ptr + int(starts[j]) * kb, int(starts[j + 1] - starts[j]), sink=ctx) for j, w in enumerate(self.workers)]
+            else:
+                # every slice's records go over the "wire" packed (kasa_batch_records_pack on the worker, _unpack on the owner,
+                # into the inbox the whole records would have been received at)
+                inbox, parts, at = ctx.records_inbox(n * rw), [], 0
+                for j, w in enumerate(self.workers):
+                    nq = int(starts[j + 1] - starts[j])
+                    rp, nrw, pp, npw = w.group_slice_device(ptr + int(starts[j]) * kb, nq, sink=ctx)
+                    nb = w.ctx.records_pack_size(rp, nq)
+                    buf = capi.DeviceBuffer(nb, ctx.dix.device)
+                    w.ctx.records_pack(rp, nq, buf.ptr, nb)
+                    ctx.records_unpack(buf.ptr, nb, nq, inbox + at * rw * 4)
+                    buf.close()
+                    parts.append((inbox + at * rw * 4, nq * rw, pp, npw))
+                    at += nq
+                    self.wire_bytes += nb; self.whole_bytes += nq * rw * 4
             ctx.records_import_device(parts)
             ctx.score(want_per_read)
             return ctx
@@ -139,6 +159,14 @@ class LocalExchange:
         starts = slice_starts(km, self.cuts, self.K)
         parts = [w.group_slice(km[starts[j]:starts[j + 1]], rd[starts[j]:starts[j + 1]], ctx.n_reads, sink=ctx)
                  for j, w in enumerate(self.workers)]
+        if self.packed:                                             # (the numpy statement of the same wire format)
+            packed = []
+            for j, (rec_j, pool_j) in enumerate(parts):
+                nq = int(starts[j + 1] - starts[j])
+                wire = pack_records(np.asarray(rec_j).reshape(-1, rw), rw)
+                packed.append((unpack_records(wire, nq, rw), pool_j))
+                self.wire_bytes += int(wire.nbytes); self.whole_bytes += nq * rw * 4
+            parts = packed
         rec, pool = assemble_records(parts, starts)
         ctx.records_import(rec, pool)
         ctx.score(want_per_read)
@@ -150,3 +178,54 @@ class LocalExchange:
             w.close()
         for d in self.dix:
             d.close()
+
+
+# ---- the wire format of exported records (kasa_batch_records_pack / _unpack in the C ABI; this is its statement in numpy, used
+# by the host-staged exchange and as the cross-check of the device kernels): one byte of classes per four records (2 bits
+# each: 0 = unmatched; 1, 2, 3 = words [1 .. n] of the record, n = 4 / 6 / 7 for 8-word records (at most one / at most three /
+# more segments), 9 / 11 / 15 for 16-word ones (at most two / at most four / more)), padded to 16 bytes, then the words.
+_WIRE_WORDS = {8: np.array([0, 4, 6, 7], dtype=np.int64), 16: np.array([0, 9, 11, 15], dtype=np.int64)}
+
+
+def _wire_classes(rec: np.ndarray, rw: int) -> np.ndarray:
+    d = rec[:, 2] & 31
+    n = (rec[:, 3] & 255) if rw == 8 else rec[:, 3]
+    lo, hi = (1, 3) if rw == 8 else (2, 4)
+    cls = np.where(n <= lo, 1, np.where(n <= hi, 2, 3)).astype(np.uint8)
+    cls[d == 0] = 0
+    return cls
+
+
+def pack_records(rec: np.ndarray, rw: int) -> np.ndarray:
+    """rec[n, rw] (uint32, slice order) -> the bytes on the wire (uint8)."""
+    rec = np.ascontiguousarray(rec, dtype=np.uint32).reshape(-1, rw)
+    n = rec.shape[0]
+    cls = _wire_classes(rec, rw)
+    pad = np.zeros((-n) % 4, dtype=np.uint8)
+    c4 = np.concatenate((cls, pad)).reshape(-1, 4)
+    cbytes = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8)
+    cb = np.zeros(((n + 3) // 4 + 15) // 16 * 16, dtype=np.uint8)
+    cb[:cbytes.shape[0]] = cbytes
+    nw = _WIRE_WORDS[rw][cls]
+    keep = np.arange(rw - 1)[None, :] < nw[:, None]                      # words [1 .. nw] of every record, row-major
+    words = rec[:, 1:][keep]
+    return np.concatenate((cb, words.astype(np.uint32).view(np.uint8)))
+
+
+def unpack_records(wire: np.ndarray, n: int, rw: int) -> np.ndarray:
+    """The inverse: rec[n, rw] with word [0] = the record's place in the slice, unused words zero."""
+    wire = np.ascontiguousarray(wire, dtype=np.uint8)
+    nb = ((n + 3) // 4 + 15) // 16 * 16
+    cb = wire[:nb]
+    cls = ((cb[:, None] >> (2 * np.arange(4, dtype=np.uint8))[None, :]) & 3).reshape(-1)[:n]
+    nw = _WIRE_WORDS[rw][cls]
+    words = wire[nb:].view(np.uint32)
+    if int(nw.sum()) != words.shape[0]:
+        raise ValueError("unpack_records: the classes announce %d words, the buffer holds %d" % (int(nw.sum()), words.shape[0]))
+    rec = np.zeros((n, rw), dtype=np.uint32)
+    rec[:, 0] = np.arange(n, dtype=np.uint32)
+    keep = np.arange(rw - 1)[None, :] < nw[:, None]
+    body = rec[:, 1:]
+    body[keep] = words
+    rec[:, 1:] = body
+    return rec

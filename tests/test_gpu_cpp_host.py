@@ -42,6 +42,44 @@ def test_cpp_host_byte_identical(case, text, tmp_path):
     assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
 
 
+def test_cpp_host_parameters_file(tmp_path):
+    """`--parameters <yaml>` (source/main.cpp:264-302, Utilities.hpp:1114-1400): the reference's config file instead of a command
+    line -- the same bytes as the golden command line it stands for (out_six.jsonl: --six --jsonl -b 3)."""
+    exe = hipbuild.build_host()
+    case = next(c for c in PAIRS if unpack(c)[5] == 6 and unpack(c)[2] == "jsonl" and not unpack(c)[9] and unpack(c)[8] == "idx")
+    stem, infile, fmt, kh, kl, frames, thr, beasts, idx, uniq = unpack(case)
+    d = os.path.join(helpers.GOLDEN, "pairs")
+    out, prof = str(tmp_path / "out"), str(tmp_path / "prof.csv")
+    y = tmp_path / "config.yaml"
+    y.write_text(f"""# kASA config
+Mode: identify
+Index: "{os.path.join(d, idx)}"
+ContentFile: {os.path.join(d, 'content.txt')}
+kHigh: {kh}
+kLow: {kl}
+NumberOfThreads: 1
+AvailableRAMinGB: 4
+FilePathForTemporaryFiles: {tmp_path}
+InputFileOrFolder: {os.path.join(d, infile)}
+Six: true
+Three: false
+ProfileOutputfile: {prof}
+ReadIDtoTaxIDOutputfile: {out}
+ReadIDtoTaxIDOutputFormat: jsonl
+NumberOfTaxaPerRead: {beasts}
+UniqueKmersOnly: false
+ThresholdForScore: {thr if thr else 0}
+Filter: _ _
+ShrinkingStrategy: 2
+""")
+    r = subprocess.run([exe, "--parameters", str(y)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == _read(os.path.join(d, "out_" + stem))
+    assert _read(prof) == _read(os.path.join(d, "prof_" + stem.rsplit(".", 1)[0] + ".csv"))
+    r = subprocess.run([exe, "--parameters", str(tmp_path / "nope.yaml")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == 1 and "Config file not found" in r.stderr
+
+
 def test_cpp_host_errors_like_the_reference(tmp_path):
     exe = hipbuild.build_host()
     d = os.path.join(helpers.GOLDEN, "pairs")

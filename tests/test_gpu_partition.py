@@ -118,6 +118,55 @@ dist.destroy_process_group()
 """
 
 
+@pytest.mark.parametrize("case", [(12, 7, 12), (25, 7, 25), (12, 9, 25)], ids=["narrow_records", "wide_records", "narrow_records_of_a_128_bit_index"])
+def test_records_on_the_wire(case):
+    """The return leg of the exchange: kasa_batch_records_pack writes exactly the bytes partition.pack_records (the wire format's
+    statement in numpy) makes of the same records -- a byte of classes per four queries, then the words a record really uses --
+    kasa_batch_records_unpack gives the records back with their unused words zero, and a batch whose records crossed that way
+    (LocalExchange, the default) scores bit for bit like one whose whole records did.  SURVEY 8(e): 12-20 bytes per query."""
+    kh, kl, K = case
+    ix, batch = synthetic_world(61, 10, 4000, 600, K=K)
+    parts, cuts = partition.split_index(ix, 3)
+    dix = capi.DeviceIndex(parts[1])
+    owner = capi.Context(dix, kh, kl, 3)
+    owner.upload(batch.bases, batch.offsets)
+    owner.encode()
+    owner.sort_and_range()
+    ptr, n, kb = owner.queries_device()
+    starts = owner.slice_starts(cuts)
+    w = partition.Worker(dix, kh, kl, 3)
+    nq = int(starts[2] - starts[1])
+    rp, nrw, pp, npw = w.group_slice_device(ptr + int(starts[1]) * kb, nq)
+    rw = owner.rec_words
+    assert nrw == nq * rw and nq > 1000
+    rec, _ = w.ctx.records()
+    rec = np.asarray(rec).reshape(-1, rw)
+    want = partition.pack_records(rec, rw)
+    nb = w.ctx.records_pack_size(rp, nq)
+    assert nb == want.nbytes
+    buf = capi.DeviceBuffer(nb)
+    w.ctx.records_pack(rp, nq, buf.ptr, nb)
+    assert np.array_equal(buf.read(), want)
+    back = capi.DeviceBuffer(nq * rw * 4)
+    owner.records_unpack(buf.ptr, nb, nq, back.ptr)
+    assert np.array_equal(back.read().view(np.uint32).reshape(-1, rw), partition.unpack_records(want, nq, rw))
+    matched = (rec[:, 2] & 31) != 0
+    assert nb < 0.8 * nq * rw * 4 and 0.5 < matched.mean() < 1.0, (nb, nq * rw * 4, matched.mean())
+    with pytest.raises(RuntimeError):
+        owner.records_unpack(buf.ptr, nb - 4, nq, back.ptr)               # (the classes announce more words than the buffer holds)
+    buf.close(); back.close(); w.close(); owner.close(); dix.close()
+    (off, tax, sc), limbs = _whole(ix, batch, kh, kl, 3)
+    for resident in (False, True):
+        for packed in (True, False):
+            ex = partition.LocalExchange(parts, cuts, kh, kl, 3, device_resident=resident, packed=packed)
+            ctx = ex.run_batch(batch)
+            o2, t2, s2 = ctx.scores()
+            assert np.array_equal(off, o2) and np.array_equal(tax, t2) and np.array_equal(sc.view(np.uint32), s2.view(np.uint32))
+            assert np.array_equal(limbs, ctx.profile_limbs())
+            assert (ex.wire_bytes < 0.8 * ex.whole_bytes) if packed else ex.wire_bytes == 0
+            ex.close()
+
+
 def test_device_resident_exchange_over_rccl(tmp_path):
     """kasa_amd/dist.py:partitioned_batch on the `nccl` backend (RCCL): the slices and the records travel as device
     tensors through all_to_all_single and the kasa_batch_*_device entry points -- Context.queries()/records() are

@@ -258,3 +258,29 @@ def test_library_does_not_link_rccl():
         pytest.skip("libkasa_hip.so is not built")
     out = subprocess.run(["readelf", "-d", capi.SO_PATH], capture_output=True, text=True).stdout
     assert "librccl" not in out and "libamdhip64.so" in out
+
+
+def test_wire_format_of_exported_records_round_trips():
+    """partition.pack_records / unpack_records (the numpy statement of kasa_batch_records_pack's wire format): random records of
+    both widths come back with word [0] = their place and their unused words zero; an unmatched record costs two bits."""
+    import numpy as np
+    from kasa_amd import partition
+    rng = np.random.default_rng(5)
+    for rw in (8, 16):
+        for n in (0, 1, 3, 4, 5, 63, 64, 65, 1003):
+            rec = rng.integers(0, 2 ** 32, size=(n, rw), dtype=np.uint64).astype(np.uint32)
+            rec[:, 0] = np.arange(n, dtype=np.uint32)
+            d = rng.integers(0, 13, n).astype(np.uint32)
+            rec[:, 2] = (rec[:, 2] & ~np.uint32(31)) | d
+            ns = rng.integers(0, 12, n).astype(np.uint32)
+            rec[:, 3] = ((rec[:, 3] & ~np.uint32(255)) | ns) if rw == 8 else ns
+            wire = partition.pack_records(rec, rw)
+            back = partition.unpack_records(wire, n, rw)
+            nw = partition._WIRE_WORDS[rw][partition._wire_classes(rec, rw)] if n else np.zeros(0, dtype=np.int64)
+            want = rec.copy()
+            for i in range(n):
+                want[i, 1 + nw[i]:] = 0
+            assert np.array_equal(back, want)
+            assert wire.nbytes == ((n + 3) // 4 + 15) // 16 * 16 + 4 * int(nw.sum())
+    none = np.zeros((100, 8), dtype=np.uint32)
+    assert partition.pack_records(none, 8).nbytes == 32
