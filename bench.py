@@ -741,6 +741,13 @@ def long_reads_leg(args, capi, synth, torch, device, read_len=10_000):
 def make_comm(rank, world, share, torch, dist, kdist):
     """The C ABI's own RCCL communicator for the profile reduce (N > 1) -> (comm, ranks RCCL reports, how the reduce runs)."""
     comm, rccl_ranks, reduce_how = 0, None, None
+    if world > 1:                                        # every rank says which runtimes it runs on (a bad curve starts with a mismatch somewhere)
+        try:
+            from kasa_amd import capi
+            ri = capi.runtime_info()
+            log(f"[rank {rank}] hip_runtime {ri.get('hip_runtime')} (built with {ri.get('hip_built')}), rccl_runtime {ri.get('rccl_runtime')}, from {ri.get('runtime_from')}")
+        except Exception as ex:
+            log(f"[rank {rank}] runtime info: {ex}")
     if world > 1 and not share:
         try:
             comm, rccl_ranks = kdist.rccl_communicator(rank, world)

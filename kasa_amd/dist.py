@@ -88,7 +88,20 @@ def rccl_communicator(rank: int, world: int):
         dist.broadcast_object_list(box, src=0)
     C.memmove(C.byref(uid), box[0], 128)
     comm = C.c_void_p()
-    rc = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    # ncclCommInitRank is a collective: a rank that never arrives leaves the others waiting for ever.  It runs on a helper
+    # thread with a deadline (KASA_RCCL_INIT_TIMEOUT seconds, default 180): a caller that gets the exception falls back to
+    # another reduce or ends the run -- it does not hang.
+    import threading
+    res = {}
+
+    def init():
+        res["rc"] = L.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("KASA_RCCL_INIT_TIMEOUT", "180")))
+    if th.is_alive():
+        raise TimeoutError(f"ncclCommInitRank did not return within the deadline on rank {rank} of {world}")
+    rc = res.get("rc", -1)
     if rc != 0:
         raise RuntimeError("ncclCommInitRank: " + L.ncclGetErrorString(rc).decode())
     n = C.c_int(0)

@@ -9,7 +9,7 @@
 """
 import csv, glob, json, os, re, subprocess, sys, collections
 
-tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "r06"
 WIDE = "--wide" in sys.argv          # the 128-bit configuration (C3): its own kernel summary and counter passes, files <tag>_*_wide.*
 CROWDED = "--crowded" in sys.argv    # the crowded-index workload (`tertiary` of the bench line): files <tag>_*_crowded.*
 SFX = "_wide" if WIDE else ("_crowded" if CROWDED else "")
@@ -17,7 +17,7 @@ WARGS = ["--wide"] if WIDE else (["--crowded", "--warmup", "2"] if CROWDED else 
 out = "gpurun_out/profiles"
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
-KERNELS = "lookup_tile_kernel|group_kernel|group2_kernel|score_dense_kernel|score_kernel|profile_group_accum_kernel|profile_reduce_kernel|bucket_rank64_kernel|score_main_kernel|score_other_flat_kernel|score_other_flat16_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|profile_group_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|bucket_rank_kernel|row_copy_kernel"
+KERNELS = "esr_emit_kernel|esr_chain_big_kernel|lookup_tile_kernel|group_kernel|group2_kernel|score_dense_kernel|score_kernel|profile_group_accum_kernel|profile_reduce_kernel|bucket_rank64_kernel|score_main_kernel|score_other_flat_kernel|score_other_flat16_kernel|score_other_kernel|row_merge_bitmap_kernel|profile_table_kernel|profile_group_table_kernel|encode_kernel|pass_kernel|hist_kernel|bucket_rank32_kernel|bucket_rank_kernel|row_copy_kernel"
 sys.path.insert(0, os.getcwd())
 import bench as _bench
 SHA = _bench.source_sha16()
@@ -46,8 +46,9 @@ else:
           w.writerow([r["Name"][:200], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
   md = subprocess.run([sys.executable, "tools/kernel_stats.py", d, "40"], stdout=subprocess.PIPE, text=True).stdout
   open(os.path.join(out, tag + "_kernel_stats_bench_10M" + SFX + ".md"), "w").write(
-      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-secondary --no-tertiary --no-pmc" + (" --wide" if WIDE else "") + "` on one MI355X\n"
-      "(10 M reads x 150 bp, 4.2e8-record " + ("128-bit index, -k 25 7" if WIDE else "64-bit index, -k 12 7") + "; kernel sources " + SHA + ").  The run holds the index build (one call of encode / the sort of its own) plus 1 warm-up\n"
+      "Source: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-secondary --no-tertiary --no-quaternary --no-pmc" + "".join(" " + x for x in WARGS) + "` on one MI355X\n" +
+      "(" + ("2 M reads x 150 bp, crowded 4.2e8-record 64-bit index (clades of 50-200 taxa sharing conserved genes), -k 12 7" if CROWDED else
+             "10 M reads x 150 bp, 4.2e8-record " + ("128-bit index, -k 25 7" if WIDE else "64-bit index, -k 12 7")) + "; kernel sources " + SHA + ").  The run holds the index build (one call of encode / the sort of its own) plus " + ("2 warm-up\n" if CROWDED else "1 warm-up\n") +
       "and 3 timed steps.  The warm-up step launches group / score_main / score_other twice where a first attempt only sizes a buffer (it stops early\n"
       "and is repeated with the capacity it asked for): such a short call lowers the average here below the per-launch average of bench.py's HIP\n"
       "events.  Full names: the .csv next to this file.\n\n" + md)
@@ -65,8 +66,8 @@ for i, p in enumerate(passes):
             name = re.sub(r"[<(].*", "", row["Kernel_Name"]).replace("void ", "")
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {"source_sha16": SHA,
-       "command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-secondary --no-tertiary --no-pmc" + (" --wide" if WIDE else ""),
-       "workload": "10M x 150bp reads vs 419951000-record index (bench.py default); per kernel the LARGEST dispatch (the 1.3e9-query batch; the index build "
+       "command": "rocprofv3 --pmc <one group per run> --kernel-include-regex '" + KERNELS + "' -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-secondary --no-tertiary --no-quaternary --no-pmc" + "".join(" " + x for x in WARGS),
+       "workload": ("2M x 150bp reads vs the crowded 4.2e8-record index (bench.py --crowded)" if CROWDED else "10M x 150bp reads vs 419951000-record index (bench.py default)") + "; per kernel the LARGEST dispatch (the 1.3e9-query batch; the index build "
                    "launches encode/lookup once on its own input)",
        "correction": "hbm_bytes_per_launch = FETCH_SIZE[KB] x 1024 x 2 (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md section HBM; exact for "
                      "16-B-per-lane streaming reads, uncalibrated for narrower ones) + WRITE_SIZE[KB] x 1024"}
