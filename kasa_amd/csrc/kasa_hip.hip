@@ -885,7 +885,7 @@ __global__ void enc_long_list_kernel(const uint64_t *__restrict__ seqOff, int64_
 #define LDS_WAVE_SYNC_ENC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 // RM: capacity of the per-read ranking (k-mers of a read): 512, or 192 when no read of the batch has more (150-bp reads in
 // three frames have 130) -- a third of the LDS and three ranking rounds instead of eight, so more wavefronts are resident.
-template <class Key, int RM = ENC_RANK_MAX>
+template <class Key, int RM = ENC_RANK_MAX, bool LONGK = false>        // LONGK: the second launch over the listed long sequences
 __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kernel(
     const uint8_t *__restrict__ bases, const int64_t *__restrict__ baseOff, const uint64_t *__restrict__ kmerOff,
     const uint32_t *__restrict__ seqRead, int64_t nReads, int kLow, int strands, int mode, const uint8_t *__restrict__ lutG,
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kern
     const int ls = (mode == ENC_PROTEIN) ? 1 : 3;
     const int tail = (KLETTERS - 1) * ls + ((mode == ENC_PROTEIN) ? 1 : 3);   // bases of the last window
     const int chunk = (mode == ENC_ONE) ? ENC_CHUNK / 3 : ENC_CHUNK;
-    const bool longK = longList != nullptr;                               // (uniform)
+    constexpr bool longK = LONGK;
     const int64_t waveId = (int64_t)blockIdx.x * ENC_WAVES + wv;
     const int64_t nWork = longK ? (int64_t)*nLongPtr : nReads;
     for (int64_t wi = longK ? 0 : waveId; wi < nWork; wi += longK ? 1 : wavesTotal) {
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, RM <= 192 ? 6 : 1) void encode_kern
         enc_geometry(mode, KLETTERS, kLow, raw, body, L, cnt);
         if (cnt == 0) continue;
         const uint64_t o0 = kmerOff[r];
-        if (!longK && kmerOff[r + 1] - o0 >= longMin) continue;           // (the second launch's)
+        if (!longK && longMin != ~0ull && kmerOff[r + 1] - o0 >= longMin) continue;   // (the second launch's)
         const uint32_t rid = seqRead ? seqRead[r] : (uint32_t)r;          // paired-end: both mates carry the pair's id
         for (int s = 0; s < strands; ++s) {
             for (int64_t w0 = longK ? waveId * chunk : 0; w0 < cnt; w0 += longK ? wavesTotal * chunk : chunk) {
@@ -1076,11 +1076,11 @@ extern "C" int kasa_batch_encode(kasa_ctx *c, uint64_t *nKmers)
             enc_long_list_kernel<<<blocks_for((uint64_t)c->nSeq, 256), 256, 0, c->stream>>>(c->seqOff.as<uint64_t>(), c->nSeq, longMin, list, nLong);
             const unsigned lblocks = 256 * 8;
             if (c->ix->wide)
-                encode_kernel<key128><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
+                encode_kernel<key128, ENC_RANK_MAX, true><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                     c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                     c->lut.as<uint8_t>(), c->qKmerA.as<key128>(), c->qReadA.as<uint32_t>(), 0, list, nLong, longMin);
             else
-                encode_kernel<uint64_t><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
+                encode_kernel<uint64_t, ENC_RANK_MAX, true><<<lblocks, 64 * ENC_WAVES, 0, c->stream>>>(c->basesPtr, c->baseOff.as<int64_t>(),
                     c->seqOff.as<uint64_t>(), c->haveSeqRead ? c->seqRead.as<uint32_t>() : nullptr, c->nSeq, c->kLow, c->strands(), c->enc_mode(),
                     c->lut.as<uint8_t>(), c->qKmerA.as<uint64_t>(), c->qReadA.as<uint32_t>(), 0, list, nLong, longMin);
             HIPCHK(hipGetLastError());
@@ -3449,6 +3449,7 @@ __device__ __forceinline__ float event_score(const EventTables &T, int k, uint32
 struct ScoreArgs {
     const uint32_t *rec; const uint64_t *kmerOff; const uint32_t *pool;   // records by slot; slots of read r: kmerOff[r] .. kmerOff[r+1]
     uint32_t rowPerQuery;                        // fast kernels: a read's staging row may hold max(RMAX, rowPerQuery * its k-mers) records (0: RMAX) -- long reads have long rows
+    uint32_t recQS;                              // log2 of the 16-byte words from one record to the next (a shift, not a multiply, in the hot loops)
     uint32_t recCW;                              // words from one record to the next (kasa_ctx::recCW: RW, or 16 for narrow records in 64-byte cells)
     uint32_t nReads; int kHigh, kLow; uint32_t nTaxa;
     float *scratch;                              // per block: nTaxa floats, all zero between reads
@@ -4165,7 +4166,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
     }
     __syncthreads();
     const int kPromote = (nK >= 3) ? A.kLow + 2 : A.kLow;           // shallow levels collect chance matches
-    const size_t CQ = A.recCW / 4u;                                  // 16-byte words per cell (narrow records may lie in 64-byte cells)
+    const uint32_t QS = A.recQS;                                     // log2(16-byte words per cell): narrow records may lie in 64-byte cells
     for (;;) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(A.workCursor, 64u);          // persistent wavefronts take 64 reads at a time
@@ -4187,13 +4188,13 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
             // a LONG read has a long row because it has many k-mers, about one chance match of a short prefix each -- the row
             // merge streams such a row (row_merge_bitmap_kernel's LONG form); a row that is long because the taxon lists are
             // (a crowded index) still goes to score_dense_kernel
-            rowCap = max((uint32_t)RMAX, (uint32_t)min((unsigned long long)A.rowPerQuery * cnt0, 0x0FFFFFFFull));
+            if ((unsigned long long)A.rowPerQuery * cnt0 >= 2ull * RMAX) rowCap = (uint32_t)min((unsigned long long)A.rowPerQuery * cnt0, 0x0FFFFFFFull);
             if (cnt0 > (FB == 16 ? 60000u : 255u)) { fb = true; atomicAdd(&A.why[0], 1u); }   // the counters' fields
-            rp0 = reinterpret_cast<const uint4 *>(A.rec) + o0 * CQ;
+            rp0 = reinterpret_cast<const uint4 *>(A.rec) + (o0 << QS);
             // ---- A. the taxa that get the register slots: the first two with a deep match (segments come in descending
             // order of their last level: the search of a query ends at the first shallow one)
             for (uint32_t j = 0; j < cnt0 && na < FTA && !fb; ++j) {
-                const uint4 *q4 = rp0 + (size_t)j * CQ;
+                const uint4 *q4 = rp0 + ((size_t)j << QS);
                 const uint4 h = q4[0];
                 if ((int)(h.z & 31u) < kPromote) continue;                 // no segment reaches deeper than d (unmatched: d = 0)
                 uint32_t sg[RT::INL];
@@ -4227,7 +4228,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
         // this one is replayed.
         constexpr uint32_t LN = 32u / (uint32_t)RW, LW = LN * (RW / 4);        // records, 16-byte words of a line
         const uint32_t ph = (uint32_t)(o0 & (uint64_t)(LN - 1u));
-        const uint4 *lp0 = rp0 - (size_t)ph * CQ;
+        const uint4 *lp0 = rp0 - ((size_t)ph << QS);
         const uint32_t kEnd = (active && !fb) ? cnt0 + ph : 0u;               // this lane's steps: ph .. kEnd - 1
         uint32_t maxCnt = kEnd;
         for (int off = 32; off; off >>= 1) maxCnt = max(maxCnt, (uint32_t)__shfl_xor((int)maxCnt, off));
@@ -4241,7 +4242,7 @@ __global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void 
                     const bool mineRec = !fb && k >= ph && k < kEnd;
 #pragma unroll
                     for (uint32_t i = 0; i < (uint32_t)(RW / 4); ++i)
-                        nxt[r2 * (RW / 4) + i] = mineRec ? lp0[(size_t)k * CQ + i] : make_uint4(0, 0, 0, 0);
+                        nxt[r2 * (RW / 4) + i] = mineRec ? lp0[((size_t)k << QS) + i] : make_uint4(0, 0, 0, 0);
                 }
             };
             if (PF) loadLine(0);
@@ -4630,8 +4631,8 @@ __global__ __launch_bounds__(256, 8) void score_other_flat_kernel(ScoreArgs A)
         uint64_t readStart = 0;
         uint4 mo = make_uint4(0, 0, 0, 0);
         if (inRange) {
-            cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u)];
-            cur[1] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot * (A.recCW / 4u) + 1];
+            cur[0] = reinterpret_cast<const uint4 *>(A.rec)[(size_t)slot << A.recQS];
+            cur[1] = reinterpret_cast<const uint4 *>(A.rec)[((size_t)slot << A.recQS) + 1];
             r = (uint32_t)((double)slot * readsPerSlot);                       // reads are mostly equally long: the guess is right, else search
             if (r >= A.nReads) r = A.nReads - 1u;
             readStart = A.kmerOff[r];
@@ -5467,12 +5468,17 @@ static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, u
     const uint32_t grid = nTiles;
     if (c->ix->wide) group2_kernel<key128, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
     else if (c->nK == 6) {                                                                                // the default -k 12 7
+        // (timing variants of the kernel -- template parameter VAR: 1 straight-line key cutting, 2 a barrier before the record
+        // stores, 4 no cursors -- are instantiated only in experiment builds: -DKASA_G2_VARIANTS; each is 100 KB of code object)
+#ifdef KASA_G2_VARIANTS
         static const int var = getenv("KASA_G2_VAR") ? atoi(getenv("KASA_G2_VAR")) : 0;
         if (var == 1) group2_kernel<uint64_t, 6, 1><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else if (var == 2) group2_kernel<uint64_t, 6, 2><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else if (var == 3) group2_kernel<uint64_t, 6, 3><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
         else if (var == 4) group2_kernel<uint64_t, 6, 4><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
-        else group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
+        else
+#endif
+        group2_kernel<uint64_t, 6><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
     }
     else group2_kernel<uint64_t, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));
 #undef KASA_GROUP2_ARGS
@@ -5965,7 +5971,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
         HIPCHK(hipMemsetAsync(stCursor, 0, 8, c->stream));             // staging cursor
         HIPCHK(hipMemsetAsync(keyCursor, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->rowLen.p, 0, (size_t)nReads * 4, c->stream));
-        A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.kmerOff = c->kmerOff.as<uint64_t>();
+        A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.recQS = c->recCW == 8u ? 1u : 2u; A.kmerOff = c->kmerOff.as<uint64_t>();
         // long rows for long reads: the streaming row merge keeps a slot per taxon in LDS (up to 4096 taxa), the bitmap merge must be the one in use (test tap 4: the sorting merge)
         A.rowPerQuery = (nTaxa <= 4096u && !(c->debugFlags & 4) && !(getenv("KASA_NO_LONG_ROWS") && atoi(getenv("KASA_NO_LONG_ROWS")))) ? 8u : 0u;   // (KASA_NO_LONG_ROWS=1: round 5's limit, tests)
         A.pool = c->pool.as<uint32_t>(); A.nReads = nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nTaxa = nTaxa;
@@ -6228,7 +6234,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             }
             row_merge_bitmap_kernel<RMAX, BM_WORDS><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                 c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, mLo, PL);
-            if (A.rowPerQuery && c->maxCnt > (uint32_t)RMAX / A.rowPerQuery) {   // long reads' rows (beyond RMAX records): streamed, slots in LDS
+            if (A.rowPerQuery && (uint64_t)c->maxCnt * A.rowPerQuery >= 2ull * RMAX) {   // long reads' rows (beyond RMAX records): streamed, slots in LDS
                 if (nTaxa <= 2048u)
                     row_merge_bitmap_kernel<2048, 64, true><<<std::min<uint32_t>(nReads, 256u * 16u), 64, 0, c->stream>>>(c->rowPos.as<uint32_t>(),
                         c->rowLen.as<uint32_t>(), c->rowKey.as<uint32_t>(), nReads, c->st.as<uint2>(), noKeys, c->kHigh, nTaxa, (uint32_t)RMAX, PL);
@@ -7847,7 +7853,7 @@ extern "C" int kasa_debug_record_stats(kasa_ctx *c, uint64_t *out32)
     HIPCHK(hipMemsetAsync(tmp.p, 0, 32 * 8, c->stream));
     ScoreArgs A;
     memset(&A, 0, sizeof(A));
-    A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.rowPerQuery = 0u; A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
+    A.rec = c->rec.as<uint32_t>(); A.recCW = c->recCW; A.recQS = c->recCW == 8u ? 1u : 2u; A.rowPerQuery = 0u; A.kmerOff = c->kmerOff.as<uint64_t>(); A.pool = c->pool.as<uint32_t>();
     A.nReads = (uint32_t)c->nReads; A.kHigh = c->kHigh; A.kLow = c->kLow; A.nQ = (uint32_t)c->nQ; A.mainOut = c->fastScratch.as<uint32_t>();
     record_stats_kernel<<<blocks_for(c->nQ, 256), 256, 0, c->stream>>>(A, tmp.as<unsigned long long>());
     HIPCHK(hipGetLastError());

@@ -318,9 +318,9 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
             int rb = 0;
             while ((1u << rb) < w1 - w0) ++rb;
             const unsigned endBit = (unsigned)(37 + taxBits + rb);
-            HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<float>(), c->esrValB.as<float>(), (size_t)E, 0u, endBit, c->stream));
+            HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<uint32_t>(), c->esrValB.as<uint32_t>(), (size_t)E, 0u, endBit, c->stream));   // (the addends travel as 32-bit words: the query sort's fallback is the same instantiation of the library's sort)
             if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
-            HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<float>(), c->esrValB.as<float>(), (size_t)E, 0u, endBit, c->stream));
+            HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<uint32_t>(), c->esrValB.as<uint32_t>(), (size_t)E, 0u, endBit, c->stream));   // (the addends travel as 32-bit words: the query sort's fallback is the same instantiation of the library's sort)
             // chains: heads -> ranks (a running sum, in the dead key buffer) -> starts
             const uint32_t n = (uint32_t)E;
             uint32_t *head = c->esrKeyA.as<uint32_t>(), *headRank = head + ((size_t)n + 16);

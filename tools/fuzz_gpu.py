@@ -33,7 +33,7 @@ def fuzz_text(seed):
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 480.0
-CYCLE = [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192, 1 | 16384 | 8388608]
+CYCLE = [0, 1, 2, 4, 262144, 262144 | 1, 2048, 1 | 8192, 1 | 16384 | 8388608, 1 | 1073741824, 1073741824, 134217728]   # (1073741824: sorted-event replay; 134217728: 64-byte cells)
 if os.environ.get("FUZZ_NO_THIRD"):
     CYCLE = CYCLE[:-1]
 import faulthandler

@@ -4,7 +4,7 @@ tools/make_profiles.py stored) so that the prose never drifts from the committed
 import json, os, re, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 d = json.load(open(os.path.join(root, "profiles", tag + "_bench_1gpu.json")))
 K, st, e, sec, cb = d["kernels"], d["stage_ms_per_step"], d["e2e"], d["secondary"], d["cpu_baseline"]
 ter = d.get("tertiary", {})
@@ -31,6 +31,23 @@ def krow(label, k, note):
 
 
 tb = roof.get("third_bound") or {}
+qua = d.get("quaternary") or {}
+
+
+def quaternary_rows():
+    out = ""
+    names = {"reads_10kb": "long reads (`quaternary`): 100 000 × 10 kb reads, the same index", "contig_different_genomes": "ONE 9.6 Mbp contig, 32 different genomes behind each other (`quaternary`)",
+             "contig_one_genome_32_times": "ONE 9.6 Mbp contig, one genome 32 times over: a 5e7-addend float chain (`quaternary`)"}
+    prev = {"reads_10kb": "not measured before", "contig_different_genomes": "round 5: 0.26 M k-mers/s, 37 s", "contig_one_genome_32_times": "round 5: 0.35 M k-mers/s, 27 s"}
+    for k, label in names.items():
+        v = qua.get(k)
+        if not isinstance(v, dict) or "kmers_per_s" not in v:
+            continue
+        sm = v["stage_ms_per_step"]
+        out += (f"| {label} | {v['kmers_per_s'] / 1e6:.0f} M k-mers/s ({prev[k]}) | {v['ms_per_step']:.0f} | {sm['encode']:.0f} / {sm['sort']:.0f} / {sm['lookup']:.0f} / {sm['group'] + sm.get('regroup', 0):.0f} / {sm['score']:.0f}; "
+                f"{v['general_reads']} reads on the general kernel, {v['dense_reads']} on `score_dense_kernel`, {v['replay_reads']} replayed from {v['replay_events'] / 1e6:.0f} M sorted events |\n")
+    return out
+
 TK = ter.get("kernels", {}) if ter else {}
 
 
@@ -40,17 +57,18 @@ def kms(table, name):
 
 
 measured = (
-    f"Round 5, one MI355X (`profiles/{tag}_bench_1gpu.json`, `{tag}_kernel_stats_bench_10M*.*`, `{tag}_kernel_pmc*.json`; the scatter floor: `r04_scatter_probe.json`):\n\n"
+    f"Round 6, one MI355X (`profiles/{tag}_bench_1gpu.json`, `{tag}_kernel_stats_bench_10M*.*`, `{tag}_kernel_pmc*.json`; the scatter floor: `r04_scatter_probe.json`, full cells: `r06_scatter_probe.json`):\n\n"
     "| config | reads/s | ms per batch | stages (ms): encode / sort / lookup / group / score |\n|---|---|---|---|\n"
-    f"| C2: 10 M × 150 bp, 4.2e8-record 64-bit index, `-k 12 7` | **{d['value'] / 1e6:.1f} M** (round 4: 50.3 M, round 3: 46.6 M, round 2: 40.1 M, round 1: 21.3 M) | {d['ms_per_step']:.0f} | "
-    f"{st['encode']:.0f} / {st['sort']:.0f} / {st['lookup']:.0f} / {st['group']:.0f} / {st['score']:.0f} (round 4: 13 / 43 / 5 / 79 / 57) |\n"
-    f"| C3: the same reads, 4.2e8-record 128-bit index, `-k 25 7` (`secondary` of the same line) | {sec['value'] / 1e6:.1f} M (round 4: 29.0 M, round 3: 25.4 M, round 2: 19.3 M) | {sec['ms_per_step']:.0f} | "
-    f"{ss['encode']:.0f} / {ss['sort']:.0f} / {ss['lookup']:.0f} / {ss['group']:.0f} / {ss['score']:.0f} (round 4: 20 / 85 / 11 / 75 / 154) |\n"
-    + (f"| crowded index (`tertiary`): {ter['config']['reads_per_gpu'] / 1e6:.0f} M reads, clades of 50-200 taxa sharing conserved genes, same index size | **{ter['value'] / 1e6:.2f} M** (round 4: 3.45 M, round 3: `KASA_E_LIMIT`) | {ter['ms_per_step']:.0f} | "
-       f"{ter['stage_ms_per_step']['encode']:.0f} / {ter['stage_ms_per_step']['sort']:.0f} / {ter['stage_ms_per_step']['lookup']:.0f} / {ter['stage_ms_per_step']['group']:.0f} / {ter['stage_ms_per_step']['score']:.0f} (round 4: 3 / 11 / 3 / 212 / 350); "
+    f"| C2: 10 M × 150 bp, 4.2e8-record 64-bit index, `-k 12 7` | **{d['value'] / 1e6:.1f} M** (round 5: 54.5 M, round 4: 50.3 M, round 3: 46.6 M, round 2: 40.1 M, round 1: 21.3 M) | {d['ms_per_step']:.0f} | "
+    f"{st['encode']:.0f} / {st['sort']:.0f} / {st['lookup']:.0f} / {st['group']:.0f} / {st['score']:.0f} (round 5: 14 / 44 / 5 / 69 / 52) |\n"
+    f"| C3: the same reads, 4.2e8-record 128-bit index, `-k 25 7` (`secondary` of the same line) | {sec['value'] / 1e6:.1f} M (round 5: 29.2 M, round 4: 29.0 M, round 3: 25.4 M, round 2: 19.3 M) | {sec['ms_per_step']:.0f} | "
+    f"{ss['encode']:.0f} / {ss['sort']:.0f} / {ss['lookup']:.0f} / {ss['group']:.0f} / {ss['score']:.0f} (round 5: 20 / 86 / 11 / 75 / 149) |\n"
+    + (f"| crowded index (`tertiary`): {ter['config']['reads_per_gpu'] / 1e6:.0f} M reads, clades of 50-200 taxa sharing conserved genes, same index size | **{ter['value'] / 1e6:.2f} M** (round 5: 9.39 M, round 4: 3.45 M, round 3: `KASA_E_LIMIT`) | {ter['ms_per_step']:.0f} | "
+       f"{ter['stage_ms_per_step']['encode']:.0f} / {ter['stage_ms_per_step']['sort']:.0f} / {ter['stage_ms_per_step']['lookup']:.0f} / {ter['stage_ms_per_step']['group']:.0f} / {ter['stage_ms_per_step']['score']:.0f} (round 5: 3 / 11 / 3 / 130 / 65); "
        f"{ter['batch'].get('dense_reads', 0)} reads on `score_dense_kernel` ({kms(TK, 'score_dense_kernel'):.0f} ms), {ter['batch']['general_reads']} on the general kernel; `group_kernel<COOP>` {kms(TK, 'group_kernel'):.0f} ms, "
        f"profile tables {kms(TK, 'profile_table_kernels'):.0f} ms (round 4: 53); {ter['batch']['pool_words'] / ter['batch']['queries']:.1f} pool words and {ter['batch']['profile_keys'] / ter['batch']['queries']:.1f} profile keys per query; "
        f"HBM traffic of its dominant kernel: {((ter['roofline'].get('traffic') or 0) / 1e9):.1f} GB per launch ({ter['roofline'].get('traffic_source', '')}) |\n" if ter and "value" in ter else "")
+    + quaternary_rows()
     + f"\nThe step includes `kasa_batch_upload_device` ({d['upload_ms_per_batch']:.1f} ms per batch: read geometry on the device). `roofline`: the group stage's kernels (`group2_kernel` over all tiles + `group_kernel<COOP>` over the "
     f"{d['batch'].get('group_tiles_listed', 0)} of {d['batch'].get('group_tiles', 0)} tiles it lists; timed together as `group_kernel`) {roof['avg_launch_ms']:.1f} ms = {roof['frac'] * 100:.1f} % of the HBM peak by their algorithmic bytes, "
     f"HBM traffic {((roof.get('traffic') or 0) / 1e9):.1f} GB ({roof.get('traffic_source', '')}); "
@@ -89,11 +107,11 @@ measured = (
     f"({cb['speedup_over_1']:.1f} ×) on {cb['cpu']}: the box shows {cb['host_cpus']['logical']} CPUs but grants the job a cgroup quota of "
     f"{cb['host_cpus']['cgroup_quota_cpus']:.0f} — more threads than that run slower (measured in round 3: 19 s with 16, 23 s with 64, 27 s with 256 on the same 5 M reads).\n\n"
     f"The line itself: `attempts` {d.get('attempts')}, `retried` {d.get('retried')}; `runtime`: library built with HIP {d.get('runtime', {}).get('hip_built')}, runs on {d.get('runtime', {}).get('hip_runtime')} "
-    f"({d.get('runtime', {}).get('runtime_from')}) -- bench.py shares its process with torch (torch.distributed), so the torch wheel's runtime is the one in the process; hosts without torch run on ROCm's own (§7).\n\n"
+    f"({d.get('runtime', {}).get('runtime_from')}) -- at N = 1 bench.py holds no torch: its reads lie in plain device buffers of the C ABI and the library runs on the runtime it was built for (§7); N > 1 shares its process with torch.distributed.\n\n"
 )
 p = os.path.join(root, "DESIGN.md")
 s = open(p).read()
-s = block(s, "<!-- r05:measured:begin (generated by tools/refresh_docs.py from profiles/r05_bench_1gpu.json) -->", "<!-- r05:measured:end -->", measured)
+s = block(s, "<!-- r06:measured:begin (generated by tools/refresh_docs.py from profiles/r06_bench_1gpu.json) -->", "<!-- r06:measured:end -->", measured)
 s = re.sub(r"\| `encode_kernel` \| 150 B in \+ 130·12 B out per read \| [^|]* \|", f"| `encode_kernel` | 150 B in + 130·12 B out per read | {st['encode']:.0f} ms (stage) |", s)
 s = re.sub(r"\| 5 passes × 24 B \+ one pass of 24 B per query \| [^|]* \|", f"| 5 passes × 24 B + one pass of 24 B per query | {st['sort']:.0f} ms (round 2, library passes: 66 ms) |", s)
 for name, k in (("`tile_bounds_kernel` + `lookup_tile_kernel`", "lookup_tile_kernel"), ("`group2_kernel<Key, NK>` (narrow records; `group_kernel<RW, Key, NK, COOP>` for the tiles it lists and for 64-byte records)", "group_kernel"), ("`score_main_kernel<RW>`", "score_main_kernel"),
@@ -108,7 +126,7 @@ p = os.path.join(root, "README.md")
 r = open(p).read()
 r = block(r, "<!-- measured:begin -->", "<!-- measured:end -->",
           f"One MI355X, 10 M × 150 bp reads against a 4.2e8-record (5 GB) index, profile + per-read scores: **{d['value'] / 1e6:.0f} M reads/s**\n"
-          f"({d['ms_per_step']:.0f} ms per batch; round 4: 50 M, round 3: 47 M, round 2: 40 M, round 1: 21 M), {e['pcie_inclusive_reads_per_s'] / 1e6:.0f} M reads/s with the PCIe legs inside the clock (reads up, ranking\n"
+          f"({d['ms_per_step']:.0f} ms per batch; round 5: 55 M, round 4: 50 M, round 3: 47 M, round 2: 40 M, round 1: 21 M), {e['pcie_inclusive_reads_per_s'] / 1e6:.0f} M reads/s with the PCIe legs inside the clock (reads up, ranking\n"
           f"on the device, printable hits down" + (f"; {e['pcie_pipelined_reads_per_s'] / 1e6:.0f} M with two contexts in flight" if "pcie_pipelined_reads_per_s" in e else "") + "), "
           f"{e['file_to_file_reads_per_s'] / 1e6:.1f} M reads/s file to file through the C++ driver (FASTQ in, JSON lines out);\n"
           f"{sec['value'] / 1e6:.0f} M reads/s against a 128-bit index with `-k 25 7`"
