@@ -417,6 +417,10 @@ int kasa_ctx_third_pass_reads(kasa_ctx *ctx, uint32_t *thirdPassReads);
  * streams such a sequence at merge speed (Compare.hpp:747-1043; pieces: Read.hpp:437-443,678-695); one wavefront per read
  * does not.  Narrow records. */
 int kasa_ctx_replay_stats(kasa_ctx *ctx, uint32_t *reads, uint64_t *events);
+/* Of the tiles kasa_ctx_group_tiles reports as listed by the dense-leader kernel: those that its second launch -- the same
+ * kernel with a park buffer four times as large, for tiles that only parked too many segments (a heavy 7-letter group) --
+ * listed AGAIN and left to the cooperative kernel (long taxon lists, walks beyond the staged index span).  Ours. */
+int kasa_ctx_group_second_chance(kasa_ctx *ctx, uint32_t *listedAgain);
 
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row

@@ -30,7 +30,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats", "kasa_ctx_group_second_chance",
     "kasa_device_alloc", "kasa_device_free", "kasa_device_write", "kasa_device_read", "kasa_batch_records_pack_size", "kasa_batch_records_pack", "kasa_batch_records_unpack",
 ]
 
@@ -730,6 +730,9 @@ class Context:
         keys = ("queries", "staging_records", "profile_keys", "pool_words", "general_reads", "second_pass_reads", "nnz", "encoder_ranked")
         out = {k: int(v) for k, v in zip(keys, st)}
         out["group_tiles"], out["group_tiles_listed"] = self.group_tiles()
+        again = C.c_uint32(0)
+        _check(lib().kasa_ctx_group_second_chance(self.h, C.byref(again)))
+        out["group_tiles_listed_again"] = int(again.value)
         n = C.c_uint32(0)
         _check(lib().kasa_ctx_dense_reads(self.h, C.byref(n)))
         out["dense_reads"] = int(n.value)

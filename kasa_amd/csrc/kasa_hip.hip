@@ -544,7 +544,7 @@ struct kasa_ctx {
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
     DevBuf rTab;                               // floor(2^64 / n) for n < 8192 (profile_group_accum_kernel)
     DevBuf tileList;                           // tiles group2_kernel leaves to group_kernel (long lists, walks beyond the staged span)
-    uint32_t lastSlowTiles = 0;
+    uint32_t lastSlowTiles = 0, lastSlowTiles2 = 0;   // tiles group2_kernel listed; of those, tiles its second chance (larger park buffer) listed again
     DevBuf tileChunks;                         // tile_suffix: minima of chunks of 1024 tiles
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
     DevBuf rec;                                // event records, recWords() u32 each, by slot
@@ -2932,7 +2932,7 @@ __device__ __forceinline__ void block_excl_prefix_sum2(uint32_t a, uint32_t b, u
     offA = ba + ia - a; offB = bb + ib - b; totA = ta; totB = tb;
 }
 
-template <class Key, int NKT, int VAR = 0>                            // VAR: timing variants (KASA_G2_VAR), the product is 0
+template <class Key, int NKT, int VAR = 0, int PARKX = 1>             // VAR: timing variants (KASA_G2_VAR), the product is 0; PARKX: a park buffer that many times as large
 __device__ __forceinline__ void group2_tile(const uint32_t tile,
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
@@ -2957,7 +2957,7 @@ __device__ __forceinline__ void group2_tile(const uint32_t tile,
     // hits of the groups it heads inside its wavefront and |T| per level, 8 bits per level each: two 64-bit words, or -- six
     // levels, the default -- 48 + 48 bits in three 32-bit words (the room that saves is the park buffer's second half)
     constexpr bool PACK6 = NL <= 6;
-    constexpr int OVF = PACK6 ? G2_OVF : G2_OVF / 2;
+    constexpr int OVF = (PACK6 ? G2_OVF : G2_OVF / 2) * PARKX;
     __shared__ uint32_t sHS[(PACK6 ? 3 : 4) * TILE];
     __shared__ uint2 sOvf[OVF];                         // {segment, leader | place in its pool list << 10}: segments beyond the FOURTH
     auto putHits = [&](uint32_t L, unsigned long long h) {
@@ -3869,17 +3869,18 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
 // scattered record stores -- what bounds the stage, tools/scatter_probe.hip -- drain while the workgroup computes its next
 // tile: 71.7 ms against 63.7 at C2.  The hardware's own scheduling of fresh workgroups overlaps the phases better than a
 // loop with a barrier at every tile's end.)
-template <class Key, int NKT, int VAR = 0>
-__global__ __launch_bounds__(GTHREADS, 6) void group2_kernel(
+template <class Key, int NKT, int VAR = 0, int PARKX = 1>
+__global__ __launch_bounds__(GTHREADS, PARKX == 1 ? 6 : 4) void group2_kernel(
     const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth, const uint32_t *__restrict__ rep,
     const uint32_t *__restrict__ slotOf, uint32_t nQ, const uint32_t *__restrict__ tileNext, uint32_t nTiles,
     const typename KeyTraits<Key>::Meta *__restrict__ meta, const uint32_t *__restrict__ tax, uint32_t nIdx, int kHigh, int kLow,
     uint32_t *__restrict__ rec, uint32_t *__restrict__ pool, uint32_t poolCap, unsigned long long *__restrict__ poolCursor, int flags,
     uint32_t nTaxa, uint64_t *__restrict__ profKeys, uint32_t keyCap, unsigned long long *__restrict__ keyCursor, ProfLayout PL,
     uint64_t *__restrict__ cntAllHi, uint64_t *__restrict__ cntAllMid, uint64_t *__restrict__ cntAllLo,
-    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList, uint32_t cellW)
+    uint32_t *__restrict__ slowCount, uint32_t *__restrict__ slowList, uint32_t cellW, const uint32_t *__restrict__ tileIn)
 {
-    group2_tile<Key, NKT, VAR>(blockIdx.x, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
+    // (tileIn: the tiles a first launch listed -- PARKX > 1: those that only parked too many segments get a second chance here)
+    group2_tile<Key, NKT, VAR, PARKX>(tileIn ? (tileIn[blockIdx.x] & 0x0FFFFFFFu) : blockIdx.x, qKmer, depth, rep, slotOf, nQ, tileNext, nTiles, meta, tax, nIdx, kHigh, kLow, rec, pool, poolCap, poolCursor, flags,
                           nTaxa, profKeys, keyCap, keyCursor, PL, cntAllHi, cntAllMid, cntAllLo, slowCount, slowList, cellW);
 }
 
@@ -5456,16 +5457,19 @@ static int launch_group(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, ui
 }
 
 // group2_kernel over all tiles (narrow records); the tiles it lists are the caller's to give to group_kernel
-static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, uint32_t *slowCount)
+static int launch_group2(kasa_ctx *c, const uint32_t *slotOf, uint32_t nTiles, uint32_t cap, uint32_t keyCap, int cov, unsigned long long *cursor, uint32_t *slowCount,
+                         const uint32_t *tileIn = nullptr, uint32_t nIn = 0, uint32_t *slowListOut = nullptr)
 {
     const uint64_t nQ = c->nQ;
 #define KASA_GROUP2_ARGS(KEY, META) c->keys<KEY>(), c->depth.as<uint8_t>(), c->rep.as<uint32_t>(), slotOf, (uint32_t)nQ, \
         c->tileNext.as<uint32_t>(), nTiles, c->ix->meta.as<META>(), c->ix->tax.as<uint32_t>(), (uint32_t)c->ix->n, \
         c->kHigh, c->kLow, c->recOut ? c->recOut : c->rec.as<uint32_t>(), c->pool.as<uint32_t>(), cap, cursor, cov, c->ix->nTaxa, \
         c->profKeys.as<uint64_t>(), keyCap, cursor + 2, prof_layout(c->ix->nTaxa, c->nK), c->cntAllHi.as<uint64_t>(), c->cntAllMid.as<uint64_t>(), c->cntAllLo.as<uint64_t>(), \
-        slowCount, c->tileList.as<uint32_t>(), c->recOut ? 8u : c->recCW
+        slowCount, slowListOut ? slowListOut : c->tileList.as<uint32_t>(), c->recOut ? 8u : c->recCW, tileIn
     static const size_t pad = getenv("KASA_G2_PADLDS") ? (size_t)atoi(getenv("KASA_G2_PADLDS")) : 0;   // (occupancy experiments: unused dynamic LDS)
-    const uint32_t grid = nTiles;
+    const uint32_t grid = tileIn ? nIn : nTiles;
+    if (tileIn) group2_kernel<uint64_t, 6, 0, 4><<<grid, GTHREADS, 0, c->stream>>>(KASA_GROUP2_ARGS(uint64_t, uint8_t));   // (the default level count, 64-bit keys: group_stage asks for nothing else)
+    else
     if (c->ix->wide) group2_kernel<key128, 0><<<grid, GTHREADS, pad, c->stream>>>(KASA_GROUP2_ARGS(key128, uint16_t));
     else if (c->nK == 6) {                                                                                // the default -k 12 7
         // (timing variants of the kernel -- template parameter VAR: 1 straight-line key cutting, 2 a barrier before the record
@@ -5843,12 +5847,12 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
         const bool g2 = RW == 8 && !coop && !(cov & 1) && !(c->debugFlags & (16777216 | 2048 | 131072));
         unsigned long long used[4] = {0, 0, 0, 0};
         if (g2) {
-            if ((rc = c->tileList.reserve((size_t)nTiles * 4 + 64))) return rc;
+            if ((rc = c->tileList.reserve((size_t)nTiles * 8 + 256))) return rc;   // (the first launch's list, then the second chance's)
             if ((rc = launch_group2(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, reinterpret_cast<uint32_t *>(cursor + 3) + 1))) return rc;
             HIPCHK(hipMemcpyAsync(used, cursor, 32, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             const uint32_t nListed = (uint32_t)(used[3] >> 32);
-            c->lastSlowTiles = nListed;
+            c->lastSlowTiles = nListed; c->lastSlowTiles2 = nListed;
             if (nListed && getenv("KASA_DEBUG_WHY")) {
                 std::vector<uint32_t> h(nListed);
                 HIPCHK(hipMemcpy(h.data(), c->tileList.p, (size_t)nListed * 4, hipMemcpyDeviceToHost));
@@ -5857,10 +5861,25 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
                 fprintf(stderr, "[kasa] group2 left %u of %u tiles: long list %u, span %u, both %u, parked only %u, parked + long %u, parked + span %u, all %u\n",
                         nListed, nTiles, why[1], why[2], why[3], why[4], why[5], why[6], why[7]);
             }
-            if (nListed && (rc = launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, true, c->tileList.as<uint32_t>(), nListed))) return rc;
+            // The listed tiles (3 % at C2) are nearly all "parked too much": tiles that hold a heavy 7-letter group.  They get a second
+            // chance with a park buffer four times as large (two workgroups per CU instead of three) before the cooperative kernel
+            // -- 172 ns per tile there, 40 here -- takes what is left (long lists, walks beyond the span).
+            const uint32_t *coopList = c->tileList.as<uint32_t>();
+            uint32_t nCoop = nListed;
+            if (nListed && c->nK == 6 && !c->ix->wide && !(cov & (32 | 64 | 128 | 256)) && (uint64_t)nListed * 4 <= nTiles && !getenv("KASA_NO_SECOND_CHANCE")) {
+                uint32_t *count2 = c->misc.as<uint32_t>() + 78, *list2 = c->tileList.as<uint32_t>() + nTiles + 16;
+                HIPCHK(hipMemsetAsync(count2, 0, 4, c->stream));
+                if ((rc = launch_group2(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, count2, c->tileList.as<uint32_t>(), nListed, list2))) return rc;
+                uint32_t n2 = 0;
+                HIPCHK(hipMemcpyAsync(&n2, count2, 4, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                coopList = list2; nCoop = n2;
+                c->lastSlowTiles2 = n2;
+            }
+            if (nCoop && (rc = launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, true, coopList, nCoop))) return rc;
             if ((uint64_t)nListed * 4 > nTiles) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to the older kernel directly
         } else {
-            c->lastSlowTiles = 0;
+            c->lastSlowTiles = 0; c->lastSlowTiles2 = 0;
             if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;
         }
         if ((rc = timer_end(c, c->kernels[KASA_KERNEL_GROUP], ka, kb))) return rc;
@@ -8031,6 +8050,13 @@ extern "C" int kasa_ctx_replay_stats(kasa_ctx *c, uint32_t *reads, uint64_t *eve
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (reads) *reads = c->lastReplayReads;
     if (events) *events = c->lastReplayEvents;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_group_second_chance(kasa_ctx *c, uint32_t *listedAgain)
+{
+    if (!c || !listedAgain) return fail(KASA_E_ARG, "kasa_ctx_group_second_chance: NULL argument");
+    *listedAgain = c->lastSlowTiles2;
     return KASA_OK;
 }
 

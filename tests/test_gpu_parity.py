@@ -1001,6 +1001,55 @@ def test_general_kernel_on_huge_taxon_sets(flags):
     ctx.close(); dix.close()
 
 
+def test_tiles_with_heavy_groups_get_a_second_chance(monkeypatch):
+    """A clade of 16 near-identical taxa among 30 unrelated ones: a query of the clade meets sixteen segments, and the tiles that
+    hold many such leaders park more than group2_kernel's 1024 slots take but fewer than the 4096 of its second launch -- those
+    tiles are grouped by that launch, not by the cooperative kernel, and the batch is bit-equal to the oracle either way
+    (KASA_NO_SECOND_CHANCE=1: round 5's route).  (The world is dense on purpose: a tile's queries must not span more index entries
+    than the kernel stages.)"""
+    _gpu_or_fail()
+    rng = np.random.default_rng(23)
+    alphabet = np.frombuffer(b"ACGT", dtype=np.uint8)
+    genomes = []
+    root = alphabet[rng.integers(0, 4, size=10000)]
+    for _ in range(16):
+        s_ = root.copy()
+        m = rng.random(10000) < 0.003
+        s_[m] = alphabet[rng.integers(0, 4, size=int(m.sum()))]
+        genomes.append(s_)
+    for _ in range(30):
+        genomes.append(alphabet[rng.integers(0, 4, size=10000)])
+    n_taxa = len(genomes)
+    content = formats.Content(["non_unique"] + [f"T{g}" for g in range(n_taxa)], np.concatenate(([0], 100 + np.arange(n_taxa))).astype(np.uint32))
+    p = oracle.params(12, 7, 3)
+    kms, tids = [], []
+    for g, s_ in enumerate(genomes):
+        km, _ = oracle.encode(s_, np.array([0, 10000], dtype=np.int64), p)
+        kms.append(km); tids.append(np.full(km.shape[0], 100 + g, dtype=np.uint32))
+    ix = formats.make_index(np.concatenate(kms), np.concatenate(tids), content)
+    batch = reads.synthetic_reads(genomes, 6000, 150, 9)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    want = helpers.csr_from_dense(res.M)
+    dix = capi.DeviceIndex(ix)
+    seen = {}
+    for off in ("0", "1"):
+        if off == "1":
+            monkeypatch.setenv("KASA_NO_SECOND_CHANCE", "1")
+        ctx = capi.Context(dix, 12, 7, 3)
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        st = ctx.batch_stats()
+        seen[off] = (st["group_tiles"], st["group_tiles_listed"], st["group_tiles_listed_again"])
+        ca, cu, _ = ctx.profile()
+        assert np.array_equal(cu, res.count_unique)
+        np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+        assert_csr_equal(csr_rows(*ctx.scores()), want)
+        ctx.close()
+    dix.close()
+    tiles, listed, again = seen["0"]
+    assert 0 < listed <= tiles // 4 and again < listed, seen              # (the second launch kept listed tiles)
+    assert seen["1"][2] == seen["1"][1] == listed, seen                    # (without it: everything listed is the cooperative kernel's)
+
+
 def test_context_releases_every_device_buffer():
     """kasa_ctx_destroy gives back everything a context allocated, the third pass's window and list included (round 4
     leaked `gwin` and `ovList2`: up to 2 GB per context that ever ran the third pass)."""
