@@ -6659,6 +6659,8 @@ extern "C" int kasa_batch_records_pack(kasa_ctx *c, const uint32_t *recordsDev, 
     const uint64_t nBlocks = (nQueries + WIRE_BLOCK - 1) / WIRE_BLOCK;
     uint8_t *classes = static_cast<uint8_t *>(outDev);
     uint32_t *words = reinterpret_cast<uint32_t *>(classes + wire_class_bytes(nQueries));
+    if (wire_class_bytes(nQueries) > (nQueries + 3) / 4)                  // (the padding of the class bytes: zeros on the wire)
+        HIPCHK(hipMemsetAsync(classes + (nQueries + 3) / 4, 0, wire_class_bytes(nQueries) - (nQueries + 3) / 4, c->stream));
     if (c->recWords() == 8) wire_pack_kernel<8><<<(unsigned)nBlocks, 256, 0, c->stream>>>(recordsDev, nQueries, c->wireOff.as<uint64_t>(), classes, words);
     else wire_pack_kernel<16><<<(unsigned)nBlocks, 256, 0, c->stream>>>(recordsDev, nQueries, c->wireOff.as<uint64_t>(), classes, words);
     HIPCHK(hipGetLastError());
@@ -6994,7 +6996,9 @@ struct LaneStack {
     }
 };
 __host__ __device__ constexpr int rank_exact_stack_cap(int rows) { int lg = 0; while ((rows >> (lg + 1)) != 0) ++lg; return 2 * lg + 2; }
-template <int ROWS>
+// BIG: the launch for the reads of the last class with MORE hits than its LDS columns take (they sort in global memory with a
+// stack in scratch: 412 bytes per lane that the common form does not carry any more); each form skips the other's reads.
+template <int ROWS, bool BIG = false>
 __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ rowOff,
                                                         const uint32_t *__restrict__ rowPos, const uint2 *__restrict__ rows,
                                                         const double *__restrict__ den, uint32_t nTaxa, const uint32_t *__restrict__ readClass,
@@ -7017,13 +7021,16 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
     uint32_t r = 0, cnt = 0, nOut = 0;
     uint64_t lo = 0;
     float maxV = 0.0f;
-    bool ok = false, inLds = true;
+    bool ok = false, inLds = true, skip = false;
     if (have) {
         r = list[x];
         lo = rowOff[r];
         const uint4 mt = meta[r];
         cnt = mt.w; maxV = __uint_as_float(mt.z);
         inLds = cnt <= (uint32_t)ROWS;
+        skip = inLds == BIG;                                                   // (the other form's read)
+    }
+    if (have && !skip) {
         const uint32_t m = (uint32_t)(rowOff[r + 1] - lo);
         if (inLds) {
             for (uint32_t i = 0; i < cnt; ++i) { shKey[(size_t)i * RANK_EXACT_LANES + lane] = (uint8_t)keyS[lo + i]; shId[(size_t)i * RANK_EXACT_LANES + lane] = (uint8_t)i; }
@@ -7063,7 +7070,7 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
                 const uint8_t *ky = shKey + lane;
                 rankRead(LaneIds<uint8_t>{shId + lane, RANK_EXACT_LANES}, [ky](uint16_t a, uint16_t b) { return ky[(size_t)a * RANK_EXACT_LANES] < ky[(size_t)b * RANK_EXACT_LANES]; },
                          LaneStack<SCAP>{shStack + lane});
-            } else if constexpr (ROWS == RANK_ROWS)                        // (only the last class holds reads with more hits than its LDS takes)
+            } else if constexpr (BIG)                                      // (only the last class holds reads with more hits than its LDS takes)
                 rankRead(LaneIds<uint16_t>{idS + lo, 1}, [hs](uint16_t a, uint16_t b) { return hs[a].rel > hs[b].rel; }, StdsortLocalStack());
         }
     }
@@ -7078,7 +7085,7 @@ __global__ __launch_bounds__(RANK_EXACT_LANES) void rank_exact_kernel(const uint
             for (uint32_t k = 0; k < nOut; ++k) entries[at + k] = hits[lo + (inLds ? shId[(size_t)k * RANK_EXACT_LANES + lane] : idS[lo + k])];
         meta[r] = make_uint4((uint32_t)at, nOut, __float_as_uint(maxV), cnt);
     }
-    const unsigned long long left = __ballot(have && !ok);
+    const unsigned long long left = __ballot(have && !ok && !skip);
     if (lane == 0 && left) atomicAdd(nFlagged, (uint32_t)__popcll(left));
 }
 
@@ -7151,7 +7158,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
             for (int cl = 0; cl < 4; ++cl) {
                 const uint32_t nCl = hClass[cl];
                 if (nCl == 0) continue;
-#define KASA_RANK_EXACT(ROWS) rank_exact_kernel<ROWS><<<blocks_for(nCl, RANK_EXACT_LANES), RANK_EXACT_LANES, 0, c->stream>>>(list1 + from, nCl, c->rowOff.as<uint64_t>(), \
+#define KASA_RANK_EXACT(...) rank_exact_kernel<__VA_ARGS__><<<blocks_for(nCl, RANK_EXACT_LANES), RANK_EXACT_LANES, 0, c->stream>>>(list1 + from, nCl, c->rowOff.as<uint64_t>(), \
                 c->rowPos.as<uint32_t>(), c->st.as<uint2>(), c->rankDen.as<double>(), nTaxa, c->rankClass.as<uint32_t>(), (double)threshold, beasts, \
                 handOver, handKey, idS, c->rankMeta.as<uint4>(), c->rankOut.as<RankEntry>(), c->rankCap, cursor, flagged)
                 if (c->debugFlags & 1048576) KASA_RANK_EXACT(RANK_ROWS);   // (test tap: every class in the largest form)
@@ -7159,6 +7166,7 @@ extern "C" int kasa_batch_rank(kasa_ctx *c, const double *den, uint32_t nClasses
                 else if (cl == 1) KASA_RANK_EXACT(64);
                 else if (cl == 2) KASA_RANK_EXACT(128);
                 else KASA_RANK_EXACT(RANK_ROWS);
+                if (cl == 3 || (c->debugFlags & 1048576)) KASA_RANK_EXACT(RANK_ROWS, true);   // the reads with more hits than the LDS columns take
 #undef KASA_RANK_EXACT
                 HIPCHK(hipGetLastError());
                 from += nCl;
