@@ -684,12 +684,13 @@ def long_reads_leg(args, capi, synth, torch, device, read_len=10_000):
     in the headline: upload_device (geometry) + encode + sort + lookup + group + score."""
     import numpy as np
     g = synth.genomes(args.taxa, args.genome_len, seed=11)
-    ix = synth.index_from_genomes(g, device=device, K=12)
+    wide = bool(getattr(args, "wide", False))                             # (--long-reads --wide: the same against the 128-bit index, -k 25 7)
+    ix = synth.index_from_genomes(g, device=device, K=25 if wide else 12)
     dix = capi.DeviceIndex(ix, device, check_trie=False)
-    ctx = capi.Context(dix, 12, 7, 3)
+    ctx = capi.Context(dix, 25 if wide else 12, 7, 3)
     if args.debug_flags:
         ctx.debug_flags(args.debug_flags)
-    out = {"index_records": int(ix.n), "step": "kasa_batch_upload_device + encode + sort + lookup + group + score, inputs resident in HBM"}
+    out = {"index_records": int(ix.n), "index": "128-bit, -k 25 7" if wide else "64-bit, -k 12 7", "step": "kasa_batch_upload_device + encode + sort + lookup + group + score, inputs resident in HBM"}
 
     def run(name, bases, offsets, steps, what):
         n = int(offsets.shape[0] - 1)

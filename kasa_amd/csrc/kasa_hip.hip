@@ -3585,6 +3585,9 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
     float *score = DENSE ? sRowDyn : A.scratch + (size_t)blockIdx.x * A.nTaxa;
     if constexpr (DENSE) for (uint32_t tx = lane; tx < A.nTaxa; tx += 64) score[tx] = 0.0f;
     uint32_t cachedSlot = NOPOS, cachedN = 0;     // DENSE: the query whose segments and level sizes lie in LDS (uniform)
+    uint32_t mySeg = 0;                            // DENSE, a query of at most 64 segments: lane i holds segment i (no staging in LDS)
+    __shared__ EventTables evT;
+    event_tables_init(evT);
 
     for (int i = lane; i < AGGN; i += 64) { aKey[i] = AGG_EMPTY; aCnt[i] = 0u; }
     const uint32_t nWork = A.list ? A.nList : A.nReads;
@@ -3629,6 +3632,27 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreArgs A)
         auto applyVals = [&](const int k, const uint32_t slot, const uint32_t c) {
             const uint32_t *w = A.rec + (size_t)slot * A.recCW;
             if constexpr (DENSE) {
+                // A query of at most 64 segments (nearly all of them: two or three as a rule) is a register per lane: |T_k| is a
+                // ballot, its score a table look-up -- the staging below (LDS marks, two running sums, four wave syncs) and a float
+                // division per event were 700 instructions per query, and a read of this kernel is ONE wavefront's (the long-read
+                // workload: 12 % of 10 kb reads repeat a prefix of their own; round 6: 196 -> see DESIGN 3d)
+                if (slot != cachedSlot && rec_nseg<RW>(w, A.pool) <= 64u) {
+                    cachedN = rec_nseg<RW>(w, A.pool);
+                    cachedSlot = slot;
+                    mySeg = (uint32_t)lane < cachedN ? rec_seg<RW>(w, A.pool, cachedN, (uint32_t)lane) : 0u;
+                }
+                if (slot == cachedSlot && cachedN <= 64u) {
+                    const bool cov = (uint32_t)lane < cachedN && seg_covers(mySeg, (uint32_t)k);
+                    const uint32_t n = (uint32_t)__popcll(__ballot(cov));
+                    const float sc = event_score(evT, k, n);
+                    if (cov) {
+                        const uint32_t tx = mySeg & SEG_TAX_MASK;
+                        if (A.wantPerRead) { float v = score[tx]; for (uint32_t j = 0; j < c; ++j) v = __fadd_rn(v, sc); score[tx] = v; }
+                        if (A.addProfile) aggAdd(A.kHigh - k, n, tx, c);
+                    }
+                    LDS_WAVE_SYNC();
+                    return;
+                }
                 if (slot != cachedSlot) {                                    // stage the query: segments, +1 / -1 at the ends of their level ranges, running sum
                     const uint32_t ns = rec_nseg<RW>(w, A.pool);
                     cachedN = ns;
@@ -5976,6 +6000,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
     if (c->stCap == 0) c->stCap = std::max<uint64_t>(1u << 16, (uint64_t)nReads * 8);
     const bool fast = nK <= 25 && nTaxa <= (1u << 20) && !c->forceSlowScore;   // staging records keep the taxon in 20 bits
     bool slowProfileDone = false;   // score_kernel adds to the profile tables itself: only once, whatever is rerun
+    bool replayAddedProfile = false;
     c->lastOverflowReads = 0; c->lastThirdPassReads = 0;
     uint64_t staged = 0, nKeys = 0;
     if (!gp && c->keyCapScore == 0) c->keyCapScore = c->stCap;
@@ -6096,7 +6121,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             A.list = c->fbList2.as<uint32_t>(); A.nList = nSlow;
         }
         c->lastReplayReads = 0; c->lastReplayEvents = 0;
-        if (nSlow > 0 && gp && wantPerRead && !(c->debugFlags & 536870912)) {   // (test tap 536870912: never)
+        if (nSlow > 0 && (wantPerRead || !gp) && !(c->debugFlags & 536870912)) {   // (test tap 536870912: never)
             // very long reads: events sorted by (read, taxon, flush position, level), one float chain per (read, taxon) (kasa_replay.h)
             const uint32_t minEnv = getenv("KASA_ESR_MIN_KMERS") ? (uint32_t)strtoul(getenv("KASA_ESR_MIN_KMERS"), nullptr, 10) : 0u;   // (tests: short reads through it)
             const uint32_t minK = (c->debugFlags & 1073741824) ? 1u : (minEnv ? minEnv : ESR_MIN_KMERS);   // (test tap 1073741824: every read of the general kernel's list)
@@ -6105,7 +6130,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             const uint32_t *rest = nullptr; uint32_t nRest = 0;
             if ((rc = esr_stage(c, A, nSlow, minK, &rest, &nRest, counters))) return rc;
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_REPLAY], ea, eb))) return rc;
-            if (c->lastReplayReads) { A.list = rest; A.nList = nRest; nSlow = nRest; }
+            if (c->lastReplayReads) { A.list = rest; A.nList = nRest; nSlow = nRest; if (!gp) replayAddedProfile = true; }
         }
         hipEvent_t ga = nullptr, gb = nullptr;
         if (nSlow > 0 && (rc = timer_begin(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], &ga, &gb))) return rc;
@@ -6219,6 +6244,7 @@ static int score_stage(kasa_ctx *c, int wantPerRead)
             slowProfileDone = true;
             if ((rc = timer_end(c, c->kernels[KASA_KERNEL_SCORE_GENERAL], ga, gb))) return rc;
         }
+        if (replayAddedProfile) slowProfileDone = true;              // (64-byte records: the replay added its reads' events to the tables -- once, whatever is rerun)
         c->lastSlowReads = nSlow;
         if ((rc = timer_end(c, c->timers[KASA_STAGE_SCORE], a, b))) return rc;
         uint32_t err = 0; unsigned long long want = 0;

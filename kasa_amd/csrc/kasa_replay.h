@@ -17,8 +17,9 @@
 //      each, long ones a wavefront each (the addends staged in LDS a kilobyte ahead of the adds);
 //   4. esr_rows_kernel: the chains of a read in ascending taxon order ARE its row.
 // What bounds it is the longest chain (a taxon that every k-mer of a 20 M-k-mer read touches: 1e8 dependent float adds of one
-// lane, a few hundred ms); everything else is parallel work of the kind the batch does anyway.  Narrow records (the profile
-// is the group stage's; 64-byte records add to the profile as they are replayed and stay on the general kernel).
+// lane, a few hundred ms); everything else is parallel work of the kind the batch does anyway.  Both record widths: the
+// events of 64-byte records (a 128-bit index: the profile is not the group stage's) are also added to the profile tables,
+// one exact integer add per event (esr_addend_kernel).
 #pragma once
 
 static constexpr uint32_t ESR_MIN_KMERS = 16384;      // reads of the general kernel's list with at least this many k-mers are replayed from sorted events
@@ -53,6 +54,7 @@ __device__ __forceinline__ uint32_t esr_owner(const uint64_t *__restrict__ qOff,
 }
 
 // events a query yields: one per (segment, level of the segment)
+template <int RW>
 __global__ __launch_bounds__(256) void esr_count_kernel(ScoreArgs A, const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ qOff,
                                                         uint64_t nq, uint32_t *__restrict__ evCnt)
 {
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(256) void esr_count_kernel(ScoreArgs A, const uint3
         const uint32_t *w = A.rec + slot * A.recCW;
         uint32_t n = 0;
         if ((w[2] & 31u) != 0u) {
-            const uint32_t nseg = rec_nseg<8>(w, A.pool);
-            for (uint32_t i = 0; i < nseg; ++i) { const uint32_t s = rec_seg<8>(w, A.pool, nseg, i); n += (s >> 27) - ((s >> 22) & 31u) + 1u; }
+            const uint32_t nseg = rec_nseg<RW>(w, A.pool);
+            for (uint32_t i = 0; i < nseg; ++i) { const uint32_t s = rec_seg<RW>(w, A.pool, nseg, i); n += (s >> 27) - ((s >> 22) & 31u) + 1u; }
         }
         evCnt[g] = n;
     }
@@ -79,12 +81,12 @@ __global__ void esr_read_events_kernel(const uint64_t *__restrict__ qOff, uint32
 // One WAVEFRONT per query: its flush positions (as flush_positions_kernel: the rest of p's tile, then the per-tile table), then
 // one event per (segment, level): key = read (its place in the round) | taxon | F | k -- ascending keys = (read, taxon) chains in
 // the reference's flush order -- and the addend w_k * (1 / |T_k|) in float32 (Compare.hpp:923-924).
-template <class Key>
+template <class Key, int RW>
 __global__ __launch_bounds__(256) void esr_emit_kernel(ScoreArgs A, const uint32_t *__restrict__ list, uint32_t nList, const uint64_t *__restrict__ qOff,
     uint32_t w0, uint64_t q0, uint64_t q1, const uint64_t *__restrict__ evOff, const Key *__restrict__ qKmer, const uint8_t *__restrict__ depth,
-    const uint32_t *__restrict__ tileNext, uint32_t nTiles, int taxBits, uint64_t *__restrict__ keys, float *__restrict__ vals)
+    const uint32_t *__restrict__ tileNext, uint32_t nTiles, int taxBits, uint64_t *__restrict__ keys, uint32_t *__restrict__ sizes)
 {
-    __shared__ uint32_t sF[4][32];
+    __shared__ uint32_t sF[4][32], sN[4][33];                       // per wavefront: F of every level; |T| of every level (marks, then their running sum)
     const int nK = A.kHigh - A.kLow + 1;
     const uint32_t allLv = (1u << nK) - 1u;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -116,16 +118,33 @@ __global__ __launch_bounds__(256) void esr_emit_kernel(ScoreArgs A, const uint32
             }
             if (lane < nK && ((todo >> lane) & 1u)) myF = tileNext[(size_t)lane * nTiles + tile];
         }
-        if (lane < 32) sF[wv][lane] = myF;
+        if (lane < 32) { sF[wv][lane] = myF; sN[wv][lane] = 0u; }
+        if (lane == 32) sN[wv][32] = 0u;
         LDS_WAVE_SYNC();
-        QueryRec<8> Q;
-        Q.decode(reinterpret_cast<const uint4 *>(w), A.pool);
-        const uint32_t nseg = Q.nseg;
+        // |T_k| of every level of the query: +1 / -1 at the ends of each segment's level range, then a running sum (the records
+        // of a narrow index carry them, those of a 128-bit index do not: one way for both)
+        const uint32_t nseg = rec_nseg<RW>(w, A.pool);
+        for (uint32_t b0 = 0; b0 < nseg; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            if (i < nseg) {
+                const uint32_t sg = rec_seg<RW>(w, A.pool, nseg, i);
+                atomicAdd(&sN[wv][A.kHigh - (int)(sg >> 27)], 1u);
+                atomicSub(&sN[wv][A.kHigh - (int)((sg >> 22) & 31u) + 1], 1u);
+            }
+        }
+        LDS_WAVE_SYNC();
+        {
+            uint32_t v = lane < 32 ? sN[wv][lane] : 0u;
+            v = wave_incl_sum(v);
+            LDS_WAVE_SYNC();
+            if (lane < 32) sN[wv][lane] = v;
+        }
+        LDS_WAVE_SYNC();
         const uint64_t readKey = (uint64_t)(wi - w0) << (37 + taxBits);
         uint64_t at = evOff[g] - evBase;
         for (uint32_t b0 = 0; b0 < nseg; b0 += 64) {
             const uint32_t i = b0 + lane;
-            const uint32_t sg = i < nseg ? rec_seg<8>(w, A.pool, nseg, i) : 0u;
+            const uint32_t sg = i < nseg ? rec_seg<RW>(w, A.pool, nseg, i) : 0u;
             const uint32_t kFirst = (sg >> 22) & 31u, kLast = sg >> 27;
             const uint32_t cnt = i < nseg ? kLast - kFirst + 1u : 0u;
             const uint32_t incl = wave_incl_sum(cnt);
@@ -134,12 +153,26 @@ __global__ __launch_bounds__(256) void esr_emit_kernel(ScoreArgs A, const uint32
             for (uint32_t k = kFirst; i < nseg && k <= kLast; ++k, ++o) {
                 const int lv = A.kHigh - (int)k;
                 keys[o] = tk | ((uint64_t)sF[wv][lv] << 5) | (uint64_t)k;
-                vals[o] = event_score((int)k, Q.set_size(lv, A.kHigh));
+                sizes[o] = sN[wv][lv];
             }
             at += lane_value<63>(incl);
         }
         LDS_WAVE_SYNC();
     }
+}
+
+// after the sort: the payload |T_k| becomes the event's float32 addend w_k * (1 / |T_k|) (Compare.hpp:923-924), in place; records of
+// a 128-bit index (the profile is not the group stage's there) also add the event to the profile tables: countAll[k][t] += 1 / |T|,
+// countUnique[k][t] += 1 iff |T| = 1 (Compare.hpp:922-925; exact integer limbs, the order does not matter)
+__global__ void esr_addend_kernel(const uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n, int taxBits, ScoreArgs A, int addProfile)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const int k = (int)(key & 31u);
+    const uint32_t sz = vals[i];
+    vals[i] = __float_as_uint(event_score(k, sz));
+    if (addProfile) profile_add(A, A.kHigh - k, (uint32_t)(key >> 37) & ((1u << taxBits) - 1u), sz, 1ull);
 }
 
 // chain heads of the sorted events: a new (read, taxon)
@@ -273,7 +306,8 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = c->esrEvCnt.reserve((nq + 1) * 4 + 64)) || (rc = c->esrEvOff.reserve((nq + 1) * 8 + 64))) return rc;
     HIPCHK(hipMemsetAsync(c->esrEvCnt.as<uint32_t>() + nq, 0, 4, c->stream));
-    esr_count_kernel<<<std::min<unsigned>(blocks_for(nq, 256), 256u * 64u), 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), nq, c->esrEvCnt.as<uint32_t>());
+    if (c->recWords() == 8) esr_count_kernel<8><<<std::min<unsigned>(blocks_for(nq, 256), 256u * 64u), 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), nq, c->esrEvCnt.as<uint32_t>());
+    else esr_count_kernel<16><<<std::min<unsigned>(blocks_for(nq, 256), 256u * 64u), 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), nq, c->esrEvCnt.as<uint32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, c->esrEvCnt.as<uint32_t>(), c->esrEvOff.as<uint64_t>(), (uint64_t)0, (size_t)nq + 1, rocprim::plus<uint64_t>(), c->stream));
     if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
@@ -308,12 +342,11 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
         if (E > 0) {
             if ((rc = c->esrKeyA.reserve(E * 8 + 256)) || (rc = c->esrKeyB.reserve(E * 8 + 256)) || (rc = c->esrValA.reserve(E * 4 + 64)) || (rc = c->esrValB.reserve(E * 4 + 64))) return rc;
             const unsigned eblocks = (unsigned)std::min<uint64_t>((q1 - q0 + 3) / 4, 256u * 32u);
-            if (c->ix->wide)
-                esr_emit_kernel<key128><<<eblocks, 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), w0, q0, q1, c->esrEvOff.as<uint64_t>(), c->keys<key128>(),
-                    c->depth.as<uint8_t>(), c->tileNext.as<uint32_t>(), nTiles, taxBits, c->esrKeyA.as<uint64_t>(), c->esrValA.as<float>());
-            else
-                esr_emit_kernel<uint64_t><<<eblocks, 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), w0, q0, q1, c->esrEvOff.as<uint64_t>(), c->keys<uint64_t>(),
-                    c->depth.as<uint8_t>(), c->tileNext.as<uint32_t>(), nTiles, taxBits, c->esrKeyA.as<uint64_t>(), c->esrValA.as<float>());
+#define KASA_ESR_EMIT(KEY, RWV) esr_emit_kernel<KEY, RWV><<<eblocks, 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), w0, q0, q1, c->esrEvOff.as<uint64_t>(), \
+                c->keys<KEY>(), c->depth.as<uint8_t>(), c->tileNext.as<uint32_t>(), nTiles, taxBits, c->esrKeyA.as<uint64_t>(), c->esrValA.as<uint32_t>())
+            if (c->ix->wide) { if (c->recWords() == 8) KASA_ESR_EMIT(key128, 8); else KASA_ESR_EMIT(key128, 16); }
+            else KASA_ESR_EMIT(uint64_t, 8);
+#undef KASA_ESR_EMIT
             HIPCHK(hipGetLastError());
             int rb = 0;
             while ((1u << rb) < w1 - w0) ++rb;
@@ -321,8 +354,11 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
             HIPCHK(rocprim::radix_sort_pairs(nullptr, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<uint32_t>(), c->esrValB.as<uint32_t>(), (size_t)E, 0u, endBit, c->stream));   // (the addends travel as 32-bit words: the query sort's fallback is the same instantiation of the library's sort)
             if ((rc = c->sortTmp.reserve(tmpBytes))) return rc;
             HIPCHK(rocprim::radix_sort_pairs(c->sortTmp.p, tmpBytes, c->esrKeyA.as<uint64_t>(), c->esrKeyB.as<uint64_t>(), c->esrValA.as<uint32_t>(), c->esrValB.as<uint32_t>(), (size_t)E, 0u, endBit, c->stream));   // (the addends travel as 32-bit words: the query sort's fallback is the same instantiation of the library's sort)
-            // chains: heads -> ranks (a running sum, in the dead key buffer) -> starts
             const uint32_t n = (uint32_t)E;
+            esr_addend_kernel<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->esrKeyB.as<uint64_t>(), c->esrValB.as<uint32_t>(), n, taxBits, A, A.addProfile);
+            HIPCHK(hipGetLastError());
+            if (!A.wantPerRead) { c->lastReplayEvents += E; c->lastReplayReads += w1 - w0; w0 = w1; continue; }   // (a profile-only run of a 128-bit index: no rows)
+            // chains: heads -> ranks (a running sum, in the dead key buffer) -> starts
             uint32_t *head = c->esrKeyA.as<uint32_t>(), *headRank = head + ((size_t)n + 16);
             esr_heads_kernel<<<blocks_for(n, 256), 256, 0, c->stream>>>(c->esrKeyB.as<uint64_t>(), n, head);
             HIPCHK(rocprim::exclusive_scan(nullptr, tmpBytes, head, headRank, 0u, (size_t)n, rocprim::plus<uint32_t>(), c->stream));

@@ -423,6 +423,51 @@ def test_very_long_reads_replayed_from_sorted_events(frames, round_events, monke
     ctx.close(); dix.close()
 
 
+@pytest.mark.parametrize("krange,want_rows", [((25, 7), True), ((25, 18), True), ((25, 7), False)], ids=["k25_7", "k25_18", "profile_only"])
+def test_very_long_reads_against_a_128_bit_index(krange, want_rows, monkeypatch):
+    """The same replay for 64-byte records (a 128-bit index, up to 19 levels): the sizes of a query's taxon sets are made from
+    its segments, and -- the profile of such an index is not the group stage's -- every event also adds its exact share to the
+    profile tables.  Rows and tables equal the oracle's; a profile-only run (kASA without -q) replays for the tables alone."""
+    _gpu_or_fail()
+    rng = np.random.default_rng(5)
+    kh, kl = krange
+    ix, base = synthetic_world(47, 6, 30000, 30, K=25)
+    g = synth_genomes_of(47, 6, 30000)
+    parts = []
+    for _ in range(14):
+        t = int(rng.integers(0, len(g)))
+        a = int(rng.integers(0, 30000 - 4000))
+        piece = g[t][a:a + int(rng.integers(800, 4000))].copy()
+        parts.append(piece)
+        if rng.integers(0, 3) == 0:
+            parts.append(piece[: int(rng.integers(100, piece.shape[0]))].copy())
+    long_a = np.concatenate(parts)
+    seqs = [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(6)] + [long_a] + [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(6, 10)] + [np.tile(g[1][:400], 50)]
+    off = np.concatenate(([0], np.cumsum([x.shape[0] for x in seqs]))).astype(np.int64)
+    batch = reads.ReadBatch(np.concatenate(seqs), off, None, np.asarray([x.shape[0] + 1 for x in seqs], dtype=np.uint32))
+    p = oracle.params(kh, kl, 3, K=25)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, kh, kl, 3)
+    ctx.run_batch(batch.bases, batch.offsets, want_rows)
+    st = ctx.batch_stats()
+    if want_rows:                                                 # (without per-read scores no read breaks an order rule: the lane-per-read kernels keep them all)
+        assert st["replay_reads"] >= 2 and st["replay_events"] > 0, st
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    if want_rows:
+        assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+        ctx.debug_flags(536870912)                                # (never the replay)
+        ctx.profile_reset()
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        assert ctx.batch_stats()["replay_reads"] == 0
+        assert_csr_equal(csr_rows(*ctx.scores()), helpers.csr_from_dense(res.M))
+        ca2, cu2, _ = ctx.profile()
+        assert np.array_equal(cu2, cu)
+    ctx.close(); dix.close()
+
+
 @pytest.mark.parametrize("frames", [3, 6])
 @pytest.mark.parametrize("flags", [0, 1, 8])   # 8: slots from a sort by read id instead of the encoder's ranking
 def test_unique_drops_repeats_inside_reads(frames, flags):
