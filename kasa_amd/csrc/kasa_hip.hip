@@ -4164,8 +4164,11 @@ template <int RW> __device__ __forceinline__ uint32_t seg_records(uint32_t level
 // PF: the next line is loaded while this one is replayed.  Off for narrow records: the 32 registers that holds cost two of six
 // resident wavefronts per SIMD, and those hide the latency better (22.0 -> 21.0 ms; debug flag 1024 runs the prefetching
 // variant).  Wide records: the LDS tables limit the wavefronts anyway, prefetching wins (60 against 64 ms).
+#ifndef KASA_MAIN16_WAVES
+#define KASA_MAIN16_WAVES 1
+#endif
 template <int RW, bool PERREAD, int FB = 16, int NLV = RecTraits<RW>::LEVELS, bool PF = (RW != 8)>
-__global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : 1) void score_main_kernel(ScoreArgs A)
+__global__ __launch_bounds__(64, (RW == 8 && NLV <= 6 && FB == 8) ? 7 : (RW == 16 ? KASA_MAIN16_WAVES : 1)) void score_main_kernel(ScoreArgs A)
 {
     typedef RecTraits<RW> RT;
     constexpr int NL = NLV, OB = RT::OBITS;
@@ -5890,7 +5893,8 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
             // -- 172 ns per tile there, 40 here -- takes what is left (long lists, walks beyond the span).
             const uint32_t *coopList = c->tileList.as<uint32_t>();
             uint32_t nCoop = nListed;
-            if (nListed && c->nK == 6 && !c->ix->wide && !(cov & (32 | 64 | 128 | 256)) && (uint64_t)nListed * 4 <= nTiles && !getenv("KASA_NO_SECOND_CHANCE")) {
+            static const bool g2Always = getenv("KASA_G2_ALWAYS") && atoi(getenv("KASA_G2_ALWAYS")) != 0;   // (experiment: group2_kernel + its second launch whatever the share of listed tiles)
+            if (nListed && c->nK == 6 && !c->ix->wide && !(cov & (32 | 64 | 128 | 256)) && ((uint64_t)nListed * 4 <= nTiles || g2Always) && !getenv("KASA_NO_SECOND_CHANCE")) {
                 uint32_t *count2 = c->misc.as<uint32_t>() + 78, *list2 = c->tileList.as<uint32_t>() + nTiles + 16;
                 HIPCHK(hipMemsetAsync(count2, 0, 4, c->stream));
                 if ((rc = launch_group2(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, count2, c->tileList.as<uint32_t>(), nListed, list2))) return rc;
@@ -5899,9 +5903,10 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
                 HIPCHK(hipStreamSynchronize(c->stream));
                 coopList = list2; nCoop = n2;
                 c->lastSlowTiles2 = n2;
+                if (getenv("KASA_DEBUG_WHY")) fprintf(stderr, "[kasa] group2's second launch left %u of %u listed tiles to the cooperative kernel\n", n2, nListed);
             }
             if (nCoop && (rc = launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, true, coopList, nCoop))) return rc;
-            if ((uint64_t)nListed * 4 > nTiles) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to the older kernel directly
+            if ((uint64_t)nListed * 4 > nTiles && !(getenv("KASA_G2_ALWAYS") && atoi(getenv("KASA_G2_ALWAYS")) != 0)) c->groupCoop = true;       // crowded taxon lists: the context's further batches go to the older kernel directly
         } else {
             c->lastSlowTiles = 0; c->lastSlowTiles2 = 0;
             if ((rc = (RW == 8 ? launch_group<8>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, coop) : launch_group<16>(c, slotOf, nTiles, cap, (uint32_t)c->keyCap, cov, cursor, false)))) return rc;
