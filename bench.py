@@ -10,9 +10,12 @@ torch.distributed).  `value` = all reads of all ranks / max-over-ranks time.
   N = 1   BASELINE.json configs[1] (C2): ONE batch of 10 M synthetic 150 bp reads against a ~5 GB k<=12 64-bit index
           (1400 taxa x 300 kb, sibling genomes 3 % apart; 1 % read errors; -k 12 7, three frames).  The same line also
           carries `secondary` = configs[2] (C3: the same reads against the 128-bit index, -k 25 7), `tertiary` (a crowded
-          index: clades of taxa sharing conserved genes), `e2e` (PCIe-inclusive rates and the file-to-file rate of the
-          C++ driver: FASTQ in, JSONL + profile out, index load excluded) and `cpu_baseline` (the oracle with the
-          reference's threading model on the host cores).
+          index: clades of taxa sharing conserved genes), `quaternary` (long reads: 100 000 x 10 kb reads and two 9.6 Mbp
+          contigs against the same index), `e2e` (PCIe-inclusive rates and the file-to-file rate of the
+          C++ driver: FASTQ in, JSONL + profile out, index load excluded), `cpu_baseline` (the oracle with the
+          reference's threading model on the host cores) and, as its LAST key, `summary` (every leg in under 1900
+          characters: a reader that keeps the line's tail sees them all).  At N = 1 the process imports no torch: the reads
+          lie in plain device buffers of the C ABI and the library runs on the HIP runtime it was built for (`runtime`).
   N > 1   the same 10 M-read batch on EVERY rank, index replicated ("weak": N x 10 M reads per step; N = 1 and N = 8 differ
           by the reduce only).  The same line carries `c2_strong` = BASELINE.json's metric read literally (10 M reads in all,
           10 M / N per rank) and `c4` = BASELINE.json configs[3]: 100 M reads in all, 100 M / N per rank in batches of at
