@@ -345,7 +345,7 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
 #define KASA_ESR_EMIT(KEY, RWV) esr_emit_kernel<KEY, RWV><<<eblocks, 256, 0, c->stream>>>(A, longList, nLong, c->esrQOff.as<uint64_t>(), w0, q0, q1, c->esrEvOff.as<uint64_t>(), \
                 c->keys<KEY>(), c->depth.as<uint8_t>(), c->tileNext.as<uint32_t>(), nTiles, taxBits, c->esrKeyA.as<uint64_t>(), c->esrValA.as<uint32_t>())
             if (c->ix->wide) { if (c->recWords() == 8) KASA_ESR_EMIT(key128, 8); else KASA_ESR_EMIT(key128, 16); }
-            else KASA_ESR_EMIT(uint64_t, 8);
+            else { if (c->recWords() == 8) KASA_ESR_EMIT(uint64_t, 8); else KASA_ESR_EMIT(uint64_t, 16); }   // (a 64-bit index with more than eight levels has 64-byte records too)
 #undef KASA_ESR_EMIT
             HIPCHK(hipGetLastError());
             int rb = 0;
@@ -391,6 +391,11 @@ static int esr_stage(kasa_ctx *c, ScoreArgs &A, uint32_t nSlow, uint32_t minK, c
         std::vector<uint32_t> longH(nLong);
         HIPCHK(hipMemcpy(longH.data(), c->esrLong.p, (size_t)nLong * 4, hipMemcpyDeviceToHost));
         for (uint32_t wi : back) { HIPCHK(hipMemcpy(c->esrShort.as<uint32_t>() + nShort, &longH[wi], 4, hipMemcpyHostToDevice)); ++nShort; }
+    }
+    // the event buffers of a contig are tens of gigabytes: a context that goes on with ordinary batches gets them back
+    if (c->esrKeyA.cap + c->esrKeyB.cap + c->esrValA.cap + c->esrValB.cap > ((size_t)2 << 30)) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->esrKeyA.release(); c->esrKeyB.release(); c->esrValA.release(); c->esrValB.release();
     }
     *listOut = c->esrShort.as<uint32_t>(); *nOut = nShort;
     return KASA_OK;

@@ -423,15 +423,16 @@ def test_very_long_reads_replayed_from_sorted_events(frames, round_events, monke
     ctx.close(); dix.close()
 
 
-@pytest.mark.parametrize("krange,want_rows", [((25, 7), True), ((25, 18), True), ((25, 7), False)], ids=["k25_7", "k25_18", "profile_only"])
-def test_very_long_reads_against_a_128_bit_index(krange, want_rows, monkeypatch):
+@pytest.mark.parametrize("krange,want_rows,K", [((25, 7), True, 25), ((25, 18), True, 25), ((25, 7), False, 25), ((12, 3), True, 12)],
+                         ids=["k25_7", "k25_18", "profile_only", "64_byte_records_of_a_64_bit_index"])
+def test_very_long_reads_against_a_128_bit_index(krange, want_rows, K, monkeypatch):
     """The same replay for 64-byte records (a 128-bit index, up to 19 levels): the sizes of a query's taxon sets are made from
     its segments, and -- the profile of such an index is not the group stage's -- every event also adds its exact share to the
     profile tables.  Rows and tables equal the oracle's; a profile-only run (kASA without -q) replays for the tables alone."""
     _gpu_or_fail()
     rng = np.random.default_rng(5)
-    kh, kl = krange
-    ix, base = synthetic_world(47, 6, 30000, 30, K=25)
+    kh, kl = krange                                               # ((12, 3): ten levels -- 64-byte records with 64-bit keys; a fuzz seed found the replay reading them as narrow ones)
+    ix, base = synthetic_world(47, 6, 30000, 30, K=K)
     g = synth_genomes_of(47, 6, 30000)
     parts = []
     for _ in range(14):
@@ -445,7 +446,7 @@ def test_very_long_reads_against_a_128_bit_index(krange, want_rows, monkeypatch)
     seqs = [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(6)] + [long_a] + [base.bases[base.offsets[i]:base.offsets[i + 1]] for i in range(6, 10)] + [np.tile(g[1][:400], 50)]
     off = np.concatenate(([0], np.cumsum([x.shape[0] for x in seqs]))).astype(np.int64)
     batch = reads.ReadBatch(np.concatenate(seqs), off, None, np.asarray([x.shape[0] + 1 for x in seqs], dtype=np.uint32))
-    p = oracle.params(kh, kl, 3, K=25)
+    p = oracle.params(kh, kl, 3, K=K)
     res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True)
     dix = capi.DeviceIndex(ix)
     ctx = capi.Context(dix, kh, kl, 3)

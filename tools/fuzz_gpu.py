@@ -45,6 +45,8 @@ for seed in range(first, first + count):
         break
     if done % 50 == 0:
         print("at seed", seed, file=sys.stderr, flush=True)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("seed", seed, file=sys.stderr, flush=True)
     try:
         T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
         T.test_adversarial_queries_vs_oracle(seed, CYCLE[seed % len(CYCLE)])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
