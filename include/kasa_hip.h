@@ -415,7 +415,7 @@ int kasa_ctx_third_pass_reads(kasa_ctx *ctx, uint32_t *thirdPassReads);
  * read id) to be replayed from SORTED EVENTS instead -- every query of theirs turned into events {read, taxon, flush position,
  * level} by all wavefronts, one radix sort, one float32 chain per (read, taxon) -- and the events that took.  The reference
  * streams such a sequence at merge speed (Compare.hpp:747-1043; pieces: Read.hpp:437-443,678-695); one wavefront per read
- * does not.  Narrow records. */
+ * does not.  Both record widths (64-byte records: the replay also adds the events to the profile tables). */
 int kasa_ctx_replay_stats(kasa_ctx *ctx, uint32_t *reads, uint64_t *events);
 /* Of the tiles kasa_ctx_group_tiles reports as listed by the dense-leader kernel: those that its second launch -- the same
  * kernel with a park buffer four times as large, for tiles that only parked too many segments (a heavy 7-letter group) --
