@@ -30,6 +30,66 @@ def fuzz_text(seed):
     assert texts[0] == texts[1], (seed, fmt, beasts, thr, frames)
 
 
+def fuzz_long(seed):
+    """long reads (contigs of pieces of the genomes, regions met again, tandem repeats) against the oracle: the sorted-event replay,
+    the encoder's long sequences, long staging rows -- over key widths, k ranges (more than eight levels with either key width),
+    frames, -e"""
+    import numpy as np
+    from kasa_amd import capi, reads
+    from oracle import oracle
+    rng = np.random.default_rng(123000 + seed)
+    K = 25 if seed % 3 == 2 else 12
+    k_high = int(rng.integers(max(2, K - 6), K + 1))
+    k_low = int(rng.integers(1, min(k_high, 9) + 1))
+    if seed % 4 == 0:
+        k_high, k_low = K, 7
+    frames = int(rng.choice([1, 3, 3, 6]))
+    unique = bool(rng.integers(0, 4) == 0)
+    n_taxa, glen = int(rng.integers(2, 10)), int(rng.integers(8000, 30000))
+    ix, base = T.synthetic_world(int(rng.integers(1, 1 << 30)), n_taxa, glen, 30, K=K)
+    pool = base.bases
+    seqs = []
+    for r in range(int(rng.integers(3, 9))):
+        if rng.integers(0, 2) == 0:
+            a = int(rng.integers(0, pool.shape[0] - 200)); seqs.append(pool[a:a + int(rng.integers(0, 200))].copy())
+            continue
+        parts = []
+        total, want = 0, int(rng.integers(17000, 60000)) * (3 if frames == 1 else 1)
+        while total < want:
+            L = int(rng.integers(300, 5000))
+            a = int(rng.integers(0, max(1, pool.shape[0] - L)))
+            piece = pool[a:a + L].copy()
+            kind = int(rng.integers(0, 6))
+            if kind == 0 and parts:
+                piece = parts[int(rng.integers(0, len(parts)))][:L].copy()       # a region once more
+            elif kind == 1:
+                piece = np.tile(piece[:int(rng.integers(20, 400))], int(rng.integers(2, 30)))   # a tandem repeat
+            parts.append(piece); total += piece.shape[0]
+        seqs.append(np.concatenate(parts))
+    off = np.concatenate(([0], np.cumsum([x.shape[0] for x in seqs]))).astype(np.int64)
+    batch = reads.ReadBatch(np.concatenate(seqs), off, None, np.asarray([x.shape[0] + 1 for x in seqs], dtype=np.uint32))
+    flags = int(rng.choice([0, 0, 0, 1, 1073741824, 134217728, 536870912]))
+    p = oracle.params(k_high, k_low, frames, K=ix.K)
+    res, nq = oracle.identify_batch(ix, batch.bases, batch.offsets, p, True, unique=unique, seg_read=None, n_reads=batch.n)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, k_high, k_low, frames)
+    ctx.debug_flags(flags)
+    ctx.run_batch(batch.bases, batch.offsets, True, unique=unique)
+    assert ctx.n_kmers == nq
+    st = ctx.batch_stats()
+    for k in ("replay_reads", "replay_events", "general_reads", "dense_reads"):
+        LONG_STATS[k] = LONG_STATS.get(k, 0) + st[k]
+    LONG_STATS["batches"] = LONG_STATS.get("batches", 0) + 1
+    ca, cu, _ = ctx.profile()
+    assert np.array_equal(cu, res.count_unique)
+    np.testing.assert_allclose(ca, res.count_all, rtol=1e-12, atol=0)
+    T.assert_csr_equal(T.csr_rows(*ctx.scores()), T.helpers.csr_from_dense(res.M))
+    ctx.close(); dix.close()
+
+
+LONG_STATS = {}
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 budget = float(sys.argv[3]) if len(sys.argv) > 3 else 480.0
@@ -48,13 +108,17 @@ for seed in range(first, first + count):
     if os.environ.get("FUZZ_VERBOSE"):
         print("seed", seed, file=sys.stderr, flush=True)
     try:
-        T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
-        T.test_adversarial_queries_vs_oracle(seed, CYCLE[seed % len(CYCLE)])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
+        if not os.environ.get("FUZZ_ONLY_LONG"):
+            T.test_random_configurations.__wrapped__(seed) if hasattr(T.test_random_configurations, "__wrapped__") else T.test_random_configurations(seed)
+        if not os.environ.get("FUZZ_ONLY_LONG"):
+            T.test_adversarial_queries_vs_oracle(seed, CYCLE[seed % len(CYCLE)])   # (262144: long lists by whole wavefronts; 2048: no followers; 8192: lane-owned cells; 16384 | 8388608: the pending window in device memory)
         if os.environ.get("FUZZ_TEXT"):
             fuzz_text(seed)
+        if os.environ.get("FUZZ_LONG"):
+            fuzz_long(seed)
     except Exception:
         print("FAILED at seed", seed)
         traceback.print_exc()
         sys.exit(1)
     done += 1
-print("ok:", done, "seeds from", first, "in %.0f s" % (time.time() - t0))
+print("ok:", done, "seeds from", first, "in %.0f s" % (time.time() - t0), LONG_STATS if LONG_STATS else "")
