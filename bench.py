@@ -403,6 +403,7 @@ def report(args, ctx, reads, ix, world, res, wide, n_reads, n_batches, scaling, 
         "rank_step_ms": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "reduce_ms_per_step": res["reduce_ms_per_step"], "upload_ms_per_batch": res["upload_ms_per_batch"],
         "batch": stats,
+        "record_placement": ctx.record_placement(),                       # how the record buffer was chosen: the rate of random 32-byte stores is a property of the memory behind it (tools/place_probe.hip)
         "stage_ms_per_step": {k: v[0] / max(1, args.steps) for k, v in stages.items()},
         "stage_algorithmic_gbps": {k: (b / (stages[k][0] / max(1, args.steps) * 1e-3) / 1e9 if stages.get(k, (0,))[0] > 0 else None)
                                    for k, b in sb.items()},
@@ -1134,6 +1135,8 @@ def summary_of(out):
                              "frac": None if o.get("roofline", {}).get("frac") is None else round(o["roofline"]["frac"], 3)}}
     sm = {"stage_ms": {k: r1(v) for k, v in out.get("stage_ms_per_step", {}).items() if v},
           "kernel_ms": {k: r1(v.get("avg_launch_ms", v.get("ms_per_step"))) for k, v in out.get("kernels", {}).items()}}
+    if isinstance(out.get("record_placement"), dict):
+        sm["record_buffer_g_stores_per_s"] = out["record_placement"].get("candidates_g_records_per_s")   # (candidates timed; the best is kept)
     e = out.get("e2e") or {}
     sm["e2e_reads_per_s"] = {k.replace("_reads_per_s", ""): round(v) for k, v in e.items() if k.endswith("_reads_per_s") and isinstance(v, (int, float))}
     for name in ("secondary", "tertiary", "c2_strong", "c4"):

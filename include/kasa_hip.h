@@ -421,6 +421,13 @@ int kasa_ctx_replay_stats(kasa_ctx *ctx, uint32_t *reads, uint64_t *events);
  * kernel with a park buffer four times as large, for tiles that only parked too many segments (a heavy 7-letter group) --
  * listed AGAIN and left to the cooperative kernel (long taxon lists, walks beyond the staged index span).  Ours. */
 int kasa_ctx_group_second_chance(kasa_ctx *ctx, uint32_t *listedAgain);
+/* How the buffer of 32-byte event records was chosen.  The rate at which an MI355X takes random 32-byte stores is a property
+ * of the physical memory behind a buffer (21 to 28 G records/s, tools/place_probe.hip), and the group stage ends in one such
+ * store per query: a buffer of 8 GB and more (KASA_PLACE_MIN_MB) is taken from up to three candidates (KASA_PLACE_TRIES),
+ * each timed with a few milliseconds of scattered stores when it is allocated.  candidates = 0: allocated plainly (a small
+ * buffer, 64-byte records); keptRate and rates4[0..3] in G records/s.  rates4 may be NULL.  Ours: the reference has no
+ * device memory (its record of a k-mer's hits is the host vector of Compare.hpp:1430-1467). */
+int kasa_ctx_record_placement(kasa_ctx *ctx, uint32_t *candidates, float *keptRate, float *rates4);
 
 /* Test tap: forceSlowScore >= 0 is a bit set: bit 0 = every read takes the general (wavefront-per-read)
  * score kernel, bit 1 = per-query index search instead of the streamed-tile lookup, bit 2 = sorting row

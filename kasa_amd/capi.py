@@ -30,7 +30,7 @@ EXPORTS = [
     "kasa_batch_rank", "kasa_batch_rank_fetch", "kasa_host_alloc", "kasa_host_free", "kasa_thread_device",
     "kasa_batch_queries_device", "kasa_batch_slice_starts", "kasa_batch_set_sorted_device", "kasa_batch_records_device",
     "kasa_batch_records_import_device", "kasa_batch_records_inbox", "kasa_batch_coherence",
-    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats", "kasa_ctx_group_second_chance",
+    "kasa_ctx_set_taxa_text", "kasa_batch_text", "kasa_batch_text_fetch", "kasa_batch_text_fetch_range", "kasa_text_dtoa", "kasa_ctx_reserve", "kasa_runtime_versions", "kasa_ctx_group_tiles", "kasa_ctx_dense_reads", "kasa_ctx_replay_stats", "kasa_ctx_group_second_chance", "kasa_ctx_record_placement",
     "kasa_device_alloc", "kasa_device_free", "kasa_device_write", "kasa_device_read", "kasa_batch_records_pack_size", "kasa_batch_records_pack", "kasa_batch_records_unpack",
 ]
 
@@ -740,6 +740,14 @@ class Context:
         _check(lib().kasa_ctx_replay_stats(self.h, C.byref(n), C.byref(ev)))
         out["replay_reads"], out["replay_events"] = int(n.value), int(ev.value)
         return out
+
+    def record_placement(self):
+        """How the record buffer was chosen (kasa_ctx_record_placement): candidates timed, the kept one's rate of random 32-byte
+        stores and every candidate's, in G records/s; candidates = 0: allocated plainly."""
+        n, kept = C.c_uint32(0), C.c_float(0)
+        rates = (C.c_float * 4)()
+        _check(lib().kasa_ctx_record_placement(self.h, C.byref(n), C.byref(kept), rates))
+        return {"candidates": int(n.value), "kept_g_records_per_s": round(float(kept.value), 2), "candidates_g_records_per_s": [round(float(x), 2) for x in rates[:int(n.value)]]}
 
     def group_tiles(self):
         """(tiles of the last batch's group stage, tiles group2_kernel left to group_kernel) -- kasa_ctx_group_tiles."""

@@ -135,6 +135,80 @@ struct DevBuf {
 };
 typedef DevBuf ScopedBuf;                                     // a function's own scratch
 
+// ---- a buffer that takes random 32-byte stores is CHOSEN ---------------------------------------------------------------
+// The rate at which this chip takes random 32-byte stores is a property of the PHYSICAL memory a buffer got: 21.2, 25.8, 27.2
+// or 28.4 G records/s for 34 GB pieces of one device, the same piece always the same and whatever virtual address it is
+// mapped at (tools/place_probe.hip, profiles/r06_place_probe.json) -- and the group stage ends in one such store per query:
+// its kernels took 56 or 61 ms for the same batch depending on what hipMalloc had handed out (in ONE process before and
+// after the record buffer was allocated again; between boxes).  So up to three candidates are allocated (held together: they
+// are different memory), each is timed with 2^27 scattered 32-byte stores (5 ms), the first that is fast enough or else
+// the best is kept.  Buffers below 8 GB are not worth it (KASA_PLACE_MIN_MB; KASA_PLACE_TRIES=1: plain allocation).
+__global__ void place_probe_kernel(uint4 *__restrict__ dst, uint32_t n, unsigned long long slots)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long h = (i + 1ull) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const size_t s = (size_t)__umul64hi(h, slots);                  // uniform over the buffer's 32-byte slots
+    dst[s * 2] = make_uint4(i, 0u, 0u, 0u);
+    dst[s * 2 + 1] = make_uint4(0u, i, 0u, 0u);
+}
+
+struct Placement { uint32_t candidates = 0; float kept = 0.0f, rates[4] = {0.0f, 0.0f, 0.0f, 0.0f}; };
+
+static float place_probe_rate(void *p, size_t bytes, hipStream_t stream)   // G records/s; 0 when it could not be measured
+{
+    const uint32_t n = 1u << 27;
+    const unsigned long long slots = bytes / 32;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (slots < 2 || hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { if (a) (void)hipEventDestroy(a); (void)hipGetLastError(); return 0.0f; }
+    float best = 0.0f;
+    for (int rep = 0; rep < 3; ++rep) {                              // (the first launch warms up)
+        float ms = 0.0f;
+        (void)hipEventRecord(a, stream);
+        place_probe_kernel<<<n / 256, 256, 0, stream>>>(reinterpret_cast<uint4 *>(p), n, slots);
+        (void)hipEventRecord(b, stream);
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess || ms <= 0.0f) { best = 0.0f; (void)hipGetLastError(); break; }
+        if (rep) best = std::max(best, (float)(n / (ms * 1e6)));
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return best;
+}
+
+static int reserve_placed(DevBuf &buf, size_t bytes, hipStream_t stream, Placement *out)
+{
+    if (bytes <= buf.cap) return KASA_OK;
+    const char *minEnv = getenv("KASA_PLACE_MIN_MB"), *triesEnv = getenv("KASA_PLACE_TRIES");
+    const size_t minBytes = (size_t)(minEnv ? atol(minEnv) : 8192) << 20;
+    const int tries = std::min(4, triesEnv ? atoi(triesEnv) : 3);
+    if (tries <= 1 || bytes < minBytes) return buf.reserve(bytes);
+    const float goodEnough = 26.5f;                                  // G records/s: the three fast kinds of memory
+    buf.release();
+    DevBuf cand[4];
+    Placement pl;
+    int best = -1;
+    for (int t = 0; t < tries; ++t) {
+        if (t > 0) {                                                 // a further candidate only where a quarter of the device stays free beside it
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (freeB < bytes + bytes / 16 + totalB / 4) break;
+        }
+        const int rc = cand[t].reserve(bytes);
+        if (rc) { if (t == 0) return rc; break; }
+        pl.rates[t] = place_probe_rate(cand[t].p, bytes, stream);
+        pl.candidates = (uint32_t)t + 1;
+        if (best < 0 || pl.rates[t] > pl.rates[best]) best = t;
+        if (pl.rates[t] >= goodEnough || pl.rates[t] == 0.0f) break; // (not measurable: no reason to go on)
+    }
+    pl.kept = pl.rates[best];
+    buf = std::move(cand[best]);                                     // (the others go back as `cand` leaves)
+    if (getenv("KASA_PLACE_VERBOSE"))
+        fprintf(stderr, "kasa: buffer of %.1f GB for random 32-byte stores: %u candidate(s) %.1f %.1f %.1f %.1f -> kept %.1f G records/s\n", bytes / 1e9, pl.candidates,
+                pl.rates[0], pl.rates[1], pl.rates[2], pl.rates[3], pl.kept);
+    if (out) *out = pl;
+    return KASA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------------
@@ -544,6 +618,7 @@ struct kasa_ctx {
     DevBuf tileFirst, tileNext, tileBounds;    // u32[nK][nTiles]; index span of every tile
     DevBuf rTab;                               // floor(2^64 / n) for n < 8192 (profile_group_accum_kernel)
     DevBuf tileList;                           // tiles group2_kernel leaves to group_kernel (long lists, walks beyond the staged span)
+    Placement recPlacement;                           // how the record buffer was chosen (reserve_placed)
     uint32_t lastSlowTiles = 0, lastSlowTiles2 = 0;   // tiles group2_kernel listed; of those, tiles its second chance (larger park buffer) listed again
     DevBuf tileChunks;                         // tile_suffix: minima of chunks of 1024 tiles
     int lookupMode = 0;                        // 0 = streaming tiles, 1 = per-query search only
@@ -5845,7 +5920,8 @@ static int group_stage(kasa_ctx *c, int coverage, bool exportSorted, uint32_t *r
         }
         if (!c->noWideCells) c->recCW = 16u;
     }
-    if (!c->recOut && (rc = c->rec.reserve(nQ * (size_t)c->recCW * 4 + 64))) return rc;
+    if (!c->recOut && (rc = (RW == 8 && c->recCW == 8u) ? reserve_placed(c->rec, nQ * (size_t)32 + 64, c->stream, &c->recPlacement)   // (32-byte slots: partial cells)
+                                                          : c->rec.reserve(nQ * (size_t)c->recCW * 4 + 64))) return rc;
     unsigned long long *cursor = c->misc.as<unsigned long long>() + 16;   // 64-bit cursors: [16] pool, [17] staging, [18] profile keys
     hipEvent_t a, b;
     if (c->poolCap == 0) c->poolCap = std::max<uint64_t>(1u << 16, nQ);   // (a word per query: a first batch with crowded taxon lists -- 0.75 words per query on the bench data -- need not run group_kernel twice)
@@ -8063,7 +8139,8 @@ extern "C" int kasa_ctx_reserve(kasa_ctx *c, uint64_t nQueries, uint64_t nBases,
     int rc;
     if ((rc = c->bases.reserve((size_t)nBases + 64)) || (rc = c->qKmerA.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadA.reserve(nQ * 4 + 64)) ||
         (rc = c->qKmerB.reserve(nQ * c->keyBytes() + 64)) || (rc = c->qReadB.reserve(nQ * 4 + 64)) || (rc = c->depth.reserve(nQ + 64)) || (rc = c->rep.reserve(nQ * 4 + 64)) ||
-        (rc = c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))   // (64-byte cells for narrow records, where asked for: group_stage)
+        (rc = c->recWords() == 8u ? reserve_placed(c->rec, nQ * (size_t)32 + 64, c->stream, &c->recPlacement)
+                                  : c->rec.reserve(nQ * (size_t)c->recWords() * 4 + 64)))   // (64-byte cells for narrow records, where asked for: group_stage)
         return rc;
     (void)wantPerRead;
     return KASA_OK;
@@ -8089,6 +8166,15 @@ extern "C" int kasa_ctx_replay_stats(kasa_ctx *c, uint32_t *reads, uint64_t *eve
     if (!c) return fail(KASA_E_ARG, "ctx is NULL");
     if (reads) *reads = c->lastReplayReads;
     if (events) *events = c->lastReplayEvents;
+    return KASA_OK;
+}
+
+extern "C" int kasa_ctx_record_placement(kasa_ctx *c, uint32_t *candidates, float *keptRate, float *rates4)
+{
+    if (!c || !candidates || !keptRate) return fail(KASA_E_ARG, "kasa_ctx_record_placement: NULL argument");
+    *candidates = c->recPlacement.candidates;
+    *keptRate = c->recPlacement.kept;
+    if (rates4) for (int i = 0; i < 4; ++i) rates4[i] = c->recPlacement.rates[i];
     return KASA_OK;
 }
 

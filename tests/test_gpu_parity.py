@@ -1047,6 +1047,45 @@ def test_general_kernel_on_huge_taxon_sets(flags):
     ctx.close(); dix.close()
 
 
+def test_record_buffer_is_chosen_among_candidates(monkeypatch):
+    """The buffer of 32-byte event records is taken from candidates that are timed with scattered stores when it is allocated
+    (reserve_placed: the rate of such stores is a property of the physical memory behind a buffer, tools/place_probe.hip).
+    Buffers of 8 GB and more by default; KASA_PLACE_MIN_MB=0 sends this small batch through it: same batch bit for bit, the
+    context says how it chose; KASA_PLACE_TRIES=1 and 64-byte records allocate plainly."""
+    _gpu_or_fail()
+    ix, batch = synthetic_world(5, 12, 9000, 4000)
+    dix = capi.DeviceIndex(ix)
+    ctx = capi.Context(dix, 12, 7, 3)
+    ctx.run_batch(batch.bases, batch.offsets, True)
+    ref = (ctx.scores(), ctx.profile_limbs().copy())
+    assert ctx.record_placement()["candidates"] == 0                  # (a small buffer: plain)
+    ctx.close()
+    monkeypatch.setenv("KASA_PLACE_MIN_MB", "0")
+    monkeypatch.setenv("KASA_PLACE_VERBOSE", "1")
+    for tries, k_high in (("3", 12), ("4", 12), ("1", 12), ("3", 10)):
+        monkeypatch.setenv("KASA_PLACE_TRIES", tries)
+        ctx = capi.Context(dix, k_high, 7, 3)
+        ctx.run_batch(batch.bases, batch.offsets, True)
+        pl = ctx.record_placement()
+        if tries == "1":
+            assert pl["candidates"] == 0
+        else:
+            assert 1 <= pl["candidates"] <= int(tries) and pl["kept_g_records_per_s"] == max(pl["candidates_g_records_per_s"]) > 0, pl
+        if k_high == 12:
+            got = (ctx.scores(), ctx.profile_limbs().copy())
+            assert all(np.array_equal(x, y) for x, y in zip(got[0], ref[0])) and np.array_equal(got[1], ref[1])
+        ctx.run_batch(batch.bases, batch.offsets, True)               # (the buffer is there: nothing is chosen again)
+        assert ctx.record_placement() == pl
+        ctx.close()
+    dix.close()
+    ix16, batch16 = synthetic_world(5, 12, 9000, 2000, K=25)                 # 64-byte records are written as whole cells: plain
+    dix = capi.DeviceIndex(ix16)
+    ctx = capi.Context(dix, 25, 7, 3)
+    ctx.run_batch(batch16.bases, batch16.offsets, True)
+    assert ctx.record_placement()["candidates"] == 0
+    ctx.close(); dix.close()
+
+
 def test_tiles_with_heavy_groups_get_a_second_chance(monkeypatch):
     """A clade of 16 near-identical taxa among 30 unrelated ones: a query of the clade meets sixteen segments, and the tiles that
     hold many such leaders park more than group2_kernel's 1024 slots take but fewer than the 4096 of its second launch -- those
